@@ -1,0 +1,130 @@
+"""CPU: the oracle (oracle/advmil_oracle.py) against the golden vectors captured from the real
+reference by tests/golden/gen_golden.py. Tolerances are fp32 round-off (the two sides run the
+same arithmetic through different op orders)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import advmil_oracle as O
+from tests import helpers as H
+from advmil_amd import synth
+
+TOL = 2e-6
+
+
+def close(a, b, tol=TOL):
+    a = torch.as_tensor(np.asarray(a)).double().reshape(-1)
+    b = torch.as_tensor(np.asarray(b)).double().reshape(-1)
+    assert a.shape == b.shape
+    assert float((a - b).abs().max()) <= tol, float((a - b).abs().max())
+
+
+def test_pin_report_is_tight():
+    meta = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ORACLE_PIN.json")))
+    assert meta["worst"] < 2e-5
+    assert len(meta["oracle_vs_reference_maxabs"]) >= 20
+
+
+@pytest.mark.parametrize("kind", ["abmil", "patch", "cluster"])
+@pytest.mark.parametrize("N", [512, 1024, 8192])
+def test_G1_eval_forward(golden, kind, N):
+    P = H.synth_params(H.shapes_generator(kind), f"G-{kind}:")
+    x = H.bag(0, N)
+    ext = H.T(synth.cluster_ids(0, 0, N)) if kind == "cluster" else None
+    with torch.no_grad():
+        y, A, Hh = O.generator(P, x, ext, kind, (0, 1), None, None, "sigmoid", return_attn=True)
+    key = f"G1_{kind}_{N}"
+    close(y, golden[key + "_y"])
+    close(Hh, golden[key + "_H"], 5e-6)
+    A = A.reshape(-1)
+    if N <= 1024:
+        close(A, golden[key + "_A"], 1e-7)
+    else:
+        close(A[::32], golden[key + "_A_strided"], 1e-7)
+    st = golden[key + "_Astat"]
+    assert abs(float(A.double().sum()) - st[0]) < 1e-5
+    assert int(A.argmax()) == int(st[2])
+
+
+@pytest.mark.parametrize("kind", ["abmil", "patch"])
+def test_G2_eval_sampling(golden, kind):
+    PG = H.synth_params(H.shapes_generator(kind), f"G-{kind}:")
+    PD = H.synth_params(H.shapes_disc(), "D-prj:")
+    cfg = O.StepConfig(kind=kind)
+    for i in range(2):
+        ns = [H.noise_tensor(f"G2:{kind}:{i}", k, 192) for k in range(31)]
+        yh, ff, dist, avg = O.test_model_bag(cfg, PG, PD, H.bag(i, 512), None, [ns[0]], [[n] for n in ns[1:]])
+        close(yh, golden[f"G2_{kind}_y_hat"][i])
+        close(ff, golden[f"G2_{kind}_f_fake"][i])
+        close(dist, golden[f"G2_{kind}_dist_y_hat"][i])
+        close(avg, golden[f"G2_{kind}_avg_y_hat"][i])
+
+
+@pytest.mark.parametrize("disc_type,iprd,prj", [("prj", "instance", "x"), ("prj", "bag", "x"), ("prj", "instance", "y"),
+                                                ("prj", "bag", None), ("cat", "bag", None)])
+def test_G3_discriminators(golden, disc_type, iprd, prj):
+    P = H.synth_params(H.shapes_disc(disc_type, prj), "D-prj:" if disc_type == "prj" else "D-cat:")
+    x, t = H.bag(3, 512), torch.tensor([[0.37]])
+    with torch.no_grad():
+        f = O.prj_discriminator(P, x, t, iprd, prj) if disc_type == "prj" else O.discriminator_cat(P, x, t)
+        hx, fi, _ = O.embed_x_layer(O._sub(P, "net_pair_one."), x)
+    name = f"D-{disc_type}-{iprd}-{prj}"
+    close(f, golden[f"G3_{name}_f"])
+    close(hx, golden[f"G3_{name}_hid_x"])
+    close(fi.mean(dim=1), golden[f"G3_{name}_fc_ins_mean"])
+
+
+@pytest.mark.parametrize("kind", ["abmil", "patch"])
+def test_G4_two_optimizer_steps(golden, kind):
+    PG = H.synth_params(H.shapes_generator(kind), f"G-{kind}:")
+    PD = H.synth_params(H.shapes_disc(), "D-prj:")
+    cfg = O.StepConfig(kind=kind)
+    bags = [(H.bag(i, 512), None, H.label(i)) for i in range(32)]
+    nd = [[H.noise_tensor(f"G4d:{kind}", i, 192)] for i in range(32)]
+    ng = [[H.noise_tensor(f"G4g:{kind}", i, 192)] for i in range(32)]
+    stG, stD = {}, {}
+    PG0, PD0 = PG, PD
+    ys, fs = [], []
+    for s in range(2):
+        sl = slice(16 * s, 16 * s + 16)
+        PG, PD, lg, yh, ff, gG, gD = O.train_step(cfg, PG, PD, stG, stD, bags[sl], nd[sl], ng[sl])
+        ref = golden[f"G4_{kind}_logs"][s]
+        got = [lg[k] for k in ("Loss_D", "D_real", "D_fake", "Loss_G_fake", "Loss_G_time", "Loss_G_total", "D_fake_avg")]
+        close(got, ref)
+        ys.append(yh); fs.append(ff)
+    close(torch.cat(ys), golden[f"G4_{kind}_y_hat"])
+    close(torch.cat(fs), golden[f"G4_{kind}_f_fake"])
+    for tag, P, P0 in (("G", PG, PG0), ("D", PD, PD0)):
+        keys = [str(k) for k in golden[f"G4_{kind}_keys{tag}"]]
+        d = np.array([[float((P[k].double() - P0[k].double()).sum()), float((P[k].double() - P0[k].double()).norm())] for k in keys])
+        ref = golden[f"G4_{kind}_d{tag}_stats"]
+        # Adam's first steps move every weight by ~lr; compare delta norms relatively
+        assert np.all(np.abs(d[:, 1] - ref[:, 1]) <= 2e-3 * ref[:, 1] + 2e-5), np.abs(d[:, 1] - ref[:, 1]).max()
+    gk = [str(k) for k in golden[f"G4_{kind}_gradG2_keys"]]
+    gn = np.array([float(gG[k].double().norm()) for k in gk])
+    assert np.allclose(gn, golden[f"G4_{kind}_gradG2_norm"], rtol=1e-4, atol=1e-9)
+
+
+def test_G5_losses(golden):
+    real = H.T(synth.normal(synth.stream_key(1, "G5real"), 7))
+    fake = H.T(synth.normal(synth.stream_key(1, "G5fake"), 16))
+    p = H.T(synth.uniform01(synth.stream_key(1, "G5p"), 16)); t = H.T(synth.uniform01(synth.stream_key(1, "G5t"), 16))
+    e = (torch.arange(16) % 2).float()
+    vals = []
+    for which in ("bce", "hinge", "wasserstein"):
+        for r in (real, None):
+            vals.append(float(O.real_fake_loss(r, fake, which)))
+    for norm in ("l1", "l2"):
+        for alpha, gamma in ((0.0, 0.0), (0.3, 1.0)):
+            vals.append(float(O.recon_loss(p, t, e, alpha, gamma, norm)))
+    vals.append(float(O.fake_generator_loss(fake)))
+    vals.append(float(O.loss_reg_l1(1e-5, [real, fake.reshape(4, 4)])))
+    close(vals, golden["G5_vals"], 1e-6)
+
+
+def test_first_step_loss_d_quirk(golden):
+    # bce D loss is -mean(1 - log s(fake)) - mean(log s(real)); first step ~ -1
+    assert -1.2 < golden["G4_abmil_logs"][0][0] < -0.8
