@@ -1,0 +1,86 @@
+"""ctypes binding of libadvmil_hip.so (C ABI declared in include/advmil_hip.h).
+
+The product path has no CPU or eager-PyTorch fallback: if the shared library is missing or a
+tensor is not on a HIP device, the ops raise. Build with `python -c "import __graft_entry__ as g;
+g.build()"` or `make -C advmil_amd/csrc`.
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libadvmil_hip.so")
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class AdvmilHipError(RuntimeError):
+    pass
+
+
+class Epilogue(ctypes.Structure):
+    """advmil_epilogue_t"""
+    _fields_ = [("bias", c_void_p), ("act0", c_int), ("act1", c_int), ("act_split", c_int), ("drop_p", c_float),
+                ("seed", c_void_p), ("stream_id", c_uint64), ("rowv", c_void_p), ("colv", c_void_p),
+                ("maskref", c_void_p), ("ldmask", c_int), ("mask_scale", c_float), ("accumulate", c_int),
+                ("alpha", c_float)]
+
+
+# name -> (restype, argtypes); must list every symbol include/advmil_hip.h declares
+SIGNATURES = {
+    "advmil_version": (c_int, []),
+    "advmil_gemm_f32_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
+    "advmil_gemm_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                                c_int64, ctypes.POINTER(Epilogue), c_int, c_void_p, c_size_t, c_void_p]),
+    "advmil_gate_score_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_uint64, c_uint64, c_int64, c_int64,
+                                      c_void_p, c_void_p]),
+    "advmil_softmax_pool_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "advmil_softmax_pool_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_size_t,
+                                        c_void_p]),
+    "advmil_softmax_pool_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
+                                        c_size_t, c_void_p]),
+    "advmil_gate_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "advmil_gate_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_uint64, c_uint64, c_int64, c_int64,
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "advmil_colsum_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "advmil_act_dropout_bwd": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_uint64, c_int64, c_int64, c_void_p,
+                                       c_void_p, c_void_p, c_size_t, c_void_p]),
+    "advmil_colsum": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "advmil_ln_relu_mean16_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int64, c_void_p, c_void_p,
+                                          c_void_p, c_void_p]),
+    "advmil_ln_relu_mean16_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "advmil_ln_relu_mean16_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "advmil_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
+                                 c_float, c_float, c_float, c_void_p, c_void_p]),
+    "advmil_abs_sum": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "advmil_abs_sum_workspace_bytes": (c_size_t, [c_int64]),
+    "advmil_uniform_fill": (c_int, [c_void_p, c_int64, c_void_p, c_uint64, c_void_p]),
+    "advmil_seed_advance": (c_int, [c_void_p, c_uint64, c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raises HipLibraryMissing if it was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: the AdvMIL HIP kernels are not built (run __graft_entry__.build()). "
+                "There is no CPU fallback in the product path.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError if the .so is stale
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        kind = {-1: "invalid argument (shape/alignment/null)", -2: "workspace too small"}.get(code, f"hipError_t {code}")
+        raise AdvmilHipError(f"{what} failed: {kind}")

@@ -1,0 +1,69 @@
+// Shared device helpers for the AdvMIL gfx950 kernels (wave64, CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ADVMIL_OK 0
+#define ADVMIL_EINVAL -1     // bad shape / alignment / null pointer
+#define ADVMIL_EWORKSPACE -2 // workspace too small
+
+#define ADVMIL_LAUNCH_CHECK()                      \
+  do {                                             \
+    hipError_t _e = hipGetLastError();             \
+    if (_e != hipSuccess) return (int)_e;          \
+  } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- counter RNG: splitmix64(key + idx); restated on the host in advmil_amd/synth.py ----
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  uint64_t z = x + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint64_t rng_key(uint64_t seed, uint64_t stream) {
+  return splitmix64(seed ^ splitmix64(stream));
+}
+// U[0,1) with 24 random bits
+__device__ __forceinline__ float rng_uniform(uint64_t key, uint64_t idx) {
+  return (float)(uint32_t)(splitmix64(key + idx) >> 40) * 5.9604644775390625e-8f;
+}
+// multiplicative dropout factor: 0 or 1/(1-p)
+__device__ __forceinline__ float rng_keep(uint64_t key, uint64_t idx, float p, float inv_keep) {
+  return rng_uniform(key, idx) >= p ? inv_keep : 0.0f;
+}
+
+// ---- activations ----
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3 };
+
+__device__ __forceinline__ float act_apply(int act, float v) {
+  switch (act) {
+    case ACT_RELU: return v > 0.0f ? v : 0.0f;
+    case ACT_TANH: return tanhf(v);
+    case ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+    default: return v;
+  }
+}
+// derivative expressed through the activation OUTPUT y
+__device__ __forceinline__ float act_grad_from_out(int act, float y) {
+  switch (act) {
+    case ACT_RELU: return y > 0.0f ? 1.0f : 0.0f;
+    case ACT_TANH: return 1.0f - y * y;
+    case ACT_SIGMOID: return y * (1.0f - y);
+    default: return 1.0f;
+  }
+}
+
+// ---- wave64 reductions ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

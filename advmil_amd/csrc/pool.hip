@@ -1,0 +1,568 @@
+// HBM-bound kernels of the AdvMIL path: gated-attention score, instance softmax + weighted pooling,
+// their backward, the Linear activation/dropout backward, the LayerNorm-ReLU-mean16 region embedding
+// tail, and column-sum utilities. All loads are 16 B/lane (float4) along the contiguous dimension or
+// one-wave-per-row with 256 B coalesced segments; reductions are deterministic two-stage (per-workgroup
+// partials in a caller workspace, then a merge launch) -- no float atomics.
+#include "common.h"
+#include "../../include/advmil_hip.h"
+
+#define ROWS_PER_BLOCK 32
+
+// 256 threads cover `rpp` rows x `cols4` float4 columns
+struct RowColMap {
+  int cols4, rpp, c4, r;
+  bool active;
+};
+__device__ __forceinline__ RowColMap make_map(int64_t D) {
+  RowColMap m;
+  m.cols4 = (int)(D >> 2);
+  m.rpp = 256 / m.cols4;
+  if (m.rpp < 1) m.rpp = 1;
+  m.c4 = threadIdx.x % m.cols4;
+  m.r = threadIdx.x / m.cols4;
+  m.active = m.r < m.rpp;
+  return m;
+}
+
+// sum a float4 held by each (r, c4) thread over r; result valid in threads with r == 0
+__device__ __forceinline__ float4 reduce_rows(float4 v, const RowColMap& m, float* red /* >= 1024 floats */) {
+  __syncthreads();
+  if (m.active) *reinterpret_cast<float4*>(red + (m.r * m.cols4 + m.c4) * 4) = v;
+  __syncthreads();
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (m.active && m.r == 0) {
+    for (int r = 0; r < m.rpp; ++r) {
+      const float4 p = *reinterpret_cast<const float4*>(red + (r * m.cols4 + m.c4) * 4);
+      s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    }
+  }
+  return s;
+}
+
+// out[c] (+)= sum_b partial[b][c]
+__global__ __launch_bounds__(256) void colsum_merge_kernel(const float* __restrict__ partial, int nblk, int64_t stride,
+                                                           int64_t ncols, float* __restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * stride + c];
+  out[c] = s;
+}
+
+// =====================================================================================
+// gate score: s[n] = sum_j (a ka)(b kb) wc[j] + bc          one wave per row
+// =====================================================================================
+__global__ __launch_bounds__(256) void gate_score_kernel(const float* __restrict__ ab, const float* __restrict__ wc,
+                                                         const float* __restrict__ bc, float p, const uint64_t* seed,
+                                                         uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D,
+                                                         float* __restrict__ s) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const bool drop = seed && p > 0.f;
+  uint64_t ka = 0, kb = 0;
+  float inv = 1.f;
+  if (drop) {
+    const uint64_t sd = *seed;
+    ka = rng_key(sd, stream_a); kb = rng_key(sd, stream_b); inv = 1.f / (1.f - p);
+  }
+  const float* row = ab + n * 2 * D;
+  float acc = 0.f;
+  for (int64_t j = lane; j < D; j += 64) {
+    float a = row[j], b = row[D + j];
+    if (drop) {
+      a *= rng_keep(ka, (uint64_t)(n * D + j), p, inv);
+      b *= rng_keep(kb, (uint64_t)(n * D + j), p, inv);
+    }
+    acc += a * b * wc[j];
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) s[n] = acc + bc[0];
+}
+
+extern "C" int advmil_gate_score_fwd(const float* ab, const float* wc, const float* bc, float drop_p, const uint64_t* seed,
+                                     uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D, float* s,
+                                     advmil_stream_t stream) {
+  if (!ab || !wc || !bc || !s || N <= 0 || D <= 0) return ADVMIL_EINVAL;
+  hipLaunchKernelGGL(gate_score_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ab, wc, bc,
+                     drop_p, seed, stream_a, stream_b, N, D, s);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}
+
+// =====================================================================================
+// softmax over instances + weighted pooling
+// =====================================================================================
+// stats[0] = max_n s, stats[1] = 1 / sum_n exp(s - max)
+__global__ __launch_bounds__(1024) void softmax_stats_kernel(const float* __restrict__ s, int64_t N, float* __restrict__ stats) {
+  __shared__ float red[16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  float mx = -INFINITY;
+  for (int64_t n = tid; n < N; n += 1024) mx = fmaxf(mx, s[n]);
+  mx = wave_max(mx);
+  if (lane == 0) red[w] = mx;
+  __syncthreads();
+  mx = red[0];
+  for (int k = 1; k < 16; ++k) mx = fmaxf(mx, red[k]);
+  __syncthreads();
+  float sum = 0.f;
+  for (int64_t n = tid; n < N; n += 1024) sum += expf(s[n] - mx);
+  sum = wave_sum(sum);
+  if (lane == 0) red[w] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int k = 0; k < 16; ++k) t += red[k];
+    stats[0] = mx;
+    stats[1] = 1.f / t;
+  }
+}
+
+__global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restrict__ s, const float* __restrict__ h,
+                                                           int64_t ldh, int64_t N, int64_t D,
+                                                           const float* __restrict__ stats, float* __restrict__ A,
+                                                           float* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) float red[1024];
+  const RowColMap m = make_map(D);
+  const float mx = stats[0], inv = stats[1];
+  const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (m.active) {
+    for (int r = m.r; r < ROWS_PER_BLOCK; r += m.rpp) {
+      const int64_t n = r0 + r;
+      if (n >= N) break;
+      const float w = expf(s[n] - mx) * inv;
+      if (m.c4 == 0) A[n] = w;
+      const float4 v = *reinterpret_cast<const float4*>(h + n * ldh + m.c4 * 4);
+      acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+    }
+  }
+  const float4 t = reduce_rows(acc, m, red);
+  if (m.active && m.r == 0) *reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * D + m.c4 * 4) = t;
+}
+
+extern "C" size_t advmil_softmax_pool_workspace_bytes(int64_t N, int64_t D) {
+  const int64_t nblk = (N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  const int64_t nwg4 = (N + 3) / 4;
+  const int64_t a = 4 + nblk * D;   // fwd: stats + partials
+  const int64_t b = 4 + nwg4;       // bwd: per-workgroup partial of sum A t
+  return (size_t)(a > b ? a : b) * sizeof(float);
+}
+
+extern "C" int advmil_softmax_pool_fwd(const float* s, const float* h, int64_t ldh, int64_t N, int64_t D, float* A,
+                                       float* pooled, void* ws, size_t ws_bytes, advmil_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!s || !h || !A || !pooled || !ws || N <= 0 || D <= 0 || (D & 3) || D > 1024 || (ldh & 3)) return ADVMIL_EINVAL;
+  if (ws_bytes < advmil_softmax_pool_workspace_bytes(N, D)) return ADVMIL_EWORKSPACE;
+  float* stats = (float*)ws;
+  float* partial = stats + 4;
+  const int nblk = (int)((N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+  hipLaunchKernelGGL(softmax_stats_kernel, dim3(1), dim3(1024), 0, stream, s, N, stats);
+  ADVMIL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(pool_partial_kernel, dim3(nblk), dim3(256), 0, stream, s, h, ldh, N, D, stats, A, partial);
+  ADVMIL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_merge_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, stream, partial, nblk, D, D, pooled);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}
+
+// backward stage 1: t[n] = dA[n] + dot(dpooled, h[n]); partial[wg] = sum over the wg's 4 rows of A[n] t[n]
+__global__ __launch_bounds__(256) void pool_bwd_dot_kernel(const float* __restrict__ dp, const float* __restrict__ dA,
+                                                           const float* __restrict__ A, const float* __restrict__ h,
+                                                           int64_t ldh, int64_t N, int64_t D, float* __restrict__ t,
+                                                           float* __restrict__ partial) {
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.x * 4 + w;
+  float contrib = 0.f;
+  if (n < N) {
+    const float* row = h + n * ldh;
+    float acc = 0.f;
+    for (int64_t j = lane; j < D; j += 64) acc += dp[j] * row[j];
+    acc = wave_sum(acc);
+    if (dA) acc += dA[n];
+    if (lane == 0) t[n] = acc;
+    contrib = A[n] * acc;
+  }
+  if (lane == 0) red[w] = contrib;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// backward stage 2: c = sum partial; ds[n] = A[n] (t[n] - c)   (t aliases ds)
+__global__ __launch_bounds__(256) void pool_bwd_ds_kernel(const float* __restrict__ A, const float* __restrict__ partial,
+                                                          int npart, int64_t N, float* __restrict__ ds) {
+  __shared__ float red[4];
+  float c = 0.f;
+  for (int k = threadIdx.x; k < npart; k += 256) c += partial[k];
+  c = wave_sum(c);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  c = red[0] + red[1] + red[2] + red[3];
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n < N) ds[n] = A[n] * (ds[n] - c);
+}
+
+extern "C" int advmil_softmax_pool_bwd(const float* dpooled, const float* dA, const float* A, const float* h, int64_t ldh,
+                                       int64_t N, int64_t D, float* ds, void* ws, size_t ws_bytes,
+                                       advmil_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!dpooled || !A || !h || !ds || !ws || N <= 0 || D <= 0) return ADVMIL_EINVAL;
+  if (ws_bytes < advmil_softmax_pool_workspace_bytes(N, D)) return ADVMIL_EWORKSPACE;
+  float* partial = (float*)ws + 4;
+  const int nwg = (int)((N + 3) / 4);
+  hipLaunchKernelGGL(pool_bwd_dot_kernel, dim3(nwg), dim3(256), 0, stream, dpooled, dA, A, h, ldh, N, D, ds, partial);
+  ADVMIL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(pool_bwd_ds_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, A, partial, nwg, N, ds);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}
+
+// =====================================================================================
+// gate backward: ds[N] -> dG[N,2D] (grads wrt the two pre-activations), dwc, dbc, dbias
+// =====================================================================================
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ ab, const float* __restrict__ ds,
+                                                       const float* __restrict__ wc, float p, const uint64_t* seed,
+                                                       uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D,
+                                                       float* __restrict__ dG, float* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) float red[1024];
+  const RowColMap m = make_map(D);
+  const bool drop = seed && p > 0.f;
+  uint64_t ka = 0, kb = 0;
+  float inv = 1.f;
+  if (drop) {
+    const uint64_t sd = *seed;
+    ka = rng_key(sd, stream_a); kb = rng_key(sd, stream_b); inv = 1.f / (1.f - p);
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+  float4 s_wc = make_float4(0.f, 0.f, 0.f, 0.f), s_a = s_wc, s_b = s_wc;
+  float s_ds = 0.f;
+  if (m.active) {
+    const float4 w4 = *reinterpret_cast<const float4*>(wc + m.c4 * 4);
+    const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+    for (int r = m.r; r < ROWS_PER_BLOCK; r += m.rpp) {
+      const int64_t n = r0 + r;
+      if (n >= N) break;
+      const float d = ds[n];
+      if (m.c4 == 0) s_ds += d;
+      const float4 a4 = *reinterpret_cast<const float4*>(ab + n * 2 * D + m.c4 * 4);
+      const float4 b4 = *reinterpret_cast<const float4*>(ab + n * 2 * D + D + m.c4 * 4);
+      const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+      float ga[4], gb[4], gw[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float fa = 1.f, fb = 1.f;
+        if (drop) {
+          const uint64_t idx = (uint64_t)(n * D + m.c4 * 4 + q);
+          fa = rng_keep(ka, idx, p, inv);
+          fb = rng_keep(kb, idx, p, inv);
+        }
+        const float ad = av[q] * fa, bd = bv[q] * fb;      // post-dropout branch values
+        gw[q] = d * ad * bd;                               // d wc[j]
+        ga[q] = d * wv[q] * bd * fa * (1.f - av[q] * av[q]);   // d pre_a  (tanh')
+        gb[q] = d * wv[q] * ad * fb * bv[q] * (1.f - bv[q]);   // d pre_b  (sigmoid')
+      }
+      *reinterpret_cast<float4*>(dG + n * 2 * D + m.c4 * 4) = make_float4(ga[0], ga[1], ga[2], ga[3]);
+      *reinterpret_cast<float4*>(dG + n * 2 * D + D + m.c4 * 4) = make_float4(gb[0], gb[1], gb[2], gb[3]);
+      s_wc.x += gw[0]; s_wc.y += gw[1]; s_wc.z += gw[2]; s_wc.w += gw[3];
+      s_a.x += ga[0]; s_a.y += ga[1]; s_a.z += ga[2]; s_a.w += ga[3];
+      s_b.x += gb[0]; s_b.y += gb[1]; s_b.z += gb[2]; s_b.w += gb[3];
+    }
+  }
+  float* prow = partial + (int64_t)blockIdx.x * (3 * D + 4);
+  float4 t = reduce_rows(s_wc, m, red);
+  if (m.active && m.r == 0) *reinterpret_cast<float4*>(prow + m.c4 * 4) = t;
+  t = reduce_rows(s_a, m, red);
+  if (m.active && m.r == 0) *reinterpret_cast<float4*>(prow + D + m.c4 * 4) = t;
+  t = reduce_rows(s_b, m, red);
+  if (m.active && m.r == 0) *reinterpret_cast<float4*>(prow + 2 * D + m.c4 * 4) = t;
+  // sum of ds over the block's rows (threads with c4 == 0 hold pieces)
+  __syncthreads();
+  if (m.active && m.c4 == 0) red[m.r] = s_ds;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float q = 0.f;
+    for (int r = 0; r < m.rpp; ++r) q += red[r];
+    prow[3 * D] = q;
+  }
+}
+
+extern "C" size_t advmil_gate_bwd_workspace_bytes(int64_t N, int64_t D) {
+  const int64_t nblk = (N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  return (size_t)(nblk * (3 * D + 4)) * sizeof(float);
+}
+
+extern "C" int advmil_gate_bwd(const float* ab, const float* ds, const float* wc, float drop_p, const uint64_t* seed,
+                               uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D, float* dG, float* dwc,
+                               float* dbc, float* dbias, void* ws, size_t ws_bytes, advmil_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!ab || !ds || !wc || !dG || !dwc || !dbc || !dbias || !ws || N <= 0 || D <= 0 || (D & 3) || D > 1024)
+    return ADVMIL_EINVAL;
+  if (ws_bytes < advmil_gate_bwd_workspace_bytes(N, D)) return ADVMIL_EWORKSPACE;
+  const int nblk = (int)((N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+  float* partial = (float*)ws;
+  const int64_t stride = 3 * D + 4;
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(nblk), dim3(256), 0, stream, ab, ds, wc, drop_p, seed, stream_a, stream_b, N, D,
+                     dG, partial);
+  ADVMIL_LAUNCH_CHECK();
+  const unsigned g = (unsigned)((D + 255) / 256);
+  hipLaunchKernelGGL(colsum_merge_kernel, dim3(g), dim3(256), 0, stream, partial, nblk, stride, D, dwc);
+  hipLaunchKernelGGL(colsum_merge_kernel, dim3(2 * g), dim3(256), 0, stream, partial + D, nblk, stride, 2 * D, dbias);
+  hipLaunchKernelGGL(colsum_merge_kernel, dim3(1), dim3(256), 0, stream, partial + 3 * D, nblk, stride, (int64_t)1, dbc);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}
+
+// =====================================================================================
+// backward of y = dropout(act(pre)):  dpre = dy * keep * act'(y_pre_dropout);  dbias = colsum(dpre)
+// =====================================================================================
+__global__ __launch_bounds__(256) void act_dropout_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                              int act, float p, const uint64_t* seed, uint64_t stream_id,
+                                                              int64_t M, int64_t N, int64_t c0, int64_t W,
+                                                              float* __restrict__ dpre, float* __restrict__ partial,
+                                                              int64_t pstride) {
+  __shared__ __attribute__((aligned(16))) float red[1024];
+  const RowColMap m = make_map(W);
+  const bool drop = seed && p > 0.f;
+  uint64_t key = 0;
+  float inv = 1.f;
+  if (drop) { key = rng_key(*seed, stream_id); inv = 1.f / (1.f - p); }
+  const float keep_scale = 1.f - p;
+  const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (m.active) {
+    for (int r = m.r; r < ROWS_PER_BLOCK; r += m.rpp) {
+      const int64_t row = r0 + r;
+      if (row >= M) break;
+      const int64_t off = row * N + c0 + m.c4 * 4;
+      const float4 g4 = *reinterpret_cast<const float4*>(dy + off);
+      const float4 y4 = *reinterpret_cast<const float4*>(y + off);
+      const float gv[4] = {g4.x, g4.y, g4.z, g4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w};
+      float o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float f = 1.f, yy = yv[q];
+        if (drop) {
+          f = rng_keep(key, (uint64_t)(off + q), p, inv);
+          yy *= keep_scale;   // undo the 1/(1-p) on kept elements (dropped ones get f = 0 anyway)
+        }
+        o[q] = gv[q] * f * act_grad_from_out(act, yy);
+      }
+      *reinterpret_cast<float4*>(dpre + off) = make_float4(o[0], o[1], o[2], o[3]);
+      sum.x += o[0]; sum.y += o[1]; sum.z += o[2]; sum.w += o[3];
+    }
+  }
+  if (partial) {
+    const float4 t = reduce_rows(sum, m, red);
+    if (m.active && m.r == 0) *reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * pstride + c0 + m.c4 * 4) = t;
+  }
+}
+
+extern "C" size_t advmil_colsum_workspace_bytes(int64_t M, int64_t N) {
+  const int64_t nblk = (M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  return (size_t)(nblk * N) * sizeof(float);
+}
+
+extern "C" int advmil_act_dropout_bwd(const float* dy, const float* y, int act, float drop_p, const uint64_t* seed,
+                                      uint64_t stream_id, int64_t M, int64_t N, float* dpre, float* dbias, void* ws,
+                                      size_t ws_bytes, advmil_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!dy || !y || !dpre || M <= 0 || N <= 0 || (N & 3)) return ADVMIL_EINVAL;
+  if (dbias && (!ws || ws_bytes < advmil_colsum_workspace_bytes(M, N))) return ADVMIL_EWORKSPACE;
+  const int nblk = (int)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+  float* partial = dbias ? (float*)ws : nullptr;
+  for (int64_t c0 = 0; c0 < N; c0 += 1024) {
+    const int64_t W = (N - c0 < 1024) ? (N - c0) : 1024;
+    hipLaunchKernelGGL(act_dropout_bwd_kernel, dim3(nblk), dim3(256), 0, stream, dy, y, act, drop_p, seed, stream_id, M, N,
+                       c0, W, dpre, partial, N);
+  }
+  ADVMIL_LAUNCH_CHECK();
+  if (dbias) {
+    hipLaunchKernelGGL(colsum_merge_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, partial, nblk, N, N, dbias);
+    ADVMIL_LAUNCH_CHECK();
+  }
+  return ADVMIL_OK;
+}
+
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int64_t M, int64_t N, int64_t c0,
+                                                             int64_t W, float* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) float red[1024];
+  const RowColMap m = make_map(W);
+  const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (m.active) {
+    for (int r = m.r; r < ROWS_PER_BLOCK; r += m.rpp) {
+      const int64_t row = r0 + r;
+      if (row >= M) break;
+      const float4 v = *reinterpret_cast<const float4*>(x + row * N + c0 + m.c4 * 4);
+      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+  }
+  const float4 t = reduce_rows(sum, m, red);
+  if (m.active && m.r == 0) *reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * N + c0 + m.c4 * 4) = t;
+}
+
+extern "C" int advmil_colsum(const float* x, int64_t M, int64_t N, float* out, void* ws, size_t ws_bytes,
+                             advmil_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !out || !ws || M <= 0 || N <= 0 || (N & 3)) return ADVMIL_EINVAL;
+  if (ws_bytes < advmil_colsum_workspace_bytes(M, N)) return ADVMIL_EWORKSPACE;
+  const int nblk = (int)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+  for (int64_t c0 = 0; c0 < N; c0 += 1024) {
+    const int64_t W = (N - c0 < 1024) ? (N - c0) : 1024;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, x, M, N, c0, W, (float*)ws);
+  }
+  hipLaunchKernelGGL(colsum_merge_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, (const float*)ws, nblk, N, N, out);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}
+
+// =====================================================================================
+// LayerNorm(d) -> ReLU -> mean over 16 consecutive rows.   One workgroup (4 waves) per region;
+// wave w owns rows 4w..4w+3, lane owns columns lane, lane+64, ... (d <= 512).
+// =====================================================================================
+#define LN_MAXQ 8
+
+__global__ __launch_bounds__(256) void ln_relu_mean16_fwd_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float eps, int64_t N,
+                                                                 int64_t d, float* __restrict__ emb,
+                                                                 float* __restrict__ mean, float* __restrict__ rstd) {
+  __shared__ float red[4 * 512];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t g = blockIdx.x;
+  const int Q = (int)((d + 63) / 64);
+  float gm[LN_MAXQ], bt[LN_MAXQ], acc[LN_MAXQ];
+#pragma unroll
+  for (int q = 0; q < LN_MAXQ; ++q) {
+    const int64_t j = lane + 64 * q;
+    const bool ok = q < Q && j < d;
+    gm[q] = ok ? gamma[j] : 0.f; bt[q] = ok ? beta[j] : 0.f; acc[q] = 0.f;
+  }
+  const float invd = 1.f / (float)d;
+  for (int rr = 0; rr < 4; ++rr) {
+    const int64_t n = g * 16 + w * 4 + rr;
+    const float* row = y + n * d;
+    float v[LN_MAXQ];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < LN_MAXQ; ++q) {
+      const int64_t j = lane + 64 * q;
+      v[q] = (q < Q && j < d) ? row[j] : 0.f;
+      s += v[q];
+    }
+    const float mu = wave_sum(s) * invd;
+    float s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < LN_MAXQ; ++q) {
+      const int64_t j = lane + 64 * q;
+      const float c = (q < Q && j < d) ? v[q] - mu : 0.f;
+      s2 += c * c;
+    }
+    const float rs = rsqrtf(wave_sum(s2) * invd + eps);
+    if (lane == 0) { mean[n] = mu; rstd[n] = rs; }
+#pragma unroll
+    for (int q = 0; q < LN_MAXQ; ++q) {
+      const float z = (v[q] - mu) * rs * gm[q] + bt[q];
+      acc[q] += z > 0.f ? z : 0.f;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < LN_MAXQ; ++q) {
+    const int64_t j = lane + 64 * q;
+    if (q < Q && j < d) red[w * 512 + j] = acc[q];
+  }
+  __syncthreads();
+  for (int64_t j = threadIdx.x; j < d; j += 256)
+    emb[g * d + j] = (red[j] + red[512 + j] + red[1024 + j] + red[1536 + j]) * (1.f / 16.f);
+}
+
+extern "C" int advmil_ln_relu_mean16_fwd(const float* y, const float* gamma, const float* beta, float eps, int64_t N,
+                                         int64_t d, float* emb, float* mean, float* rstd, advmil_stream_t stream) {
+  if (!y || !gamma || !beta || !emb || !mean || !rstd || N <= 0 || (N & 15) || d <= 0 || d > 512) return ADVMIL_EINVAL;
+  hipLaunchKernelGGL(ln_relu_mean16_fwd_kernel, dim3((unsigned)(N / 16)), dim3(256), 0, (hipStream_t)stream, y, gamma, beta,
+                     eps, N, d, emb, mean, rstd);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}
+
+__global__ __launch_bounds__(256) void ln_relu_mean16_bwd_kernel(const float* __restrict__ demb, const float* __restrict__ y,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                 int64_t N, int64_t d, float* __restrict__ dy,
+                                                                 float* __restrict__ partial) {
+  __shared__ float red[4 * 1024];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t g = blockIdx.x;
+  const int Q = (int)((d + 63) / 64);
+  float gm[LN_MAXQ], bt[LN_MAXQ], de[LN_MAXQ], ag[LN_MAXQ], abt[LN_MAXQ];
+#pragma unroll
+  for (int q = 0; q < LN_MAXQ; ++q) {
+    const int64_t j = lane + 64 * q;
+    const bool ok = q < Q && j < d;
+    gm[q] = ok ? gamma[j] : 0.f; bt[q] = ok ? beta[j] : 0.f;
+    de[q] = ok ? demb[g * d + j] * (1.f / 16.f) : 0.f;
+    ag[q] = 0.f; abt[q] = 0.f;
+  }
+  const float invd = 1.f / (float)d;
+  for (int rr = 0; rr < 4; ++rr) {
+    const int64_t n = g * 16 + w * 4 + rr;
+    const float* row = y + n * d;
+    const float mu = mean[n], rs = rstd[n];
+    float xh[LN_MAXQ], dxh[LN_MAXQ];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < LN_MAXQ; ++q) {
+      const int64_t j = lane + 64 * q;
+      const bool ok = q < Q && j < d;
+      xh[q] = ok ? (row[j] - mu) * rs : 0.f;
+      const float z = xh[q] * gm[q] + bt[q];
+      const float dz = (ok && z > 0.f) ? de[q] : 0.f;
+      dxh[q] = dz * gm[q];
+      ag[q] += dz * xh[q];
+      abt[q] += dz;
+      c1 += dxh[q];
+      c2 += dxh[q] * xh[q];
+    }
+    c1 = wave_sum(c1) * invd;
+    c2 = wave_sum(c2) * invd;
+#pragma unroll
+    for (int q = 0; q < LN_MAXQ; ++q) {
+      const int64_t j = lane + 64 * q;
+      if (q < Q && j < d) dy[n * d + j] = rs * (dxh[q] - c1 - xh[q] * c2);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < LN_MAXQ; ++q) {
+    const int64_t j = lane + 64 * q;
+    if (q < Q && j < d) { red[w * 1024 + j] = ag[q]; red[w * 1024 + 512 + j] = abt[q]; }
+  }
+  __syncthreads();
+  for (int64_t j = threadIdx.x; j < d; j += 256) {
+    partial[g * 2 * d + j] = red[j] + red[1024 + j] + red[2048 + j] + red[3072 + j];
+    partial[g * 2 * d + d + j] = red[512 + j] + red[1536 + j] + red[2560 + j] + red[3584 + j];
+  }
+}
+
+extern "C" size_t advmil_ln_relu_mean16_bwd_workspace_bytes(int64_t N, int64_t d) {
+  return (size_t)((N / 16) * 2 * d) * sizeof(float);
+}
+
+extern "C" int advmil_ln_relu_mean16_bwd(const float* demb, const float* y, const float* gamma, const float* beta,
+                                         const float* mean, const float* rstd, int64_t N, int64_t d, float* dy,
+                                         float* dgamma, float* dbeta, void* ws, size_t ws_bytes, advmil_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!demb || !y || !gamma || !beta || !mean || !rstd || !dy || !dgamma || !dbeta || !ws || N <= 0 || (N & 15) || d <= 0 ||
+      d > 512)
+    return ADVMIL_EINVAL;
+  if (ws_bytes < advmil_ln_relu_mean16_bwd_workspace_bytes(N, d)) return ADVMIL_EWORKSPACE;
+  const int L = (int)(N / 16);
+  float* partial = (float*)ws;
+  hipLaunchKernelGGL(ln_relu_mean16_bwd_kernel, dim3(L), dim3(256), 0, stream, demb, y, gamma, beta, mean, rstd, N, d, dy,
+                     partial);
+  ADVMIL_LAUNCH_CHECK();
+  const unsigned gb = (unsigned)((d + 255) / 256);
+  hipLaunchKernelGGL(colsum_merge_kernel, dim3(gb), dim3(256), 0, stream, partial, L, 2 * d, d, dgamma);
+  hipLaunchKernelGGL(colsum_merge_kernel, dim3(gb), dim3(256), 0, stream, partial + d, L, 2 * d, d, dbeta);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}

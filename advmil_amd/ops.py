@@ -1,0 +1,359 @@
+"""Host-side wrappers over the C ABI (include/advmil_hip.h): raw launches + torch.autograd Functions.
+
+PyTorch is plumbing here: device memory (caching allocator), the current HIP stream, autograd
+bookkeeping. Every N-row computation of the AdvMIL path runs in libadvmil_hip.so; there is no
+eager fallback -- CPU tensors raise.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import Epilogue
+
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+_ACT = {None: 0, "none": 0, "relu": 1, "tanh": 2, "sigmoid": 3}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"advmil_amd: `{name}` lives on {t.device}; the HIP path needs a ROCm device tensor "
+                           "(no CPU fallback in the product path)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"advmil_amd: `{name}` must be float32, got {t.dtype}")
+    return t
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16) // 4 + 4, dtype=torch.float32, device=device)
+
+
+# ---------------------------------------------------------------------------------------
+# counter RNG state (seed in device memory so HIP graphs can replay with fresh randomness)
+# ---------------------------------------------------------------------------------------
+class DeviceRng:
+    def __init__(self, device, seed=0):
+        self.device = torch.device(device)
+        self.seed = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.counter = 0
+        self.record = False
+        self.log = []
+        self.reset(seed)
+
+    def reset(self, seed):
+        """Set the step seed and rewind the call-site counter (not capturable: does a H2D copy)."""
+        s = int(seed) & 0xFFFFFFFFFFFFFFFF
+        if s >= 1 << 63:
+            s -= 1 << 64
+        self.seed.fill_(s)
+        self.counter = 0
+        self.log = []
+
+    def site(self, tag="", shape=None, p=None):
+        """A fresh stream id for one dropout/noise call site."""
+        self.counter += 1
+        if self.record:
+            self.log.append((tag, self.counter, shape, p))
+        return self.counter
+
+    def advance(self, inc=1):
+        """seed += inc on the device (capturable)."""
+        _lib.check(_lib.lib().advmil_seed_advance(_p(self.seed), inc, _stream()), "seed_advance")
+
+    def uniform(self, n, tag="noise"):
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        sid = self.site(tag, (n,), None)
+        _lib.check(_lib.lib().advmil_uniform_fill(_p(out), n, _p(self.seed), sid, _stream()), "uniform_fill")
+        return out
+
+
+_RNGS = {}
+
+
+def default_rng(device):
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _RNGS:
+        _RNGS[key] = DeviceRng(device)
+    return _RNGS[key]
+
+
+# ---------------------------------------------------------------------------------------
+# raw launches
+# ---------------------------------------------------------------------------------------
+def auto_splits(M, N, K):
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles >= 128:
+        return 1
+    want = (384 + tiles - 1) // tiles
+    cap = max(1, K // 128)
+    return max(1, min(want, cap))
+
+
+def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=None, act_split=None, drop_p=0.0,
+         seed=None, stream_id=0, rowv=None, colv=None, maskref=None, mask_scale=1.0, accumulate=False, alpha=1.0,
+         splits=None):
+    """C[M,N] = epilogue(alpha * op(A) op(B)); see include/advmil_hip.h::advmil_gemm_f32."""
+    _chk(A, "A"); _chk(B, "B")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+        ldc = N
+    elif ldc is None:
+        ldc = out.stride(0)
+    lda = A.stride(0)
+    ldb = B.stride(0)
+    e = Epilogue()
+    e.bias = None if bias is None else bias.data_ptr()
+    e.act0 = act0
+    e.act1 = act0 if act1 is None else act1
+    e.act_split = (1 << 30) if act_split is None else act_split
+    e.drop_p = float(drop_p)
+    e.seed = None if (seed is None or drop_p <= 0.0) else seed.data_ptr()
+    e.stream_id = stream_id
+    e.rowv = None if rowv is None else rowv.data_ptr()
+    e.colv = None if colv is None else colv.data_ptr()
+    e.maskref = None if maskref is None else maskref.data_ptr()
+    e.ldmask = 0 if maskref is None else maskref.stride(0)
+    e.mask_scale = float(mask_scale)
+    e.accumulate = 1 if accumulate else 0
+    e.alpha = float(alpha)
+    if splits is None:
+        splits = auto_splits(M, N, K)
+    L = _lib.lib()
+    wsb = L.advmil_gemm_f32_workspace_bytes(M, N, splits)
+    ws = _ws(wsb, A.device) if wsb else None
+    _lib.check(L.advmil_gemm_f32(1 if a_kc else 0, 1 if b_kc else 0, M, N, K, _p(A), lda, _p(B), ldb, _p(out), ldc,
+                                 ctypes.byref(e), splits, _p(ws), wsb, _stream()), f"gemm_f32[{M}x{N}x{K}]")
+    return out
+
+
+def gate_score(ab, wc, bc, N, D, p=0.0, seed=None, stream_a=0, stream_b=0):
+    s = torch.empty(N, dtype=torch.float32, device=ab.device)
+    sd = seed if p > 0.0 else None
+    _lib.check(_lib.lib().advmil_gate_score_fwd(_p(ab), _p(wc), _p(bc), p, _p(sd), stream_a, stream_b, N, D, _p(s),
+                                                _stream()), "gate_score_fwd")
+    return s
+
+
+def softmax_pool(s, h, N, D):
+    L = _lib.lib()
+    A = torch.empty(N, dtype=torch.float32, device=h.device)
+    pooled = torch.empty(D, dtype=torch.float32, device=h.device)
+    wsb = L.advmil_softmax_pool_workspace_bytes(N, D)
+    ws = _ws(wsb, h.device)
+    _lib.check(L.advmil_softmax_pool_fwd(_p(s), _p(h), h.stride(0), N, D, _p(A), _p(pooled), _p(ws), wsb, _stream()),
+               "softmax_pool_fwd")
+    return A, pooled
+
+
+def softmax_pool_bwd(dpooled, dA, A, h, N, D):
+    L = _lib.lib()
+    ds = torch.empty(N, dtype=torch.float32, device=h.device)
+    wsb = L.advmil_softmax_pool_workspace_bytes(N, D)
+    ws = _ws(wsb, h.device)
+    _lib.check(L.advmil_softmax_pool_bwd(_p(dpooled), _p(dA), _p(A), _p(h), h.stride(0), N, D, _p(ds), _p(ws), wsb,
+                                         _stream()), "softmax_pool_bwd")
+    return ds
+
+
+def gate_bwd(ab, ds, wc, N, D, p=0.0, seed=None, stream_a=0, stream_b=0):
+    L = _lib.lib()
+    dev = ab.device
+    dG = torch.empty(N, 2 * D, dtype=torch.float32, device=dev)
+    dwc = torch.empty(D, dtype=torch.float32, device=dev)
+    dbc = torch.empty(1, dtype=torch.float32, device=dev)
+    dbias = torch.empty(2 * D, dtype=torch.float32, device=dev)
+    wsb = L.advmil_gate_bwd_workspace_bytes(N, D)
+    ws = _ws(wsb, dev)
+    sd = seed if p > 0.0 else None
+    _lib.check(L.advmil_gate_bwd(_p(ab), _p(ds), _p(wc), p, _p(sd), stream_a, stream_b, N, D, _p(dG), _p(dwc), _p(dbc),
+                                 _p(dbias), _p(ws), wsb, _stream()), "gate_bwd")
+    return dG, dwc, dbc, dbias
+
+
+def act_dropout_bwd(dy, y, act, M, N, p=0.0, seed=None, stream_id=0, want_bias=True):
+    L = _lib.lib()
+    dpre = torch.empty(M, N, dtype=torch.float32, device=dy.device)
+    db = torch.empty(N, dtype=torch.float32, device=dy.device) if want_bias else None
+    wsb = L.advmil_colsum_workspace_bytes(M, N) if want_bias else 0
+    ws = _ws(wsb, dy.device) if want_bias else None
+    sd = seed if p > 0.0 else None
+    _lib.check(L.advmil_act_dropout_bwd(_p(dy), _p(y), act, p, _p(sd), stream_id, M, N, _p(dpre), _p(db), _p(ws), wsb,
+                                        _stream()), "act_dropout_bwd")
+    return dpre, db
+
+
+def colsum(x, M, N):
+    L = _lib.lib()
+    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    wsb = L.advmil_colsum_workspace_bytes(M, N)
+    ws = _ws(wsb, x.device)
+    _lib.check(L.advmil_colsum(_p(x), M, N, _p(out), _p(ws), wsb, _stream()), "colsum")
+    return out
+
+
+def ln_relu_mean16_fwd(y, gamma, beta, N, d, eps=1e-5):
+    dev = y.device
+    emb = torch.empty(N // 16, d, dtype=torch.float32, device=dev)
+    mean = torch.empty(N, dtype=torch.float32, device=dev)
+    rstd = torch.empty(N, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().advmil_ln_relu_mean16_fwd(_p(y), _p(gamma), _p(beta), eps, N, d, _p(emb), _p(mean), _p(rstd),
+                                                    _stream()), "ln_relu_mean16_fwd")
+    return emb, mean, rstd
+
+
+def ln_relu_mean16_bwd(demb, y, gamma, beta, mean, rstd, N, d):
+    L = _lib.lib()
+    dev = y.device
+    dy = torch.empty(N, d, dtype=torch.float32, device=dev)
+    dg = torch.empty(d, dtype=torch.float32, device=dev)
+    db = torch.empty(d, dtype=torch.float32, device=dev)
+    wsb = L.advmil_ln_relu_mean16_bwd_workspace_bytes(N, d)
+    ws = _ws(wsb, dev)
+    _lib.check(L.advmil_ln_relu_mean16_bwd(_p(demb), _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), N, d, _p(dy), _p(dg),
+                                           _p(db), _p(ws), wsb, _stream()), "ln_relu_mean16_bwd")
+    return dy, dg, db
+
+
+def adam_step(p, grad, m, v, wd, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, l1_coef=0.0):
+    """In place over flat fp32 arenas; `step` is an int32 device tensor bumped by the kernel."""
+    _lib.check(_lib.lib().advmil_adam_step(_p(p), _p(grad), _p(m), _p(v), _p(wd), p.numel(), lr, beta1, beta2, eps,
+                                           grad_scale, l1_coef, _p(step), _stream()), "adam_step")
+
+
+def abs_sum(p):
+    L = _lib.lib()
+    out = torch.empty(1, dtype=torch.float32, device=p.device)
+    wsb = L.advmil_abs_sum_workspace_bytes(p.numel())
+    ws = _ws(wsb, p.device)
+    _lib.check(L.advmil_abs_sum(_p(p), p.numel(), _p(out), _p(ws), wsb, _stream()), "abs_sum")
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+# autograd Functions
+# ---------------------------------------------------------------------------------------
+class LinearActFn(torch.autograd.Function):
+    """y = dropout(act(x W^T + b)); x[M,K], W[N,K]. Dropout index = m*N + n on stream `sid`."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act, p, seed, sid):
+        _chk(x, "x"); _chk(W, "weight")
+        x = x.contiguous()
+        W2 = W.reshape(W.shape[0], -1)
+        M, K = x.shape
+        N = W2.shape[0]
+        y = gemm(x, W2, True, True, M, N, K, bias=b, act0=act, drop_p=p, seed=seed, stream_id=sid)
+        ctx.save_for_backward(x, W2, y)
+        ctx.cfg = (act, p, seed, sid, M, N, K, W.shape, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W2, y = ctx.saved_tensors
+        act, p, seed, sid, M, N, K, wshape, has_b = ctx.cfg
+        dy = dy.contiguous()
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if act == ACT_NONE and p <= 0.0:
+            dpre = dy
+            db = colsum(dy, M, N) if has_b else None
+        else:
+            dpre, db = act_dropout_bwd(dy, y, act, M, N, p, seed, sid, want_bias=has_b)
+        dW = gemm(dpre, x, False, False, N, K, M).reshape(wshape) if need_w else None   # dpre^T x
+        dx = gemm(dpre, W2, True, False, M, K, N) if need_x else None                   # dpre W
+        return dx, dW, db, None, None, None, None
+
+
+def linear_act(x, W, b, act="none", p=0.0, rng=None, tag=""):
+    """x[..., K] -> [..., N] through the HIP GEMM (any leading dims are flattened)."""
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1])
+    sid, seed = 0, None
+    if p > 0.0:
+        rng = rng or default_rng(x.device)
+        N = W.shape[0]
+        sid, seed = rng.site(tag, (x2.shape[0], N), p), rng.seed
+    y = LinearActFn.apply(x2, W, b, _ACT[act], float(p), seed, sid)
+    return y.reshape(*lead, y.shape[-1])
+
+
+class GatedAttnPoolFn(torch.autograd.Function):
+    """(pooled[D], A[N]) = softmax-pool of h[N,D] scored by the gated attention net.
+    Attn_Net_Gated + softmax + mm (model/backbone_utils.py:11-29, model/backbone.py:81-85) and GAPool
+    (model/backbone_utils.py:47-56): the pooled tensor is the scored tensor in every use."""
+
+    @staticmethod
+    def forward(ctx, h, Wa, ba, Wb, bb, wc, bc, p, seed, sa, sb):
+        _chk(h, "h")
+        h = h.contiguous()
+        N, D = h.shape
+        Wab = torch.cat([Wa, Wb], dim=0).contiguous()        # [2D, D]
+        bab = torch.cat([ba, bb], dim=0).contiguous()
+        ab = gemm(h, Wab, True, True, N, 2 * D, D, bias=bab, act0=ACT_TANH, act1=ACT_SIGMOID, act_split=D)
+        wcv = wc.reshape(-1).contiguous()
+        s = gate_score(ab, wcv, bc, N, D, p, seed, sa, sb)
+        A, pooled = softmax_pool(s, h, N, D)
+        ctx.save_for_backward(h, Wab, ab, A, wcv)
+        ctx.cfg = (p, seed, sa, sb, N, D, wc.shape)
+        ctx.mark_non_differentiable(s)
+        ctx.set_materialize_grads(False)
+        return pooled, A, s
+
+    @staticmethod
+    def backward(ctx, dpooled, dA, _ds_unused):
+        h, Wab, ab, A, wcv = ctx.saved_tensors
+        p, seed, sa, sb, N, D, wcshape = ctx.cfg
+        dpooled = torch.zeros(D, dtype=torch.float32, device=h.device) if dpooled is None else dpooled.contiguous()
+        dA_ = None if dA is None else dA.contiguous()
+        ds = softmax_pool_bwd(dpooled, dA_, A, h, N, D)
+        dG, dwc, dbc, dbias = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb)
+        dh = None
+        if ctx.needs_input_grad[0]:
+            # dG [N,2D] . Wab [2D,D]  +  A[n] * dpooled[d]   (pooling's direct path)
+            dh = gemm(dG, Wab, True, False, N, D, 2 * D, rowv=A, colv=dpooled)
+        dWab = gemm(dG, h, False, False, 2 * D, D, N)         # dG^T h
+        return (dh, dWab[:D], dbias[:D], dWab[D:], dbias[D:], dwc.reshape(wcshape), dbc, None, None, None, None)
+
+
+def gated_attn_pool(h, Wa, ba, Wb, bb, wc, bc, p=0.0, rng=None, tag=""):
+    sa = sb = 0
+    seed = None
+    if p > 0.0:
+        rng = rng or default_rng(h.device)
+        sa = rng.site(tag + "att_a", tuple(h.shape), p)
+        sb = rng.site(tag + "att_b", tuple(h.shape), p)
+        seed = rng.seed
+    return GatedAttnPoolFn.apply(h, Wa, ba, Wb, bb, wc, bc, float(p), seed, sa, sb)
+
+
+class LNReLUMean16Fn(torch.autograd.Function):
+    """emb[N/16,d] = mean16(relu(LayerNorm(y))) -- tail of AVGPoolPatchEmbedding
+    (model/backbone_utils.py:161-167)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, eps):
+        _chk(y, "y")
+        y = y.contiguous()
+        N, d = y.shape
+        emb, mean, rstd = ln_relu_mean16_fwd(y, gamma, beta, N, d, eps)
+        ctx.save_for_backward(y, gamma, beta, mean, rstd)
+        return emb
+
+    @staticmethod
+    def backward(ctx, demb):
+        y, gamma, beta, mean, rstd = ctx.saved_tensors
+        N, d = y.shape
+        dy, dg, db = ln_relu_mean16_bwd(demb.contiguous(), y, gamma, beta, mean, rstd, N, d)
+        return dy, dg, db, None
+
+
+def ln_relu_mean16(y, gamma, beta, eps=1e-5):
+    return LNReLUMean16Fn.apply(y, gamma, beta, eps)

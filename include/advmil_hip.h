@@ -1,0 +1,139 @@
+/* C ABI of libadvmil_hip.so — the MI355X (gfx950) kernels underneath the AdvMIL plugin surface.
+ *
+ * The reference (liupei101/AdvMIL @ v1) is pure Python/PyTorch and has no FFI: its "operator
+ * interface" for the generator+discriminator training path is the set of nn.Module forwards in
+ * model/backbone.py, model/backbone_utils.py, model/GANSurv.py, model/model_utils.py and the loss
+ * functions in loss/utils.py. Each entry point below names the reference code it replaces
+ * (file:line into /root/reference). The Python host side (advmil_amd/) binds these with ctypes
+ * and mirrors the reference's class names / ctor + forward signatures / state_dict keys.
+ *
+ * Conventions
+ *  - all pointers are DEVICE pointers borrowed for the duration of the enqueue; row-major,
+ *    contiguous unless a leading dimension is given; 16-byte aligned; fp32 unless noted.
+ *  - every call is asynchronous on `stream` (a hipStream_t), never allocates, never syncs; it is
+ *    safe under hipStreamBeginCapture (HIP graphs).
+ *  - return value: 0 = ok, <0 = ADVMIL_E* (bad argument), >0 = hipError_t of the launch.
+ *  - randomness (dropout, generator noise) is counter based: u = splitmix64(key(seed, stream_id)
+ *    + element_index); `seed` is a DEVICE pointer to a uint64 so a captured graph can be
+ *    replayed with a fresh seed; `stream_id` distinguishes call sites. NULL seed or p == 0
+ *    disables dropout. advmil_amd/synth.py restates the generator on the host.
+ */
+#ifndef ADVMIL_HIP_H
+#define ADVMIL_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* advmil_stream_t; /* hipStream_t */
+
+enum { ADVMIL_ACT_NONE = 0, ADVMIL_ACT_RELU = 1, ADVMIL_ACT_TANH = 2, ADVMIL_ACT_SIGMOID = 3 };
+
+int advmil_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense contraction engine (fp32 MFMA v_mfma_f32_32x32x2_f32, exact fp32 accumulate).
+ *   C[M,N] = epilogue( alpha * op(A)[M,K] . op(B)[K,N] )
+ *   a_kc != 0 : A is [M,K] row-major (k contiguous, lda = row pitch); else A is [K,M] (m contiguous)
+ *   b_kc != 0 : B is [N,K] row-major (a torch Linear weight);         else B is [K,N] (n contiguous)
+ * replaces: nn.Linear / Conv2d(1x1) forwards (model/backbone.py:69,72-75,98,102;
+ *   model/backbone_utils.py:16-17,35-44,150; model/model_utils.py:157-176) and the
+ *   addmm/mm calls autograd issues for their backward.
+ * epilogue, applied in this order per element (row m, col n):
+ *   v = alpha*acc (+ bias[n]) (+ rowv[m]*colv[n]); v = act(v)  [act0 for n < act_split, else act1];
+ *   v *= dropout(m*N+n); v *= (maskref[m*ldmask+n] > 0 ? mask_scale : 0) if maskref;
+ *   C = v (+ C if accumulate).
+ * splits > 1 partitions K across workgroups (needed when M*N is small and K is the bag length);
+ * partials go to `ws` (advmil_gemm_f32_workspace_bytes) and a second launch reduces them.
+ * Requirements: contiguous dims and leading dims multiples of 4 floats. */
+typedef struct {
+  const float* bias;
+  int act0, act1, act_split;
+  float drop_p;
+  const uint64_t* seed;
+  uint64_t stream_id;
+  const float* rowv;
+  const float* colv;
+  const float* maskref;
+  int ldmask;
+  float mask_scale;
+  int accumulate;
+  float alpha;
+} advmil_epilogue_t;
+
+size_t advmil_gemm_f32_workspace_bytes(int64_t M, int64_t N, int splits);
+int advmil_gemm_f32(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                    const float* B, int64_t ldb, float* C, int64_t ldc, const advmil_epilogue_t* epi,
+                    int splits, void* ws, size_t ws_bytes, advmil_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Gated-attention MIL pooling (Attn_Net_Gated + softmax + mm: model/backbone_utils.py:11-29,
+ * model/backbone.py:81-85, 118-122, 163-167; GAPool: model/backbone_utils.py:47-56).
+ *
+ * gate_score: ab[N,2D] holds tanh-branch a (cols 0..D-1) and sigmoid-branch b (cols D..2D-1),
+ *   post-activation, PRE-dropout. s[n] = sum_j (a*ka)(b*kb) wc[j] + bc[0], ka/kb the dropout
+ *   factors (stream_a/stream_b, element index n*D+j).
+ * softmax_pool_fwd: A = softmax(s) over the N instances; pooled[d] = sum_n A[n] h[n,d].
+ *   ws >= advmil_softmax_pool_workspace_bytes. Deterministic two-stage reduction.
+ * softmax_pool_bwd: ds[n] = A[n] * (dA[n] + dot(dpooled, h[n,:]) - sum_m A[m](dA[m] + dot(dpooled,h[m,:])));
+ *   dA may be NULL. (dh gets A[n]*dpooled[d] through the rank-1 term of the gemm epilogue.)
+ * gate_bwd: from ds -> dG[N,2D] = grads wrt the two pre-activations, plus dwc[D], dbc[1], dbias[2D]
+ *   (column sums of dG). */
+int advmil_gate_score_fwd(const float* ab, const float* wc, const float* bc, float drop_p, const uint64_t* seed,
+                          uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D, float* s, advmil_stream_t stream);
+size_t advmil_softmax_pool_workspace_bytes(int64_t N, int64_t D);
+int advmil_softmax_pool_fwd(const float* s, const float* h, int64_t ldh, int64_t N, int64_t D, float* A,
+                            float* pooled, void* ws, size_t ws_bytes, advmil_stream_t stream);
+int advmil_softmax_pool_bwd(const float* dpooled, const float* dA, const float* A, const float* h, int64_t ldh,
+                            int64_t N, int64_t D, float* ds, void* ws, size_t ws_bytes, advmil_stream_t stream);
+size_t advmil_gate_bwd_workspace_bytes(int64_t N, int64_t D);
+int advmil_gate_bwd(const float* ab, const float* ds, const float* wc, float drop_p, const uint64_t* seed,
+                    uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D, float* dG, float* dwc, float* dbc,
+                    float* dbias, void* ws, size_t ws_bytes, advmil_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Backward of y = dropout(act(pre)) for the Linear layers: dpre = dy * keep * act'(y) and
+ * dbias[n] = sum_m dpre[m,n] (NULL to skip). y is the stored post-dropout output.
+ * replaces: autograd of ReLU/Tanh/Sigmoid/Dropout modules (model/backbone.py:70-75 etc.). */
+size_t advmil_colsum_workspace_bytes(int64_t M, int64_t N);
+int advmil_act_dropout_bwd(const float* dy, const float* y, int act, float drop_p, const uint64_t* seed,
+                           uint64_t stream_id, int64_t M, int64_t N, float* dpre, float* dbias, void* ws,
+                           size_t ws_bytes, advmil_stream_t stream);
+/* out[n] = sum_m x[m,n] */
+int advmil_colsum(const float* x, int64_t M, int64_t N, float* out, void* ws, size_t ws_bytes, advmil_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Region embedding tail of AVGPoolPatchEmbedding (model/backbone_utils.py:158-168):
+ * y[N,d] (the 1x1-conv / FC output) -> LayerNorm(d, eps) -> ReLU -> mean over each consecutive 16
+ * rows -> emb[N/16,d]. Saves mean/rstd per row for the backward. N % 16 == 0 (backbone_utils.py:65).
+ * bwd: demb[N/16,d] -> dy[N,d], dgamma[d], dbeta[d]. */
+int advmil_ln_relu_mean16_fwd(const float* y, const float* gamma, const float* beta, float eps, int64_t N, int64_t d,
+                              float* emb, float* mean, float* rstd, advmil_stream_t stream);
+size_t advmil_ln_relu_mean16_bwd_workspace_bytes(int64_t N, int64_t d);
+int advmil_ln_relu_mean16_bwd(const float* demb, const float* y, const float* gamma, const float* beta,
+                              const float* mean, const float* rstd, int64_t N, int64_t d, float* dy, float* dgamma,
+                              float* dbeta, void* ws, size_t ws_bytes, advmil_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimizer + regulariser over a flat parameter arena (torch.optim.Adam, L2-in-grad weight decay:
+ * optim/optim_factory.py:25-37,76-77; model/model_handler.py:104-107; L1: loss/utils.py:6-14).
+ *   g = grad*grad_scale + l1_coef*sign(p) + wd[i]*p ; Adam(m, v) ; p -= lr/(1-b1^t) * m/(sqrt(v)/sqrt(1-b2^t)+eps)
+ * `step` is a device int32 incremented by the kernel (graph-replay safe). wd may be NULL.
+ * abs_sum: out[0] = sum |p| (for the logged Loss_G_total). */
+int advmil_adam_step(float* p, const float* grad, float* m, float* v, const float* wd, int64_t n, float lr,
+                     float beta1, float beta2, float eps, float grad_scale, float l1_coef, int32_t* step,
+                     advmil_stream_t stream);
+int advmil_abs_sum(const float* p, int64_t n, float* out, void* ws, size_t ws_bytes, advmil_stream_t stream);
+size_t advmil_abs_sum_workspace_bytes(int64_t n);
+
+/* fill out[i] = U[0,1) from the counter RNG (generator noise, utils/func.py:154-164) */
+int advmil_uniform_fill(float* out, int64_t n, const uint64_t* seed, uint64_t stream_id, advmil_stream_t stream);
+/* seed[0] += inc  (advance the step seed between graph replays) */
+int advmil_seed_advance(uint64_t* seed, uint64_t inc, advmil_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
