@@ -1,0 +1,61 @@
+"""Losses of the G+D step (reference loss/utils.py): loss_reg_l1 (6-14), recon_loss (21-41),
+real_fake_loss (182-203), fake_generator_loss (205-208). They act on <= bp_every_batch scalars, so
+they are a handful of tiny device ops; the one N-sized piece -- sum|W| over the generator arena -- is
+the abs_sum kernel, and its gradient is folded into the fused Adam kernel (advmil_amd/optim.py)."""
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+
+
+def loss_reg_l1(coef):
+    coef = 0.0 if coef is None else coef
+
+    def func(model_params):
+        if coef <= 1e-8:
+            return 0.0
+        params = list(model_params)
+        return coef * sum(ops.abs_sum(w.detach().reshape(-1))[0] if w.is_cuda and w.is_contiguous() else w.abs().sum()
+                          for w in params)
+    return func
+
+
+def recon_loss(pred_t, t, e, alpha=0.0, gamma=1.0, norm="l1", cur_alpha=None):
+    pred_t, t, e = pred_t.reshape(-1), t.reshape(-1), e.reshape(-1)
+    loss_obs = e * torch.abs(pred_t - t)
+    loss_cen = (1 - e) * F.relu(gamma - (pred_t - t))
+    if norm == "l2":
+        loss_obs, loss_cen = loss_obs * loss_obs, loss_cen * loss_cen
+    a = alpha if cur_alpha is None else cur_alpha
+    return ((1.0 - a) * (loss_obs + loss_cen) + a * loss_obs).mean()
+
+
+def real_fake_terms(real, fake, which="bce"):
+    """Per-sample terms whose means make up real_fake_loss: (terms_real | None, terms_fake).
+    bce keeps the reference's shipped form -(1 - log(sigmoid(fake)+1e-8)) (loss/utils.py:185-186)."""
+    fake = fake.reshape(-1)
+    real = None if real is None else real.reshape(-1)
+    if which == "bce":
+        tf = -(1.0 - torch.log(torch.sigmoid(fake) + 1e-8))
+        tr = None if real is None else -torch.log(torch.sigmoid(real) + 1e-8)
+    elif which == "hinge":
+        tf = F.relu(1.0 + fake)
+        tr = None if real is None else F.relu(1.0 - real)
+    elif which == "wasserstein":
+        tf = fake
+        tr = None if real is None else -real
+    else:
+        raise ValueError(which)
+    return tr, tf
+
+
+def real_fake_loss(real, fake, which="bce"):
+    tr, tf = real_fake_terms(real, fake, which)
+    loss = tf.mean()
+    if tr is not None:
+        loss = loss + tr.mean()
+    return loss
+
+
+def fake_generator_loss(fake_score):
+    return -torch.mean(fake_score.reshape(-1))

@@ -1,0 +1,115 @@
+"""Generator / Discriminator / PrjDiscriminator (RLIP) of the reference's model/GANSurv.py (13-49, 52-68,
+71-105): same ctor arguments, forward signatures and state_dict keys."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..utils.func import generate_noise
+from .backbone_utils import _rng_of
+from .model_utils import EmbedXLayer, make_embedding_y_layer, make_noise_mlp_layer, run_mlp_small
+
+
+class Generator(nn.Module):
+    def __init__(self, dim_in, dim_out, backbone: nn.Module, args_noise, norm=False, dropout=0.25, out_scale: str = "sigmoid"):
+        super().__init__()
+        self.noise = args_noise.noise
+        self.hops = args_noise.hops
+        self.noise_dist = "uniform" if args_noise.noise_dist is None else args_noise.noise_dist
+        assert len(self.noise) == self.hops + 1
+        self.MLPs = make_noise_mlp_layer(dim_in, dim_out, self.noise, hops=self.hops, norm=norm, dropout=dropout)
+        self.backbone = backbone
+        self.out_scale = out_scale
+
+    def head(self, H, zero_noise=False, noise=None):
+        """H[1, dim_in] -> prediction. `noise`: optional list of injected tensors (one per noisy layer)."""
+        rng = _rng_of(self, H)
+        it = iter(noise) if noise is not None else None
+        for i, layer in enumerate(self.MLPs):
+            if self.noise[i] == 1:
+                if zero_noise:
+                    n = torch.zeros_like(H)
+                elif it is not None:
+                    n = next(it).to(H.device)
+                else:
+                    n = generate_noise(*H.size(), to_device=H.device, distribution=self.noise_dist, rng=rng)
+                H = torch.cat([H, n], dim=1)
+            H = run_mlp_small(layer, H, rng, f"gen_mlp{i}")
+        if self.out_scale == "sigmoid":
+            return torch.sigmoid(H)
+        if self.out_scale == "exp":
+            return torch.exp(H)
+        return H
+
+    def forward(self, x, x_ext, zero_noise=False, noise=None):
+        return self.head(self.backbone(x, x_ext), zero_noise, noise)
+
+
+class _PairNet(nn.Module):
+    def __init__(self, args_netx, args_nety):
+        super().__init__()
+        self.net_pair_one = EmbedXLayer(args_netx)
+        self.net_pair_two = make_embedding_y_layer(args_nety)
+
+    def embed_x(self, x):
+        return self.net_pair_one.embed(x)
+
+    def forward(self, x, t):
+        return self.from_embedding(self.embed_x(x), t)
+
+
+class Discriminator(_PairNet):
+    """Concat fusion (disc_type: cat)."""
+
+    def __init__(self, args_netx, args_nety, **kws):
+        super().__init__(args_netx, args_nety)
+        self.fc = nn.Linear(args_netx.out_dim + args_nety.hid_dims[-1], 1)
+
+    def x_features(self, emb_ins):
+        return (self.net_pair_one.from_embedding(emb_ins),)
+
+    def fuse(self, feats, t):
+        hid_t = run_mlp_small(self.net_pair_two, t, _rng_of(self, t), "dy")
+        return nn.functional.linear(torch.cat([feats[0], hid_t], dim=1), self.fc.weight, self.fc.bias)
+
+    def from_embedding(self, emb_ins, t):
+        return self.fuse(self.x_features(emb_ins), t)
+
+
+class PrjDiscriminator(_PairNet):
+    """Projection discriminator; inner_product='instance' is RLIP (region-level inner product)."""
+
+    def __init__(self, args_netx, args_nety, prj_path="x", inner_product="bag"):
+        super().__init__(args_netx, args_nety)
+        assert inner_product in ["bag", "instance"]
+        self.inner_product = inner_product
+        dim_x, dim_y = args_netx.out_dim, args_nety.hid_dims[-1]
+        self.prj_path = prj_path
+        if prj_path == "x":
+            self.prj_layer = nn.Linear(dim_x, 1)
+        elif prj_path == "y":
+            self.prj_layer = nn.Linear(dim_y, 1)
+        else:
+            self.prj_layer = None
+
+    def x_features(self, emb_ins):
+        """Everything that does not depend on t: (hid_x[1,C'], mean_r fc_ins[1,C'] | None)."""
+        if self.inner_product == "instance":
+            hid_x, fc_ins = self.net_pair_one.from_embedding(emb_ins, return_instance=True)
+            # RLIP is linear in the region mean: mean_r(fc_ins_r . hid_t) == mean_r(fc_ins_r) . hid_t
+            return hid_x, fc_ins.mean(dim=1)
+        return self.net_pair_one.from_embedding(emb_ins), None
+
+    def fuse(self, feats, t):
+        hid_x, ins_mean = feats
+        hid_t = run_mlp_small(self.net_pair_two, t, _rng_of(self, t), "dy")
+        if self.inner_product == "bag":
+            out = (hid_t * hid_x).sum(dim=-1, keepdim=True)
+        else:
+            out = (ins_mean * hid_t).sum(dim=-1, keepdim=True)
+        if self.prj_layer is not None:
+            src = hid_x if self.prj_path == "x" else hid_t
+            out = out + nn.functional.linear(src, self.prj_layer.weight, self.prj_layer.bias)
+        return out
+
+    def from_embedding(self, emb_ins, t):
+        return self.fuse(self.x_features(emb_ins), t)

@@ -1,0 +1,121 @@
+"""MIL backbones behind the reference's `load_backbone(mode, dims)` (model/backbone.py:19-51):
+ABMIL (54-86), DeepAttMISL (89-123), DualTrans_HS = ESAT (171-196), PatchGCN (126-168).
+Each is `forward(x, x_ext, *args) -> H[1, dim_out]` with the reference's state_dict keys; the N-row
+work is in the HIP library (advmil_amd/ops.py)."""
+from types import SimpleNamespace
+from typing import List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..utils.func import dropout_small
+from .backbone_utils import Attn_Net_Gated, GAPool, make_embedding_layer, make_transformer_layer, _rng_of
+
+
+def Model_Zoo(mode):
+    return {"patch": DualTrans_HS, "cluster": DeepAttMISL, "graph": PatchGCN}.get(mode, ABMIL)
+
+
+def load_backbone_param(mode, dims):
+    if mode == "patch":
+        emb = SimpleNamespace(in_dim=dims[0], out_dim=dims[1], scale=4, dw_conv=False, ksize=1)
+        tra = SimpleNamespace(d_model=dims[1], nhead=8, dropout=0.25, num_layers=1)
+        return [dims[:3], "avgpool", emb, "Transformer", tra], {"dropout": 0.25}
+    if mode == "cluster":
+        return [dims[:3]], {"num_clusters": 8, "dropout": 0.25}
+    if mode == "graph":
+        return [dims[:3]], {"num_layers": 1, "dropout": 0.25}
+    return [dims[:3]], {"dropout": 0.25}
+
+
+def load_backbone(mode, dims):
+    args, kws = load_backbone_param(mode, dims)
+    return Model_Zoo(mode)(*args, **kws)
+
+
+def _small_fc(seq, x, rng, tag):
+    """Linear -> ReLU -> Dropout on a [1, d] vector (launch-bound; stays a couple of tiny device ops)."""
+    lin, drop = seq[0], seq[2]
+    return dropout_small(F.relu(F.linear(x, lin.weight, lin.bias)), drop.p, seq.training, rng, tag)
+
+
+class ABMIL(nn.Module):
+    def __init__(self, dims: List, dropout: float = 0.25):
+        super().__init__()
+        assert len(dims) == 3
+        dim_in, dim_hid, dim_out = dims
+        self.attention_net = nn.Sequential(nn.Linear(dim_in, dim_hid), nn.ReLU(), nn.Dropout(dropout),
+                                           Attn_Net_Gated(L=dim_hid, D=dim_hid, dropout=dropout, n_classes=1))
+        self.rho = nn.Sequential(nn.Linear(dim_hid, dim_out), nn.ReLU(), nn.Dropout(dropout))
+
+    def forward(self, x_path, *args):
+        x = x_path.squeeze(0)                                   # batch_size = 1
+        rng = _rng_of(self, x)
+        fc, p = self.attention_net[0], (self.attention_net[2].p if self.training else 0.0)
+        h = ops.linear_act(x, fc.weight, fc.bias, "relu", p, rng, "abmil_fc")       # [N, hid]
+        pooled, A, _ = self.attention_net[3].pool(h)
+        self.last_attention = A.detach()
+        return _small_fc(self.rho, pooled.unsqueeze(0), rng, "abmil_rho")
+
+
+class DeepAttMISL(nn.Module):
+    def __init__(self, dims: List, num_clusters=8, dropout=0.25):
+        super().__init__()
+        assert len(dims) == 3
+        dim_in, dim_hid, dim_out = dims
+        assert dim_hid == dim_out
+        self.dim_hid, self.num_clusters = dim_hid, num_clusters
+        self.phis = nn.Sequential(nn.Conv2d(dim_in, dim_hid, 1), nn.ReLU())
+        self.pool1d = nn.AdaptiveAvgPool1d(1)
+        self.attention_net = nn.Sequential(nn.Linear(dim_hid, dim_hid), nn.ReLU(), nn.Dropout(dropout),
+                                           Attn_Net_Gated(L=dim_hid, D=dim_hid, dropout=dropout, n_classes=1))
+
+    def forward(self, x_path, cluster_id, *args):
+        x = x_path.squeeze(0)
+        rng = _rng_of(self, x)
+        # per-patch FC+ReLU (the 1x1 conv), then a per-cluster mean as ONE [8,N] x [N,hid] contraction with the
+        # normalised membership matrix: no host sync on the ids, no per-cluster gathers, empty cluster -> zeros
+        # (reference: D2H of ids + python loop of boolean gathers, backbone.py:107-116).
+        h = ops.linear_act(x, self.phis[0].weight, self.phis[0].bias, "relu")
+        h_cluster = ops.segmented_mean(h, cluster_id, self.num_clusters)          # [8, hid]
+        fc, p = self.attention_net[0], (self.attention_net[2].p if self.training else 0.0)
+        hc = dropout_small(F.relu(F.linear(h_cluster, fc.weight, fc.bias)), p, self.training, rng, "misl_fc")
+        pooled, A, _ = self.attention_net[3].pool(hc)
+        self.last_attention = A.detach()
+        return pooled.unsqueeze(0)
+
+
+class DualTrans_HS(nn.Module):
+    """ESAT: region embedding (FC+LN+ReLU+mean16) -> 1 post-norm transformer layer -> GAPool."""
+
+    def __init__(self, dims: List, emb_backbone: str, args_emb_backbone, tra_backbone: str, args_tra_backbone,
+                 dropout: float = 0.25):
+        super().__init__()
+        assert len(dims) == 3
+        dim_in, dim_hid, dim_out = dims
+        assert dim_hid == dim_out
+        assert emb_backbone in ["avgpool", "gapool"]
+        assert tra_backbone in ["Transformer", "Identity"]
+        self.patch_embedding_layer = make_embedding_layer(emb_backbone, args_emb_backbone)
+        self.dim_hid = dim_hid
+        self.patch_encoder_layer = make_transformer_layer(tra_backbone, args_tra_backbone)
+        self.pool = GAPool(dim_out, dim_out)
+
+    def forward(self, x, coord=None, *args):
+        if coord is not None:
+            raise NotImplementedError("positional encoding is unreachable in the reference (model_handler.py:390 passes None)")
+        emb = self.patch_embedding_layer(x)
+        feat = self.patch_encoder_layer(emb)
+        H = self.pool(feat)
+        self.last_attention = self.pool.last_attention
+        return H
+
+
+class PatchGCN(nn.Module):
+    """Placeholder until the GENConv softmax-gather kernel lands (parity unpinned: torch_geometric absent)."""
+
+    def __init__(self, dims: List, num_layers: int = 3, edge_agg: str = "spatial", dropout: float = 0.25):
+        super().__init__()
+        raise NotImplementedError("PatchGCN (bcb_mode: graph) is scheduled after the ESAT kernels; see DESIGN.md")

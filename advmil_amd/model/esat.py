@@ -1,0 +1,59 @@
+"""ESAT instance self-attention: the post-norm TransformerEncoder(1 layer) that the reference builds with
+nn.TransformerEncoderLayer(d_model, nhead, dim_feedforward=d_model, dropout, relu, batch_first)
+(model/backbone_utils.py:113-127). Same parameter names (layers.0.self_attn.in_proj_weight, ...) and the
+same initialisation: nn.MultiheadAttention / nn.Linear / nn.LayerNorm are kept as parameter holders.
+
+Dense projections (in-proj, out-proj, FFN) run on the HIP GEMM engine; the attention core
+(QK^T -> softmax -> dropout -> PV) runs in ops.mha.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..utils.func import dropout_small
+
+
+class HipTransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward, dropout):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout, batch_first=True)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.nhead = nhead
+
+    def forward(self, x):
+        if x.dim() != 3 or x.shape[0] != 1:
+            raise ValueError("ESAT layer: batch_size 1 expected")
+        rng = getattr(self, "rng", None) or ops.default_rng(x.device)
+        tr = self.training
+        sa = self.self_attn
+        L, d = x.shape[1], x.shape[2]
+        x2 = x[0]
+        qkv = ops.linear_act(x2, sa.in_proj_weight, sa.in_proj_bias, "none")           # [L, 3d]
+        o = ops.mha(qkv, self.nhead, sa.dropout if tr else 0.0, rng)                     # [L, d]
+        o = ops.linear_act(o, sa.out_proj.weight, sa.out_proj.bias, "none")
+        o = dropout_small(o, self.dropout1.p, tr, rng, "esat_drop1")
+        x2 = F.layer_norm(x2 + o, (d,), self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        f = ops.linear_act(x2, self.linear1.weight, self.linear1.bias, "relu", self.dropout.p if tr else 0.0, rng, "esat_ffn")
+        f = ops.linear_act(f, self.linear2.weight, self.linear2.bias, "none")
+        f = dropout_small(f, self.dropout2.p, tr, rng, "esat_drop2")
+        x2 = F.layer_norm(x2 + f, (d,), self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        return x2.unsqueeze(0)
+
+
+class HipTransformerEncoder(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward, dropout, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([HipTransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout)
+                                     for _ in range(num_layers)])
+
+    def forward(self, x):
+        for layer in self.layers:
+            x = layer(x)
+        return x

@@ -1,0 +1,321 @@
+"""MyHandler: the training-step caller of the reference (model/model_handler.py) -- ctor (37-137),
+_train_each_epoch (301-347), _update_disc (349-424), _update_gen (426-498), test_model (598-643),
+save_model / resume_model (645-678) -- with the same names, arguments, return values, logged keys and
+checkpoint layout, driving the HIP path.
+
+What is deliberately different from the reference's schedule (results identical):
+  * the D embedding (FC+LN+ReLU+mean16 of the bag) is computed once per bag in the D phase and shared by the
+    real and the fake pair (it has no dropout and does not depend on t);
+  * the D-phase generator forward runs under no_grad (the reference builds then detaches its graph);
+  * in the G phase nothing of D that touches the bag is differentiated (dD/dx is not a function of G's weights);
+  * each bag's loss term is back-propagated as soon as it exists, scaled by the step-batch denominators the
+    reference's means use, instead of keeping bp_every_batch autograd graphs alive;
+  * no per-bag host syncs: event flags come from the host copy of the labels, logs stay on the device until the
+    epoch ends; the bag is never copied by a boolean mask; no empty_cache() per step;
+  * the L1 term's gradient is applied inside the fused Adam kernel; its value is still added to Loss_G_total.
+Dataset / evaluator / wandb orchestration (exec, _run_training, _eval_all, exec_semi_sl) is out of scope
+(SURVEY.md §2 #6, #9-11): see INTEGRATION.md for how the reference's own handler binds to this class.
+"""
+import os
+import os.path as osp
+from functools import partial
+from types import SimpleNamespace
+
+import torch
+
+from .. import ops
+from ..loss.utils import fake_generator_loss, real_fake_loss, real_fake_terms, recon_loss
+from ..optim import FlatAdam, create_optimizer
+from ..parallel import BagParallel
+from ..utils.func import agg_tensor, seed_everything, sparse_key, sparse_str
+from .backbone import load_backbone
+from .GANSurv import Discriminator, Generator, PrjDiscriminator
+from .model_utils import init_weights
+
+
+def _check_configs(cfg):
+    """The constraints of model_handler.py:780-812 that concern the step."""
+    assert cfg["task"] in ("cont_gansurv",), "HIP path covers task=cont_gansurv (the only task in the shipped config)"
+    assert cfg["batch_size"] == 1, "batch_size must be 1 (one WSI per forward)"
+    assert cfg["loss_netD"] in ("bce", "hinge", "wasserstein")
+    assert cfg["disc_type"] in ("prj", "cat")
+    assert cfg["gen_out_scale"] in ("sigmoid", "exp", "none", None)
+
+
+class MyHandler(object):
+    def __init__(self, cfg, device=None, parallel=None):
+        _check_configs(cfg)
+        if device is None:
+            ndev = torch.cuda.device_count()
+            if ndev == 0:
+                raise RuntimeError("advmil_amd.MyHandler needs an MI355X: no ROCm device visible (no CPU fallback)")
+            local = int(os.environ.get("LOCAL_RANK", cfg.get("cuda_id", 0)))
+            device = torch.device("cuda", local % ndev)
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        seed_everything(cfg["seed"])
+        self.rng = ops.default_rng(self.device)
+        self.dp = parallel or BagParallel()
+        self.cfg = cfg
+        self.bcb = cfg["bcb_mode"]
+        self.task = cfg["task"]
+
+        save_path = cfg.get("save_path")
+        if save_path:
+            os.makedirs(save_path, exist_ok=True)
+            self.last_netD_ckpt_path = osp.join(save_path, "modelD-last.pth")
+            self.best_netD_ckpt_path = osp.join(save_path, "modelD-best.pth")
+            self.last_netG_ckpt_path = osp.join(save_path, "modelG-last.pth")
+            self.best_netG_ckpt_path = osp.join(save_path, "modelG-best.pth")
+
+        # ---- networks (model_handler.py:70-91)
+        backbone = load_backbone(self.bcb, sparse_str(cfg["bcb_dims"]))
+        dim_in, dim_out = sparse_str(cfg["gen_dims"])
+        args_noise = SimpleNamespace(**sparse_key(cfg, prefixes="gen_noi"))
+        args_noise.noise = sparse_str(args_noise.noise)
+        self.netG = Generator(dim_in, dim_out, backbone, args_noise, cfg["gen_norm"], cfg["gen_dropout"], cfg["gen_out_scale"])
+        self.netG.apply(init_weights)                      # G: xavier; D keeps torch defaults (model_handler.py:81)
+        disc_x = SimpleNamespace(**sparse_key(cfg, prefixes="disc_netx"))
+        disc_y = SimpleNamespace(**sparse_key(cfg, prefixes="disc_nety"))
+        disc_y.hid_dims = sparse_str(disc_y.hid_dims)
+        cls = PrjDiscriminator if cfg["disc_type"] == "prj" else Discriminator
+        self.netD = cls(disc_x, disc_y, prj_path=cfg["disc_prj_path"], inner_product=cfg["disc_prj_iprd"])
+        self.netG = self.netG.to(self.device)
+        self.netD = self.netD.to(self.device)
+        for m in list(self.netG.modules()) + list(self.netD.modules()):
+            m.rng = self.rng
+        if self.dp.world > 1:                              # replicas start identical
+            for net in (self.netG, self.netD):
+                for p in net.parameters():
+                    self.dp.broadcast_(p.data)
+
+        # ---- losses / optimizers (model_handler.py:94-109)
+        self.which_loss = cfg["loss_netD"]
+        self.real_fake_loss = partial(real_fake_loss, which=cfg["loss_netD"])
+        self.supervised_loss = partial(recon_loss, **sparse_key(cfg, prefixes="loss_recon"))
+        self.coef_ganloss = cfg["loss_gan_coef"]
+        self.coef_l1 = 0.0 if cfg["loss_regl1_coef"] is None else float(cfg["loss_regl1_coef"])
+        opt_cfg = SimpleNamespace(opt=cfg["opt_netG"], weight_decay=cfg["opt_netG_weight_decay"], lr=cfg["opt_netG_lr"],
+                                  opt_eps=None, opt_betas=None, momentum=None)
+        self.optimizerG = create_optimizer(opt_cfg, self.netG)
+        self.optimizerG.l1_coef = self.coef_l1 if self.coef_l1 > 1e-8 else 0.0
+        self.optimizerD = FlatAdam(self.netD, lr=cfg["opt_netD_lr"], betas=(0.9, 0.999), weight_decay=0.0)
+        self.steplr = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizerG, mode="min", factor=0.5, patience=10)
+
+        self.patient_id = dict()
+        self.history = []          # list of dicts of DEVICE scalars, flushed by pop_logs()
+        self.epoch = 0
+        self.noise_hook = None     # tests: callable(phase 'd'|'g', bag idx) -> [noise tensors] injected into G
+
+    # ------------------------------------------------------------------------------------------
+    def log(self, d):
+        self.history.append(d)
+
+    def pop_logs(self):
+        """Device scalars -> python floats (one sync for the whole backlog)."""
+        out = [{k: (float(v) if torch.is_tensor(v) else v) for k, v in d.items()} for d in self.history]
+        self.history = []
+        return out
+
+    def _get_patient_id(self, k, idxs):
+        pids = self.patient_id[k]
+        return [pids[i] for i in idxs.reshape(-1).tolist()]
+
+    def _get_label_visiable_mask(self, k, idxs):
+        if "label_visible" not in self.patient_id:
+            return None
+        if isinstance(idxs, list):
+            idxs = torch.cat(idxs, dim=0)
+        visible = set(self.patient_id["label_visible"])
+        return [p in visible for p in self._get_patient_id(k, idxs)]
+
+    def _gen_forward(self, data_x, data_x_ext, **kw):
+        if self.bcb == "graph":
+            return self.netG(data_x_ext, None, **kw)
+        if self.bcb == "patch":
+            return self.netG(data_x, None, **kw)       # coords skipped (model_handler.py:390)
+        return self.netG(data_x, data_x_ext, **kw)
+
+    @staticmethod
+    def _vis(mode, n, label_visible_mask):
+        if label_visible_mask is None:
+            return [mode == "wlabel"] * n
+        return [mode == "wlabel" or (mode == "wolabel" and bool(m)) for m in label_visible_mask]
+
+    # ------------------------------------------------------------------------------------------
+    def _train_each_epoch(self, train_loader, name_loader, mode="wlabel"):
+        bp_every_batch = self.cfg["bp_every_batch"]
+        num_update_gen = self.cfg["gen_updates"]
+        ys_all, yhat_all, ffake_all = [], [], []
+        i_col, x_col, y_col, yh_col = [], [], [], []
+        i_batch = 0
+        for data_idx, data_x, data_y in train_loader:
+            i_batch += 1
+            yh_col.append(data_y if not data_y.is_cuda else None)
+            data_x = [dx.to(self.device, non_blocking=True) if torch.is_tensor(dx) else dx for dx in data_x]
+            data_y = data_y.to(self.device, non_blocking=True)
+            i_col.append(data_idx); x_col.append(data_x); y_col.append(data_y)
+            if i_batch % bp_every_batch == 0:
+                mask = self._get_label_visiable_mask(name_loader, i_col)
+                ys_host = None if any(h is None for h in yh_col) else yh_col
+                nz_d = nz_g = None
+                if self.noise_hook is not None:
+                    nz_d = [self.noise_hook("d", int(ix.reshape(-1)[0])) for ix in i_col]
+                    nz_g = [self.noise_hook("g", int(ix.reshape(-1)[0])) for ix in i_col]
+                preds, fakes = self._update_disc(i_batch, x_col, y_col, mode, mask, ys_host=ys_host, noise=nz_d)
+                for _ in range(num_update_gen):
+                    self._update_gen(i_batch, x_col, y_col, mode, mask, ys_host=ys_host, noise=nz_g)
+                ys_all.append(torch.cat(y_col, dim=0)); yhat_all.append(torch.cat(preds, dim=0).detach())
+                ffake_all.append(torch.cat(fakes, dim=0))
+                i_col, x_col, y_col, yh_col = [], [], [], []
+        cltor = {"y": None, "y_hat": None, "f_fake": None}
+        if ys_all:                                      # one D2H per epoch instead of one per step
+            cltor = agg_tensor(cltor, {"y": torch.cat(ys_all).cpu(), "y_hat": torch.cat(yhat_all).cpu(),
+                                       "f_fake": torch.cat(ffake_all).cpu()})
+        return cltor
+
+    # ------------------------------------------------------------------------------------------
+    def _update_disc(self, i_batch, xs, ys, mode="wlabel", label_visible_mask=None, ys_host=None, noise=None):
+        """netD.train(), netG.eval(); real pairs only for event bags with a visible label, fake pairs for all.
+        `noise`: optional per-bag injected generator noise (tests). Returns (pred_collector, fake_collector)."""
+        self.netD.train()
+        self.netG.eval()
+        n = len(xs)
+        vis = self._vis(mode, n, label_visible_mask)
+        if ys_host is None:
+            ys_host = [y.cpu() for y in ys]             # fallback: one sync (the epoch loop passes host labels)
+        is_real = [bool(float(yh[0, 1]) == 1.0) and vis[i] for i, yh in enumerate(ys_host)]
+        n_real, n_fake = self.dp.global_counts([sum(is_real), n], self.device)
+
+        self.optimizerD.zero_grad()
+        preds, fakes = [], []
+        z = torch.zeros((), device=self.device)
+        s_loss, s_real, s_fake = z.clone(), z.clone(), z.clone()
+        for i in range(n):
+            data_x, data_x_ext = xs[i][0], xs[i][1]
+            data_t = ys[i][:, [0]]
+            with torch.no_grad():
+                pred = self._gen_forward(data_x, data_x_ext, **({} if noise is None else {"noise": noise[i]}))
+            preds.append(pred)
+            emb = self.netD.embed_x(data_x)                                   # shared by both pairs
+            f_real = self.netD.from_embedding(emb, data_t).view(-1) if is_real[i] else None
+            f_fake = self.netD.from_embedding(emb, pred).view(-1)
+            tr, tf = real_fake_terms(f_real, f_fake, self.which_loss)
+            loss_i = tf.sum() / n_fake
+            if tr is not None:
+                loss_i = loss_i + tr.sum() / n_real
+                s_real += f_real.detach().sum()
+            loss_i.backward()
+            s_loss += loss_i.detach(); s_fake += f_fake.detach().sum()
+            fakes.append(f_fake.detach())
+        self.dp.allreduce_(self.optimizerD.flat_grad)
+        self.optimizerD.step()
+        self.log({"train_batch/netD/Loss_D": s_loss, "train_batch/netD/D_real": s_real / max(n_real, 1),
+                  "train_batch/netD/D_fake": s_fake / n_fake, "i_batch": i_batch})
+        return preds, fakes
+
+    # ------------------------------------------------------------------------------------------
+    def _update_gen(self, i_batch, xs, ys, mode="wlabel", label_visible_mask=None, ys_host=None, noise=None):
+        """netD.eval(), netG.train(); gen_total = t_reg + coef * (-mean f_fake) + l1 * sum|W_G|."""
+        self.netD.eval()
+        self.netG.train()
+        n = len(xs)
+        vis = self._vis(mode, n, label_visible_mask)
+        n_vis, n_fake = self.dp.global_counts([sum(vis), n], self.device)
+
+        self.optimizerG.zero_grad()
+        z = torch.zeros((), device=self.device)
+        s_gen, s_reg, s_fake = z.clone(), z.clone(), z.clone()
+        for i in range(n):
+            data_x, data_x_ext = xs[i][0], xs[i][1]
+            data_t, data_ind = ys[i][:, [0]], ys[i][:, [1]]
+            pred = self._gen_forward(data_x, data_x_ext, **({} if noise is None else {"noise": noise[i]}))
+            with torch.no_grad():                                              # nothing of D(x) depends on G
+                feats = self.netD.x_features(self.netD.embed_x(data_x))
+            f_fake = self.netD.fuse(feats, pred).view(-1)
+            gen_i = -f_fake.sum() / n_fake
+            loss_i = self.coef_ganloss * gen_i if self.coef_ganloss != 0.0 else 0.0
+            if vis[i]:
+                reg_i = self.supervised_loss(pred, data_t, data_ind) / n_vis   # one sample: mean == the term
+                loss_i = loss_i + reg_i
+                s_reg += reg_i.detach()
+            if torch.is_tensor(loss_i):
+                loss_i.backward()
+            s_gen += gen_i.detach(); s_fake += f_fake.detach().sum()
+        self.dp.allreduce_(self.optimizerG.flat_grad)
+        total = s_reg + (self.coef_ganloss * s_gen if self.coef_ganloss != 0.0 else 0.0)
+        if self.coef_l1 > 1e-8:
+            total = total + self.coef_l1 * ops.abs_sum(self.optimizerG.flat_param)[0]
+        self.optimizerG.step()                                                 # L1 sub-gradient folded in
+        self.log({"train_batch/netG/Loss_G_fake": s_gen, "train_batch/netG/Loss_G_time": s_reg,
+                  "train_batch/netG/Loss_G_total": total, "train_batch/netG/D_fake_avg": s_fake / n_fake, "i_batch": i_batch})
+
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def test_model(modelG, modelD, backbone, loader, times_test_sample=1, checkpoints=None, test_zero_noise=False, noise=None):
+        """Eval: y_hat, f_fake, and `times_test_sample` more generator samples + their median per bag.
+        In eval mode the backbone output is identical across the samples (only the head noise differs), so the
+        bag is embedded ONCE and the head is sampled times_test_sample+1 times (reference: that many full forwards,
+        model_handler.py:624-636). `noise`: optional per-bag list of injected noise tensors (tests)."""
+        if checkpoints is not None:
+            dev = next(modelG.parameters()).device
+            modelG.load_state_dict(torch.load(checkpoints[0], map_location=dev)["model"])
+            modelD.load_state_dict(torch.load(checkpoints[1], map_location=dev)["model"])
+        modelG.eval(); modelD.eval()
+        dev = next(modelG.parameters()).device
+        res = {"idx": None, "y": None, "y_hat": None, "f_fake": None}
+        with torch.no_grad():
+            for b, (idx, x, y) in enumerate(loader):
+                x_data, x_ext = [t.to(dev) if torch.is_tensor(t) else t for t in x]
+                if backbone == "graph":
+                    H = modelG.backbone(x_ext, None)
+                elif backbone == "patch":
+                    H = modelG.backbone(x_data, None)
+                else:
+                    H = modelG.backbone(x_data, x_ext)
+                it = iter(noise[b]) if noise is not None else None
+                y_hat = modelG.head(H, test_zero_noise, None if it is None else [next(it)])
+                f_fake = modelD(x_data, y_hat)
+                res = agg_tensor(res, {"idx": idx.detach().cpu(), "y": y.detach().cpu(), "y_hat": y_hat.detach().cpu(),
+                                       "f_fake": f_fake.detach().cpu()})
+                if times_test_sample > 1:
+                    ys = torch.stack([modelG.head(H, test_zero_noise, None if it is None else [next(it)])
+                                      for _ in range(times_test_sample)])
+                    res = agg_tensor(res, {"dist_y_hat": ys.transpose(0, 1).detach().cpu()})
+                    res = agg_tensor(res, {"avg_y_hat": torch.median(ys, dim=0)[0].detach().cpu()})
+        return res
+
+    # ------------------------------------------------------------------------------------------
+    def _get_state_dict(self, epoch, model="G"):
+        net, opt = (self.netG, self.optimizerG) if model == "G" else (self.netD, self.optimizerD)
+        return {"epoch": epoch, "model": net.state_dict(), "optimizer": opt.state_dict()}
+
+    @staticmethod
+    def _prefixed(path, prefix):
+        d, f = osp.split(path)
+        return osp.join(d, prefix + "_" + f)
+
+    def save_model(self, epoch, ckpt_type="best", run_name="train"):
+        if ckpt_type not in ("best", "last"):
+            raise KeyError("Expected best or last for `ckpt_type`, but got {}.".format(ckpt_type))
+        pg = self.last_netG_ckpt_path if ckpt_type == "last" else self.best_netG_ckpt_path
+        pd = self.last_netD_ckpt_path if ckpt_type == "last" else self.best_netD_ckpt_path
+        torch.save(self._get_state_dict(epoch, "G"), self._prefixed(pg, run_name))
+        torch.save(self._get_state_dict(epoch, "D"), self._prefixed(pd, run_name))
+
+    def resume_model(self, ckpt_type="best", run_name="train"):
+        if ckpt_type not in ("best", "last"):
+            raise KeyError("Expected best or last for `ckpt_type`, but got {}.".format(ckpt_type))
+        pg = self.last_netG_ckpt_path if ckpt_type == "last" else self.best_netG_ckpt_path
+        pd = self.last_netD_ckpt_path if ckpt_type == "last" else self.best_netD_ckpt_path
+        g = torch.load(self._prefixed(pg, run_name), map_location=self.device)
+        d = torch.load(self._prefixed(pd, run_name), map_location=self.device)
+        self.netG.load_state_dict(g["model"]); self.optimizerG.load_state_dict(g["optimizer"])
+        self.netD.load_state_dict(d["model"]); self.optimizerD.load_state_dict(d["optimizer"])
+
+    # ---- orchestration around the step is the reference's own (dataset / evaluator / wandb): INTEGRATION.md
+    def exec(self):
+        raise NotImplementedError("dataset / evaluator orchestration is out of scope here; see INTEGRATION.md for "
+                                  "binding this class under the reference's main.py")
+
+    exec_test = exec_semi_sl = exec

@@ -1,0 +1,111 @@
+"""model/model_utils.py of the reference: init_weights (12-17), get_hop_dims / make_noise_mlp_layer (106-133),
+make_efficient_mlp_layer (157-166), make_mlp_layer (168-176), make_embedding_y_layer (178-186),
+EmbedXLayer (188-210). Same names, arguments and state_dict keys."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..utils.func import dropout_small
+from .backbone_utils import GAPool, make_embedding_layer, _rng_of
+
+
+@torch.no_grad()
+def init_weights(m):
+    if isinstance(m, nn.Linear):
+        nn.init.xavier_uniform_(m.weight)
+        if m.bias is not None:
+            m.bias.data.zero_()
+
+
+def get_hop_dims(d, hops):
+    dims, cur = [], d
+    for _ in range(hops):
+        cur //= 2
+        if cur <= 1:
+            break
+        dims.append(cur)
+    return dims
+
+
+def make_mlp_layer(dim_in, dim_out, layer_norm=True, dropout=0.25):
+    layers = [nn.Linear(dim_in, dim_out), nn.ReLU(inplace=True), nn.Dropout(dropout)]
+    if layer_norm:
+        layers.insert(1, nn.LayerNorm(dim_out))
+    return nn.Sequential(*layers)
+
+
+def make_noise_mlp_layer(in_dim: int, out_dim: int, noise, hops: int = 1, norm: bool = False, dropout: float = 0.25):
+    hid = get_hop_dims(in_dim, hops)
+    ins, outs = [in_dim] + hid, hid + [out_dim]
+    mlps = nn.ModuleList()
+    for i, (di, do) in enumerate(zip(ins, outs)):
+        di = di * 2 if noise[i] == 1 else di          # noise is concatenated at full width (GANSurv.py:33-38)
+        if i == len(outs) - 1:
+            mlps.append(nn.Sequential(nn.Linear(di, do)))
+        else:
+            mlps.append(make_mlp_layer(di, do, norm, dropout))
+    return mlps
+
+
+def make_efficient_mlp_layer(dim, layer_norm=True, dropout=0.25):
+    if layer_norm:
+        raise NotImplementedError("the reference raises NameError here (model_utils.py:165); it is only called with False")
+    return nn.Sequential(nn.Linear(dim, dim // 2), nn.ReLU(inplace=True), nn.Dropout(dropout), nn.Linear(dim // 2, dim))
+
+
+def make_embedding_y_layer(args):
+    layers, d = [], args.in_dim
+    for h in args.hid_dims:
+        layers.append(make_mlp_layer(d, h, args.norm, args.dropout))
+        d = h
+    return nn.Sequential(*layers)
+
+
+def run_mlp_small(seq, x, rng, tag):
+    """Apply a Sequential of Linear / LayerNorm / ReLU / Dropout holders to a [1, d]-sized tensor."""
+    for j, m in enumerate(seq):
+        if isinstance(m, nn.Sequential):
+            x = run_mlp_small(m, x, rng, f"{tag}.{j}")
+        elif isinstance(m, nn.Linear):
+            x = F.linear(x, m.weight, m.bias)
+        elif isinstance(m, nn.LayerNorm):
+            x = F.layer_norm(x, m.normalized_shape, m.weight, m.bias, m.eps)
+        elif isinstance(m, nn.ReLU):
+            x = F.relu(x)
+        elif isinstance(m, nn.Dropout):
+            x = dropout_small(x, m.p, seq.training, rng, f"{tag}.{j}")
+        else:
+            raise NotImplementedError(type(m))
+    return x
+
+
+class EmbedXLayer(nn.Module):
+    """[1, N, C] -> region embedding [1, N/16, C'] -> per-region MLP -> GAPool -> MLP -> [1, C']."""
+
+    def __init__(self, args):
+        super().__init__()
+        out_dim = args.out_dim
+        args.scale = 4
+        args.dw_conv = False
+        self.embedding = make_embedding_layer(args.backbone, args)
+        self.fc1 = make_efficient_mlp_layer(out_dim, False, args.dropout)
+        self.pool = GAPool(out_dim, out_dim, args.dropout)
+        self.fc2 = make_efficient_mlp_layer(out_dim, False, args.dropout)
+
+    def embed(self, x):
+        """The dropout-free, t-independent part: x -> emb_ins[1, L, C'] (shared by the real and fake pairs)."""
+        return self.embedding(x)
+
+    def from_embedding(self, emb_ins, return_instance=False):
+        rng = _rng_of(self, emb_ins)
+        tr = self.training
+        e = emb_ins[0]
+        h = ops.linear_act(e, self.fc1[0].weight, self.fc1[0].bias, "relu", self.fc1[2].p if tr else 0.0, rng, "dx_fc1")
+        fc_ins = ops.linear_act(h, self.fc1[3].weight, self.fc1[3].bias, "none").unsqueeze(0)
+        emb_bag = self.pool(fc_ins)
+        fc_bag = run_mlp_small(self.fc2, emb_bag, rng, "dx_fc2")
+        return (fc_bag, fc_ins) if return_instance else fc_bag
+
+    def forward(self, x, return_instance=False):
+        return self.from_embedding(self.embed(x), return_instance)

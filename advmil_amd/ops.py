@@ -357,3 +357,86 @@ class LNReLUMean16Fn(torch.autograd.Function):
 
 def ln_relu_mean16(y, gamma, beta, eps=1e-5):
     return LNReLUMean16Fn.apply(y, gamma, beta, eps)
+
+
+class GateScoreFn(torch.autograd.Function):
+    """Raw gated-attention scores s[N] only (the reference's Attn_Net_Gated.forward contract,
+    model/backbone_utils.py:24-29); the fused pool above is what the backbones call."""
+
+    @staticmethod
+    def forward(ctx, h, Wa, ba, Wb, bb, wc, bc, p, seed, sa, sb):
+        _chk(h, "h")
+        h = h.contiguous()
+        N, D = h.shape
+        Wab = torch.cat([Wa, Wb], dim=0).contiguous()
+        bab = torch.cat([ba, bb], dim=0).contiguous()
+        ab = gemm(h, Wab, True, True, N, 2 * D, D, bias=bab, act0=ACT_TANH, act1=ACT_SIGMOID, act_split=D)
+        wcv = wc.reshape(-1).contiguous()
+        s = gate_score(ab, wcv, bc, N, D, p, seed, sa, sb)
+        ctx.save_for_backward(h, Wab, ab, wcv)
+        ctx.cfg = (p, seed, sa, sb, N, D, wc.shape)
+        return s
+
+    @staticmethod
+    def backward(ctx, ds):
+        h, Wab, ab, wcv = ctx.saved_tensors
+        p, seed, sa, sb, N, D, wcshape = ctx.cfg
+        dG, dwc, dbc, dbias = gate_bwd(ab, ds.contiguous(), wcv, N, D, p, seed, sa, sb)
+        dh = gemm(dG, Wab, True, False, N, D, 2 * D) if ctx.needs_input_grad[0] else None
+        dWab = gemm(dG, h, False, False, 2 * D, D, N)
+        return (dh, dWab[:D], dbias[:D], dWab[D:], dbias[D:], dwc.reshape(wcshape), dbc, None, None, None, None)
+
+
+def gate_scores(h, Wa, ba, Wb, bb, wc, bc, p=0.0, rng=None, tag=""):
+    sa = sb = 0
+    seed = None
+    if p > 0.0:
+        rng = rng or default_rng(h.device)
+        sa = rng.site(tag + "att_a", tuple(h.shape), p)
+        sb = rng.site(tag + "att_b", tuple(h.shape), p)
+        seed = rng.seed
+    return GateScoreFn.apply(h, Wa, ba, Wb, bb, wc, bc, float(p), seed, sa, sb)
+
+
+def mha(qkv, nhead, p=0.0, rng=None):
+    """Self-attention core for one bag: qkv[L, 3d] (packed in-proj output) -> [L, d].
+    softmax(Q K^T / sqrt(hd)) with dropout p on the probabilities (index (h*L + i)*L + j), then P V.
+    TODO(K4): this is still batched-matmul plumbing through torch; the LDS-tiled MFMA flash kernel replaces it."""
+    L, d3 = qkv.shape
+    d = d3 // 3
+    hd = d // nhead
+    q, k, v = (t.reshape(L, nhead, hd).transpose(0, 1) for t in qkv.split(d, dim=1))
+    s = torch.matmul(q, k.transpose(-1, -2)) * (1.0 / float(hd) ** 0.5)
+    pr = torch.softmax(s, dim=-1)
+    if p > 0.0:
+        rng = rng or default_rng(qkv.device)
+        u = rng.uniform(pr.numel(), "mha_attn").reshape(pr.shape)
+        pr = pr * (u >= p).to(pr.dtype) * (1.0 / (1.0 - p))
+    return torch.matmul(pr, v).transpose(0, 1).reshape(L, d)
+
+
+class SegMeanFn(torch.autograd.Function):
+    """out[S, D] = Wn^T h with Wn[N, S] the normalised one-hot membership (per-cluster mean of DeepAttMISL,
+    model/backbone.py:112-117) -- one contraction over the bag instead of 8 boolean gathers."""
+
+    @staticmethod
+    def forward(ctx, h, wn):
+        N, D = h.shape
+        S = wn.shape[1]
+        ctx.save_for_backward(wn)
+        ctx.dims = (N, D, S)
+        return gemm(wn, h.contiguous(), False, False, S, D, N)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (wn,) = ctx.saved_tensors
+        N, D, S = ctx.dims
+        return gemm(wn, dout.contiguous(), True, False, N, D, S), None
+
+
+def segmented_mean(h, seg_id, num_segments):
+    """Mean of the rows of h[N, D] per segment id (float or int ids in [0, S)); empty segment -> zeros."""
+    S = (num_segments + 3) // 4 * 4                       # contiguous dim of the [N, S] operand must be 4-aligned
+    onehot = torch.nn.functional.one_hot(seg_id.reshape(-1).to(device=h.device, dtype=torch.long), S).to(h.dtype)
+    wn = (onehot / onehot.sum(dim=0).clamp_min(1.0)).contiguous()
+    return SegMeanFn.apply(h, wn)[:num_segments]
