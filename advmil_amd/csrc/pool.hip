@@ -39,15 +39,34 @@ __device__ __forceinline__ float4 reduce_rows(float4 v, const RowColMap& m, floa
   return s;
 }
 
-// out[c] (+)= sum_b partial[b][c]
+// out[c] = sum_b partial[b*stride + c].  16 columns x 16 row-lanes per workgroup: every lane keeps 4 independent
+// loads in flight and the 16 row-lanes are folded through LDS, so the serial depth is nblk/64 (was nblk).
 __global__ __launch_bounds__(256) void colsum_merge_kernel(const float* __restrict__ partial, int nblk, int64_t stride,
                                                            int64_t ncols, float* __restrict__ out) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ncols) return;
-  float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * stride + c];
-  out[c] = s;
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int64_t c = (int64_t)blockIdx.x * 16 + cl;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < ncols) {
+    int b = rl;
+    for (; b + 48 < nblk; b += 64) {
+      s0 += partial[(int64_t)b * stride + c];
+      s1 += partial[(int64_t)(b + 16) * stride + c];
+      s2 += partial[(int64_t)(b + 32) * stride + c];
+      s3 += partial[(int64_t)(b + 48) * stride + c];
+    }
+    for (; b < nblk; b += 16) s0 += partial[(int64_t)b * stride + c];
+  }
+  red[rl][cl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rl == 0 && c < ncols) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += red[r][cl];
+    out[c] = t;
+  }
 }
+#define MERGE_GRID(ncols) dim3((unsigned)(((ncols) + 15) / 16))
 
 // =====================================================================================
 // gate score: s[n] = sum_j (a ka)(b kb) wc[j] + bc          one wave per row
@@ -161,7 +180,7 @@ extern "C" int advmil_softmax_pool_fwd(const float* s, const float* h, int64_t l
   ADVMIL_LAUNCH_CHECK();
   hipLaunchKernelGGL(pool_partial_kernel, dim3(nblk), dim3(256), 0, stream, s, h, ldh, N, D, stats, A, partial);
   ADVMIL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_merge_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, stream, partial, nblk, D, D, pooled);
+  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(D), dim3(256), 0, stream, partial, nblk, D, D, pooled);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }
@@ -305,10 +324,11 @@ extern "C" int advmil_gate_bwd(const float* ab, const float* ds, const float* wc
   hipLaunchKernelGGL(gate_bwd_kernel, dim3(nblk), dim3(256), 0, stream, ab, ds, wc, drop_p, seed, stream_a, stream_b, N, D,
                      dG, partial);
   ADVMIL_LAUNCH_CHECK();
-  const unsigned g = (unsigned)((D + 255) / 256);
-  hipLaunchKernelGGL(colsum_merge_kernel, dim3(g), dim3(256), 0, stream, partial, nblk, stride, D, dwc);
-  hipLaunchKernelGGL(colsum_merge_kernel, dim3(2 * g), dim3(256), 0, stream, partial + D, nblk, stride, 2 * D, dbias);
-  hipLaunchKernelGGL(colsum_merge_kernel, dim3(1), dim3(256), 0, stream, partial + 3 * D, nblk, stride, (int64_t)1, dbc);
+  // dwc | dbias(a) | dbias(b) | dbc are adjacent in the partial rows: one merge launch over 3D+1 columns into a
+  // scratch row, then scattered by the three tiny copies below would cost more launches; instead merge each target.
+  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(D), dim3(256), 0, stream, partial, nblk, stride, D, dwc);
+  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(2 * D), dim3(256), 0, stream, partial + D, nblk, stride, 2 * D, dbias);
+  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(1), dim3(256), 0, stream, partial + 3 * D, nblk, stride, (int64_t)1, dbc);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }
@@ -378,7 +398,7 @@ extern "C" int advmil_act_dropout_bwd(const float* dy, const float* y, int act, 
   }
   ADVMIL_LAUNCH_CHECK();
   if (dbias) {
-    hipLaunchKernelGGL(colsum_merge_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, partial, nblk, N, N, dbias);
+    hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(N), dim3(256), 0, stream, partial, nblk, N, N, dbias);
     ADVMIL_LAUNCH_CHECK();
   }
   return ADVMIL_OK;
@@ -412,7 +432,7 @@ extern "C" int advmil_colsum(const float* x, int64_t M, int64_t N, float* out, v
     const int64_t W = (N - c0 < 1024) ? (N - c0) : 1024;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, x, M, N, c0, W, (float*)ws);
   }
-  hipLaunchKernelGGL(colsum_merge_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, (const float*)ws, nblk, N, N, out);
+  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(N), dim3(256), 0, stream, (const float*)ws, nblk, N, N, out);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }
@@ -560,9 +580,8 @@ extern "C" int advmil_ln_relu_mean16_bwd(const float* demb, const float* y, cons
   hipLaunchKernelGGL(ln_relu_mean16_bwd_kernel, dim3(L), dim3(256), 0, stream, demb, y, gamma, beta, mean, rstd, N, d, dy,
                      partial);
   ADVMIL_LAUNCH_CHECK();
-  const unsigned gb = (unsigned)((d + 255) / 256);
-  hipLaunchKernelGGL(colsum_merge_kernel, dim3(gb), dim3(256), 0, stream, partial, L, 2 * d, d, dgamma);
-  hipLaunchKernelGGL(colsum_merge_kernel, dim3(gb), dim3(256), 0, stream, partial + d, L, 2 * d, d, dbeta);
+  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial, L, 2 * d, d, dgamma);
+  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial + d, L, 2 * d, d, dbeta);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }

@@ -1,0 +1,83 @@
+"""HIP-graph capture of the G+D optimizer step for a fixed group of resident bags.
+
+The step is launch-bound when driven eagerly (hundreds of short kernels per bag), so the whole schedule --
+D forward/backward over the group, D Adam, G forward/backward, G Adam, RNG seed advance -- is captured once
+with torch.cuda.graph (hipGraph underneath) and replayed. The ctypes launches go to the capturing stream, so
+the hand-written kernels are captured exactly like torch's own. Dropout/noise stay fresh across replays because
+the kernels read the step seed from device memory and the graph itself bumps it.
+
+Under bag-parallel (world > 1) the collectives stay OUTSIDE the graphs (three segments with the two RCCL
+all-reduces between them), so capture never depends on RCCL's graph support.
+"""
+import torch
+
+
+class GraphedStep:
+    def __init__(self, handler, xs, ys, ys_host, mode="wlabel", label_visible_mask=None, warmup=2):
+        self.h = handler
+        self.xs, self.ys = xs, ys
+        self.plan = handler._plan(xs, ys, mode, label_visible_mask, ys_host)   # python ints: baked into the graph
+        self.lrs = self._lrs()
+        self.segments = []
+        self.logs = None
+        self._capture(warmup)
+
+    def _lrs(self):
+        return (self.h.optimizerG.param_groups[0]["lr"], self.h.optimizerD.param_groups[0]["lr"])
+
+    # the step, cut at the collectives
+    def _seg_disc(self):
+        self.preds, self.fakes = self.h._disc_backward(0, self.xs, self.ys, self.plan)
+
+    def _seg_mid(self):
+        self.h.optimizerD.step()
+        self.h._gen_backward(0, self.xs, self.ys, self.plan)
+
+    def _seg_end(self):
+        self.h.optimizerG.step()
+        self.h.rng.advance(1)
+
+    def _eager(self):
+        self._seg_disc()
+        self.h.dp.allreduce_(self.h.optimizerD.flat_grad)
+        self._seg_mid()
+        self.h.dp.allreduce_(self.h.optimizerG.flat_grad)
+        self._seg_end()
+
+    def _capture(self, warmup):
+        h = self.h
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):                       # warm-up off the default stream, as capture requires
+            for _ in range(warmup):
+                self._eager()
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        h.history.clear()
+        pool = torch.cuda.graph_pool_handle()
+        if h.dp.world > 1:
+            parts = (self._seg_disc, self._seg_mid, self._seg_end)
+        else:
+            parts = (lambda: (self._seg_disc(), self._seg_mid(), self._seg_end()),)
+        for fn in parts:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                fn()
+            self.segments.append(g)
+        self.logs = list(h.history)                          # device scalars rewritten by every replay
+        h.history.clear()
+
+    def replay(self):
+        if self._lrs() != self.lrs:                          # lr is a launch constant: re-capture after a scheduler step
+            self.segments, self.lrs = [], self._lrs()
+            self._capture(0)
+        segs = self.segments
+        if len(segs) == 1:
+            segs[0].replay()
+            return
+        segs[0].replay()
+        self.h.dp.allreduce_(self.h.optimizerD.flat_grad)
+        segs[1].replay()
+        self.h.dp.allreduce_(self.h.optimizerG.flat_grad)
+        segs[2].replay()

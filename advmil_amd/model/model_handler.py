@@ -178,77 +178,96 @@ class MyHandler(object):
     def _update_disc(self, i_batch, xs, ys, mode="wlabel", label_visible_mask=None, ys_host=None, noise=None):
         """netD.train(), netG.eval(); real pairs only for event bags with a visible label, fake pairs for all.
         `noise`: optional per-bag injected generator noise (tests). Returns (pred_collector, fake_collector)."""
-        self.netD.train()
-        self.netG.eval()
+        plan = self._plan(xs, ys, mode, label_visible_mask, ys_host)
+        preds, fakes = self._disc_backward(i_batch, xs, ys, plan, noise)
+        self._disc_apply()
+        return preds, fakes
+
+    def _plan(self, xs, ys, mode, label_visible_mask, ys_host):
+        """Host-side facts of a step batch: which bags feed a real pair / the supervised loss, and the GLOBAL
+        denominators of the reference's means (one tiny all-reduce under bag-parallel)."""
         n = len(xs)
         vis = self._vis(mode, n, label_visible_mask)
         if ys_host is None:
             ys_host = [y.cpu() for y in ys]             # fallback: one sync (the epoch loop passes host labels)
         is_real = [bool(float(yh[0, 1]) == 1.0) and vis[i] for i, yh in enumerate(ys_host)]
-        n_real, n_fake = self.dp.global_counts([sum(is_real), n], self.device)
+        n_real, n_fake, n_vis = self.dp.global_counts([sum(is_real), n, sum(vis)], self.device)
+        return SimpleNamespace(vis=vis, is_real=is_real, n_real=n_real, n_fake=n_fake, n_vis=n_vis)
 
+    def _disc_backward(self, i_batch, xs, ys, plan, noise=None):
+        """Capturable (no host sync, no collective): zero D grads, per-bag forward + backward of the D loss terms."""
+        self.netD.train()
+        self.netG.eval()
+        n = len(xs)
         self.optimizerD.zero_grad()
         preds, fakes = [], []
         z = torch.zeros((), device=self.device)
         s_loss, s_real, s_fake = z.clone(), z.clone(), z.clone()
         for i in range(n):
             data_x, data_x_ext = xs[i][0], xs[i][1]
-            data_t = ys[i][:, [0]]
+            data_t = ys[i][:, 0:1]
             with torch.no_grad():
                 pred = self._gen_forward(data_x, data_x_ext, **({} if noise is None else {"noise": noise[i]}))
             preds.append(pred)
             emb = self.netD.embed_x(data_x)                                   # shared by both pairs
-            f_real = self.netD.from_embedding(emb, data_t).view(-1) if is_real[i] else None
+            f_real = self.netD.from_embedding(emb, data_t).view(-1) if plan.is_real[i] else None
             f_fake = self.netD.from_embedding(emb, pred).view(-1)
             tr, tf = real_fake_terms(f_real, f_fake, self.which_loss)
-            loss_i = tf.sum() / n_fake
+            loss_i = tf.sum() / plan.n_fake
             if tr is not None:
-                loss_i = loss_i + tr.sum() / n_real
+                loss_i = loss_i + tr.sum() / plan.n_real
                 s_real += f_real.detach().sum()
             loss_i.backward()
             s_loss += loss_i.detach(); s_fake += f_fake.detach().sum()
             fakes.append(f_fake.detach())
+        self.log({"train_batch/netD/Loss_D": s_loss, "train_batch/netD/D_real": s_real / max(plan.n_real, 1),
+                  "train_batch/netD/D_fake": s_fake / plan.n_fake, "i_batch": i_batch})
+        return preds, fakes
+
+    def _disc_apply(self):
         self.dp.allreduce_(self.optimizerD.flat_grad)
         self.optimizerD.step()
-        self.log({"train_batch/netD/Loss_D": s_loss, "train_batch/netD/D_real": s_real / max(n_real, 1),
-                  "train_batch/netD/D_fake": s_fake / n_fake, "i_batch": i_batch})
-        return preds, fakes
 
     # ------------------------------------------------------------------------------------------
     def _update_gen(self, i_batch, xs, ys, mode="wlabel", label_visible_mask=None, ys_host=None, noise=None):
         """netD.eval(), netG.train(); gen_total = t_reg + coef * (-mean f_fake) + l1 * sum|W_G|."""
+        plan = self._plan(xs, ys, mode, label_visible_mask, ys_host)
+        self._gen_backward(i_batch, xs, ys, plan, noise)
+        self._gen_apply()
+
+    def _gen_backward(self, i_batch, xs, ys, plan, noise=None):
+        """Capturable: zero G grads, per-bag forward + backward of the G loss terms."""
         self.netD.eval()
         self.netG.train()
         n = len(xs)
-        vis = self._vis(mode, n, label_visible_mask)
-        n_vis, n_fake = self.dp.global_counts([sum(vis), n], self.device)
-
         self.optimizerG.zero_grad()
         z = torch.zeros((), device=self.device)
         s_gen, s_reg, s_fake = z.clone(), z.clone(), z.clone()
         for i in range(n):
             data_x, data_x_ext = xs[i][0], xs[i][1]
-            data_t, data_ind = ys[i][:, [0]], ys[i][:, [1]]
+            data_t, data_ind = ys[i][:, 0:1], ys[i][:, 1:2]
             pred = self._gen_forward(data_x, data_x_ext, **({} if noise is None else {"noise": noise[i]}))
             with torch.no_grad():                                              # nothing of D(x) depends on G
                 feats = self.netD.x_features(self.netD.embed_x(data_x))
             f_fake = self.netD.fuse(feats, pred).view(-1)
-            gen_i = -f_fake.sum() / n_fake
+            gen_i = -f_fake.sum() / plan.n_fake
             loss_i = self.coef_ganloss * gen_i if self.coef_ganloss != 0.0 else 0.0
-            if vis[i]:
-                reg_i = self.supervised_loss(pred, data_t, data_ind) / n_vis   # one sample: mean == the term
+            if plan.vis[i]:
+                reg_i = self.supervised_loss(pred, data_t, data_ind) / plan.n_vis   # one sample: mean == the term
                 loss_i = loss_i + reg_i
                 s_reg += reg_i.detach()
             if torch.is_tensor(loss_i):
                 loss_i.backward()
             s_gen += gen_i.detach(); s_fake += f_fake.detach().sum()
-        self.dp.allreduce_(self.optimizerG.flat_grad)
         total = s_reg + (self.coef_ganloss * s_gen if self.coef_ganloss != 0.0 else 0.0)
         if self.coef_l1 > 1e-8:
             total = total + self.coef_l1 * ops.abs_sum(self.optimizerG.flat_param)[0]
-        self.optimizerG.step()                                                 # L1 sub-gradient folded in
         self.log({"train_batch/netG/Loss_G_fake": s_gen, "train_batch/netG/Loss_G_time": s_reg,
-                  "train_batch/netG/Loss_G_total": total, "train_batch/netG/D_fake_avg": s_fake / n_fake, "i_batch": i_batch})
+                  "train_batch/netG/Loss_G_total": total, "train_batch/netG/D_fake_avg": s_fake / plan.n_fake, "i_batch": i_batch})
+
+    def _gen_apply(self):
+        self.dp.allreduce_(self.optimizerG.flat_grad)
+        self.optimizerG.step()                                                 # L1 sub-gradient folded in
 
     # ------------------------------------------------------------------------------------------
     @staticmethod

@@ -12,6 +12,9 @@ from . import _lib
 from ._lib import Epilogue
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+# bench.py sets this to a list to bracket every GEMM launch with HIP events on the launch stream:
+# entries are (kernel name, (M, N, K, splits), flops, start_event, stop_event)
+KERNEL_PROFILE = None
 _ACT = {None: 0, "none": 0, "relu": 1, "tanh": 2, "sigmoid": 3}
 
 
@@ -130,8 +133,16 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
     L = _lib.lib()
     wsb = L.advmil_gemm_f32_workspace_bytes(M, N, splits)
     ws = _ws(wsb, A.device) if wsb else None
+    prof = KERNEL_PROFILE
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(L.advmil_gemm_f32(1 if a_kc else 0, 1 if b_kc else 0, M, N, K, _p(A), lda, _p(B), ldb, _p(out), ldc,
                                  ctypes.byref(e), splits, _p(ws), wsb, _stream()), f"gemm_f32[{M}x{N}x{K}]")
+    if prof is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        prof.append(("gemm_f32_kernel<%d,%d>" % (bool(a_kc), bool(b_kc)), (M, N, K, splits), 2.0 * M * N * K, e0, e1))
     return out
 
 

@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""bench.py -- WSI bags/sec through the full AdvMIL G+D training step on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One "step" = one optimizer step of the hot path (`_update_disc` + `gen_updates=1` x `_update_gen`,
+reference model/model_handler.py:321-345) over `--bags` bags per GPU (default bp_every_batch = 16,
+config/cfg_nlst.yaml:71). Workload = BASELINE.json configs[1]: ABMIL generator + RLIP projection
+discriminator on synthetic 8192-patch x 1024 bags, resident in HBM before the timed region
+(>= 64 distinct bags per GPU = 2.1 GB >> the 256 MB Infinity Cache). Multi-GPU: bag-parallel, every rank
+runs its own bags, one RCCL all-reduce of each network's flat gradient arena per step (weak scaling:
+global step batch = bags x N).
+
+Prints ONE JSON line (rank 0). Extra objects:
+  roofline     : the dominant kernel (by summed device time) of the step, HIP-event bracketed per launch on the
+                 launch stream in a second, instrumented pass over the same steps; algorithmic FLOPs / duration
+                 against the fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md).
+  cpu_baseline : the oracle (pure PyTorch CPU restatement of the reference schedule, pinned against the
+                 reference to <=1e-6) timed on this box's host cores over a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--bags", type=int, default=16, help="bags per optimizer step per GPU (bp_every_batch)")
+    ap.add_argument("--patches", type=int, default=8192)
+    ap.add_argument("--mode", default="abmil", choices=["abmil", "patch", "cluster"])
+    ap.add_argument("--pool", type=int, default=64, help="distinct resident bags per GPU")
+    ap.add_argument("--eager", action="store_true", help="drive the step eagerly instead of replaying HIP graphs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-bags", type=int, default=4, help="bags in the CPU-baseline sample")
+    return ap.parse_args()
+
+
+def make_pool(torch, dev, mode, n_pool, n_patches, seed):
+    """Synthetic bags x ~ N(0,1) [1,N,1024] fp32 generated on the device + labels (t~U, e = i mod 2)."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    xs, ys, ys_host = [], [], []
+    for i in range(n_pool):
+        x = torch.randn(1, n_patches, 1024, device=dev, generator=g)
+        if mode == "cluster":
+            ext = torch.randint(0, 8, (1, n_patches), device=dev, generator=g).float()
+        else:
+            ext = torch.zeros(1, 1, device=dev)
+        t = 0.05 + 0.9 * float(torch.rand((), device=dev, generator=g))
+        y = torch.tensor([[t, float(i % 2)]], dtype=torch.float32)
+        xs.append([x, ext]); ys_host.append(y); ys.append(y.to(dev))
+    return xs, ys, ys_host
+
+
+def cpu_baseline(args, torch):
+    """Oracle train_step on a bounded sample (cpu-bags bags of the same size, shipped dropout rates as explicit masks
+    drawn inside the timed region, the way the reference draws them)."""
+    from oracle import advmil_oracle as O
+    from advmil_amd.config import default_cfg
+    from advmil_amd.model import Generator, load_backbone  # noqa: F401  (shapes only, built on CPU)
+    from types import SimpleNamespace
+    import advmil_amd.model.GANSurv as GS
+    nthreads = torch.get_num_threads()
+    kind, N, nb = args.mode, args.patches, args.cpu_bags
+    bb = load_backbone(kind, [1024, 384, 384])
+    G = Generator(384, 1, bb, SimpleNamespace(noise=[0, 1], hops=1, noise_dist="uniform"), False, 0.6, "sigmoid")
+    from advmil_amd.model.model_utils import init_weights
+    G.apply(init_weights)
+    ax = SimpleNamespace(in_dim=1024, out_dim=128, ksize=1, backbone="avgpool", dropout=0.25)
+    ay = SimpleNamespace(in_dim=1, hid_dims=[64, 128], norm=False, dropout=0.0)
+    D = GS.PrjDiscriminator(ax, ay, prj_path="x", inner_product="instance")
+    PG = {k: v.detach().clone() for k, v in G.state_dict().items()}
+    PD = {k: v.detach().clone() for k, v in D.state_dict().items()}
+    gen = torch.Generator().manual_seed(0)
+    bags = [(torch.randn(1, N, 1024, generator=gen), (torch.randint(0, 8, (N,), generator=gen).float() if kind == "cluster" else None),
+             torch.tensor([[0.3 + 0.05 * i, float(i % 2)]])) for i in range(nb)]
+    L = N // 16
+
+    def drop(shape, p):
+        return (torch.rand(shape) >= p).float() / (1 - p)
+
+    def masks_g():
+        if kind == "abmil":
+            m = {"fc": drop((N, 384), .25), "att_a": drop((N, 384), .25), "att_b": drop((N, 384), .25), "rho": drop((1, 384), .25)}
+        elif kind == "cluster":
+            m = {"fc": drop((8, 384), .25), "att_a": drop((8, 384), .25), "att_b": drop((8, 384), .25)}
+        else:
+            m = {"attn": drop((1, 8, L, L), .25), "drop1": drop((1, L, 384), .25), "ffn": drop((1, L, 384), .25),
+                 "drop2": drop((1, L, 384), .25), "pool_a": drop((1, L, 384), .25), "pool_b": drop((1, L, 384), .25)}
+        m["mlp0"] = drop((1, 192), .6)
+        return m
+
+    def masks_d():
+        return {"fc1": drop((1, L, 64), .25), "pool_a": drop((1, L, 128), .25), "pool_b": drop((1, L, 128), .25), "fc2": drop((1, 64), .25)}
+
+    cfg = O.StepConfig(kind=kind)
+
+    def one_step():
+        nd = [[torch.rand(1, 192)] for _ in range(nb)]
+        ng = [[torch.rand(1, 192)] for _ in range(nb)]
+        O.train_step(cfg, PG, PD, {}, {}, bags, nd, ng, [masks_d() for _ in range(nb)], [masks_d() for _ in range(nb)],
+                     [masks_g() for _ in range(nb)])
+
+    one_step()                                   # warm-up (allocator, thread pool)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        one_step()
+        reps += 1
+        if time.perf_counter() - t0 > 10.0 or reps >= 8:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(nb * reps / dt, 4), "unit": "bags/s", "cores": nthreads, "kind": "port",
+            "sample": f"{reps} optimizer step(s) of {nb} bags x {N} patches x 1024 fp32, {kind}+RLIP, shipped dropout rates, "
+                      f"oracle/advmil_oracle.py::train_step, torch {torch.__version__} CPU, {nthreads} threads of {os.cpu_count()} cpus"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from advmil_amd import ops, parallel
+    from advmil_amd.config import default_cfg
+    from advmil_amd.model import MyHandler
+
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
+    torch.cuda.set_device(dev)
+
+    cfg = default_cfg(bcb_mode=args.mode, bp_every_batch=args.bags, cuda_id=dev.index)
+    h = MyHandler(cfg, device=dev)
+    n_pool = max(args.pool, args.bags)
+    xs, ys, ys_host = make_pool(torch, dev, args.mode, n_pool, args.patches, seed=1234 + rank)
+    cursor = [0]
+
+    def eager_step():
+        i0 = cursor[0]
+        idx = [(i0 + j) % n_pool for j in range(args.bags)]
+        cursor[0] = (i0 + args.bags) % n_pool
+        bx, by, bh = [xs[i] for i in idx], [ys[i] for i in idx], [ys_host[i] for i in idx]
+        h._update_disc(0, bx, by, "wlabel", None, ys_host=bh)
+        h._update_gen(0, bx, by, "wlabel", None, ys_host=bh)
+        h.rng.advance(1)
+        if len(h.history) > 64:
+            h.history.clear()
+
+    # HIP graphs: one captured step per group of resident bags (the pool is cut into n_pool/bags groups)
+    graphs = []
+    if not args.eager:
+        from advmil_amd.graphed import GraphedStep
+        for g0 in range(0, n_pool - args.bags + 1, args.bags):
+            idx = list(range(g0, g0 + args.bags))
+            graphs.append(GraphedStep(h, [xs[i] for i in idx], [ys[i] for i in idx], [ys_host[i] for i in idx], warmup=1))
+
+    def graph_step():
+        g = graphs[cursor[0] % len(graphs)]
+        cursor[0] += 1
+        g.replay()
+
+    step = eager_step if args.eager else graph_step
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    logs = h.pop_logs() if args.eager else [{k: float(v) for k, v in d.items() if k != "i_batch"} for g in graphs for d in g.logs]
+    finite = all(v == v and abs(v) != float("inf") for d in logs for v in d.values())
+
+    # ---- instrumented pass: HIP events around every GEMM launch on the launch stream
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        ops.KERNEL_PROFILE = []
+        nprof = max(1, min(3, args.steps))
+        cursor[0] = 0
+        for _ in range(nprof):
+            eager_step()            # same schedule, eagerly, so each GEMM launch can be bracketed by HIP events
+        torch.cuda.synchronize()
+        agg = {}
+        for name, shape, flops, e0, e1 in ops.KERNEL_PROFILE:
+            a = agg.setdefault(name, {"ms": 0.0, "flops": 0.0, "n": 0, "shapes": {}})
+            ms = e0.elapsed_time(e1)
+            a["ms"] += ms; a["flops"] += flops; a["n"] += 1
+            sh = a["shapes"].setdefault(str(shape), [0, 0.0, flops])
+            sh[0] += 1; sh[1] += ms
+        ops.KERNEL_PROFILE = None
+        h.history.clear()
+        name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
+        achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "launches_per_step": a["n"] // nprof, "avg_launch_us": round(1e3 * a["ms"] / a["n"], 2),
+                "flops_per_launch": a["flops"] / a["n"],
+                "by_shape": {k: {"n": v[0] // nprof, "avg_us": round(1e3 * v[1] / v[0], 2),
+                                 "tflops": round(v[2] / (1e-3 * v[1] / v[0]) / 1e12, 2)} for k, v in a["shapes"].items()},
+                "other_kernels": {k: {"ms_per_step": round(v["ms"] / nprof, 3),
+                                      "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in agg.items() if k != name},
+                "gemm_ms_per_step": round(sum(v["ms"] for v in agg.values()) / nprof, 3)}
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, torch)
+
+    if rank == 0:
+        bags_total = args.bags * world * args.steps
+        out = {
+            "metric": "WSI bags/sec (full G+D step)", "value": round(bags_total / dt, 3), "unit": "bags/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.mode.upper()}+AdvMIL(RLIP prj discriminator), {args.patches}-patch x 1024 fp32 bags "
+                                   f"(BASELINE.json configs[1] shape; fp32 storage+MFMA-f32 arithmetic instead of bf16)",
+                       "bags_per_step_per_gpu": args.bags, "global_bags_per_step": args.bags * world, "gen_updates": 1,
+                       "distinct_resident_bags_per_gpu": n_pool, "parallelism": f"bag-parallel dp{world}", "dropout": "shipped rates",
+                       "launch": "eager" if args.eager else f"hipGraph replay ({len(graphs)} captured bag groups)"},
+            "gd_steps_per_sec": round(args.steps / dt, 3), "losses_finite": bool(finite),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
