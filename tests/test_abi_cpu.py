@@ -1,0 +1,88 @@
+"""CPU: the C-ABI library loads and exports every symbol include/advmil_hip.h declares (no compute calls
+without a GPU), the ctypes table covers the header, and the product path refuses CPU tensors."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "advmil_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(advmil_[a-z0-9_]+)\s*\(", txt)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    from advmil_amd import _lib
+    return _lib
+
+
+def test_header_and_ctypes_table_agree(built):
+    syms = header_symbols()
+    assert len(syms) >= 20
+    assert sorted(built.SIGNATURES) == syms
+
+
+def test_library_exports_every_declared_symbol(built):
+    handle = ctypes.CDLL(built.LIB_PATH)
+    for name in header_symbols():
+        assert hasattr(handle, name), name
+    assert built.lib().advmil_version() >= 100
+
+
+def test_workspace_queries_are_pure_host_functions(built):
+    L = built.lib()
+    assert L.advmil_gemm_f32_workspace_bytes(384, 1024, 16) == 16 * 384 * 1024 * 4
+    assert L.advmil_gemm_f32_workspace_bytes(8192, 384, 1) == 0
+    assert L.advmil_softmax_pool_workspace_bytes(8192, 384) >= (8192 // 32) * 384 * 4
+    assert L.advmil_ln_relu_mean16_bwd_workspace_bytes(8192, 128) == 512 * 256 * 4
+
+
+def test_epilogue_struct_layout_matches_c(built, tmp_path):
+    """Compile a 10-line C program against include/advmil_hip.h and compare sizeof/offsetof with the ctypes mirror."""
+    import shutil
+    import subprocess
+    fields = [n for n, _ in built.Epilogue._fields_]
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    src = tmp_path / "layout.c"
+    body = "".join(f'printf("%zu\\n", offsetof(advmil_epilogue_t, {f}));' for f in fields)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "advmil_hip.h"\n'
+                   f'int main(void){{printf("%zu\\n", sizeof(advmil_epilogue_t));{body}return 0;}}\n')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out[0] == ctypes.sizeof(built.Epilogue)
+    assert out[1:] == [getattr(built.Epilogue, f).offset for f in fields]
+
+
+def test_product_path_has_no_cpu_fallback(built):
+    from advmil_amd import ops
+    from advmil_amd.model import load_backbone
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.gemm(torch.zeros(8, 8), torch.zeros(8, 8), True, True, 8, 8, 8)
+    net = load_backbone("abmil", [1024, 384, 384])
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 16, 1024), None)
+
+
+def test_missing_library_fails_loudly(built, monkeypatch):
+    monkeypatch.setattr(built, "_lib", None)
+    monkeypatch.setattr(built, "LIB_PATH", "/nonexistent/libadvmil_hip.so")
+    with pytest.raises(built.HipLibraryMissing):
+        built.lib()
+
+
+def test_product_never_imports_the_oracle():
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|__import__\(\s*[\"']oracle|importlib.*oracle", re.M)
+    for d, _, files in os.walk(os.path.join(ROOT, "advmil_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                assert not pat.search(open(os.path.join(d, f)).read()), os.path.join(d, f)

@@ -1,0 +1,77 @@
+"""CPU: host-side logic of the path that needs no GPU -- config slicing helpers, synthetic-data determinism,
+the counter RNG restatement, module construction / state_dict surface, split heuristic."""
+import numpy as np
+import torch
+
+from advmil_amd import synth
+from advmil_amd.config import default_cfg
+from advmil_amd.utils.func import agg_tensor, collect_tensor, sparse_key, sparse_str
+from tests import helpers as H
+
+
+def test_sparse_helpers_match_reference_semantics():
+    cfg = default_cfg()
+    assert sparse_str(cfg["bcb_dims"]) == [1024, 384, 384]
+    assert sparse_str(0.5) == [0.5]
+    k = sparse_key(cfg, prefixes="disc_netx")
+    assert k == {"in_dim": 1024, "out_dim": 128, "ksize": 1, "backbone": "avgpool", "dropout": 0.25}
+    assert sparse_key(cfg, "loss_recon") == {"norm": "l1", "alpha": 0.0, "gamma": 0.0}
+    assert sparse_key(cfg, "gen_noi") == {"noise": "0-1", "noise_dist": "uniform", "hops": 1}
+
+
+def test_collectors():
+    c = {"real": None, "fake": None}
+    c = collect_tensor(c, None, torch.ones(2))
+    c = collect_tensor(c, torch.zeros(1), torch.ones(1))
+    assert c["real"].shape == (1,) and c["fake"].shape == (3,)
+    a = agg_tensor({"y": None}, {"y": torch.ones(2, 2)})
+    a = agg_tensor(a, {"y": torch.ones(1, 2)})
+    assert a["y"].shape == (3, 2)
+
+
+def test_synth_is_deterministic_and_well_distributed():
+    a = synth.bag(0, 3, 512)
+    b = synth.bag(0, 3, 512)
+    assert np.array_equal(a, b) and a.shape == (1, 512, 1024) and a.dtype == np.float32
+    assert abs(a.mean()) < 0.01 and abs(a.std() - 1.0) < 0.01
+    assert not np.array_equal(a, synth.bag(0, 4, 512))
+    y = synth.label(0, 5)
+    assert y.shape == (1, 2) and y[0, 1] == 1.0 and 0.05 <= y[0, 0] <= 0.95
+    u = synth.device_uniform(7, 3, 100000)
+    assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.01
+    keep = synth.dropout_keep(7, 3, 100000, 0.25)
+    assert abs(keep.mean() - 0.75) < 0.01
+    # known-answer: splitmix64(0) (the published first output of the generator seeded with 0)
+    assert int(synth.splitmix64(np.uint64(0))) == 0xE220A8397B1DCDAF
+
+
+def test_grid_graph_shape():
+    e = synth.grid_knn_graph(100, 8)
+    assert e.shape == (2, 800) and e.min() >= 0 and e.max() < 100
+    assert np.array_equal(e[0], np.repeat(np.arange(100), 8))
+
+
+def test_state_dict_surface_on_cpu():
+    from types import SimpleNamespace
+    from advmil_amd.model import Generator, PrjDiscriminator, Discriminator, load_backbone
+    for kind in ("abmil", "patch", "cluster"):
+        g = Generator(384, 1, load_backbone(kind, [1024, 384, 384]), SimpleNamespace(noise=[0, 1], hops=1, noise_dist=None),
+                      False, 0.6, "sigmoid")
+        want = H.shapes_generator(kind)
+        got = {k: tuple(v.shape) for k, v in g.state_dict().items()}
+        assert got == want, kind
+    ax = SimpleNamespace(in_dim=1024, out_dim=128, ksize=1, backbone="avgpool", dropout=0.25)
+    ay = SimpleNamespace(in_dim=1, hid_dims=[64, 128], norm=False, dropout=0.0)
+    assert {k: tuple(v.shape) for k, v in PrjDiscriminator(ax, ay, "x", "instance").state_dict().items()} == H.shapes_disc("prj", "x")
+    assert {k: tuple(v.shape) for k, v in Discriminator(ax, ay).state_dict().items()} == H.shapes_disc("cat", None)
+    # parameter counts probed from the reference
+    n = lambda sh: sum(int(np.prod(s)) for s in sh.values())
+    assert n(H.shapes_generator("abmil")) == 911810 and n(H.shapes_generator("patch")) == 1653314
+    assert n(H.shapes_disc("prj", "x")) == 206338
+
+
+def test_auto_splits_heuristic():
+    from advmil_amd.ops import auto_splits
+    assert auto_splits(8192, 384, 1024) == 1            # 192 tiles: enough parallelism
+    assert auto_splits(384, 1024, 8192) > 1             # dW: 24 tiles, the bag length is K
+    assert auto_splits(8, 384, 64) == 1

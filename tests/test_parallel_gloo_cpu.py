@@ -1,0 +1,88 @@
+"""CPU, world_size 2 over gloo: the bag-parallel exchange layer (advmil_amd/parallel.py) is world-size invariant.
+Compute here is the oracle (tests may use it); the exchange, partition, global-denominator and gather logic is the
+product's. The 2-rank run must reproduce the 1-rank oracle step: same losses, same summed gradients."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from advmil_amd import parallel
+    from oracle import advmil_oracle as O
+    from tests import helpers as H
+    parallel.init_from_env(backend="gloo")
+    dp = parallel.BagParallel()
+    assert dp.world == world and dp.rank == rank
+    kind, nb, N = "abmil", 4, 64
+    PG = H.synth_params(H.shapes_generator(kind), f"G-{kind}:")
+    PD = H.synth_params(H.shapes_disc(), "D-prj:")
+    bags = [(H.bag(i, N), None, H.label(i)) for i in range(nb)]
+    nd = [[H.noise_tensor("dp_d", i, 192)] for i in range(nb)]
+    ng = [[H.noise_tensor("dp_g", i, 192)] for i in range(nb)]
+    cfg = O.StepConfig(kind=kind)
+    mine = [i for i in range(nb) if dp.owns(i)]
+    assert dp.shard(list(range(nb))) == mine and [dp.global_index(j) for j in range(len(mine))] == mine
+    lb, lnd, lng = [bags[i] for i in mine], [nd[i] for i in mine], [ng[i] for i in mine]
+    n_real_l = sum(int(b[2][0, 1] == 1) for b in lb)
+    n_real, n_fake = dp.global_counts([n_real_l, len(lb)])
+    assert (n_real, n_fake) == (2, 4)
+    # ---- D phase on the shard with global denominators, then ONE all-reduce of the flat grad arena
+    logs_d, gD, preds, fakes = O.update_disc(cfg, PG, PD, lb, lnd, n_real_global=n_real, n_fake_global=n_fake)
+    keys = sorted(PD)
+    flat = torch.cat([gD.get(k, torch.zeros_like(PD[k])).reshape(-1) for k in keys])
+    dp.allreduce_(flat)
+    loss = torch.tensor([logs_d["Loss_D"]], dtype=torch.float64)
+    dist.all_reduce(loss)
+    # ---- G phase
+    logs_g, gG, _ = O.update_gen(cfg, PG, PD, lb, lng, n_global=n_fake)
+    keysg = sorted(PG)
+    flatg = torch.cat([gG[k].reshape(-1) for k in keysg])
+    dp.allreduce_(flatg)
+    yh = dp.allgather_cat(torch.cat(preds))            # epoch collector in global bag order
+    if rank == 0:
+        q.put({"flat_d": flat.numpy().copy(), "flat_g": flatg.numpy().copy(), "loss_d": float(loss), "y_hat": yh.numpy().copy()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_step_equals_single_rank():
+    sys.path.insert(0, ROOT)
+    from oracle import advmil_oracle as O
+    from tests import helpers as H
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    got = {k: (torch.from_numpy(v) if not isinstance(v, float) else v) for k, v in got.items()}
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    kind, nb, N = "abmil", 4, 64
+    PG = H.synth_params(H.shapes_generator(kind), f"G-{kind}:")
+    PD = H.synth_params(H.shapes_disc(), "D-prj:")
+    bags = [(H.bag(i, N), None, H.label(i)) for i in range(nb)]
+    nd = [[H.noise_tensor("dp_d", i, 192)] for i in range(nb)]
+    ng = [[H.noise_tensor("dp_g", i, 192)] for i in range(nb)]
+    cfg = O.StepConfig(kind=kind)
+    logs_d, gD, preds, _ = O.update_disc(cfg, PG, PD, bags, nd)
+    flat = torch.cat([gD.get(k, torch.zeros_like(PD[k])).reshape(-1) for k in sorted(PD)])
+    cfg_nol1 = O.StepConfig(kind=kind, l1_coef=0.0)     # the shard backward leaves L1 to the optimizer kernel
+    _, gG, _ = O.update_gen(cfg_nol1, PG, PD, bags, ng)
+    flatg = torch.cat([gG[k].reshape(-1) for k in sorted(PG)])
+    assert abs(got["loss_d"] - logs_d["Loss_D"]) < 1e-6
+    assert float((got["flat_d"] - flat).abs().max()) < 1e-6 * (1 + float(flat.abs().max()))
+    assert float((got["flat_g"] - flatg).abs().max()) < 1e-6 * (1 + float(flatg.abs().max()))
+    assert float((got["y_hat"].reshape(-1) - torch.cat(preds).reshape(-1)).abs().max()) < 1e-6
