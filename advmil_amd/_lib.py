@@ -33,6 +33,9 @@ SIGNATURES = {
     "advmil_gemm_f32_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "advmil_gemm_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                                 c_int64, ctypes.POINTER(Epilogue), c_int, c_void_p, c_size_t, c_void_p]),
+    "advmil_gemm_f32_plan": (c_int, [c_int64, c_int64, c_int64, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "advmil_gemm_f32_tiled": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                                      c_int64, ctypes.POINTER(Epilogue), c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "advmil_gate_score_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_uint64, c_uint64, c_int64, c_int64,
                                       c_void_p, c_void_p]),
     "advmil_softmax_pool_workspace_bytes": (c_size_t, [c_int64, c_int64]),
@@ -42,16 +45,16 @@ SIGNATURES = {
                                         c_size_t, c_void_p]),
     "advmil_gate_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "advmil_gate_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_uint64, c_uint64, c_int64, c_int64,
-                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "advmil_colsum_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "advmil_act_dropout_bwd": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_uint64, c_int64, c_int64, c_void_p,
-                                       c_void_p, c_void_p, c_size_t, c_void_p]),
-    "advmil_colsum": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                       c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "advmil_colsum": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "advmil_ln_relu_mean16_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int64, c_void_p, c_void_p,
                                           c_void_p, c_void_p]),
     "advmil_ln_relu_mean16_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "advmil_ln_relu_mean16_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
-                                          c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                          c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "advmil_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                                  c_float, c_float, c_float, c_void_p, c_void_p]),
     "advmil_abs_sum": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -15,11 +15,8 @@
 #include "common.h"
 #include "../../include/advmil_hip.h"
 
-#define BM 128
-#define BN 128
 #define BK 32
 #define PITCH_KC 36
-#define PITCH_MC 128
 
 struct GemmArgs {
   int64_t M, N, K;
@@ -44,65 +41,55 @@ __device__ __forceinline__ float epilogue_elem(const advmil_epilogue_t& e, float
   return v;
 }
 
-template <bool KC>
+// ROWS = 64*T rows (m or n) x 32 k per tile; P = ROWS/32 float4 per thread.
+template <bool KC, int ROWS>
 __device__ __forceinline__ void load_tile(const float* __restrict__ src, int64_t ld, int64_t row0, int64_t rows,
-                                          int64_t k0, int64_t kend, int tid, float4 (&r)[4]) {
-  if (KC) {
-    // 128 rows x 32 k; thread -> (row = p*32 + tid/8, k = (tid%8)*4)
-    const int kq = (tid & 7) * 4;
+                                          int64_t k0, int64_t kend, int tid, float4 (&r)[ROWS / 32]) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int64_t row = row0 + p * 32 + (tid >> 3);
-      const int64_t k = k0 + kq;
-      if (row < rows && k < kend)
-        r[p] = *reinterpret_cast<const float4*>(src + row * ld + k);
-      else
-        r[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  } else {
-    // 32 k x 128 rows(m); thread -> (k = p*8 + tid/32, m = (tid%32)*4)
-    const int mq = (tid & 31) * 4;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int64_t k = k0 + p * 8 + (tid >> 5);
-      const int64_t m = row0 + mq;
-      if (k < kend && m < rows)
-        r[p] = *reinterpret_cast<const float4*>(src + k * ld + m);
-      else
-        r[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p = 0; p < ROWS / 32; ++p) {
+    const int e = p * 256 + tid;
+    if (KC) {   // [row][k]: 8 float4 per row
+      const int64_t row = row0 + (e >> 3);
+      const int64_t k = k0 + (e & 7) * 4;
+      r[p] = (row < rows && k < kend) ? *reinterpret_cast<const float4*>(src + row * ld + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {    // [k][m]: ROWS/4 float4 per k
+      const int64_t k = k0 + e / (ROWS / 4);
+      const int64_t m = row0 + (e % (ROWS / 4)) * 4;
+      r[p] = (k < kend && m < rows) ? *reinterpret_cast<const float4*>(src + k * ld + m) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
 }
 
-template <bool KC>
-__device__ __forceinline__ void store_tile(float* __restrict__ s, int tid, const float4 (&r)[4]) {
-  if (KC) {
-    const int kq = (tid & 7) * 4;
+template <bool KC, int ROWS>
+__device__ __forceinline__ void store_tile(float* __restrict__ s, int tid, const float4 (&r)[ROWS / 32]) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) *reinterpret_cast<float4*>(s + (p * 32 + (tid >> 3)) * PITCH_KC + kq) = r[p];
-  } else {
-    const int mq = (tid & 31) * 4;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) *reinterpret_cast<float4*>(s + (p * 8 + (tid >> 5)) * PITCH_MC + mq) = r[p];
+  for (int p = 0; p < ROWS / 32; ++p) {
+    const int e = p * 256 + tid;
+    if (KC)
+      *reinterpret_cast<float4*>(s + (e >> 3) * PITCH_KC + (e & 7) * 4) = r[p];
+    else
+      *reinterpret_cast<float4*>(s + (e / (ROWS / 4)) * ROWS + (e % (ROWS / 4)) * 4) = r[p];
   }
 }
 
-// fragment for the 32-row block starting at `rbase` (0..127), k-group t4: f[u], u = 0..3
-template <bool KC>
+// fragment for the 32-row block starting at `rbase`, k-group t4: f[u], u = 0..3
+template <bool KC, int ROWS>
 __device__ __forceinline__ void read_frag(const float* __restrict__ s, int rbase, int t4, int i, int hi, float (&f)[4]) {
   if (KC) {
     const float4 v = *reinterpret_cast<const float4*>(s + (rbase + i) * PITCH_KC + t4 * 8 + hi * 4);
     f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
   } else {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) f[u] = s[(t4 * 8 + hi * 4 + u) * PITCH_MC + rbase + i];
+    for (int u = 0; u < 4; ++u) f[u] = s[(t4 * 8 + hi * 4 + u) * ROWS + rbase + i];
   }
 }
 
-template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float sA[BM * PITCH_KC];
-  __shared__ __attribute__((aligned(16))) float sB[BN * PITCH_KC];
+template <bool A_KC, bool B_KC, int TM, int TN>
+__global__ __launch_bounds__(256, (TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(GemmArgs g) {
+  constexpr int BM_ = 64 * TM, BN_ = 64 * TN;
+  __shared__ __attribute__((aligned(16))) float smem[(BM_ + BN_) * PITCH_KC];
+  float* const sA = smem;
+  float* const sB = smem + BM_ * PITCH_KC;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -111,51 +98,53 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 
   const int bid = blockIdx.x;
   const int mt_i = bid % g.mtiles, nt_i = bid / g.mtiles;
-  const int64_t m0 = (int64_t)mt_i * BM, n0 = (int64_t)nt_i * BN;
+  const int64_t m0 = (int64_t)mt_i * BM_, n0 = (int64_t)nt_i * BN_;
   const int z = blockIdx.y;
   const int64_t kbeg = (int64_t)z * g.k_chunk;
   const int64_t kend = (kbeg + g.k_chunk < g.K) ? kbeg + g.k_chunk : g.K;
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-  float4 ra[4], rb[4];
+  float4 ra[BM_ / 32], rb[BN_ / 32];
   if (kbeg < kend) {
-    load_tile<A_KC>(g.A, g.lda, m0, g.M, kbeg, kend, tid, ra);
-    load_tile<B_KC>(g.B, g.ldb, n0, g.N, kbeg, kend, tid, rb);
+    load_tile<A_KC, BM_>(g.A, g.lda, m0, g.M, kbeg, kend, tid, ra);
+    load_tile<B_KC, BN_>(g.B, g.ldb, n0, g.N, kbeg, kend, tid, rb);
   }
   for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
     __syncthreads();  // all waves finished reading the previous chunk
-    store_tile<A_KC>(sA, tid, ra);
-    store_tile<B_KC>(sB, tid, rb);
+    store_tile<A_KC, BM_>(sA, tid, ra);
+    store_tile<B_KC, BN_>(sB, tid, rb);
     __syncthreads();
     if (k0 + BK < kend) {  // prefetch next chunk; lands while the MFMAs below run
-      load_tile<A_KC>(g.A, g.lda, m0, g.M, k0 + BK, kend, tid, ra);
-      load_tile<B_KC>(g.B, g.ldb, n0, g.N, k0 + BK, kend, tid, rb);
+      load_tile<A_KC, BM_>(g.A, g.lda, m0, g.M, k0 + BK, kend, tid, ra);
+      load_tile<B_KC, BN_>(g.B, g.ldb, n0, g.N, k0 + BK, kend, tid, rb);
     }
 #pragma unroll
     for (int t4 = 0; t4 < 4; ++t4) {
-      float fa[2][4], fb[2][4];
-      read_frag<A_KC>(sA, wr * 64, t4, i, hi, fa[0]);
-      read_frag<A_KC>(sA, wr * 64 + 32, t4, i, hi, fa[1]);
-      read_frag<B_KC>(sB, wc * 64, t4, i, hi, fb[0]);
-      read_frag<B_KC>(sB, wc * 64 + 32, t4, i, hi, fb[1]);
+      float fa[TM][4], fb[TN][4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][u], fb[0][u], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][u], fb[1][u], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][u], fb[0][u], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][u], fb[1][u], acc[1][1], 0, 0, 0);
-      }
+      for (int a = 0; a < TM; ++a) read_frag<A_KC, BM_>(sA, wr * 32 * TM + a * 32, t4, i, hi, fa[a]);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) read_frag<B_KC, BN_>(sB, wc * 32 * TN + b * 32, t4, i, hi, fb[b]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][u], fb[b][u], acc[a][b], 0, 0, 0);
     }
   }
 
-  // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // ---- epilogue. MFMA C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5). Each 32x32 accumulator
+  // tile goes through a per-wave LDS patch ([32][36] floats, carved from the operand buffers) so that the math
+  // below runs once per float4 in a compact loop and the global stores are 16 B per lane along the row.
   const advmil_epilogue_t& e = g.epi;
   const bool direct = (g.splits == 1);
   uint64_t key = 0;
@@ -164,26 +153,46 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     key = rng_key(*e.seed, e.stream_id);
     inv_keep = 1.0f / (1.0f - e.drop_p);
   }
-  float* ws = direct ? nullptr : g.ws + (int64_t)z * g.M * g.N;
+  float* const out = direct ? g.C : g.ws + (int64_t)z * g.M * g.N;
+  const int64_t ldo = direct ? g.ldc : g.N;
+  const bool vec_ok = ((ldo & 3) == 0) && (((uintptr_t)out & 15) == 0);
+  float* const patch = smem + wave * (32 * PITCH_KC);
+  __syncthreads();   // every wave is done reading the operand tiles
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
+  for (int a = 0; a < TM; ++a) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int64_t col = n0 + wc * 64 + b * 32 + i;
-      if (col >= g.N) continue;
+    for (int b = 0; b < TN; ++b) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (row >= g.M) continue;
-        if (direct) {
-          float v = epilogue_elem(e, acc[a][b][r], row, col, g.N, key, inv_keep);
-          float* c = g.C + row * g.ldc + col;
-          if (e.accumulate) v += *c;
-          *c = v;
-        } else {
-          ws[row * g.N + col] = acc[a][b][r];
+      for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * PITCH_KC + i] = acc[a][b][r];
+      __syncthreads();
+      const int64_t rbase = m0 + wr * 32 * TM + a * 32;
+      const int64_t cbase = n0 + wc * 32 * TN + b * 32;
+#pragma unroll 1
+      for (int q = 0; q < 4; ++q) {
+        const int idx = q * 64 + lane;
+        const int pr = idx >> 3, pc = (idx & 7) * 4;
+        const int64_t row = rbase + pr, col = cbase + pc;
+        const float4 v4 = *reinterpret_cast<const float4*>(patch + pr * PITCH_KC + pc);
+        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        if (row < g.M && col < g.N) {
+          const int nvalid = (g.N - col >= 4) ? 4 : (int)(g.N - col);
+          float* c = out + row * ldo + col;
+          if (direct) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              if (t < nvalid) {
+                v[t] = epilogue_elem(e, v[t], row, col + t, g.N, key, inv_keep);
+                if (e.accumulate) v[t] += c[t];
+              }
+          }
+          if (nvalid == 4 && vec_ok) {
+            *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            for (int t = 0; t < nvalid; ++t) c[t] = v[t];
+          }
         }
       }
+      __syncthreads();
     }
   }
 }
@@ -221,9 +230,56 @@ extern "C" size_t advmil_gemm_f32_workspace_bytes(int64_t M, int64_t N, int spli
   return splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
 
-extern "C" int advmil_gemm_f32(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
-                               const float* B, int64_t ldb, float* C, int64_t ldc, const advmil_epilogue_t* epi,
-                               int splits, void* ws, size_t ws_bytes, advmil_stream_t stream_) {
+template <int TM, int TN>
+static void launch_tile(int a_kc, int b_kc, dim3 grid, hipStream_t stream, const GemmArgs& g) {
+  dim3 block(256);
+  if (a_kc && b_kc)
+    hipLaunchKernelGGL((gemm_f32_kernel<true, true, TM, TN>), grid, block, 0, stream, g);
+  else if (a_kc && !b_kc)
+    hipLaunchKernelGGL((gemm_f32_kernel<true, false, TM, TN>), grid, block, 0, stream, g);
+  else if (!a_kc && !b_kc)
+    hipLaunchKernelGGL((gemm_f32_kernel<false, false, TM, TN>), grid, block, 0, stream, g);
+  else
+    hipLaunchKernelGGL((gemm_f32_kernel<false, true, TM, TN>), grid, block, 0, stream, g);
+}
+
+// tile = 10*TM + TN  (22: 128x128, 23: 128x192, 13: 64x192, 12: 64x128, 11: 64x64).
+static int64_t n_tiles(int tile, int64_t M, int64_t N) {
+  const int tm = tile / 10, tn = tile % 10;
+  return ((M + 64 * tm - 1) / (64 * tm)) * ((N + 64 * tn - 1) / (64 * tn));
+}
+
+// Launch plan, from the tools/gemm_sweep.py measurements on MI355X (256 CUs): a 4-wave workgroup alone on a CU leaves
+// MFMA bubbles at every barrier, two or more co-resident workgroups fill them, so take the LARGEST tile that still
+// yields >= 512 workgroups (8k-row bags -> 64x64 / 64x128 tiles at ~95-103 TF; 32k-row bags -> 128x192 at ~122 TF).
+// If even 64x64 tiles are too few and K is deep (the dW = dY^T X contractions, K = bag length), split K so that
+// ~768 workgroups each keep >= 1024 of K (partials reduced by a second launch).
+extern "C" int advmil_gemm_f32_plan(int64_t M, int64_t N, int64_t K, int* tile, int* splits) {
+  static const int order[5] = {23, 22, 13, 12, 11};
+  for (int c = 0; c < 5; ++c)
+    if (n_tiles(order[c], M, N) >= 512) { *tile = order[c]; *splits = 1; return ADVMIL_OK; }
+  const int64_t w11 = n_tiles(11, M, N);
+  if (K >= 2048 && w11 < 384 && (N & 3) == 0) {
+    static const int sorder[3] = {22, 12, 11};
+    for (int c = 0; c < 3; ++c) {
+      const int64_t w = n_tiles(sorder[c], M, N);
+      const int64_t sp = (768 + w - 1) / w;
+      if (K / sp >= 1024) { *tile = sorder[c]; *splits = (int)sp; return ADVMIL_OK; }
+    }
+    int64_t sp = (768 + w11 - 1) / w11;
+    const int64_t cap = K / 256 > 0 ? K / 256 : 1;
+    if (sp > cap) sp = cap;
+    if (sp > 16) sp = 16;
+    *tile = 11; *splits = (int)sp;
+    return ADVMIL_OK;
+  }
+  *tile = 11; *splits = 1;
+  return ADVMIL_OK;
+}
+
+extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                                     const float* B, int64_t ldb, float* C, int64_t ldc, const advmil_epilogue_t* epi,
+                                     int splits, int tile, void* ws, size_t ws_bytes, advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!A || !B || !C || !epi || M <= 0 || N <= 0 || K <= 0) return ADVMIL_EINVAL;
   if ((lda & 3) || (ldb & 3)) return ADVMIL_EINVAL;
@@ -245,24 +301,32 @@ extern "C" int advmil_gemm_f32(int a_kc, int b_kc, int64_t M, int64_t N, int64_t
     if (!ws || ws_bytes < advmil_gemm_f32_workspace_bytes(M, N, splits)) return ADVMIL_EWORKSPACE;
     if ((uintptr_t)ws & 15) return ADVMIL_EINVAL;
   }
-  g.mtiles = (int)((M + BM - 1) / BM);
-  const int ntiles = (int)((N + BN - 1) / BN);
-  dim3 grid(g.mtiles * ntiles, splits), block(256);
-  if (a_kc && b_kc)
-    hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, stream, g);
-  else if (a_kc && !b_kc)
-    hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, stream, g);
-  else if (!a_kc && !b_kc)
-    hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, stream, g);
-  else
-    hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, stream, g);
+  if (tile == 0) { int t = 0, sp = 0; advmil_gemm_f32_plan(M, N, K, &t, &sp); tile = t; }
+  const int tm = tile / 10, tn = tile % 10;
+  g.mtiles = (int)((M + 64 * tm - 1) / (64 * tm));
+  const int ntiles = (int)((N + 64 * tn - 1) / (64 * tn));
+  dim3 grid(g.mtiles * ntiles, splits);
+  switch (tile) {
+    case 23: launch_tile<2, 3>(a_kc, b_kc, grid, stream, g); break;
+    case 22: launch_tile<2, 2>(a_kc, b_kc, grid, stream, g); break;
+    case 13: launch_tile<1, 3>(a_kc, b_kc, grid, stream, g); break;
+    case 12: launch_tile<1, 2>(a_kc, b_kc, grid, stream, g); break;
+    case 11: launch_tile<1, 1>(a_kc, b_kc, grid, stream, g); break;
+    default: return ADVMIL_EINVAL;
+  }
   ADVMIL_LAUNCH_CHECK();
   if (splits > 1) {
     const int64_t total = M * (N / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), block, 0, stream, g);
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, g);
     ADVMIL_LAUNCH_CHECK();
   }
   return ADVMIL_OK;
+}
+
+extern "C" int advmil_gemm_f32(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                               const float* B, int64_t ldb, float* C, int64_t ldc, const advmil_epilogue_t* epi,
+                               int splits, void* ws, size_t ws_bytes, advmil_stream_t stream) {
+  return advmil_gemm_f32_tiled(a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, epi, splits, 0, ws, ws_bytes, stream);
 }

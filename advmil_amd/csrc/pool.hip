@@ -42,7 +42,7 @@ __device__ __forceinline__ float4 reduce_rows(float4 v, const RowColMap& m, floa
 // out[c] = sum_b partial[b*stride + c].  16 columns x 16 row-lanes per workgroup: every lane keeps 4 independent
 // loads in flight and the 16 row-lanes are folded through LDS, so the serial depth is nblk/64 (was nblk).
 __global__ __launch_bounds__(256) void colsum_merge_kernel(const float* __restrict__ partial, int nblk, int64_t stride,
-                                                           int64_t ncols, float* __restrict__ out) {
+                                                           int64_t ncols, float* __restrict__ out, int accumulate) {
   __shared__ float red[16][17];
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int64_t c = (int64_t)blockIdx.x * 16 + cl;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void colsum_merge_kernel(const float* __restri
     float t = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) t += red[r][cl];
-    out[c] = t;
+    out[c] = accumulate ? out[c] + t : t;
   }
 }
 #define MERGE_GRID(ncols) dim3((unsigned)(((ncols) + 15) / 16))
@@ -180,7 +180,7 @@ extern "C" int advmil_softmax_pool_fwd(const float* s, const float* h, int64_t l
   ADVMIL_LAUNCH_CHECK();
   hipLaunchKernelGGL(pool_partial_kernel, dim3(nblk), dim3(256), 0, stream, s, h, ldh, N, D, stats, A, partial);
   ADVMIL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(D), dim3(256), 0, stream, partial, nblk, D, D, pooled);
+  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(D), dim3(256), 0, stream, partial, nblk, D, D, pooled, 0);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }
@@ -313,7 +313,7 @@ extern "C" size_t advmil_gate_bwd_workspace_bytes(int64_t N, int64_t D) {
 
 extern "C" int advmil_gate_bwd(const float* ab, const float* ds, const float* wc, float drop_p, const uint64_t* seed,
                                uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D, float* dG, float* dwc,
-                               float* dbc, float* dbias, void* ws, size_t ws_bytes, advmil_stream_t stream_) {
+                               float* dbc, float* dbias, int accumulate, void* ws, size_t ws_bytes, advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!ab || !ds || !wc || !dG || !dwc || !dbc || !dbias || !ws || N <= 0 || D <= 0 || (D & 3) || D > 1024)
     return ADVMIL_EINVAL;
@@ -326,9 +326,9 @@ extern "C" int advmil_gate_bwd(const float* ab, const float* ds, const float* wc
   ADVMIL_LAUNCH_CHECK();
   // dwc | dbias(a) | dbias(b) | dbc are adjacent in the partial rows: one merge launch over 3D+1 columns into a
   // scratch row, then scattered by the three tiny copies below would cost more launches; instead merge each target.
-  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(D), dim3(256), 0, stream, partial, nblk, stride, D, dwc);
-  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(2 * D), dim3(256), 0, stream, partial + D, nblk, stride, 2 * D, dbias);
-  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(1), dim3(256), 0, stream, partial + 3 * D, nblk, stride, (int64_t)1, dbc);
+  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(D), dim3(256), 0, stream, partial, nblk, stride, D, dwc, accumulate);
+  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(2 * D), dim3(256), 0, stream, partial + D, nblk, stride, 2 * D, dbias, accumulate);
+  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(1), dim3(256), 0, stream, partial + 3 * D, nblk, stride, (int64_t)1, dbc, accumulate);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }
@@ -384,8 +384,8 @@ extern "C" size_t advmil_colsum_workspace_bytes(int64_t M, int64_t N) {
 }
 
 extern "C" int advmil_act_dropout_bwd(const float* dy, const float* y, int act, float drop_p, const uint64_t* seed,
-                                      uint64_t stream_id, int64_t M, int64_t N, float* dpre, float* dbias, void* ws,
-                                      size_t ws_bytes, advmil_stream_t stream_) {
+                                      uint64_t stream_id, int64_t M, int64_t N, float* dpre, float* dbias, int accumulate,
+                                      void* ws, size_t ws_bytes, advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!dy || !y || !dpre || M <= 0 || N <= 0 || (N & 3)) return ADVMIL_EINVAL;
   if (dbias && (!ws || ws_bytes < advmil_colsum_workspace_bytes(M, N))) return ADVMIL_EWORKSPACE;
@@ -398,7 +398,7 @@ extern "C" int advmil_act_dropout_bwd(const float* dy, const float* y, int act, 
   }
   ADVMIL_LAUNCH_CHECK();
   if (dbias) {
-    hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(N), dim3(256), 0, stream, partial, nblk, N, N, dbias);
+    hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(N), dim3(256), 0, stream, partial, nblk, N, N, dbias, accumulate);
     ADVMIL_LAUNCH_CHECK();
   }
   return ADVMIL_OK;
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   if (m.active && m.r == 0) *reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * N + c0 + m.c4 * 4) = t;
 }
 
-extern "C" int advmil_colsum(const float* x, int64_t M, int64_t N, float* out, void* ws, size_t ws_bytes,
+extern "C" int advmil_colsum(const float* x, int64_t M, int64_t N, float* out, int accumulate, void* ws, size_t ws_bytes,
                              advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!x || !out || !ws || M <= 0 || N <= 0 || (N & 3)) return ADVMIL_EINVAL;
@@ -432,7 +432,7 @@ extern "C" int advmil_colsum(const float* x, int64_t M, int64_t N, float* out, v
     const int64_t W = (N - c0 < 1024) ? (N - c0) : 1024;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, x, M, N, c0, W, (float*)ws);
   }
-  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(N), dim3(256), 0, stream, (const float*)ws, nblk, N, N, out);
+  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(N), dim3(256), 0, stream, (const float*)ws, nblk, N, N, out, accumulate);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }
@@ -569,7 +569,8 @@ extern "C" size_t advmil_ln_relu_mean16_bwd_workspace_bytes(int64_t N, int64_t d
 
 extern "C" int advmil_ln_relu_mean16_bwd(const float* demb, const float* y, const float* gamma, const float* beta,
                                          const float* mean, const float* rstd, int64_t N, int64_t d, float* dy,
-                                         float* dgamma, float* dbeta, void* ws, size_t ws_bytes, advmil_stream_t stream_) {
+                                         float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes,
+                                         advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!demb || !y || !gamma || !beta || !mean || !rstd || !dy || !dgamma || !dbeta || !ws || N <= 0 || (N & 15) || d <= 0 ||
       d > 512)
@@ -580,8 +581,8 @@ extern "C" int advmil_ln_relu_mean16_bwd(const float* demb, const float* y, cons
   hipLaunchKernelGGL(ln_relu_mean16_bwd_kernel, dim3(L), dim3(256), 0, stream, demb, y, gamma, beta, mean, rstd, N, d, dy,
                      partial);
   ADVMIL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial, L, 2 * d, d, dgamma);
-  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial + d, L, 2 * d, d, dbeta);
+  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial, L, 2 * d, d, dgamma, accumulate);
+  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial + d, L, 2 * d, d, dbeta, accumulate);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }

@@ -20,14 +20,19 @@ def loss_reg_l1(coef):
     return func
 
 
-def recon_loss(pred_t, t, e, alpha=0.0, gamma=1.0, norm="l1", cur_alpha=None):
+def recon_terms(pred_t, t, e, alpha=0.0, gamma=1.0, norm="l1", cur_alpha=None):
+    """Per-sample terms whose mean is recon_loss (loss/utils.py:21-41)."""
     pred_t, t, e = pred_t.reshape(-1), t.reshape(-1), e.reshape(-1)
     loss_obs = e * torch.abs(pred_t - t)
     loss_cen = (1 - e) * F.relu(gamma - (pred_t - t))
     if norm == "l2":
         loss_obs, loss_cen = loss_obs * loss_obs, loss_cen * loss_cen
     a = alpha if cur_alpha is None else cur_alpha
-    return ((1.0 - a) * (loss_obs + loss_cen) + a * loss_obs).mean()
+    return (1.0 - a) * (loss_obs + loss_cen) + a * loss_obs
+
+
+def recon_loss(pred_t, t, e, alpha=0.0, gamma=1.0, norm="l1", cur_alpha=None):
+    return recon_terms(pred_t, t, e, alpha, gamma, norm, cur_alpha).mean()
 
 
 def real_fake_terms(real, fake, which="bce"):

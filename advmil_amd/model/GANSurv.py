@@ -40,8 +40,19 @@ class Generator(nn.Module):
             return torch.exp(H)
         return H
 
+    def features(self, x, x_ext):
+        """Per-bag N-row work only; the [1,d]-sized remainder (`finish`) can then run once for a whole step batch."""
+        bb = self.backbone
+        return bb.features(x, x_ext) if hasattr(bb, "features") else bb(x, x_ext)
+
+    def finish(self, feats, zero_noise=False, noise=None):
+        """feats[B, d] (stacked `features`) -> predictions [B, dim_out]."""
+        bb = self.backbone
+        H = bb.post(feats) if hasattr(bb, "post") else feats
+        return self.head(H, zero_noise, noise)
+
     def forward(self, x, x_ext, zero_noise=False, noise=None):
-        return self.head(self.backbone(x, x_ext), zero_noise, noise)
+        return self.finish(self.features(x, x_ext), zero_noise, noise)
 
 
 class _PairNet(nn.Module):
@@ -64,15 +75,20 @@ class Discriminator(_PairNet):
         super().__init__(args_netx, args_nety)
         self.fc = nn.Linear(args_netx.out_dim + args_nety.hid_dims[-1], 1)
 
-    def x_features(self, emb_ins):
-        return (self.net_pair_one.from_embedding(emb_ins),)
+    def bag_features(self, emb_ins):
+        """Per-bag region-level work (fc1 MLP + GAPool): (emb_bag[1,C'], None)."""
+        emb_bag, _ = self.net_pair_one.pool_features(emb_ins)
+        return emb_bag, None
 
-    def fuse(self, feats, t):
-        hid_t = run_mlp_small(self.net_pair_two, t, _rng_of(self, t), "dy")
-        return nn.functional.linear(torch.cat([feats[0], hid_t], dim=1), self.fc.weight, self.fc.bias)
+    def tail(self, emb_bag, ins_mean, t):
+        """[B,C'] stacks + t[B,1] -> f[B,1]: fc2, net_pair_two and the concat head, once per step batch."""
+        rng = _rng_of(self, t)
+        hid_x = run_mlp_small(self.net_pair_one.fc2, emb_bag, rng, "dx_fc2")
+        hid_t = run_mlp_small(self.net_pair_two, t, rng, "dy")
+        return nn.functional.linear(torch.cat([hid_x, hid_t], dim=1), self.fc.weight, self.fc.bias)
 
     def from_embedding(self, emb_ins, t):
-        return self.fuse(self.x_features(emb_ins), t)
+        return self.tail(*self.bag_features(emb_ins), t)
 
 
 class PrjDiscriminator(_PairNet):
@@ -91,17 +107,19 @@ class PrjDiscriminator(_PairNet):
         else:
             self.prj_layer = None
 
-    def x_features(self, emb_ins):
-        """Everything that does not depend on t: (hid_x[1,C'], mean_r fc_ins[1,C'] | None)."""
-        if self.inner_product == "instance":
-            hid_x, fc_ins = self.net_pair_one.from_embedding(emb_ins, return_instance=True)
-            # RLIP is linear in the region mean: mean_r(fc_ins_r . hid_t) == mean_r(fc_ins_r) . hid_t
-            return hid_x, fc_ins.mean(dim=1)
-        return self.net_pair_one.from_embedding(emb_ins), None
+    def bag_features(self, emb_ins):
+        """Per-bag region-level work that does not depend on t (fc1 MLP + GAPool, HIP kernels):
+        (emb_bag[1,C'], mean_r fc_ins[1,C'] | None). RLIP is linear in the region mean:
+        mean_r(fc_ins_r . hid_t) == mean_r(fc_ins_r) . hid_t (GANSurv.py:96-98)."""
+        emb_bag, fc_ins = self.net_pair_one.pool_features(emb_ins)
+        return emb_bag, (fc_ins.mean(dim=1) if self.inner_product == "instance" else None)
 
-    def fuse(self, feats, t):
-        hid_x, ins_mean = feats
-        hid_t = run_mlp_small(self.net_pair_two, t, _rng_of(self, t), "dy")
+    def tail(self, emb_bag, ins_mean, t):
+        """[B,C'] stacks + t[B,1] -> f[B,1]: fc2, net_pair_two, the (region-level) inner product and the projection,
+        once per step batch instead of once per bag."""
+        rng = _rng_of(self, t)
+        hid_x = run_mlp_small(self.net_pair_one.fc2, emb_bag, rng, "dx_fc2")
+        hid_t = run_mlp_small(self.net_pair_two, t, rng, "dy")
         if self.inner_product == "bag":
             out = (hid_t * hid_x).sum(dim=-1, keepdim=True)
         else:
@@ -112,4 +130,4 @@ class PrjDiscriminator(_PairNet):
         return out
 
     def from_embedding(self, emb_ins, t):
-        return self.fuse(self.x_features(emb_ins), t)
+        return self.tail(*self.bag_features(emb_ins), t)

@@ -50,14 +50,22 @@ class ABMIL(nn.Module):
                                            Attn_Net_Gated(L=dim_hid, D=dim_hid, dropout=dropout, n_classes=1))
         self.rho = nn.Sequential(nn.Linear(dim_hid, dim_out), nn.ReLU(), nn.Dropout(dropout))
 
-    def forward(self, x_path, *args):
+    def features(self, x_path, *args):
+        """The N-row part: bag -> attention-pooled instance embedding [1, hid] (everything before `rho`)."""
         x = x_path.squeeze(0)                                   # batch_size = 1
         rng = _rng_of(self, x)
         fc, p = self.attention_net[0], (self.attention_net[2].p if self.training else 0.0)
         h = ops.linear_act(x, fc.weight, fc.bias, "relu", p, rng, "abmil_fc")       # [N, hid]
         pooled, A, _ = self.attention_net[3].pool(h)
         self.last_attention = A.detach()
-        return _small_fc(self.rho, pooled.unsqueeze(0), rng, "abmil_rho")
+        return pooled.unsqueeze(0)
+
+    def post(self, pooled):
+        """`rho` on a [B, hid] stack of pooled bags (B = the bags of one optimizer step)."""
+        return _small_fc(self.rho, pooled, _rng_of(self, pooled), "abmil_rho")
+
+    def forward(self, x_path, *args):
+        return self.post(self.features(x_path, *args))
 
 
 class DeepAttMISL(nn.Module):

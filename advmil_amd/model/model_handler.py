@@ -24,7 +24,7 @@ from types import SimpleNamespace
 import torch
 
 from .. import ops
-from ..loss.utils import fake_generator_loss, real_fake_loss, real_fake_terms, recon_loss
+from ..loss.utils import fake_generator_loss, real_fake_loss, real_fake_terms, recon_loss, recon_terms
 from ..optim import FlatAdam, create_optimizer
 from ..parallel import BagParallel
 from ..utils.func import agg_tensor, seed_everything, sparse_key, sparse_str
@@ -93,6 +93,7 @@ class MyHandler(object):
         self.which_loss = cfg["loss_netD"]
         self.real_fake_loss = partial(real_fake_loss, which=cfg["loss_netD"])
         self.supervised_loss = partial(recon_loss, **sparse_key(cfg, prefixes="loss_recon"))
+        self.supervised_terms = partial(recon_terms, **sparse_key(cfg, prefixes="loss_recon"))
         self.coef_ganloss = cfg["loss_gan_coef"]
         self.coef_l1 = 0.0 if cfg["loss_regl1_coef"] is None else float(cfg["loss_regl1_coef"])
         opt_cfg = SimpleNamespace(opt=cfg["opt_netG"], weight_decay=cfg["opt_netG_weight_decay"], lr=cfg["opt_netG_lr"],
@@ -192,36 +193,59 @@ class MyHandler(object):
             ys_host = [y.cpu() for y in ys]             # fallback: one sync (the epoch loop passes host labels)
         is_real = [bool(float(yh[0, 1]) == 1.0) and vis[i] for i, yh in enumerate(ys_host)]
         n_real, n_fake, n_vis = self.dp.global_counts([sum(is_real), n, sum(vis)], self.device)
-        return SimpleNamespace(vis=vis, is_real=is_real, n_real=n_real, n_fake=n_fake, n_vis=n_vis)
+        vis_mask = None if all(vis) else torch.tensor([float(v) for v in vis], device=self.device)   # made OUTSIDE capture
+        return SimpleNamespace(vis=vis, is_real=is_real, n_real=n_real, n_fake=n_fake, n_vis=n_vis, vis_mask=vis_mask)
+
+    @staticmethod
+    def _stack_noise(noise):
+        """per-bag [[n_layer0, ...], ...] -> per-layer [B, w] stacks for the batched head."""
+        if noise is None:
+            return None
+        return [torch.cat([nb[j] for nb in noise], dim=0) for j in range(len(noise[0]))]
+
+    def _gen_features(self, data_x, data_x_ext):
+        if self.bcb == "graph":
+            return self.netG.features(data_x_ext, None)
+        if self.bcb == "patch":
+            return self.netG.features(data_x, None)            # coords skipped (model_handler.py:390)
+        return self.netG.features(data_x, data_x_ext)
 
     def _disc_backward(self, i_batch, xs, ys, plan, noise=None):
-        """Capturable (no host sync, no collective): zero D grads, per-bag forward + backward of the D loss terms."""
+        """Capturable (no host sync, no collective): zero D grads, forward of every bag, ONE backward of the D loss.
+        Per bag only the N-row / region-row kernels run; the [1,d]-sized heads and tails run once on [B,d] stacks."""
         self.netD.train()
         self.netG.eval()
         n = len(xs)
+        dev = self.device
         self.optimizerD.zero_grad()
-        preds, fakes = [], []
-        z = torch.zeros((), device=self.device)
-        s_loss, s_real, s_fake = z.clone(), z.clone(), z.clone()
+        with torch.no_grad():                                                  # the reference builds, then detaches (400)
+            feats = torch.cat([self._gen_features(xs[i][0], xs[i][1]) for i in range(n)], dim=0)
+            pred = self.netG.finish(feats, noise=self._stack_noise(noise))     # [B,1]
+        fake_b, fake_m, real_b, real_m = [], [], [], []
         for i in range(n):
-            data_x, data_x_ext = xs[i][0], xs[i][1]
-            data_t = ys[i][:, 0:1]
-            with torch.no_grad():
-                pred = self._gen_forward(data_x, data_x_ext, **({} if noise is None else {"noise": noise[i]}))
-            preds.append(pred)
-            emb = self.netD.embed_x(data_x)                                   # shared by both pairs
-            f_real = self.netD.from_embedding(emb, data_t).view(-1) if plan.is_real[i] else None
-            f_fake = self.netD.from_embedding(emb, pred).view(-1)
-            tr, tf = real_fake_terms(f_real, f_fake, self.which_loss)
-            loss_i = tf.sum() / plan.n_fake
-            if tr is not None:
-                loss_i = loss_i + tr.sum() / plan.n_real
-                s_real += f_real.detach().sum()
-            loss_i.backward()
-            s_loss += loss_i.detach(); s_fake += f_fake.detach().sum()
-            fakes.append(f_fake.detach())
-        self.log({"train_batch/netD/Loss_D": s_loss, "train_batch/netD/D_real": s_real / max(plan.n_real, 1),
-                  "train_batch/netD/D_fake": s_fake / plan.n_fake, "i_batch": i_batch})
+            emb = self.netD.embed_x(xs[i][0])                                  # shared by both pairs of the bag
+            if plan.is_real[i]:
+                eb, im = self.netD.bag_features(emb)
+                real_b.append(eb); real_m.append(im)
+            eb, im = self.netD.bag_features(emb)
+            fake_b.append(eb); fake_m.append(im)
+        cat = lambda lst: None if lst[0] is None else torch.cat(lst, dim=0)
+        f_fake = self.netD.tail(torch.cat(fake_b, dim=0), cat(fake_m), pred).view(-1)
+        f_real = None
+        if real_b:
+            t_real = torch.cat([ys[i][:, 0:1] for i in range(n) if plan.is_real[i]], dim=0)
+            f_real = self.netD.tail(torch.cat(real_b, dim=0), cat(real_m), t_real).view(-1)
+        tr, tf = real_fake_terms(f_real, f_fake, self.which_loss)
+        loss = tf.sum() / plan.n_fake
+        s_real = torch.zeros((), device=dev)
+        if tr is not None:
+            loss = loss + tr.sum() / plan.n_real
+            s_real = f_real.detach().sum()
+        loss.backward()
+        self.log({"train_batch/netD/Loss_D": loss.detach(), "train_batch/netD/D_real": s_real / max(plan.n_real, 1),
+                  "train_batch/netD/D_fake": f_fake.detach().sum() / plan.n_fake, "i_batch": i_batch})
+        preds = list(pred.split(1, dim=0))
+        fakes = list(f_fake.detach().split(1, dim=0))
         return preds, fakes
 
     def _disc_apply(self):
@@ -236,34 +260,36 @@ class MyHandler(object):
         self._gen_apply()
 
     def _gen_backward(self, i_batch, xs, ys, plan, noise=None):
-        """Capturable: zero G grads, per-bag forward + backward of the G loss terms."""
+        """Capturable: zero G grads, forward of every bag, ONE backward of the G loss (heads/tails on [B,d] stacks)."""
         self.netD.eval()
         self.netG.train()
         n = len(xs)
+        dev = self.device
         self.optimizerG.zero_grad()
-        z = torch.zeros((), device=self.device)
-        s_gen, s_reg, s_fake = z.clone(), z.clone(), z.clone()
-        for i in range(n):
-            data_x, data_x_ext = xs[i][0], xs[i][1]
-            data_t, data_ind = ys[i][:, 0:1], ys[i][:, 1:2]
-            pred = self._gen_forward(data_x, data_x_ext, **({} if noise is None else {"noise": noise[i]}))
-            with torch.no_grad():                                              # nothing of D(x) depends on G
-                feats = self.netD.x_features(self.netD.embed_x(data_x))
-            f_fake = self.netD.fuse(feats, pred).view(-1)
-            gen_i = -f_fake.sum() / plan.n_fake
-            loss_i = self.coef_ganloss * gen_i if self.coef_ganloss != 0.0 else 0.0
-            if plan.vis[i]:
-                reg_i = self.supervised_loss(pred, data_t, data_ind) / plan.n_vis   # one sample: mean == the term
-                loss_i = loss_i + reg_i
-                s_reg += reg_i.detach()
-            if torch.is_tensor(loss_i):
-                loss_i.backward()
-            s_gen += gen_i.detach(); s_fake += f_fake.detach().sum()
-        total = s_reg + (self.coef_ganloss * s_gen if self.coef_ganloss != 0.0 else 0.0)
+        feats = torch.cat([self._gen_features(xs[i][0], xs[i][1]) for i in range(n)], dim=0)
+        pred = self.netG.finish(feats, noise=self._stack_noise(noise))        # [B,1], graph kept
+        with torch.no_grad():                                                  # nothing of D(x) depends on G
+            bf = [self.netD.bag_features(self.netD.embed_x(xs[i][0])) for i in range(n)]
+            eb = torch.cat([b[0] for b in bf], dim=0)
+            im = None if bf[0][1] is None else torch.cat([b[1] for b in bf], dim=0)
+        f_fake = self.netD.tail(eb, im, pred).view(-1)
+        gen = -f_fake.sum() / plan.n_fake
+        if plan.n_vis > 0 and any(plan.vis):
+            y = torch.cat(ys, dim=0)
+            terms = self.supervised_terms(pred, y[:, 0:1], y[:, 1:2])          # per bag; the mean is over visible labels
+            if plan.vis_mask is not None:
+                terms = terms * plan.vis_mask
+            reg = terms.sum() / plan.n_vis
+        else:
+            reg = torch.zeros((), device=dev)
+        total = reg + self.coef_ganloss * gen if self.coef_ganloss != 0.0 else reg
+        total.backward()
+        total = total.detach()
         if self.coef_l1 > 1e-8:
             total = total + self.coef_l1 * ops.abs_sum(self.optimizerG.flat_param)[0]
-        self.log({"train_batch/netG/Loss_G_fake": s_gen, "train_batch/netG/Loss_G_time": s_reg,
-                  "train_batch/netG/Loss_G_total": total, "train_batch/netG/D_fake_avg": s_fake / plan.n_fake, "i_batch": i_batch})
+        self.log({"train_batch/netG/Loss_G_fake": gen.detach(), "train_batch/netG/Loss_G_time": reg.detach(),
+                  "train_batch/netG/Loss_G_total": total, "train_batch/netG/D_fake_avg": f_fake.detach().sum() / plan.n_fake,
+                  "i_batch": i_batch})
 
     def _gen_apply(self):
         self.dp.allreduce_(self.optimizerG.flat_grad)

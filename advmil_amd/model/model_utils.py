@@ -97,14 +97,18 @@ class EmbedXLayer(nn.Module):
         """The dropout-free, t-independent part: x -> emb_ins[1, L, C'] (shared by the real and fake pairs)."""
         return self.embedding(x)
 
-    def from_embedding(self, emb_ins, return_instance=False):
+    def pool_features(self, emb_ins):
+        """Region-level part: emb_ins[1,L,C'] -> (emb_bag[1,C'] (pooled, before fc2), fc_ins[1,L,C'])."""
         rng = _rng_of(self, emb_ins)
         tr = self.training
         e = emb_ins[0]
         h = ops.linear_act(e, self.fc1[0].weight, self.fc1[0].bias, "relu", self.fc1[2].p if tr else 0.0, rng, "dx_fc1")
         fc_ins = ops.linear_act(h, self.fc1[3].weight, self.fc1[3].bias, "none").unsqueeze(0)
-        emb_bag = self.pool(fc_ins)
-        fc_bag = run_mlp_small(self.fc2, emb_bag, rng, "dx_fc2")
+        return self.pool(fc_ins), fc_ins
+
+    def from_embedding(self, emb_ins, return_instance=False):
+        emb_bag, fc_ins = self.pool_features(emb_ins)
+        fc_bag = run_mlp_small(self.fc2, emb_bag, _rng_of(self, emb_ins), "dx_fc2")
         return (fc_bag, fc_ins) if return_instance else fc_bag
 
     def forward(self, x, return_instance=False):

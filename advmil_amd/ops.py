@@ -12,6 +12,8 @@ from . import _lib
 from ._lib import Epilogue
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+# True: backward kernels add parameter gradients straight into the optimizer's flat gradient arena (see _arena_grad)
+FUSED_WGRAD = True
 # bench.py sets this to a list to bracket every GEMM launch with HIP events on the launch stream:
 # entries are (kernel name, (M, N, K, splits), flops, start_event, stop_event)
 KERNEL_PROFILE = None
@@ -92,18 +94,26 @@ def default_rng(device):
 # ---------------------------------------------------------------------------------------
 # raw launches
 # ---------------------------------------------------------------------------------------
+_PLAN_CACHE = {}
+
+
+def gemm_plan(M, N, K):
+    """(tile, splits) from the library's launch plan (advmil_gemm_f32_plan)."""
+    key = (M, N, K)
+    if key not in _PLAN_CACHE:
+        t, sp = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(_lib.lib().advmil_gemm_f32_plan(M, N, K, ctypes.byref(t), ctypes.byref(sp)), "gemm_plan")
+        _PLAN_CACHE[key] = (t.value, sp.value)
+    return _PLAN_CACHE[key]
+
+
 def auto_splits(M, N, K):
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if tiles >= 128:
-        return 1
-    want = (384 + tiles - 1) // tiles
-    cap = max(1, K // 128)
-    return max(1, min(want, cap))
+    return gemm_plan(M, N, K)[1]
 
 
 def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=None, act_split=None, drop_p=0.0,
          seed=None, stream_id=0, rowv=None, colv=None, maskref=None, mask_scale=1.0, accumulate=False, alpha=1.0,
-         splits=None):
+         splits=None, tile=0):
     """C[M,N] = epilogue(alpha * op(A) op(B)); see include/advmil_hip.h::advmil_gemm_f32."""
     _chk(A, "A"); _chk(B, "B")
     if out is None:
@@ -129,7 +139,9 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
     e.accumulate = 1 if accumulate else 0
     e.alpha = float(alpha)
     if splits is None:
-        splits = auto_splits(M, N, K)
+        ptile, splits = gemm_plan(M, N, K)
+        if tile == 0:
+            tile = ptile
     L = _lib.lib()
     wsb = L.advmil_gemm_f32_workspace_bytes(M, N, splits)
     ws = _ws(wsb, A.device) if wsb else None
@@ -137,8 +149,8 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(L.advmil_gemm_f32(1 if a_kc else 0, 1 if b_kc else 0, M, N, K, _p(A), lda, _p(B), ldb, _p(out), ldc,
-                                 ctypes.byref(e), splits, _p(ws), wsb, _stream()), f"gemm_f32[{M}x{N}x{K}]")
+    _lib.check(L.advmil_gemm_f32_tiled(1 if a_kc else 0, 1 if b_kc else 0, M, N, K, _p(A), lda, _p(B), ldb, _p(out), ldc,
+                                       ctypes.byref(e), splits, tile, _p(ws), wsb, _stream()), f"gemm_f32[{M}x{N}x{K}]")
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
@@ -175,39 +187,46 @@ def softmax_pool_bwd(dpooled, dA, A, h, N, D):
     return ds
 
 
-def gate_bwd(ab, ds, wc, N, D, p=0.0, seed=None, stream_a=0, stream_b=0):
+def gate_bwd(ab, ds, wc, N, D, p=0.0, seed=None, stream_a=0, stream_b=0, dwc=None, dbc=None, dbias=None):
+    """dwc/dbc/dbias given -> gradients are ADDED into them (views of the gradient arena)."""
     L = _lib.lib()
     dev = ab.device
+    acc = dwc is not None
     dG = torch.empty(N, 2 * D, dtype=torch.float32, device=dev)
-    dwc = torch.empty(D, dtype=torch.float32, device=dev)
-    dbc = torch.empty(1, dtype=torch.float32, device=dev)
-    dbias = torch.empty(2 * D, dtype=torch.float32, device=dev)
+    if not acc:
+        dwc = torch.empty(D, dtype=torch.float32, device=dev)
+        dbc = torch.empty(1, dtype=torch.float32, device=dev)
+        dbias = torch.empty(2 * D, dtype=torch.float32, device=dev)
     wsb = L.advmil_gate_bwd_workspace_bytes(N, D)
     ws = _ws(wsb, dev)
     sd = seed if p > 0.0 else None
     _lib.check(L.advmil_gate_bwd(_p(ab), _p(ds), _p(wc), p, _p(sd), stream_a, stream_b, N, D, _p(dG), _p(dwc), _p(dbc),
-                                 _p(dbias), _p(ws), wsb, _stream()), "gate_bwd")
+                                 _p(dbias), 1 if acc else 0, _p(ws), wsb, _stream()), "gate_bwd")
     return dG, dwc, dbc, dbias
 
 
-def act_dropout_bwd(dy, y, act, M, N, p=0.0, seed=None, stream_id=0, want_bias=True):
+def act_dropout_bwd(dy, y, act, M, N, p=0.0, seed=None, stream_id=0, want_bias=True, db_out=None):
     L = _lib.lib()
     dpre = torch.empty(M, N, dtype=torch.float32, device=dy.device)
-    db = torch.empty(N, dtype=torch.float32, device=dy.device) if want_bias else None
-    wsb = L.advmil_colsum_workspace_bytes(M, N) if want_bias else 0
-    ws = _ws(wsb, dy.device) if want_bias else None
+    acc = db_out is not None
+    db = db_out if acc else (torch.empty(N, dtype=torch.float32, device=dy.device) if want_bias else None)
+    need = acc or want_bias
+    wsb = L.advmil_colsum_workspace_bytes(M, N) if need else 0
+    ws = _ws(wsb, dy.device) if need else None
     sd = seed if p > 0.0 else None
-    _lib.check(L.advmil_act_dropout_bwd(_p(dy), _p(y), act, p, _p(sd), stream_id, M, N, _p(dpre), _p(db), _p(ws), wsb,
-                                        _stream()), "act_dropout_bwd")
+    _lib.check(L.advmil_act_dropout_bwd(_p(dy), _p(y), act, p, _p(sd), stream_id, M, N, _p(dpre), _p(db), 1 if acc else 0,
+                                        _p(ws), wsb, _stream()), "act_dropout_bwd")
     return dpre, db
 
 
-def colsum(x, M, N):
+def colsum(x, M, N, out=None):
     L = _lib.lib()
-    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    acc = out is not None
+    if not acc:
+        out = torch.empty(N, dtype=torch.float32, device=x.device)
     wsb = L.advmil_colsum_workspace_bytes(M, N)
     ws = _ws(wsb, x.device)
-    _lib.check(L.advmil_colsum(_p(x), M, N, _p(out), _p(ws), wsb, _stream()), "colsum")
+    _lib.check(L.advmil_colsum(_p(x), M, N, _p(out), 1 if acc else 0, _p(ws), wsb, _stream()), "colsum")
     return out
 
 
@@ -221,16 +240,17 @@ def ln_relu_mean16_fwd(y, gamma, beta, N, d, eps=1e-5):
     return emb, mean, rstd
 
 
-def ln_relu_mean16_bwd(demb, y, gamma, beta, mean, rstd, N, d):
+def ln_relu_mean16_bwd(demb, y, gamma, beta, mean, rstd, N, d, dg_out=None, db_out=None):
     L = _lib.lib()
     dev = y.device
     dy = torch.empty(N, d, dtype=torch.float32, device=dev)
-    dg = torch.empty(d, dtype=torch.float32, device=dev)
-    db = torch.empty(d, dtype=torch.float32, device=dev)
+    acc = dg_out is not None
+    dg = dg_out if acc else torch.empty(d, dtype=torch.float32, device=dev)
+    db = db_out if acc else torch.empty(d, dtype=torch.float32, device=dev)
     wsb = L.advmil_ln_relu_mean16_bwd_workspace_bytes(N, d)
     ws = _ws(wsb, dev)
     _lib.check(L.advmil_ln_relu_mean16_bwd(_p(demb), _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), N, d, _p(dy), _p(dg),
-                                           _p(db), _p(ws), wsb, _stream()), "ln_relu_mean16_bwd")
+                                           _p(db), 1 if acc else 0, _p(ws), wsb, _stream()), "ln_relu_mean16_bwd")
     return dy, dg, db
 
 
@@ -252,6 +272,31 @@ def abs_sum(p):
 # ---------------------------------------------------------------------------------------
 # autograd Functions
 # ---------------------------------------------------------------------------------------
+def _arena_grad(p):
+    """The parameter's slot in its optimizer's flat gradient arena (set by advmil_amd.optim.FlatAdam), or None.
+    When present, backward kernels ADD the parameter gradient straight into it and hand autograd `None`, which removes
+    one accumulate launch per parameter per bag."""
+    g = getattr(p, "_arena_grad", None) if p is not None else None
+    if g is not None and FUSED_WGRAD and p.requires_grad:
+        return g
+    return None
+
+
+def _adjacent(a, b):
+    return (a is not None and b is not None and a.is_contiguous() and b.is_contiguous()
+            and b.data_ptr() == a.data_ptr() + a.numel() * 4
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr())     # same arena, not allocator luck
+
+
+def _stack2(a, b, rows, cols):
+    """[2*rows, cols] view over two adjacent arena tensors (attention_a|attention_b weights or biases), else a copy."""
+    if _adjacent(a, b):
+        shape = (2 * rows, cols) if cols else (2 * rows,)
+        stride = (cols, 1) if cols else (1,)
+        return a.detach().as_strided(shape, stride, a.storage_offset()), True
+    return torch.cat([a.detach(), b.detach()], dim=0).contiguous(), False
+
+
 class LinearActFn(torch.autograd.Function):
     """y = dropout(act(x W^T + b)); x[M,K], W[N,K]. Dropout index = m*N + n on stream `sid`."""
 
@@ -259,12 +304,13 @@ class LinearActFn(torch.autograd.Function):
     def forward(ctx, x, W, b, act, p, seed, sid):
         _chk(x, "x"); _chk(W, "weight")
         x = x.contiguous()
-        W2 = W.reshape(W.shape[0], -1)
+        W2 = W.detach().reshape(W.shape[0], -1)
         M, K = x.shape
         N = W2.shape[0]
         y = gemm(x, W2, True, True, M, N, K, bias=b, act0=act, drop_p=p, seed=seed, stream_id=sid)
         ctx.save_for_backward(x, W2, y)
         ctx.cfg = (act, p, seed, sid, M, N, K, W.shape, b is not None)
+        ctx.gW, ctx.gb = _arena_grad(W), _arena_grad(b)
         return y
 
     @staticmethod
@@ -273,14 +319,22 @@ class LinearActFn(torch.autograd.Function):
         act, p, seed, sid, M, N, K, wshape, has_b = ctx.cfg
         dy = dy.contiguous()
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_b = has_b and ctx.needs_input_grad[2]
+        db = None
         if act == ACT_NONE and p <= 0.0:
             dpre = dy
-            db = colsum(dy, M, N) if has_b else None
+            if need_b:
+                db = colsum(dy, M, N, out=ctx.gb)
         else:
-            dpre, db = act_dropout_bwd(dy, y, act, M, N, p, seed, sid, want_bias=has_b)
-        dW = gemm(dpre, x, False, False, N, K, M).reshape(wshape) if need_w else None   # dpre^T x
+            dpre, db = act_dropout_bwd(dy, y, act, M, N, p, seed, sid, want_bias=need_b, db_out=ctx.gb if need_b else None)
+        dW = None
+        if need_w:                                           # dpre^T x
+            if ctx.gW is not None:
+                gemm(dpre, x, False, False, N, K, M, out=ctx.gW.view(N, K), ldc=K, accumulate=True)
+            else:
+                dW = gemm(dpre, x, False, False, N, K, M).reshape(wshape)
         dx = gemm(dpre, W2, True, False, M, K, N) if need_x else None                   # dpre W
-        return dx, dW, db, None, None, None, None
+        return dx, dW, (None if ctx.gb is not None else db), None, None, None, None
 
 
 def linear_act(x, W, b, act="none", p=0.0, rng=None, tag=""):
@@ -306,14 +360,20 @@ class GatedAttnPoolFn(torch.autograd.Function):
         _chk(h, "h")
         h = h.contiguous()
         N, D = h.shape
-        Wab = torch.cat([Wa, Wb], dim=0).contiguous()        # [2D, D]
-        bab = torch.cat([ba, bb], dim=0).contiguous()
+        Wab, _ = _stack2(Wa, Wb, D, D)                       # [2D, D]: a view when the two live side by side in the arena
+        bab, _ = _stack2(ba, bb, D, 0)
         ab = gemm(h, Wab, True, True, N, 2 * D, D, bias=bab, act0=ACT_TANH, act1=ACT_SIGMOID, act_split=D)
-        wcv = wc.reshape(-1).contiguous()
+        wcv = wc.detach().reshape(-1)
         s = gate_score(ab, wcv, bc, N, D, p, seed, sa, sb)
         A, pooled = softmax_pool(s, h, N, D)
         ctx.save_for_backward(h, Wab, ab, A, wcv)
         ctx.cfg = (p, seed, sa, sb, N, D, wc.shape)
+        # fused weight-gradient accumulation needs every parameter's arena slot, with the a|b pairs adjacent
+        gs = [_arena_grad(t) for t in (Wa, ba, Wb, bb, wc, bc)]
+        ctx.arena = None
+        if all(g is not None for g in gs) and _adjacent(gs[0], gs[2]) and _adjacent(gs[1], gs[3]):
+            ctx.arena = (gs[0].as_strided((2 * D, D), (D, 1), gs[0].storage_offset()),
+                         gs[1].as_strided((2 * D,), (1,), gs[1].storage_offset()), gs[4].view(-1), gs[5])
         ctx.mark_non_differentiable(s)
         ctx.set_materialize_grads(False)
         return pooled, A, s
@@ -325,12 +385,19 @@ class GatedAttnPoolFn(torch.autograd.Function):
         dpooled = torch.zeros(D, dtype=torch.float32, device=h.device) if dpooled is None else dpooled.contiguous()
         dA_ = None if dA is None else dA.contiguous()
         ds = softmax_pool_bwd(dpooled, dA_, A, h, N, D)
-        dG, dwc, dbc, dbias = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb)
+        if ctx.arena is not None:
+            gWab, gbab, gwc, gbc = ctx.arena
+            dG, _, _, _ = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb, dwc=gwc, dbc=gbc, dbias=gbab)
+        else:
+            dG, dwc, dbc, dbias = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb)
         dh = None
         if ctx.needs_input_grad[0]:
             # dG [N,2D] . Wab [2D,D]  +  A[n] * dpooled[d]   (pooling's direct path)
             dh = gemm(dG, Wab, True, False, N, D, 2 * D, rowv=A, colv=dpooled)
-        dWab = gemm(dG, h, False, False, 2 * D, D, N)         # dG^T h
+        if ctx.arena is not None:
+            gemm(dG, h, False, False, 2 * D, D, N, out=gWab, ldc=D, accumulate=True)       # dG^T h
+            return (dh, None, None, None, None, None, None, None, None, None, None)
+        dWab = gemm(dG, h, False, False, 2 * D, D, N)
         return (dh, dWab[:D], dbias[:D], dWab[D:], dbias[D:], dwc.reshape(wcshape), dbc, None, None, None, None)
 
 
@@ -355,13 +422,18 @@ class LNReLUMean16Fn(torch.autograd.Function):
         y = y.contiguous()
         N, d = y.shape
         emb, mean, rstd = ln_relu_mean16_fwd(y, gamma, beta, N, d, eps)
-        ctx.save_for_backward(y, gamma, beta, mean, rstd)
+        ctx.save_for_backward(y, gamma.detach(), beta.detach(), mean, rstd)
+        gg, gb = _arena_grad(gamma), _arena_grad(beta)
+        ctx.arena = (gg, gb) if (gg is not None and gb is not None) else None
         return emb
 
     @staticmethod
     def backward(ctx, demb):
         y, gamma, beta, mean, rstd = ctx.saved_tensors
         N, d = y.shape
+        if ctx.arena is not None:
+            dy, _, _ = ln_relu_mean16_bwd(demb.contiguous(), y, gamma, beta, mean, rstd, N, d, ctx.arena[0], ctx.arena[1])
+            return dy, None, None, None
         dy, dg, db = ln_relu_mean16_bwd(demb.contiguous(), y, gamma, beta, mean, rstd, N, d)
         return dy, dg, db, None
 
@@ -379,10 +451,10 @@ class GateScoreFn(torch.autograd.Function):
         _chk(h, "h")
         h = h.contiguous()
         N, D = h.shape
-        Wab = torch.cat([Wa, Wb], dim=0).contiguous()
-        bab = torch.cat([ba, bb], dim=0).contiguous()
+        Wab, _ = _stack2(Wa, Wb, D, D)
+        bab, _ = _stack2(ba, bb, D, 0)
         ab = gemm(h, Wab, True, True, N, 2 * D, D, bias=bab, act0=ACT_TANH, act1=ACT_SIGMOID, act_split=D)
-        wcv = wc.reshape(-1).contiguous()
+        wcv = wc.detach().reshape(-1).contiguous()
         s = gate_score(ab, wcv, bc, N, D, p, seed, sa, sb)
         ctx.save_for_backward(h, Wab, ab, wcv)
         ctx.cfg = (p, seed, sa, sb, N, D, wc.shape)

@@ -62,6 +62,7 @@ class FlatAdam(torch.optim.Optimizer):
                 self.flat_param[o:o + k].copy_(p.reshape(-1))
                 p.data = self.flat_param[o:o + k].view(p.shape)
                 p.grad = self.flat_grad[o:o + k].view(p.shape)
+                p._arena_grad = p.grad                     # backward kernels accumulate here directly (ops._arena_grad)
                 self._views.append((p, o, k))
             for g in self.param_groups:
                 for p in g["params"]:
@@ -76,6 +77,7 @@ class FlatAdam(torch.optim.Optimizer):
         for p, o, k in self._views:          # re-attach if someone replaced .grad
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
                 p.grad = self.flat_grad[o:o + k].view(p.shape)
+                p._arena_grad = p.grad
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):

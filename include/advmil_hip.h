@@ -67,6 +67,14 @@ size_t advmil_gemm_f32_workspace_bytes(int64_t M, int64_t N, int splits);
 int advmil_gemm_f32(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                     const float* B, int64_t ldb, float* C, int64_t ldc, const advmil_epilogue_t* epi,
                     int splits, void* ws, size_t ws_bytes, advmil_stream_t stream);
+/* The library's launch plan for a shape: block tile (see below) and K split count. Host callers size the workspace
+ * from `splits` (advmil_gemm_f32_workspace_bytes) and pass both to advmil_gemm_f32_tiled. */
+int advmil_gemm_f32_plan(int64_t M, int64_t N, int64_t K, int* tile, int* splits);
+/* Same, with an explicit block tile: tile = 10*TM + TN selects (64*TM) x (64*TN) output tiles
+ * (22 = 128x128, 23 = 128x192, 13 = 64x192, 12 = 64x128, 11 = 64x64); 0 = the plan's choice (what advmil_gemm_f32 uses). */
+int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                          const float* B, int64_t ldb, float* C, int64_t ldc, const advmil_epilogue_t* epi,
+                          int splits, int tile, void* ws, size_t ws_bytes, advmil_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Gated-attention MIL pooling (Attn_Net_Gated + softmax + mm: model/backbone_utils.py:11-29,
@@ -80,7 +88,10 @@ int advmil_gemm_f32(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, const f
  * softmax_pool_bwd: ds[n] = A[n] * (dA[n] + dot(dpooled, h[n,:]) - sum_m A[m](dA[m] + dot(dpooled,h[m,:])));
  *   dA may be NULL. (dh gets A[n]*dpooled[d] through the rank-1 term of the gemm epilogue.)
  * gate_bwd: from ds -> dG[N,2D] = grads wrt the two pre-activations, plus dwc[D], dbc[1], dbias[2D]
- *   (column sums of dG). */
+ *   (column sums of dG).
+ * `accumulate` (here and in the other backward entry points): non-zero ADDS the parameter gradients into the
+ *   destination instead of overwriting it -- the destinations are then views of the flat gradient arena, which
+ *   removes the per-parameter accumulate launches autograd would issue for every bag. */
 int advmil_gate_score_fwd(const float* ab, const float* wc, const float* bc, float drop_p, const uint64_t* seed,
                           uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D, float* s, advmil_stream_t stream);
 size_t advmil_softmax_pool_workspace_bytes(int64_t N, int64_t D);
@@ -91,7 +102,7 @@ int advmil_softmax_pool_bwd(const float* dpooled, const float* dA, const float* 
 size_t advmil_gate_bwd_workspace_bytes(int64_t N, int64_t D);
 int advmil_gate_bwd(const float* ab, const float* ds, const float* wc, float drop_p, const uint64_t* seed,
                     uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D, float* dG, float* dwc, float* dbc,
-                    float* dbias, void* ws, size_t ws_bytes, advmil_stream_t stream);
+                    float* dbias, int accumulate, void* ws, size_t ws_bytes, advmil_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Backward of y = dropout(act(pre)) for the Linear layers: dpre = dy * keep * act'(y) and
@@ -99,10 +110,11 @@ int advmil_gate_bwd(const float* ab, const float* ds, const float* wc, float dro
  * replaces: autograd of ReLU/Tanh/Sigmoid/Dropout modules (model/backbone.py:70-75 etc.). */
 size_t advmil_colsum_workspace_bytes(int64_t M, int64_t N);
 int advmil_act_dropout_bwd(const float* dy, const float* y, int act, float drop_p, const uint64_t* seed,
-                           uint64_t stream_id, int64_t M, int64_t N, float* dpre, float* dbias, void* ws,
-                           size_t ws_bytes, advmil_stream_t stream);
-/* out[n] = sum_m x[m,n] */
-int advmil_colsum(const float* x, int64_t M, int64_t N, float* out, void* ws, size_t ws_bytes, advmil_stream_t stream);
+                           uint64_t stream_id, int64_t M, int64_t N, float* dpre, float* dbias, int accumulate,
+                           void* ws, size_t ws_bytes, advmil_stream_t stream);
+/* out[n] (+)= sum_m x[m,n] */
+int advmil_colsum(const float* x, int64_t M, int64_t N, float* out, int accumulate, void* ws, size_t ws_bytes,
+                  advmil_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Region embedding tail of AVGPoolPatchEmbedding (model/backbone_utils.py:158-168):
@@ -114,7 +126,7 @@ int advmil_ln_relu_mean16_fwd(const float* y, const float* gamma, const float* b
 size_t advmil_ln_relu_mean16_bwd_workspace_bytes(int64_t N, int64_t d);
 int advmil_ln_relu_mean16_bwd(const float* demb, const float* y, const float* gamma, const float* beta,
                               const float* mean, const float* rstd, int64_t N, int64_t d, float* dy, float* dgamma,
-                              float* dbeta, void* ws, size_t ws_bytes, advmil_stream_t stream);
+                              float* dbeta, int accumulate, void* ws, size_t ws_bytes, advmil_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimizer + regulariser over a flat parameter arena (torch.optim.Adam, L2-in-grad weight decay:

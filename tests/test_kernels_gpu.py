@@ -35,15 +35,16 @@ ACT = {0: lambda v: v, 1: torch.relu, 2: torch.tanh, 3: torch.sigmoid}
 
 
 @pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, False), (False, True)])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 72, 100), (512, 384, 1024), (384, 1024, 520), (16, 64, 128)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 72, 100), (512, 384, 1024), (384, 1024, 520), (16, 64, 128), (260, 196, 36)])
 def test_gemm_layouts(ops, a_kc, b_kc, M, N, K):
     A = rnd(f"A{M}{K}", M, K); B = rnd(f"B{K}{N}", K, N)      # asymmetric, non-square
     ref = A.double() @ B.double()
     Ad = (A if a_kc else A.t().contiguous()).to(DEV)
     Bd = (B.t().contiguous() if b_kc else B).to(DEV)
     for splits in (1, 3):
-        C = ops.gemm(Ad, Bd, a_kc, b_kc, M, N, K, splits=splits)
-        assert relerr(C, ref) < 2e-6, (splits, relerr(C, ref))
+        for tile in (0, 22, 23, 13, 12, 11):
+            C = ops.gemm(Ad, Bd, a_kc, b_kc, M, N, K, splits=splits, tile=tile)
+            assert relerr(C, ref) < 2e-6, (splits, tile, relerr(C, ref))
 
 
 def test_gemm_epilogue_all(ops):
@@ -54,11 +55,12 @@ def test_gemm_epilogue_all(ops):
     v = torch.cat([torch.tanh(pre[:, :128]), torch.sigmoid(pre[:, 128:])], dim=1)
     v = v * (maskref.double() > 0) * 1.25 + C0.double()
     for splits in (1, 2):
-        out = C0.clone().to(DEV)
-        ops.gemm(A.to(DEV), W.to(DEV), True, True, M, N, K, out=out, bias=bias.to(DEV), act0=2, act1=3, act_split=128,
-                 rowv=rowv.to(DEV), colv=colv.to(DEV), maskref=maskref.to(DEV), mask_scale=1.25, accumulate=True, alpha=0.5,
-                 splits=splits)
-        assert relerr(out, v) < 2e-6
+        for tile in (0, 23, 13, 11):
+            out = C0.clone().to(DEV)
+            ops.gemm(A.to(DEV), W.to(DEV), True, True, M, N, K, out=out, bias=bias.to(DEV), act0=2, act1=3, act_split=128,
+                     rowv=rowv.to(DEV), colv=colv.to(DEV), maskref=maskref.to(DEV), mask_scale=1.25, accumulate=True, alpha=0.5,
+                     splits=splits, tile=tile)
+            assert relerr(out, v) < 2e-6, (splits, tile)
 
 
 def test_gemm_strided_output(ops):
