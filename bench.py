@@ -192,35 +192,64 @@ def main():
     logs = h.pop_logs() if args.eager else [{k: float(v) for k, v in d.items() if k != "i_batch"} for g in graphs for d in g.logs]
     finite = all(v == v and abs(v) != float("inf") for d in logs for v in d.values())
 
-    # ---- instrumented pass: HIP events around every GEMM launch on the launch stream
+    # ---- roofline of the dominant kernel.
+    # (1) an instrumented eager pass over the same steps brackets every GEMM launch with HIP events on the launch
+    #     stream to find which (kernel, shape) owns the most device time;
+    # (2) that exact launch is then timed back-to-back (queue kept full, so no host gaps pollute the per-launch time)
+    #     between two HIP events on the same stream. achieved = algorithmic FLOPs per launch / that duration.
     roof = None
     if rank == 0 and not args.no_roofline:
         ops.KERNEL_PROFILE = []
-        nprof = max(1, min(3, args.steps))
+        nprof = max(1, min(2, args.steps))
         cursor[0] = 0
         for _ in range(nprof):
-            eager_step()            # same schedule, eagerly, so each GEMM launch can be bracketed by HIP events
+            eager_step()
         torch.cuda.synchronize()
-        agg = {}
-        for name, shape, flops, e0, e1 in ops.KERNEL_PROFILE:
-            a = agg.setdefault(name, {"ms": 0.0, "flops": 0.0, "n": 0, "shapes": {}})
-            ms = e0.elapsed_time(e1)
-            a["ms"] += ms; a["flops"] += flops; a["n"] += 1
-            sh = a["shapes"].setdefault(str(shape), [0, 0.0, flops])
-            sh[0] += 1; sh[1] += ms
-        ops.KERNEL_PROFILE = None
+        prof, ops.KERNEL_PROFILE = ops.KERNEL_PROFILE, None
         h.history.clear()
-        name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
-        achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                "launches_per_step": a["n"] // nprof, "avg_launch_us": round(1e3 * a["ms"] / a["n"], 2),
-                "flops_per_launch": a["flops"] / a["n"],
-                "by_shape": {k: {"n": v[0] // nprof, "avg_us": round(1e3 * v[1] / v[0], 2),
-                                 "tflops": round(v[2] / (1e-3 * v[1] / v[0]) / 1e12, 2)} for k, v in a["shapes"].items()},
-                "other_kernels": {k: {"ms_per_step": round(v["ms"] / nprof, 3),
-                                      "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in agg.items() if k != name},
-                "gemm_ms_per_step": round(sum(v["ms"] for v in agg.values()) / nprof, 3)}
+        agg = {}
+        for name, shape, flops, e0, e1 in prof:
+            M, N, K, sp = shape
+            tile, _ = ops.gemm_plan(M, N, K)
+            key = (f"{name[:-1]},{tile // 10},{tile % 10}>", shape)
+            a = agg.setdefault(key, {"ms": 0.0, "n": 0, "flops": flops})
+            a["ms"] += e0.elapsed_time(e1); a["n"] += 1
+        (kname, shape), top = max(agg.items(), key=lambda kv: kv[1]["ms"])
+        M, N, K, sp = shape
+        a_kc, b_kc = kname.split("<")[1].startswith("1"), kname.split("<")[1].split(",")[1].startswith("1")
+        A = torch.randn((M, K) if a_kc else (K, M), device=dev)
+        B = torch.randn((N, K) if b_kc else (K, N), device=dev)
+        out = torch.empty(M, N, device=dev)
+        for _ in range(3):
+            ops.gemm(A, B, a_kc, b_kc, M, N, K, out=out)
+        torch.cuda.synchronize()
+        iters = 50
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            ops.gemm(A, B, a_kc, b_kc, M, N, K, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        flops = 2.0 * M * N * K
+        achieved = flops / us / 1e6
+        pmc = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")))
+        except Exception:
+            pass
+        traffic = None
+        if pmc and pmc.get("shape") == [M, N, K]:
+            traffic = pmc["hbm_bytes_per_launch"]
+        total_gemm_ms = sum(v["ms"] for v in agg.values()) / nprof
+        roof = {"bound": "mfma", "kernel": kname, "shape_MNK": [M, N, K], "achieved": round(achieved, 2),
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                "traffic": traffic, "avg_launch_us": round(us, 2), "flops_per_launch": flops,
+                "algorithmic_bytes_per_launch": 4.0 * (M * K + N * K + M * N),
+                "launches_per_step": top["n"] // nprof, "share_of_gemm_time_eager": round(top["ms"] / nprof / total_gemm_ms, 3),
+                "method": "50 back-to-back launches between two HIP events on the launch stream",
+                "eager_event_bracketed_us": {f"{k[0]} {list(k[1][:3])}": round(1e3 * v["ms"] / v["n"], 1)
+                                             for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]}}
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Launch ONE GEMM shape N times (for `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, run separately).
+usage: pmc_gemm.py M N K a_kc b_kc [iters]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from advmil_amd import ops  # noqa: E402
+
+M, N, K, a_kc, b_kc = (int(v) for v in sys.argv[1:6])
+iters = int(sys.argv[6]) if len(sys.argv) > 6 else 20
+dev = "cuda:0"
+# a pool of distinct operands larger than the 256 MB Infinity Cache so that reads come from HBM
+npool = max(2, int(400e6 // (4 * M * K)) + 1)
+As = [torch.randn((M, K) if a_kc else (K, M), device=dev) for _ in range(npool)]
+B = torch.randn((N, K) if b_kc else (K, N), device=dev)
+out = torch.empty(M, N, device=dev)
+for i in range(iters):
+    ops.gemm(As[i % npool], B, bool(a_kc), bool(b_kc), M, N, K, out=out)
+torch.cuda.synchronize()
+print("done", M, N, K, ops.gemm_plan(M, N, K))
