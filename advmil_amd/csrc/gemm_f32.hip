@@ -27,6 +27,7 @@ struct GemmArgs {
   float* ws;         // [splits][M][N] partials when splits > 1
   int splits;
   int mtiles;
+  int64_t sA, sB, sC;   // per-batch element strides (gridDim.z = batch)
   advmil_epilogue_t epi;
 };
 
@@ -100,6 +101,9 @@ __global__ __launch_bounds__(256, (TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(Ge
   const int mt_i = bid % g.mtiles, nt_i = bid / g.mtiles;
   const int64_t m0 = (int64_t)mt_i * BM_, n0 = (int64_t)nt_i * BN_;
   const int z = blockIdx.y;
+  g.A += (int64_t)blockIdx.z * g.sA;   // batched heads: plain pointer offsets
+  g.B += (int64_t)blockIdx.z * g.sB;
+  g.C += (int64_t)blockIdx.z * g.sC;
   const int64_t kbeg = (int64_t)z * g.k_chunk;
   const int64_t kend = (kbeg + g.k_chunk < g.K) ? kbeg + g.k_chunk : g.K;
 
@@ -297,6 +301,7 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
   g.splits = splits;
   g.ws = (float*)ws;
   g.epi = *epi;
+  g.sA = g.sB = g.sC = 0;
   if (splits > 1) {
     if (!ws || ws_bytes < advmil_gemm_f32_workspace_bytes(M, N, splits)) return ADVMIL_EWORKSPACE;
     if ((uintptr_t)ws & 15) return ADVMIL_EINVAL;
@@ -329,4 +334,36 @@ extern "C" int advmil_gemm_f32(int a_kc, int b_kc, int64_t M, int64_t N, int64_t
                                const float* B, int64_t ldb, float* C, int64_t ldc, const advmil_epilogue_t* epi,
                                int splits, void* ws, size_t ws_bytes, advmil_stream_t stream) {
   return advmil_gemm_f32_tiled(a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, epi, splits, 0, ws, ws_bytes, stream);
+}
+
+// Batched form (gridDim.z = batch): operand/result pointers advance by element strides per batch. Used for the ESAT
+// attention heads, which are strided slices of the packed qkv[L, 3d] and of O[L, d] -- no gather/permute copies.
+extern "C" int advmil_gemm_f32_batched(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                                       int64_t strideA, const float* B, int64_t ldb, int64_t strideB, float* C, int64_t ldc,
+                                       int64_t strideC, int batch, float alpha, int accumulate, advmil_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return ADVMIL_EINVAL;
+  if ((lda & 3) || (ldb & 3) || (strideA & 3) || (strideB & 3)) return ADVMIL_EINVAL;
+  if (a_kc ? (K & 3) : (M & 3)) return ADVMIL_EINVAL;
+  if (b_kc ? (K & 3) : (N & 3)) return ADVMIL_EINVAL;
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return ADVMIL_EINVAL;
+  GemmArgs g;
+  g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.k_chunk = ((K + BK - 1) / BK) * BK;
+  g.splits = 1; g.ws = nullptr;
+  g.sA = strideA; g.sB = strideB; g.sC = strideC;
+  advmil_epilogue_t e;
+  e.bias = nullptr; e.act0 = e.act1 = ACT_NONE; e.act_split = 1 << 30; e.drop_p = 0.f; e.seed = nullptr; e.stream_id = 0;
+  e.rowv = e.colv = e.maskref = nullptr; e.ldmask = 0; e.mask_scale = 1.f; e.accumulate = accumulate; e.alpha = alpha;
+  g.epi = e;
+  // small per-head problems: 64x64 tiles unless one head alone already fills the chip with 64x128
+  const int tile = (n_tiles(12, M, N) * batch >= 512) ? 12 : 11;
+  const int tm = tile / 10, tn = tile % 10;
+  g.mtiles = (int)((M + 64 * tm - 1) / (64 * tm));
+  const int ntiles = (int)((N + 64 * tn - 1) / (64 * tn));
+  dim3 grid(g.mtiles * ntiles, 1, batch);
+  if (tile == 12) launch_tile<1, 2>(a_kc, b_kc, grid, stream, g);
+  else launch_tile<1, 1>(a_kc, b_kc, grid, stream, g);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
 }

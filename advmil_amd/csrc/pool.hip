@@ -586,3 +586,79 @@ extern "C" int advmil_ln_relu_mean16_bwd(const float* demb, const float* y, cons
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }
+
+// =====================================================================================
+// Row softmax with dropout for the ESAT attention probabilities: one wave per row of S[R, C].
+//   P = softmax(S) (pre-dropout, kept for the backward); Pd = P * keep  (what multiplies V)
+//   bwd: dPp = dPd * keep; dS = P * (dPp - sum_j dPp_j P_j)
+// dropout element index = r*C + j  (r = head*L + query) -- the [H, L, L] layout of nn.MultiheadAttention's dropout.
+// =====================================================================================
+// R rows of pitch C; only the first Cv columns are real keys (the rest are alignment padding -> probability 0).
+// Lq = rows per head (padded query count). RNG index = ((r / Lq) * Cv + r % Lq) * Cv + j, i.e. the un-padded [H, L, L] layout.
+__global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(const float* __restrict__ S, float* __restrict__ P,
+                                                               float* __restrict__ Pd, int64_t R, int64_t C, int64_t Cv,
+                                                               int64_t Lq, float p, const uint64_t* seed, uint64_t stream_id) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const float* row = S + r * C;
+  float mx = -INFINITY;
+  for (int64_t j = lane; j < Cv; j += 64) mx = fmaxf(mx, row[j]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int64_t j = lane; j < Cv; j += 64) sum += expf(row[j] - mx);
+  const float inv = 1.f / wave_sum(sum);
+  const bool drop = Pd && seed && p > 0.f;
+  uint64_t key = 0;
+  float ik = 1.f;
+  if (drop) { key = rng_key(*seed, stream_id); ik = 1.f / (1.f - p); }
+  const uint64_t base = (uint64_t)(((r / Lq) * Cv + (r % Lq)) * Cv);
+  for (int64_t j = lane; j < C; j += 64) {
+    const float v = j < Cv ? expf(row[j] - mx) * inv : 0.f;
+    P[r * C + j] = v;
+    if (Pd) Pd[r * C + j] = (drop && j < Cv) ? v * rng_keep(key, base + (uint64_t)j, p, ik) : v;
+  }
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ P, const float* __restrict__ dPd,
+                                                               float* __restrict__ dS, int64_t R, int64_t C, int64_t Cv,
+                                                               int64_t Lq, float p, const uint64_t* seed, uint64_t stream_id) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const bool drop = seed && p > 0.f;
+  uint64_t key = 0;
+  float ik = 1.f;
+  if (drop) { key = rng_key(*seed, stream_id); ik = 1.f / (1.f - p); }
+  const uint64_t base = (uint64_t)(((r / Lq) * Cv + (r % Lq)) * Cv);
+  float c = 0.f;
+  for (int64_t j = lane; j < Cv; j += 64) {
+    float g = dPd[r * C + j];
+    if (drop) g *= rng_keep(key, base + (uint64_t)j, p, ik);
+    c += g * P[r * C + j];
+  }
+  c = wave_sum(c);
+  for (int64_t j = lane; j < C; j += 64) {
+    float g = j < Cv ? dPd[r * C + j] : 0.f;
+    if (drop && j < Cv) g *= rng_keep(key, base + (uint64_t)j, p, ik);
+    dS[r * C + j] = j < Cv ? P[r * C + j] * (g - c) : 0.f;
+  }
+}
+
+extern "C" int advmil_softmax_rows_fwd(const float* S, float* P, float* Pd, int64_t R, int64_t C, int64_t Cv, int64_t Lq,
+                                       float drop_p, const uint64_t* seed, uint64_t stream_id, advmil_stream_t stream) {
+  if (!S || !P || R <= 0 || C <= 0 || Cv <= 0 || Cv > C || Lq <= 0) return ADVMIL_EINVAL;
+  hipLaunchKernelGGL(softmax_rows_fwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, P, Pd, R, C,
+                     Cv, Lq, drop_p, seed, stream_id);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}
+
+extern "C" int advmil_softmax_rows_bwd(const float* P, const float* dPd, float* dS, int64_t R, int64_t C, int64_t Cv, int64_t Lq,
+                                       float drop_p, const uint64_t* seed, uint64_t stream_id, advmil_stream_t stream) {
+  if (!P || !dPd || !dS || R <= 0 || C <= 0 || Cv <= 0 || Cv > C || Lq <= 0) return ADVMIL_EINVAL;
+  hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, P, dPd, dS, R, C,
+                     Cv, Lq, drop_p, seed, stream_id);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}

@@ -481,21 +481,77 @@ def gate_scores(h, Wa, ba, Wb, bb, wc, bc, p=0.0, rng=None, tag=""):
     return GateScoreFn.apply(h, Wa, ba, Wb, bb, wc, bc, float(p), seed, sa, sb)
 
 
+def gemm_batched(A, B, a_kc, b_kc, M, N, K, lda, sA, ldb, sB, C, ldc, sC, batch, alpha=1.0, accumulate=False):
+    _lib.check(_lib.lib().advmil_gemm_f32_batched(1 if a_kc else 0, 1 if b_kc else 0, M, N, K, _p(A), lda, sA, _p(B), ldb, sB,
+                                                  _p(C), ldc, sC, batch, float(alpha), 1 if accumulate else 0, _stream()),
+               f"gemm_f32_batched[{batch}x{M}x{N}x{K}]")
+    return C
+
+
+def _off(t, n):
+    """View of a flat-addressable tensor starting n elements in (pointer arithmetic for strided heads)."""
+    return t.reshape(-1)[n:]
+
+
+class MhaFn(torch.autograd.Function):
+    """Self-attention core of the ESAT layer for one bag: packed qkv[L, 3d] -> O[L, d].
+    Per head h (strided slices, no permute copies):  S_h = Q_h K_h^T / sqrt(hd)  (batched MFMA GEMM)
+      -> P = dropout(softmax(S)) (row kernel, counter RNG index (h*L + i)*L + j) -> O_h = P_h V_h (batched MFMA GEMM,
+      written straight into O[:, h*hd:(h+1)*hd]).  Backward = four more batched GEMMs + one row kernel.
+    The token axis is padded to a multiple of 4 (16 B operand alignment); padded keys get probability 0."""
+
+    @staticmethod
+    def forward(ctx, qkv, nhead, p, seed, sid):
+        _chk(qkv, "qkv")
+        L, d3 = qkv.shape
+        Lp = (L + 3) // 4 * 4
+        qkv = qkv.contiguous() if Lp == L else torch.nn.functional.pad(qkv, (0, 0, 0, Lp - L)).contiguous()
+        d = d3 // 3
+        hd = d // nhead
+        dev = qkv.device
+        scale = 1.0 / float(hd) ** 0.5
+        S = torch.empty(nhead, Lp, Lp, dtype=torch.float32, device=dev)
+        gemm_batched(qkv, _off(qkv, d), True, True, Lp, Lp, hd, d3, hd, d3, hd, S, Lp, Lp * Lp, nhead, alpha=scale)
+        P = torch.empty_like(S)
+        Pd = torch.empty_like(S) if p > 0.0 else None
+        _lib.check(_lib.lib().advmil_softmax_rows_fwd(_p(S), _p(P), _p(Pd), nhead * Lp, Lp, L, Lp, p,
+                                                      _p(seed if p > 0.0 else None), sid, _stream()), "softmax_rows_fwd")
+        O = torch.empty(Lp, d, dtype=torch.float32, device=dev)
+        gemm_batched(Pd if Pd is not None else P, _off(qkv, 2 * d), True, False, Lp, hd, Lp, Lp, Lp * Lp, d3, hd, O, d, hd, nhead)
+        ctx.save_for_backward(qkv, P, Pd if Pd is not None else P)
+        ctx.cfg = (nhead, p, seed, sid, L, Lp, d, hd, scale)
+        return O[:L]
+
+    @staticmethod
+    def backward(ctx, dO):
+        qkv, P, Pd = ctx.saved_tensors
+        nhead, p, seed, sid, L, Lp, d, hd, scale = ctx.cfg
+        d3 = 3 * d
+        dev = qkv.device
+        dO = dO.contiguous() if Lp == L else torch.nn.functional.pad(dO, (0, 0, 0, Lp - L)).contiguous()
+        dqkv = torch.empty(Lp, d3, dtype=torch.float32, device=dev)
+        # dPd_h = dO_h V_h^T            [L, L]  (A = dO_h [L,hd] k-contig, B = V_h [L,hd] k-contig)
+        dPd = torch.empty(nhead, Lp, Lp, dtype=torch.float32, device=dev)
+        gemm_batched(dO, _off(qkv, 2 * d), True, True, Lp, Lp, hd, d, hd, d3, hd, dPd, Lp, Lp * Lp, nhead)
+        # dV_h = Pd_h^T dO_h            [L, hd] (A = Pd_h [K=L, M=L] m-contig, B = dO_h [K=L, N=hd] n-contig)
+        gemm_batched(Pd, dO, False, False, Lp, hd, Lp, Lp, Lp * Lp, d, hd, _off(dqkv, 2 * d), d3, hd, nhead)
+        dS = torch.empty_like(dPd)
+        _lib.check(_lib.lib().advmil_softmax_rows_bwd(_p(P), _p(dPd), _p(dS), nhead * Lp, Lp, L, Lp, p,
+                                                      _p(seed if p > 0.0 else None), sid, _stream()), "softmax_rows_bwd")
+        # dQ_h = scale * dS_h K_h       (A = dS_h [L, L] k-contig, B = K_h [K=L, N=hd] n-contig)
+        gemm_batched(dS, _off(qkv, d), True, False, Lp, hd, Lp, Lp, Lp * Lp, d3, hd, dqkv, d3, hd, nhead, alpha=scale)
+        # dK_h = scale * dS_h^T Q_h     (A = dS_h [K=L, M=L] m-contig, B = Q_h [K=L, N=hd] n-contig)
+        gemm_batched(dS, qkv, False, False, Lp, hd, Lp, Lp, Lp * Lp, d3, hd, _off(dqkv, d), d3, hd, nhead, alpha=scale)
+        return dqkv[:L], None, None, None, None
+
+
 def mha(qkv, nhead, p=0.0, rng=None):
-    """Self-attention core for one bag: qkv[L, 3d] (packed in-proj output) -> [L, d].
-    softmax(Q K^T / sqrt(hd)) with dropout p on the probabilities (index (h*L + i)*L + j), then P V.
-    TODO(K4): this is still batched-matmul plumbing through torch; the LDS-tiled MFMA flash kernel replaces it."""
-    L, d3 = qkv.shape
-    d = d3 // 3
-    hd = d // nhead
-    q, k, v = (t.reshape(L, nhead, hd).transpose(0, 1) for t in qkv.split(d, dim=1))
-    s = torch.matmul(q, k.transpose(-1, -2)) * (1.0 / float(hd) ** 0.5)
-    pr = torch.softmax(s, dim=-1)
+    sid, seed = 0, None
     if p > 0.0:
         rng = rng or default_rng(qkv.device)
-        u = rng.uniform(pr.numel(), "mha_attn").reshape(pr.shape)
-        pr = pr * (u >= p).to(pr.dtype) * (1.0 / (1.0 - p))
-    return torch.matmul(pr, v).transpose(0, 1).reshape(L, d)
+        L = qkv.shape[0]
+        sid, seed = rng.site("mha_attn", (nhead, L, L), p), rng.seed
+    return MhaFn.apply(qkv, nhead, float(p), seed, sid)
 
 
 class SegMeanFn(torch.autograd.Function):

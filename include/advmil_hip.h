@@ -76,6 +76,21 @@ int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, c
                           const float* B, int64_t ldb, float* C, int64_t ldc, const advmil_epilogue_t* epi,
                           int splits, int tile, void* ws, size_t ws_bytes, advmil_stream_t stream);
 
+/* Batched form for the ESAT attention heads (nn.MultiheadAttention inside nn.TransformerEncoderLayer,
+ * model/backbone_utils.py:113-127): batch b uses A + b*strideA, B + b*strideB, C + b*strideC (element strides), so the
+ * heads are read as strided slices of the packed qkv[L,3d] and written straight into O[L,d]. C = alpha*op(A)op(B) (+C). */
+int advmil_gemm_f32_batched(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                            int64_t strideA, const float* B, int64_t ldb, int64_t strideB, float* C, int64_t ldc,
+                            int64_t strideC, int batch, float alpha, int accumulate, advmil_stream_t stream);
+/* Row softmax of the attention scores S[R,C] with dropout on the probabilities: P = softmax(S) (kept for backward),
+ * Pd = P*keep (NULL = eval). bwd: dS = P * (dPd*keep - sum_j dPd_j*keep_j*P_j).
+ * C = row pitch, Cv <= C = number of real keys (columns >= Cv are alignment padding and get probability 0),
+ * Lq = rows per head. Dropout index ((r / Lq)*Cv + r % Lq)*Cv + j: the un-padded [H, L, L] layout. */
+int advmil_softmax_rows_fwd(const float* S, float* P, float* Pd, int64_t R, int64_t C, int64_t Cv, int64_t Lq, float drop_p,
+                            const uint64_t* seed, uint64_t stream_id, advmil_stream_t stream);
+int advmil_softmax_rows_bwd(const float* P, const float* dPd, float* dS, int64_t R, int64_t C, int64_t Cv, int64_t Lq,
+                            float drop_p, const uint64_t* seed, uint64_t stream_id, advmil_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Gated-attention MIL pooling (Attn_Net_Gated + softmax + mm: model/backbone_utils.py:11-29,
  * model/backbone.py:81-85, 118-122, 163-167; GAPool: model/backbone_utils.py:47-56).

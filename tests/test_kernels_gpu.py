@@ -189,3 +189,23 @@ def test_adam_matches_oracle(ops):
     ref = torch.cat([P["w.weight"].reshape(-1), P["w.bias"]])
     assert float((pd.cpu() - ref).abs().max()) < 1e-7
     assert int(step.item()) == 3
+
+
+@pytest.mark.parametrize("L,p", [(32, 0.0), (512, 0.25), (210, 0.25), (70, 0.0)])
+def test_mha_batched_heads(ops, L, p):
+    """ESAT attention core: batched-head MFMA GEMMs + row softmax/dropout vs float64 torch (masks regenerated on host)."""
+    H_, d = 8, 384
+    qkv = rnd(f"mq{L}", L, 3 * d, scale=0.5); go = rnd(f"mg{L}", L, d)
+    q = qkv.clone().to(DEV).requires_grad_(True)
+    rng = ops.DeviceRng(DEV, seed=31)
+    o = ops.mha(q, H_, p, rng)
+    (o * go.to(DEV)).sum().backward()
+    r = qkv.clone().double().requires_grad_(True)
+    qq, kk, vv = (t.reshape(L, H_, 48).transpose(0, 1) for t in r.split(d, dim=1))
+    pr = torch.softmax(qq @ kk.transpose(-1, -2) / 48 ** 0.5, dim=-1)
+    if p > 0:
+        pr = pr * H.T(synth.dropout_keep(31, 1, H_ * L * L, p).reshape(H_, L, L)).double() / (1 - p)
+    orf = (pr @ vv).transpose(0, 1).reshape(L, d)
+    (orf * go.double()).sum().backward()
+    assert relerr(o, orf) < 1e-5
+    assert relerr(q.grad, r.grad) < 5e-5
