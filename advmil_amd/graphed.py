@@ -13,7 +13,8 @@ import torch
 
 
 class GraphedStep:
-    def __init__(self, handler, xs, ys, ys_host, mode="wlabel", label_visible_mask=None, warmup=2):
+    def __init__(self, handler, xs, ys, ys_host, mode="wlabel", label_visible_mask=None, warmup=2, force_segments=False):
+        self.force_segments = force_segments
         self.h = handler
         self.xs, self.ys = xs, ys
         self.plan = handler._plan(xs, ys, mode, label_visible_mask, ys_host)   # python ints: baked into the graph
@@ -56,13 +57,14 @@ class GraphedStep:
         torch.cuda.synchronize()
         h.history.clear()
         pool = torch.cuda.graph_pool_handle()
-        if h.dp.world > 1:
+        if h.dp.world > 1 or self.force_segments:
             parts = (self._seg_disc, self._seg_mid, self._seg_end)
         else:
             parts = (lambda: (self._seg_disc(), self._seg_mid(), self._seg_end()),)
         for fn in parts:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            # thread_local: RCCL's watchdog thread may query events while this thread captures
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                 fn()
             self.segments.append(g)
         self.logs = list(h.history)                          # device scalars rewritten by every replay

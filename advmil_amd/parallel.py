@@ -72,10 +72,10 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("ADVMIL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
-            torch.cuda.set_device(local)
-            kw["device_id"] = torch.device("cuda", local)
+            torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+            kw["device_id"] = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local

@@ -159,18 +159,30 @@ def main():
 
     # HIP graphs: one captured step per group of resident bags (the pool is cut into n_pool/bags groups)
     graphs = []
+    launch_note = "eager"
     if not args.eager:
         from advmil_amd.graphed import GraphedStep
-        for g0 in range(0, n_pool - args.bags + 1, args.bags):
-            idx = list(range(g0, g0 + args.bags))
-            graphs.append(GraphedStep(h, [xs[i] for i in idx], [ys[i] for i in idx], [ys_host[i] for i in idx], warmup=1))
+        try:
+            for g0 in range(0, n_pool - args.bags + 1, args.bags):
+                idx = list(range(g0, g0 + args.bags))
+                graphs.append(GraphedStep(h, [xs[i] for i in idx], [ys[i] for i in idx], [ys_host[i] for i in idx], warmup=1))
+            launch_note = f"hipGraph replay ({len(graphs)} captured bag groups" + (", 3 segments around the 2 all-reduces)" if world > 1 else ")")
+        except Exception as exc:          # never lose the run to a capture problem: the eager schedule is the same step
+            graphs = []
+            torch.cuda.synchronize()
+            launch_note = f"eager (graph capture failed: {type(exc).__name__}: {str(exc)[:120]})"
+    ok = torch.tensor([1.0 if (graphs or args.eager) else 0.0], device=dev)
+    if world > 1:                          # all ranks must take the same path
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if float(ok.item()) == 0.0:
+        graphs = []
 
     def graph_step():
         g = graphs[cursor[0] % len(graphs)]
         cursor[0] += 1
         g.replay()
 
-    step = eager_step if args.eager else graph_step
+    step = graph_step if graphs else eager_step
 
     def barrier():
         if world > 1:
@@ -189,8 +201,17 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    logs = h.pop_logs() if args.eager else [{k: float(v) for k, v in d.items() if k != "i_batch"} for g in graphs for d in g.logs]
+    logs = h.pop_logs() if not graphs else [{k: float(v) for k, v in d.items() if k != "i_batch"} for g in graphs for d in g.logs]
     finite = all(v == v and abs(v) != float("inf") for d in logs for v in d.values())
+
+    # replicas must hold bit-identical weights after the timed steps (same reduced gradients, same Adam)
+    in_sync = True
+    if world > 1:
+        cs = torch.stack([h.optimizerG.flat_param.double().sum(), h.optimizerD.flat_param.double().sum()])
+        hi, lo = cs.clone(), cs.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        in_sync = bool(torch.equal(hi, lo))
 
     # ---- roofline of the dominant kernel.
     # (1) an instrumented eager pass over the same steps brackets every GEMM launch with HIP events on the launch
@@ -265,8 +286,8 @@ def main():
                                    f"(BASELINE.json configs[1] shape; fp32 storage+MFMA-f32 arithmetic instead of bf16)",
                        "bags_per_step_per_gpu": args.bags, "global_bags_per_step": args.bags * world, "gen_updates": 1,
                        "distinct_resident_bags_per_gpu": n_pool, "parallelism": f"bag-parallel dp{world}", "dropout": "shipped rates",
-                       "launch": "eager" if args.eager else f"hipGraph replay ({len(graphs)} captured bag groups)"},
-            "gd_steps_per_sec": round(args.steps / dt, 3), "losses_finite": bool(finite),
+                       "launch": launch_note},
+            "gd_steps_per_sec": round(args.steps / dt, 3), "losses_finite": bool(finite), "replicas_in_sync": in_sync,
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

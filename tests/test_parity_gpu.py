@@ -276,3 +276,35 @@ def test_full_size_properties(N):
         close(pooled, ref, 1e-5)
         pooled2, _, _ = gate.pool(2.0 * h)   # different scores, but pooled must still be the A-weighted mean
     assert torch.isfinite(pooled2).all()
+
+
+def test_graphed_step_equals_eager_step():
+    """HIP-graph replay (single graph and the 3-segment form used under bag-parallel) reproduces the eager schedule:
+    dropout off, generator noise off (zero-width effect removed by injecting the same tensors), same bags."""
+    from advmil_amd.graphed import GraphedStep
+    res = {}
+    for mode in ("eager", "graph", "segments"):
+        h, _, _ = make_handler("abmil", bp_every_batch=4)
+        zero_dropout(h.netG); zero_dropout(h.netD)
+        h.netG.noise = [0, 0]                       # no noise concat: rebuild the last layer for the narrower input
+        torch.manual_seed(0)
+        h.netG.MLPs[1][0] = torch.nn.Linear(192, 1).to(DEV)
+        from advmil_amd.optim import create_optimizer
+        from types import SimpleNamespace
+        h.optimizerG = create_optimizer(SimpleNamespace(opt="adam", weight_decay=5e-4, lr=8e-5, opt_eps=None, opt_betas=None), h.netG)
+        h.optimizerG.l1_coef = 1e-5
+        xs = [[H.bag(i, 512, DEV), torch.zeros(1, 1, device=DEV)] for i in range(4)]
+        ys_host = [H.label(i) for i in range(4)]
+        ys = [y.to(DEV) for y in ys_host]
+        if mode == "eager":
+            for _ in range(3):
+                h._update_disc(0, xs, ys, ys_host=ys_host)
+                h._update_gen(0, xs, ys, ys_host=ys_host)
+        else:
+            g = GraphedStep(h, xs, ys, ys_host, warmup=1, force_segments=(mode == "segments"))
+            g.replay(); g.replay()                  # 1 warm-up step + 2 replays = 3 steps
+        torch.cuda.synchronize()
+        res[mode] = (h.optimizerG.flat_param.clone(), h.optimizerD.flat_param.clone())
+    for mode in ("graph", "segments"):
+        for a, b in zip(res["eager"], res[mode]):
+            assert float((a - b).abs().max()) < 1e-6, mode
