@@ -446,7 +446,8 @@ extern "C" int advmil_colsum(const float* x, int64_t M, int64_t N, float* out, i
 __global__ __launch_bounds__(256) void ln_relu_mean16_fwd_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, float eps, int64_t N,
                                                                  int64_t d, float* __restrict__ emb,
-                                                                 float* __restrict__ mean, float* __restrict__ rstd) {
+                                                                 float* __restrict__ mean, float* __restrict__ rstd,
+                                                                 int pool16) {
   __shared__ float red[4 * 512];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t g = blockIdx.x;
@@ -461,6 +462,7 @@ __global__ __launch_bounds__(256) void ln_relu_mean16_fwd_kernel(const float* __
   const float invd = 1.f / (float)d;
   for (int rr = 0; rr < 4; ++rr) {
     const int64_t n = g * 16 + w * 4 + rr;
+    if (n >= N) break;
     const float* row = y + n * d;
     float v[LN_MAXQ];
     float s = 0.f;
@@ -483,9 +485,13 @@ __global__ __launch_bounds__(256) void ln_relu_mean16_fwd_kernel(const float* __
 #pragma unroll
     for (int q = 0; q < LN_MAXQ; ++q) {
       const float z = (v[q] - mu) * rs * gm[q] + bt[q];
-      acc[q] += z > 0.f ? z : 0.f;
+      const float zr = z > 0.f ? z : 0.f;
+      acc[q] += zr;
+      const int64_t j = lane + 64 * q;
+      if (!pool16 && q < Q && j < d) emb[n * d + j] = zr;          // plain LayerNorm+ReLU rows (GENConv MLP)
     }
   }
+  if (!pool16) return;
 #pragma unroll
   for (int q = 0; q < LN_MAXQ; ++q) {
     const int64_t j = lane + 64 * q;
@@ -500,7 +506,16 @@ extern "C" int advmil_ln_relu_mean16_fwd(const float* y, const float* gamma, con
                                          int64_t d, float* emb, float* mean, float* rstd, advmil_stream_t stream) {
   if (!y || !gamma || !beta || !emb || !mean || !rstd || N <= 0 || (N & 15) || d <= 0 || d > 512) return ADVMIL_EINVAL;
   hipLaunchKernelGGL(ln_relu_mean16_fwd_kernel, dim3((unsigned)(N / 16)), dim3(256), 0, (hipStream_t)stream, y, gamma, beta,
-                     eps, N, d, emb, mean, rstd);
+                     eps, N, d, emb, mean, rstd, 1);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}
+
+extern "C" int advmil_ln_relu_fwd(const float* y, const float* gamma, const float* beta, float eps, int64_t N, int64_t d,
+                                  float* out, float* mean, float* rstd, advmil_stream_t stream) {
+  if (!y || !gamma || !beta || !out || !mean || !rstd || N <= 0 || d <= 0 || d > 512) return ADVMIL_EINVAL;
+  hipLaunchKernelGGL(ln_relu_mean16_fwd_kernel, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, (hipStream_t)stream, y, gamma,
+                     beta, eps, N, d, out, mean, rstd, 0);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }
@@ -509,7 +524,7 @@ __global__ __launch_bounds__(256) void ln_relu_mean16_bwd_kernel(const float* __
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  int64_t N, int64_t d, float* __restrict__ dy,
-                                                                 float* __restrict__ partial) {
+                                                                 float* __restrict__ partial, int pool16) {
   __shared__ float red[4 * 1024];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t g = blockIdx.x;
@@ -520,14 +535,22 @@ __global__ __launch_bounds__(256) void ln_relu_mean16_bwd_kernel(const float* __
     const int64_t j = lane + 64 * q;
     const bool ok = q < Q && j < d;
     gm[q] = ok ? gamma[j] : 0.f; bt[q] = ok ? beta[j] : 0.f;
-    de[q] = ok ? demb[g * d + j] * (1.f / 16.f) : 0.f;
+    de[q] = (ok && pool16) ? demb[g * d + j] * (1.f / 16.f) : 0.f;
     ag[q] = 0.f; abt[q] = 0.f;
   }
   const float invd = 1.f / (float)d;
   for (int rr = 0; rr < 4; ++rr) {
     const int64_t n = g * 16 + w * 4 + rr;
+    if (n >= N) break;
     const float* row = y + n * d;
     const float mu = mean[n], rs = rstd[n];
+    if (!pool16) {
+#pragma unroll
+      for (int q = 0; q < LN_MAXQ; ++q) {
+        const int64_t j = lane + 64 * q;
+        de[q] = (q < Q && j < d) ? demb[n * d + j] : 0.f;
+      }
+    }
     float xh[LN_MAXQ], dxh[LN_MAXQ];
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
@@ -579,7 +602,29 @@ extern "C" int advmil_ln_relu_mean16_bwd(const float* demb, const float* y, cons
   const int L = (int)(N / 16);
   float* partial = (float*)ws;
   hipLaunchKernelGGL(ln_relu_mean16_bwd_kernel, dim3(L), dim3(256), 0, stream, demb, y, gamma, beta, mean, rstd, N, d, dy,
-                     partial);
+                     partial, 1);
+  ADVMIL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial, L, 2 * d, d, dgamma, accumulate);
+  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial + d, L, 2 * d, d, dbeta, accumulate);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}
+
+extern "C" size_t advmil_ln_relu_bwd_workspace_bytes(int64_t N, int64_t d) {
+  return (size_t)(((N + 15) / 16) * 2 * d) * sizeof(float);
+}
+
+extern "C" int advmil_ln_relu_bwd(const float* dout, const float* y, const float* gamma, const float* beta, const float* mean,
+                                  const float* rstd, int64_t N, int64_t d, float* dy, float* dgamma, float* dbeta,
+                                  int accumulate, void* ws, size_t ws_bytes, advmil_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!dout || !y || !gamma || !beta || !mean || !rstd || !dy || !dgamma || !dbeta || !ws || N <= 0 || d <= 0 || d > 512)
+    return ADVMIL_EINVAL;
+  if (ws_bytes < advmil_ln_relu_bwd_workspace_bytes(N, d)) return ADVMIL_EWORKSPACE;
+  const int L = (int)((N + 15) / 16);
+  float* partial = (float*)ws;
+  hipLaunchKernelGGL(ln_relu_mean16_bwd_kernel, dim3(L), dim3(256), 0, stream, dout, y, gamma, beta, mean, rstd, N, d, dy,
+                     partial, 0);
   ADVMIL_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial, L, 2 * d, d, dgamma, accumulate);
   hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial + d, L, 2 * d, d, dbeta, accumulate);

@@ -121,9 +121,59 @@ class DualTrans_HS(nn.Module):
         return H
 
 
+class _GENConvParams(nn.Module):
+    """Parameter holder with torch_geometric.nn.GENConv's state_dict keys: `t` [1] and `mlp.{0,1,4}`
+    (Linear(d,2d), LayerNorm(2d), ReLU, Dropout, Linear(2d,d); num_layers=2, norm='layer')."""
+
+    def __init__(self, dim, t=1.0):
+        super().__init__()
+        self.t = nn.Parameter(torch.tensor([float(t)]))
+        self.mlp = nn.Sequential(nn.Linear(dim, 2 * dim), nn.LayerNorm(2 * dim), nn.ReLU(), nn.Dropout(0.0), nn.Linear(2 * dim, dim))
+        self.eps = 1e-7
+
+
+class _DeepGCNLayerParams(nn.Module):
+    """DeepGCNLayer(conv, norm, act): only `conv` runs when num_layers == 1 (model/backbone.py:157); `norm` exists in
+    the reference's state_dict, so it exists here."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.conv = _GENConvParams(dim)
+        self.norm = nn.LayerNorm(dim, elementwise_affine=True)
+        self.act = nn.ReLU(inplace=True)
+
+
 class PatchGCN(nn.Module):
-    """Placeholder until the GENConv softmax-gather kernel lands (parity unpinned: torch_geometric absent)."""
+    """FC -> GENConv(softmax aggr, learnable t) -> cat -> FC -> gated attention pool. `x_path` is a graph object with
+    `.x [N, dim_in]` and `.edge_index [2, E]` (a torch_geometric Batch in the reference; any object with those two
+    attributes here). Parity unpinned (GENConv's arithmetic is torch_geometric's, absent and unversioned)."""
 
     def __init__(self, dims: List, num_layers: int = 3, edge_agg: str = "spatial", dropout: float = 0.25):
         super().__init__()
-        raise NotImplementedError("PatchGCN (bcb_mode: graph) is scheduled after the ESAT kernels; see DESIGN.md")
+        assert len(dims) == 3
+        dim_in, dim_hid, dim_out = dims
+        if num_layers != 1:
+            raise NotImplementedError("HIP PatchGCN covers num_layers=1, the value load_backbone_param ships (backbone.py:40)")
+        self.edge_agg, self.num_layers = edge_agg, num_layers
+        self.fc = nn.Sequential(nn.Linear(dim_in, dim_hid), nn.ReLU(), nn.Dropout(dropout))
+        self.layers = nn.ModuleList([_DeepGCNLayerParams(dim_hid) for _ in range(num_layers)])
+        self.path_phi = nn.Sequential(nn.Linear(dim_hid * (1 + num_layers), dim_out), nn.ReLU(), nn.Dropout(dropout))
+        self.path_attention_head = Attn_Net_Gated(L=dim_out, D=dim_out, dropout=dropout, n_classes=1)
+
+    def forward(self, x_path, *args):
+        data = x_path
+        x_in = data.x
+        rng = _rng_of(self, x_in)
+        tr = self.training
+        csr = ops.graph_csr(data)
+        x = ops.linear_act(x_in, self.fc[0].weight, self.fc[0].bias, "relu", self.fc[2].p if tr else 0.0, rng, "gcn_fc")
+        conv = self.layers[0].conv
+        agg = ops.genconv_aggregate(x, conv.t, csr, conv.eps)
+        hmid = ops.linear_act(agg, conv.mlp[0].weight, conv.mlp[0].bias, "none")
+        hmid = ops.ln_relu(hmid, conv.mlp[1].weight, conv.mlp[1].bias, conv.mlp[1].eps)
+        x1 = ops.linear_act(hmid, conv.mlp[4].weight, conv.mlp[4].bias, "none")
+        h = torch.cat([x, x1], dim=1)
+        h = ops.linear_act(h, self.path_phi[0].weight, self.path_phi[0].bias, "relu", self.path_phi[2].p if tr else 0.0, rng, "gcn_phi")
+        pooled, A, _ = self.path_attention_head.pool(h)
+        self.last_attention = A.detach()
+        return pooled.unsqueeze(0)

@@ -579,3 +579,111 @@ def segmented_mean(h, seg_id, num_segments):
     onehot = torch.nn.functional.one_hot(seg_id.reshape(-1).to(device=h.device, dtype=torch.long), S).to(h.dtype)
     wn = (onehot / onehot.sum(dim=0).clamp_min(1.0)).contiguous()
     return SegMeanFn.apply(h, wn)[:num_segments]
+
+
+# ---------------------------------------------------------------------------------------
+# PatchGCN pieces: LayerNorm+ReLU rows, graph CSR images, GENConv softmax aggregation
+# ---------------------------------------------------------------------------------------
+class LNReLUFn(torch.autograd.Function):
+    """relu(LayerNorm(y)) per row (GENConv's norm='layer' MLP)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, eps):
+        _chk(y, "y")
+        y = y.contiguous()
+        N, d = y.shape
+        out = torch.empty_like(y)
+        mean = torch.empty(N, dtype=torch.float32, device=y.device)
+        rstd = torch.empty(N, dtype=torch.float32, device=y.device)
+        _lib.check(_lib.lib().advmil_ln_relu_fwd(_p(y), _p(gamma), _p(beta), eps, N, d, _p(out), _p(mean), _p(rstd), _stream()),
+                   "ln_relu_fwd")
+        ctx.save_for_backward(y, gamma.detach(), beta.detach(), mean, rstd)
+        gg, gb = _arena_grad(gamma), _arena_grad(beta)
+        ctx.arena = (gg, gb) if (gg is not None and gb is not None) else None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, gamma, beta, mean, rstd = ctx.saved_tensors
+        N, d = y.shape
+        L = _lib.lib()
+        dy = torch.empty_like(y)
+        acc = ctx.arena is not None
+        dg = ctx.arena[0] if acc else torch.empty(d, dtype=torch.float32, device=y.device)
+        db = ctx.arena[1] if acc else torch.empty(d, dtype=torch.float32, device=y.device)
+        wsb = L.advmil_ln_relu_bwd_workspace_bytes(N, d)
+        ws = _ws(wsb, y.device)
+        _lib.check(L.advmil_ln_relu_bwd(_p(dout.contiguous()), _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), N, d, _p(dy), _p(dg),
+                                        _p(db), 1 if acc else 0, _p(ws), wsb, _stream()), "ln_relu_bwd")
+        return (dy, None, None, None) if acc else (dy, dg, db, None)
+
+
+def ln_relu(y, gamma, beta, eps=1e-5):
+    return LNReLUFn.apply(y, gamma, beta, eps)
+
+
+class GraphCSR:
+    """Both CSR images of a WSI patch graph edge_index[2, E] (row 0 = source, row 1 = target; layout of
+    tools/patchgcn_graph_s2.py:78-80). Built once per graph with integer device ops (sort / bincount / cumsum)."""
+
+    def __init__(self, edge_index, num_nodes):
+        ei = edge_index.to(torch.long)
+        src, dst = ei[0], ei[1]
+        self.N = int(num_nodes)
+        self.E = int(src.numel())
+        self.rowptr_dst, self.col_src = self._csr(dst, src)
+        self.rowptr_src, self.col_dst = self._csr(src, dst)
+
+    def _csr(self, key, val):
+        order = torch.argsort(key, stable=True)
+        counts = torch.bincount(key, minlength=self.N)
+        rowptr = torch.zeros(self.N + 1, dtype=torch.int32, device=key.device)
+        rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        return rowptr.contiguous(), val[order].to(torch.int32).contiguous()
+
+
+def graph_csr(data):
+    """Cached GraphCSR of a graph object with `.edge_index` (and `.x`)."""
+    g = getattr(data, "_advmil_csr", None)
+    if g is None:
+        g = GraphCSR(data.edge_index, data.x.shape[0])
+        try:
+            data._advmil_csr = g
+        except Exception:
+            pass
+    return g
+
+
+class GenConvAggFn(torch.autograd.Function):
+    """out = softmax-aggregated messages + x (GENConv before its MLP); t is the learnable temperature [1]."""
+
+    @staticmethod
+    def forward(ctx, x, t, csr, eps):
+        _chk(x, "x")
+        x = x.contiguous()
+        N, C = x.shape
+        out = torch.empty_like(x)
+        lse = torch.empty_like(x)
+        m2 = torch.empty_like(x)
+        _lib.check(_lib.lib().advmil_genconv_fwd(_p(x), _p(csr.rowptr_dst), _p(csr.col_src), _p(t), eps, N, C, _p(out), _p(lse),
+                                                 _p(m2), _stream()), "genconv_fwd")
+        ctx.save_for_backward(x, t.detach(), out, lse, m2)
+        ctx.csr, ctx.eps = csr, eps
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, t, out, lse, m2 = ctx.saved_tensors
+        csr = ctx.csr
+        N, C = x.shape
+        dout = dout.contiguous()
+        dx = torch.empty_like(x)
+        _lib.check(_lib.lib().advmil_genconv_bwd(_p(dout), _p(x), _p(out), _p(lse), _p(csr.rowptr_src), _p(csr.col_dst), _p(t),
+                                                 ctx.eps, N, C, _p(dx), _stream()), "genconv_bwd")
+        agg = out - x
+        dt = (dout * (m2 - agg * agg)).sum().reshape(1)          # d/dt of the softmax weights, reduced over nodes x channels
+        return dx, dt, None, None
+
+
+def genconv_aggregate(x, t, csr, eps=1e-7):
+    return GenConvAggFn.apply(x, t, csr, eps)

@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bags", type=int, default=16, help="bags per optimizer step per GPU (bp_every_batch)")
     ap.add_argument("--patches", type=int, default=8192)
-    ap.add_argument("--mode", default="abmil", choices=["abmil", "patch", "cluster"])
+    ap.add_argument("--mode", default="abmil", choices=["abmil", "patch", "cluster", "graph"])
     ap.add_argument("--pool", type=int, default=64, help="distinct resident bags per GPU")
     ap.add_argument("--eager", action="store_true", help="drive the step eagerly instead of replaying HIP graphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -55,6 +55,12 @@ def make_pool(torch, dev, mode, n_pool, n_patches, seed):
         x = torch.randn(1, n_patches, 1024, device=dev, generator=g)
         if mode == "cluster":
             ext = torch.randint(0, 8, (1, n_patches), device=dev, generator=g).float()
+        elif mode == "graph":   # patches on a sqrt(N) grid, 8-NN (tools/patchgcn_graph_s2.py:66-80 layout)
+            from types import SimpleNamespace
+            from advmil_amd import synth
+            if i == 0:
+                make_pool.ei = torch.from_numpy(synth.grid_knn_graph(n_patches, 8)).to(dev)
+            ext = SimpleNamespace(x=x[0], edge_index=make_pool.ei)
         else:
             ext = torch.zeros(1, 1, device=dev)
         t = 0.05 + 0.9 * float(torch.rand((), device=dev, generator=g))
@@ -73,8 +79,9 @@ def cpu_baseline(args, torch):
     import advmil_amd.model.GANSurv as GS
     nthreads = torch.get_num_threads()
     kind, N, nb = args.mode, args.patches, args.cpu_bags
-    bb = load_backbone(kind, [1024, 384, 384])
-    G = Generator(384, 1, bb, SimpleNamespace(noise=[0, 1], hops=1, noise_dist="uniform"), False, 0.6, "sigmoid")
+    dg = 128 if kind == "graph" else 384
+    bb = load_backbone(kind, [1024, dg, dg])
+    G = Generator(dg, 1, bb, SimpleNamespace(noise=[0, 1], hops=1, noise_dist="uniform"), False, 0.6, "sigmoid")
     from advmil_amd.model.model_utils import init_weights
     G.apply(init_weights)
     ax = SimpleNamespace(in_dim=1024, out_dim=128, ksize=1, backbone="avgpool", dropout=0.25)
@@ -83,7 +90,10 @@ def cpu_baseline(args, torch):
     PG = {k: v.detach().clone() for k, v in G.state_dict().items()}
     PD = {k: v.detach().clone() for k, v in D.state_dict().items()}
     gen = torch.Generator().manual_seed(0)
-    bags = [(torch.randn(1, N, 1024, generator=gen), (torch.randint(0, 8, (N,), generator=gen).float() if kind == "cluster" else None),
+    from advmil_amd import synth as _synth
+    ei = torch.from_numpy(_synth.grid_knn_graph(N, 8)) if kind == "graph" else None
+    bags = [(torch.randn(1, N, 1024, generator=gen),
+             (torch.randint(0, 8, (N,), generator=gen).float() if kind == "cluster" else ei),
              torch.tensor([[0.3 + 0.05 * i, float(i % 2)]])) for i in range(nb)]
     L = N // 16
 
@@ -95,10 +105,12 @@ def cpu_baseline(args, torch):
             m = {"fc": drop((N, 384), .25), "att_a": drop((N, 384), .25), "att_b": drop((N, 384), .25), "rho": drop((1, 384), .25)}
         elif kind == "cluster":
             m = {"fc": drop((8, 384), .25), "att_a": drop((8, 384), .25), "att_b": drop((8, 384), .25)}
+        elif kind == "graph":
+            m = {"fc": drop((N, 128), .25), "phi": drop((N, 128), .25), "att_a": drop((N, 128), .25), "att_b": drop((N, 128), .25)}
         else:
             m = {"attn": drop((1, 8, L, L), .25), "drop1": drop((1, L, 384), .25), "ffn": drop((1, L, 384), .25),
                  "drop2": drop((1, L, 384), .25), "pool_a": drop((1, L, 384), .25), "pool_b": drop((1, L, 384), .25)}
-        m["mlp0"] = drop((1, 192), .6)
+        m["mlp0"] = drop((1, dg // 2), .6)
         return m
 
     def masks_d():
@@ -107,8 +119,8 @@ def cpu_baseline(args, torch):
     cfg = O.StepConfig(kind=kind)
 
     def one_step():
-        nd = [[torch.rand(1, 192)] for _ in range(nb)]
-        ng = [[torch.rand(1, 192)] for _ in range(nb)]
+        nd = [[torch.rand(1, dg // 2)] for _ in range(nb)]
+        ng = [[torch.rand(1, dg // 2)] for _ in range(nb)]
         O.train_step(cfg, PG, PD, {}, {}, bags, nd, ng, [masks_d() for _ in range(nb)], [masks_d() for _ in range(nb)],
                      [masks_g() for _ in range(nb)])
 
@@ -141,6 +153,8 @@ def main():
     torch.cuda.set_device(dev)
 
     cfg = default_cfg(bcb_mode=args.mode, bp_every_batch=args.bags, cuda_id=dev.index)
+    if args.mode == "graph":            # PatchGCN dims of the reference's model_stats.py:63
+        cfg.update(bcb_dims="1024-128-128", gen_dims="128-1")
     h = MyHandler(cfg, device=dev)
     n_pool = max(args.pool, args.bags)
     xs, ys, ys_host = make_pool(torch, dev, args.mode, n_pool, args.patches, seed=1234 + rank)

@@ -143,6 +143,28 @@ int advmil_ln_relu_mean16_bwd(const float* demb, const float* y, const float* ga
                               const float* mean, const float* rstd, int64_t N, int64_t d, float* dy, float* dgamma,
                               float* dbeta, int accumulate, void* ws, size_t ws_bytes, advmil_stream_t stream);
 
+/* Plain row-wise LayerNorm(d) -> ReLU (the norm='layer' MLP inside GENConv; N arbitrary). Same kernels as above. */
+int advmil_ln_relu_fwd(const float* y, const float* gamma, const float* beta, float eps, int64_t N, int64_t d, float* out,
+                       float* mean, float* rstd, advmil_stream_t stream);
+size_t advmil_ln_relu_bwd_workspace_bytes(int64_t N, int64_t d);
+int advmil_ln_relu_bwd(const float* dout, const float* y, const float* gamma, const float* beta, const float* mean,
+                       const float* rstd, int64_t N, int64_t d, float* dy, float* dgamma, float* dbeta, int accumulate,
+                       void* ws, size_t ws_bytes, advmil_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * PatchGCN's GENConv softmax aggregation (model/backbone.py:139,157 -> torch_geometric.nn.GENConv, aggr='softmax',
+ * learn_t; parity unpinned: restated from the published semantics). x[N,C]; the graph arrives as two int32 CSR images:
+ *   by destination (rowptr_dst[N+1], col_src[E] = source of each in-edge)  -> forward
+ *   by source      (rowptr_src[N+1], col_dst[E] = target of each out-edge) -> backward
+ * fwd: out = sum_j softmax_j(t*m_j) m_j + x, m = relu(x)+eps; saves lse (log-sum-exp of t*m over in-edges) and
+ *      m2 = sum_j w m^2 (for dt = sum dout*(m2 - agg^2), reduced on the caller's side).
+ * bwd: dx = dout + relu'(x) * sum_{j->i} dout_i w_ij (1 + t (m_j - agg_i)). No atomics in either direction. */
+int advmil_genconv_fwd(const float* x, const int32_t* rowptr_dst, const int32_t* col_src, const float* t, float eps, int64_t N,
+                       int64_t C, float* out, float* lse, float* m2, advmil_stream_t stream);
+int advmil_genconv_bwd(const float* dout, const float* x, const float* out, const float* lse, const int32_t* rowptr_src,
+                       const int32_t* col_dst, const float* t, float eps, int64_t N, int64_t C, float* dx,
+                       advmil_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Optimizer + regulariser over a flat parameter arena (torch.optim.Adam, L2-in-grad weight decay:
  * optim/optim_factory.py:25-37,76-77; model/model_handler.py:104-107; L1: loss/utils.py:6-14).

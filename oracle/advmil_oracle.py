@@ -249,7 +249,7 @@ def backbone_forward(kind, P, x, x_ext, masks=None):
     if kind == "cluster":
         return deep_att_misl(P, x, x_ext, masks)
     if kind == "graph":
-        return patch_gcn(P, x, x_ext, masks)
+        return patch_gcn(P, x.squeeze(0) if x.dim() == 3 else x, x_ext, masks)
     return abmil(P, x, masks)
 
 

@@ -49,6 +49,16 @@ def shapes_generator(kind, c=1024, d=384):
                   t + "linear1.weight": (d, d), t + "linear1.bias": (d,), t + "linear2.weight": (d, d), t + "linear2.bias": (d,),
                   t + "norm1.weight": (d,), t + "norm1.bias": (d,), t + "norm2.weight": (d,), t + "norm2.bias": (d,)})
         s.update(shapes_gapool(b + "pool.", d))
+    elif kind == "graph":
+        d = 128
+        s = dict(shapes_head(d))
+        c_ = b + "layers.0.conv."
+        s.update({b + "fc.0.weight": (d, c), b + "fc.0.bias": (d,), c_ + "t": (1,),
+                  c_ + "mlp.0.weight": (2 * d, d), c_ + "mlp.0.bias": (2 * d,), c_ + "mlp.1.weight": (2 * d,), c_ + "mlp.1.bias": (2 * d,),
+                  c_ + "mlp.4.weight": (d, 2 * d), c_ + "mlp.4.bias": (d,),
+                  b + "layers.0.norm.weight": (d,), b + "layers.0.norm.bias": (d,),
+                  b + "path_phi.0.weight": (d, 2 * d), b + "path_phi.0.bias": (d,)})
+        s.update(shapes_attn_gated(b + "path_attention_head.", d))
     else:
         raise ValueError(kind)
     return s

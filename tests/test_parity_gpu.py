@@ -308,3 +308,49 @@ def test_graphed_step_equals_eager_step():
     for mode in ("graph", "segments"):
         for a, b in zip(res["eager"], res[mode]):
             assert float((a - b).abs().max()) < 1e-6, mode
+
+
+@pytest.mark.parametrize("p_on", [False, True])
+def test_patchgcn_vs_oracle(p_on):
+    """PatchGCN (GENConv softmax gather, HIP) against the oracle's restatement on a synthetic 8-NN grid graph --
+    forward + all parameter gradients. PARITY UNPINNED against upstream torch_geometric (absent): self-consistency only."""
+    from types import SimpleNamespace
+    from advmil_amd import ops
+    from advmil_amd.model import Generator, load_backbone
+    N = 500                                               # not a multiple of 16/64: ragged node count
+    bb = load_backbone("graph", [1024, 128, 128])
+    g = Generator(128, 1, bb, SimpleNamespace(noise=[0, 1], hops=1, noise_dist="uniform"), False, 0.6, "sigmoid").to(DEV)
+    assert set(g.state_dict().keys()) == set(H.shapes_generator("graph").keys())
+    PG = load_synth(g, "G-graph:")
+    g.train(p_on)
+    rng = ops.DeviceRng(DEV, seed=77); rng.record = True
+    for m in g.modules():
+        m.rng = rng
+    x = H.bag(9, 512, DEV)[0, :N].contiguous()
+    ei = H.T(synth.grid_knn_graph(N, 8), DEV)
+    data = SimpleNamespace(x=x, edge_index=ei)
+    nz = [H.noise_tensor("gcn", 0, 64, DEV)]
+    pred = g(data, None, noise=nz)
+    pred.sum().backward()
+    masks = None
+    if p_on:
+        def mk(tag):
+            e = [e for e in rng.log if e[0] == tag][0]
+            return H.T(synth.dropout_keep(77, e[1], int(np.prod(e[2])), e[3]).reshape(e[2]).astype(np.float32) / (1 - e[3]))
+        def small(tag, p, shape):
+            e = [e for e in rng.log if e[0] == tag][0]
+            u = synth.device_uniform(77, e[1], int(np.prod(shape))).reshape(shape)
+            return H.T((u >= np.float32(p)).astype(np.float32) / (1 - p))
+        masks = {"fc": mk("gcn_fc"), "phi": mk("gcn_phi"), "att_a": mk("gate_att_a"), "att_b": mk("gate_att_b"),
+                 "mlp0": small("gen_mlp0.2", 0.6, (1, 64))}
+    Pr = {k: v.clone().requires_grad_(True) for k, v in PG.items()}
+    pr = O.generator(Pr, x.cpu(), ei.cpu(), "graph", (0, 1), [nz[0].cpu()], masks, "sigmoid")
+    pr.sum().backward()
+    close(pred, pr)
+    for k, p in g.named_parameters():
+        want = Pr[k].grad
+        if want is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        scale = float(want.abs().max()) + 1e-12
+        assert float((p.grad.cpu() - want).abs().max()) <= 2e-4 * scale + 1e-8, k
