@@ -22,7 +22,7 @@ class AdvmilHipError(RuntimeError):
 class Epilogue(ctypes.Structure):
     """advmil_epilogue_t"""
     _fields_ = [("bias", c_void_p), ("act0", c_int), ("act1", c_int), ("act_split", c_int), ("drop_p", c_float),
-                ("seed", c_void_p), ("stream_id", c_uint64), ("rowv", c_void_p), ("colv", c_void_p),
+                ("seed", c_void_p), ("stream_id", c_uint64), ("rowv", c_void_p), ("colv", c_void_p), ("rowseg", c_void_p),
                 ("maskref", c_void_p), ("ldmask", c_int), ("mask_scale", c_float), ("accumulate", c_int),
                 ("alpha", c_float)]
 
@@ -44,11 +44,11 @@ SIGNATURES = {
                                         c_uint64, c_void_p]),
     "advmil_gate_score_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_uint64, c_uint64, c_int64, c_int64,
                                       c_void_p, c_void_p]),
-    "advmil_softmax_pool_workspace_bytes": (c_size_t, [c_int64, c_int64]),
-    "advmil_softmax_pool_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_size_t,
-                                        c_void_p]),
-    "advmil_softmax_pool_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
-                                        c_size_t, c_void_p]),
+    "advmil_softmax_pool_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
+    "advmil_softmax_pool_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p,
+                                        c_void_p, c_void_p, c_size_t, c_void_p]),
+    "advmil_softmax_pool_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p,
+                                        c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "advmil_gate_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "advmil_gate_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_uint64, c_uint64, c_int64, c_int64,
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),

@@ -35,7 +35,7 @@ __device__ __forceinline__ float epilogue_elem(const advmil_epilogue_t& e, float
                                                uint64_t key, float inv_keep) {
   float v = acc * e.alpha;
   if (e.bias) v += e.bias[n];
-  if (e.rowv) v += e.rowv[m] * e.colv[n];
+  if (e.rowv) v += e.rowv[m] * e.colv[(e.rowseg ? (int64_t)e.rowseg[m] * N : 0) + n];
   v = act_apply(n < e.act_split ? e.act0 : e.act1, v);
   if (e.seed && e.drop_p > 0.0f) v *= rng_keep(key, (uint64_t)(m * N + n), e.drop_p, inv_keep);
   if (e.maskref) v *= (e.maskref[m * (int64_t)e.ldmask + n] > 0.0f ? e.mask_scale : 0.0f);
@@ -354,7 +354,7 @@ extern "C" int advmil_gemm_f32_batched(int a_kc, int b_kc, int64_t M, int64_t N,
   g.sA = strideA; g.sB = strideB; g.sC = strideC;
   advmil_epilogue_t e;
   e.bias = nullptr; e.act0 = e.act1 = ACT_NONE; e.act_split = 1 << 30; e.drop_p = 0.f; e.seed = nullptr; e.stream_id = 0;
-  e.rowv = e.colv = e.maskref = nullptr; e.ldmask = 0; e.mask_scale = 1.f; e.accumulate = accumulate; e.alpha = alpha;
+  e.rowv = e.colv = e.maskref = nullptr; e.rowseg = nullptr; e.ldmask = 0; e.mask_scale = 1.f; e.accumulate = accumulate; e.alpha = alpha;
   g.epi = e;
   // small per-head problems: 64x64 tiles unless one head alone already fills the chip with 64x128
   const int tile = (n_tiles(12, M, N) * batch >= 512) ? 12 : 11;

@@ -42,8 +42,11 @@ __device__ __forceinline__ float4 reduce_rows(float4 v, const RowColMap& m, floa
 // out[c] = sum_b partial[b*stride + c].  16 columns x 16 row-lanes per workgroup: every lane keeps 4 independent
 // loads in flight and the 16 row-lanes are folded through LDS, so the serial depth is nblk/64 (was nblk).
 __global__ __launch_bounds__(256) void colsum_merge_kernel(const float* __restrict__ partial, int nblk, int64_t stride,
-                                                           int64_t ncols, float* __restrict__ out, int accumulate) {
+                                                           int64_t ncols, float* __restrict__ out, int accumulate,
+                                                           int64_t seg_pstride = 0, int64_t seg_ostride = 0) {
   __shared__ float red[16][17];
+  partial += (int64_t)blockIdx.y * seg_pstride;      // gridDim.y = segments (bags of a step slab)
+  out += (int64_t)blockIdx.y * seg_ostride;
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int64_t c = (int64_t)blockIdx.x * 16 + cl;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -112,12 +115,22 @@ extern "C" int advmil_gate_score_fwd(const float* ab, const float* wc, const flo
 // =====================================================================================
 // softmax over instances + weighted pooling
 // =====================================================================================
-// stats[0] = max_n s, stats[1] = 1 / sum_n exp(s - max)
-__global__ __launch_bounds__(1024) void softmax_stats_kernel(const float* __restrict__ s, int64_t N, float* __restrict__ stats) {
+// Segments: a step batch is a ragged slab of bags; segment b owns rows [seg_ptr[b], seg_ptr[b+1]) (seg_ptr == NULL: one
+// segment [0, N)). gridDim.y (or .x for the stats kernel) indexes the segment.
+__device__ __forceinline__ void seg_range(const int64_t* seg_ptr, int b, int64_t N, int64_t& beg, int64_t& end) {
+  beg = seg_ptr ? seg_ptr[b] : 0;
+  end = seg_ptr ? seg_ptr[b + 1] : N;
+}
+
+// stats[2b] = max_n s, stats[2b+1] = 1 / sum_n exp(s - max) over segment b
+__global__ __launch_bounds__(1024) void softmax_stats_kernel(const float* __restrict__ s, int64_t N,
+                                                             const int64_t* __restrict__ seg_ptr, float* __restrict__ stats) {
   __shared__ float red[16];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int64_t beg, end;
+  seg_range(seg_ptr, blockIdx.x, N, beg, end);
   float mx = -INFINITY;
-  for (int64_t n = tid; n < N; n += 1024) mx = fmaxf(mx, s[n]);
+  for (int64_t n = beg + tid; n < end; n += 1024) mx = fmaxf(mx, s[n]);
   mx = wave_max(mx);
   if (lane == 0) red[w] = mx;
   __syncthreads();
@@ -125,79 +138,94 @@ __global__ __launch_bounds__(1024) void softmax_stats_kernel(const float* __rest
   for (int k = 1; k < 16; ++k) mx = fmaxf(mx, red[k]);
   __syncthreads();
   float sum = 0.f;
-  for (int64_t n = tid; n < N; n += 1024) sum += expf(s[n] - mx);
+  for (int64_t n = beg + tid; n < end; n += 1024) sum += expf(s[n] - mx);
   sum = wave_sum(sum);
   if (lane == 0) red[w] = sum;
   __syncthreads();
   if (tid == 0) {
     float t = 0.f;
     for (int k = 0; k < 16; ++k) t += red[k];
-    stats[0] = mx;
-    stats[1] = 1.f / t;
+    stats[2 * blockIdx.x] = mx;
+    stats[2 * blockIdx.x + 1] = 1.f / t;
   }
 }
 
 __global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restrict__ s, const float* __restrict__ h,
                                                            int64_t ldh, int64_t N, int64_t D,
+                                                           const int64_t* __restrict__ seg_ptr,
                                                            const float* __restrict__ stats, float* __restrict__ A,
                                                            float* __restrict__ partial) {
   __shared__ __attribute__((aligned(16))) float red[1024];
   const RowColMap m = make_map(D);
-  const float mx = stats[0], inv = stats[1];
-  const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+  const int b = blockIdx.y;
+  int64_t beg, end;
+  seg_range(seg_ptr, b, N, beg, end);
+  const float mx = stats[2 * b], inv = stats[2 * b + 1];
+  const int64_t r0 = beg + (int64_t)blockIdx.x * ROWS_PER_BLOCK;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (m.active) {
     for (int r = m.r; r < ROWS_PER_BLOCK; r += m.rpp) {
       const int64_t n = r0 + r;
-      if (n >= N) break;
+      if (n >= end) break;
       const float w = expf(s[n] - mx) * inv;
       if (m.c4 == 0) A[n] = w;
       const float4 v = *reinterpret_cast<const float4*>(h + n * ldh + m.c4 * 4);
       acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
     }
   }
-  const float4 t = reduce_rows(acc, m, red);
-  if (m.active && m.r == 0) *reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * D + m.c4 * 4) = t;
+  const float4 t = reduce_rows(acc, m, red);   // blocks past the segment's end contribute zeros
+  if (m.active && m.r == 0)
+    *reinterpret_cast<float4*>(partial + ((int64_t)b * gridDim.x + blockIdx.x) * D + m.c4 * 4) = t;
 }
 
-extern "C" size_t advmil_softmax_pool_workspace_bytes(int64_t N, int64_t D) {
-  const int64_t nblk = (N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-  const int64_t nwg4 = (N + 3) / 4;
-  const int64_t a = 4 + nblk * D;   // fwd: stats + partials
-  const int64_t b = 4 + nwg4;       // bwd: per-workgroup partial of sum A t
+static inline int64_t pool_nblk(int64_t max_len) { return (max_len + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK; }
+
+extern "C" size_t advmil_softmax_pool_workspace_bytes(int64_t max_len, int64_t D, int nseg) {
+  if (nseg < 1) nseg = 1;
+  const int64_t a = 4 * (int64_t)nseg + (int64_t)nseg * pool_nblk(max_len) * D;   // fwd: stats + partials
+  const int64_t b = 4 + (int64_t)nseg * ((max_len + 3) / 4);                       // bwd: per-workgroup partials of sum A t
   return (size_t)(a > b ? a : b) * sizeof(float);
 }
 
-extern "C" int advmil_softmax_pool_fwd(const float* s, const float* h, int64_t ldh, int64_t N, int64_t D, float* A,
-                                       float* pooled, void* ws, size_t ws_bytes, advmil_stream_t stream_) {
+extern "C" int advmil_softmax_pool_fwd(const float* s, const float* h, int64_t ldh, int64_t N, int64_t D, int nseg,
+                                       const int64_t* seg_ptr, int64_t max_len, float* A, float* pooled, void* ws,
+                                       size_t ws_bytes, advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!s || !h || !A || !pooled || !ws || N <= 0 || D <= 0 || (D & 3) || D > 1024 || (ldh & 3)) return ADVMIL_EINVAL;
-  if (ws_bytes < advmil_softmax_pool_workspace_bytes(N, D)) return ADVMIL_EWORKSPACE;
+  if (!seg_ptr) { nseg = 1; max_len = N; }
+  if (nseg < 1 || max_len <= 0) return ADVMIL_EINVAL;
+  if (ws_bytes < advmil_softmax_pool_workspace_bytes(max_len, D, nseg)) return ADVMIL_EWORKSPACE;
   float* stats = (float*)ws;
-  float* partial = stats + 4;
-  const int nblk = (int)((N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
-  hipLaunchKernelGGL(softmax_stats_kernel, dim3(1), dim3(1024), 0, stream, s, N, stats);
+  float* partial = stats + 4 * nseg;
+  const int nblk = (int)pool_nblk(max_len);
+  hipLaunchKernelGGL(softmax_stats_kernel, dim3(nseg), dim3(1024), 0, stream, s, N, seg_ptr, stats);
   ADVMIL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(pool_partial_kernel, dim3(nblk), dim3(256), 0, stream, s, h, ldh, N, D, stats, A, partial);
+  hipLaunchKernelGGL(pool_partial_kernel, dim3(nblk, nseg), dim3(256), 0, stream, s, h, ldh, N, D, seg_ptr, stats, A, partial);
   ADVMIL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(D), dim3(256), 0, stream, partial, nblk, D, D, pooled, 0);
+  hipLaunchKernelGGL(colsum_merge_kernel, dim3((unsigned)((D + 15) / 16), nseg), dim3(256), 0, stream, partial, nblk, D, D, pooled,
+                     0, (int64_t)nblk * D, D);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }
 
-// backward stage 1: t[n] = dA[n] + dot(dpooled, h[n]); partial[wg] = sum over the wg's 4 rows of A[n] t[n]
+// backward stage 1: t[n] = dA[n] + dot(dpooled[seg], h[n]); partial[seg][wg] = sum over the wg's 4 rows of A[n] t[n]
 __global__ __launch_bounds__(256) void pool_bwd_dot_kernel(const float* __restrict__ dp, const float* __restrict__ dA,
                                                            const float* __restrict__ A, const float* __restrict__ h,
-                                                           int64_t ldh, int64_t N, int64_t D, float* __restrict__ t,
+                                                           int64_t ldh, int64_t N, int64_t D,
+                                                           const int64_t* __restrict__ seg_ptr, float* __restrict__ t,
                                                            float* __restrict__ partial) {
   __shared__ float red[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t n = (int64_t)blockIdx.x * 4 + w;
+  const int b = blockIdx.y;
+  int64_t beg, end;
+  seg_range(seg_ptr, b, N, beg, end);
+  const int64_t n = beg + (int64_t)blockIdx.x * 4 + w;
+  const float* dpb = dp + (int64_t)b * D;
   float contrib = 0.f;
-  if (n < N) {
+  if (n < end) {
     const float* row = h + n * ldh;
     float acc = 0.f;
-    for (int64_t j = lane; j < D; j += 64) acc += dp[j] * row[j];
+    for (int64_t j = lane; j < D; j += 64) acc += dpb[j] * row[j];
     acc = wave_sum(acc);
     if (dA) acc += dA[n];
     if (lane == 0) t[n] = acc;
@@ -205,34 +233,41 @@ __global__ __launch_bounds__(256) void pool_bwd_dot_kernel(const float* __restri
   }
   if (lane == 0) red[w] = contrib;
   __syncthreads();
-  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x == 0) partial[(int64_t)b * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-// backward stage 2: c = sum partial; ds[n] = A[n] (t[n] - c)   (t aliases ds)
+// backward stage 2: c = sum partial[seg]; ds[n] = A[n] (t[n] - c)   (t aliases ds)
 __global__ __launch_bounds__(256) void pool_bwd_ds_kernel(const float* __restrict__ A, const float* __restrict__ partial,
-                                                          int npart, int64_t N, float* __restrict__ ds) {
+                                                          int npart, int64_t N, const int64_t* __restrict__ seg_ptr,
+                                                          float* __restrict__ ds) {
   __shared__ float red[4];
+  const int b = blockIdx.y;
+  int64_t beg, end;
+  seg_range(seg_ptr, b, N, beg, end);
   float c = 0.f;
-  for (int k = threadIdx.x; k < npart; k += 256) c += partial[k];
+  for (int k = threadIdx.x; k < npart; k += 256) c += partial[(int64_t)b * npart + k];
   c = wave_sum(c);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
   __syncthreads();
   c = red[0] + red[1] + red[2] + red[3];
-  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (n < N) ds[n] = A[n] * (ds[n] - c);
+  const int64_t n = beg + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n < end) ds[n] = A[n] * (ds[n] - c);
 }
 
 extern "C" int advmil_softmax_pool_bwd(const float* dpooled, const float* dA, const float* A, const float* h, int64_t ldh,
-                                       int64_t N, int64_t D, float* ds, void* ws, size_t ws_bytes,
-                                       advmil_stream_t stream_) {
+                                       int64_t N, int64_t D, int nseg, const int64_t* seg_ptr, int64_t max_len, float* ds,
+                                       void* ws, size_t ws_bytes, advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!dpooled || !A || !h || !ds || !ws || N <= 0 || D <= 0) return ADVMIL_EINVAL;
-  if (ws_bytes < advmil_softmax_pool_workspace_bytes(N, D)) return ADVMIL_EWORKSPACE;
+  if (!seg_ptr) { nseg = 1; max_len = N; }
+  if (nseg < 1 || max_len <= 0) return ADVMIL_EINVAL;
+  if (ws_bytes < advmil_softmax_pool_workspace_bytes(max_len, D, nseg)) return ADVMIL_EWORKSPACE;
   float* partial = (float*)ws + 4;
-  const int nwg = (int)((N + 3) / 4);
-  hipLaunchKernelGGL(pool_bwd_dot_kernel, dim3(nwg), dim3(256), 0, stream, dpooled, dA, A, h, ldh, N, D, ds, partial);
+  const int nwg = (int)((max_len + 3) / 4);
+  hipLaunchKernelGGL(pool_bwd_dot_kernel, dim3(nwg, nseg), dim3(256), 0, stream, dpooled, dA, A, h, ldh, N, D, seg_ptr, ds, partial);
   ADVMIL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(pool_bwd_ds_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, A, partial, nwg, N, ds);
+  hipLaunchKernelGGL(pool_bwd_ds_kernel, dim3((unsigned)((max_len + 255) / 256), nseg), dim3(256), 0, stream, A, partial, nwg, N,
+                     seg_ptr, ds);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }

@@ -45,6 +45,10 @@ class Generator(nn.Module):
         bb = self.backbone
         return bb.features(x, x_ext) if hasattr(bb, "features") else bb(x, x_ext)
 
+    def features_multi(self, X, seg, exts=None):
+        """Slab form of `features`: X[N_total, C] holding the B bags of a step back to back -> [B, d]."""
+        return self.backbone.features_multi(X, seg, exts)
+
     def finish(self, feats, zero_noise=False, noise=None):
         """feats[B, d] (stacked `features`) -> predictions [B, dim_out]."""
         bb = self.backbone
@@ -64,6 +68,10 @@ class _PairNet(nn.Module):
     def embed_x(self, x):
         return self.net_pair_one.embed(x)
 
+    def embed_rows(self, X):
+        """Slab form: X[N_total, C] -> region embeddings [N_total/16, C']."""
+        return self.net_pair_one.embedding.embed_rows(X)
+
     def forward(self, x, t):
         return self.from_embedding(self.embed_x(x), t)
 
@@ -78,6 +86,10 @@ class Discriminator(_PairNet):
     def bag_features(self, emb_ins):
         """Per-bag region-level work (fc1 MLP + GAPool): (emb_bag[1,C'], None)."""
         emb_bag, _ = self.net_pair_one.pool_features(emb_ins)
+        return emb_bag, None
+
+    def bag_features_multi(self, emb, seg16):
+        emb_bag, _ = self.net_pair_one.pool_features_rows(emb, seg16)
         return emb_bag, None
 
     def tail(self, emb_bag, ins_mean, t):
@@ -113,6 +125,13 @@ class PrjDiscriminator(_PairNet):
         mean_r(fc_ins_r . hid_t) == mean_r(fc_ins_r) . hid_t (GANSurv.py:96-98)."""
         emb_bag, fc_ins = self.net_pair_one.pool_features(emb_ins)
         return emb_bag, (fc_ins.mean(dim=1) if self.inner_product == "instance" else None)
+
+    def bag_features_multi(self, emb, seg16):
+        """Slab form of `bag_features`: emb[L_total, C'] + region segments -> (emb_bag[B,C'], mean_r fc_ins[B,C'] | None)."""
+        emb_bag, fc_ins = self.net_pair_one.pool_features_rows(emb, seg16)
+        if self.inner_product != "instance":
+            return emb_bag, None
+        return emb_bag, ops.segmented_mean(fc_ins, seg16.rowseg, seg16.nseg)
 
     def tail(self, emb_bag, ins_mean, t):
         """[B,C'] stacks + t[B,1] -> f[B,1]: fc2, net_pair_two, the (region-level) inner product and the projection,

@@ -50,15 +50,18 @@ class ABMIL(nn.Module):
                                            Attn_Net_Gated(L=dim_hid, D=dim_hid, dropout=dropout, n_classes=1))
         self.rho = nn.Sequential(nn.Linear(dim_hid, dim_out), nn.ReLU(), nn.Dropout(dropout))
 
-    def features(self, x_path, *args):
-        """The N-row part: bag -> attention-pooled instance embedding [1, hid] (everything before `rho`)."""
-        x = x_path.squeeze(0)                                   # batch_size = 1
-        rng = _rng_of(self, x)
+    def features_multi(self, X, seg=None, exts=None):
+        """The N-row part over a slab X[N_total, C] of B bags (`seg`; None = one bag): -> pooled [B, hid]
+        (everything before `rho`). One FC GEMM, one gate GEMM and one segmented softmax-pool for the whole step batch."""
+        rng = _rng_of(self, X)
         fc, p = self.attention_net[0], (self.attention_net[2].p if self.training else 0.0)
-        h = ops.linear_act(x, fc.weight, fc.bias, "relu", p, rng, "abmil_fc")       # [N, hid]
-        pooled, A, _ = self.attention_net[3].pool(h)
+        h = ops.linear_act(X, fc.weight, fc.bias, "relu", p, rng, "abmil_fc")       # [N_total, hid]
+        pooled, A, _ = self.attention_net[3].pool(h, seg)
         self.last_attention = A.detach()
-        return pooled.unsqueeze(0)
+        return pooled.unsqueeze(0) if seg is None else pooled
+
+    def features(self, x_path, *args):
+        return self.features_multi(x_path.squeeze(0))            # batch_size = 1
 
     def post(self, pooled):
         """`rho` on a [B, hid] stack of pooled bags (B = the bags of one optimizer step)."""
@@ -80,19 +83,27 @@ class DeepAttMISL(nn.Module):
         self.attention_net = nn.Sequential(nn.Linear(dim_hid, dim_hid), nn.ReLU(), nn.Dropout(dropout),
                                            Attn_Net_Gated(L=dim_hid, D=dim_hid, dropout=dropout, n_classes=1))
 
-    def forward(self, x_path, cluster_id, *args):
-        x = x_path.squeeze(0)
-        rng = _rng_of(self, x)
-        # per-patch FC+ReLU (the 1x1 conv), then a per-cluster mean as ONE [8,N] x [N,hid] contraction with the
-        # normalised membership matrix: no host sync on the ids, no per-cluster gathers, empty cluster -> zeros
-        # (reference: D2H of ids + python loop of boolean gathers, backbone.py:107-116).
-        h = ops.linear_act(x, self.phis[0].weight, self.phis[0].bias, "relu")
-        h_cluster = ops.segmented_mean(h, cluster_id, self.num_clusters)          # [8, hid]
+    def features_multi(self, X, seg=None, exts=None):
+        """Slab form. exts = per-bag cluster-id tensors. Per-patch FC+ReLU (the 1x1 conv), then the per-(bag, cluster)
+        means as ONE [8B, N_total] x [N_total, hid] contraction with the normalised membership matrix: no host sync on the
+        ids, no per-cluster gathers, empty cluster -> zeros (reference: D2H of ids + python loop of boolean gathers,
+        backbone.py:107-116); then the 8-row attention pool per bag."""
+        rng = _rng_of(self, X)
+        K = self.num_clusters
+        h = ops.linear_act(X, self.phis[0].weight, self.phis[0].bias, "relu")
+        cid = torch.cat([e.reshape(-1) for e in exts]).to(device=X.device, dtype=torch.long)
+        nb = 1 if seg is None else seg.nseg
+        if seg is not None:
+            cid = cid + seg.rowseg.to(torch.long) * K
+        h_cluster = ops.segmented_mean(h, cid, K * nb)                            # [8B, hid]
         fc, p = self.attention_net[0], (self.attention_net[2].p if self.training else 0.0)
         hc = dropout_small(F.relu(F.linear(h_cluster, fc.weight, fc.bias)), p, self.training, rng, "misl_fc")
-        pooled, A, _ = self.attention_net[3].pool(hc)
+        pooled, A, _ = self.attention_net[3].pool(hc, None if seg is None else seg.uniform(K))
         self.last_attention = A.detach()
-        return pooled.unsqueeze(0)
+        return pooled.unsqueeze(0) if seg is None else pooled
+
+    def forward(self, x_path, cluster_id, *args):
+        return self.features_multi(x_path.squeeze(0), None, [cluster_id])
 
 
 class DualTrans_HS(nn.Module):
@@ -111,14 +122,21 @@ class DualTrans_HS(nn.Module):
         self.patch_encoder_layer = make_transformer_layer(tra_backbone, args_tra_backbone)
         self.pool = GAPool(dim_out, dim_out)
 
+    def features_multi(self, X, seg=None, exts=None):
+        """Slab form: region embedding and every projection / FFN of the transformer layer run once over all bags'
+        rows; only the attention core and the final GAPool respect bag boundaries."""
+        seg16 = None if seg is None else seg.div(16)
+        emb = self.patch_embedding_layer.embed_rows(X)
+        enc = self.patch_encoder_layer
+        feat = enc.forward_rows(emb, seg16) if hasattr(enc, "forward_rows") else emb
+        H = self.pool.pool_rows(feat, seg16)
+        self.last_attention = self.pool.last_attention
+        return H
+
     def forward(self, x, coord=None, *args):
         if coord is not None:
             raise NotImplementedError("positional encoding is unreachable in the reference (model_handler.py:390 passes None)")
-        emb = self.patch_embedding_layer(x)
-        feat = self.patch_encoder_layer(emb)
-        H = self.pool(feat)
-        self.last_attention = self.pool.last_attention
-        return H
+        return self.features_multi(x.squeeze(0))
 
 
 class _GENConvParams(nn.Module):
@@ -160,8 +178,26 @@ class PatchGCN(nn.Module):
         self.path_phi = nn.Sequential(nn.Linear(dim_hid * (1 + num_layers), dim_out), nn.ReLU(), nn.Dropout(dropout))
         self.path_attention_head = Attn_Net_Gated(L=dim_out, D=dim_out, dropout=dropout, n_classes=1)
 
+    def features_multi(self, X, seg=None, exts=None):
+        """Slab form: the bags' graphs become one block-diagonal graph over the slab's rows (node ids offset per bag)."""
+        if seg is None:
+            return self.forward(exts[0])
+        key = tuple(id(e) for e in exts)
+        cache = getattr(self, "_union_cache", None)
+        if cache is None or cache[0] != key:
+            ei = torch.cat([e.edge_index.to(torch.long) + seg.offsets[b] for b, e in enumerate(exts)], dim=1)
+            from types import SimpleNamespace
+            union = SimpleNamespace(x=X, edge_index=ei)
+            union._advmil_csr = ops.GraphCSR(ei, seg.total)
+            self._union_cache = cache = (key, union)
+        union = cache[1]
+        union.x = X
+        return self._run(union, seg)
+
     def forward(self, x_path, *args):
-        data = x_path
+        return self._run(x_path, None)
+
+    def _run(self, data, seg):
         x_in = data.x
         rng = _rng_of(self, x_in)
         tr = self.training
@@ -174,6 +210,6 @@ class PatchGCN(nn.Module):
         x1 = ops.linear_act(hmid, conv.mlp[4].weight, conv.mlp[4].bias, "none")
         h = torch.cat([x, x1], dim=1)
         h = ops.linear_act(h, self.path_phi[0].weight, self.path_phi[0].bias, "relu", self.path_phi[2].p if tr else 0.0, rng, "gcn_phi")
-        pooled, A, _ = self.path_attention_head.pool(h)
+        pooled, A, _ = self.path_attention_head.pool(h, seg)
         self.last_attention = A.detach()
-        return pooled.unsqueeze(0)
+        return pooled.unsqueeze(0) if seg is None else pooled

@@ -39,12 +39,13 @@ class Attn_Net_Gated(nn.Module):
         if n_classes != 1 or L != D:
             raise NotImplementedError("HIP gated-attention kernels cover n_classes=1 and L==D (all AdvMIL configs)")
 
-    def pool(self, x):
-        """Fused scorer + softmax over instances + weighted sum: x[N,D] -> (pooled[D], A[N], raw scores[N])."""
+    def pool(self, x, seg=None):
+        """Fused scorer + softmax over instances + weighted sum: x[N,D] -> (pooled[D], A[N], raw scores[N]).
+        With `seg` (ops.Segments) the rows are a slab of B bags and pooled is [B, D] (softmax per bag)."""
         p = self.drop_p if self.training else 0.0
         return ops.gated_attn_pool(x, self.attention_a[0].weight, self.attention_a[0].bias, self.attention_b[0].weight,
                                    self.attention_b[0].bias, self.attention_c.weight, self.attention_c.bias, p,
-                                   _rng_of(self, x), "gate_")
+                                   _rng_of(self, x), "gate_", seg)
 
     def forward(self, x):
         """Reference contract: (A[N,1] raw scores, x)."""
@@ -66,14 +67,18 @@ class GAPool(nn.Module):
         if in_dim != hid_dim:
             raise NotImplementedError("HIP GAPool covers in_dim == hid_dim (all AdvMIL configs)")
 
+    def pool_rows(self, x2, seg=None):
+        """x2[L_total, d] (one bag, or a slab of bags partitioned by `seg`) -> pooled [B, d]."""
+        p = self.drop_p if self.training else 0.0
+        pooled, A, _ = ops.gated_attn_pool(x2, self.fc1[0].weight, self.fc1[0].bias, self.score[0].weight,
+                                           self.score[0].bias, self.fc2.weight, self.fc2.bias, p, _rng_of(self, x2), "gapool_", seg)
+        self.last_attention = A.detach()
+        return pooled.unsqueeze(0) if seg is None else pooled
+
     def forward(self, x):
         if x.dim() != 3 or x.shape[0] != 1:
             raise ValueError("GAPool: the AdvMIL path is batch_size 1 (config/cfg_nlst.yaml:70); got %s" % (tuple(x.shape),))
-        p = self.drop_p if self.training else 0.0
-        pooled, A, _ = ops.gated_attn_pool(x[0], self.fc1[0].weight, self.fc1[0].bias, self.score[0].weight,
-                                           self.score[0].bias, self.fc2.weight, self.fc2.bias, p, _rng_of(self, x), "gapool_")
-        self.last_attention = A.detach()
-        return pooled.unsqueeze(0)
+        return self.pool_rows(x[0])
 
 
 class AVGPoolPatchEmbedding(nn.Module):
@@ -92,14 +97,17 @@ class AVGPoolPatchEmbedding(nn.Module):
         self.norm = nn.LayerNorm(out_dim)
         self.act = nn.ReLU(inplace=True)
 
+    def embed_rows(self, x2):
+        """x2[N_total, C] -> [N_total/16, out_dim]; rows may be a slab of bags (each bag a multiple of 16 rows, so the
+        16-row regions never straddle two bags)."""
+        assert x2.shape[0] % (self.scale * self.scale) == 0
+        y = ops.linear_act(x2, self.conv.weight, self.conv.bias, "none")
+        return ops.ln_relu_mean16(y, self.norm.weight, self.norm.bias, self.norm.eps)
+
     def forward(self, x):
         if x.dim() != 3 or x.shape[0] != 1:
             raise ValueError("AVGPoolPatchEmbedding: batch_size 1 expected, got %s" % (tuple(x.shape),))
-        N = x.shape[1]
-        assert N % (self.scale * self.scale) == 0
-        y = ops.linear_act(x[0], self.conv.weight, self.conv.bias, "none")
-        emb = ops.ln_relu_mean16(y, self.norm.weight, self.norm.bias, self.norm.eps)
-        return emb.unsqueeze(0)
+        return self.embed_rows(x[0]).unsqueeze(0)
 
 
 def make_embedding_layer(backbone: str, args):

@@ -27,24 +27,31 @@ class HipTransformerEncoderLayer(nn.Module):
         self.dropout2 = nn.Dropout(dropout)
         self.nhead = nhead
 
-    def forward(self, x):
-        if x.dim() != 3 or x.shape[0] != 1:
-            raise ValueError("ESAT layer: batch_size 1 expected")
-        rng = getattr(self, "rng", None) or ops.default_rng(x.device)
+    def forward_rows(self, x2, seg=None):
+        """x2[L_total, d]: one bag's region tokens, or a slab of bags (`seg`); attention never crosses a bag boundary,
+        everything else in the layer is row-wise and runs once over the slab."""
+        rng = getattr(self, "rng", None) or ops.default_rng(x2.device)
         tr = self.training
         sa = self.self_attn
-        L, d = x.shape[1], x.shape[2]
-        x2 = x[0]
-        qkv = ops.linear_act(x2, sa.in_proj_weight, sa.in_proj_bias, "none")           # [L, 3d]
-        o = ops.mha(qkv, self.nhead, sa.dropout if tr else 0.0, rng)                     # [L, d]
+        d = x2.shape[1]
+        qkv = ops.linear_act(x2, sa.in_proj_weight, sa.in_proj_bias, "none")           # [L_total, 3d]
+        p_att = sa.dropout if tr else 0.0
+        if seg is None:
+            o = ops.mha(qkv, self.nhead, p_att, rng)
+        else:
+            o = torch.cat([ops.mha(qkv[seg.offsets[b]:seg.offsets[b + 1]], self.nhead, p_att, rng) for b in range(seg.nseg)], dim=0)
         o = ops.linear_act(o, sa.out_proj.weight, sa.out_proj.bias, "none")
         o = dropout_small(o, self.dropout1.p, tr, rng, "esat_drop1")
         x2 = F.layer_norm(x2 + o, (d,), self.norm1.weight, self.norm1.bias, self.norm1.eps)
         f = ops.linear_act(x2, self.linear1.weight, self.linear1.bias, "relu", self.dropout.p if tr else 0.0, rng, "esat_ffn")
         f = ops.linear_act(f, self.linear2.weight, self.linear2.bias, "none")
         f = dropout_small(f, self.dropout2.p, tr, rng, "esat_drop2")
-        x2 = F.layer_norm(x2 + f, (d,), self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        return x2.unsqueeze(0)
+        return F.layer_norm(x2 + f, (d,), self.norm2.weight, self.norm2.bias, self.norm2.eps)
+
+    def forward(self, x):
+        if x.dim() != 3 or x.shape[0] != 1:
+            raise ValueError("ESAT layer: batch_size 1 expected")
+        return self.forward_rows(x[0]).unsqueeze(0)
 
 
 class HipTransformerEncoder(nn.Module):
@@ -52,6 +59,11 @@ class HipTransformerEncoder(nn.Module):
         super().__init__()
         self.layers = nn.ModuleList([HipTransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout)
                                      for _ in range(num_layers)])
+
+    def forward_rows(self, x2, seg=None):
+        for layer in self.layers:
+            x2 = layer.forward_rows(x2, seg)
+        return x2
 
     def forward(self, x):
         for layer in self.layers:

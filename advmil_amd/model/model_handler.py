@@ -185,16 +185,44 @@ class MyHandler(object):
         return preds, fakes
 
     def _plan(self, xs, ys, mode, label_visible_mask, ys_host):
-        """Host-side facts of a step batch: which bags feed a real pair / the supervised loss, and the GLOBAL
-        denominators of the reference's means (one tiny all-reduce under bag-parallel)."""
+        """Host-side facts of a step batch (built OUTSIDE HIP-graph capture: it does small H2D copies): which bags feed
+        a real pair / the supervised loss, the GLOBAL denominators of the reference's means (one tiny all-reduce under
+        bag-parallel), and the row segments of the step slab."""
         n = len(xs)
         vis = self._vis(mode, n, label_visible_mask)
         if ys_host is None:
             ys_host = [y.cpu() for y in ys]             # fallback: one sync (the epoch loop passes host labels)
         is_real = [bool(float(yh[0, 1]) == 1.0) and vis[i] for i, yh in enumerate(ys_host)]
         n_real, n_fake, n_vis = self.dp.global_counts([sum(is_real), n, sum(vis)], self.device)
-        vis_mask = None if all(vis) else torch.tensor([float(v) for v in vis], device=self.device)   # made OUTSIDE capture
-        return SimpleNamespace(vis=vis, is_real=is_real, n_real=n_real, n_fake=n_fake, n_vis=n_vis, vis_mask=vis_mask)
+        vis_mask = None if all(vis) else torch.tensor([float(v) for v in vis], device=self.device)
+        real_idx = torch.tensor([i for i in range(n) if is_real[i]], dtype=torch.long, device=self.device)
+        seg = ops.Segments([self._rows(x[0]) for x in xs], self.device)
+        seg16 = seg.div(16)                              # D's region embedding needs N % 16 == 0 (backbone_utils.py:65)
+        return SimpleNamespace(vis=vis, is_real=is_real, n_real=n_real, n_fake=n_fake, n_vis=n_vis, vis_mask=vis_mask,
+                               real_idx=real_idx, seg=seg, seg16=seg16)
+
+    @staticmethod
+    def _rows(x):
+        return x.shape[-2]
+
+    def _slab(self, xs):
+        """The step's bags as ONE [N_total, C] matrix: a zero-copy view when they already sit back to back in one
+        allocation (the staging slab of the loader / the resident pool of the bench), else one concatenation."""
+        x0 = xs[0][0]
+        c = x0.shape[-1]
+        rows = [self._rows(x[0]) for x in xs]
+        ok = all(x[0].is_contiguous() for x in xs)
+        if ok:
+            st = x0.untyped_storage().data_ptr()
+            ptr = x0.data_ptr()
+            for x, r in zip(xs, rows):
+                if x[0].data_ptr() != ptr or x[0].untyped_storage().data_ptr() != st:
+                    ok = False
+                    break
+                ptr += r * c * 4
+        if ok:
+            return x0.as_strided((sum(rows), c), (c, 1), x0.storage_offset())
+        return torch.cat([x[0].reshape(-1, c) for x in xs], dim=0)
 
     @staticmethod
     def _stack_noise(noise):
@@ -203,38 +231,31 @@ class MyHandler(object):
             return None
         return [torch.cat([nb[j] for nb in noise], dim=0) for j in range(len(noise[0]))]
 
-    def _gen_features(self, data_x, data_x_ext):
-        if self.bcb == "graph":
-            return self.netG.features(data_x_ext, None)
-        if self.bcb == "patch":
-            return self.netG.features(data_x, None)            # coords skipped (model_handler.py:390)
-        return self.netG.features(data_x, data_x_ext)
+    def _gen_features(self, X, plan, xs):
+        """Generator backbone over the whole step slab -> [B, d]. `patch` mode skips coords (model_handler.py:390)."""
+        exts = [x[1] for x in xs] if self.bcb in ("cluster", "graph") else None
+        return self.netG.features_multi(X, plan.seg, exts)
 
     def _disc_backward(self, i_batch, xs, ys, plan, noise=None):
-        """Capturable (no host sync, no collective): zero D grads, forward of every bag, ONE backward of the D loss.
-        Per bag only the N-row / region-row kernels run; the [1,d]-sized heads and tails run once on [B,d] stacks."""
+        """Capturable (no host sync, no collective): zero D grads, forward of the step slab, ONE backward of the D loss.
+        All N-row / region-row kernels run once over the B bags' rows (segmented softmax-pool per bag); the [1,d]-sized
+        heads and tails run once on [B,d] stacks."""
         self.netD.train()
         self.netG.eval()
-        n = len(xs)
         dev = self.device
         self.optimizerD.zero_grad()
+        X = self._slab(xs)
+        y = torch.cat(ys, dim=0)
         with torch.no_grad():                                                  # the reference builds, then detaches (400)
-            feats = torch.cat([self._gen_features(xs[i][0], xs[i][1]) for i in range(n)], dim=0)
-            pred = self.netG.finish(feats, noise=self._stack_noise(noise))     # [B,1]
-        fake_b, fake_m, real_b, real_m = [], [], [], []
-        for i in range(n):
-            emb = self.netD.embed_x(xs[i][0])                                  # shared by both pairs of the bag
-            if plan.is_real[i]:
-                eb, im = self.netD.bag_features(emb)
-                real_b.append(eb); real_m.append(im)
-            eb, im = self.netD.bag_features(emb)
-            fake_b.append(eb); fake_m.append(im)
-        cat = lambda lst: None if lst[0] is None else torch.cat(lst, dim=0)
-        f_fake = self.netD.tail(torch.cat(fake_b, dim=0), cat(fake_m), pred).view(-1)
+            pred = self.netG.finish(self._gen_features(X, plan, xs), noise=self._stack_noise(noise))     # [B,1]
+        emb = self.netD.embed_rows(X)                                          # shared by the real and the fake pairs
+        eb, im = self.netD.bag_features_multi(emb, plan.seg16)
+        f_fake = self.netD.tail(eb, im, pred).view(-1)
         f_real = None
-        if real_b:
-            t_real = torch.cat([ys[i][:, 0:1] for i in range(n) if plan.is_real[i]], dim=0)
-            f_real = self.netD.tail(torch.cat(real_b, dim=0), cat(real_m), t_real).view(-1)
+        if any(plan.is_real):                                                  # own dropout draw, as a separate forward has
+            eb_r, im_r = self.netD.bag_features_multi(emb, plan.seg16)
+            sel = plan.real_idx
+            f_real = self.netD.tail(eb_r[sel], None if im_r is None else im_r[sel], y[sel, 0:1]).view(-1)
         tr, tf = real_fake_terms(f_real, f_fake, self.which_loss)
         loss = tf.sum() / plan.n_fake
         s_real = torch.zeros((), device=dev)
@@ -260,18 +281,15 @@ class MyHandler(object):
         self._gen_apply()
 
     def _gen_backward(self, i_batch, xs, ys, plan, noise=None):
-        """Capturable: zero G grads, forward of every bag, ONE backward of the G loss (heads/tails on [B,d] stacks)."""
+        """Capturable: zero G grads, forward of the step slab, ONE backward of the G loss."""
         self.netD.eval()
         self.netG.train()
-        n = len(xs)
         dev = self.device
         self.optimizerG.zero_grad()
-        feats = torch.cat([self._gen_features(xs[i][0], xs[i][1]) for i in range(n)], dim=0)
-        pred = self.netG.finish(feats, noise=self._stack_noise(noise))        # [B,1], graph kept
+        X = self._slab(xs)
+        pred = self.netG.finish(self._gen_features(X, plan, xs), noise=self._stack_noise(noise))      # [B,1], graph kept
         with torch.no_grad():                                                  # nothing of D(x) depends on G
-            bf = [self.netD.bag_features(self.netD.embed_x(xs[i][0])) for i in range(n)]
-            eb = torch.cat([b[0] for b in bf], dim=0)
-            im = None if bf[0][1] is None else torch.cat([b[1] for b in bf], dim=0)
+            eb, im = self.netD.bag_features_multi(self.netD.embed_rows(X), plan.seg16)
         f_fake = self.netD.tail(eb, im, pred).view(-1)
         gen = -f_fake.sum() / plan.n_fake
         if plan.n_vis > 0 and any(plan.vis):

@@ -97,14 +97,18 @@ class EmbedXLayer(nn.Module):
         """The dropout-free, t-independent part: x -> emb_ins[1, L, C'] (shared by the real and fake pairs)."""
         return self.embedding(x)
 
-    def pool_features(self, emb_ins):
-        """Region-level part: emb_ins[1,L,C'] -> (emb_bag[1,C'] (pooled, before fc2), fc_ins[1,L,C'])."""
-        rng = _rng_of(self, emb_ins)
+    def pool_features_rows(self, e, seg16=None):
+        """Region-level part over rows e[L_total, C'] (one bag or a slab): -> (emb_bag[B,C'] pooled before fc2, fc_ins[L_total,C'])."""
+        rng = _rng_of(self, e)
         tr = self.training
-        e = emb_ins[0]
         h = ops.linear_act(e, self.fc1[0].weight, self.fc1[0].bias, "relu", self.fc1[2].p if tr else 0.0, rng, "dx_fc1")
-        fc_ins = ops.linear_act(h, self.fc1[3].weight, self.fc1[3].bias, "none").unsqueeze(0)
-        return self.pool(fc_ins), fc_ins
+        fc_ins = ops.linear_act(h, self.fc1[3].weight, self.fc1[3].bias, "none")
+        return self.pool.pool_rows(fc_ins, seg16), fc_ins
+
+    def pool_features(self, emb_ins):
+        """emb_ins[1,L,C'] -> (emb_bag[1,C'], fc_ins[1,L,C'])."""
+        emb_bag, fc_ins = self.pool_features_rows(emb_ins[0])
+        return emb_bag, fc_ins.unsqueeze(0)
 
     def from_embedding(self, emb_ins, return_instance=False):
         emb_bag, fc_ins = self.pool_features(emb_ins)

@@ -112,8 +112,8 @@ def auto_splits(M, N, K):
 
 
 def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=None, act_split=None, drop_p=0.0,
-         seed=None, stream_id=0, rowv=None, colv=None, maskref=None, mask_scale=1.0, accumulate=False, alpha=1.0,
-         splits=None, tile=0):
+         seed=None, stream_id=0, rowv=None, colv=None, rowseg=None, maskref=None, mask_scale=1.0, accumulate=False,
+         alpha=1.0, splits=None, tile=0):
     """C[M,N] = epilogue(alpha * op(A) op(B)); see include/advmil_hip.h::advmil_gemm_f32."""
     _chk(A, "A"); _chk(B, "B")
     if out is None:
@@ -133,6 +133,7 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
     e.stream_id = stream_id
     e.rowv = None if rowv is None else rowv.data_ptr()
     e.colv = None if colv is None else colv.data_ptr()
+    e.rowseg = None if rowseg is None else rowseg.data_ptr()
     e.maskref = None if maskref is None else maskref.data_ptr()
     e.ldmask = 0 if maskref is None else maskref.stride(0)
     e.mask_scale = float(mask_scale)
@@ -166,24 +167,63 @@ def gate_score(ab, wc, bc, N, D, p=0.0, seed=None, stream_a=0, stream_b=0):
     return s
 
 
-def softmax_pool(s, h, N, D):
+class Segments:
+    """Row partition of a step slab: bag b owns rows [ptr[b], ptr[b+1]). Holds the device arrays the segmented kernels
+    read (built with small H2D copies, so construct it OUTSIDE HIP-graph capture)."""
+
+    def __init__(self, lens, device):
+        self.lens = [int(v) for v in lens]
+        self.nseg = len(self.lens)
+        self.total = sum(self.lens)
+        self.max_len = max(self.lens)
+        self.device = torch.device(device)
+        offs = [0]
+        for v in self.lens:
+            offs.append(offs[-1] + v)
+        self.offsets = offs
+        self.ptr = torch.tensor(offs, dtype=torch.int64, device=self.device)
+        self.rowseg = torch.repeat_interleave(torch.arange(self.nseg, dtype=torch.int32, device=self.device),
+                                              torch.tensor(self.lens, device=self.device)).contiguous()
+        self._div = {}
+
+    def div(self, k):
+        """Segments of the k-fold pooled rows (regions of 16 patches)."""
+        if k not in self._div:
+            assert all(v % k == 0 for v in self.lens)
+            self._div[k] = Segments([v // k for v in self.lens], self.device)
+        return self._div[k]
+
+    def uniform(self, rows):
+        """nseg segments of `rows` rows each (e.g. the 8 cluster rows of every bag)."""
+        key = ("u", rows)
+        if key not in self._div:
+            self._div[key] = Segments([rows] * self.nseg, self.device)
+        return self._div[key]
+
+
+def softmax_pool(s, h, N, D, seg=None):
     L = _lib.lib()
+    nseg = 1 if seg is None else seg.nseg
+    mlen = N if seg is None else seg.max_len
     A = torch.empty(N, dtype=torch.float32, device=h.device)
-    pooled = torch.empty(D, dtype=torch.float32, device=h.device)
-    wsb = L.advmil_softmax_pool_workspace_bytes(N, D)
+    pooled = torch.empty(nseg, D, dtype=torch.float32, device=h.device)
+    wsb = L.advmil_softmax_pool_workspace_bytes(mlen, D, nseg)
     ws = _ws(wsb, h.device)
-    _lib.check(L.advmil_softmax_pool_fwd(_p(s), _p(h), h.stride(0), N, D, _p(A), _p(pooled), _p(ws), wsb, _stream()),
-               "softmax_pool_fwd")
+    _lib.check(L.advmil_softmax_pool_fwd(_p(s), _p(h), h.stride(0), N, D, nseg, _p(None if seg is None else seg.ptr), mlen, _p(A),
+                                         _p(pooled), _p(ws), wsb, _stream()), "softmax_pool_fwd")
     return A, pooled
 
 
-def softmax_pool_bwd(dpooled, dA, A, h, N, D):
+def softmax_pool_bwd(dpooled, dA, A, h, N, D, seg=None):
     L = _lib.lib()
+    nseg = 1 if seg is None else seg.nseg
+    mlen = N if seg is None else seg.max_len
     ds = torch.empty(N, dtype=torch.float32, device=h.device)
-    wsb = L.advmil_softmax_pool_workspace_bytes(N, D)
+    wsb = L.advmil_softmax_pool_workspace_bytes(mlen, D, nseg)
     ws = _ws(wsb, h.device)
-    _lib.check(L.advmil_softmax_pool_bwd(_p(dpooled), _p(dA), _p(A), _p(h), h.stride(0), N, D, _p(ds), _p(ws), wsb,
-                                         _stream()), "softmax_pool_bwd")
+    _lib.check(L.advmil_softmax_pool_bwd(_p(dpooled), _p(dA), _p(A), _p(h), h.stride(0), N, D, nseg,
+                                         _p(None if seg is None else seg.ptr), mlen, _p(ds), _p(ws), wsb, _stream()),
+               "softmax_pool_bwd")
     return ds
 
 
@@ -351,12 +391,12 @@ def linear_act(x, W, b, act="none", p=0.0, rng=None, tag=""):
 
 
 class GatedAttnPoolFn(torch.autograd.Function):
-    """(pooled[D], A[N]) = softmax-pool of h[N,D] scored by the gated attention net.
-    Attn_Net_Gated + softmax + mm (model/backbone_utils.py:11-29, model/backbone.py:81-85) and GAPool
-    (model/backbone_utils.py:47-56): the pooled tensor is the scored tensor in every use."""
+    """(pooled[B,D], A[N]) = per-bag softmax-pool of h[N,D] scored by the gated attention net; `seg` partitions the rows
+    into the B bags of a step slab (None = one bag). Attn_Net_Gated + softmax + mm (model/backbone_utils.py:11-29,
+    model/backbone.py:81-85) and GAPool (model/backbone_utils.py:47-56): the pooled tensor is the scored tensor in every use."""
 
     @staticmethod
-    def forward(ctx, h, Wa, ba, Wb, bb, wc, bc, p, seed, sa, sb):
+    def forward(ctx, h, Wa, ba, Wb, bb, wc, bc, p, seed, sa, sb, seg):
         _chk(h, "h")
         h = h.contiguous()
         N, D = h.shape
@@ -365,9 +405,9 @@ class GatedAttnPoolFn(torch.autograd.Function):
         ab = gemm(h, Wab, True, True, N, 2 * D, D, bias=bab, act0=ACT_TANH, act1=ACT_SIGMOID, act_split=D)
         wcv = wc.detach().reshape(-1)
         s = gate_score(ab, wcv, bc, N, D, p, seed, sa, sb)
-        A, pooled = softmax_pool(s, h, N, D)
+        A, pooled = softmax_pool(s, h, N, D, seg)
         ctx.save_for_backward(h, Wab, ab, A, wcv)
-        ctx.cfg = (p, seed, sa, sb, N, D, wc.shape)
+        ctx.cfg = (p, seed, sa, sb, N, D, wc.shape, seg)
         # fused weight-gradient accumulation needs every parameter's arena slot, with the a|b pairs adjacent
         gs = [_arena_grad(t) for t in (Wa, ba, Wb, bb, wc, bc)]
         ctx.arena = None
@@ -381,10 +421,12 @@ class GatedAttnPoolFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dpooled, dA, _ds_unused):
         h, Wab, ab, A, wcv = ctx.saved_tensors
-        p, seed, sa, sb, N, D, wcshape = ctx.cfg
-        dpooled = torch.zeros(D, dtype=torch.float32, device=h.device) if dpooled is None else dpooled.contiguous()
+        p, seed, sa, sb, N, D, wcshape, seg = ctx.cfg
+        nseg = 1 if seg is None else seg.nseg
+        dpooled = (torch.zeros(nseg, D, dtype=torch.float32, device=h.device) if dpooled is None
+                   else dpooled.contiguous().reshape(nseg, D))
         dA_ = None if dA is None else dA.contiguous()
-        ds = softmax_pool_bwd(dpooled, dA_, A, h, N, D)
+        ds = softmax_pool_bwd(dpooled, dA_, A, h, N, D, seg)
         if ctx.arena is not None:
             gWab, gbab, gwc, gbc = ctx.arena
             dG, _, _, _ = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb, dwc=gwc, dbc=gbc, dbias=gbab)
@@ -392,16 +434,18 @@ class GatedAttnPoolFn(torch.autograd.Function):
             dG, dwc, dbc, dbias = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb)
         dh = None
         if ctx.needs_input_grad[0]:
-            # dG [N,2D] . Wab [2D,D]  +  A[n] * dpooled[d]   (pooling's direct path)
-            dh = gemm(dG, Wab, True, False, N, D, 2 * D, rowv=A, colv=dpooled)
+            # dG [N,2D] . Wab [2D,D]  +  A[n] * dpooled[bag(n), d]   (pooling's direct path, rank-1 per bag)
+            dh = gemm(dG, Wab, True, False, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg)
+        nones = (None,) * 5
         if ctx.arena is not None:
             gemm(dG, h, False, False, 2 * D, D, N, out=gWab, ldc=D, accumulate=True)       # dG^T h
-            return (dh, None, None, None, None, None, None, None, None, None, None)
+            return (dh, None, None, None, None, None, None) + nones
         dWab = gemm(dG, h, False, False, 2 * D, D, N)
-        return (dh, dWab[:D], dbias[:D], dWab[D:], dbias[D:], dwc.reshape(wcshape), dbc, None, None, None, None)
+        return (dh, dWab[:D], dbias[:D], dWab[D:], dbias[D:], dwc.reshape(wcshape), dbc) + nones
 
 
-def gated_attn_pool(h, Wa, ba, Wb, bb, wc, bc, p=0.0, rng=None, tag=""):
+def gated_attn_pool(h, Wa, ba, Wb, bb, wc, bc, p=0.0, rng=None, tag="", seg=None):
+    """Returns (pooled [nseg, D] -- [D] when seg is None --, A[N], raw scores[N])."""
     sa = sb = 0
     seed = None
     if p > 0.0:
@@ -409,7 +453,8 @@ def gated_attn_pool(h, Wa, ba, Wb, bb, wc, bc, p=0.0, rng=None, tag=""):
         sa = rng.site(tag + "att_a", tuple(h.shape), p)
         sb = rng.site(tag + "att_b", tuple(h.shape), p)
         seed = rng.seed
-    return GatedAttnPoolFn.apply(h, Wa, ba, Wb, bb, wc, bc, float(p), seed, sa, sb)
+    pooled, A, s = GatedAttnPoolFn.apply(h, Wa, ba, Wb, bb, wc, bc, float(p), seed, sa, sb, seg)
+    return (pooled[0] if seg is None else pooled), A, s
 
 
 class LNReLUMean16Fn(torch.autograd.Function):

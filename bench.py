@@ -47,12 +47,17 @@ def parse():
     return ap.parse_args()
 
 
-def make_pool(torch, dev, mode, n_pool, n_patches, seed):
-    """Synthetic bags x ~ N(0,1) [1,N,1024] fp32 generated on the device + labels (t~U, e = i mod 2)."""
+def make_pool(torch, dev, mode, n_pool, n_patches, seed, group=16):
+    """Synthetic bags x ~ N(0,1) [1,N,1024] fp32 generated on the device + labels (t~U, e = i mod 2). The pool is laid out
+    as slabs of `group` bags (what a loader's staging buffer looks like), so a step batch is one contiguous [group*N, 1024]."""
     g = torch.Generator(device=dev).manual_seed(seed)
     xs, ys, ys_host = [], [], []
+    slab = None
     for i in range(n_pool):
-        x = torch.randn(1, n_patches, 1024, device=dev, generator=g)
+        if i % group == 0:
+            slab = torch.empty(min(group, n_pool - i), n_patches, 1024, device=dev)
+        x = slab[i % group].unsqueeze(0)
+        x.normal_(generator=g)
         if mode == "cluster":
             ext = torch.randint(0, 8, (1, n_patches), device=dev, generator=g).float()
         elif mode == "graph":   # patches on a sqrt(N) grid, 8-NN (tools/patchgcn_graph_s2.py:66-80 layout)
@@ -157,7 +162,7 @@ def main():
         cfg.update(bcb_dims="1024-128-128", gen_dims="128-1")
     h = MyHandler(cfg, device=dev)
     n_pool = max(args.pool, args.bags)
-    xs, ys, ys_host = make_pool(torch, dev, args.mode, n_pool, args.patches, seed=1234 + rank)
+    xs, ys, ys_host = make_pool(torch, dev, args.mode, n_pool, args.patches, seed=1234 + rank, group=args.bags)
     cursor = [0]
 
     def eager_step():

@@ -42,7 +42,7 @@ int advmil_version(void);
  *   model/backbone_utils.py:16-17,35-44,150; model/model_utils.py:157-176) and the
  *   addmm/mm calls autograd issues for their backward.
  * epilogue, applied in this order per element (row m, col n):
- *   v = alpha*acc (+ bias[n]) (+ rowv[m]*colv[n]); v = act(v)  [act0 for n < act_split, else act1];
+ *   v = alpha*acc (+ bias[n]) (+ rowv[m]*colv[rowseg[m]*N + n]); v = act(v)  [act0 for n < act_split, else act1];
  *   v *= dropout(m*N+n); v *= (maskref[m*ldmask+n] > 0 ? mask_scale : 0) if maskref;
  *   C = v (+ C if accumulate).
  * splits > 1 partitions K across workgroups (needed when M*N is small and K is the bag length);
@@ -56,6 +56,7 @@ typedef struct {
   uint64_t stream_id;
   const float* rowv;
   const float* colv;
+  const int32_t* rowseg; /* NULL, or the segment (bag) of each row: the rank-1 term reads colv[rowseg[m]*N + n] */
   const float* maskref;
   int ldmask;
   float mask_scale;
@@ -109,11 +110,15 @@ int advmil_softmax_rows_bwd(const float* P, const float* dPd, float* dS, int64_t
  *   removes the per-parameter accumulate launches autograd would issue for every bag. */
 int advmil_gate_score_fwd(const float* ab, const float* wc, const float* bc, float drop_p, const uint64_t* seed,
                           uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D, float* s, advmil_stream_t stream);
-size_t advmil_softmax_pool_workspace_bytes(int64_t N, int64_t D);
-int advmil_softmax_pool_fwd(const float* s, const float* h, int64_t ldh, int64_t N, int64_t D, float* A,
-                            float* pooled, void* ws, size_t ws_bytes, advmil_stream_t stream);
+/* Segmented form: the N rows are a ragged slab of `nseg` bags, bag b = rows [seg_ptr[b], seg_ptr[b+1]) (device int64
+ * array; NULL = one segment), max_len = longest segment. pooled / dpooled are [nseg, D]; A, s, ds are [N]. */
+size_t advmil_softmax_pool_workspace_bytes(int64_t max_len, int64_t D, int nseg);
+int advmil_softmax_pool_fwd(const float* s, const float* h, int64_t ldh, int64_t N, int64_t D, int nseg,
+                            const int64_t* seg_ptr, int64_t max_len, float* A, float* pooled, void* ws, size_t ws_bytes,
+                            advmil_stream_t stream);
 int advmil_softmax_pool_bwd(const float* dpooled, const float* dA, const float* A, const float* h, int64_t ldh,
-                            int64_t N, int64_t D, float* ds, void* ws, size_t ws_bytes, advmil_stream_t stream);
+                            int64_t N, int64_t D, int nseg, const int64_t* seg_ptr, int64_t max_len, float* ds, void* ws,
+                            size_t ws_bytes, advmil_stream_t stream);
 size_t advmil_gate_bwd_workspace_bytes(int64_t N, int64_t D);
 int advmil_gate_bwd(const float* ab, const float* ds, const float* wc, float drop_p, const uint64_t* seed,
                     uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D, float* dG, float* dwc, float* dbc,

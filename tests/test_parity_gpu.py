@@ -354,3 +354,28 @@ def test_patchgcn_vs_oracle(p_on):
             continue
         scale = float(want.abs().max()) + 1e-12
         assert float((p.grad.cpu() - want).abs().max()) <= 2e-4 * scale + 1e-8, k
+
+
+@pytest.mark.parametrize("kind", ["abmil", "patch", "cluster", "graph"])
+def test_slab_features_equal_per_bag_features(kind):
+    """The step-slab path (one launch set over B ragged bags, segmented softmax-pool) reproduces the per-bag path."""
+    from types import SimpleNamespace
+    from advmil_amd import ops
+    from advmil_amd.model import load_backbone
+    dims = [1024, 128, 128] if kind == "graph" else [1024, 384, 384]
+    bb = load_backbone(kind, dims).to(DEV).eval()
+    lens = [64, 512, 208]                                    # ragged; 208/16 = 13 regions (padding path of the attention)
+    xs = [H.bag(20 + i, 512, DEV)[0, :n].contiguous() for i, n in enumerate(lens)]
+    if kind == "cluster":
+        exts = [H.T(synth.cluster_ids(0, 20 + i, n), DEV) for i, n in enumerate(lens)]
+    elif kind == "graph":
+        exts = [SimpleNamespace(x=x, edge_index=H.T(synth.grid_knn_graph(n, 8), DEV)) for x, n in zip(xs, lens)]
+    else:
+        exts = None
+    seg = ops.Segments(lens, DEV)
+    X = torch.cat(xs, dim=0)
+    with torch.no_grad():
+        multi = bb.features_multi(X, seg, exts)
+        single = torch.cat([bb.features_multi(x, None, None if exts is None else [exts[i]]) for i, x in enumerate(xs)], dim=0)
+    assert multi.shape == single.shape == (3, dims[1])
+    close(multi, single, 1e-5)
