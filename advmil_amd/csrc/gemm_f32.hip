@@ -26,7 +26,7 @@ struct GemmArgs {
   int64_t k_chunk;   // K range per split (multiple of BK)
   float* ws;         // [splits][M][N] partials when splits > 1
   int splits;
-  int mtiles;
+  int mtiles, ntiles;
   int64_t sA, sB, sC;   // per-batch element strides (gridDim.z = batch)
   advmil_epilogue_t epi;
 };
@@ -97,8 +97,29 @@ __global__ __launch_bounds__(256, (TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(Ge
   const int i = lane & 31, hi = lane >> 5;
   const int wr = wave >> 1, wc = wave & 1;
 
+  // XCD-aware tile order. Workgroup b runs on XCD b % 8 (each XCD has a private 4 MB L2), so tiles that share an
+  // operand panel are given ids 8 apart: same XCD, dispatched back to back -> the panel is fetched from HBM once and
+  // re-read from that L2. "inner" is the shorter tile axis: n-tiles of one A row-panel for the forward GEMMs
+  // (ntiles = 2..4), m-tiles of one B panel for the dW = dY^T X contractions (mtiles = 3..6).
   const int bid = blockIdx.x;
-  const int mt_i = bid % g.mtiles, nt_i = bid / g.mtiles;
+  int mt_i, nt_i;
+  {
+    const bool inner_n = g.ntiles <= g.mtiles;
+    const int inner = inner_n ? g.ntiles : g.mtiles, outer = inner_n ? g.mtiles : g.ntiles;
+    const int per_group = 8 * inner, full = (outer / 8) * per_group;
+    int o, i_;
+    if (bid < full) {
+      const int r = bid % per_group;
+      o = (bid / per_group) * 8 + (r & 7);
+      i_ = r >> 3;
+    } else {
+      const int rem = outer - (outer / 8) * 8, r = bid - full;
+      o = (outer / 8) * 8 + r % rem;
+      i_ = r / rem;
+    }
+    mt_i = inner_n ? o : i_;
+    nt_i = inner_n ? i_ : o;
+  }
   const int64_t m0 = (int64_t)mt_i * BM_, n0 = (int64_t)nt_i * BN_;
   const int z = blockIdx.y;
   g.A += (int64_t)blockIdx.z * g.sA;   // batched heads: plain pointer offsets
@@ -310,6 +331,7 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
   const int tm = tile / 10, tn = tile % 10;
   g.mtiles = (int)((M + 64 * tm - 1) / (64 * tm));
   const int ntiles = (int)((N + 64 * tn - 1) / (64 * tn));
+  g.ntiles = ntiles;
   dim3 grid(g.mtiles * ntiles, splits);
   switch (tile) {
     case 23: launch_tile<2, 3>(a_kc, b_kc, grid, stream, g); break;
@@ -361,6 +383,7 @@ extern "C" int advmil_gemm_f32_batched(int a_kc, int b_kc, int64_t M, int64_t N,
   const int tm = tile / 10, tn = tile % 10;
   g.mtiles = (int)((M + 64 * tm - 1) / (64 * tm));
   const int ntiles = (int)((N + 64 * tn - 1) / (64 * tn));
+  g.ntiles = ntiles;
   dim3 grid(g.mtiles * ntiles, 1, batch);
   if (tile == 12) launch_tile<1, 2>(a_kc, b_kc, grid, stream, g);
   else launch_tile<1, 1>(a_kc, b_kc, grid, stream, g);

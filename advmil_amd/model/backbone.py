@@ -182,14 +182,17 @@ class PatchGCN(nn.Module):
         """Slab form: the bags' graphs become one block-diagonal graph over the slab's rows (node ids offset per bag)."""
         if seg is None:
             return self.forward(exts[0])
+        # one union CSR per distinct group of graphs, kept alive for the module's lifetime: captured HIP graphs hold the
+        # raw addresses of these index arrays
         key = tuple(id(e) for e in exts)
-        cache = getattr(self, "_union_cache", None)
-        if cache is None or cache[0] != key:
+        caches = self.__dict__.setdefault("_union_cache", {})
+        cache = caches.get(key)
+        if cache is None:
             ei = torch.cat([e.edge_index.to(torch.long) + seg.offsets[b] for b, e in enumerate(exts)], dim=1)
             from types import SimpleNamespace
             union = SimpleNamespace(x=X, edge_index=ei)
             union._advmil_csr = ops.GraphCSR(ei, seg.total)
-            self._union_cache = cache = (key, union)
+            caches[key] = cache = (key, union, list(exts))
         union = cache[1]
         union.x = X
         return self._run(union, seg)
