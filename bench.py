@@ -40,7 +40,10 @@ def parse():
     ap.add_argument("--patches", type=int, default=8192)
     ap.add_argument("--mode", default="abmil", choices=["abmil", "patch", "cluster", "graph"])
     ap.add_argument("--pool", type=int, default=64, help="distinct resident bags per GPU")
+    ap.add_argument("--gen-dtype", default="f32", choices=["f32", "bf16"],
+                    help="generator contraction operands: f32 (exact) or bf16 MFMA (mixed precision, D stays f32)")
     ap.add_argument("--eager", action="store_true", help="drive the step eagerly instead of replaying HIP graphs")
+    ap.add_argument("--no-bf16-extra", action="store_true", help="skip the extra mixed-precision (bf16 generator) measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-bags", type=int, default=4, help="bags in the CPU-baseline sample")
@@ -157,7 +160,7 @@ def main():
     dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
 
-    cfg = default_cfg(bcb_mode=args.mode, bp_every_batch=args.bags, cuda_id=dev.index)
+    cfg = default_cfg(bcb_mode=args.mode, bp_every_batch=args.bags, cuda_id=dev.index, gen_gemm_dtype=args.gen_dtype)
     if args.mode == "graph":            # PatchGCN dims of the reference's model_stats.py:63
         cfg.update(bcb_dims="1024-128-128", gen_dims="128-1")
     h = MyHandler(cfg, device=dev)
@@ -291,6 +294,33 @@ def main():
                 "eager_event_bracketed_us": {f"{k[0]} {list(k[1][:3])}": round(1e3 * v["ms"] / v["n"], 1)
                                              for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]}}
 
+    # ---- extra (single GPU, f32 runs only): the same step with bf16 MFMA operands in the generator's contractions
+    bf16_extra = None
+    if world == 1 and args.gen_dtype == "f32" and args.mode == "abmil" and not args.no_bf16_extra and not args.eager:
+        try:
+            from advmil_amd.graphed import GraphedStep
+            h2 = MyHandler(default_cfg(bcb_mode=args.mode, bp_every_batch=args.bags, cuda_id=dev.index, gen_gemm_dtype="bf16"), device=dev)
+            g2 = []
+            for g0 in range(0, n_pool - args.bags + 1, args.bags):
+                idx = list(range(g0, g0 + args.bags))
+                g2.append(GraphedStep(h2, [xs[i] for i in idx], [ys[i] for i in idx], [ys_host[i] for i in idx], warmup=1))
+            for k in range(args.warmup):
+                g2[k % len(g2)].replay()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for k in range(args.steps):
+                g2[k % len(g2)].replay()
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            bf16_extra = {"value": round(args.bags * args.steps / dt2, 3), "unit": "bags/s", "ms_per_step": round(1e3 * dt2 / args.steps, 3),
+                          "dtype": "bf16 MFMA operands for the generator's contractions, fp32 accumulate; discriminator and all element-wise math fp32",
+                          "parity": "tests/test_parity_gpu.py::test_bf16_generator_mode_meets_the_contract: from identical weights y/f/losses "
+                                    "within 1e-4 of the reference; after an Adam step on bf16-operand gradients per-bag outputs drift to ~4e-4 "
+                                    "(not the headline for that reason)"}
+            del g2, h2
+        except Exception as exc:
+            bf16_extra = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
+
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, torch)
@@ -300,14 +330,17 @@ def main():
         out = {
             "metric": "WSI bags/sec (full G+D step)", "value": round(bags_total / dt, 3), "unit": "bags/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.gen_dtype == "f32" else "bf16(generator contractions)+f32", "data": "synthetic",
             "config": {"workload": f"{args.mode.upper()}+AdvMIL(RLIP prj discriminator), {args.patches}-patch x 1024 fp32 bags "
-                                   f"(BASELINE.json configs[1] shape; fp32 storage+MFMA-f32 arithmetic instead of bf16)",
+                                   f"(BASELINE.json configs[1] shape; fp32 storage, "
+                                   + ("exact fp32 MFMA arithmetic -- higher precision than the bf16 the config names)" if args.gen_dtype == "f32"
+                                      else "bf16 MFMA operands in the generator)"),
                        "bags_per_step_per_gpu": args.bags, "global_bags_per_step": args.bags * world, "gen_updates": 1,
                        "distinct_resident_bags_per_gpu": n_pool, "parallelism": f"bag-parallel dp{world}", "dropout": "shipped rates",
                        "launch": launch_note},
             "gd_steps_per_sec": round(args.steps / dt, 3), "losses_finite": bool(finite), "replicas_in_sync": in_sync,
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "mixed_precision_bf16_generator": bf16_extra,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -77,6 +77,22 @@ int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, c
                           const float* B, int64_t ldb, float* C, int64_t ldc, const advmil_epilogue_t* epi,
                           int splits, int tile, void* ws, size_t ws_bytes, advmil_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * bf16-operand / fp32-accumulate engine (v_mfma_f32_32x32x16_bf16): C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T), both
+ * operands k-contiguous bf16 (uint16 storage; lda/ldb/K multiples of 8). Same epilogue as advmil_gemm_f32. Outputs, any
+ * subset: C fp32 [M,N]; Cb bf16 [M,N]; Ct bf16 TRANSPOSED [N][ldct] -- the transposed copy is what lets the backward
+ * contractions (dW = dY^T X, dX = dY W) run in this same NT form. splits > 1: fp32 C only. tile as in advmil_gemm_f32_tiled
+ * (22/12/11; 0 = advmil_gemm_bf16_plan). Used for the GENERATOR's contractions; the discriminator stays fp32 (DESIGN.md §4:
+ * its logit moves 2.7e-4 under bf16 operands, above the 1e-4 parity contract; y and the attention weights move < 2e-6). */
+int advmil_gemm_bf16_plan(int64_t M, int64_t N, int64_t K, int* tile, int* splits);
+size_t advmil_gemm_bf16_workspace_bytes(int64_t M, int64_t N, int splits);
+int advmil_gemm_bf16_nt(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, float* C,
+                        int64_t ldc, void* Cb, int64_t ldcb, void* Ct, int64_t ldct, const advmil_epilogue_t* epi, int splits,
+                        int tile, void* ws, size_t ws_bytes, advmil_stream_t stream);
+/* fp32 [R,C] (row pitch ld_src) -> bf16 [R,C] (dst, may be NULL) and/or bf16 transposed [C,R] (dstT, may be NULL). */
+int advmil_cast_bf16(const float* src, int64_t ld_src, int64_t R, int64_t C, void* dst, int64_t ld_dst, void* dstT,
+                     int64_t ld_dstT, advmil_stream_t stream);
+
 /* Batched form for the ESAT attention heads (nn.MultiheadAttention inside nn.TransformerEncoderLayer,
  * model/backbone_utils.py:113-127): batch b uses A + b*strideA, B + b*strideB, C + b*strideC (element strides), so the
  * heads are read as strided slices of the packed qkv[L,3d] and written straight into O[L,d]. C = alpha*op(A)op(B) (+C). */

@@ -209,3 +209,30 @@ def test_mha_batched_heads(ops, L, p):
     (orf * go.double()).sum().backward()
     assert relerr(o, orf) < 1e-5
     assert relerr(q.grad, r.grad) < 5e-5
+
+
+def _bf(t):
+    return t.bfloat16().double()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 104), (1024, 384, 1024), (384, 1024, 4096), (64, 64, 8)])
+def test_gemm_bf16_nt(ops, M, N, K):
+    """bf16-operand MFMA engine vs float64 on the SAME bf16-rounded operands (isolates the kernel from the rounding)."""
+    A = rnd(f"hA{M}{K}", M, K); B = rnd(f"hB{N}{K}", N, K); bias = rnd("hb", N)
+    Ab, Bb = A.to(DEV).bfloat16(), B.to(DEV).bfloat16()
+    ref = torch.relu(_bf(A) @ _bf(B).t() + bias.double())
+    for tile in (0, 22, 12, 11):
+        for splits in ((1, 2) if K >= 128 else (1,)):
+            both = splits == 1
+            C, Cb, Ct = ops.gemm_bf16(Ab, Bb, M, N, K, bias=bias.to(DEV), act0=1, want_bf16=both, want_bf16_t=both,
+                                      splits=splits, tile=tile)
+            assert relerr(C, ref) < 2e-6, (tile, splits, relerr(C, ref))
+            if both:
+                assert relerr(Cb.float(), ref) < 5e-3 and relerr(Ct.float().t(), ref) < 5e-3
+                assert torch.equal(Cb, C.bfloat16()) and torch.equal(Ct.t().contiguous(), C.bfloat16())
+
+
+def test_cast_bf16_and_transpose(ops):
+    x = rnd("cb", 200, 136)
+    d, dT = ops.cast_bf16(x.to(DEV), True, True)
+    assert torch.equal(d.cpu(), x.bfloat16()) and torch.equal(dT.cpu(), x.bfloat16().t().contiguous())
