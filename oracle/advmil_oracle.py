@@ -386,7 +386,7 @@ def _req(P):
 
 
 def update_disc(cfg, PG, PD, bags, noise_d, masks_real=None, masks_fake=None,
-                n_real_global=None, n_fake_global=None):
+                n_real_global=None, n_fake_global=None, visible=None):
     """netD.train(), netG.eval() (model_handler.py:355-356). bags = [(x[1,N,C], x_ext, y[1,2])].
     noise_d[i] = generator noise tensors for bag i. masks_real/fake[i] = D dropout masks for the
     real / fake forward of bag i. Returns (losses dict, grads of D, preds, f_fake list).
@@ -395,7 +395,7 @@ def update_disc(cfg, PG, PD, bags, noise_d, masks_real=None, masks_fake=None,
     reals, fakes, preds = [], [], []
     for i, (x, x_ext, y) in enumerate(bags):
         t, e = y[:, [0]], y[:, [1]]
-        if e.item() == 1:                                               # 373-379
+        if e.item() == 1 and (visible is None or visible[i]):           # 373-379: event bag with a visible label
             reals.append(_netD(cfg, PDg, x, t, None if masks_real is None else masks_real[i]).reshape(-1))
         with torch.no_grad():                                           # detached at 400
             pred = generator(PG, x, x_ext, cfg.kind, cfg.noise_flags, noise_d[i], None, cfg.out_scale)
@@ -416,8 +416,9 @@ def update_disc(cfg, PG, PD, bags, noise_d, masks_real=None, masks_fake=None,
     return logs, grads, preds, [f.detach() for f in fakes]
 
 
-def update_gen(cfg, PG, PD, bags, noise_g, masks_g=None, n_global=None):
-    """netD.eval(), netG.train() (model_handler.py:432-433); all labels visible ('wlabel')."""
+def update_gen(cfg, PG, PD, bags, noise_g, masks_g=None, n_global=None, visible=None):
+    """netD.eval(), netG.train() (model_handler.py:432-433). visible[i] False = label invisible ('wolabel' mode): the bag
+    still feeds the adversarial term but not the supervised loss (473-480)."""
     PGg = _req(PG)
     preds, fakes = [], []
     for i, (x, x_ext, y) in enumerate(bags):
@@ -426,12 +427,14 @@ def update_gen(cfg, PG, PD, bags, noise_g, masks_g=None, n_global=None):
         preds.append(pred)
         fakes.append(_netD(cfg, PD, x, pred, None).reshape(-1))
     fake = torch.cat(fakes)
-    P_ = torch.cat(preds)
-    T_ = torch.cat([y[:, [0]] for _, _, y in bags])
-    E_ = torch.cat([y[:, [1]] for _, _, y in bags])
+    keep = [i for i in range(len(bags)) if visible is None or visible[i]]
+    P_ = torch.cat([preds[i] for i in keep]) if keep else None
+    T_ = torch.cat([bags[i][2][:, [0]] for i in keep]) if keep else None
+    E_ = torch.cat([bags[i][2][:, [1]] for i in keep]) if keep else None
     if n_global is None:
         gen_loss = fake_generator_loss(fake)                            # 472
-        t_reg = recon_loss(P_, T_, E_, cfg.recon_alpha, cfg.recon_gamma, cfg.recon_norm)
+        t_reg = (recon_loss(P_, T_, E_, cfg.recon_alpha, cfg.recon_gamma, cfg.recon_norm) if keep
+                 else torch.zeros(()))                                  # 479-480
     else:
         gen_loss = -fake.sum() / n_global
         t_reg = recon_loss(P_, T_, E_, cfg.recon_alpha, cfg.recon_gamma, cfg.recon_norm) * (len(bags) / n_global)
@@ -449,12 +452,12 @@ def update_gen(cfg, PG, PD, bags, noise_g, masks_g=None, n_global=None):
     return logs, grads, preds
 
 
-def train_step(cfg, PG, PD, stG, stD, bags, noise_d, noise_g, masks_real=None, masks_fake=None, masks_g=None):
+def train_step(cfg, PG, PD, stG, stD, bags, noise_d, noise_g, masks_real=None, masks_fake=None, masks_g=None, visible=None):
     """One optimizer step of `_train_each_epoch` (model_handler.py:321-345): D update, then
     gen_updates=1 G update against the UPDATED D. Returns (PG', PD', logs, y_hat, f_fake)."""
-    logs_d, gD, preds, f_fake = update_disc(cfg, PG, PD, bags, noise_d, masks_real, masks_fake)
+    logs_d, gD, preds, f_fake = update_disc(cfg, PG, PD, bags, noise_d, masks_real, masks_fake, visible=visible)
     PD2 = adam_step(PD, gD, stD, cfg.lr_d, 0.0, decay_filter=False)
-    logs_g, gG, _ = update_gen(cfg, PG, PD2, bags, noise_g, masks_g)
+    logs_g, gG, _ = update_gen(cfg, PG, PD2, bags, noise_g, masks_g, visible=visible)
     PG2 = adam_step(PG, gG, stG, cfg.lr_g, cfg.wd_g, decay_filter=True)
     logs = dict(logs_d)
     logs.update(logs_g)

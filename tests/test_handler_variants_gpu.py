@@ -1,0 +1,156 @@
+"""GPU: the handler's step on the edge cases of the path, against the oracle on the same seeded inputs (dropout off,
+injected noise): ragged bags inside one step, steps without any event bag (no real pair), partially visible labels
+('wolabel'), the hinge / wasserstein losses, the concat and bag-level discriminators, checkpoint save/resume, and
+HIP-graph re-capture after a learning-rate change."""
+import numpy as np
+import pytest
+import torch
+
+from advmil_amd.config import default_cfg
+from oracle import advmil_oracle as O
+from tests import helpers as H
+from tests.test_parity_gpu import DEV, close, load_synth, zero_dropout
+
+pytestmark = pytest.mark.gpu
+
+
+def run_case(kind="abmil", lens=(256, 512, 128, 64), events=None, visible=None, mode="wlabel", steps=2, tol=2e-5, **cfg_over):
+    from advmil_amd.model import MyHandler
+    nb = len(lens)
+    h = MyHandler(default_cfg(bcb_mode=kind, bp_every_batch=nb, **cfg_over), device=DEV)
+    prj = cfg_over.get("disc_prj_path", "x")
+    dt = cfg_over.get("disc_type", "prj")
+    PG = load_synth(h.netG, f"G-{kind}:")
+    PD = load_synth(h.netD, "D-prj:" if dt == "prj" else "D-cat:")
+    zero_dropout(h.netG); zero_dropout(h.netD)
+    bags_all, loader = [], []
+    for s in range(steps):
+        for j, n in enumerate(lens):
+            i = s * nb + j
+            x = H.bag(40 + i, 512)[:, :n].contiguous()
+            y = H.label(i)
+            if events is not None:
+                y[0, 1] = float(events[j])
+            bags_all.append((x, None, y))
+            loader.append((torch.tensor([[i]], dtype=torch.int), [x, torch.zeros(1, 1)], y))
+    nd = [[H.noise_tensor("var_d", i, 192)] for i in range(steps * nb)]
+    ng = [[H.noise_tensor("var_g", i, 192)] for i in range(steps * nb)]
+    h.noise_hook = lambda ph, i: [(nd if ph == "d" else ng)[i][0].to(DEV)]
+    if visible is not None:
+        h.patient_id["train"] = [str(i) for i in range(steps * nb)]
+        h.patient_id["label_visible"] = [str(i) for i in range(steps * nb) if visible[i % nb]]
+    cl = h._train_each_epoch(loader, "train", mode)
+    logs = h.pop_logs()
+    cfg = O.StepConfig(kind=kind, disc_type=dt, inner_product=cfg_over.get("disc_prj_iprd", "instance"), prj_path=prj,
+                       loss_netD=cfg_over.get("loss_netD", "bce"))
+    stG, stD, oPG, oPD = {}, {}, PG, PD
+    for s in range(steps):
+        sl = slice(s * nb, s * nb + nb)
+        vis = None if visible is None else list(visible)
+        oPG, oPD, lg, yh, ff, _, _ = O.train_step(cfg, oPG, oPD, stG, stD, bags_all[sl], nd[sl], ng[sl], visible=vis)
+        d, g = logs[2 * s], logs[2 * s + 1]
+        got = {k.split("/")[-1]: v for k, v in list(d.items()) + list(g.items())}
+        for k in ("Loss_D", "D_real", "D_fake", "Loss_G_fake", "Loss_G_time", "Loss_G_total"):
+            assert abs(got[k] - lg[k]) < tol, (s, k, got[k], lg[k])
+        close(cl["y_hat"][sl], yh, tol); close(cl["f_fake"][sl], ff, tol)
+    for net, P in ((h.netG, oPG), (h.netD, oPD)):
+        for k, v in net.state_dict().items():
+            if k.endswith("pool.fc2.bias") or k.endswith("attention_c.bias") or (tol > 2e-5 and k in ("prj_layer.bias", "fc.bias")):
+                continue      # parameters whose true gradient is exactly 0: Adam amplifies round-off to +-lr on both sides
+            assert float((v.cpu() - P[k]).abs().max()) < 5e-5, k      # two Adam steps; lr = 8e-5
+    return h
+
+
+@pytest.mark.parametrize("kind", ["abmil", "patch"])
+def test_ragged_bags_in_one_step(kind):
+    run_case(kind=kind, lens=(256, 512, 128, 64, 208, 16))
+
+
+def test_step_without_event_bags_has_no_real_pairs():
+    h = run_case(lens=(128, 256, 64), events=(0, 0, 0))
+
+
+def test_single_bag_step():
+    run_case(lens=(512,), events=(1,))
+
+
+def test_wolabel_mode_partial_visibility():
+    # invisible labels: no real pair and no supervised term for those bags (model_handler.py:361-364, 473-480)
+    run_case(lens=(128, 256, 64, 512), events=(1, 1, 0, 1), visible=(True, False, True, False), mode="wolabel")
+
+
+def test_wolabel_mode_nothing_visible():
+    run_case(lens=(128, 64), events=(1, 0), visible=(False, False), mode="wolabel")
+
+
+@pytest.mark.parametrize("which", ["hinge", "wasserstein"])
+def test_other_d_losses(which):
+    # mean(1+f_fake) + mean(1-f_real) and mean(f_fake) - mean(f_real): the logit's additive bias has d/db = 1 - 1 = 0, so its
+    # Adam updates are round-off noise times lr on either side; logits after the D step may differ by a few lr (8e-5)
+    run_case(lens=(128, 256, 64), loss_netD=which, tol=4e-4)
+
+
+@pytest.mark.parametrize("over", [dict(disc_type="cat", disc_prj_path=None), dict(disc_prj_iprd="bag"), dict(disc_prj_path="y"),
+                                  dict(disc_prj_iprd="bag", disc_prj_path=None)])
+def test_discriminator_variants(over):
+    run_case(lens=(128, 256, 64), **over)
+
+
+def test_checkpoint_save_resume_round_trip(tmp_path):
+    from advmil_amd.model import MyHandler
+    cfg = default_cfg(bp_every_batch=2, save_path=str(tmp_path))
+    xs = [[H.bag(60 + i, 256, DEV), torch.zeros(1, 1, device=DEV)] for i in range(2)]
+    ys_host = [H.label(i) for i in range(2)]
+    ys = [y.to(DEV) for y in ys_host]
+    nz = [[H.noise_tensor("ck", i, 192, DEV)] for i in range(2)]
+
+    def steps(h, n):
+        for _ in range(n):
+            h._update_disc(0, xs, ys, ys_host=ys_host, noise=nz)
+            h._update_gen(0, xs, ys, ys_host=ys_host, noise=nz)
+
+    a = MyHandler(cfg, device=DEV); zero_dropout(a.netG); zero_dropout(a.netD)
+    steps(a, 2)
+    a.save_model(2, "last", "train")
+    ck = torch.load(a._prefixed(a.last_netG_ckpt_path, "train"))
+    assert set(ck) == {"epoch", "model", "optimizer"} and set(ck["optimizer"]) == {"state", "param_groups"}
+    st0 = ck["optimizer"]["state"][0]
+    assert set(st0) >= {"step", "exp_avg", "exp_avg_sq"} and float(st0["step"]) == 2.0      # torch.optim.Adam layout
+    steps(a, 1)
+    b = MyHandler(cfg, device=DEV); zero_dropout(b.netG); zero_dropout(b.netD)
+    b.resume_model("last", "train")
+    steps(b, 1)
+    for pa, pb in ((a.optimizerG, b.optimizerG), (a.optimizerD, b.optimizerD)):
+        assert float((pa.flat_param - pb.flat_param).abs().max()) == 0.0
+        assert float((pa.flat_m - pb.flat_m).abs().max()) == 0.0 and int(pa.step_t) == int(pb.step_t) == 3
+
+
+def test_reference_style_adam_state_loads(tmp_path):
+    """A torch.optim.Adam state_dict (what the reference's checkpoints hold) loads into FlatAdam."""
+    from advmil_amd.model import MyHandler
+    h = MyHandler(default_cfg(bp_every_batch=1), device=DEV)
+    ref_opt = torch.optim.Adam(h.netD.parameters(), lr=8e-5)
+    for p in h.netD.parameters():
+        p.grad = torch.ones_like(p) * 1e-3
+    ref_opt.step()
+    sd = ref_opt.state_dict()
+    h.optimizerD.load_state_dict(sd)
+    assert int(h.optimizerD.step_t) == 1
+    p0 = next(iter(h.netD.parameters()))
+    assert torch.allclose(h.optimizerD.state[p0]["exp_avg"], ref_opt.state[p0]["exp_avg"])
+
+
+def test_graph_recapture_after_lr_change():
+    from advmil_amd.graphed import GraphedStep
+    from advmil_amd.model import MyHandler
+    h = MyHandler(default_cfg(bp_every_batch=2), device=DEV)
+    xs = [[H.bag(70 + i, 256, DEV), torch.zeros(1, 1, device=DEV)] for i in range(2)]
+    ys_host = [H.label(i) for i in range(2)]
+    g = GraphedStep(h, xs, [y.to(DEV) for y in ys_host], ys_host, warmup=1)
+    g.replay()
+    for grp in h.optimizerG.param_groups:
+        grp["lr"] *= 0.5                                  # what ReduceLROnPlateau does (model_handler.py:109)
+    g.replay()                                            # must re-capture with the new launch constant
+    assert g.lrs[0] == h.optimizerG.param_groups[0]["lr"]
+    torch.cuda.synchronize()
+    assert torch.isfinite(h.optimizerG.flat_param).all()
