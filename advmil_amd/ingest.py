@@ -1,0 +1,83 @@
+"""Bag ingest for the step slab (replaces the synchronous pageable `.cuda()` per bag at
+reference model/model_handler.py:315).
+
+The loader hands over CPU tensors `x[1, N, 1024]`. `SlabStager` owns two (pinned host slab, device slab) pairs. Each bag is
+memcpy'd into the pinned slab and sent to the device slab with an async H2D copy on a dedicated copy stream, so
+  * the bags of one optimizer step land BACK TO BACK in HBM -> the step's `[sum N, 1024]` matrix is a zero-copy view;
+  * while step t computes on pair k, the host already stages step t+1 into pair k^1 (PCIe overlaps compute);
+  * a pair is only rewritten after the step that read it has finished (event from the compute stream).
+"""
+import torch
+
+
+class SlabStager:
+    def __init__(self, device, channels=1024, dtype=torch.float32):
+        self.device = torch.device(device)
+        self.channels = channels
+        self.dtype = dtype
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.host = [None, None]
+        self.dev = [None, None]
+        self.free_evt = [None, None]      # recorded on the compute stream when the step reading pair k is enqueued
+        self.k = 1
+        self.rows = 0
+        self.views = []
+
+    def _ensure(self, k, rows):
+        cap = 0 if self.dev[k] is None else self.dev[k].shape[0]
+        if rows <= cap:
+            return
+        new_cap = max(rows, int(cap * 1.5), 1024)
+        host = torch.empty(new_cap, self.channels, dtype=self.dtype).pin_memory()
+        dev = torch.empty(new_cap, self.channels, dtype=self.dtype, device=self.device)
+        if self.rows and self.dev[k] is not None:               # growing in the middle of a batch: keep what is staged
+            self.copy_stream.synchronize()
+            host[:self.rows].copy_(self.host[k][:self.rows])
+            dev[:self.rows].copy_(self.dev[k][:self.rows])
+            torch.cuda.current_stream(self.device).synchronize()
+        self.host[k], self.dev[k] = host, dev
+        self.views = [self.dev[k][a:b].unsqueeze(0) for a, b in self._spans]
+
+    def begin(self):
+        """Start staging a new step batch into the other buffer pair."""
+        self.k ^= 1
+        self.rows = 0
+        self.views = []
+        self._spans = []
+        self._keep = []
+        if self.free_evt[self.k] is not None:                    # do not overwrite bags a running step still reads
+            self.copy_stream.wait_event(self.free_evt[self.k])
+
+    def add(self, x_cpu):
+        """Stage one bag x[1, N, C] (CPU) -> device view [1, N, C] inside the slab (valid after `ready()`)."""
+        x2 = x_cpu.reshape(-1, x_cpu.shape[-1])
+        n = x2.shape[0]
+        k = self.k
+        self._spans.append((self.rows, self.rows + n))
+        self._ensure(k, self.rows + n)
+        a, b = self.rows, self.rows + n
+        if x2.is_pinned():                                        # DataLoader(pin_memory=True): DMA straight from the loader's buffer
+            src = x2
+            self._keep.append(x_cpu)                              # keep the source alive until the copy has run
+        else:
+            self.host[k][a:b].copy_(x2)                           # pageable -> pinned (one host memcpy, ~10 GB/s per thread)
+            src = self.host[k][a:b]
+        with torch.cuda.stream(self.copy_stream):
+            self.dev[k][a:b].copy_(src, non_blocking=True)
+        self.rows = b
+        if len(self.views) < len(self._spans):
+            self.views.append(self.dev[k][a:b].unsqueeze(0))
+        return self.views[-1]
+
+    def ready(self):
+        """Make the compute stream wait for the staged copies; returns the per-bag device views of this batch."""
+        evt = torch.cuda.Event()
+        evt.record(self.copy_stream)
+        torch.cuda.current_stream(self.device).wait_event(evt)
+        return list(self.views)
+
+    def release(self):
+        """Call after the step that reads this batch has been enqueued on the compute stream."""
+        evt = torch.cuda.Event()
+        evt.record(torch.cuda.current_stream(self.device))
+        self.free_evt[self.k] = evt

@@ -26,6 +26,7 @@ import torch
 from .. import ops
 from ..loss.utils import fake_generator_loss, real_fake_loss, real_fake_terms, recon_loss, recon_terms
 from ..optim import FlatAdam, create_optimizer
+from ..ingest import SlabStager
 from ..parallel import BagParallel
 from ..utils.func import agg_tensor, seed_everything, sparse_key, sparse_str
 from .backbone import load_backbone
@@ -152,18 +153,35 @@ class MyHandler(object):
 
     # ------------------------------------------------------------------------------------------
     def _train_each_epoch(self, train_loader, name_loader, mode="wlabel"):
+        """Same contract as the reference (model_handler.py:301-347). Bags arriving as CPU tensors are staged through the
+        double-buffered pinned slab (advmil_amd/ingest.py): async H2D on a copy stream, the step batch contiguous in HBM."""
         bp_every_batch = self.cfg["bp_every_batch"]
         num_update_gen = self.cfg["gen_updates"]
         ys_all, yhat_all, ffake_all = [], [], []
         i_col, x_col, y_col, yh_col = [], [], [], []
+        stager = None
+        staged = False
         i_batch = 0
         for data_idx, data_x, data_y in train_loader:
             i_batch += 1
             yh_col.append(data_y if not data_y.is_cuda else None)
-            data_x = [dx.to(self.device, non_blocking=True) if torch.is_tensor(dx) else dx for dx in data_x]
+            x0 = data_x[0]
+            if torch.is_tensor(x0) and not x0.is_cuda and self.bcb != "graph":
+                if stager is None:
+                    stager = self.__dict__.setdefault("_stager", None) or SlabStager(self.device, x0.shape[-1])
+                    self._stager = stager
+                if not staged:
+                    stager.begin()
+                    staged = True
+                data_x = [stager.add(x0)] + [dx.to(self.device, non_blocking=True) if torch.is_tensor(dx) else dx for dx in data_x[1:]]
+            else:
+                data_x = [dx.to(self.device, non_blocking=True) if torch.is_tensor(dx) else dx for dx in data_x]
             data_y = data_y.to(self.device, non_blocking=True)
             i_col.append(data_idx); x_col.append(data_x); y_col.append(data_y)
             if i_batch % bp_every_batch == 0:
+                if staged:                               # growth may have re-based the views: take the final ones
+                    for xc, v in zip(x_col, stager.ready()):
+                        xc[0] = v
                 mask = self._get_label_visiable_mask(name_loader, i_col)
                 ys_host = None if any(h is None for h in yh_col) else yh_col
                 nz_d = nz_g = None
@@ -173,6 +191,9 @@ class MyHandler(object):
                 preds, fakes = self._update_disc(i_batch, x_col, y_col, mode, mask, ys_host=ys_host, noise=nz_d)
                 for _ in range(num_update_gen):
                     self._update_gen(i_batch, x_col, y_col, mode, mask, ys_host=ys_host, noise=nz_g)
+                if staged:
+                    stager.release()
+                    staged = False
                 ys_all.append(torch.cat(y_col, dim=0)); yhat_all.append(torch.cat(preds, dim=0).detach())
                 ffake_all.append(torch.cat(fakes, dim=0))
                 i_col, x_col, y_col, yh_col = [], [], [], []

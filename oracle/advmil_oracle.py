@@ -448,7 +448,7 @@ def update_gen(cfg, PG, PD, bags, noise_g, masks_g=None, n_global=None, visible=
         total = total + l1
     grads = {k: v.grad for k, v in PGg.items() if v.grad is not None}
     logs = {"Loss_G_fake": gen_loss.item(), "Loss_G_time": t_reg.item(),
-            "Loss_G_total": float(total), "D_fake_avg": fake.mean().item()}
+            "Loss_G_total": float(total.detach()) if torch.is_tensor(total) else float(total), "D_fake_avg": fake.mean().item()}
     return logs, grads, preds
 
 
