@@ -280,7 +280,7 @@ static int64_t n_tiles(int tile, int64_t M, int64_t N) {
 // If even 64x64 tiles are too few and K is deep (the dW = dY^T X contractions, K = bag length), split K so that
 // ~768 workgroups each keep >= 1024 of K (partials reduced by a second launch).
 extern "C" int advmil_gemm_f32_plan(int64_t M, int64_t N, int64_t K, int* tile, int* splits) {
-  static const int order[5] = {23, 22, 13, 12, 11};
+  static const int order[5] = {22, 12, 23, 13, 11};   // 128x192 is never better than 128x128 / 64x128 once M is a slab (tools/gemm_slab_check.py)
   for (int c = 0; c < 5; ++c)
     if (n_tiles(order[c], M, N) >= 512) { *tile = order[c]; *splits = 1; return ADVMIL_OK; }
   const int64_t w11 = n_tiles(11, M, N);
