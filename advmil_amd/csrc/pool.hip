@@ -7,6 +7,15 @@
 #include "../../include/advmil_hip.h"
 
 #define ROWS_PER_BLOCK 32
+// rows per workgroup of the two-stage reductions: 32 for one bag, grown so that a step slab yields <= ~1024 partial rows
+// (the merge kernels walk the partials serially per column)
+static inline int rows_per_block(int64_t rows) {
+  int64_t r = (rows + 1023) / 1024;
+  r = (r + 31) / 32 * 32;
+  if (r < ROWS_PER_BLOCK) r = ROWS_PER_BLOCK;
+  if (r > 512) r = 512;
+  return (int)r;
+}
 
 // 256 threads cover `rpp` rows x `cols4` float4 columns
 struct RowColMap {
@@ -154,17 +163,17 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restri
                                                            int64_t ldh, int64_t N, int64_t D,
                                                            const int64_t* __restrict__ seg_ptr,
                                                            const float* __restrict__ stats, float* __restrict__ A,
-                                                           float* __restrict__ partial) {
+                                                           float* __restrict__ partial, int rpb) {
   __shared__ __attribute__((aligned(16))) float red[1024];
   const RowColMap m = make_map(D);
   const int b = blockIdx.y;
   int64_t beg, end;
   seg_range(seg_ptr, b, N, beg, end);
   const float mx = stats[2 * b], inv = stats[2 * b + 1];
-  const int64_t r0 = beg + (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+  const int64_t r0 = beg + (int64_t)blockIdx.x * rpb;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (m.active) {
-    for (int r = m.r; r < ROWS_PER_BLOCK; r += m.rpp) {
+    for (int r = m.r; r < rpb; r += m.rpp) {
       const int64_t n = r0 + r;
       if (n >= end) break;
       const float w = expf(s[n] - mx) * inv;
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restri
     *reinterpret_cast<float4*>(partial + ((int64_t)b * gridDim.x + blockIdx.x) * D + m.c4 * 4) = t;
 }
 
-static inline int64_t pool_nblk(int64_t max_len) { return (max_len + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK; }
+static inline int64_t pool_nblk(int64_t max_len) { const int r = rows_per_block(max_len); return (max_len + r - 1) / r; }
 
 extern "C" size_t advmil_softmax_pool_workspace_bytes(int64_t max_len, int64_t D, int nseg) {
   if (nseg < 1) nseg = 1;
@@ -200,7 +209,8 @@ extern "C" int advmil_softmax_pool_fwd(const float* s, const float* h, int64_t l
   const int nblk = (int)pool_nblk(max_len);
   hipLaunchKernelGGL(softmax_stats_kernel, dim3(nseg), dim3(1024), 0, stream, s, N, seg_ptr, stats);
   ADVMIL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(pool_partial_kernel, dim3(nblk, nseg), dim3(256), 0, stream, s, h, ldh, N, D, seg_ptr, stats, A, partial);
+  hipLaunchKernelGGL(pool_partial_kernel, dim3(nblk, nseg), dim3(256), 0, stream, s, h, ldh, N, D, seg_ptr, stats, A, partial,
+                     rows_per_block(max_len));
   ADVMIL_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_merge_kernel, dim3((unsigned)((D + 15) / 16), nseg), dim3(256), 0, stream, partial, nblk, D, D, pooled,
                      0, (int64_t)nblk * D, D);
@@ -278,7 +288,7 @@ extern "C" int advmil_softmax_pool_bwd(const float* dpooled, const float* dA, co
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ ab, const float* __restrict__ ds,
                                                        const float* __restrict__ wc, float p, const uint64_t* seed,
                                                        uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D,
-                                                       float* __restrict__ dG, float* __restrict__ partial) {
+                                                       float* __restrict__ dG, float* __restrict__ partial, int rpb) {
   __shared__ __attribute__((aligned(16))) float red[1024];
   const RowColMap m = make_map(D);
   const bool drop = seed && p > 0.f;
@@ -288,13 +298,13 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
     const uint64_t sd = *seed;
     ka = rng_key(sd, stream_a); kb = rng_key(sd, stream_b); inv = 1.f / (1.f - p);
   }
-  const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+  const int64_t r0 = (int64_t)blockIdx.x * rpb;
   float4 s_wc = make_float4(0.f, 0.f, 0.f, 0.f), s_a = s_wc, s_b = s_wc;
   float s_ds = 0.f;
   if (m.active) {
     const float4 w4 = *reinterpret_cast<const float4*>(wc + m.c4 * 4);
     const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
-    for (int r = m.r; r < ROWS_PER_BLOCK; r += m.rpp) {
+    for (int r = m.r; r < rpb; r += m.rpp) {
       const int64_t n = r0 + r;
       if (n >= N) break;
       const float d = ds[n];
@@ -342,7 +352,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
 }
 
 extern "C" size_t advmil_gate_bwd_workspace_bytes(int64_t N, int64_t D) {
-  const int64_t nblk = (N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  const int64_t nblk = (N + rows_per_block(N) - 1) / rows_per_block(N);
   return (size_t)(nblk * (3 * D + 4)) * sizeof(float);
 }
 
@@ -353,11 +363,12 @@ extern "C" int advmil_gate_bwd(const float* ab, const float* ds, const float* wc
   if (!ab || !ds || !wc || !dG || !dwc || !dbc || !dbias || !ws || N <= 0 || D <= 0 || (D & 3) || D > 1024)
     return ADVMIL_EINVAL;
   if (ws_bytes < advmil_gate_bwd_workspace_bytes(N, D)) return ADVMIL_EWORKSPACE;
-  const int nblk = (int)((N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+  const int rpb = rows_per_block(N);
+  const int nblk = (int)((N + rpb - 1) / rpb);
   float* partial = (float*)ws;
   const int64_t stride = 3 * D + 4;
   hipLaunchKernelGGL(gate_bwd_kernel, dim3(nblk), dim3(256), 0, stream, ab, ds, wc, drop_p, seed, stream_a, stream_b, N, D,
-                     dG, partial);
+                     dG, partial, rpb);
   ADVMIL_LAUNCH_CHECK();
   // dwc | dbias(a) | dbias(b) | dbc are adjacent in the partial rows: one merge launch over 3D+1 columns into a
   // scratch row, then scattered by the three tiny copies below would cost more launches; instead merge each target.
@@ -375,7 +386,7 @@ __global__ __launch_bounds__(256) void act_dropout_bwd_kernel(const float* __res
                                                               int act, float p, const uint64_t* seed, uint64_t stream_id,
                                                               int64_t M, int64_t N, int64_t c0, int64_t W,
                                                               float* __restrict__ dpre, float* __restrict__ partial,
-                                                              int64_t pstride) {
+                                                              int64_t pstride, int rpb) {
   __shared__ __attribute__((aligned(16))) float red[1024];
   const RowColMap m = make_map(W);
   const bool drop = seed && p > 0.f;
@@ -383,10 +394,10 @@ __global__ __launch_bounds__(256) void act_dropout_bwd_kernel(const float* __res
   float inv = 1.f;
   if (drop) { key = rng_key(*seed, stream_id); inv = 1.f / (1.f - p); }
   const float keep_scale = 1.f - p;
-  const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+  const int64_t r0 = (int64_t)blockIdx.x * rpb;
   float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
   if (m.active) {
-    for (int r = m.r; r < ROWS_PER_BLOCK; r += m.rpp) {
+    for (int r = m.r; r < rpb; r += m.rpp) {
       const int64_t row = r0 + r;
       if (row >= M) break;
       const int64_t off = row * N + c0 + m.c4 * 4;
@@ -414,7 +425,7 @@ __global__ __launch_bounds__(256) void act_dropout_bwd_kernel(const float* __res
 }
 
 extern "C" size_t advmil_colsum_workspace_bytes(int64_t M, int64_t N) {
-  const int64_t nblk = (M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  const int64_t nblk = (M + rows_per_block(M) - 1) / rows_per_block(M);
   return (size_t)(nblk * N) * sizeof(float);
 }
 
@@ -424,12 +435,13 @@ extern "C" int advmil_act_dropout_bwd(const float* dy, const float* y, int act, 
   hipStream_t stream = (hipStream_t)stream_;
   if (!dy || !y || !dpre || M <= 0 || N <= 0 || (N & 3)) return ADVMIL_EINVAL;
   if (dbias && (!ws || ws_bytes < advmil_colsum_workspace_bytes(M, N))) return ADVMIL_EWORKSPACE;
-  const int nblk = (int)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+  const int rpb = rows_per_block(M);
+  const int nblk = (int)((M + rpb - 1) / rpb);
   float* partial = dbias ? (float*)ws : nullptr;
   for (int64_t c0 = 0; c0 < N; c0 += 1024) {
     const int64_t W = (N - c0 < 1024) ? (N - c0) : 1024;
     hipLaunchKernelGGL(act_dropout_bwd_kernel, dim3(nblk), dim3(256), 0, stream, dy, y, act, drop_p, seed, stream_id, M, N,
-                       c0, W, dpre, partial, N);
+                       c0, W, dpre, partial, N, rpb);
   }
   ADVMIL_LAUNCH_CHECK();
   if (dbias) {
@@ -440,13 +452,13 @@ extern "C" int advmil_act_dropout_bwd(const float* dy, const float* y, int act, 
 }
 
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int64_t M, int64_t N, int64_t c0,
-                                                             int64_t W, float* __restrict__ partial) {
+                                                             int64_t W, float* __restrict__ partial, int rpb) {
   __shared__ __attribute__((aligned(16))) float red[1024];
   const RowColMap m = make_map(W);
-  const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+  const int64_t r0 = (int64_t)blockIdx.x * rpb;
   float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
   if (m.active) {
-    for (int r = m.r; r < ROWS_PER_BLOCK; r += m.rpp) {
+    for (int r = m.r; r < rpb; r += m.rpp) {
       const int64_t row = r0 + r;
       if (row >= M) break;
       const float4 v = *reinterpret_cast<const float4*>(x + row * N + c0 + m.c4 * 4);
@@ -462,10 +474,11 @@ extern "C" int advmil_colsum(const float* x, int64_t M, int64_t N, float* out, i
   hipStream_t stream = (hipStream_t)stream_;
   if (!x || !out || !ws || M <= 0 || N <= 0 || (N & 3)) return ADVMIL_EINVAL;
   if (ws_bytes < advmil_colsum_workspace_bytes(M, N)) return ADVMIL_EWORKSPACE;
-  const int nblk = (int)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+  const int rpb = rows_per_block(M);
+  const int nblk = (int)((M + rpb - 1) / rpb);
   for (int64_t c0 = 0; c0 < N; c0 += 1024) {
     const int64_t W = (N - c0 < 1024) ? (N - c0) : 1024;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, x, M, N, c0, W, (float*)ws);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, x, M, N, c0, W, (float*)ws, rpb);
   }
   hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(N), dim3(256), 0, stream, (const float*)ws, nblk, N, N, out, accumulate);
   ADVMIL_LAUNCH_CHECK();
