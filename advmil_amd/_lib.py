@@ -33,6 +33,8 @@ SIGNATURES = {
     "advmil_gemm_f32_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "advmil_gemm_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                                 c_int64, ctypes.POINTER(Epilogue), c_int, c_void_p, c_size_t, c_void_p]),
+    "advmil_set_gemm_mode": (c_int, [c_int]),
+    "advmil_get_gemm_mode": (c_int, []),
     "advmil_gemm_f32_plan": (c_int, [c_int64, c_int64, c_int64, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "advmil_gemm_f32_tiled": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                                       c_int64, ctypes.POINTER(Epilogue), c_int, c_int, c_void_p, c_size_t, c_void_p]),
@@ -98,6 +100,9 @@ def lib():
             fn = getattr(handle, name)   # AttributeError if the .so is stale
             fn.restype = res
             fn.argtypes = args
+        mode = os.environ.get("ADVMIL_GEMM_MODE")        # "exact" (default) | "bf16x3"
+        if mode:
+            handle.advmil_set_gemm_mode({"exact": 0, "f32": 0, "bf16x3": 1, "split": 1}[mode])
         _lib = handle
     return _lib
 

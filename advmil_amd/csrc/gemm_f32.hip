@@ -85,7 +85,36 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ s, int rbase
   }
 }
 
-template <bool A_KC, bool B_KC, int TM, int TN>
+// ---- split-bf16 ("bf16x3") arithmetic: x = hi + lo with hi = bf16(x), lo = bf16(x - hi); a.b ~= ah.bh + ah.bl + al.bh on the
+// bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate), fp32 accumulate. The dropped terms are ~2^-17 of |a||b|
+// per product (fp32 MFMA: 2^-24), i.e. near-fp32 results at 3/16 of the matrix-pipe time. Operands stay fp32 in HBM and LDS; the
+// split happens per fragment in the (otherwise idle) VALU.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// the 8 consecutive k of MFMA k-step `ks` (16 k) that lane-half `hi` feeds, for the 32-row block at rbase
+template <bool KC, int ROWS>
+__device__ __forceinline__ void read_frag8(const float* __restrict__ s, int rbase, int ks, int i, int hi, float (&x)[8]) {
+  if (KC) {
+    const float* p = s + (rbase + i) * PITCH_KC + ks * 16 + hi * 8;
+    const float4 v0 = *reinterpret_cast<const float4*>(p);
+    const float4 v1 = *reinterpret_cast<const float4*>(p + 4);
+    x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = s[(ks * 16 + hi * 8 + j) * ROWS + rbase + i];
+  }
+}
+
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& h, bf16x8& l) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 hj = (__bf16)x[j];
+    h[j] = hj;
+    l[j] = (__bf16)(x[j] - (float)hj);
+  }
+}
+
+template <bool A_KC, bool B_KC, int TM, int TN, bool SPLIT>
 __global__ __launch_bounds__(256, (TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(GemmArgs g) {
   constexpr int BM_ = 64 * TM, BN_ = 64 * TN;
   __shared__ __attribute__((aligned(16))) float smem[(BM_ + BN_) * PITCH_KC];
@@ -150,20 +179,47 @@ __global__ __launch_bounds__(256, (TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(Ge
       load_tile<A_KC, BM_>(g.A, g.lda, m0, g.M, k0 + BK, kend, tid, ra);
       load_tile<B_KC, BN_>(g.B, g.ldb, n0, g.N, k0 + BK, kend, tid, rb);
     }
+    if (SPLIT) {
 #pragma unroll
-    for (int t4 = 0; t4 < 4; ++t4) {
-      float fa[TM][4], fb[TN][4];
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-      for (int a = 0; a < TM; ++a) read_frag<A_KC, BM_>(sA, wr * 32 * TM + a * 32, t4, i, hi, fa[a]);
+        for (int a = 0; a < TM; ++a) {
+          float x[8];
+          read_frag8<A_KC, BM_>(sA, wr * 32 * TM + a * 32, ks, i, hi, x);
+          split8(x, ah[a], al[a]);
+        }
 #pragma unroll
-      for (int b = 0; b < TN; ++b) read_frag<B_KC, BN_>(sB, wc * 32 * TN + b * 32, t4, i, hi, fb[b]);
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
+        for (int b = 0; b < TN; ++b) {
+          float x[8];
+          read_frag8<B_KC, BN_>(sB, wc * 32 * TN + b * 32, ks, i, hi, x);
+          split8(x, bh[b], bl[b]);
+        }
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
-          for (int b = 0; b < TN; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][u], fb[b][u], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < TN; ++b) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+          }
+      }
+    } else {
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) {
+        float fa[TM][4], fb[TN][4];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) read_frag<A_KC, BM_>(sA, wr * 32 * TM + a * 32, t4, i, hi, fa[a]);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) read_frag<B_KC, BN_>(sB, wc * 32 * TN + b * 32, t4, i, hi, fb[b]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][u], fb[b][u], acc[a][b], 0, 0, 0);
+      }
     }
   }
 
@@ -255,17 +311,32 @@ extern "C" size_t advmil_gemm_f32_workspace_bytes(int64_t M, int64_t N, int spli
   return splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
 
-template <int TM, int TN>
-static void launch_tile(int a_kc, int b_kc, dim3 grid, hipStream_t stream, const GemmArgs& g) {
+// 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = split-bf16 ("bf16x3") on the bf16 matrix pipe
+static int g_gemm_mode = 0;
+extern "C" int advmil_set_gemm_mode(int mode) {
+  if (mode != 0 && mode != 1) return ADVMIL_EINVAL;
+  g_gemm_mode = mode;
+  return ADVMIL_OK;
+}
+extern "C" int advmil_get_gemm_mode(void) { return g_gemm_mode; }
+
+template <int TM, int TN, bool SPLIT>
+static void launch_tile_m(int a_kc, int b_kc, dim3 grid, hipStream_t stream, const GemmArgs& g) {
   dim3 block(256);
   if (a_kc && b_kc)
-    hipLaunchKernelGGL((gemm_f32_kernel<true, true, TM, TN>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<true, true, TM, TN, SPLIT>), grid, block, 0, stream, g);
   else if (a_kc && !b_kc)
-    hipLaunchKernelGGL((gemm_f32_kernel<true, false, TM, TN>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<true, false, TM, TN, SPLIT>), grid, block, 0, stream, g);
   else if (!a_kc && !b_kc)
-    hipLaunchKernelGGL((gemm_f32_kernel<false, false, TM, TN>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<false, false, TM, TN, SPLIT>), grid, block, 0, stream, g);
   else
-    hipLaunchKernelGGL((gemm_f32_kernel<false, true, TM, TN>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<false, true, TM, TN, SPLIT>), grid, block, 0, stream, g);
+}
+
+template <int TM, int TN>
+static void launch_tile(int a_kc, int b_kc, dim3 grid, hipStream_t stream, const GemmArgs& g) {
+  if (g_gemm_mode == 1) launch_tile_m<TM, TN, true>(a_kc, b_kc, grid, stream, g);
+  else launch_tile_m<TM, TN, false>(a_kc, b_kc, grid, stream, g);
 }
 
 // tile = 10*TM + TN  (22: 128x128, 23: 128x192, 13: 64x192, 12: 64x128, 11: 64x64).

@@ -87,6 +87,10 @@ class MyHandler(object):
             m.rng = self.rng
         # generator contraction precision: "f32" (exact fp32 MFMA, default) or "bf16" (bf16 MFMA operands, fp32 accumulate;
         # ABMIL backbone). The discriminator always runs fp32: its logit moves 2.7e-4 under bf16 operands (> 1e-4 contract).
+        # arithmetic of the fp32 contraction engine (process-wide switch in the library): "exact" = fp32 MFMA,
+        # "bf16x3" = split-bf16 on the bf16 matrix pipe with fp32 accumulate (near-fp32: ~2^-17 per product). None = leave as is.
+        if cfg.get("gemm_mode") is not None:
+            ops.set_gemm_mode(cfg["gemm_mode"])
         self.gen_gemm_dtype = cfg.get("gen_gemm_dtype", "f32")
         assert self.gen_gemm_dtype in ("f32", "bf16")
         for m in self.netG.modules():

@@ -97,6 +97,16 @@ def default_rng(device):
 _PLAN_CACHE = {}
 
 
+def set_gemm_mode(mode):
+    """'exact' (fp32 MFMA) or 'bf16x3' (split-bf16 on the bf16 matrix pipe, fp32 accumulate) for the fp32 engine."""
+    code = {"exact": 0, "f32": 0, 0: 0, "bf16x3": 1, "split": 1, 1: 1}[mode]
+    _lib.check(_lib.lib().advmil_set_gemm_mode(code), "set_gemm_mode")
+
+
+def get_gemm_mode():
+    return "bf16x3" if _lib.lib().advmil_get_gemm_mode() == 1 else "exact"
+
+
 def gemm_plan(M, N, K):
     """(tile, splits) from the library's launch plan (advmil_gemm_f32_plan)."""
     key = (M, N, K)

@@ -29,6 +29,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
+PEAK_BF16_MFMA_TFLOPS = 2500.0 # ibid.: dense bf16 MFMA. The bf16x3 arithmetic issues 3 bf16 MFMAs per fp32-equivalent product,
+PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0   # so its roof in ALGORITHMIC flops (2*M*N*K) is a third of that
 
 
 def parse():
@@ -40,6 +42,9 @@ def parse():
     ap.add_argument("--patches", type=int, default=8192)
     ap.add_argument("--mode", default="abmil", choices=["abmil", "patch", "cluster", "graph"])
     ap.add_argument("--pool", type=int, default=64, help="distinct resident bags per GPU")
+    ap.add_argument("--gemm-mode", default="bf16x3", choices=["bf16x3", "exact"],
+                    help="arithmetic of the fp32 contraction engine: bf16x3 = split-bf16 products on the bf16 matrix pipe with fp32 "
+                         "accumulate (near-fp32, parity-tested); exact = fp32 MFMA")
     ap.add_argument("--gen-dtype", default="f32", choices=["f32", "bf16"],
                     help="generator contraction operands: f32 (exact) or bf16 MFMA (mixed precision, D stays f32)")
     ap.add_argument("--eager", action="store_true", help="drive the step eagerly instead of replaying HIP graphs")
@@ -160,7 +165,8 @@ def main():
     dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
 
-    cfg = default_cfg(bcb_mode=args.mode, bp_every_batch=args.bags, cuda_id=dev.index, gen_gemm_dtype=args.gen_dtype)
+    cfg = default_cfg(bcb_mode=args.mode, bp_every_batch=args.bags, cuda_id=dev.index, gen_gemm_dtype=args.gen_dtype,
+                      gemm_mode=args.gemm_mode)
     if args.mode == "graph":            # PatchGCN dims of the reference's model_stats.py:63
         cfg.update(bcb_dims="1024-128-128", gen_dims="128-1")
     h = MyHandler(cfg, device=dev)
@@ -282,11 +288,18 @@ def main():
         except Exception:
             pass
         traffic = None
-        if pmc and pmc.get("shape") == [M, N, K]:
+        if pmc and pmc.get("shape") == [M, N, K]:     # same launch geometry and memory traffic in both arithmetic modes
             traffic = pmc["hbm_bytes_per_launch"]
         total_gemm_ms = sum(v["ms"] for v in agg.values()) / nprof
+        if kname.startswith("gemm_bf16"):
+            peak, peak_note = PEAK_BF16_MFMA_TFLOPS, "dense bf16 MFMA peak"
+        elif args.gemm_mode == "bf16x3":
+            peak, peak_note = PEAK_BF16X3_TFLOPS, ("bf16x3: 3 bf16 MFMAs per fp32-equivalent product -> roof = dense bf16 MFMA peak / 3 "
+                                                   "in algorithmic 2MNK flops (the fp32 MFMA roof would be 157.3)")
+        else:
+            peak, peak_note = PEAK_F32_MFMA_TFLOPS, "fp32 MFMA peak"
         roof = {"bound": "mfma", "kernel": kname, "shape_MNK": [M, N, K], "achieved": round(achieved, 2),
-                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                "peak": round(peak, 1), "peak_note": peak_note, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": traffic, "avg_launch_us": round(us, 2), "flops_per_launch": flops,
                 "algorithmic_bytes_per_launch": 4.0 * (M * K + N * K + M * N),
                 "launches_per_step": top["n"] // nprof, "share_of_gemm_time_eager": round(top["ms"] / nprof / total_gemm_ms, 3),
@@ -294,9 +307,52 @@ def main():
                 "eager_event_bracketed_us": {f"{k[0]} {list(k[1][:3])}": round(1e3 * v["ms"] / v["n"], 1)
                                              for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]}}
 
+    # ---- extra (single GPU): the same step with EXACT fp32 MFMA arithmetic
+    exact_extra = None
+    if world == 1 and args.gemm_mode == "bf16x3" and not args.eager and graphs:
+        try:
+            from advmil_amd.graphed import GraphedStep
+            ops.set_gemm_mode("exact")
+            g3 = []
+            for g0 in range(0, n_pool - args.bags + 1, args.bags):
+                idx = list(range(g0, g0 + args.bags))
+                g3.append(GraphedStep(h, [xs[i] for i in idx], [ys[i] for i in idx], [ys_host[i] for i in idx], warmup=1))
+            for k in range(args.warmup):
+                g3[k % len(g3)].replay()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for k in range(args.steps):
+                g3[k % len(g3)].replay()
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t1
+            A_ = torch.randn(131072 if args.patches * args.bags >= 131072 else args.patches * args.bags, 1024, device=dev)
+            B_ = torch.randn(384, 1024, device=dev)
+            Mx = A_.shape[0]
+            o_ = torch.empty(Mx, 384, device=dev)
+            for _ in range(3):
+                ops.gemm(A_, B_, True, True, Mx, 384, 1024, out=o_)
+            torch.cuda.synchronize()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(20):
+                ops.gemm(A_, B_, True, True, Mx, 384, 1024, out=o_)
+            ev1.record(); torch.cuda.synchronize()
+            usx = ev0.elapsed_time(ev1) * 50
+            tfx = 2.0 * Mx * 384 * 1024 / usx / 1e6
+            exact_extra = {"value": round(args.bags * args.steps / dt3, 3), "unit": "bags/s", "ms_per_step": round(1e3 * dt3 / args.steps, 3),
+                           "dtype": "f32 (v_mfma_f32_32x32x2_f32)",
+                           "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel<1,1,2,2> exact", "shape_MNK": [Mx, 384, 1024],
+                                        "achieved": round(tfx, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": round(tfx / PEAK_F32_MFMA_TFLOPS, 4), "avg_launch_us": round(usx, 2)}}
+            del g3
+        except Exception as exc:
+            exact_extra = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
+        finally:
+            ops.set_gemm_mode(args.gemm_mode)
+
     # ---- extra (single GPU, f32 runs only): the same step with bf16 MFMA operands in the generator's contractions
     bf16_extra = None
-    if world == 1 and args.gen_dtype == "f32" and args.mode == "abmil" and not args.no_bf16_extra and not args.eager:
+    if world == 1 and args.gen_dtype == "f32" and args.gemm_mode == "exact" and args.mode == "abmil" and not args.no_bf16_extra and not args.eager:
         try:
             from advmil_amd.graphed import GraphedStep
             h2 = MyHandler(default_cfg(bcb_mode=args.mode, bp_every_batch=args.bags, cuda_id=dev.index, gen_gemm_dtype="bf16"), device=dev)
@@ -331,16 +387,20 @@ def main():
             "metric": "WSI bags/sec (full G+D step)", "value": round(bags_total / dt, 3), "unit": "bags/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.gen_dtype == "f32" else "bf16(generator contractions)+f32", "data": "synthetic",
+            "dtype": ("bf16(generator contractions)+f32" if args.gen_dtype != "f32" else
+                      ("bf16x3 (fp32 operands split hi+lo in registers, 3 bf16 MFMAs per product, fp32 accumulate; fp32 storage)"
+                       if args.gemm_mode == "bf16x3" else "f32")), "data": "synthetic",
             "config": {"workload": f"{args.mode.upper()}+AdvMIL(RLIP prj discriminator), {args.patches}-patch x 1024 fp32 bags "
                                    f"(BASELINE.json configs[1] shape; fp32 storage, "
-                                   + ("exact fp32 MFMA arithmetic -- higher precision than the bf16 the config names)" if args.gen_dtype == "f32"
-                                      else "bf16 MFMA operands in the generator)"),
+                                   + ("bf16 MFMA operands in the generator)" if args.gen_dtype != "f32" else
+                                      ("bf16x3 split arithmetic: >= the bf16 the config names, within 2e-5 of the fp32 reference)"
+                                       if args.gemm_mode == "bf16x3" else "exact fp32 MFMA arithmetic)")),
                        "bags_per_step_per_gpu": args.bags, "global_bags_per_step": args.bags * world, "gen_updates": 1,
                        "distinct_resident_bags_per_gpu": n_pool, "parallelism": f"bag-parallel dp{world}", "dropout": "shipped rates",
                        "launch": launch_note},
             "gd_steps_per_sec": round(args.steps / dt, 3), "losses_finite": bool(finite), "replicas_in_sync": in_sync,
-            "roofline": roof, "cpu_baseline": cpu, "mixed_precision_bf16_generator": bf16_extra,
+            "roofline": roof, "cpu_baseline": cpu, "exact_f32_mfma_mode": exact_extra,
+            "mixed_precision_bf16_generator": bf16_extra,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -68,6 +68,11 @@ size_t advmil_gemm_f32_workspace_bytes(int64_t M, int64_t N, int splits);
 int advmil_gemm_f32(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                     const float* B, int64_t ldb, float* C, int64_t ldc, const advmil_epilogue_t* epi,
                     int splits, void* ws, size_t ws_bytes, advmil_stream_t stream);
+/* Arithmetic of the fp32 engine (process-wide): 0 = exact fp32 MFMA; 1 = split-bf16 ("bf16x3"): every fp32 operand is
+ * split into hi + lo bf16 in registers and a.b is formed as ah.bh + ah.bl + al.bh on the bf16 matrix pipe with fp32
+ * accumulate -- dropped terms ~2^-17 |a||b| per product, 3/16 of the matrix-pipe time. Storage stays fp32 everywhere. */
+int advmil_set_gemm_mode(int mode);
+int advmil_get_gemm_mode(void);
 /* The library's launch plan for a shape: block tile (see below) and K split count. Host callers size the workspace
  * from `splits` (advmil_gemm_f32_workspace_bytes) and pass both to advmil_gemm_f32_tiled. */
 int advmil_gemm_f32_plan(int64_t M, int64_t N, int64_t K, int* tile, int* splits);

@@ -236,3 +236,26 @@ def test_cast_bf16_and_transpose(ops):
     x = rnd("cb", 200, 136)
     d, dT = ops.cast_bf16(x.to(DEV), True, True)
     assert torch.equal(d.cpu(), x.bfloat16()) and torch.equal(dT.cpu(), x.bfloat16().t().contiguous())
+
+
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, False)])
+def test_gemm_split_bf16x3_mode(ops, a_kc, b_kc):
+    """bf16x3 arithmetic of the fp32 engine: products of the hi/lo bf16 splits on the bf16 matrix pipe, fp32 accumulate.
+    Error model: ~2^-17 |a||b| per product -> a few 1e-6 of the result scale at K ~ 1000 (exact fp32 MFMA: ~1e-7)."""
+    M, N, K = 520, 200, 1000
+    A = rnd("xA", M, K); B = rnd("xB", K, N)
+    ref = A.double() @ B.double()
+    Ad = (A if a_kc else A.t().contiguous()).to(DEV)
+    Bd = (B.t().contiguous() if b_kc else B).to(DEV)
+    prev = ops.get_gemm_mode()
+    try:
+        ops.set_gemm_mode("bf16x3")
+        for tile in (22, 23, 13, 12, 11):
+            for splits in (1, 2):
+                C = ops.gemm(Ad, Bd, a_kc, b_kc, M, N, K, splits=splits, tile=tile)
+                err = relerr(C, ref)
+                assert err < 1.5e-5, (tile, splits, err)
+        ops.set_gemm_mode("exact")
+        assert relerr(ops.gemm(Ad, Bd, a_kc, b_kc, M, N, K), ref) < 2e-6
+    finally:
+        ops.set_gemm_mode(prev)

@@ -425,3 +425,38 @@ def test_bf16_generator_mode_meets_the_contract(golden):
     named = dict(h.netG.named_parameters())
     gn = np.array([float((named[k].grad.double() + 1e-5 * torch.sign(named[k].detach().double())).norm()) for k in gk])
     assert np.allclose(gn, golden[f"G4_{kind}_gradG2_norm"], rtol=6e-2, atol=1e-5)   # step-2 gradients: bf16 operand rounding + the drifted weights
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bf16x3 arithmetic of the contraction engine (what bench.py runs): the same reference-golden checks, same tolerances.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture
+def bf16x3():
+    from advmil_amd import ops
+    prev = ops.get_gemm_mode()
+    ops.set_gemm_mode("bf16x3")
+    yield
+    ops.set_gemm_mode(prev)
+
+
+@pytest.mark.parametrize("kind", ["abmil", "patch", "cluster"])
+@pytest.mark.parametrize("N", [512, 8192])
+def test_bf16x3_G1_eval_forward_vs_reference(golden, bf16x3, kind, N):
+    test_G1_eval_forward_vs_reference(golden, kind, N)
+
+
+@pytest.mark.parametrize("kind", ["abmil", "patch"])
+def test_bf16x3_G2_sampling_vs_reference(golden, bf16x3, kind):
+    test_G2_test_model_sampling_vs_reference(golden, kind)
+
+
+@pytest.mark.parametrize("kind", ["abmil", "patch"])
+def test_bf16x3_G4_two_optimizer_steps_vs_reference(golden, bf16x3, kind):
+    """Losses, per-bag predictions and logits of two optimizer steps vs the reference's own handler at TOL = 2e-5,
+    post-step weight delta norms and second-step gradient norms at the same relative bounds as the exact mode."""
+    test_G4_two_optimizer_steps_vs_reference(golden, kind)
+
+
+@pytest.mark.parametrize("kind", ["abmil", "patch", "cluster"])
+def test_bf16x3_train_mode_dropout_parity_vs_oracle(bf16x3, kind):
+    test_train_mode_dropout_parity_vs_oracle(kind)
