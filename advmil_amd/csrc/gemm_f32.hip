@@ -15,8 +15,8 @@
 #include "common.h"
 #include "../../include/advmil_hip.h"
 
-#define BK 32
-#define PITCH_KC 36
+#define BK 32          // k per chunk of the exact-fp32 variant (and the granularity of split-K chunking)
+#define PITCH_KC 36    // BK + 4
 
 struct GemmArgs {
   int64_t M, N, K;
@@ -43,15 +43,15 @@ __device__ __forceinline__ float epilogue_elem(const advmil_epilogue_t& e, float
 }
 
 // ROWS = 64*T rows (m or n) x 32 k per tile; P = ROWS/32 float4 per thread.
-template <bool KC, int ROWS>
+template <bool KC, int ROWS, int BKT>
 __device__ __forceinline__ void load_tile(const float* __restrict__ src, int64_t ld, int64_t row0, int64_t rows,
-                                          int64_t k0, int64_t kend, int tid, float4 (&r)[ROWS / 32]) {
+                                          int64_t k0, int64_t kend, int tid, float4 (&r)[ROWS * BKT / 1024]) {
 #pragma unroll
-  for (int p = 0; p < ROWS / 32; ++p) {
+  for (int p = 0; p < ROWS * BKT / 1024; ++p) {
     const int e = p * 256 + tid;
-    if (KC) {   // [row][k]: 8 float4 per row
-      const int64_t row = row0 + (e >> 3);
-      const int64_t k = k0 + (e & 7) * 4;
+    if (KC) {   // [row][k]: BKT/4 float4 per row
+      const int64_t row = row0 + e / (BKT / 4);
+      const int64_t k = k0 + (e % (BKT / 4)) * 4;
       r[p] = (row < rows && k < kend) ? *reinterpret_cast<const float4*>(src + row * ld + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     } else {    // [k][m]: ROWS/4 float4 per k
       const int64_t k = k0 + e / (ROWS / 4);
@@ -61,13 +61,13 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ src, int64_t
   }
 }
 
-template <bool KC, int ROWS>
-__device__ __forceinline__ void store_tile(float* __restrict__ s, int tid, const float4 (&r)[ROWS / 32]) {
+template <bool KC, int ROWS, int BKT>
+__device__ __forceinline__ void store_tile(float* __restrict__ s, int tid, const float4 (&r)[ROWS * BKT / 1024]) {
 #pragma unroll
-  for (int p = 0; p < ROWS / 32; ++p) {
+  for (int p = 0; p < ROWS * BKT / 1024; ++p) {
     const int e = p * 256 + tid;
     if (KC)
-      *reinterpret_cast<float4*>(s + (e >> 3) * PITCH_KC + (e & 7) * 4) = r[p];
+      *reinterpret_cast<float4*>(s + (e / (BKT / 4)) * (BKT + 4) + (e % (BKT / 4)) * 4) = r[p];
     else
       *reinterpret_cast<float4*>(s + (e / (ROWS / 4)) * ROWS + (e % (ROWS / 4)) * 4) = r[p];
   }
@@ -87,39 +87,111 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ s, int rbase
 
 // ---- split-bf16 ("bf16x3") arithmetic: x = hi + lo with hi = bf16(x), lo = bf16(x - hi); a.b ~= ah.bh + ah.bl + al.bh on the
 // bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate), fp32 accumulate. The dropped terms are ~2^-17 of |a||b|
-// per product (fp32 MFMA: 2^-24), i.e. near-fp32 results at 3/16 of the matrix-pipe time. Operands stay fp32 in HBM and LDS; the
-// split happens per fragment in the (otherwise idle) VALU.
+// per product (fp32 MFMA: 2^-24), i.e. near-fp32 results at 3/16 of the matrix-pipe time. Operands stay fp32 in HBM; the split
+// happens once per staged element on the way into LDS, which holds two bf16 planes (hi, lo) per operand tile.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// the 8 consecutive k of MFMA k-step `ks` (16 k) that lane-half `hi` feeds, for the 32-row block at rbase
-template <bool KC, int ROWS>
-__device__ __forceinline__ void read_frag8(const float* __restrict__ s, int rbase, int ks, int i, int hi, float (&x)[8]) {
-  if (KC) {
-    const float* p = s + (rbase + i) * PITCH_KC + ks * 16 + hi * 8;
-    const float4 v0 = *reinterpret_cast<const float4*>(p);
-    const float4 v1 = *reinterpret_cast<const float4*>(p + 4);
-    x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
-  } else {
+// Pre-split LDS image of a k-contiguous operand tile (bf16x3 mode): two bf16 planes [row][PITCH_PS], hi then lo, written once
+// per element when the tile is staged (every element is consumed by two waves, so splitting here halves the conversion work
+// and leaves the inner loop with ds_read_b128 + MFMA only). PITCH_PS = 40 bf16 = 20 dwords: 16-lane b128 groups hit 64 banks.
+#define PITCH_PS 40
+typedef unsigned short bf16raw;
+union Frag8 { uint4 u; bf16x8 v; };
+
+template <int ROWS>
+__device__ __forceinline__ void store_tile_presplit(bf16raw* __restrict__ planes, int tid, const float4 (&r)[ROWS / 32]) {
+  bf16raw* const hiP = planes;
+  bf16raw* const loP = planes + ROWS * PITCH_PS;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = s[(ks * 16 + hi * 8 + j) * ROWS + rbase + i];
+  for (int p = 0; p < ROWS / 32; ++p) {
+    const int e = p * 256 + tid;
+    const int row = e >> 3, k4 = (e & 7) * 4;
+    const float x[4] = {r[p].x, r[p].y, r[p].z, r[p].w};
+    union { __bf16 b[4]; uint2 u; } h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      h.b[j] = (__bf16)x[j];
+      l.b[j] = (__bf16)(x[j] - (float)h.b[j]);
+    }
+    *reinterpret_cast<uint2*>(hiP + row * PITCH_PS + k4) = h.u;
+    *reinterpret_cast<uint2*>(loP + row * PITCH_PS + k4) = l.u;
   }
 }
 
-__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& h, bf16x8& l) {
+template <int ROWS>
+__device__ __forceinline__ void read_frag_presplit(const bf16raw* __restrict__ planes, int rbase, int ks, int i, int hi,
+                                                   bf16x8& h, bf16x8& l) {
+  const bf16raw* p = planes + (rbase + i) * PITCH_PS + ks * 16 + hi * 8;
+  Frag8 a, b;
+  a.u = *reinterpret_cast<const uint4*>(p);
+  b.u = *reinterpret_cast<const uint4*>(p + ROWS * PITCH_PS);
+  h = a.v; l = b.v;
+}
+
+// Pre-split LDS image of an m-contiguous operand tile ([k][rows] source, e.g. both operands of dW = dY^T X): two bf16 planes
+// [k][PITCH_MC(ROWS)], hi then lo, in the SOURCE orientation (coalesced 8-byte stores), consumed with the gfx950 LDS transpose
+// read: ds_read_b64_tr_b16 hands lane c of a 16-lane group the 4 k-consecutive halfwords of column c out of a [4 k][16 m]
+// block whose 16 8-byte pieces are addressed by the group's lanes (lane s: k row s>>2, m piece s&3; measured with
+// tools/probe/tr_probe.hip). Two such reads give a lane the 8 consecutive k of its row that v_mfma_f32_32x32x16_bf16 wants, with no
+// per-element LDS traffic. Pitch = ROWS*2 + 64 bytes: the 4 k-rows of one read land in 4 different 64-byte bank quarters.
+#define PITCH_MC(ROWS) ((ROWS) + 32)
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4_t;
+#define LDS_AS __attribute__((address_space(3)))
+
+template <int ROWS, int BKT>
+__device__ __forceinline__ void store_tile_presplit_mc(bf16raw* __restrict__ planes, int tid, const float4 (&r)[ROWS * BKT / 1024]) {
+  bf16raw* const hiP = planes;
+  bf16raw* const loP = planes + BKT * PITCH_MC(ROWS);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const __bf16 hj = (__bf16)x[j];
-    h[j] = hj;
-    l[j] = (__bf16)(x[j] - (float)hj);
+  for (int p = 0; p < ROWS * BKT / 1024; ++p) {
+    const int e = p * 256 + tid;
+    const int k = e / (ROWS / 4), m4 = (e % (ROWS / 4)) * 4;
+    const float x[4] = {r[p].x, r[p].y, r[p].z, r[p].w};
+    union { __bf16 b[4]; uint2 u; } h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      h.b[j] = (__bf16)x[j];
+      l.b[j] = (__bf16)(x[j] - (float)h.b[j]);
+    }
+    *reinterpret_cast<uint2*>(hiP + k * PITCH_MC(ROWS) + m4) = h.u;
+    *reinterpret_cast<uint2*>(loP + k * PITCH_MC(ROWS) + m4) = l.u;
   }
+}
+
+template <int ROWS, int BKT>
+__device__ __forceinline__ void read_frag_presplit_mc(const bf16raw* __restrict__ planes, int rbase, int ks, int lane,
+                                                      bf16x8& h, bf16x8& l) {
+  // lane -> (k row of its 8-byte piece, m piece); the result lane holds row rbase + (lane & 31), k = ks*16 + (lane>>5)*8 + 0..7
+  const int krow = ks * 16 + (lane >> 5) * 8 + ((lane & 15) >> 2);
+  const int mcol = rbase + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+  const bf16raw* p = planes + krow * PITCH_MC(ROWS) + mcol;
+  union { bf16x4_t q[2]; bf16x8 v; } a, b;
+  a.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(p));
+  a.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(p + 4 * PITCH_MC(ROWS)));
+  b.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(p + BKT * PITCH_MC(ROWS)));
+  b.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(p + (BKT + 4) * PITCH_MC(ROWS)));
+  h = a.v; l = b.v;
 }
 
 template <bool A_KC, bool B_KC, int TM, int TN, bool SPLIT>
 __global__ __launch_bounds__(256, (TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(GemmArgs g) {
   constexpr int BM_ = 64 * TM, BN_ = 64 * TN;
-  __shared__ __attribute__((aligned(16))) float smem[(BM_ + BN_) * PITCH_KC];
+  // k per chunk: 32 for the exact variant; 64 for bf16x3, whose matrix-pipe time per k is 5x smaller, so that the two
+  // barriers / staging phase per chunk are amortised over twice the work (and 4 independent k-steps instead of 2)
+  constexpr int BKT = 32;   // (64 was measured for the bf16x3 variant: no gain, +60 VGPRs)
+  constexpr int PITCH = BKT + 4;
+  // bf16x3: k-contiguous operands are kept pre-split in LDS (two bf16 planes, 160 B per row instead of 144 B of fp32)
+  // (MC operands: two [k][rows+32] bf16 planes read with the LDS transpose read)
+  constexpr int TILEF_A = !SPLIT ? BM_ * PITCH : (A_KC ? BM_ * PITCH_PS : BKT * PITCH_MC(BM_));   // floats per operand tile
+  constexpr int TILEF_B = !SPLIT ? BN_ * PITCH : (B_KC ? BN_ * PITCH_PS : BKT * PITCH_MC(BN_));
+  // bf16x3: two LDS buffers (one barrier per chunk, the next chunk is staged while the current one feeds the matrix pipe).
+  // The exact variant stays single-buffered: there the doubled LDS footprint costs co-resident workgroups and measured slower.
+  constexpr int NBUF = SPLIT ? 2 : 1;
+  constexpr int BUF_FLOATS = TILEF_A + TILEF_B;
+  constexpr int PATCH_FLOATS = 4 * 32 * PITCH_KC;   // the epilogue's per-wave patches reuse the operand buffers
+  __shared__ __attribute__((aligned(16))) float smem[NBUF * BUF_FLOATS > PATCH_FLOATS ? NBUF * BUF_FLOATS : PATCH_FLOATS];
   float* const sA = smem;
-  float* const sB = smem + BM_ * PITCH_KC;
+  float* const sB = smem + TILEF_A;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -165,35 +237,43 @@ __global__ __launch_bounds__(256, (TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(Ge
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-  float4 ra[BM_ / 32], rb[BN_ / 32];
+  float4 ra[BM_ * BKT / 1024], rb[BN_ * BKT / 1024];
   if (kbeg < kend) {
-    load_tile<A_KC, BM_>(g.A, g.lda, m0, g.M, kbeg, kend, tid, ra);
-    load_tile<B_KC, BN_>(g.B, g.ldb, n0, g.N, kbeg, kend, tid, rb);
+    load_tile<A_KC, BM_, BKT>(g.A, g.lda, m0, g.M, kbeg, kend, tid, ra);
+    load_tile<B_KC, BN_, BKT>(g.B, g.ldb, n0, g.N, kbeg, kend, tid, rb);
   }
-  for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
-    __syncthreads();  // all waves finished reading the previous chunk
-    store_tile<A_KC, BM_>(sA, tid, ra);
-    store_tile<B_KC, BN_>(sB, tid, rb);
-    __syncthreads();
-    if (k0 + BK < kend) {  // prefetch next chunk; lands while the MFMAs below run
-      load_tile<A_KC, BM_>(g.A, g.lda, m0, g.M, k0 + BK, kend, tid, ra);
-      load_tile<B_KC, BN_>(g.B, g.ldb, n0, g.N, k0 + BK, kend, tid, rb);
+  if (SPLIT) {
+    // ---- bf16x3 main loop, LDS double-buffered; both operands live pre-split (hi/lo bf16 planes) in LDS
+    auto stage = [&](float* nA, float* nB) {
+      if (A_KC) store_tile_presplit<BM_>(reinterpret_cast<bf16raw*>(nA), tid, ra);
+      else store_tile_presplit_mc<BM_, BKT>(reinterpret_cast<bf16raw*>(nA), tid, ra);
+      if (B_KC) store_tile_presplit<BN_>(reinterpret_cast<bf16raw*>(nB), tid, rb);
+      else store_tile_presplit_mc<BN_, BKT>(reinterpret_cast<bf16raw*>(nB), tid, rb);
+    };
+    int cur = 0;
+    if (kbeg < kend) {
+      stage(sA, sB);
+      if (kbeg + BKT < kend) {
+        load_tile<A_KC, BM_, BKT>(g.A, g.lda, m0, g.M, kbeg + BKT, kend, tid, ra);
+        load_tile<B_KC, BN_, BKT>(g.B, g.ldb, n0, g.N, kbeg + BKT, kend, tid, rb);
+      }
+      __syncthreads();
     }
-    if (SPLIT) {
+    for (int64_t k0 = kbeg; k0 < kend; k0 += BKT) {
+      const bf16raw* cA = reinterpret_cast<const bf16raw*>(sA + cur * BUF_FLOATS);
+      const bf16raw* cB = reinterpret_cast<const bf16raw*>(sB + cur * BUF_FLOATS);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < BKT / 16; ++ks) {
         bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
-          float x[8];
-          read_frag8<A_KC, BM_>(sA, wr * 32 * TM + a * 32, ks, i, hi, x);
-          split8(x, ah[a], al[a]);
+          if (A_KC) read_frag_presplit<BM_>(cA, wr * 32 * TM + a * 32, ks, i, hi, ah[a], al[a]);
+          else read_frag_presplit_mc<BM_, BKT>(cA, wr * 32 * TM + a * 32, ks, lane, ah[a], al[a]);
         }
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
-          float x[8];
-          read_frag8<B_KC, BN_>(sB, wc * 32 * TN + b * 32, ks, i, hi, x);
-          split8(x, bh[b], bl[b]);
+          if (B_KC) read_frag_presplit<BN_>(cB, wc * 32 * TN + b * 32, ks, i, hi, bh[b], bl[b]);
+          else read_frag_presplit_mc<BN_, BKT>(cB, wc * 32 * TN + b * 32, ks, lane, bh[b], bl[b]);
         }
 #pragma unroll
         for (int a = 0; a < TM; ++a)
@@ -203,8 +283,28 @@ __global__ __launch_bounds__(256, (TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(Ge
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
           }
+        if (ks == 0 && k0 + BKT < kend) {     // stage chunk c+1 behind the first MFMA group, then request chunk c+2
+          stage(sA + (cur ^ 1) * BUF_FLOATS, sB + (cur ^ 1) * BUF_FLOATS);
+          if (k0 + 2 * BKT < kend) {
+            load_tile<A_KC, BM_, BKT>(g.A, g.lda, m0, g.M, k0 + 2 * BKT, kend, tid, ra);
+            load_tile<B_KC, BN_, BKT>(g.B, g.ldb, n0, g.N, k0 + 2 * BKT, kend, tid, rb);
+          }
+        }
       }
-    } else {
+      __syncthreads();   // buffer cur^1 complete, buffer cur free
+      cur ^= 1;
+    }
+  } else {
+    // ---- exact fp32 main loop, single LDS buffer
+    for (int64_t k0 = kbeg; k0 < kend; k0 += BKT) {
+      __syncthreads();  // all waves finished reading the previous chunk
+      store_tile<A_KC, BM_, BKT>(sA, tid, ra);
+      store_tile<B_KC, BN_, BKT>(sB, tid, rb);
+      __syncthreads();
+      if (k0 + BKT < kend) {  // prefetch next chunk; lands while the MFMAs below run
+        load_tile<A_KC, BM_, BKT>(g.A, g.lda, m0, g.M, k0 + BKT, kend, tid, ra);
+        load_tile<B_KC, BN_, BKT>(g.B, g.ldb, n0, g.N, k0 + BKT, kend, tid, rb);
+      }
 #pragma unroll
       for (int t4 = 0; t4 < 4; ++t4) {
         float fa[TM][4], fb[TN][4];

@@ -223,6 +223,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_submit = time.perf_counter() - t0     # host time to enqueue all K steps (== dt when the host is the bottleneck)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -263,6 +264,10 @@ def main():
             key = (f"{name[:-1]},{tile // 10},{tile % 10}>", shape)
             a = agg.setdefault(key, {"ms": 0.0, "n": 0, "flops": flops})
             a["ms"] += e0.elapsed_time(e1); a["n"] += 1
+        if os.environ.get("ADVMIL_BENCH_TABLE"):   # per-step GEMM table (launch, shape, count, ms) on stderr
+            for (kn, sh), v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+                print(f"  {kn:28s} M,N,K,splits={sh}  n/step={v['n'] / nprof:.1f}  ms/step={v['ms'] / nprof:.3f}  "
+                      f"us/launch={1e3 * v['ms'] / v['n']:.1f}  TF={v['flops'] * v['n'] / v['ms'] / 1e9:.0f}", file=sys.stderr)
         (kname, shape), top = max(agg.items(), key=lambda kv: kv[1]["ms"])
         M, N, K, sp = shape
         a_kc, b_kc = kname.split("<")[1].startswith("1"), kname.split("<")[1].split(",")[1].startswith("1")
@@ -399,6 +404,7 @@ def main():
                        "distinct_resident_bags_per_gpu": n_pool, "parallelism": f"bag-parallel dp{world}", "dropout": "shipped rates",
                        "launch": launch_note},
             "gd_steps_per_sec": round(args.steps / dt, 3), "losses_finite": bool(finite), "replicas_in_sync": in_sync,
+            "host_submit_ms_per_step": round(1e3 * t_submit / args.steps, 3),
             "roofline": roof, "cpu_baseline": cpu, "exact_f32_mfma_mode": exact_extra,
             "mixed_precision_bf16_generator": bf16_extra,
         }
