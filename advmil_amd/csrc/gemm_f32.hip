@@ -173,7 +173,85 @@ __device__ __forceinline__ void read_frag_presplit_mc(const bf16raw* __restrict_
   h = a.v; l = b.v;
 }
 
-template <bool A_KC, bool B_KC, int TM, int TN, bool SPLIT>
+// planes of 4 consecutive final outputs (row pitch = ldc): what the next contraction consumes without re-splitting
+__device__ __forceinline__ void emit_planes4(const advmil_epilogue_t& e, int64_t off, const float (&v)[4], int nvalid) {
+  union { __bf16 b[4]; uint2 u; bf16raw r[4]; } h, l;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    h.b[j] = (__bf16)v[j];
+    l.b[j] = (__bf16)(v[j] - (float)h.b[j]);
+  }
+  bf16raw* ch = reinterpret_cast<bf16raw*>(e.c_hi) + off;
+  bf16raw* cl = reinterpret_cast<bf16raw*>(e.c_lo) + off;
+  if (nvalid == 4 && ((off & 3) == 0)) {
+    *reinterpret_cast<uint2*>(ch) = h.u;
+    *reinterpret_cast<uint2*>(cl) = l.u;
+  } else {
+    for (int j = 0; j < nvalid; ++j) { ch[j] = h.r[j]; cl[j] = l.r[j]; }
+  }
+}
+
+// One operand's register stage in bf16x3 mode: global -> registers (load) -> the pre-split LDS image (store).
+// PRE = false: the source is the fp32 matrix; the hi/lo split happens in store() (once per staged element).
+// PRE = true : the source is a pair of bf16 planes the caller already holds in HBM (advmil_split_planes, the Adam kernel for the
+//   weights, or a producing GEMM's epilogue): same bytes from memory, 16-byte pieces straight into LDS, no conversion work at
+//   all. That matters because the bf16x3 loop is instruction-issue bound (PMC: ~255 VALU per 24 MFMA per k-chunk and wave, half
+//   of them this split, repeated by every workgroup that re-reads the element: 3x for X, 1024x for a weight).
+template <bool KC, int ROWS, int BKT, bool PRE>
+struct OperandStage {
+  static constexpr int NF4 = ROWS * BKT / 1024;   // float4 per thread (fp32 source)
+  static constexpr int NP = ROWS * BKT / 2048;    // 16-byte pieces per thread and plane (plane source)
+  float4 f[PRE ? 1 : NF4];
+  uint4 ph[PRE ? NP : 1], pl[PRE ? NP : 1];
+
+  __device__ __forceinline__ void load(const float* __restrict__ src, const bf16raw* __restrict__ hi, const bf16raw* __restrict__ lo,
+                                       int64_t ld, int64_t row0, int64_t rows, int64_t k0, int64_t kend, int tid) {
+    if constexpr (!PRE) {
+      load_tile<KC, ROWS, BKT>(src, ld, row0, rows, k0, kend, tid, f);
+    } else {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int e = p * 256 + tid;
+        int64_t off;
+        bool ok;
+        if (KC) {   // [row][k]: BKT/8 pieces per row
+          const int64_t row = row0 + e / (BKT / 8), k = k0 + (e % (BKT / 8)) * 8;
+          ok = row < rows && k < kend;
+          off = row * ld + k;
+        } else {    // [k][m]: ROWS/8 pieces per k
+          const int64_t k = k0 + e / (ROWS / 8), m = row0 + (e % (ROWS / 8)) * 8;
+          ok = k < kend && m < rows;
+          off = k * ld + m;
+        }
+        ph[p] = ok ? *reinterpret_cast<const uint4*>(hi + off) : make_uint4(0u, 0u, 0u, 0u);
+        pl[p] = ok ? *reinterpret_cast<const uint4*>(lo + off) : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(bf16raw* __restrict__ planes, int tid) const {
+    if constexpr (!PRE) {
+      if (KC) store_tile_presplit<ROWS>(planes, tid, f);
+      else store_tile_presplit_mc<ROWS, BKT>(planes, tid, f);
+    } else {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int e = p * 256 + tid;
+        if (KC) {
+          bf16raw* d = planes + (e / (BKT / 8)) * PITCH_PS + (e % (BKT / 8)) * 8;
+          *reinterpret_cast<uint4*>(d) = ph[p];
+          *reinterpret_cast<uint4*>(d + ROWS * PITCH_PS) = pl[p];
+        } else {
+          bf16raw* d = planes + (e / (ROWS / 8)) * PITCH_MC(ROWS) + (e % (ROWS / 8)) * 8;
+          *reinterpret_cast<uint4*>(d) = ph[p];
+          *reinterpret_cast<uint4*>(d + BKT * PITCH_MC(ROWS)) = pl[p];
+        }
+      }
+    }
+  }
+};
+
+template <bool A_KC, bool B_KC, int TM, int TN, bool SPLIT, int PRE>
 __global__ __launch_bounds__(256, (TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(GemmArgs g) {
   constexpr int BM_ = 64 * TM, BN_ = 64 * TN;
   // k per chunk: 32 for the exact variant; 64 for bf16x3, whose matrix-pipe time per k is 5x smaller, so that the two
@@ -237,26 +315,27 @@ __global__ __launch_bounds__(256, (TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(Ge
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-  float4 ra[BM_ * BKT / 1024], rb[BN_ * BKT / 1024];
-  if (kbeg < kend) {
-    load_tile<A_KC, BM_, BKT>(g.A, g.lda, m0, g.M, kbeg, kend, tid, ra);
-    load_tile<B_KC, BN_, BKT>(g.B, g.ldb, n0, g.N, kbeg, kend, tid, rb);
-  }
-  if (SPLIT) {
+  if constexpr (SPLIT) {
     // ---- bf16x3 main loop, LDS double-buffered; both operands live pre-split (hi/lo bf16 planes) in LDS
+    OperandStage<A_KC, BM_, BKT, (PRE & 1) != 0> ra;
+    OperandStage<B_KC, BN_, BKT, (PRE & 2) != 0> rb;
+    const bf16raw* const a_hi = reinterpret_cast<const bf16raw*>(g.epi.a_hi) + (int64_t)blockIdx.z * g.sA;
+    const bf16raw* const a_lo = reinterpret_cast<const bf16raw*>(g.epi.a_lo) + (int64_t)blockIdx.z * g.sA;
+    const bf16raw* const b_hi = reinterpret_cast<const bf16raw*>(g.epi.b_hi) + (int64_t)blockIdx.z * g.sB;
+    const bf16raw* const b_lo = reinterpret_cast<const bf16raw*>(g.epi.b_lo) + (int64_t)blockIdx.z * g.sB;
+    auto fetch = [&](int64_t k0) {
+      ra.load(g.A, a_hi, a_lo, g.lda, m0, g.M, k0, kend, tid);
+      rb.load(g.B, b_hi, b_lo, g.ldb, n0, g.N, k0, kend, tid);
+    };
     auto stage = [&](float* nA, float* nB) {
-      if (A_KC) store_tile_presplit<BM_>(reinterpret_cast<bf16raw*>(nA), tid, ra);
-      else store_tile_presplit_mc<BM_, BKT>(reinterpret_cast<bf16raw*>(nA), tid, ra);
-      if (B_KC) store_tile_presplit<BN_>(reinterpret_cast<bf16raw*>(nB), tid, rb);
-      else store_tile_presplit_mc<BN_, BKT>(reinterpret_cast<bf16raw*>(nB), tid, rb);
+      ra.store(reinterpret_cast<bf16raw*>(nA), tid);
+      rb.store(reinterpret_cast<bf16raw*>(nB), tid);
     };
     int cur = 0;
     if (kbeg < kend) {
+      fetch(kbeg);
       stage(sA, sB);
-      if (kbeg + BKT < kend) {
-        load_tile<A_KC, BM_, BKT>(g.A, g.lda, m0, g.M, kbeg + BKT, kend, tid, ra);
-        load_tile<B_KC, BN_, BKT>(g.B, g.ldb, n0, g.N, kbeg + BKT, kend, tid, rb);
-      }
+      if (kbeg + BKT < kend) fetch(kbeg + BKT);
       __syncthreads();
     }
     for (int64_t k0 = kbeg; k0 < kend; k0 += BKT) {
@@ -285,10 +364,7 @@ __global__ __launch_bounds__(256, (TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(Ge
           }
         if (ks == 0 && k0 + BKT < kend) {     // stage chunk c+1 behind the first MFMA group, then request chunk c+2
           stage(sA + (cur ^ 1) * BUF_FLOATS, sB + (cur ^ 1) * BUF_FLOATS);
-          if (k0 + 2 * BKT < kend) {
-            load_tile<A_KC, BM_, BKT>(g.A, g.lda, m0, g.M, k0 + 2 * BKT, kend, tid, ra);
-            load_tile<B_KC, BN_, BKT>(g.B, g.ldb, n0, g.N, k0 + 2 * BKT, kend, tid, rb);
-          }
+          if (k0 + 2 * BKT < kend) fetch(k0 + 2 * BKT);
         }
       }
       __syncthreads();   // buffer cur^1 complete, buffer cur free
@@ -296,6 +372,11 @@ __global__ __launch_bounds__(256, (TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(Ge
     }
   } else {
     // ---- exact fp32 main loop, single LDS buffer
+    float4 ra[BM_ * BKT / 1024], rb[BN_ * BKT / 1024];
+    if (kbeg < kend) {
+      load_tile<A_KC, BM_, BKT>(g.A, g.lda, m0, g.M, kbeg, kend, tid, ra);
+      load_tile<B_KC, BN_, BKT>(g.B, g.ldb, n0, g.N, kbeg, kend, tid, rb);
+    }
     for (int64_t k0 = kbeg; k0 < kend; k0 += BKT) {
       __syncthreads();  // all waves finished reading the previous chunk
       store_tile<A_KC, BM_, BKT>(sA, tid, ra);
@@ -371,6 +452,7 @@ __global__ __launch_bounds__(256, (TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(Ge
           } else {
             for (int t = 0; t < nvalid; ++t) c[t] = v[t];
           }
+          if (direct && e.c_hi) emit_planes4(e, (int64_t)blockIdx.z * g.sC + row * ldo + col, v, nvalid);
         }
       }
       __syncthreads();
@@ -403,7 +485,9 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g) {
       float o = epilogue_elem(e, v[q], m, n + q, g.N, key, inv_keep);
       if (e.accumulate) o += c[q];
       c[q] = o;
+      v[q] = o;
     }
+    if (e.c_hi) emit_planes4(e, m * g.ldc + n, v, 4);
   }
 }
 
@@ -420,23 +504,38 @@ extern "C" int advmil_set_gemm_mode(int mode) {
 }
 extern "C" int advmil_get_gemm_mode(void) { return g_gemm_mode; }
 
-template <int TM, int TN, bool SPLIT>
+template <int TM, int TN, bool SPLIT, int PRE>
 static void launch_tile_m(int a_kc, int b_kc, dim3 grid, hipStream_t stream, const GemmArgs& g) {
   dim3 block(256);
   if (a_kc && b_kc)
-    hipLaunchKernelGGL((gemm_f32_kernel<true, true, TM, TN, SPLIT>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<true, true, TM, TN, SPLIT, PRE>), grid, block, 0, stream, g);
   else if (a_kc && !b_kc)
-    hipLaunchKernelGGL((gemm_f32_kernel<true, false, TM, TN, SPLIT>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<true, false, TM, TN, SPLIT, PRE>), grid, block, 0, stream, g);
   else if (!a_kc && !b_kc)
-    hipLaunchKernelGGL((gemm_f32_kernel<false, false, TM, TN, SPLIT>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<false, false, TM, TN, SPLIT, PRE>), grid, block, 0, stream, g);
   else
-    hipLaunchKernelGGL((gemm_f32_kernel<false, true, TM, TN, SPLIT>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<false, true, TM, TN, SPLIT, PRE>), grid, block, 0, stream, g);
 }
 
-template <int TM, int TN>
-static void launch_tile(int a_kc, int b_kc, dim3 grid, hipStream_t stream, const GemmArgs& g) {
-  if (g_gemm_mode == 1) launch_tile_m<TM, TN, true>(a_kc, b_kc, grid, stream, g);
-  else launch_tile_m<TM, TN, false>(a_kc, b_kc, grid, stream, g);
+// PLANES: this tile is also built for operands that arrive as bf16 planes (the slab-sized contractions only use 22/12/11)
+template <int TM, int TN, bool PLANES>
+static void launch_tile(int a_kc, int b_kc, dim3 grid, hipStream_t stream, const GemmArgs& g, int pre) {
+  if (g_gemm_mode != 1) { launch_tile_m<TM, TN, false, 0>(a_kc, b_kc, grid, stream, g); return; }
+  if constexpr (PLANES) {
+    switch (pre) {
+      case 1: launch_tile_m<TM, TN, true, 1>(a_kc, b_kc, grid, stream, g); return;
+      case 2: launch_tile_m<TM, TN, true, 2>(a_kc, b_kc, grid, stream, g); return;
+      case 3: launch_tile_m<TM, TN, true, 3>(a_kc, b_kc, grid, stream, g); return;
+      default: break;
+    }
+  }
+  launch_tile_m<TM, TN, true, 0>(a_kc, b_kc, grid, stream, g);
+}
+
+// Which operands can be taken from caller-provided planes: both planes present, 16-byte aligned, pitch and contiguous extent
+// multiples of 8 halfwords (a 16-byte piece never straddles a row end or the K range).
+static int planes_usable(const void* hi, const void* lo, int64_t ld, int64_t contiguous_extent) {
+  return hi && lo && !((uintptr_t)hi & 15) && !((uintptr_t)lo & 15) && !(ld & 7) && !(contiguous_extent & 7);
 }
 
 // tile = 10*TM + TN  (22: 128x128, 23: 128x192, 13: 64x192, 12: 64x128, 11: 64x64).
@@ -504,12 +603,19 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
   const int ntiles = (int)((N + 64 * tn - 1) / (64 * tn));
   g.ntiles = ntiles;
   dim3 grid(g.mtiles * ntiles, splits);
+  int pre = 0;
+  if (g_gemm_mode == 1) {
+    // split-K chunks are multiples of BK = 32, so only the last chunk can end off a multiple of 8 -- covered by K % 8 == 0
+    if (planes_usable(epi->a_hi, epi->a_lo, lda, a_kc ? K : M)) pre |= 1;
+    if (planes_usable(epi->b_hi, epi->b_lo, ldb, b_kc ? K : N)) pre |= 2;
+  }
+  if ((epi->c_hi != nullptr) != (epi->c_lo != nullptr)) return ADVMIL_EINVAL;
   switch (tile) {
-    case 23: launch_tile<2, 3>(a_kc, b_kc, grid, stream, g); break;
-    case 22: launch_tile<2, 2>(a_kc, b_kc, grid, stream, g); break;
-    case 13: launch_tile<1, 3>(a_kc, b_kc, grid, stream, g); break;
-    case 12: launch_tile<1, 2>(a_kc, b_kc, grid, stream, g); break;
-    case 11: launch_tile<1, 1>(a_kc, b_kc, grid, stream, g); break;
+    case 23: launch_tile<2, 3, false>(a_kc, b_kc, grid, stream, g, pre); break;
+    case 22: launch_tile<2, 2, true>(a_kc, b_kc, grid, stream, g, pre); break;
+    case 13: launch_tile<1, 3, false>(a_kc, b_kc, grid, stream, g, pre); break;
+    case 12: launch_tile<1, 2, true>(a_kc, b_kc, grid, stream, g, pre); break;
+    case 11: launch_tile<1, 1, true>(a_kc, b_kc, grid, stream, g, pre); break;
     default: return ADVMIL_EINVAL;
   }
   ADVMIL_LAUNCH_CHECK();
@@ -545,7 +651,7 @@ extern "C" int advmil_gemm_f32_batched(int a_kc, int b_kc, int64_t M, int64_t N,
   g.k_chunk = ((K + BK - 1) / BK) * BK;
   g.splits = 1; g.ws = nullptr;
   g.sA = strideA; g.sB = strideB; g.sC = strideC;
-  advmil_epilogue_t e;
+  advmil_epilogue_t e = {};      // every optional field (planes included) off
   e.bias = nullptr; e.act0 = e.act1 = ACT_NONE; e.act_split = 1 << 30; e.drop_p = 0.f; e.seed = nullptr; e.stream_id = 0;
   e.rowv = e.colv = e.maskref = nullptr; e.rowseg = nullptr; e.ldmask = 0; e.mask_scale = 1.f; e.accumulate = accumulate; e.alpha = alpha;
   g.epi = e;
@@ -556,8 +662,45 @@ extern "C" int advmil_gemm_f32_batched(int a_kc, int b_kc, int64_t M, int64_t N,
   const int ntiles = (int)((N + 64 * tn - 1) / (64 * tn));
   g.ntiles = ntiles;
   dim3 grid(g.mtiles * ntiles, 1, batch);
-  if (tile == 12) launch_tile<1, 2>(a_kc, b_kc, grid, stream, g);
-  else launch_tile<1, 1>(a_kc, b_kc, grid, stream, g);
+  if (tile == 12) launch_tile<1, 2, false>(a_kc, b_kc, grid, stream, g, 0);
+  else launch_tile<1, 1, false>(a_kc, b_kc, grid, stream, g, 0);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}
+
+// ---- fp32 matrix -> bf16 planes (hi = bf16(x), lo = bf16(x - hi)); the same rounding the staging path applies on the fly
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int64_t n, bf16raw* __restrict__ hi,
+                                                           bf16raw* __restrict__ lo) {
+  const int64_t n8 = n >> 3;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n8; idx += (int64_t)gridDim.x * blockDim.x) {
+    const float4 a = reinterpret_cast<const float4*>(src)[2 * idx], b = reinterpret_cast<const float4*>(src)[2 * idx + 1];
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    union { __bf16 v[8]; uint4 u; } h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      h.v[j] = (__bf16)x[j];
+      l.v[j] = (__bf16)(x[j] - (float)h.v[j]);
+    }
+    reinterpret_cast<uint4*>(hi)[idx] = h.u;
+    reinterpret_cast<uint4*>(lo)[idx] = l.u;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+    const int64_t j = (n8 << 3) + threadIdx.x;
+    const __bf16 h = (__bf16)src[j];
+    const __bf16 l = (__bf16)(src[j] - (float)h);
+    hi[j] = *reinterpret_cast<const bf16raw*>(&h);
+    lo[j] = *reinterpret_cast<const bf16raw*>(&l);
+  }
+}
+
+extern "C" int advmil_split_planes(const float* src, int64_t n, void* hi, void* lo, advmil_stream_t stream_) {
+  if (!src || !hi || !lo || n < 0) return ADVMIL_EINVAL;
+  if (((uintptr_t)src & 15) || ((uintptr_t)hi & 15) || ((uintptr_t)lo & 15)) return ADVMIL_EINVAL;
+  if (n == 0) return ADVMIL_OK;
+  int64_t blocks = ((n >> 3) + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, src, n, (bf16raw*)hi, (bf16raw*)lo);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }

@@ -295,8 +295,12 @@ class MyHandler(object):
         self.optimizerD.zero_grad()
         X = self._slab(xs)
         y = torch.cat(ys, dim=0)
-        with torch.no_grad():                                                  # the reference builds, then detaches (400)
-            pred = self.netG.finish(self._gen_features(X, plan, xs), noise=self._stack_noise(noise))     # [B,1]
+        ops.MEMO.begin("record", ("G", id(self.netG), getattr(self.optimizerG, "n_updates", 0)))
+        try:
+            with torch.no_grad():                                              # the reference builds, then detaches (400)
+                pred = self.netG.finish(self._gen_features(X, plan, xs), noise=self._stack_noise(noise))     # [B,1]
+        finally:
+            ops.MEMO.end()
         emb = self.netD.embed_rows(X)                                          # shared by the real and the fake pairs
         eb, im = self.netD.bag_features_multi(emb, plan.seg16)
         f_fake = self.netD.tail(eb, im, pred).view(-1)
@@ -336,7 +340,13 @@ class MyHandler(object):
         dev = self.device
         self.optimizerG.zero_grad()
         X = self._slab(xs)
-        pred = self.netG.finish(self._gen_features(X, plan, xs), noise=self._stack_noise(noise))      # [B,1], graph kept
+        # row-sized pre-dropout layer outputs of the eval forward in _disc_backward are reused (same rows, same G weights)
+        ops.MEMO.begin("replay", ("G", id(self.netG), getattr(self.optimizerG, "n_updates", 0)))
+        try:
+            feats = self._gen_features(X, plan, xs)
+        finally:
+            ops.MEMO.end(clear=True)
+        pred = self.netG.finish(feats, noise=self._stack_noise(noise))         # [B,1], graph kept
         with torch.no_grad():                                                  # nothing of D(x) depends on G
             eb, im = self.netD.bag_features_multi(self.netD.embed_rows(X), plan.seg16)
         f_fake = self.netD.tail(eb, im, pred).view(-1)

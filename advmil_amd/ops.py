@@ -5,6 +5,7 @@ bookkeeping. Every N-row computation of the AdvMIL path runs in libadvmil_hip.so
 eager fallback -- CPU tensors raise.
 """
 import ctypes
+import os
 
 import torch
 
@@ -17,6 +18,7 @@ FUSED_WGRAD = True
 # bench.py sets this to a list to bracket every GEMM launch with HIP events on the launch stream:
 # entries are (kernel name, (M, N, K, splits), flops, start_event, stop_event)
 KERNEL_PROFILE = None
+USE_PLANES = True     # bf16x3 mode: carry weights / bag rows / activations as pre-split bf16 planes
 _ACT = {None: 0, "none": 0, "relu": 1, "tanh": 2, "sigmoid": 3}
 
 
@@ -121,10 +123,43 @@ def auto_splits(M, N, K):
     return gemm_plan(M, N, K)[1]
 
 
+class Planes:
+    """bf16x3 operand image of an fp32 matrix: hi = bf16(x), lo = bf16(x - hi), same shape/strides as x
+    (include/advmil_hip.h::advmil_epilogue_t.a_hi..c_lo). A contraction given the planes of an operand skips the per-workgroup
+    re-split of that operand; results are bit-identical."""
+    __slots__ = ("hi", "lo")
+
+    def __init__(self, hi, lo):
+        self.hi, self.lo = hi, lo
+
+    @staticmethod
+    def empty_like(x):
+        return Planes(torch.empty_strided(x.shape, x.stride(), dtype=torch.bfloat16, device=x.device),
+                      torch.empty_strided(x.shape, x.stride(), dtype=torch.bfloat16, device=x.device))
+
+    def view_rows(self, r0, r1):
+        return Planes(self.hi[r0:r1], self.lo[r0:r1])
+
+
+def planes_enabled():
+    """Planes only pay in bf16x3 mode (the exact engine reads the fp32 operands)."""
+    return USE_PLANES and get_gemm_mode() == "bf16x3"
+
+
+def split_planes(x, out=None):
+    """x (fp32, dense storage) -> Planes(hi, lo)."""
+    _chk(x, "x")
+    if out is None:
+        out = Planes.empty_like(x)
+    _lib.check(_lib.lib().advmil_split_planes(_p(x), x.numel(), _p(out.hi), _p(out.lo), _stream()), "split_planes")
+    return out
+
+
 def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=None, act_split=None, drop_p=0.0,
          seed=None, stream_id=0, rowv=None, colv=None, rowseg=None, maskref=None, mask_scale=1.0, accumulate=False,
-         alpha=1.0, splits=None, tile=0):
-    """C[M,N] = epilogue(alpha * op(A) op(B)); see include/advmil_hip.h::advmil_gemm_f32."""
+         alpha=1.0, splits=None, tile=0, a_planes=None, b_planes=None, c_planes=None):
+    """C[M,N] = epilogue(alpha * op(A) op(B)); see include/advmil_hip.h::advmil_gemm_f32. a_planes / b_planes: optional
+    Planes of A / B; c_planes: Planes to receive the split of the final C (pitch ldc)."""
     _chk(A, "A"); _chk(B, "B")
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=A.device)
@@ -149,6 +184,12 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
     e.mask_scale = float(mask_scale)
     e.accumulate = 1 if accumulate else 0
     e.alpha = float(alpha)
+    if a_planes is not None:
+        e.a_hi, e.a_lo = a_planes.hi.data_ptr(), a_planes.lo.data_ptr()
+    if b_planes is not None:
+        e.b_hi, e.b_lo = b_planes.hi.data_ptr(), b_planes.lo.data_ptr()
+    if c_planes is not None:
+        e.c_hi, e.c_lo = c_planes.hi.data_ptr(), c_planes.lo.data_ptr()
     if splits is None:
         ptile, splits = gemm_plan(M, N, K)
         if tile == 0:
@@ -351,13 +392,18 @@ class LinearActFn(torch.autograd.Function):
     """y = dropout(act(x W^T + b)); x[M,K], W[N,K]. Dropout index = m*N + n on stream `sid`."""
 
     @staticmethod
-    def forward(ctx, x, W, b, act, p, seed, sid):
+    def forward(ctx, x, W, b, act, p, seed, sid, y0=None):
         _chk(x, "x"); _chk(W, "weight")
         x = x.contiguous()
         W2 = W.detach().reshape(W.shape[0], -1)
         M, K = x.shape
         N = W2.shape[0]
-        y = gemm(x, W2, True, True, M, N, K, bias=b, act0=act, drop_p=p, seed=seed, stream_id=sid)
+        if y0 is None:
+            y = gemm(x, W2, True, True, M, N, K, bias=b, act0=act, drop_p=p, seed=seed, stream_id=sid)
+        elif p > 0.0:       # memoized act(x W^T + b) of the eval forward: only this forward's dropout draw is new
+            y, _ = act_dropout_bwd(y0, y0, ACT_NONE, M, N, p, seed, sid, want_bias=False)
+        else:
+            y = y0
         ctx.save_for_backward(x, W2, y)
         ctx.cfg = (act, p, seed, sid, M, N, K, W.shape, b is not None)
         ctx.gW, ctx.gb = _arena_grad(W), _arena_grad(b)
@@ -384,7 +430,35 @@ class LinearActFn(torch.autograd.Function):
             else:
                 dW = gemm(dpre, x, False, False, N, K, M).reshape(wshape)
         dx = gemm(dpre, W2, True, False, M, K, N) if need_x else None                   # dpre W
-        return dx, dW, (None if ctx.gb is not None else db), None, None, None, None
+        return dx, dW, (None if ctx.gb is not None else db), None, None, None, None, None
+
+
+class ForwardMemo:
+    """Reuse of row-sized pre-dropout layer outputs between two forwards over the SAME rows with the SAME weights.
+
+    The reference runs the generator twice per optimizer step on every bag -- netG.eval() under no_grad for the discriminator
+    update (model_handler.py:398-400), netG.train() for the generator update (model_handler.py:420-425) -- and the generator's
+    weights do not change in between. act(x W^T + b) of a row-sized layer is therefore identical in both; only the dropout draw
+    differs. mode 'record' (the no-grad eval forward) keeps each such output; mode 'replay' (the train forward) takes it back,
+    applies its own dropout mask elementwise and rebuilds the same autograd node, instead of repeating the contraction
+    (131072x384x1024: ~0.45 ms saved per step). `token` must identify the weights' version; entries from another token are dropped."""
+
+    def __init__(self):
+        self.mode, self.token, self.store = None, None, {}
+
+    def begin(self, mode, token):
+        if token != self.token:
+            self.store.clear()
+        self.mode, self.token = mode, token
+
+    def end(self, clear=False):
+        self.mode = None
+        if clear:
+            self.store.clear()
+
+
+MEMO = ForwardMemo()
+MEMO_MIN_ROWS = int(os.environ.get("ADVMIL_MEMO_MIN_ROWS", "4096"))       # only slab-sized layers are worth carrying
 
 
 def linear_act(x, W, b, act="none", p=0.0, rng=None, tag=""):
@@ -396,7 +470,14 @@ def linear_act(x, W, b, act="none", p=0.0, rng=None, tag=""):
         rng = rng or default_rng(x.device)
         N = W.shape[0]
         sid, seed = rng.site(tag, (x2.shape[0], N), p), rng.seed
-    y = LinearActFn.apply(x2, W, b, _ACT[act], float(p), seed, sid)
+    memo = MEMO if (MEMO.mode is not None and x2.shape[0] >= MEMO_MIN_ROWS and not x2.requires_grad) else None
+    key = (x2.data_ptr(), tuple(x2.shape), W.data_ptr(), act) if memo is not None else None
+    y0 = None
+    if memo is not None and memo.mode == "replay":
+        y0 = memo.store.pop(key, None)
+    y = LinearActFn.apply(x2, W, b, _ACT[act], float(p), seed, sid, y0)
+    if memo is not None and memo.mode == "record" and p <= 0.0 and not torch.is_grad_enabled():
+        memo.store[key] = y
     return y.reshape(*lead, y.shape[-1])
 
 

@@ -62,6 +62,17 @@ typedef struct {
   float mask_scale;
   int accumulate;
   float alpha;
+  /* bf16x3 operand planes (all optional, ignored in exact mode). An fp32 matrix x can be accompanied by two bf16 matrices
+   * hi = bf16(x), lo = bf16(x - hi) of the SAME shape and leading dimension (advmil_split_planes; the Adam kernel emits them
+   * for the weights; c_hi/c_lo below for activations). When both planes of an operand are given (16-byte aligned, leading
+   * dimension and contiguous extent multiples of 8) the engine stages them straight into LDS instead of re-splitting the fp32
+   * values in every workgroup that re-reads them -- results are bit-identical to the on-the-fly split. */
+  const void* a_hi;
+  const void* a_lo;
+  const void* b_hi;
+  const void* b_lo;
+  void* c_hi; /* also write the planes of the final C values (pitch ldc) for the next contraction */
+  void* c_lo;
 } advmil_epilogue_t;
 
 size_t advmil_gemm_f32_workspace_bytes(int64_t M, int64_t N, int splits);
@@ -71,6 +82,7 @@ int advmil_gemm_f32(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, const f
 /* Arithmetic of the fp32 engine (process-wide): 0 = exact fp32 MFMA; 1 = split-bf16 ("bf16x3"): every fp32 operand is
  * split into hi + lo bf16 in registers and a.b is formed as ah.bh + ah.bl + al.bh on the bf16 matrix pipe with fp32
  * accumulate -- dropped terms ~2^-17 |a||b| per product, 3/16 of the matrix-pipe time. Storage stays fp32 everywhere. */
+int advmil_split_planes(const float* src, int64_t n, void* hi, void* lo, advmil_stream_t stream);
 int advmil_set_gemm_mode(int mode);
 int advmil_get_gemm_mode(void);
 /* The library's launch plan for a shape: block tile (see below) and K split count. Host callers size the workspace

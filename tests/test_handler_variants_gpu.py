@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+from advmil_amd import synth
 from advmil_amd.config import default_cfg
 from oracle import advmil_oracle as O
 from tests import helpers as H
@@ -178,3 +179,60 @@ def test_ingest_stager_makes_the_step_slab_zero_copy():
     torch.cuda.synchronize()
     want = torch.cat([loader[3 + j][1][0][0] for j in range(3)], dim=0)       # second step's bags, in order
     assert torch.equal(seen[-1].cpu(), want)
+
+
+@pytest.mark.parametrize("kind", ["abmil", "patch", "cluster"])
+def test_forward_memo_is_bitwise_neutral(kind):
+    """The G-step reuses the row-sized pre-dropout layer outputs of the D-step's eval forward (ops.ForwardMemo). With
+    dropout ON, two optimizer steps with the memo must equal two steps without it bit for bit."""
+    from advmil_amd import ops
+    from advmil_amd.model import MyHandler
+
+    def run(min_rows):
+        old = ops.MEMO_MIN_ROWS
+        ops.MEMO_MIN_ROWS = min_rows
+        try:
+            nb, lens = 3, (256, 128, 64)
+            h = MyHandler(default_cfg(bcb_mode=kind, bp_every_batch=nb), device=DEV)
+            load_synth(h.netG, f"G-{kind}:"); load_synth(h.netD, "D-prj:")
+            h.rng.reset(1234)
+            loader = []
+            for i in range(2 * nb):
+                x = H.bag(70 + i, 512)[:, :lens[i % nb]].contiguous()
+                ext = H.T(synth.cluster_ids(0, i, lens[i % nb])) if kind == "cluster" else torch.zeros(1, 1)
+                loader.append((torch.tensor([[i]], dtype=torch.int), [x, ext], H.label(i)))
+            cl = h._train_each_epoch(loader, "train", "wlabel")
+            logs = h.pop_logs()
+            return cl, logs, {k: v.clone() for k, v in h.netG.state_dict().items()}, {k: v.clone() for k, v in h.netD.state_dict().items()}
+        finally:
+            ops.MEMO_MIN_ROWS = old
+
+    a, b = run(1), run(10 ** 9)
+    assert torch.equal(a[0]["y_hat"], b[0]["y_hat"]) and torch.equal(a[0]["f_fake"], b[0]["f_fake"])
+    for la, lb in zip(a[1], b[1]):
+        for k in la:
+            assert float(la[k]) == float(lb[k]), k
+    for sa, sb in ((a[2], b[2]), (a[3], b[3])):
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), k
+
+
+def test_forward_memo_is_consumed_and_cleared():
+    from advmil_amd import ops
+    from advmil_amd.model import MyHandler
+    old = ops.MEMO_MIN_ROWS
+    ops.MEMO_MIN_ROWS = 1
+    try:
+        h = MyHandler(default_cfg(bcb_mode="abmil", bp_every_batch=2), device=DEV)
+        xs = [[H.bag(90 + i, 256).to(DEV), None] for i in range(2)]
+        ys = [H.label(i).to(DEV) for i in range(2)]
+        h._update_disc(1, xs, ys)
+        assert len(ops.MEMO.store) == 1 and ops.MEMO.mode is None          # the FC output of the eval forward
+        h._update_gen(1, xs, ys)
+        assert len(ops.MEMO.store) == 0
+        h._update_disc(2, xs, ys)
+        h.optimizerG.step()                                                 # weights moved: the stale entry must not be used
+        h._update_gen(2, xs, ys)
+        assert len(ops.MEMO.store) == 0
+    finally:
+        ops.MEMO_MIN_ROWS = old

@@ -259,3 +259,39 @@ def test_gemm_split_bf16x3_mode(ops, a_kc, b_kc):
         assert relerr(ops.gemm(Ad, Bd, a_kc, b_kc, M, N, K), ref) < 2e-6
     finally:
         ops.set_gemm_mode(prev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, False), (False, True)])
+@pytest.mark.parametrize("shape", [(512, 384, 1024, 0), (200, 136, 72, 11), (384, 256, 4096, 22)])
+def test_gemm_planes_bit_identical_to_on_the_fly_split(ops, a_kc, b_kc, shape):
+    """bf16x3 mode: operands given as pre-split planes (any subset) give bit-identical results to the in-kernel split, and
+    the planes the epilogue emits equal split_planes(C)."""
+    M, N, K, tile = shape
+    prev = ops.get_gemm_mode()
+    ops.set_gemm_mode("bf16x3")
+    try:
+        g = torch.Generator(device="cuda").manual_seed(5)
+        A = torch.randn((M, K) if a_kc else (K, M), device="cuda", generator=g)
+        B = torch.randn((N, K) if b_kc else (K, N), device="cuda", generator=g)
+        bias = torch.randn(N, device="cuda", generator=g)
+        pa, pb = ops.split_planes(A), ops.split_planes(B)
+        # planes hold exactly bf16(x) and bf16(x - bf16(x))
+        assert torch.equal(pa.hi, A.to(torch.bfloat16))
+        assert torch.equal(pa.lo, (A - A.to(torch.bfloat16).float()).to(torch.bfloat16))
+        ref = ops.gemm(A, B, a_kc, b_kc, M, N, K, bias=bias, act0=1, tile=tile)
+        for use_a, use_b in [(True, False), (False, True), (True, True)]:
+            cp = ops.Planes.empty_like(ref)
+            got = ops.gemm(A, B, a_kc, b_kc, M, N, K, bias=bias, act0=1, tile=tile, a_planes=pa if use_a else None,
+                           b_planes=pb if use_b else None, c_planes=cp)
+            assert torch.equal(got, ref), (use_a, use_b)
+            want = ops.split_planes(got)
+            assert torch.equal(cp.hi, want.hi) and torch.equal(cp.lo, want.lo)
+        # split-K path: planes in, planes out of the reduce launch
+        cp = ops.Planes.empty_like(ref)
+        r2 = ops.gemm(A, B, a_kc, b_kc, M, N, K, splits=2, tile=tile)
+        g2 = ops.gemm(A, B, a_kc, b_kc, M, N, K, splits=2, tile=tile, a_planes=pa, b_planes=pb, c_planes=cp)
+        assert torch.equal(g2, r2)
+        assert torch.equal(cp.hi, g2.to(torch.bfloat16))
+    finally:
+        ops.set_gemm_mode(prev)
