@@ -83,6 +83,7 @@ SIGNATURES = {
     "advmil_abs_sum": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "advmil_abs_sum_workspace_bytes": (c_size_t, [c_int64]),
     "advmil_uniform_fill": (c_int, [c_void_p, c_int64, c_void_p, c_uint64, c_void_p]),
+    "advmil_dropout_apply": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_uint64, c_void_p]),
     "advmil_seed_advance": (c_int, [c_void_p, c_uint64, c_void_p]),
 }
 

@@ -74,10 +74,10 @@ __device__ __forceinline__ void store_tile(float* __restrict__ s, int tid, const
 }
 
 // fragment for the 32-row block starting at `rbase`, k-group t4: f[u], u = 0..3
-template <bool KC, int ROWS>
+template <bool KC, int ROWS, int BKT>
 __device__ __forceinline__ void read_frag(const float* __restrict__ s, int rbase, int t4, int i, int hi, float (&f)[4]) {
   if (KC) {
-    const float4 v = *reinterpret_cast<const float4*>(s + (rbase + i) * PITCH_KC + t4 * 8 + hi * 4);
+    const float4 v = *reinterpret_cast<const float4*>(s + (rbase + i) * (BKT + 4) + t4 * 8 + hi * 4);
     f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
   } else {
 #pragma unroll
@@ -93,19 +93,19 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // Pre-split LDS image of a k-contiguous operand tile (bf16x3 mode): two bf16 planes [row][PITCH_PS], hi then lo, written once
 // per element when the tile is staged (every element is consumed by two waves, so splitting here halves the conversion work
-// and leaves the inner loop with ds_read_b128 + MFMA only). PITCH_PS = 40 bf16 = 20 dwords: 16-lane b128 groups hit 64 banks.
-#define PITCH_PS 40
+// and leaves the inner loop with ds_read_b128 + MFMA only). PITCH_PS = BKT + 8 bf16 (20 dwords at BKT = 32): 16-lane b128 groups hit 64 banks.
+#define PITCH_PS(BKT) ((BKT) + 8)
 typedef unsigned short bf16raw;
 union Frag8 { uint4 u; bf16x8 v; };
 
-template <int ROWS>
-__device__ __forceinline__ void store_tile_presplit(bf16raw* __restrict__ planes, int tid, const float4 (&r)[ROWS / 32]) {
+template <int ROWS, int BKT>
+__device__ __forceinline__ void store_tile_presplit(bf16raw* __restrict__ planes, int tid, const float4 (&r)[ROWS * BKT / 1024]) {
   bf16raw* const hiP = planes;
-  bf16raw* const loP = planes + ROWS * PITCH_PS;
+  bf16raw* const loP = planes + ROWS * PITCH_PS(BKT);
 #pragma unroll
-  for (int p = 0; p < ROWS / 32; ++p) {
+  for (int p = 0; p < ROWS * BKT / 1024; ++p) {
     const int e = p * 256 + tid;
-    const int row = e >> 3, k4 = (e & 7) * 4;
+    const int row = e / (BKT / 4), k4 = (e % (BKT / 4)) * 4;
     const float x[4] = {r[p].x, r[p].y, r[p].z, r[p].w};
     union { __bf16 b[4]; uint2 u; } h, l;
 #pragma unroll
@@ -113,18 +113,18 @@ __device__ __forceinline__ void store_tile_presplit(bf16raw* __restrict__ planes
       h.b[j] = (__bf16)x[j];
       l.b[j] = (__bf16)(x[j] - (float)h.b[j]);
     }
-    *reinterpret_cast<uint2*>(hiP + row * PITCH_PS + k4) = h.u;
-    *reinterpret_cast<uint2*>(loP + row * PITCH_PS + k4) = l.u;
+    *reinterpret_cast<uint2*>(hiP + row * PITCH_PS(BKT) + k4) = h.u;
+    *reinterpret_cast<uint2*>(loP + row * PITCH_PS(BKT) + k4) = l.u;
   }
 }
 
-template <int ROWS>
+template <int ROWS, int BKT>
 __device__ __forceinline__ void read_frag_presplit(const bf16raw* __restrict__ planes, int rbase, int ks, int i, int hi,
                                                    bf16x8& h, bf16x8& l) {
-  const bf16raw* p = planes + (rbase + i) * PITCH_PS + ks * 16 + hi * 8;
+  const bf16raw* p = planes + (rbase + i) * PITCH_PS(BKT) + ks * 16 + hi * 8;
   Frag8 a, b;
   a.u = *reinterpret_cast<const uint4*>(p);
-  b.u = *reinterpret_cast<const uint4*>(p + ROWS * PITCH_PS);
+  b.u = *reinterpret_cast<const uint4*>(p + ROWS * PITCH_PS(BKT));
   h = a.v; l = b.v;
 }
 
@@ -187,7 +187,9 @@ __device__ __forceinline__ void emit_planes4(const advmil_epilogue_t& e, int64_t
     *reinterpret_cast<uint2*>(ch) = h.u;
     *reinterpret_cast<uint2*>(cl) = l.u;
   } else {
-    for (int j = 0; j < nvalid; ++j) { ch[j] = h.r[j]; cl[j] = l.r[j]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < nvalid) { ch[j] = h.r[j]; cl[j] = l.r[j]; }
   }
 }
 
@@ -231,16 +233,16 @@ struct OperandStage {
 
   __device__ __forceinline__ void store(bf16raw* __restrict__ planes, int tid) const {
     if constexpr (!PRE) {
-      if (KC) store_tile_presplit<ROWS>(planes, tid, f);
+      if (KC) store_tile_presplit<ROWS, BKT>(planes, tid, f);
       else store_tile_presplit_mc<ROWS, BKT>(planes, tid, f);
     } else {
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         const int e = p * 256 + tid;
         if (KC) {
-          bf16raw* d = planes + (e / (BKT / 8)) * PITCH_PS + (e % (BKT / 8)) * 8;
+          bf16raw* d = planes + (e / (BKT / 8)) * PITCH_PS(BKT) + (e % (BKT / 8)) * 8;
           *reinterpret_cast<uint4*>(d) = ph[p];
-          *reinterpret_cast<uint4*>(d + ROWS * PITCH_PS) = pl[p];
+          *reinterpret_cast<uint4*>(d + ROWS * PITCH_PS(BKT)) = pl[p];
         } else {
           bf16raw* d = planes + (e / (ROWS / 8)) * PITCH_MC(ROWS) + (e % (ROWS / 8)) * 8;
           *reinterpret_cast<uint4*>(d) = ph[p];
@@ -251,17 +253,16 @@ struct OperandStage {
   }
 };
 
-template <bool A_KC, bool B_KC, int TM, int TN, bool SPLIT, int PRE>
+template <bool A_KC, bool B_KC, int TM, int TN, bool SPLIT, int PRE, int BKT>
 __global__ __launch_bounds__(256, (TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(GemmArgs g) {
   constexpr int BM_ = 64 * TM, BN_ = 64 * TN;
-  // k per chunk: 32 for the exact variant; 64 for bf16x3, whose matrix-pipe time per k is 5x smaller, so that the two
-  // barriers / staging phase per chunk are amortised over twice the work (and 4 independent k-steps instead of 2)
-  constexpr int BKT = 32;   // (64 was measured for the bf16x3 variant: no gain, +60 VGPRs)
+  // BKT = k per chunk, 32 everywhere. Measured alternatives: 64 for the bf16x3 variant (no gain, +60 VGPRs); 64/128 for 64x64
+  // tiles on launch-bound shapes (no gain: their cost was an epilogue array in scratch memory, not the K walk).
   constexpr int PITCH = BKT + 4;
   // bf16x3: k-contiguous operands are kept pre-split in LDS (two bf16 planes, 160 B per row instead of 144 B of fp32)
   // (MC operands: two [k][rows+32] bf16 planes read with the LDS transpose read)
-  constexpr int TILEF_A = !SPLIT ? BM_ * PITCH : (A_KC ? BM_ * PITCH_PS : BKT * PITCH_MC(BM_));   // floats per operand tile
-  constexpr int TILEF_B = !SPLIT ? BN_ * PITCH : (B_KC ? BN_ * PITCH_PS : BKT * PITCH_MC(BN_));
+  constexpr int TILEF_A = !SPLIT ? BM_ * PITCH : (A_KC ? BM_ * PITCH_PS(BKT) : BKT * PITCH_MC(BM_));   // floats per operand tile
+  constexpr int TILEF_B = !SPLIT ? BN_ * PITCH : (B_KC ? BN_ * PITCH_PS(BKT) : BKT * PITCH_MC(BN_));
   // bf16x3: two LDS buffers (one barrier per chunk, the next chunk is staged while the current one feeds the matrix pipe).
   // The exact variant stays single-buffered: there the doubled LDS footprint costs co-resident workgroups and measured slower.
   constexpr int NBUF = SPLIT ? 2 : 1;
@@ -346,12 +347,12 @@ __global__ __launch_bounds__(256, (TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(Ge
         bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
-          if (A_KC) read_frag_presplit<BM_>(cA, wr * 32 * TM + a * 32, ks, i, hi, ah[a], al[a]);
+          if (A_KC) read_frag_presplit<BM_, BKT>(cA, wr * 32 * TM + a * 32, ks, i, hi, ah[a], al[a]);
           else read_frag_presplit_mc<BM_, BKT>(cA, wr * 32 * TM + a * 32, ks, lane, ah[a], al[a]);
         }
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
-          if (B_KC) read_frag_presplit<BN_>(cB, wc * 32 * TN + b * 32, ks, i, hi, bh[b], bl[b]);
+          if (B_KC) read_frag_presplit<BN_, BKT>(cB, wc * 32 * TN + b * 32, ks, i, hi, bh[b], bl[b]);
           else read_frag_presplit_mc<BN_, BKT>(cB, wc * 32 * TN + b * 32, ks, lane, bh[b], bl[b]);
         }
 #pragma unroll
@@ -387,12 +388,12 @@ __global__ __launch_bounds__(256, (TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(Ge
         load_tile<B_KC, BN_, BKT>(g.B, g.ldb, n0, g.N, k0 + BKT, kend, tid, rb);
       }
 #pragma unroll
-      for (int t4 = 0; t4 < 4; ++t4) {
+      for (int t4 = 0; t4 < BKT / 8; ++t4) {
         float fa[TM][4], fb[TN][4];
 #pragma unroll
-        for (int a = 0; a < TM; ++a) read_frag<A_KC, BM_>(sA, wr * 32 * TM + a * 32, t4, i, hi, fa[a]);
+        for (int a = 0; a < TM; ++a) read_frag<A_KC, BM_, BKT>(sA, wr * 32 * TM + a * 32, t4, i, hi, fa[a]);
 #pragma unroll
-        for (int b = 0; b < TN; ++b) read_frag<B_KC, BN_>(sB, wc * 32 * TN + b * 32, t4, i, hi, fb[b]);
+        for (int b = 0; b < TN; ++b) read_frag<B_KC, BN_, BKT>(sB, wc * 32 * TN + b * 32, t4, i, hi, fb[b]);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -450,7 +451,9 @@ __global__ __launch_bounds__(256, (TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(Ge
           if (nvalid == 4 && vec_ok) {
             *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
           } else {
-            for (int t = 0; t < nvalid; ++t) c[t] = v[t];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)      // static indices: a runtime-bounded loop would push v[] into scratch memory
+              if (t < nvalid) c[t] = v[t];
           }
           if (direct && e.c_hi) emit_planes4(e, (int64_t)blockIdx.z * g.sC + row * ldo + col, v, nvalid);
         }
@@ -504,32 +507,32 @@ extern "C" int advmil_set_gemm_mode(int mode) {
 }
 extern "C" int advmil_get_gemm_mode(void) { return g_gemm_mode; }
 
-template <int TM, int TN, bool SPLIT, int PRE>
+template <int TM, int TN, bool SPLIT, int PRE, int BKT>
 static void launch_tile_m(int a_kc, int b_kc, dim3 grid, hipStream_t stream, const GemmArgs& g) {
   dim3 block(256);
   if (a_kc && b_kc)
-    hipLaunchKernelGGL((gemm_f32_kernel<true, true, TM, TN, SPLIT, PRE>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<true, true, TM, TN, SPLIT, PRE, BKT>), grid, block, 0, stream, g);
   else if (a_kc && !b_kc)
-    hipLaunchKernelGGL((gemm_f32_kernel<true, false, TM, TN, SPLIT, PRE>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<true, false, TM, TN, SPLIT, PRE, BKT>), grid, block, 0, stream, g);
   else if (!a_kc && !b_kc)
-    hipLaunchKernelGGL((gemm_f32_kernel<false, false, TM, TN, SPLIT, PRE>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<false, false, TM, TN, SPLIT, PRE, BKT>), grid, block, 0, stream, g);
   else
-    hipLaunchKernelGGL((gemm_f32_kernel<false, true, TM, TN, SPLIT, PRE>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<false, true, TM, TN, SPLIT, PRE, BKT>), grid, block, 0, stream, g);
 }
 
 // PLANES: this tile is also built for operands that arrive as bf16 planes (the slab-sized contractions only use 22/12/11)
 template <int TM, int TN, bool PLANES>
 static void launch_tile(int a_kc, int b_kc, dim3 grid, hipStream_t stream, const GemmArgs& g, int pre) {
-  if (g_gemm_mode != 1) { launch_tile_m<TM, TN, false, 0>(a_kc, b_kc, grid, stream, g); return; }
+  if (g_gemm_mode != 1) { launch_tile_m<TM, TN, false, 0, 32>(a_kc, b_kc, grid, stream, g); return; }
   if constexpr (PLANES) {
     switch (pre) {
-      case 1: launch_tile_m<TM, TN, true, 1>(a_kc, b_kc, grid, stream, g); return;
-      case 2: launch_tile_m<TM, TN, true, 2>(a_kc, b_kc, grid, stream, g); return;
-      case 3: launch_tile_m<TM, TN, true, 3>(a_kc, b_kc, grid, stream, g); return;
+      case 1: launch_tile_m<TM, TN, true, 1, 32>(a_kc, b_kc, grid, stream, g); return;
+      case 2: launch_tile_m<TM, TN, true, 2, 32>(a_kc, b_kc, grid, stream, g); return;
+      case 3: launch_tile_m<TM, TN, true, 3, 32>(a_kc, b_kc, grid, stream, g); return;
       default: break;
     }
   }
-  launch_tile_m<TM, TN, true, 0>(a_kc, b_kc, grid, stream, g);
+  launch_tile_m<TM, TN, true, 0, 32>(a_kc, b_kc, grid, stream, g);
 }
 
 // Which operands can be taken from caller-provided planes: both planes present, 16-byte aligned, pitch and contiguous extent

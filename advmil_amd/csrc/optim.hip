@@ -86,6 +86,25 @@ extern "C" int advmil_uniform_fill(float* out, int64_t n, const uint64_t* seed, 
   return ADVMIL_OK;
 }
 
+// y[i] = x[i] * (u(seed, stream, i) >= p ? 1/(1-p) : 0): the dropout of the [B, d]-sized head tensors (and, applied to dy, its
+// backward) as ONE launch; same draw as the GEMM epilogue's dropout and synth.dropout_keep.
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float p,
+                                                            const uint64_t* seed, uint64_t stream_id) {
+  const uint64_t key = rng_key(*seed, stream_id);
+  const float inv = 1.0f / (1.0f - p);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = x[i] * rng_keep(key, (uint64_t)i, p, inv);
+}
+extern "C" int advmil_dropout_apply(const float* x, float* y, int64_t n, float p, const uint64_t* seed, uint64_t stream_id,
+                                    advmil_stream_t stream_) {
+  if (!x || !y || !seed || n <= 0 || !(p >= 0.0f && p < 1.0f)) return ADVMIL_EINVAL;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(dropout_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, x, y, n, p, seed, stream_id);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}
+
 __global__ void seed_advance_kernel(uint64_t* seed, uint64_t inc) { *seed += inc; }
 extern "C" int advmil_seed_advance(uint64_t* seed, uint64_t inc, advmil_stream_t stream_) {
   if (!seed) return ADVMIL_EINVAL;

@@ -38,6 +38,8 @@ def load_backbone(mode, dims):
 def _small_fc(seq, x, rng, tag):
     """Linear -> ReLU -> Dropout on a [1, d] vector (launch-bound; stays a couple of tiny device ops)."""
     lin, drop = seq[0], seq[2]
+    if x.dim() == 2 and lin.in_features % 4 == 0 and lin.out_features % 4 == 0:      # one launch, dropout in the epilogue
+        return ops.linear_act(x, lin.weight, lin.bias, "relu", drop.p if seq.training else 0.0, rng, tag)
     return dropout_small(F.relu(F.linear(x, lin.weight, lin.bias)), drop.p, seq.training, rng, tag)
 
 

@@ -295,7 +295,7 @@ class MyHandler(object):
         self.optimizerD.zero_grad()
         X = self._slab(xs)
         y = torch.cat(ys, dim=0)
-        ops.MEMO.begin("record", ("G", id(self.netG), getattr(self.optimizerG, "n_updates", 0)))
+        ops.MEMO.begin("record", ("G", id(self.netG), getattr(self.optimizerG, "n_updates", 0)), X)
         try:
             with torch.no_grad():                                              # the reference builds, then detaches (400)
                 pred = self.netG.finish(self._gen_features(X, plan, xs), noise=self._stack_noise(noise))     # [B,1]
@@ -341,7 +341,7 @@ class MyHandler(object):
         self.optimizerG.zero_grad()
         X = self._slab(xs)
         # row-sized pre-dropout layer outputs of the eval forward in _disc_backward are reused (same rows, same G weights)
-        ops.MEMO.begin("replay", ("G", id(self.netG), getattr(self.optimizerG, "n_updates", 0)))
+        ops.MEMO.begin("replay", ("G", id(self.netG), getattr(self.optimizerG, "n_updates", 0)), X)
         try:
             feats = self._gen_features(X, plan, xs)
         finally:

@@ -62,12 +62,31 @@ def make_embedding_y_layer(args):
     return nn.Sequential(*layers)
 
 
+def _fusable(lin, x):
+    """The HIP contraction engine takes the layer when every contiguous extent is a multiple of 4 floats."""
+    return x.dim() == 2 and x.is_cuda and lin.in_features % 4 == 0 and lin.out_features % 4 == 0
+
+
 def run_mlp_small(seq, x, rng, tag):
-    """Apply a Sequential of Linear / LayerNorm / ReLU / Dropout holders to a [1, d]-sized tensor."""
-    for j, m in enumerate(seq):
+    """Apply a Sequential of Linear / LayerNorm / ReLU / Dropout holders to a [B, d]-sized tensor. Linear (+ReLU) (+Dropout)
+    runs of a layer go through ONE contraction launch (bias, activation and dropout in its epilogue; in the backward the weight
+    and bias gradients are accumulated straight into the optimizer's arena), the rest stays a tiny device op each."""
+    mods = list(seq)
+    j = 0
+    while j < len(mods):
+        m = mods[j]
         if isinstance(m, nn.Sequential):
             x = run_mlp_small(m, x, rng, f"{tag}.{j}")
         elif isinstance(m, nn.Linear):
+            if _fusable(m, x):
+                act, p, k = "none", 0.0, j + 1
+                if k < len(mods) and isinstance(mods[k], nn.ReLU):
+                    act, k = "relu", k + 1
+                    if k < len(mods) and isinstance(mods[k], nn.Dropout):
+                        p, k = (mods[k].p if seq.training else 0.0), k + 1
+                x = ops.linear_act(x, m.weight, m.bias, act, p, rng, f"{tag}.{k - 1}")   # the Dropout module's index names the draw
+                j = k
+                continue
             x = F.linear(x, m.weight, m.bias)
         elif isinstance(m, nn.LayerNorm):
             x = F.layer_norm(x, m.normalized_shape, m.weight, m.bias, m.eps)
@@ -77,6 +96,7 @@ def run_mlp_small(seq, x, rng, tag):
             x = dropout_small(x, m.p, seq.training, rng, f"{tag}.{j}")
         else:
             raise NotImplementedError(type(m))
+        j += 1
     return x
 
 

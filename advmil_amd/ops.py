@@ -388,6 +388,35 @@ def _stack2(a, b, rows, cols):
     return torch.cat([a.detach(), b.detach()], dim=0).contiguous(), False
 
 
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout on a small dense tensor as one launch each way (flat index i on stream `sid`)."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed, sid):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib().advmil_dropout_apply(_p(x), _p(y), x.numel(), p, _p(seed), sid, _stream()), "dropout_apply")
+        ctx.cfg = (p, seed, sid)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, sid = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        _lib.check(_lib.lib().advmil_dropout_apply(_p(dy), _p(dx), dy.numel(), p, _p(seed), sid, _stream()), "dropout_apply")
+        return dx, None, None, None
+
+
+def dropout(x, p, rng, tag=""):
+    """Train-mode dropout of x (any shape) drawn from the counter RNG at a fresh call site."""
+    if p <= 0.0 or x.numel() == 0:
+        return x
+    _chk(x, "x")
+    sid = rng.site(tag, tuple(x.shape), p)
+    return DropoutFn.apply(x, float(p), rng.seed, sid)
+
+
 class LinearActFn(torch.autograd.Function):
     """y = dropout(act(x W^T + b)); x[M,K], W[N,K]. Dropout index = m*N + n on stream `sid`."""
 
@@ -444,12 +473,14 @@ class ForwardMemo:
     (131072x384x1024: ~0.45 ms saved per step). `token` must identify the weights' version; entries from another token are dropped."""
 
     def __init__(self):
-        self.mode, self.token, self.store = None, None, {}
+        self.mode, self.token, self.rows_ptr, self.store = None, None, None, {}
 
-    def begin(self, mode, token):
+    def begin(self, mode, token, rows):
+        """`rows`: the step slab. Only layers applied DIRECTLY to it are carried: an intermediate tensor's address says nothing
+        about its contents (the allocator reuses addresses), the slab is the one input both forwards provably share."""
         if token != self.token:
             self.store.clear()
-        self.mode, self.token = mode, token
+        self.mode, self.token, self.rows_ptr = mode, token, rows.data_ptr()
 
     def end(self, clear=False):
         self.mode = None
@@ -470,7 +501,8 @@ def linear_act(x, W, b, act="none", p=0.0, rng=None, tag=""):
         rng = rng or default_rng(x.device)
         N = W.shape[0]
         sid, seed = rng.site(tag, (x2.shape[0], N), p), rng.seed
-    memo = MEMO if (MEMO.mode is not None and x2.shape[0] >= MEMO_MIN_ROWS and not x2.requires_grad) else None
+    memo = MEMO if (MEMO.mode is not None and x2.data_ptr() == MEMO.rows_ptr and x2.shape[0] >= MEMO_MIN_ROWS
+                    and not x2.requires_grad) else None
     key = (x2.data_ptr(), tuple(x2.shape), W.data_ptr(), act) if memo is not None else None
     y0 = None
     if memo is not None and memo.mode == "replay":

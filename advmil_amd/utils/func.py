@@ -67,5 +67,4 @@ def dropout_small(x, p, training, rng, tag=""):
     (so a parity test can regenerate the mask: advmil_amd.synth.dropout_keep)."""
     if not training or p <= 0.0:
         return x
-    u = rng.uniform(x.numel(), tag).reshape(x.shape)
-    return x * (u >= p).to(x.dtype) * (1.0 / (1.0 - p))
+    return ops.dropout(x, p, rng, tag)

@@ -218,6 +218,10 @@ size_t advmil_abs_sum_workspace_bytes(int64_t n);
 /* fill out[i] = U[0,1) from the counter RNG (generator noise, utils/func.py:154-164) */
 int advmil_uniform_fill(float* out, int64_t n, const uint64_t* seed, uint64_t stream_id, advmil_stream_t stream);
 /* seed[0] += inc  (advance the step seed between graph replays) */
+/* y = x * keep/(1-p) with keep drawn at flat index i of (seed, stream_id): nn.Dropout on the [B, d]-sized head tensors
+ * (model/model_utils.py:106-176 make_mlp_layer; applied to dy it is the backward). In place (y == x) allowed. */
+int advmil_dropout_apply(const float* x, float* y, int64_t n, float p, const uint64_t* seed, uint64_t stream_id,
+                         advmil_stream_t stream);
 int advmil_seed_advance(uint64_t* seed, uint64_t inc, advmil_stream_t stream);
 
 #ifdef __cplusplus
