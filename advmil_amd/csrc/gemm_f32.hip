@@ -18,6 +18,16 @@
 #define BK 32          // k per chunk of the exact-fp32 variant (and the granularity of split-K chunking)
 #define PITCH_KC 36    // BK + 4
 
+// LDS ordering inside ONE wave (a wave's DS operations complete in issue order; this only stops the compiler from moving them
+// across and drains the queue): enough when the LDS region is private to the wave.
+#define WAVE_LDS_SYNC()                                   \
+  do {                                                    \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_s_waitcnt(0xc07f);                   \
+    __builtin_amdgcn_wave_barrier();                      \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
+
 struct GemmArgs {
   int64_t M, N, K;
   const float* A; int64_t lda;
@@ -98,6 +108,23 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short bf16raw;
 union Frag8 { uint4 u; bf16x8 v; };
 
+// hi/lo split of 4 consecutive floats into 4+4 bf16, converting PAIRS (one v_cvt_pk_bf16_f32 per two values; the scalar casts
+// compile to one cvt per value): 3 VALU per element instead of 4 in the staging path, which is what the bf16x3 loop is bound by.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
+  union { bf16x2_t b; unsigned u; } h0, h1, l0, l1;
+  const f32x2_t a = {v.x, v.y}, c = {v.z, v.w};
+  h0.b = __builtin_convertvector(a, bf16x2_t);
+  h1.b = __builtin_convertvector(c, bf16x2_t);
+  const f32x2_t ra = {v.x - __uint_as_float(h0.u << 16), v.y - __uint_as_float(h0.u & 0xffff0000u)};
+  const f32x2_t rc = {v.z - __uint_as_float(h1.u << 16), v.w - __uint_as_float(h1.u & 0xffff0000u)};
+  l0.b = __builtin_convertvector(ra, bf16x2_t);
+  l1.b = __builtin_convertvector(rc, bf16x2_t);
+  hi = make_uint2(h0.u, h1.u);
+  lo = make_uint2(l0.u, l1.u);
+}
+
 template <int ROWS, int BKT>
 __device__ __forceinline__ void store_tile_presplit(bf16raw* __restrict__ planes, int tid, const float4 (&r)[ROWS * BKT / 1024]) {
   bf16raw* const hiP = planes;
@@ -106,15 +133,10 @@ __device__ __forceinline__ void store_tile_presplit(bf16raw* __restrict__ planes
   for (int p = 0; p < ROWS * BKT / 1024; ++p) {
     const int e = p * 256 + tid;
     const int row = e / (BKT / 4), k4 = (e % (BKT / 4)) * 4;
-    const float x[4] = {r[p].x, r[p].y, r[p].z, r[p].w};
-    union { __bf16 b[4]; uint2 u; } h, l;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      h.b[j] = (__bf16)x[j];
-      l.b[j] = (__bf16)(x[j] - (float)h.b[j]);
-    }
-    *reinterpret_cast<uint2*>(hiP + row * PITCH_PS(BKT) + k4) = h.u;
-    *reinterpret_cast<uint2*>(loP + row * PITCH_PS(BKT) + k4) = l.u;
+    uint2 h, l;
+    split4(r[p], h, l);
+    *reinterpret_cast<uint2*>(hiP + row * PITCH_PS(BKT) + k4) = h;
+    *reinterpret_cast<uint2*>(loP + row * PITCH_PS(BKT) + k4) = l;
   }
 }
 
@@ -146,15 +168,10 @@ __device__ __forceinline__ void store_tile_presplit_mc(bf16raw* __restrict__ pla
   for (int p = 0; p < ROWS * BKT / 1024; ++p) {
     const int e = p * 256 + tid;
     const int k = e / (ROWS / 4), m4 = (e % (ROWS / 4)) * 4;
-    const float x[4] = {r[p].x, r[p].y, r[p].z, r[p].w};
-    union { __bf16 b[4]; uint2 u; } h, l;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      h.b[j] = (__bf16)x[j];
-      l.b[j] = (__bf16)(x[j] - (float)h.b[j]);
-    }
-    *reinterpret_cast<uint2*>(hiP + k * PITCH_MC(ROWS) + m4) = h.u;
-    *reinterpret_cast<uint2*>(loP + k * PITCH_MC(ROWS) + m4) = l.u;
+    uint2 h, l;
+    split4(r[p], h, l);
+    *reinterpret_cast<uint2*>(hiP + k * PITCH_MC(ROWS) + m4) = h;
+    *reinterpret_cast<uint2*>(loP + k * PITCH_MC(ROWS) + m4) = l;
   }
 }
 
@@ -427,25 +444,45 @@ __global__ __launch_bounds__(256, (TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(Ge
     for (int b = 0; b < TN; ++b) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * PITCH_KC + i] = acc[a][b][r];
-      __syncthreads();
+      WAVE_LDS_SYNC();   // the patch is private to this wave: order its LDS writes before the reads below, no block barrier
       const int64_t rbase = m0 + wr * 32 * TM + a * 32;
-      const int64_t cbase = n0 + wc * 32 * TN + b * 32;
+      // a lane stores columns col..col+3 of rows rbase + (lane >> 3) + 8q: everything that depends on the column only (bias,
+      // which activation) is fetched once per sub-tile, not once per element inside the row loop
+      const int64_t col = n0 + wc * 32 * TN + b * 32 + (lane & 7) * 4;
+      const int nvalid = col >= g.N ? 0 : ((g.N - col >= 4) ? 4 : (int)(g.N - col));
+      float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+      int act4[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (direct && e.bias && t < nvalid) bias4[t] = e.bias[col + t];
+        act4[t] = (col + t) < e.act_split ? e.act0 : e.act1;
+      }
+      const bool same_act = act4[0] == act4[3];
 #pragma unroll 1
       for (int q = 0; q < 4; ++q) {
-        const int idx = q * 64 + lane;
-        const int pr = idx >> 3, pc = (idx & 7) * 4;
-        const int64_t row = rbase + pr, col = cbase + pc;
-        const float4 v4 = *reinterpret_cast<const float4*>(patch + pr * PITCH_KC + pc);
+        const int pr = q * 8 + (lane >> 3);
+        const int64_t row = rbase + pr;
+        const float4 v4 = *reinterpret_cast<const float4*>(patch + pr * PITCH_KC + (lane & 7) * 4);
         float v[4] = {v4.x, v4.y, v4.z, v4.w};
-        if (row < g.M && col < g.N) {
-          const int nvalid = (g.N - col >= 4) ? 4 : (int)(g.N - col);
+        if (row < g.M && nvalid > 0) {
           float* c = out + row * ldo + col;
           if (direct) {
+            float r1 = 0.f;
+            const float* cv = nullptr;
+            if (e.rowv) {
+              r1 = e.rowv[row];
+              cv = e.colv + (e.rowseg ? (int64_t)e.rowseg[row] * g.N : 0) + col;
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
               if (t < nvalid) {
-                v[t] = epilogue_elem(e, v[t], row, col + t, g.N, key, inv_keep);
-                if (e.accumulate) v[t] += c[t];
+                float x = v[t] * e.alpha + bias4[t];
+                if (cv) x += r1 * cv[t];
+                x = act_apply(same_act ? act4[0] : act4[t], x);
+                if (e.seed && e.drop_p > 0.0f) x *= rng_keep(key, (uint64_t)(row * g.N + col + t), e.drop_p, inv_keep);
+                if (e.maskref) x *= (e.maskref[row * (int64_t)e.ldmask + col + t] > 0.0f ? e.mask_scale : 0.0f);
+                if (e.accumulate) x += c[t];
+                v[t] = x;
               }
           }
           if (nvalid == 4 && vec_ok) {
@@ -458,7 +495,7 @@ __global__ __launch_bounds__(256, (TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(Ge
           if (direct && e.c_hi) emit_planes4(e, (int64_t)blockIdx.z * g.sC + row * ldo + col, v, nvalid);
         }
       }
-      __syncthreads();
+      WAVE_LDS_SYNC();   // reads of this patch done before the next sub-tile overwrites it
     }
   }
 }

@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--gen-dtype", default="f32", choices=["f32", "bf16"],
                     help="generator contraction operands: f32 (exact) or bf16 MFMA (mixed precision, D stays f32)")
     ap.add_argument("--eager", action="store_true", help="drive the step eagerly instead of replaying HIP graphs")
-    ap.add_argument("--no-bf16-extra", action="store_true", help="skip the extra mixed-precision (bf16 generator) measurement")
+    ap.add_argument("--no-bf16-extra", action="store_true", help="skip the extra measurements (exact-fp32 mode, mixed-precision bf16 generator)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-bags", type=int, default=4, help="bags in the CPU-baseline sample")
@@ -314,7 +314,7 @@ def main():
 
     # ---- extra (single GPU): the same step with EXACT fp32 MFMA arithmetic
     exact_extra = None
-    if world == 1 and args.gemm_mode == "bf16x3" and not args.eager and graphs:
+    if world == 1 and args.gemm_mode == "bf16x3" and not args.eager and graphs and not args.no_bf16_extra:
         try:
             from advmil_amd.graphed import GraphedStep
             ops.set_gemm_mode("exact")
