@@ -101,10 +101,14 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ s, int rbase
 // happens once per staged element on the way into LDS, which holds two bf16 planes (hi, lo) per operand tile.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// Pre-split LDS image of a k-contiguous operand tile (bf16x3 mode): two bf16 planes [row][PITCH_PS], hi then lo, written once
-// per element when the tile is staged (every element is consumed by two waves, so splitting here halves the conversion work
-// and leaves the inner loop with ds_read_b128 + MFMA only). PITCH_PS = BKT + 8 bf16 (20 dwords at BKT = 32): 16-lane b128 groups hit 64 banks.
-#define PITCH_PS(BKT) ((BKT) + 8)
+// Pre-split LDS image of a k-contiguous operand tile (bf16x3 mode): two bf16 planes [row][BKT], hi then lo, written once per
+// element when the tile is staged (every element is consumed by two waves, so splitting here halves the conversion work and
+// leaves the inner loop with ds_read_b128 + MFMA only). Rows are NOT padded; instead the 16-byte unit u (8 consecutive k) of row r
+// lives at unit u ^ ((r >> 2) & (BKT/8 - 1)): the b128 fragment reads of a 16-lane group ({0-3,12-15,20-27} and their shifts)
+// then cover all 64 banks, and the 8-byte staging stores of a 16-lane group cover two whole rows = 32 distinct banks. (A padded
+// 80-byte pitch measured 33% of LDS cycles as bank conflicts: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r01_pmc_sq_bf16x3.json.)
+#define PITCH_PS(BKT) (BKT)
+__device__ __forceinline__ int ps_unit(int row, int unit, int units_per_row) { return unit ^ ((row >> 2) & (units_per_row - 1)); }
 typedef unsigned short bf16raw;
 union Frag8 { uint4 u; bf16x8 v; };
 
@@ -132,18 +136,20 @@ __device__ __forceinline__ void store_tile_presplit(bf16raw* __restrict__ planes
 #pragma unroll
   for (int p = 0; p < ROWS * BKT / 1024; ++p) {
     const int e = p * 256 + tid;
-    const int row = e / (BKT / 4), k4 = (e % (BKT / 4)) * 4;
+    const int row = e / (BKT / 4), p4 = e % (BKT / 4);        // p4: which 4-k piece of the row
+    const int off = row * PITCH_PS(BKT) + ps_unit(row, p4 >> 1, BKT / 8) * 8 + (p4 & 1) * 4;
     uint2 h, l;
     split4(r[p], h, l);
-    *reinterpret_cast<uint2*>(hiP + row * PITCH_PS(BKT) + k4) = h;
-    *reinterpret_cast<uint2*>(loP + row * PITCH_PS(BKT) + k4) = l;
+    *reinterpret_cast<uint2*>(hiP + off) = h;
+    *reinterpret_cast<uint2*>(loP + off) = l;
   }
 }
 
 template <int ROWS, int BKT>
 __device__ __forceinline__ void read_frag_presplit(const bf16raw* __restrict__ planes, int rbase, int ks, int i, int hi,
                                                    bf16x8& h, bf16x8& l) {
-  const bf16raw* p = planes + (rbase + i) * PITCH_PS(BKT) + ks * 16 + hi * 8;
+  const int row = rbase + i;
+  const bf16raw* p = planes + row * PITCH_PS(BKT) + ps_unit(row, ks * 2 + hi, BKT / 8) * 8;
   Frag8 a, b;
   a.u = *reinterpret_cast<const uint4*>(p);
   b.u = *reinterpret_cast<const uint4*>(p + ROWS * PITCH_PS(BKT));
@@ -257,7 +263,8 @@ struct OperandStage {
       for (int p = 0; p < NP; ++p) {
         const int e = p * 256 + tid;
         if (KC) {
-          bf16raw* d = planes + (e / (BKT / 8)) * PITCH_PS(BKT) + (e % (BKT / 8)) * 8;
+          const int row = e / (BKT / 8);
+          bf16raw* d = planes + row * PITCH_PS(BKT) + ps_unit(row, e % (BKT / 8), BKT / 8) * 8;
           *reinterpret_cast<uint4*>(d) = ph[p];
           *reinterpret_cast<uint4*>(d + ROWS * PITCH_PS(BKT)) = pl[p];
         } else {
@@ -380,7 +387,9 @@ __global__ __launch_bounds__(256, (TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(Ge
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
           }
-        if (ks == 0 && k0 + BKT < kend) {     // stage chunk c+1 behind the first MFMA group, then request chunk c+2
+        // stage chunk c+1 behind the first MFMA group, then request chunk c+2. (Interleaving the staging slices between the
+        // MFMA triples at source level was measured: no gain on 128x128, -15% on 64x64 tiles.)
+        if (ks == 0 && k0 + BKT < kend) {
           stage(sA + (cur ^ 1) * BUF_FLOATS, sB + (cur ^ 1) * BUF_FLOATS);
           if (k0 + 2 * BKT < kend) fetch(k0 + 2 * BKT);
         }

@@ -293,8 +293,9 @@ def main():
         except Exception:
             pass
         traffic = None
-        if pmc and pmc.get("shape") == [M, N, K]:     # same launch geometry and memory traffic in both arithmetic modes
-            traffic = pmc["hbm_bytes_per_launch"]
+        ent = (pmc or {}).get("launches", {}).get(f"{M}x{N}x{K}")       # PMC passes are separate runs (profiles/README.md)
+        if ent:
+            traffic = ent["hbm_bytes_per_launch"]
         total_gemm_ms = sum(v["ms"] for v in agg.values()) / nprof
         if kname.startswith("gemm_bf16"):
             peak, peak_note = PEAK_BF16_MFMA_TFLOPS, "dense bf16 MFMA peak"
