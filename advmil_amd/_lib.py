@@ -38,6 +38,7 @@ SIGNATURES = {
     "advmil_set_gemm_mode": (c_int, [c_int]),
     "advmil_get_gemm_mode": (c_int, []),
     "advmil_gemm_f32_plan": (c_int, [c_int64, c_int64, c_int64, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "advmil_gemm_f32_plan_layout": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "advmil_gemm_f32_tiled": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                                       c_int64, ctypes.POINTER(Epilogue), c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "advmil_gemm_bf16_plan": (c_int, [c_int64, c_int64, c_int64, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),

@@ -53,12 +53,12 @@ __device__ __forceinline__ float epilogue_elem(const advmil_epilogue_t& e, float
 }
 
 // ROWS = 64*T rows (m or n) x 32 k per tile; P = ROWS/32 float4 per thread.
-template <bool KC, int ROWS, int BKT>
+template <bool KC, int ROWS, int BKT, int NT>
 __device__ __forceinline__ void load_tile(const float* __restrict__ src, int64_t ld, int64_t row0, int64_t rows,
-                                          int64_t k0, int64_t kend, int tid, float4 (&r)[ROWS * BKT / 1024]) {
+                                          int64_t k0, int64_t kend, int tid, float4 (&r)[ROWS * BKT / (4 * NT)]) {
 #pragma unroll
-  for (int p = 0; p < ROWS * BKT / 1024; ++p) {
-    const int e = p * 256 + tid;
+  for (int p = 0; p < ROWS * BKT / (4 * NT); ++p) {
+    const int e = p * NT + tid;
     if (KC) {   // [row][k]: BKT/4 float4 per row
       const int64_t row = row0 + e / (BKT / 4);
       const int64_t k = k0 + (e % (BKT / 4)) * 4;
@@ -71,11 +71,11 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ src, int64_t
   }
 }
 
-template <bool KC, int ROWS, int BKT>
-__device__ __forceinline__ void store_tile(float* __restrict__ s, int tid, const float4 (&r)[ROWS * BKT / 1024]) {
+template <bool KC, int ROWS, int BKT, int NT>
+__device__ __forceinline__ void store_tile(float* __restrict__ s, int tid, const float4 (&r)[ROWS * BKT / (4 * NT)]) {
 #pragma unroll
-  for (int p = 0; p < ROWS * BKT / 1024; ++p) {
-    const int e = p * 256 + tid;
+  for (int p = 0; p < ROWS * BKT / (4 * NT); ++p) {
+    const int e = p * NT + tid;
     if (KC)
       *reinterpret_cast<float4*>(s + (e / (BKT / 4)) * (BKT + 4) + (e % (BKT / 4)) * 4) = r[p];
     else
@@ -129,13 +129,13 @@ __device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
   lo = make_uint2(l0.u, l1.u);
 }
 
-template <int ROWS, int BKT>
-__device__ __forceinline__ void store_tile_presplit(bf16raw* __restrict__ planes, int tid, const float4 (&r)[ROWS * BKT / 1024]) {
+template <int ROWS, int BKT, int NT>
+__device__ __forceinline__ void store_tile_presplit(bf16raw* __restrict__ planes, int tid, const float4 (&r)[ROWS * BKT / (4 * NT)]) {
   bf16raw* const hiP = planes;
   bf16raw* const loP = planes + ROWS * PITCH_PS(BKT);
 #pragma unroll
-  for (int p = 0; p < ROWS * BKT / 1024; ++p) {
-    const int e = p * 256 + tid;
+  for (int p = 0; p < ROWS * BKT / (4 * NT); ++p) {
+    const int e = p * NT + tid;
     const int row = e / (BKT / 4), p4 = e % (BKT / 4);        // p4: which 4-k piece of the row
     const int off = row * PITCH_PS(BKT) + ps_unit(row, p4 >> 1, BKT / 8) * 8 + (p4 & 1) * 4;
     uint2 h, l;
@@ -166,13 +166,13 @@ __device__ __forceinline__ void read_frag_presplit(const bf16raw* __restrict__ p
 typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4_t;
 #define LDS_AS __attribute__((address_space(3)))
 
-template <int ROWS, int BKT>
-__device__ __forceinline__ void store_tile_presplit_mc(bf16raw* __restrict__ planes, int tid, const float4 (&r)[ROWS * BKT / 1024]) {
+template <int ROWS, int BKT, int NT>
+__device__ __forceinline__ void store_tile_presplit_mc(bf16raw* __restrict__ planes, int tid, const float4 (&r)[ROWS * BKT / (4 * NT)]) {
   bf16raw* const hiP = planes;
   bf16raw* const loP = planes + BKT * PITCH_MC(ROWS);
 #pragma unroll
-  for (int p = 0; p < ROWS * BKT / 1024; ++p) {
-    const int e = p * 256 + tid;
+  for (int p = 0; p < ROWS * BKT / (4 * NT); ++p) {
+    const int e = p * NT + tid;
     const int k = e / (ROWS / 4), m4 = (e % (ROWS / 4)) * 4;
     uint2 h, l;
     split4(r[p], h, l);
@@ -222,21 +222,21 @@ __device__ __forceinline__ void emit_planes4(const advmil_epilogue_t& e, int64_t
 //   weights, or a producing GEMM's epilogue): same bytes from memory, 16-byte pieces straight into LDS, no conversion work at
 //   all. That matters because the bf16x3 loop is instruction-issue bound (PMC: ~255 VALU per 24 MFMA per k-chunk and wave, half
 //   of them this split, repeated by every workgroup that re-reads the element: 3x for X, 1024x for a weight).
-template <bool KC, int ROWS, int BKT, bool PRE>
+template <bool KC, int ROWS, int BKT, bool PRE, int NT>
 struct OperandStage {
-  static constexpr int NF4 = ROWS * BKT / 1024;   // float4 per thread (fp32 source)
-  static constexpr int NP = ROWS * BKT / 2048;    // 16-byte pieces per thread and plane (plane source)
+  static constexpr int NF4 = ROWS * BKT / (4 * NT);   // float4 per thread (fp32 source)
+  static constexpr int NP = ROWS * BKT / (8 * NT);    // 16-byte pieces per thread and plane (plane source)
   float4 f[PRE ? 1 : NF4];
   uint4 ph[PRE ? NP : 1], pl[PRE ? NP : 1];
 
   __device__ __forceinline__ void load(const float* __restrict__ src, const bf16raw* __restrict__ hi, const bf16raw* __restrict__ lo,
                                        int64_t ld, int64_t row0, int64_t rows, int64_t k0, int64_t kend, int tid) {
     if constexpr (!PRE) {
-      load_tile<KC, ROWS, BKT>(src, ld, row0, rows, k0, kend, tid, f);
+      load_tile<KC, ROWS, BKT, NT>(src, ld, row0, rows, k0, kend, tid, f);
     } else {
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        const int e = p * 256 + tid;
+        const int e = p * NT + tid;
         int64_t off;
         bool ok;
         if (KC) {   // [row][k]: BKT/8 pieces per row
@@ -256,12 +256,12 @@ struct OperandStage {
 
   __device__ __forceinline__ void store(bf16raw* __restrict__ planes, int tid) const {
     if constexpr (!PRE) {
-      if (KC) store_tile_presplit<ROWS, BKT>(planes, tid, f);
-      else store_tile_presplit_mc<ROWS, BKT>(planes, tid, f);
+      if (KC) store_tile_presplit<ROWS, BKT, NT>(planes, tid, f);
+      else store_tile_presplit_mc<ROWS, BKT, NT>(planes, tid, f);
     } else {
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        const int e = p * 256 + tid;
+        const int e = p * NT + tid;
         if (KC) {
           const int row = e / (BKT / 8);
           bf16raw* d = planes + row * PITCH_PS(BKT) + ps_unit(row, e % (BKT / 8), BKT / 8) * 8;
@@ -277,9 +277,12 @@ struct OperandStage {
   }
 };
 
-template <bool A_KC, bool B_KC, int TM, int TN, bool SPLIT, int PRE, int BKT>
-__global__ __launch_bounds__(256, (TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(GemmArgs g) {
-  constexpr int BM_ = 64 * TM, BN_ = 64 * TN;
+// WR x WC waves per workgroup (2x2 = the 256-thread tiles; 4x2 = the 512-thread 256x192 / 256x128 tiles of the bf16x3 variant, whose
+// time is set by how many operand bytes a CU pulls through its L1 per flop: ~11 B/clk/CU whatever the inner loop looks like).
+template <bool A_KC, bool B_KC, int TM, int TN, bool SPLIT, int PRE, int BKT, int WR, int WC>
+__global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 || TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(GemmArgs g) {
+  constexpr int NT = 64 * WR * WC;
+  constexpr int BM_ = 32 * TM * WR, BN_ = 32 * TN * WC;
   // BKT = k per chunk, 32 everywhere. Measured alternatives: 64 for the bf16x3 variant (no gain, +60 VGPRs); 64/128 for 64x64
   // tiles on launch-bound shapes (no gain: their cost was an epilogue array in scratch memory, not the K walk).
   constexpr int PITCH = BKT + 4;
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(256, (TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(Ge
   // The exact variant stays single-buffered: there the doubled LDS footprint costs co-resident workgroups and measured slower.
   constexpr int NBUF = SPLIT ? 2 : 1;
   constexpr int BUF_FLOATS = TILEF_A + TILEF_B;
-  constexpr int PATCH_FLOATS = 4 * 32 * PITCH_KC;   // the epilogue's per-wave patches reuse the operand buffers
+  constexpr int PATCH_FLOATS = WR * WC * 32 * PITCH_KC;   // the epilogue's per-wave patches reuse the operand buffers
   __shared__ __attribute__((aligned(16))) float smem[NBUF * BUF_FLOATS > PATCH_FLOATS ? NBUF * BUF_FLOATS : PATCH_FLOATS];
   float* const sA = smem;
   float* const sB = smem + TILEF_A;
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(256, (TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(Ge
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, hi = lane >> 5;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WC, wc = wave % WC;
 
   // XCD-aware tile order. Workgroup b runs on XCD b % 8 (each XCD has a private 4 MB L2), so tiles that share an
   // operand panel are given ids 8 apart: same XCD, dispatched back to back -> the panel is fetched from HBM once and
@@ -342,8 +345,8 @@ __global__ __launch_bounds__(256, (TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(Ge
 
   if constexpr (SPLIT) {
     // ---- bf16x3 main loop, LDS double-buffered; both operands live pre-split (hi/lo bf16 planes) in LDS
-    OperandStage<A_KC, BM_, BKT, (PRE & 1) != 0> ra;
-    OperandStage<B_KC, BN_, BKT, (PRE & 2) != 0> rb;
+    OperandStage<A_KC, BM_, BKT, (PRE & 1) != 0, NT> ra;
+    OperandStage<B_KC, BN_, BKT, (PRE & 2) != 0, NT> rb;
     const bf16raw* const a_hi = reinterpret_cast<const bf16raw*>(g.epi.a_hi) + (int64_t)blockIdx.z * g.sA;
     const bf16raw* const a_lo = reinterpret_cast<const bf16raw*>(g.epi.a_lo) + (int64_t)blockIdx.z * g.sA;
     const bf16raw* const b_hi = reinterpret_cast<const bf16raw*>(g.epi.b_hi) + (int64_t)blockIdx.z * g.sB;
@@ -399,19 +402,19 @@ __global__ __launch_bounds__(256, (TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(Ge
     }
   } else {
     // ---- exact fp32 main loop, single LDS buffer
-    float4 ra[BM_ * BKT / 1024], rb[BN_ * BKT / 1024];
+    float4 ra[BM_ * BKT / (4 * NT)], rb[BN_ * BKT / (4 * NT)];
     if (kbeg < kend) {
-      load_tile<A_KC, BM_, BKT>(g.A, g.lda, m0, g.M, kbeg, kend, tid, ra);
-      load_tile<B_KC, BN_, BKT>(g.B, g.ldb, n0, g.N, kbeg, kend, tid, rb);
+      load_tile<A_KC, BM_, BKT, NT>(g.A, g.lda, m0, g.M, kbeg, kend, tid, ra);
+      load_tile<B_KC, BN_, BKT, NT>(g.B, g.ldb, n0, g.N, kbeg, kend, tid, rb);
     }
     for (int64_t k0 = kbeg; k0 < kend; k0 += BKT) {
       __syncthreads();  // all waves finished reading the previous chunk
-      store_tile<A_KC, BM_, BKT>(sA, tid, ra);
-      store_tile<B_KC, BN_, BKT>(sB, tid, rb);
+      store_tile<A_KC, BM_, BKT, NT>(sA, tid, ra);
+      store_tile<B_KC, BN_, BKT, NT>(sB, tid, rb);
       __syncthreads();
       if (k0 + BKT < kend) {  // prefetch next chunk; lands while the MFMAs below run
-        load_tile<A_KC, BM_, BKT>(g.A, g.lda, m0, g.M, k0 + BKT, kend, tid, ra);
-        load_tile<B_KC, BN_, BKT>(g.B, g.ldb, n0, g.N, k0 + BKT, kend, tid, rb);
+        load_tile<A_KC, BM_, BKT, NT>(g.A, g.lda, m0, g.M, k0 + BKT, kend, tid, ra);
+        load_tile<B_KC, BN_, BKT, NT>(g.B, g.ldb, n0, g.N, k0 + BKT, kend, tid, rb);
       }
 #pragma unroll
       for (int t4 = 0; t4 < BKT / 8; ++t4) {
@@ -553,32 +556,32 @@ extern "C" int advmil_set_gemm_mode(int mode) {
 }
 extern "C" int advmil_get_gemm_mode(void) { return g_gemm_mode; }
 
-template <int TM, int TN, bool SPLIT, int PRE, int BKT>
+template <int TM, int TN, bool SPLIT, int PRE, int WR, int WC>
 static void launch_tile_m(int a_kc, int b_kc, dim3 grid, hipStream_t stream, const GemmArgs& g) {
-  dim3 block(256);
+  dim3 block(64 * WR * WC);
   if (a_kc && b_kc)
-    hipLaunchKernelGGL((gemm_f32_kernel<true, true, TM, TN, SPLIT, PRE, BKT>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<true, true, TM, TN, SPLIT, PRE, 32, WR, WC>), grid, block, 0, stream, g);
   else if (a_kc && !b_kc)
-    hipLaunchKernelGGL((gemm_f32_kernel<true, false, TM, TN, SPLIT, PRE, BKT>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<true, false, TM, TN, SPLIT, PRE, 32, WR, WC>), grid, block, 0, stream, g);
   else if (!a_kc && !b_kc)
-    hipLaunchKernelGGL((gemm_f32_kernel<false, false, TM, TN, SPLIT, PRE, BKT>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<false, false, TM, TN, SPLIT, PRE, 32, WR, WC>), grid, block, 0, stream, g);
   else
-    hipLaunchKernelGGL((gemm_f32_kernel<false, true, TM, TN, SPLIT, PRE, BKT>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<false, true, TM, TN, SPLIT, PRE, 32, WR, WC>), grid, block, 0, stream, g);
 }
 
 // PLANES: this tile is also built for operands that arrive as bf16 planes (the slab-sized contractions only use 22/12/11)
 template <int TM, int TN, bool PLANES>
 static void launch_tile(int a_kc, int b_kc, dim3 grid, hipStream_t stream, const GemmArgs& g, int pre) {
-  if (g_gemm_mode != 1) { launch_tile_m<TM, TN, false, 0, 32>(a_kc, b_kc, grid, stream, g); return; }
+  if (g_gemm_mode != 1) { launch_tile_m<TM, TN, false, 0, 2, 2>(a_kc, b_kc, grid, stream, g); return; }
   if constexpr (PLANES) {
     switch (pre) {
-      case 1: launch_tile_m<TM, TN, true, 1, 32>(a_kc, b_kc, grid, stream, g); return;
-      case 2: launch_tile_m<TM, TN, true, 2, 32>(a_kc, b_kc, grid, stream, g); return;
-      case 3: launch_tile_m<TM, TN, true, 3, 32>(a_kc, b_kc, grid, stream, g); return;
+      case 1: launch_tile_m<TM, TN, true, 1, 2, 2>(a_kc, b_kc, grid, stream, g); return;
+      case 2: launch_tile_m<TM, TN, true, 2, 2, 2>(a_kc, b_kc, grid, stream, g); return;
+      case 3: launch_tile_m<TM, TN, true, 3, 2, 2>(a_kc, b_kc, grid, stream, g); return;
       default: break;
     }
   }
-  launch_tile_m<TM, TN, true, 0, 32>(a_kc, b_kc, grid, stream, g);
+  launch_tile_m<TM, TN, true, 0, 2, 2>(a_kc, b_kc, grid, stream, g);
 }
 
 // Which operands can be taken from caller-provided planes: both planes present, 16-byte aligned, pitch and contiguous extent
@@ -598,7 +601,40 @@ static int64_t n_tiles(int tile, int64_t M, int64_t N) {
 // yields >= 512 workgroups (8k-row bags -> 64x64 / 64x128 tiles at ~95-103 TF; 32k-row bags -> 128x192 at ~122 TF).
 // If even 64x64 tiles are too few and K is deep (the dW = dY^T X contractions, K = bag length), split K so that
 // ~768 workgroups each keep >= 1024 of K (partials reduced by a second launch).
+static int plan_exact(int64_t M, int64_t N, int64_t K, int* tile, int* splits);
+
+// Layout-aware plan. bf16x3 mode adds, from tools/gemm_slab_check.py on the 16 x 8k slab shapes (the swizzled LDS image made the
+// 192-wide tiles fit two workgroups per CU; the 512-thread 256x192 tile stages 42% fewer operand bytes per flop):
+//   N a multiple of 192, slab-sized M:  NT (both k-contiguous) -> 128x192 (gates 419 -> 385 us, embed FC 444 -> 421 us);
+//                                      NN / TN               -> 256x192, 8 waves (dX 341 -> 314 us);
+//   deep-K weight gradients whose [M,N] divides into 256x192 / 192x256 / 128x256 tiles -> that 8-wave tile with one workgroup per CU
+//     (dWab 768x384: 356 -> 245 us).
+extern "C" int advmil_gemm_f32_plan_layout(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, int* tile, int* splits) {
+  if (!tile || !splits || M <= 0 || N <= 0 || K <= 0) return ADVMIL_EINVAL;
+  if (g_gemm_mode == 1 && N % 192 == 0) {
+    if (M >= 16384) {
+      *tile = (a_kc && b_kc) ? 23 : 43;
+      *splits = 1;
+      return ADVMIL_OK;
+    }
+  }
+  if (g_gemm_mode == 1 && K >= 16384 && M < 16384 && !(a_kc && b_kc)) {      // deep-K weight gradients: one wave of 8-wave workgroups
+    const int t8 = (M % 256 == 0 && N % 192 == 0) ? 43 : (M % 192 == 0 && N % 256 == 0) ? 34 : (M % 128 == 0 && N % 256 == 0) ? 24 : 0;
+    if (t8) {
+      const int64_t w = n_tiles(t8, M, N);
+      int64_t sp = 256 / w;                      // one 512-thread workgroup per CU
+      if (sp > K / 1024) sp = K / 1024;
+      if (sp >= 2) { *tile = t8; *splits = (int)sp; return ADVMIL_OK; }
+    }
+  }
+  return plan_exact(M, N, K, tile, splits);
+}
+
 extern "C" int advmil_gemm_f32_plan(int64_t M, int64_t N, int64_t K, int* tile, int* splits) {
+  return advmil_gemm_f32_plan_layout(1, 1, M, N, K, tile, splits);
+}
+
+static int plan_exact(int64_t M, int64_t N, int64_t K, int* tile, int* splits) {
   static const int order[5] = {22, 12, 23, 13, 11};   // 128x192 is never better than 128x128 / 64x128 once M is a slab (tools/gemm_slab_check.py)
   for (int c = 0; c < 5; ++c)
     if (n_tiles(order[c], M, N) >= 512) { *tile = order[c]; *splits = 1; return ADVMIL_OK; }
@@ -646,7 +682,11 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
     if (!ws || ws_bytes < advmil_gemm_f32_workspace_bytes(M, N, splits)) return ADVMIL_EWORKSPACE;
     if ((uintptr_t)ws & 15) return ADVMIL_EINVAL;
   }
-  if (tile == 0) { int t = 0, sp = 0; advmil_gemm_f32_plan(M, N, K, &t, &sp); tile = t; }
+  if (tile == 0) { int t = 0, sp = 0; advmil_gemm_f32_plan_layout(a_kc, b_kc, M, N, K, &t, &sp); tile = t; }
+  if (g_gemm_mode != 1) {                                            // the 512-thread tiles exist for bf16x3 only
+    if (tile / 10 == 4) tile = 20 + tile % 10;
+    else if (tile % 10 == 4) tile = (tile / 10 == 3) ? 23 : 22;
+  }
   const int tm = tile / 10, tn = tile % 10;
   g.mtiles = (int)((M + 64 * tm - 1) / (64 * tm));
   const int ntiles = (int)((N + 64 * tn - 1) / (64 * tn));
@@ -665,6 +705,10 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
     case 13: launch_tile<1, 3, false>(a_kc, b_kc, grid, stream, g, pre); break;
     case 12: launch_tile<1, 2, true>(a_kc, b_kc, grid, stream, g, pre); break;
     case 11: launch_tile<1, 1, true>(a_kc, b_kc, grid, stream, g, pre); break;
+    case 43: launch_tile_m<2, 3, true, 0, 4, 2>(a_kc, b_kc, grid, stream, g); break;   // 256x192, 8 waves
+    case 42: launch_tile_m<2, 2, true, 0, 4, 2>(a_kc, b_kc, grid, stream, g); break;   // 256x128, 8 waves
+    case 34: launch_tile_m<3, 2, true, 0, 2, 4>(a_kc, b_kc, grid, stream, g); break;   // 192x256, 8 waves (2 x 4)
+    case 24: launch_tile_m<2, 2, true, 0, 2, 4>(a_kc, b_kc, grid, stream, g); break;   // 128x256, 8 waves (2 x 4)
     default: return ADVMIL_EINVAL;
   }
   ADVMIL_LAUNCH_CHECK();

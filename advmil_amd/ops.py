@@ -109,12 +109,13 @@ def get_gemm_mode():
     return "bf16x3" if _lib.lib().advmil_get_gemm_mode() == 1 else "exact"
 
 
-def gemm_plan(M, N, K):
-    """(tile, splits) from the library's launch plan (advmil_gemm_f32_plan)."""
-    key = (M, N, K)
+def gemm_plan(M, N, K, a_kc=True, b_kc=True):
+    """(tile, splits) from the library's launch plan (advmil_gemm_f32_plan_layout); depends on the arithmetic mode."""
+    key = (M, N, K, bool(a_kc), bool(b_kc), _lib.lib().advmil_get_gemm_mode())
     if key not in _PLAN_CACHE:
         t, sp = ctypes.c_int(0), ctypes.c_int(0)
-        _lib.check(_lib.lib().advmil_gemm_f32_plan(M, N, K, ctypes.byref(t), ctypes.byref(sp)), "gemm_plan")
+        _lib.check(_lib.lib().advmil_gemm_f32_plan_layout(1 if a_kc else 0, 1 if b_kc else 0, M, N, K, ctypes.byref(t),
+                                                          ctypes.byref(sp)), "gemm_plan")
         _PLAN_CACHE[key] = (t.value, sp.value)
     return _PLAN_CACHE[key]
 
@@ -191,7 +192,7 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
     if c_planes is not None:
         e.c_hi, e.c_lo = c_planes.hi.data_ptr(), c_planes.lo.data_ptr()
     if splits is None:
-        ptile, splits = gemm_plan(M, N, K)
+        ptile, splits = gemm_plan(M, N, K, a_kc, b_kc)
         if tile == 0:
             tile = ptile
     L = _lib.lib()

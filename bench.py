@@ -260,7 +260,8 @@ def main():
         agg = {}
         for name, shape, flops, e0, e1 in prof:
             M, N, K, sp = shape
-            tile, _ = ops.gemm_plan(M, N, K)
+            lay = name.split("<")[1].rstrip(">").split(",")
+            tile, _ = ops.gemm_plan(M, N, K, lay[0] == "1", lay[1] == "1")
             key = (f"{name[:-1]},{tile // 10},{tile % 10}>", shape)
             a = agg.setdefault(key, {"ms": 0.0, "n": 0, "flops": flops})
             a["ms"] += e0.elapsed_time(e1); a["n"] += 1

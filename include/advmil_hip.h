@@ -88,8 +88,12 @@ int advmil_get_gemm_mode(void);
 /* The library's launch plan for a shape: block tile (see below) and K split count. Host callers size the workspace
  * from `splits` (advmil_gemm_f32_workspace_bytes) and pass both to advmil_gemm_f32_tiled. */
 int advmil_gemm_f32_plan(int64_t M, int64_t N, int64_t K, int* tile, int* splits);
+/* Same, knowing the operand layouts (the best tile differs between the NT forward form and the NN / TN backward forms; this is what
+ * advmil_gemm_f32 itself uses). advmil_gemm_f32_plan is the a_kc = b_kc = 1 case. */
+int advmil_gemm_f32_plan_layout(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, int* tile, int* splits);
 /* Same, with an explicit block tile: tile = 10*TM + TN selects (64*TM) x (64*TN) output tiles
- * (22 = 128x128, 23 = 128x192, 13 = 64x192, 12 = 64x128, 11 = 64x64); 0 = the plan's choice (what advmil_gemm_f32 uses). */
+ * (22 = 128x128, 23 = 128x192, 13 = 64x192, 12 = 64x128, 11 = 64x64; 43 = 256x192, 42 = 256x128, 34 = 192x256, 24 = 128x256 with 512 threads,
+ * bf16x3 mode only -- in exact mode they fall back to 23 / 22); 0 = the plan's choice (what advmil_gemm_f32 uses). */
 int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                           const float* B, int64_t ldb, float* C, int64_t ldc, const advmil_epilogue_t* epi,
                           int splits, int tile, void* ws, size_t ws_bytes, advmil_stream_t stream);

@@ -295,3 +295,27 @@ def test_gemm_planes_bit_identical_to_on_the_fly_split(ops, a_kc, b_kc, shape):
         assert torch.equal(cp.hi, g2.to(torch.bfloat16))
     finally:
         ops.set_gemm_mode(prev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, False), (False, True)])
+@pytest.mark.parametrize("tile", [43, 42, 34, 24])
+def test_gemm_bf16x3_eight_wave_tiles(ops, a_kc, b_kc, tile):
+    """The 512-thread 256x192 / 256x128 tiles of the bf16x3 variant: same arithmetic as the 128x128 tile (bit-identical: each
+    output element sees the same products in the same k order), ragged edges included."""
+    prev = ops.get_gemm_mode()
+    ops.set_gemm_mode("bf16x3")
+    try:
+        g = torch.Generator(device="cuda").manual_seed(11)
+        for M, N, K in [(1000, 392, 264), (256, 192, 64), (520, 200, 1032)]:
+            A = torch.randn((M, K) if a_kc else (K, M), device="cuda", generator=g)
+            B = torch.randn((N, K) if b_kc else (K, N), device="cuda", generator=g)
+            bias = torch.randn(N, device="cuda", generator=g)
+            ref = ops.gemm(A, B, a_kc, b_kc, M, N, K, bias=bias, act0=1, tile=22)
+            got = ops.gemm(A, B, a_kc, b_kc, M, N, K, bias=bias, act0=1, tile=tile)
+            assert torch.equal(got, ref), (M, N, K, float((got - ref).abs().max()))
+            r2 = ops.gemm(A, B, a_kc, b_kc, M, N, K, splits=3, tile=22)
+            g2 = ops.gemm(A, B, a_kc, b_kc, M, N, K, splits=3, tile=tile)
+            assert torch.equal(g2, r2)
+    finally:
+        ops.set_gemm_mode(prev)

@@ -8,7 +8,7 @@ for (name, M, N, K, akc, bkc) in (("embedG", 131072, 384, 1024, 1, 1), ("gates",
     A = torch.randn((M, K) if akc else (K, M), device="cuda"); B = torch.randn((N, K) if bkc else (K, N), device="cuda")
     out = torch.empty(M, N, device="cuda")
     rows = []
-    for tile in (23, 22, 13, 12, 11):
+    for tile in ((43, 42, 23, 22, 13, 12, 11) if ops.get_gemm_mode() == "bf16x3" else (23, 22, 13, 12, 11)):
         for sp in ([1] if M > 4096 else [16, 32, 64]):
             for _ in range(2): ops.gemm(A, B, akc, bkc, M, N, K, out=out, splits=sp, tile=tile)
             torch.cuda.synchronize()
@@ -19,4 +19,4 @@ for (name, M, N, K, akc, bkc) in (("embedG", 131072, 384, 1024, 1, 1), ("gates",
             us = e0.elapsed_time(e1) * 100
             rows.append((us, tile, sp))
     rows.sort()
-    print(f"{name:7s} plan={ops.gemm_plan(M, N, K)} " + "  ".join(f"t{t}/s{sp} {us:.0f}us {2.0*M*N*K/us/1e6:.0f}TF" for us, t, sp in rows[:6]), flush=True)
+    print(f"{name:7s} plan={ops.gemm_plan(M, N, K, akc, bkc)} " + "  ".join(f"t{t}/s{sp} {us:.0f}us {2.0*M*N*K/us/1e6:.0f}TF" for us, t, sp in rows[:6]), flush=True)
