@@ -230,6 +230,7 @@ class MyHandler(object):
         real_idx = torch.tensor([i for i in range(n) if is_real[i]], dtype=torch.long, device=self.device)
         seg = ops.Segments([self._rows(x[0]) for x in xs], self.device)
         seg16 = seg.div(16)                              # D's region embedding needs N % 16 == 0 (backbone_utils.py:65)
+        seg16.twice()                                    # (built here: the D update stacks its fake and real passes)
         return SimpleNamespace(vis=vis, is_real=is_real, n_real=n_real, n_fake=n_fake, n_vis=n_vis, vis_mask=vis_mask,
                                real_idx=real_idx, seg=seg, seg16=seg16)
 
@@ -302,13 +303,19 @@ class MyHandler(object):
         finally:
             ops.MEMO.end()
         emb = self.netD.embed_rows(X)                                          # shared by the real and the fake pairs
-        eb, im = self.netD.bag_features_multi(emb, plan.seg16)
-        f_fake = self.netD.tail(eb, im, pred).view(-1)
         f_real = None
-        if any(plan.is_real):                                                  # own dropout draw, as a separate forward has
-            eb_r, im_r = self.netD.bag_features_multi(emb, plan.seg16)
-            sel = plan.real_idx
-            f_real = self.netD.tail(eb_r[sel], None if im_r is None else im_r[sel], y[sel, 0:1]).view(-1)
+        if any(plan.is_real):
+            # The fake pairs (all bags) and the real pairs go through the region-level network and the tail as ONE stacked batch:
+            # rows [0, L) are the fake pass, rows [L, 2L) the real pass (its own dropout draw, as a separate forward has, because
+            # the draw is indexed by row). Every kernel of the tail -- ~120 launches per pass -- runs once instead of twice; real
+            # scores of bags without a visible event are computed and dropped (B rows of [B,d] work).
+            nb = len(xs)
+            eb2, im2 = self.netD.bag_features_multi(torch.cat([emb, emb], dim=0), plan.seg16.twice())
+            f2 = self.netD.tail(eb2, im2, torch.cat([pred, y[:, 0:1]], dim=0)).view(-1)
+            f_fake, f_real = f2[:nb], f2[nb:][plan.real_idx]
+        else:
+            eb, im = self.netD.bag_features_multi(emb, plan.seg16)
+            f_fake = self.netD.tail(eb, im, pred).view(-1)
         tr, tf = real_fake_terms(f_real, f_fake, self.which_loss)
         loss = tf.sum() / plan.n_fake
         s_real = torch.zeros((), device=dev)

@@ -245,6 +245,12 @@ class Segments:
             self._div[k] = Segments([v // k for v in self.lens], self.device)
         return self._div[k]
 
+    def twice(self):
+        """The partition of two copies of the slab stacked on top of each other (2 * nseg segments)."""
+        if "x2" not in self._div:
+            self._div["x2"] = Segments(self.lens + self.lens, self.device)
+        return self._div["x2"]
+
     def uniform(self, rows):
         """nseg segments of `rows` rows each (e.g. the 8 cluster rows of every bag)."""
         key = ("u", rows)
