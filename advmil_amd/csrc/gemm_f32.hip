@@ -526,8 +526,18 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g) {
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t m = idx / n4, n = (idx % n4) * 4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int z = 0; z < g.splits; ++z) {
-      const float4 p = *reinterpret_cast<const float4*>(g.ws + ((int64_t)z * g.M + m) * g.N + n);
+    const float* wp = g.ws + m * g.N + n;
+    const int64_t zs = g.M * g.N;
+    int z = 0;
+    for (; z + 8 <= g.splits; z += 8) {          // 8 partial loads in flight (the walk over 32-96 splits is latency-bound)
+      float4 p[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) p[u] = *reinterpret_cast<const float4*>(wp + (int64_t)(z + u) * zs);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s.x += p[u].x; s.y += p[u].y; s.z += p[u].z; s.w += p[u].w; }
+    }
+    for (; z < g.splits; ++z) {
+      const float4 p = *reinterpret_cast<const float4*>(wp + (int64_t)z * zs);
       s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
     }
     float v[4] = {s.x, s.y, s.z, s.w};

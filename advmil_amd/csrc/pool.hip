@@ -48,8 +48,8 @@ __device__ __forceinline__ float4 reduce_rows(float4 v, const RowColMap& m, floa
   return s;
 }
 
-// out[c] = sum_b partial[b*stride + c].  16 columns x 16 row-lanes per workgroup: every lane keeps 4 independent
-// loads in flight and the 16 row-lanes are folded through LDS, so the serial depth is nblk/64 (was nblk).
+// out[c] = sum_b partial[b*stride + c].  16 columns x 16 row-lanes per workgroup: every lane keeps 16 independent
+// loads in flight and the 16 row-lanes are folded through LDS, so the serial depth is nblk/256 (was nblk).
 __global__ __launch_bounds__(256) void colsum_merge_kernel(const float* __restrict__ partial, int nblk, int64_t stride,
                                                            int64_t ncols, float* __restrict__ out, int accumulate,
                                                            int64_t seg_pstride = 0, int64_t seg_ostride = 0) {
@@ -58,18 +58,24 @@ __global__ __launch_bounds__(256) void colsum_merge_kernel(const float* __restri
   out += (int64_t)blockIdx.y * seg_ostride;
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int64_t c = (int64_t)blockIdx.x * 16 + cl;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  // 16 independent loads in flight per lane: the walk is latency-bound (a slab leaves up to 1024 partial rows, i.e. 64 per
+  // row-lane; with 4 in flight the merge took 8-9 us, 24 times per step)
+  float sv[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) sv[u] = 0.f;
   if (c < ncols) {
     int b = rl;
-    for (; b + 48 < nblk; b += 64) {
-      s0 += partial[(int64_t)b * stride + c];
-      s1 += partial[(int64_t)(b + 16) * stride + c];
-      s2 += partial[(int64_t)(b + 32) * stride + c];
-      s3 += partial[(int64_t)(b + 48) * stride + c];
+    for (; b + 240 < nblk; b += 256) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) sv[u] += partial[(int64_t)(b + 16 * u) * stride + c];
     }
-    for (; b < nblk; b += 16) s0 += partial[(int64_t)b * stride + c];
+    for (; b < nblk; b += 16) sv[0] += partial[(int64_t)b * stride + c];
   }
-  red[rl][cl] = (s0 + s1) + (s2 + s3);
+#pragma unroll
+  for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+    for (int u = 0; u < w; ++u) sv[u] += sv[u + w];
+  red[rl][cl] = sv[0];
   __syncthreads();
   if (rl == 0 && c < ncols) {
     float t = 0.f;
