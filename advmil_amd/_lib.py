@@ -48,6 +48,9 @@ SIGNATURES = {
     "advmil_cast_bf16": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "advmil_gemm_f32_batched": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                                         c_int64, c_void_p, c_int64, c_int64, c_int, c_float, c_int, c_void_p]),
+    "advmil_gemm_f32_batched2": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p,
+                                         c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_float,
+                                         c_int, c_void_p]),
     "advmil_softmax_rows_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_float, c_void_p,
                                         c_uint64, c_void_p]),
     "advmil_softmax_rows_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_float, c_void_p,

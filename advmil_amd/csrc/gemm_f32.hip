@@ -38,6 +38,8 @@ struct GemmArgs {
   int splits;
   int mtiles, ntiles;
   int64_t sA, sB, sC;   // per-batch element strides (gridDim.z = batch)
+  int nb1;              // inner batch count: z = z2 * nb1 + z1 uses z1 * s? + z2 * s?2 (heads inside bags)
+  int64_t sA2, sB2, sC2;
   advmil_epilogue_t epi;
 };
 
@@ -329,9 +331,12 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 || TM * TN > 4 ? 1 : 2))
   }
   const int64_t m0 = (int64_t)mt_i * BM_, n0 = (int64_t)nt_i * BN_;
   const int z = blockIdx.y;
-  g.A += (int64_t)blockIdx.z * g.sA;   // batched heads: plain pointer offsets
-  g.B += (int64_t)blockIdx.z * g.sB;
-  g.C += (int64_t)blockIdx.z * g.sC;
+  {                                     // batched heads (and bags): plain pointer offsets
+    const int z1 = (int)blockIdx.z % g.nb1, z2 = (int)blockIdx.z / g.nb1;
+    g.A += (int64_t)z1 * g.sA + (int64_t)z2 * g.sA2;
+    g.B += (int64_t)z1 * g.sB + (int64_t)z2 * g.sB2;
+    g.C += (int64_t)z1 * g.sC + (int64_t)z2 * g.sC2;
+  }
   const int64_t kbeg = (int64_t)z * g.k_chunk;
   const int64_t kend = (kbeg + g.k_chunk < g.K) ? kbeg + g.k_chunk : g.K;
 
@@ -687,7 +692,7 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
   g.splits = splits;
   g.ws = (float*)ws;
   g.epi = *epi;
-  g.sA = g.sB = g.sC = 0;
+  g.sA = g.sB = g.sC = 0; g.nb1 = 1; g.sA2 = g.sB2 = g.sC2 = 0;
   if (splits > 1) {
     if (!ws || ws_bytes < advmil_gemm_f32_workspace_bytes(M, N, splits)) return ADVMIL_EWORKSPACE;
     if ((uintptr_t)ws & 15) return ADVMIL_EINVAL;
@@ -738,14 +743,16 @@ extern "C" int advmil_gemm_f32(int a_kc, int b_kc, int64_t M, int64_t N, int64_t
   return advmil_gemm_f32_tiled(a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, epi, splits, 0, ws, ws_bytes, stream);
 }
 
-// Batched form (gridDim.z = batch): operand/result pointers advance by element strides per batch. Used for the ESAT
-// attention heads, which are strided slices of the packed qkv[L, 3d] and of O[L, d] -- no gather/permute copies.
-extern "C" int advmil_gemm_f32_batched(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
-                                       int64_t strideA, const float* B, int64_t ldb, int64_t strideB, float* C, int64_t ldc,
-                                       int64_t strideC, int batch, float alpha, int accumulate, advmil_stream_t stream_) {
+// Batched form (gridDim.z = batch * batch2): operand/result pointers advance by element strides per inner batch (attention
+// head) and per outer batch (bag). The heads are strided slices of the packed qkv[L, 3d] and of O[L, d], the bags are row blocks
+// of the slab -- no gather/permute copies, one launch per attention stage for all equal-length bags of a step.
+extern "C" int advmil_gemm_f32_batched2(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                                        int64_t strideA, int64_t strideA2, const float* B, int64_t ldb, int64_t strideB,
+                                        int64_t strideB2, float* C, int64_t ldc, int64_t strideC, int64_t strideC2, int batch,
+                                        int batch2, float alpha, int accumulate, advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return ADVMIL_EINVAL;
-  if ((lda & 3) || (ldb & 3) || (strideA & 3) || (strideB & 3)) return ADVMIL_EINVAL;
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch2 <= 0 || (int64_t)batch * batch2 > 65535) return ADVMIL_EINVAL;
+  if ((lda & 3) || (ldb & 3) || (strideA & 3) || (strideB & 3) || (strideA2 & 3) || (strideB2 & 3)) return ADVMIL_EINVAL;
   if (a_kc ? (K & 3) : (M & 3)) return ADVMIL_EINVAL;
   if (b_kc ? (K & 3) : (N & 3)) return ADVMIL_EINVAL;
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return ADVMIL_EINVAL;
@@ -754,21 +761,28 @@ extern "C" int advmil_gemm_f32_batched(int a_kc, int b_kc, int64_t M, int64_t N,
   g.k_chunk = ((K + BK - 1) / BK) * BK;
   g.splits = 1; g.ws = nullptr;
   g.sA = strideA; g.sB = strideB; g.sC = strideC;
+  g.nb1 = batch; g.sA2 = strideA2; g.sB2 = strideB2; g.sC2 = strideC2;
   advmil_epilogue_t e = {};      // every optional field (planes included) off
-  e.bias = nullptr; e.act0 = e.act1 = ACT_NONE; e.act_split = 1 << 30; e.drop_p = 0.f; e.seed = nullptr; e.stream_id = 0;
-  e.rowv = e.colv = e.maskref = nullptr; e.rowseg = nullptr; e.ldmask = 0; e.mask_scale = 1.f; e.accumulate = accumulate; e.alpha = alpha;
+  e.act0 = e.act1 = ACT_NONE; e.act_split = 1 << 30; e.mask_scale = 1.f; e.accumulate = accumulate; e.alpha = alpha;
   g.epi = e;
-  // small per-head problems: 64x64 tiles unless one head alone already fills the chip with 64x128
-  const int tile = (n_tiles(12, M, N) * batch >= 512) ? 12 : 11;
+  // small per-head problems: 64x64 tiles unless the batch already fills the chip with 64x128
+  const int tile = (n_tiles(12, M, N) * batch * batch2 >= 512) ? 12 : 11;
   const int tm = tile / 10, tn = tile % 10;
   g.mtiles = (int)((M + 64 * tm - 1) / (64 * tm));
   const int ntiles = (int)((N + 64 * tn - 1) / (64 * tn));
   g.ntiles = ntiles;
-  dim3 grid(g.mtiles * ntiles, 1, batch);
+  dim3 grid(g.mtiles * ntiles, 1, batch * batch2);
   if (tile == 12) launch_tile<1, 2, false>(a_kc, b_kc, grid, stream, g, 0);
   else launch_tile<1, 1, false>(a_kc, b_kc, grid, stream, g, 0);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
+}
+
+extern "C" int advmil_gemm_f32_batched(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                                       int64_t strideA, const float* B, int64_t ldb, int64_t strideB, float* C, int64_t ldc,
+                                       int64_t strideC, int batch, float alpha, int accumulate, advmil_stream_t stream_) {
+  return advmil_gemm_f32_batched2(a_kc, b_kc, M, N, K, A, lda, strideA, 0, B, ldb, strideB, 0, C, ldc, strideC, 0, batch, 1, alpha,
+                                  accumulate, stream_);
 }
 
 // ---- fp32 matrix -> bf16 planes (hi = bf16(x), lo = bf16(x - hi)); the same rounding the staging path applies on the fly

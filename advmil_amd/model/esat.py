@@ -38,6 +38,8 @@ class HipTransformerEncoderLayer(nn.Module):
         p_att = sa.dropout if tr else 0.0
         if seg is None:
             o = ops.mha(qkv, self.nhead, p_att, rng)
+        elif len(set(seg.lens)) == 1 and seg.lens[0] % 4 == 0:     # equal-length bags: every attention stage is ONE launch
+            o = ops.mha(qkv, self.nhead, p_att, rng, bags=seg.nseg)
         else:
             o = torch.cat([ops.mha(qkv[seg.offsets[b]:seg.offsets[b + 1]], self.nhead, p_att, rng) for b in range(seg.nseg)], dim=0)
         o = ops.linear_act(o, sa.out_proj.weight, sa.out_proj.bias, "none")

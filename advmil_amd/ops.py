@@ -656,10 +656,12 @@ def gate_scores(h, Wa, ba, Wb, bb, wc, bc, p=0.0, rng=None, tag=""):
     return GateScoreFn.apply(h, Wa, ba, Wb, bb, wc, bc, float(p), seed, sa, sb)
 
 
-def gemm_batched(A, B, a_kc, b_kc, M, N, K, lda, sA, ldb, sB, C, ldc, sC, batch, alpha=1.0, accumulate=False):
-    _lib.check(_lib.lib().advmil_gemm_f32_batched(1 if a_kc else 0, 1 if b_kc else 0, M, N, K, _p(A), lda, sA, _p(B), ldb, sB,
-                                                  _p(C), ldc, sC, batch, float(alpha), 1 if accumulate else 0, _stream()),
-               f"gemm_f32_batched[{batch}x{M}x{N}x{K}]")
+def gemm_batched(A, B, a_kc, b_kc, M, N, K, lda, sA, ldb, sB, C, ldc, sC, batch, alpha=1.0, accumulate=False, batch2=1,
+                 sA2=0, sB2=0, sC2=0):
+    """batch (heads) x batch2 (equal-length bags) strided contractions in one launch."""
+    _lib.check(_lib.lib().advmil_gemm_f32_batched2(1 if a_kc else 0, 1 if b_kc else 0, M, N, K, _p(A), lda, sA, sA2, _p(B), ldb, sB,
+                                                   sB2, _p(C), ldc, sC, sC2, batch, batch2, float(alpha), 1 if accumulate else 0,
+                                                   _stream()), f"gemm_f32_batched[{batch2}x{batch}x{M}x{N}x{K}]")
     return C
 
 
@@ -669,64 +671,74 @@ def _off(t, n):
 
 
 class MhaFn(torch.autograd.Function):
-    """Self-attention core of the ESAT layer for one bag: packed qkv[L, 3d] -> O[L, d].
-    Per head h (strided slices, no permute copies):  S_h = Q_h K_h^T / sqrt(hd)  (batched MFMA GEMM)
-      -> P = dropout(softmax(S)) (row kernel, counter RNG index (h*L + i)*L + j) -> O_h = P_h V_h (batched MFMA GEMM,
-      written straight into O[:, h*hd:(h+1)*hd]).  Backward = four more batched GEMMs + one row kernel.
-    The token axis is padded to a multiple of 4 (16 B operand alignment); padded keys get probability 0."""
+    """Self-attention core of the ESAT layer: packed qkv[G*L, 3d] of G equal-length bags -> O[G*L, d]; attention never crosses
+    a bag. Per bag g and head h (strided slices, no permute copies):  S = Q K^T / sqrt(hd)  (one batched MFMA GEMM launch over
+    all G*nhead pairs) -> P = dropout(softmax(S)) (row kernel, counter RNG index ((g*nhead + h)*L + i)*L + j) -> O = P V
+    (batched GEMM, written straight into O[:, h*hd:(h+1)*hd]).  Backward = four more batched GEMMs + one row kernel.
+    The token axis is padded to a multiple of 4 (16 B operand alignment) when G == 1; padded keys get probability 0."""
 
     @staticmethod
-    def forward(ctx, qkv, nhead, p, seed, sid):
+    def forward(ctx, qkv, nhead, p, seed, sid, G):
         _chk(qkv, "qkv")
-        L, d3 = qkv.shape
+        L, d3 = qkv.shape[0] // G, qkv.shape[1]
         Lp = (L + 3) // 4 * 4
+        assert G == 1 or Lp == L
         qkv = qkv.contiguous() if Lp == L else torch.nn.functional.pad(qkv, (0, 0, 0, Lp - L)).contiguous()
         d = d3 // 3
         hd = d // nhead
         dev = qkv.device
         scale = 1.0 / float(hd) ** 0.5
-        S = torch.empty(nhead, Lp, Lp, dtype=torch.float32, device=dev)
-        gemm_batched(qkv, _off(qkv, d), True, True, Lp, Lp, hd, d3, hd, d3, hd, S, Lp, Lp * Lp, nhead, alpha=scale)
+        S = torch.empty(G * nhead, Lp, Lp, dtype=torch.float32, device=dev)
+        LL, bag = Lp * Lp, Lp * d3
+        gemm_batched(qkv, _off(qkv, d), True, True, Lp, Lp, hd, d3, hd, d3, hd, S, Lp, LL, nhead, alpha=scale, batch2=G,
+                     sA2=bag, sB2=bag, sC2=nhead * LL)
         P = torch.empty_like(S)
         Pd = torch.empty_like(S) if p > 0.0 else None
-        _lib.check(_lib.lib().advmil_softmax_rows_fwd(_p(S), _p(P), _p(Pd), nhead * Lp, Lp, L, Lp, p,
+        _lib.check(_lib.lib().advmil_softmax_rows_fwd(_p(S), _p(P), _p(Pd), G * nhead * Lp, Lp, L, Lp, p,
                                                       _p(seed if p > 0.0 else None), sid, _stream()), "softmax_rows_fwd")
-        O = torch.empty(Lp, d, dtype=torch.float32, device=dev)
-        gemm_batched(Pd if Pd is not None else P, _off(qkv, 2 * d), True, False, Lp, hd, Lp, Lp, Lp * Lp, d3, hd, O, d, hd, nhead)
+        O = torch.empty(G * Lp, d, dtype=torch.float32, device=dev)
+        gemm_batched(Pd if Pd is not None else P, _off(qkv, 2 * d), True, False, Lp, hd, Lp, Lp, LL, d3, hd, O, d, hd, nhead,
+                     batch2=G, sA2=nhead * LL, sB2=bag, sC2=Lp * d)
         ctx.save_for_backward(qkv, P, Pd if Pd is not None else P)
-        ctx.cfg = (nhead, p, seed, sid, L, Lp, d, hd, scale)
-        return O[:L]
+        ctx.cfg = (nhead, p, seed, sid, L, Lp, d, hd, scale, G)
+        return O[:L] if G == 1 else O
 
     @staticmethod
     def backward(ctx, dO):
         qkv, P, Pd = ctx.saved_tensors
-        nhead, p, seed, sid, L, Lp, d, hd, scale = ctx.cfg
+        nhead, p, seed, sid, L, Lp, d, hd, scale, G = ctx.cfg
         d3 = 3 * d
         dev = qkv.device
         dO = dO.contiguous() if Lp == L else torch.nn.functional.pad(dO, (0, 0, 0, Lp - L)).contiguous()
-        dqkv = torch.empty(Lp, d3, dtype=torch.float32, device=dev)
-        # dPd_h = dO_h V_h^T            [L, L]  (A = dO_h [L,hd] k-contig, B = V_h [L,hd] k-contig)
-        dPd = torch.empty(nhead, Lp, Lp, dtype=torch.float32, device=dev)
-        gemm_batched(dO, _off(qkv, 2 * d), True, True, Lp, Lp, hd, d, hd, d3, hd, dPd, Lp, Lp * Lp, nhead)
-        # dV_h = Pd_h^T dO_h            [L, hd] (A = Pd_h [K=L, M=L] m-contig, B = dO_h [K=L, N=hd] n-contig)
-        gemm_batched(Pd, dO, False, False, Lp, hd, Lp, Lp, Lp * Lp, d, hd, _off(dqkv, 2 * d), d3, hd, nhead)
+        dqkv = torch.empty(G * Lp, d3, dtype=torch.float32, device=dev)
+        LL, bag, hb = Lp * Lp, Lp * d3, nhead * Lp * Lp
+        # dPd = dO V^T                 [L, L]  (A = dO_h [L,hd] k-contig, B = V_h [L,hd] k-contig)
+        dPd = torch.empty(G * nhead, Lp, Lp, dtype=torch.float32, device=dev)
+        gemm_batched(dO, _off(qkv, 2 * d), True, True, Lp, Lp, hd, d, hd, d3, hd, dPd, Lp, LL, nhead, batch2=G, sA2=Lp * d, sB2=bag,
+                     sC2=hb)
+        # dV = Pd^T dO                 [L, hd] (A = Pd_h [K=L, M=L] m-contig, B = dO_h [K=L, N=hd] n-contig)
+        gemm_batched(Pd, dO, False, False, Lp, hd, Lp, Lp, LL, d, hd, _off(dqkv, 2 * d), d3, hd, nhead, batch2=G, sA2=hb, sB2=Lp * d,
+                     sC2=bag)
         dS = torch.empty_like(dPd)
-        _lib.check(_lib.lib().advmil_softmax_rows_bwd(_p(P), _p(dPd), _p(dS), nhead * Lp, Lp, L, Lp, p,
+        _lib.check(_lib.lib().advmil_softmax_rows_bwd(_p(P), _p(dPd), _p(dS), G * nhead * Lp, Lp, L, Lp, p,
                                                       _p(seed if p > 0.0 else None), sid, _stream()), "softmax_rows_bwd")
-        # dQ_h = scale * dS_h K_h       (A = dS_h [L, L] k-contig, B = K_h [K=L, N=hd] n-contig)
-        gemm_batched(dS, _off(qkv, d), True, False, Lp, hd, Lp, Lp, Lp * Lp, d3, hd, dqkv, d3, hd, nhead, alpha=scale)
-        # dK_h = scale * dS_h^T Q_h     (A = dS_h [K=L, M=L] m-contig, B = Q_h [K=L, N=hd] n-contig)
-        gemm_batched(dS, qkv, False, False, Lp, hd, Lp, Lp, Lp * Lp, d3, hd, _off(dqkv, d), d3, hd, nhead, alpha=scale)
-        return dqkv[:L], None, None, None, None
+        # dQ = scale * dS K            (A = dS_h [L, L] k-contig, B = K_h [K=L, N=hd] n-contig)
+        gemm_batched(dS, _off(qkv, d), True, False, Lp, hd, Lp, Lp, LL, d3, hd, dqkv, d3, hd, nhead, alpha=scale, batch2=G, sA2=hb,
+                     sB2=bag, sC2=bag)
+        # dK = scale * dS^T Q          (A = dS_h [K=L, M=L] m-contig, B = Q_h [K=L, N=hd] n-contig)
+        gemm_batched(dS, qkv, False, False, Lp, hd, Lp, Lp, LL, d3, hd, _off(dqkv, d), d3, hd, nhead, alpha=scale, batch2=G, sA2=hb,
+                     sB2=bag, sC2=bag)
+        return (dqkv[:L] if G == 1 else dqkv), None, None, None, None, None
 
 
-def mha(qkv, nhead, p=0.0, rng=None):
+def mha(qkv, nhead, p=0.0, rng=None, bags=1):
+    """qkv[bags*L, 3d]: `bags` equal-length bags stacked by rows (L a multiple of 4 when bags > 1)."""
     sid, seed = 0, None
     if p > 0.0:
         rng = rng or default_rng(qkv.device)
-        L = qkv.shape[0]
-        sid, seed = rng.site("mha_attn", (nhead, L, L), p), rng.seed
-    return MhaFn.apply(qkv, nhead, float(p), seed, sid)
+        L = qkv.shape[0] // bags
+        sid, seed = rng.site("mha_attn", (bags * nhead, L, L) if bags > 1 else (nhead, L, L), p), rng.seed
+    return MhaFn.apply(qkv, nhead, float(p), seed, sid, bags)
 
 
 class SegMeanFn(torch.autograd.Function):

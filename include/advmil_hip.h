@@ -120,6 +120,12 @@ int advmil_cast_bf16(const float* src, int64_t ld_src, int64_t R, int64_t C, voi
 int advmil_gemm_f32_batched(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                             int64_t strideA, const float* B, int64_t ldb, int64_t strideB, float* C, int64_t ldc,
                             int64_t strideC, int batch, float alpha, int accumulate, advmil_stream_t stream);
+/* Two batch levels: z = z2*batch + z1 uses X + z1*strideX + z2*strideX2 -- z1 the attention head, z2 the bag of a step slab whose
+ * bags have equal length (the reference loops over bags, one nn.MultiheadAttention call each: model_handler.py:352, batch_size 1). */
+int advmil_gemm_f32_batched2(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t strideA,
+                             int64_t strideA2, const float* B, int64_t ldb, int64_t strideB, int64_t strideB2, float* C,
+                             int64_t ldc, int64_t strideC, int64_t strideC2, int batch, int batch2, float alpha, int accumulate,
+                             advmil_stream_t stream);
 /* Row softmax of the attention scores S[R,C] with dropout on the probabilities: P = softmax(S) (kept for backward),
  * Pd = P*keep (NULL = eval). bwd: dS = P * (dPd*keep - sum_j dPd_j*keep_j*P_j).
  * C = row pitch, Cv <= C = number of real keys (columns >= Cv are alignment padding and get probability 0),
