@@ -25,7 +25,7 @@ class Epilogue(ctypes.Structure):
                 ("seed", c_void_p), ("stream_id", c_uint64), ("rowv", c_void_p), ("colv", c_void_p), ("rowseg", c_void_p),
                 ("maskref", c_void_p), ("ldmask", c_int), ("mask_scale", c_float), ("accumulate", c_int),
                 ("alpha", c_float), ("a_hi", c_void_p), ("a_lo", c_void_p), ("b_hi", c_void_p), ("b_lo", c_void_p),
-                ("c_hi", c_void_p), ("c_lo", c_void_p)]
+                ("c_hi", c_void_p), ("c_lo", c_void_p), ("gate_wc", c_void_p), ("gate_out", c_void_p), ("gate_np", c_int)]
 
 
 # name -> (restype, argtypes); must list every symbol include/advmil_hip.h declares
@@ -35,6 +35,7 @@ SIGNATURES = {
     "advmil_gemm_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                                 c_int64, ctypes.POINTER(Epilogue), c_int, c_void_p, c_size_t, c_void_p]),
     "advmil_split_planes": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "advmil_gemm_f32_gate_blocks": (c_int, [c_int, c_int64]),
     "advmil_set_gemm_mode": (c_int, [c_int]),
     "advmil_get_gemm_mode": (c_int, []),
     "advmil_gemm_f32_plan": (c_int, [c_int64, c_int64, c_int64, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),

@@ -455,14 +455,39 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 || TM * TN > 4 ? 1 : 2))
   const bool vec_ok = ((ldo & 3) == 0) && (((uintptr_t)out & 15) == 0);
   float* const patch = smem + wave * (32 * PITCH_KC);
   __syncthreads();   // every wave is done reading the operand tiles
+  // Gate-score mode (e.gate_wc): the columns are the interleaved branches of the gated attention scorer, col 2j = a_j (tanh),
+  // col 2j+1 = b_j (sigmoid). Instead of storing C, each row's  sum_j tanh(.)_j * sigmoid(.)_j * wc_j  over this workgroup's
+  // columns is reduced in registers / across the 8 lanes of a row and written to gate_out[row * gate_np + column-block]: the
+  // no-grad generator pass then never writes (and gate_score never re-reads) the [rows, 2D] activations.
+  const bool gate_mode = direct && e.gate_wc != nullptr;
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
+    float gsum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * PITCH_KC + i] = acc[a][b][r];
       WAVE_LDS_SYNC();   // the patch is private to this wave: order its LDS writes before the reads below, no block barrier
       const int64_t rbase = m0 + wr * 32 * TM + a * 32;
+      if (gate_mode) {
+        const int64_t col = n0 + wc * 32 * TN + b * 32 + (lane & 7) * 4;      // N % 4 == 0 in this mode: whole float4 or nothing
+        float w0 = 0.f, w1 = 0.f;
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col < g.N) {
+          w0 = e.gate_wc[col >> 1]; w1 = e.gate_wc[(col >> 1) + 1];
+          if (e.bias) b4 = *reinterpret_cast<const float4*>(e.bias + col);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int pr = q * 8 + (lane >> 3);
+          const float4 v4 = *reinterpret_cast<const float4*>(patch + pr * PITCH_KC + (lane & 7) * 4);
+          const float t0 = act_apply(ACT_TANH, v4.x * e.alpha + b4.x), s0 = act_apply(ACT_SIGMOID, v4.y * e.alpha + b4.y);
+          const float t1 = act_apply(ACT_TANH, v4.z * e.alpha + b4.z), s1 = act_apply(ACT_SIGMOID, v4.w * e.alpha + b4.w);
+          gsum[q] += t0 * s0 * w0 + t1 * s1 * w1;
+        }
+        WAVE_LDS_SYNC();
+        continue;
+      }
       // a lane stores columns col..col+3 of rows rbase + (lane >> 3) + 8q: everything that depends on the column only (bias,
       // which activation) is fetched once per sub-tile, not once per element inside the row loop
       const int64_t col = n0 + wc * 32 * TN + b * 32 + (lane & 7) * 4;
@@ -513,6 +538,15 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 || TM * TN > 4 ? 1 : 2))
         }
       }
       WAVE_LDS_SYNC();   // reads of this patch done before the next sub-tile overwrites it
+    }
+    if (gate_mode) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float t = gsum[q];
+        t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64);     // the 8 lanes that share a row
+        const int64_t row = m0 + wr * 32 * TM + a * 32 + q * 8 + (lane >> 3);
+        if ((lane & 7) == 0 && row < g.M) e.gate_out[row * e.gate_np + nt_i * WC + wc] = t;
+      }
     }
   }
 }
@@ -672,11 +706,22 @@ static int plan_exact(int64_t M, int64_t N, int64_t K, int* tile, int* splits) {
   return ADVMIL_OK;
 }
 
+// waves along N of a tile code: 2 for the 256-thread tiles and 43/42, 4 for the 2 x 4 wave grids 34/24
+static int tile_wc(int tile) { return (tile == 34 || tile == 24) ? 4 : 2; }
+extern "C" int advmil_gemm_f32_gate_blocks(int tile, int64_t N) {
+  if (g_gemm_mode != 1) {
+    if (tile / 10 == 4) tile = 20 + tile % 10;
+    else if (tile % 10 == 4) tile = (tile / 10 == 3) ? 23 : 22;
+  }
+  const int tn = tile % 10;
+  return (int)((N + 64 * tn - 1) / (64 * tn)) * tile_wc(tile);
+}
+
 extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                                      const float* B, int64_t ldb, float* C, int64_t ldc, const advmil_epilogue_t* epi,
                                      int splits, int tile, void* ws, size_t ws_bytes, advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!A || !B || !C || !epi || M <= 0 || N <= 0 || K <= 0) return ADVMIL_EINVAL;
+  if (!A || !B || !epi || (!C && !epi->gate_wc) || M <= 0 || N <= 0 || K <= 0) return ADVMIL_EINVAL;
   if ((lda & 3) || (ldb & 3)) return ADVMIL_EINVAL;
   if (a_kc ? (K & 3) : (M & 3)) return ADVMIL_EINVAL;
   if (b_kc ? (K & 3) : (N & 3)) return ADVMIL_EINVAL;
@@ -714,6 +759,10 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
     if (planes_usable(epi->b_hi, epi->b_lo, ldb, b_kc ? K : N)) pre |= 2;
   }
   if ((epi->c_hi != nullptr) != (epi->c_lo != nullptr)) return ADVMIL_EINVAL;
+  if (epi->gate_wc) {       // fused gate score: no split-K, no dropout, whole float4 column groups, one partial per 32*TN*... block
+    if (splits != 1 || !epi->gate_out || (N & 3) || epi->drop_p > 0.0f) return ADVMIL_EINVAL;
+    if (epi->gate_np != advmil_gemm_f32_gate_blocks(tile, N)) return ADVMIL_EINVAL;
+  }
   switch (tile) {
     case 23: launch_tile<2, 3, false>(a_kc, b_kc, grid, stream, g, pre); break;
     case 22: launch_tile<2, 2, true>(a_kc, b_kc, grid, stream, g, pre); break;

@@ -94,8 +94,6 @@ __global__ __launch_bounds__(256) void gate_score_kernel(const float* __restrict
                                                          uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D,
                                                          float* __restrict__ s) {
   const int lane = threadIdx.x & 63;
-  const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= N) return;
   const bool drop = seed && p > 0.f;
   uint64_t ka = 0, kb = 0;
   float inv = 1.f;
@@ -103,25 +101,64 @@ __global__ __launch_bounds__(256) void gate_score_kernel(const float* __restrict
     const uint64_t sd = *seed;
     ka = rng_key(sd, stream_a); kb = rng_key(sd, stream_b); inv = 1.f / (1.f - p);
   }
-  const float* row = ab + n * 2 * D;
-  float acc = 0.f;
-  for (int64_t j = lane; j < D; j += 64) {
-    float a = row[j], b = row[D + j];
-    if (drop) {
-      a *= rng_keep(ka, (uint64_t)(n * D + j), p, inv);
-      b *= rng_keep(kb, (uint64_t)(n * D + j), p, inv);
+  // one wave per row, grid-stride over rows; 16-byte loads (D % 4 == 0 on this path), wc kept in registers across rows
+  const int64_t D4 = D >> 2;
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  if ((D & 3) == 0 && D4 <= 128) {
+    float4 w[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int64_t q = lane + 64 * t;
+      w[t] = q < D4 ? reinterpret_cast<const float4*>(wc)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    acc += a * b * wc[j];
+    const float bias = bc[0];
+    for (int64_t n = wave0; n < N; n += nwaves) {
+      const float4* ra = reinterpret_cast<const float4*>(ab + n * 2 * D);
+      const float4* rb = ra + D4;
+      float acc = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int64_t q = lane + 64 * t;
+        if (q < D4) {
+          float4 a = ra[q], b = rb[q];
+          if (drop) {
+            const uint64_t base = (uint64_t)(n * D + q * 4);
+            a.x *= rng_keep(ka, base, p, inv);     b.x *= rng_keep(kb, base, p, inv);
+            a.y *= rng_keep(ka, base + 1, p, inv); b.y *= rng_keep(kb, base + 1, p, inv);
+            a.z *= rng_keep(ka, base + 2, p, inv); b.z *= rng_keep(kb, base + 2, p, inv);
+            a.w *= rng_keep(ka, base + 3, p, inv); b.w *= rng_keep(kb, base + 3, p, inv);
+          }
+          acc += a.x * b.x * w[t].x + a.y * b.y * w[t].y + a.z * b.z * w[t].z + a.w * b.w * w[t].w;
+        }
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) s[n] = acc + bias;
+    }
+    return;
   }
-  acc = wave_sum(acc);
-  if (lane == 0) s[n] = acc + bc[0];
+  for (int64_t n = wave0; n < N; n += nwaves) {
+    const float* row = ab + n * 2 * D;
+    float acc = 0.f;
+    for (int64_t j = lane; j < D; j += 64) {
+      float a = row[j], b = row[D + j];
+      if (drop) {
+        a *= rng_keep(ka, (uint64_t)(n * D + j), p, inv);
+        b *= rng_keep(kb, (uint64_t)(n * D + j), p, inv);
+      }
+      acc += a * b * wc[j];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) s[n] = acc + bc[0];
+  }
 }
 
 extern "C" int advmil_gate_score_fwd(const float* ab, const float* wc, const float* bc, float drop_p, const uint64_t* seed,
                                      uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D, float* s,
                                      advmil_stream_t stream) {
   if (!ab || !wc || !bc || !s || N <= 0 || D <= 0) return ADVMIL_EINVAL;
-  hipLaunchKernelGGL(gate_score_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ab, wc, bc,
+  int64_t blocks = (N + 3) / 4;
+  if (blocks > 8192) blocks = 8192;          // grid-stride over rows: 32 workgroups per CU
+  hipLaunchKernelGGL(gate_score_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ab, wc, bc,
                      drop_p, seed, stream_a, stream_b, N, D, s);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;

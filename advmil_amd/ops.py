@@ -18,6 +18,7 @@ FUSED_WGRAD = True
 # bench.py sets this to a list to bracket every GEMM launch with HIP events on the launch stream:
 # entries are (kernel name, (M, N, K, splits), flops, start_event, stop_event)
 KERNEL_PROFILE = None
+FUSED_GATE_SCORE = os.environ.get("ADVMIL_FUSED_GATE", "1") != "0"   # no-grad gated-attention passes skip the [N,2D] activations
 USE_PLANES = True     # bf16x3 mode: carry weights / bag rows / activations as pre-split bf16 planes
 _ACT = {None: 0, "none": 0, "relu": 1, "tanh": 2, "sigmoid": 3}
 
@@ -158,11 +159,18 @@ def split_planes(x, out=None):
 
 def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=None, act_split=None, drop_p=0.0,
          seed=None, stream_id=0, rowv=None, colv=None, rowseg=None, maskref=None, mask_scale=1.0, accumulate=False,
-         alpha=1.0, splits=None, tile=0, a_planes=None, b_planes=None, c_planes=None):
+         alpha=1.0, splits=None, tile=0, a_planes=None, b_planes=None, c_planes=None, gate_wc=None):
     """C[M,N] = epilogue(alpha * op(A) op(B)); see include/advmil_hip.h::advmil_gemm_f32. a_planes / b_planes: optional
     Planes of A / B; c_planes: Planes to receive the split of the final C (pitch ldc)."""
     _chk(A, "A"); _chk(B, "B")
-    if out is None:
+    if gate_wc is not None:
+        # fused gate score (advmil_epilogue_t.gate_wc): B / bias hold the INTERLEAVED branches; returns per-row partial scores
+        # [M, column blocks] instead of C
+        tile, _ = gemm_plan(M, N, K, a_kc, b_kc) if tile == 0 else (tile, 1)
+        npart = _lib.lib().advmil_gemm_f32_gate_blocks(tile, N)
+        gate_out = torch.empty(M, npart, dtype=torch.float32, device=A.device)
+        splits, out, ldc = 1, None, N
+    elif out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=A.device)
         ldc = N
     elif ldc is None:
@@ -191,6 +199,8 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
         e.b_hi, e.b_lo = b_planes.hi.data_ptr(), b_planes.lo.data_ptr()
     if c_planes is not None:
         e.c_hi, e.c_lo = c_planes.hi.data_ptr(), c_planes.lo.data_ptr()
+    if gate_wc is not None:
+        e.gate_wc, e.gate_out, e.gate_np = gate_wc.data_ptr(), gate_out.data_ptr(), npart
     if splits is None:
         ptile, splits = gemm_plan(M, N, K, a_kc, b_kc)
         if tile == 0:
@@ -208,7 +218,7 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         prof.append(("gemm_f32_kernel<%d,%d>" % (bool(a_kc), bool(b_kc)), (M, N, K, splits), 2.0 * M * N * K, e0, e1))
-    return out
+    return gate_out if gate_wc is not None else out
 
 
 def gate_score(ab, wc, bc, N, D, p=0.0, seed=None, stream_a=0, stream_b=0):
@@ -526,14 +536,23 @@ class GatedAttnPoolFn(torch.autograd.Function):
     model/backbone.py:81-85) and GAPool (model/backbone_utils.py:47-56): the pooled tensor is the scored tensor in every use."""
 
     @staticmethod
-    def forward(ctx, h, Wa, ba, Wb, bb, wc, bc, p, seed, sa, sb, seg):
+    def forward(ctx, h, Wa, ba, Wb, bb, wc, bc, p, seed, sa, sb, seg, nograd=False):
         _chk(h, "h")
         h = h.contiguous()
         N, D = h.shape
+        wcv = wc.detach().reshape(-1)
+        if FUSED_GATE_SCORE and p <= 0.0 and N >= 4096 and nograd:
+            # no-grad pass (the generator's eval forward of the discriminator update, test_model): nothing needs the [N, 2D] gate
+            # activations, so the contraction reduces the score in its epilogue from interleaved branch rows and never stores them
+            Wi = torch.stack((Wa.detach(), Wb.detach()), dim=1).reshape(2 * D, D)
+            bi = torch.stack((ba.detach(), bb.detach()), dim=1).reshape(2 * D)
+            s = gemm(h, Wi, True, True, N, 2 * D, D, bias=bi, gate_wc=wcv).sum(dim=1) + bc.detach()
+            A, pooled = softmax_pool(s, h, N, D, seg)
+            ctx.mark_non_differentiable(s)
+            return pooled, A, s
         Wab, _ = _stack2(Wa, Wb, D, D)                       # [2D, D]: a view when the two live side by side in the arena
         bab, _ = _stack2(ba, bb, D, 0)
         ab = gemm(h, Wab, True, True, N, 2 * D, D, bias=bab, act0=ACT_TANH, act1=ACT_SIGMOID, act_split=D)
-        wcv = wc.detach().reshape(-1)
         s = gate_score(ab, wcv, bc, N, D, p, seed, sa, sb)
         A, pooled = softmax_pool(s, h, N, D, seg)
         ctx.save_for_backward(h, Wab, ab, A, wcv)
@@ -566,7 +585,7 @@ class GatedAttnPoolFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # dG [N,2D] . Wab [2D,D]  +  A[n] * dpooled[bag(n), d]   (pooling's direct path, rank-1 per bag)
             dh = gemm(dG, Wab, True, False, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg)
-        nones = (None,) * 5
+        nones = (None,) * 6
         if ctx.arena is not None:
             gemm(dG, h, False, False, 2 * D, D, N, out=gWab, ldc=D, accumulate=True)       # dG^T h
             return (dh, None, None, None, None, None, None) + nones
@@ -583,7 +602,9 @@ def gated_attn_pool(h, Wa, ba, Wb, bb, wc, bc, p=0.0, rng=None, tag="", seg=None
         sa = rng.site(tag + "att_a", tuple(h.shape), p)
         sb = rng.site(tag + "att_b", tuple(h.shape), p)
         seed = rng.seed
-    pooled, A, s = GatedAttnPoolFn.apply(h, Wa, ba, Wb, bb, wc, bc, float(p), seed, sa, sb, seg)
+    # grad mode is always off INSIDE Function.forward, so "nothing here will be differentiated" is decided out here
+    nograd = not torch.is_grad_enabled() or not any(t.requires_grad for t in (h, Wa, ba, Wb, bb, wc, bc))
+    pooled, A, s = GatedAttnPoolFn.apply(h, Wa, ba, Wb, bb, wc, bc, float(p), seed, sa, sb, seg, nograd)
     return (pooled[0] if seg is None else pooled), A, s
 
 

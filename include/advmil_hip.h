@@ -73,6 +73,14 @@ typedef struct {
   const void* b_lo;
   void* c_hi; /* also write the planes of the final C values (pitch ldc) for the next contraction */
   void* c_lo;
+  /* Fused gate score (Attn_Net_Gated without its [rows, 2D] activations, model/backbone_utils.py:24-28; used by the no-grad
+   * generator pass of the discriminator update, model_handler.py:398-400): B's rows are the two branches INTERLEAVED (row 2j = Wa_j,
+   * row 2j+1 = Wb_j; bias likewise). Instead of C the launch writes, per row and per column block of the tile grid,
+   * gate_out[m*gate_np + block] = sum_j tanh(c[2j]) * sigmoid(c[2j+1]) * gate_wc[j]; the score is the sum over blocks (+ bc).
+   * gate_np = number of column blocks = n-tiles * waves along N (advmil_gemm_f32_gate_blocks). C may be NULL. No dropout, splits = 1. */
+  const float* gate_wc;
+  float* gate_out;
+  int gate_np;
 } advmil_epilogue_t;
 
 size_t advmil_gemm_f32_workspace_bytes(int64_t M, int64_t N, int splits);
@@ -83,6 +91,8 @@ int advmil_gemm_f32(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, const f
  * split into hi + lo bf16 in registers and a.b is formed as ah.bh + ah.bl + al.bh on the bf16 matrix pipe with fp32
  * accumulate -- dropped terms ~2^-17 |a||b| per product, 3/16 of the matrix-pipe time. Storage stays fp32 everywhere. */
 int advmil_split_planes(const float* src, int64_t n, void* hi, void* lo, advmil_stream_t stream);
+/* column blocks a launch with this tile writes per row in gate-score mode (see advmil_epilogue_t.gate_wc) */
+int advmil_gemm_f32_gate_blocks(int tile, int64_t N);
 int advmil_set_gemm_mode(int mode);
 int advmil_get_gemm_mode(void);
 /* The library's launch plan for a shape: block tile (see below) and K split count. Host callers size the workspace

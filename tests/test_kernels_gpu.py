@@ -343,3 +343,29 @@ def test_mha_bag_batched_equals_per_bag(ops):
     oc = ops.mha(c, nh, 0.25, rng, bags=G)
     (oc * w).sum().backward()
     assert torch.isfinite(oc).all() and torch.isfinite(c.grad).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["exact", "bf16x3"])
+@pytest.mark.parametrize("tile", [0, 22, 23, 12, 11, 43])
+def test_gemm_fused_gate_score(ops, mode, tile):
+    """Gate-score mode of the contraction (interleaved branch rows, score reduced in the epilogue, no [N,2D] store) equals the
+    two-launch path (gate contraction + gate_score kernel)."""
+    prev = ops.get_gemm_mode()
+    ops.set_gemm_mode(mode)
+    try:
+        g = torch.Generator(device="cuda").manual_seed(21)
+        N, D = 1000, 384
+        h = torch.randn(N, D, device="cuda", generator=g)
+        Wa, Wb = torch.randn(D, D, device="cuda", generator=g) * 0.05, torch.randn(D, D, device="cuda", generator=g) * 0.05
+        ba, bb = torch.randn(D, device="cuda", generator=g) * 0.1, torch.randn(D, device="cuda", generator=g) * 0.1
+        wc, bc = torch.randn(D, device="cuda", generator=g) * 0.1, torch.randn(1, device="cuda", generator=g)
+        ab = ops.gemm(h, torch.cat([Wa, Wb]), True, True, N, 2 * D, D, bias=torch.cat([ba, bb]), act0=2, act1=3, act_split=D)
+        want = ops.gate_score(ab, wc, bc, N, D)
+        Wi = torch.stack((Wa, Wb), dim=1).reshape(2 * D, D)
+        bi = torch.stack((ba, bb), dim=1).reshape(2 * D)
+        part = ops.gemm(h, Wi, True, True, N, 2 * D, D, bias=bi, gate_wc=wc, tile=tile)
+        got = part.sum(dim=1) + bc
+        assert float((got - want).abs().max()) < 2e-5, float((got - want).abs().max())
+    finally:
+        ops.set_gemm_mode(prev)
