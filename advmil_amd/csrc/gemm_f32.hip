@@ -688,17 +688,19 @@ static int plan_exact(int64_t M, int64_t N, int64_t K, int* tile, int* splits) {
   for (int c = 0; c < 5; ++c)
     if (n_tiles(order[c], M, N) >= 512) { *tile = order[c]; *splits = 1; return ADVMIL_OK; }
   const int64_t w11 = n_tiles(11, M, N);
-  if (K >= 2048 && w11 < 384 && (N & 3) == 0) {
+  if (K >= 512 && w11 < 384 && (N & 3) == 0) {
     static const int sorder[3] = {22, 12, 11};
     for (int c = 0; c < 3; ++c) {
       const int64_t w = n_tiles(sorder[c], M, N);
       const int64_t sp = (768 + w - 1) / w;
       if (K / sp >= 1024) { *tile = sorder[c]; *splits = (int)sp; return ADVMIL_OK; }
     }
+    // few 64x64 tiles over a long K (weight gradients of the [B,d] / region-level layers): a workgroup walking K/16 serially was
+    // 15 us of pure latency; >= 256 k per workgroup and up to 64 partials (the reduce launch keeps 8 loads in flight)
     int64_t sp = (768 + w11 - 1) / w11;
     const int64_t cap = K / 256 > 0 ? K / 256 : 1;
     if (sp > cap) sp = cap;
-    if (sp > 16) sp = 16;
+    if (sp > 64) sp = 64;
     *tile = 11; *splits = (int)sp;
     return ADVMIL_OK;
   }
