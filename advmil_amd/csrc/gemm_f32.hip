@@ -1,17 +1,19 @@
-// fp32 dense contraction engine for gfx950: v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF/s peak).
+// fp32 dense contraction engine for gfx950, two arithmetic modes (advmil_set_gemm_mode):
+//   exact  : v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF/s peak)
+//   bf16x3 : fp32 operands split hi + lo bf16 on the way into LDS, three v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate
 //
-// Block tile 128x128x32, 256 threads = 4 waves in a 2x2 grid, each wave a 64x64 sub-tile held
-// as 2x2 MFMA 32x32 accumulators (64 VGPRs). Operands are staged global -> registers -> LDS
-// (register prefetch of the next k-chunk overlaps the 64 MFMAs of the current one).
+// Workgroup = WR x WC waves (2x2: 256 threads; 4x2 / 2x4: 512 threads, bf16x3 only), each wave TM x TN MFMA 32x32 accumulators,
+// k walked in chunks of 32. Operands are staged global -> registers -> LDS.
 //
-// Two LDS images, chosen per operand by how the SOURCE is laid out:
-//   k-contiguous source ([rows,K] row-major, e.g. X or a Linear weight): LDS [row][36] (32 k + 4 pad),
-//     one ds_read_b128 per 32-row fragment per 8 k; pitch 36 makes every 16-lane b128 group hit 64
-//     distinct banks.
-//   m-contiguous source ([K,rows], e.g. dY in dW = dY^T X): LDS [k][128], ds_read_b32 (lanes read
-//     32 consecutive floats -> conflict free).
-// The MFMA k-slot of lane-half `hi` at step (t4,u) is k = 8*t4 + 4*hi + u for BOTH operands; the
-// contraction order is a permutation of 0..31, which fp32 accumulation does not care about.
+// exact mode, two fp32 LDS images chosen per operand by how the SOURCE is laid out (single buffer, register prefetch):
+//   k-contiguous source ([rows,K] row-major, e.g. X or a Linear weight): LDS [row][36] (32 k + 4 pad), one ds_read_b128 per
+//     32-row fragment per 8 k; pitch 36 makes every 16-lane b128 group hit 64 distinct banks.
+//   m-contiguous source ([K,rows], e.g. dY in dW = dY^T X): LDS [k][rows], ds_read_b32 (lanes read 32 consecutive floats).
+//   The MFMA k-slot of lane-half `hi` at step (t4,u) is k = 8*t4 + 4*hi + u for BOTH operands; the contraction order is a
+//   permutation of 0..31, which fp32 accumulation does not care about.
+// bf16x3 mode, two bf16 planes (hi, lo) per operand tile, double-buffered (one barrier per chunk):
+//   k-contiguous source: unpadded [row][32] planes with XOR-swizzled 16-byte units, ds_read_b128 fragments;
+//   m-contiguous source: [k][rows+32] planes in source orientation, fragments through the LDS transpose read ds_read_b64_tr_b16.
 #include "common.h"
 #include "../../include/advmil_hip.h"
 

@@ -18,8 +18,8 @@ FUSED_WGRAD = True
 # bench.py sets this to a list to bracket every GEMM launch with HIP events on the launch stream:
 # entries are (kernel name, (M, N, K, splits), flops, start_event, stop_event)
 KERNEL_PROFILE = None
-FUSED_GATE_SCORE = os.environ.get("ADVMIL_FUSED_GATE", "1") != "0"   # no-grad gated-attention passes skip the [N,2D] activations
-USE_PLANES = True     # bf16x3 mode: carry weights / bag rows / activations as pre-split bf16 planes
+# no-grad gated-attention passes skip the [N,2D] activations (ADVMIL_FUSED_GATE=0 keeps the two-launch path, for A/B timing)
+FUSED_GATE_SCORE = os.environ.get("ADVMIL_FUSED_GATE", "1") != "0"
 _ACT = {None: 0, "none": 0, "relu": 1, "tanh": 2, "sigmoid": 3}
 
 
@@ -141,11 +141,6 @@ class Planes:
 
     def view_rows(self, r0, r1):
         return Planes(self.hi[r0:r1], self.lo[r0:r1])
-
-
-def planes_enabled():
-    """Planes only pay in bf16x3 mode (the exact engine reads the fp32 operands)."""
-    return USE_PLANES and get_gemm_mode() == "bf16x3"
 
 
 def split_planes(x, out=None):
@@ -506,7 +501,8 @@ class ForwardMemo:
 
 
 MEMO = ForwardMemo()
-MEMO_MIN_ROWS = int(os.environ.get("ADVMIL_MEMO_MIN_ROWS", "4096"))       # only slab-sized layers are worth carrying
+# only slab-sized layers are worth carrying (ADVMIL_MEMO_MIN_ROWS=1000000000 turns the memo off, for A/B timing)
+MEMO_MIN_ROWS = int(os.environ.get("ADVMIL_MEMO_MIN_ROWS", "4096"))
 
 
 def linear_act(x, W, b, act="none", p=0.0, rng=None, tag=""):
