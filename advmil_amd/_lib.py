@@ -90,6 +90,7 @@ SIGNATURES = {
     "advmil_uniform_fill": (c_int, [c_void_p, c_int64, c_void_p, c_uint64, c_void_p]),
     "advmil_dropout_apply": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_uint64, c_void_p]),
     "advmil_seed_advance": (c_int, [c_void_p, c_uint64, c_void_p]),
+    "advmil_cindex_counts": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p]),
 }
 
 _lib = None

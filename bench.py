@@ -357,6 +357,28 @@ def main():
         finally:
             ops.set_gemm_mode(args.gemm_mode)
 
+    # ---- extra (single GPU): one bag per optimizer step (bp_every_batch = 1), the reading of the north star's "G+D steps/s"
+    # (then steps/s == bags/s)
+    bp1_extra = None
+    if world == 1 and not args.eager and graphs and not args.no_bf16_extra and args.bags > 1:
+        try:
+            from advmil_amd.graphed import GraphedStep
+            g1 = [GraphedStep(h, [xs[i]], [ys[i]], [ys_host[i]], warmup=1) for i in range(min(8, n_pool))]
+            for k in range(8):
+                g1[k % len(g1)].replay()
+            torch.cuda.synchronize()
+            n1 = 200
+            t1 = time.perf_counter()
+            for k in range(n1):
+                g1[k % len(g1)].replay()
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t1
+            bp1_extra = {"value": round(n1 / dt1, 2), "unit": "G+D steps/s (1 bag of %d patches per step)" % args.patches,
+                         "ms_per_step": round(1e3 * dt1 / n1, 3), "steps": n1}
+            del g1
+        except Exception as exc:
+            bp1_extra = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
+
     # ---- extra (single GPU, f32 runs only): the same step with bf16 MFMA operands in the generator's contractions
     bf16_extra = None
     if world == 1 and args.gen_dtype == "f32" and args.gemm_mode == "exact" and args.mode == "abmil" and not args.no_bf16_extra and not args.eager:
@@ -408,7 +430,7 @@ def main():
             "gd_steps_per_sec": round(args.steps / dt, 3), "losses_finite": bool(finite), "replicas_in_sync": in_sync,
             "host_submit_ms_per_step": round(1e3 * t_submit / args.steps, 3),
             "roofline": roof, "cpu_baseline": cpu, "exact_f32_mfma_mode": exact_extra,
-            "mixed_precision_bf16_generator": bf16_extra,
+            "bp_every_batch_1": bp1_extra, "mixed_precision_bf16_generator": bf16_extra,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -244,6 +244,15 @@ int advmil_dropout_apply(const float* x, float* y, int64_t n, float p, const uin
                          advmil_stream_t stream);
 int advmil_seed_advance(uint64_t* seed, uint64_t inc, advmil_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Evaluator: concordance index for right-censored data, eval/cindex.py:79-143 (`_get_comparable`,
+ * `_estimate_concordance_index`; python loops over samples there, all n^2 pair tests on the device here).
+ * time[n], event[n] (!= 0: event observed), estimate[n] (risk: higher = earlier event; the reference passes -prediction,
+ * eval/cindex.py:35,41). out6 (device, int64) = concordant, discordant, tied_risk, tied_time, comparable pairs, number of event
+ * samples the reference would register (0 -> its NoComparablePairException). cindex = (concordant + 0.5*tied_risk) / comparable. */
+int advmil_cindex_counts(const float* time, const float* event, const float* estimate, int64_t n, float tied_tol, int64_t* out6,
+                         advmil_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
