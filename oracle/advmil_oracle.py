@@ -477,3 +477,80 @@ def test_model_bag(cfg, PG, PD, x, x_ext, noise0, noise_list):
         dist = torch.stack(ys) if ys else None
         avg = torch.median(dist, dim=0)[0] if ys else None
     return y_hat, f_fake, dist, avg
+
+
+# ---------------------------------------------------------------------------------------
+# SURVEY 8f #3 — the supervised baselines: model/BaseSurv.py:22-40 (SurvNet), loss/utils.py:82-181 (MSE_loss, SurvMLE,
+# SurvPLE), model/baseline_handler.py:328-368 (_update_network). Pinned by golden G7 (tests/golden/gen_golden.py).
+# ---------------------------------------------------------------------------------------
+def surv_net(P, x, x_ext, kind="abmil", masks=None, out_scale="sigmoid", hops=1):
+    """BaseSurv.py:22-40: backbone -> out_layer (make_noise_mlp_layer with all noise flags 0, then Sigmoid if out_scale ==
+    'sigmoid'). out_layer.{i}.0 = Linear; hidden layers are Linear (-> LayerNorm) -> ReLU -> Dropout."""
+    H, _ = backbone_forward(kind, _sub(P, "backbone."), x, x_ext, masks)
+    n = 1 + hops
+    for i in range(n):
+        h = _lin(P, f"out_layer.{i}.0", H)
+        if i < n - 1:
+            if f"out_layer.{i}.1.weight" in P:
+                h = F.layer_norm(h, (h.shape[-1],), P[f"out_layer.{i}.1.weight"], P[f"out_layer.{i}.1.bias"], 1e-5)
+            h = _drop(torch.relu(h), masks, f"mlp{i}")
+        H = h
+    return torch.sigmoid(H) if out_scale == "sigmoid" else H
+
+
+def mse_loss(pred_t, t, e, include_censored=False):
+    """loss/utils.py:82-96."""
+    pred_t, t, e = pred_t.squeeze(), t.squeeze(), e.squeeze()
+    loss = e * (pred_t - t) * (pred_t - t)
+    if include_censored:
+        loss = loss + (1 - e) * (pred_t - t) * (pred_t - t)
+    return loss.mean()
+
+
+def surv_mle(hazards_hat, t, e, alpha=0.0, eps=1e-7):
+    """loss/utils.py:99-135 (SurvMLE.forward): discrete-time NLL; t = bin index, e = event indicator."""
+    b = len(t)
+    t = t.view(b, 1).long()
+    c = 1 - e.view(b, 1).float()
+    S = torch.cumprod(1 - hazards_hat, dim=1)
+    S_padded = torch.cat([torch.ones_like(c), S], 1)
+    unc = -(1 - c) * (torch.log(torch.gather(S_padded, 1, t).clamp(min=eps)) + torch.log(torch.gather(hazards_hat, 1, t).clamp(min=eps)))
+    cen = -c * torch.log(torch.gather(S_padded, 1, t + 1).clamp(min=eps))
+    neg_l = cen + unc
+    return ((1.0 - alpha) * neg_l + alpha * unc).mean()
+
+
+def surv_ple(y_hat, T, E):
+    """loss/utils.py:138-175 (SurvPLE.forward): Breslow partial likelihood; R[i,j] = (T[j] >= T[i]); predictions capped at 10."""
+    y_hat = torch.where(y_hat > 10.0, torch.full_like(y_hat, 10.0), y_hat)
+    Tf = T.reshape(-1)
+    R = (Tf.view(1, -1) >= Tf.view(-1, 1)).float()
+    theta = y_hat.reshape(-1)
+    # As shipped (loss/utils.py:171-173) the [B] vector is multiplied by E of shape [B,1] (the handler passes label columns,
+    # baseline_handler.py:350-352), which broadcasts to [B,B]: the loss is mean_j(theta_j - logsum_j) * mean_i(E_i). Restated as is.
+    return -torch.mean((theta - torch.log(torch.sum(torch.exp(theta) * R, dim=1))) * E.float().reshape(-1, 1))
+
+
+def baseline_step(P, state, bags, kind="abmil", task="surv_reg", out_scale="sigmoid", hops=1, masks=None, lr=8e-5, weight_decay=5e-4,
+                  l1_coef=1e-5, recon=(0.0, 0.0, "l1"), mle_alpha=0.0, use_censored=False):
+    """baseline_handler.py:328-368: per-bag forwards of the step batch, ONE loss over the concatenated predictions
+    (+ L1 over all parameters), backward, Adam. bags = [(x, x_ext, y[1,2])...]. Returns (new P, logs, preds)."""
+    Pg = _req(P)
+    preds = [surv_net(Pg, x, ext, kind, None if masks is None else masks[i], out_scale, hops) for i, (x, ext, y) in enumerate(bags)]
+    cur = torch.cat(preds, dim=0)
+    t = torch.cat([b[2][:, [0]] for b in bags], dim=0)
+    e = torch.cat([b[2][:, [1]] for b in bags], dim=0)
+    if task == "surv_nll":
+        net_loss = surv_mle(cur, t, e, mle_alpha)
+    elif task == "surv_cox":
+        net_loss = surv_ple(cur, t, e)
+    elif kind == "patch":
+        net_loss = mse_loss(cur, t, e, use_censored)                    # baseline_handler.py:100-104
+    else:
+        net_loss = recon_loss(cur, t, e, recon[0], recon[1], recon[2])
+    total = net_loss + loss_reg_l1(l1_coef, Pg.values())
+    total.backward()
+    grads = {k: v.grad for k, v in Pg.items() if v.grad is not None}
+    newP = adam_step(P, grads, state, lr, weight_decay)
+    logs = {"loss_supervision": float(net_loss.detach()), "loss_total": float(total.detach())}
+    return newP, logs, [p.detach() for p in preds]
