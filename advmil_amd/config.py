@@ -19,3 +19,18 @@ def default_cfg(**over):
     )
     cfg.update(over)
     return cfg
+
+
+def default_baseline_cfg(**over):
+    """Keys BaselineHandler reads (model/baseline_handler.py:34-120); the reference ships no baseline yaml, the values follow
+    cfg_nlst.yaml where the key has a counterpart there."""
+    cfg = dict(
+        task="surv_reg", seed=42, cuda_id=0, save_path=None, test=False,
+        bcb_mode="abmil", bcb_dims="1024-384-384", pdh_dims="384-1", mlp_hops=1, mlp_norm=False, mlp_dropout=0.6,
+        loss_regl1_coef=0.00001, loss_mle_alpha=0.0, loss_recon_norm="l1", loss_recon_alpha=0.0, loss_recon_gamma=0.0,
+        loss_use_censored=False, time_bins=4,
+        opt_net="adam", opt_net_lr=0.00008, opt_net_weight_decay=0.0005,
+        batch_size=1, bp_every_batch=16,
+    )
+    cfg.update(over)
+    return cfg

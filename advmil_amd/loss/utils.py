@@ -1,5 +1,6 @@
 """Losses of the G+D step (reference loss/utils.py): loss_reg_l1 (6-14), recon_loss (21-41),
-real_fake_loss (182-203), fake_generator_loss (205-208). They act on <= bp_every_batch scalars, so
+real_fake_loss (182-203), fake_generator_loss (205-208); and of the supervised baselines: MSE_loss (82-96), SurvMLE (99-135),
+SurvPLE (138-175). They act on <= bp_every_batch scalars, so
 they are a handful of tiny device ops; the one N-sized piece -- sum|W| over the generator arena -- is
 the abs_sum kernel, and its gradient is folded into the fused Adam kernel (advmil_amd/optim.py)."""
 import torch
@@ -64,3 +65,47 @@ def real_fake_loss(real, fake, which="bce"):
 
 def fake_generator_loss(fake_score):
     return -torch.mean(fake_score.reshape(-1))
+
+
+# ---- supervised baselines (model/baseline_handler.py:92-106) -------------------------------------------------------------
+def MSE_loss(pred_t, t, e, include_censored=False):
+    """loss/utils.py:82-96 (the ESAT baseline's loss)."""
+    pred_t, t, e = pred_t.squeeze(), t.squeeze(), e.squeeze()
+    loss = e * (pred_t - t) * (pred_t - t)
+    if include_censored:
+        loss = loss + (1 - e) * (pred_t - t) * (pred_t - t)
+    return loss.mean()
+
+
+class SurvMLE(torch.nn.Module):
+    """Discrete-time negative log-likelihood, loss/utils.py:99-135. t = bin index, e = event indicator."""
+
+    def __init__(self, alpha=0.0, eps=1e-7):
+        super().__init__()
+        self.alpha, self.eps = alpha, eps
+
+    def forward(self, hazards_hat, t, e, cur_alpha=None):
+        b = len(t)
+        t = t.view(b, 1).long()
+        c = 1 - e.view(b, 1).float()
+        S = torch.cumprod(1 - hazards_hat, dim=1)
+        S_padded = torch.cat([torch.ones_like(c), S], 1)
+        unc = -(1 - c) * (torch.log(torch.gather(S_padded, 1, t).clamp(min=self.eps))
+                          + torch.log(torch.gather(hazards_hat, 1, t).clamp(min=self.eps)))
+        cen = -c * torch.log(torch.gather(S_padded, 1, t + 1).clamp(min=self.eps))
+        alpha = self.alpha if cur_alpha is None else cur_alpha
+        return ((1.0 - alpha) * (cen + unc) + alpha * unc).mean()
+
+
+class SurvPLE(torch.nn.Module):
+    """Breslow partial likelihood, loss/utils.py:138-175. The risk-set matrix R[i,j] = (T[j] >= T[i]) is one broadcast compare on
+    the device (the reference fills it with a python double loop of .item()-style reads). As shipped, the [B] vector of log partial
+    likelihoods is multiplied by E of shape [B,1] (the handler passes label columns), which broadcasts to [B,B] before the mean;
+    that behaviour is kept."""
+
+    def forward(self, y_hat, T, E):
+        y_hat = torch.where(y_hat > 10.0, torch.full_like(y_hat, 10.0), y_hat)
+        Tf = T.reshape(-1)
+        R = (Tf.view(1, -1) >= Tf.view(-1, 1)).to(y_hat.dtype)
+        theta = y_hat.reshape(-1)
+        return -torch.mean((theta - torch.log(torch.sum(torch.exp(theta) * R, dim=1))) * E.float())

@@ -1,0 +1,162 @@
+"""model/baseline_handler.py of the reference (BaselineHandler: ctor 34-141, _train_each_epoch 287-326, _update_network 328-368,
+test_model 443-487, save/resume 489-516) for the three supervised tasks (surv_reg / surv_nll / surv_cox) on the same HIP path as
+the G+D handler: the bags of an optimizer step run as ONE slab through the backbone kernels, the [B,d]-sized head and the loss run
+once on the stacked predictions, the L1 sub-gradient is folded into the fused Adam launch. Orchestration (exec / k-fold / wandb /
+evaluator wiring) stays with the reference."""
+import os
+import os.path as osp
+from functools import partial
+from types import SimpleNamespace
+
+import torch
+
+from .. import ops
+from ..loss.utils import MSE_loss, SurvMLE, SurvPLE, recon_loss
+from ..optim import create_optimizer
+from ..utils.func import agg_tensor, seed_everything, sparse_key, sparse_str
+from .backbone import load_backbone
+from .BaseSurv import SurvNet
+from .model_utils import general_init_weight, init_weights
+
+
+class BaselineHandler(object):
+    def __init__(self, cfg, device=None):
+        assert cfg["task"] in ["surv_cox", "surv_nll", "surv_reg"]
+        assert cfg["bcb_mode"] in ["patch", "cluster", "graph", "abmil"]
+        if device is None:
+            if torch.cuda.device_count() == 0:
+                raise RuntimeError("advmil_amd.BaselineHandler needs an MI355X: no ROCm device visible (no CPU fallback)")
+            device = torch.device("cuda", int(cfg.get("cuda_id", 0)) % torch.cuda.device_count())
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        seed_everything(cfg["seed"])
+        self.rng = ops.default_rng(self.device)
+        self.cfg, self.bcb, self.task = cfg, cfg["bcb_mode"], cfg["task"]
+        save_path = cfg.get("save_path")
+        if save_path:
+            os.makedirs(save_path, exist_ok=True)
+            self.last_net_ckpt_path = osp.join(save_path, "model-last.pth")
+            self.best_net_ckpt_path = osp.join(save_path, "model-best.pth")
+        # out_scale / time format follow the task (baseline_handler.py:68-78)
+        out_scale = "none" if self.task == "surv_cox" else "sigmoid"
+        cfg["time_format"] = {"surv_nll": "quantile", "surv_reg": "ratio", "surv_cox": "origin"}[self.task]
+        backbone = load_backbone(self.bcb, sparse_str(cfg["bcb_dims"]))
+        dim_in, dim_out = sparse_str(cfg["pdh_dims"])
+        self.net = SurvNet(dim_in, dim_out, backbone, hops=cfg["mlp_hops"], norm=cfg["mlp_norm"], dropout=cfg["mlp_dropout"],
+                           out_scale=out_scale)
+        self.net.apply(init_weights if self.task in ("surv_reg", "surv_nll") else general_init_weight)       # 87-90
+        self.net = self.net.to(self.device)
+        for m in self.net.modules():
+            m.rng = self.rng
+        if cfg.get("gemm_mode") is not None:
+            ops.set_gemm_mode(cfg["gemm_mode"])
+        if self.task == "surv_nll":                                                                           # 93-105
+            self.supervised_loss = SurvMLE(**sparse_key(cfg, prefixes="loss_mle"))
+        elif self.task == "surv_cox":
+            self.supervised_loss = SurvPLE()
+        elif self.bcb == "patch":
+            self.supervised_loss = partial(MSE_loss, include_censored=cfg["loss_use_censored"])
+        else:
+            self.supervised_loss = partial(recon_loss, **sparse_key(cfg, prefixes="loss_recon"))
+        self.coef_l1 = 0.0 if cfg["loss_regl1_coef"] is None else float(cfg["loss_regl1_coef"])
+        opt_cfg = SimpleNamespace(opt=cfg["opt_net"], weight_decay=cfg["opt_net_weight_decay"], lr=cfg["opt_net_lr"], opt_eps=None,
+                                  opt_betas=None, momentum=None)
+        self.optimizer = create_optimizer(opt_cfg, self.net)
+        self.optimizer.l1_coef = self.coef_l1 if self.coef_l1 > 1e-8 else 0.0        # d/dW coef*sum|W| applied inside the Adam kernel
+        self.steplr = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode="min", factor=0.5, patience=10)
+        self.patient_id = dict()
+        self.history = []
+
+    # ------------------------------------------------------------------------------------------
+    def log(self, d):
+        self.history.append(d)
+
+    def pop_logs(self):
+        out = [{k: (float(v) if torch.is_tensor(v) else v) for k, v in d.items()} for d in self.history]
+        self.history = []
+        return out
+
+    def _train_each_epoch(self, train_loader, name_loader):
+        """Reference contract (287-326): returns {'y', 'y_hat'} collected over the epoch."""
+        bp = self.cfg["bp_every_batch"]
+        cltor = {"y": None, "y_hat": None}
+        xs, ys = [], []
+        for i_batch, (data_idx, data_x, data_y) in enumerate(train_loader, start=1):
+            xs.append([dx.to(self.device, non_blocking=True) if torch.is_tensor(dx) else dx for dx in data_x])
+            ys.append(data_y.to(self.device, non_blocking=True))
+            if i_batch % bp == 0:
+                preds = self._update_network(i_batch, xs, ys)
+                cltor = agg_tensor(cltor, {"y": torch.cat(ys, dim=0).detach().cpu(), "y_hat": preds.detach().cpu()})
+                xs, ys = [], []
+        return cltor
+
+    def _update_network(self, i_batch, xs, ys):
+        """One optimizer step over the collected bags (328-368): predictions [B, dim_out] of the step batch."""
+        self.net.train()
+        self.optimizer.zero_grad()
+        c = xs[0][0].shape[-1]
+        X = torch.cat([x[0].reshape(-1, c) for x in xs], dim=0) if len(xs) > 1 else xs[0][0].reshape(-1, c)
+        seg = ops.Segments([x[0].shape[-2] for x in xs], self.device)
+        exts = [x[1] for x in xs] if self.bcb in ("cluster", "graph") else None
+        preds = self.net.finish(self.net.features_multi(X, seg, exts))
+        y = torch.cat(ys, dim=0)
+        net_loss = self.supervised_loss(preds, y[:, 0:1], y[:, 1:2])
+        net_loss.backward()
+        total = net_loss.detach()
+        if self.coef_l1 > 1e-8:
+            total = total + self.coef_l1 * ops.abs_sum(self.optimizer.flat_param)[0]
+        self.log({"train_batch/net/loss_supervision": net_loss.detach(), "train_batch/net/loss_total": total, "i_batch": i_batch})
+        self.optimizer.step()
+        return preds.detach()
+
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def test_model(model, backbone, loader, times_test_sample=1, checkpoint=None):
+        """443-487. The network has no noise, so in eval mode the `times_test_sample` repeated forwards of the reference are
+        identical: the bag is run once and the sample axis is filled with that prediction."""
+        dev = next(model.parameters()).device
+        if checkpoint is not None:
+            model.load_state_dict(torch.load(checkpoint, map_location=dev)["model"])
+        model.eval()
+        res = {"idx": None, "y": None, "y_hat": None}
+        with torch.no_grad():
+            for idx, x, y in loader:
+                x_data, x_ext = [t.to(dev) if torch.is_tensor(t) else t for t in x]
+                if backbone == "graph":
+                    y_hat = model(x_ext, None)
+                elif backbone == "patch":
+                    y_hat = model(x_data, None)
+                else:
+                    y_hat = model(x_data, x_ext)
+                res = agg_tensor(res, {"idx": idx.detach().cpu(), "y": y.detach().cpu(), "y_hat": y_hat.detach().cpu()})
+                if times_test_sample > 1:
+                    ys = y_hat.unsqueeze(0).expand(times_test_sample, *y_hat.shape)
+                    res = agg_tensor(res, {"dist_y_hat": ys.transpose(0, 1).detach().cpu()})
+                    res = agg_tensor(res, {"avg_y_hat": torch.median(ys, dim=0)[0].detach().cpu()})
+        return res
+
+    # ------------------------------------------------------------------------------------------
+    def _get_state_dict(self, epoch):
+        return {"epoch": epoch, "model": self.net.state_dict(), "optimizer": self.optimizer.state_dict()}
+
+    @staticmethod
+    def _prefixed(path, prefix):
+        d, f = osp.split(path)
+        return osp.join(d, prefix + "_" + f)
+
+    def _ckpt(self, ckpt_type, run_name):
+        if ckpt_type not in ("best", "last"):
+            raise KeyError("Expected best or last for `ckpt_type`, but got {}.".format(ckpt_type))
+        return self._prefixed(self.last_net_ckpt_path if ckpt_type == "last" else self.best_net_ckpt_path, run_name)
+
+    def save_model(self, epoch, ckpt_type="best", run_name="train"):
+        torch.save(self._get_state_dict(epoch), self._ckpt(ckpt_type, run_name))
+
+    def resume_model(self, ckpt_type="best", run_name="train"):
+        ck = torch.load(self._ckpt(ckpt_type, run_name), map_location=self.device)
+        self.net.load_state_dict(ck["model"])
+        self.optimizer.load_state_dict(ck["optimizer"])
+
+    def exec(self):
+        raise NotImplementedError("orchestration (data loading, evaluator, early stopping, k-fold) stays with the reference: "
+                                  "see INTEGRATION.md for the binding of _train_each_epoch / _update_network / test_model")

@@ -1,4 +1,5 @@
-"""model/model_utils.py of the reference: init_weights (12-17), get_hop_dims / make_noise_mlp_layer (106-133),
+"""model/model_utils.py of the reference: init_weights (12-17), general_init_weight / init_pytorch_defaults (20-71),
+get_hop_dims / make_noise_mlp_layer (106-133),
 make_efficient_mlp_layer (157-166), make_mlp_layer (168-176), make_embedding_y_layer (178-186),
 EmbedXLayer (188-210). Same names, arguments and state_dict keys."""
 import torch
@@ -16,6 +17,25 @@ def init_weights(m):
         nn.init.xavier_uniform_(m.weight)
         if m.bias is not None:
             m.bias.data.zero_()
+
+
+@torch.no_grad()
+def general_init_weight(m):
+    """model_utils.py:20-71 with version='041' (the PyTorch 0.4.1 defaults, halved for Linear): used by the Cox baseline."""
+    import math
+    if isinstance(m, nn.Linear):
+        stdv = 1.0 / math.sqrt(m.weight.size(1)) * 0.5
+        m.weight.data.uniform_(-stdv, stdv)
+        if m.bias is not None:
+            m.bias.data.uniform_(-stdv, stdv)
+    elif isinstance(m, nn.Conv2d):
+        n = m.in_channels
+        for k in m.kernel_size:
+            n *= k
+        stdv = 1.0 / math.sqrt(n)
+        m.weight.data.uniform_(-stdv, stdv)
+        if m.bias is not None:
+            m.bias.data.uniform_(-stdv, stdv)
 
 
 def get_hop_dims(d, hops):
@@ -92,6 +112,8 @@ def run_mlp_small(seq, x, rng, tag):
             x = F.layer_norm(x, m.normalized_shape, m.weight, m.bias, m.eps)
         elif isinstance(m, nn.ReLU):
             x = F.relu(x)
+        elif isinstance(m, nn.Sigmoid):
+            x = torch.sigmoid(x)
         elif isinstance(m, nn.Dropout):
             x = dropout_small(x, m.p, seq.training, rng, f"{tag}.{j}")
         else:
