@@ -131,7 +131,7 @@ class PrjDiscriminator(_PairNet):
         emb_bag, fc_ins = self.net_pair_one.pool_features_rows(emb, seg16)
         if self.inner_product != "instance":
             return emb_bag, None
-        return emb_bag, ops.segmented_mean(fc_ins, seg16.rowseg, seg16.nseg)
+        return emb_bag, ops.segmented_mean_rows(fc_ins, seg16)
 
     def tail(self, emb_bag, ins_mean, t):
         """[B,C'] stacks + t[B,1] -> f[B,1]: fc2, net_pair_two, the (region-level) inner product and the projection,

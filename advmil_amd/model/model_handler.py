@@ -227,12 +227,12 @@ class MyHandler(object):
         is_real = [bool(float(yh[0, 1]) == 1.0) and vis[i] for i, yh in enumerate(ys_host)]
         n_real, n_fake, n_vis = self.dp.global_counts([sum(is_real), n, sum(vis)], self.device)
         vis_mask = None if all(vis) else torch.tensor([float(v) for v in vis], device=self.device)
-        real_idx = torch.tensor([i for i in range(n) if is_real[i]], dtype=torch.long, device=self.device)
+        real_mask = torch.tensor([1.0 if r else 0.0 for r in is_real], device=self.device)
         seg = ops.Segments([self._rows(x[0]) for x in xs], self.device)
         seg16 = seg.div(16)                              # D's region embedding needs N % 16 == 0 (backbone_utils.py:65)
         seg16.twice()                                    # (built here: the D update stacks its fake and real passes)
         return SimpleNamespace(vis=vis, is_real=is_real, n_real=n_real, n_fake=n_fake, n_vis=n_vis, vis_mask=vis_mask,
-                               real_idx=real_idx, seg=seg, seg16=seg16)
+                               real_mask=real_mask, seg=seg, seg16=seg16)
 
     @staticmethod
     def _rows(x):
@@ -312,7 +312,7 @@ class MyHandler(object):
             nb = len(xs)
             eb2, im2 = self.netD.bag_features_multi(torch.cat([emb, emb], dim=0), plan.seg16.twice())
             f2 = self.netD.tail(eb2, im2, torch.cat([pred, y[:, 0:1]], dim=0)).view(-1)
-            f_fake, f_real = f2[:nb], f2[nb:][plan.real_idx]
+            f_fake, f_real = f2[:nb], f2[nb:]                                   # real scores of ALL bags; the mask picks the pairs
         else:
             eb, im = self.netD.bag_features_multi(emb, plan.seg16)
             f_fake = self.netD.tail(eb, im, pred).view(-1)
@@ -320,8 +320,9 @@ class MyHandler(object):
         loss = tf.sum() / plan.n_fake
         s_real = torch.zeros((), device=dev)
         if tr is not None:
-            loss = loss + tr.sum() / plan.n_real
-            s_real = f_real.detach().sum()
+            # a 0/1 mask instead of f_real[real_idx]: same sum, and the backward is a multiply instead of an index_put (sort)
+            loss = loss + (tr * plan.real_mask).sum() / plan.n_real
+            s_real = (f_real.detach() * plan.real_mask).sum()
         loss.backward()
         self.log({"train_batch/netD/Loss_D": loss.detach(), "train_batch/netD/D_real": s_real / max(plan.n_real, 1),
                   "train_batch/netD/D_fake": f_fake.detach().sum() / plan.n_fake, "i_batch": i_batch})

@@ -241,6 +241,7 @@ class Segments:
         self.ptr = torch.tensor(offs, dtype=torch.int64, device=self.device)
         self.rowseg = torch.repeat_interleave(torch.arange(self.nseg, dtype=torch.int32, device=self.device),
                                               torch.tensor(self.lens, device=self.device)).contiguous()
+        self.rowseg_long = self.rowseg.to(torch.long)
         self._div = {}
 
     def div(self, k):
@@ -775,6 +776,31 @@ class SegMeanFn(torch.autograd.Function):
         (wn,) = ctx.saved_tensors
         N, D, S = ctx.dims
         return gemm(wn, dout.contiguous(), True, False, N, D, S), None
+
+
+class SegRowMeanFn(torch.autograd.Function):
+    """Mean of the rows of h[N, D] per CONTIGUOUS segment of a slab (ops.Segments) -> [nseg, D]: the segmented pooling kernels
+    with uniform weights (softmax of zero scores = 1/len per row); backward broadcasts dout[seg]/len to the rows."""
+
+    @staticmethod
+    def forward(ctx, h, seg):
+        h = h.contiguous()
+        N, D = h.shape
+        A, pooled = softmax_pool(torch.zeros(N, dtype=torch.float32, device=h.device), h, N, D, seg)
+        ctx.save_for_backward(A)
+        ctx.seg = seg
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dout):
+        (A,) = ctx.saved_tensors
+        seg = ctx.seg
+        idx = seg.rowseg_long
+        return dout.contiguous().index_select(0, idx) * A.unsqueeze(1), None
+
+
+def segmented_mean_rows(h, seg):
+    return SegRowMeanFn.apply(h, seg)
 
 
 def segmented_mean(h, seg_id, num_segments):

@@ -37,10 +37,13 @@ class FlatAdam(torch.optim.Optimizer):
             decay = [(n, p) for n, p in named if not (p.dim() == 1 or n.endswith(".bias"))]
             groups = [{"params": [p for _, p in no_decay], "weight_decay": 0.0},
                       {"params": [p for _, p in decay], "weight_decay": weight_decay}]
-            ordered = no_decay + decay
         else:
             groups = [{"params": [p for _, p in named], "weight_decay": weight_decay}]
-            ordered = named
+        # Arena layout (independent of the param_groups / state_dict order above): vectors first, then matrices, each in named
+        # order. That puts the two branch weights (and the two branch biases) of every gated-attention scorer side by side, which
+        # is what lets the pooling kernels read them as one stacked [2D, D] view and accumulate their gradients in one launch.
+        ordered = ([(n, p) for n, p in named if p.dim() == 1 or n.endswith(".bias")]
+                   + [(n, p) for n, p in named if not (p.dim() == 1 or n.endswith(".bias"))])
         super().__init__(groups, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.l1_coef = float(l1_coef)
         self.names = [n for n, _ in ordered]
