@@ -278,7 +278,16 @@ __global__ __launch_bounds__(256) void pool_bwd_dot_kernel(const float* __restri
   if (n < end) {
     const float* row = h + n * ldh;
     float acc = 0.f;
-    for (int64_t j = lane; j < D; j += 64) acc += dpb[j] * row[j];
+    if ((D & 3) == 0 && (ldh & 3) == 0) {            // 16-byte loads (one wave per row; D = 384 -> 96 float4, 1.5 per lane)
+      const float4* r4 = reinterpret_cast<const float4*>(row);
+      const float4* d4 = reinterpret_cast<const float4*>(dpb);
+      for (int64_t q = lane; q < (D >> 2); q += 64) {
+        const float4 a = d4[q], v = r4[q];
+        acc += a.x * v.x + a.y * v.y + a.z * v.z + a.w * v.w;
+      }
+    } else {
+      for (int64_t j = lane; j < D; j += 64) acc += dpb[j] * row[j];
+    }
     acc = wave_sum(acc);
     if (dA) acc += dA[n];
     if (lane == 0) t[n] = acc;
