@@ -357,7 +357,17 @@ class MyHandler(object):
         pred = self.netG.finish(feats, noise=self._stack_noise(noise))         # [B,1], graph kept
         with torch.no_grad():                                                  # nothing of D(x) depends on G
             eb, im = self.netD.bag_features_multi(self.netD.embed_rows(X), plan.seg16)
-        f_fake = self.netD.tail(eb, im, pred).view(-1)
+        # The generator loss only needs d f / d pred. The reference lets autograd also fill netD's weight gradients here and
+        # throws them away at the next optimizerD.zero_grad() (model_handler.py:409, 497); with D's parameters frozen for this
+        # backward those contractions (five small dW launches + their reductions) are never issued.
+        d_params = [p for p in self.netD.parameters() if p.requires_grad]
+        for p in d_params:
+            p.requires_grad_(False)
+        try:
+            f_fake = self.netD.tail(eb, im, pred).view(-1)
+        finally:
+            for p in d_params:
+                p.requires_grad_(True)
         gen = -f_fake.sum() / plan.n_fake
         if plan.n_vis > 0 and any(plan.vis):
             y = torch.cat(ys, dim=0)
