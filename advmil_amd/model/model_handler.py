@@ -106,6 +106,8 @@ class MyHandler(object):
         self.real_fake_loss = partial(real_fake_loss, which=cfg["loss_netD"])
         self.supervised_loss = partial(recon_loss, **sparse_key(cfg, prefixes="loss_recon"))
         self.supervised_terms = partial(recon_terms, **sparse_key(cfg, prefixes="loss_recon"))
+        self._recon = dict(alpha=0.0, gamma=1.0, norm="l1")
+        self._recon.update(sparse_key(cfg, prefixes="loss_recon"))
         self.coef_ganloss = cfg["loss_gan_coef"]
         self.coef_l1 = 0.0 if cfg["loss_regl1_coef"] is None else float(cfg["loss_regl1_coef"])
         opt_cfg = SimpleNamespace(opt=cfg["opt_netG"], weight_decay=cfg["opt_netG_weight_decay"], lr=cfg["opt_netG_lr"],
@@ -316,16 +318,12 @@ class MyHandler(object):
         else:
             eb, im = self.netD.bag_features_multi(emb, plan.seg16)
             f_fake = self.netD.tail(eb, im, pred).view(-1)
-        tr, tf = real_fake_terms(f_real, f_fake, self.which_loss)
-        loss = tf.sum() / plan.n_fake
-        s_real = torch.zeros((), device=dev)
-        if tr is not None:
-            # a 0/1 mask instead of f_real[real_idx]: same sum, and the backward is a multiply instead of an index_put (sort)
-            loss = loss + (tr * plan.real_mask).sum() / plan.n_real
-            s_real = (f_real.detach() * plan.real_mask).sum()
+        # real_fake_loss with the global denominators (loss/utils.py:182-203, model_handler.py:412) as ONE launch that also yields
+        # d loss / d score; the real pairs are selected by a 0/1 mask (same sum as f_real[event & visible], no index backward)
+        loss, st = ops.gan_d_loss(f_fake, f_real, None if f_real is None else plan.real_mask, self.which_loss, plan.n_fake, plan.n_real)
         loss.backward()
-        self.log({"train_batch/netD/Loss_D": loss.detach(), "train_batch/netD/D_real": s_real / max(plan.n_real, 1),
-                  "train_batch/netD/D_fake": f_fake.detach().sum() / plan.n_fake, "i_batch": i_batch})
+        self.log({"train_batch/netD/Loss_D": st[0], "train_batch/netD/D_real": st[1] / max(plan.n_real, 1),
+                  "train_batch/netD/D_fake": st[2] / plan.n_fake, "i_batch": i_batch})
         preds = list(pred.split(1, dim=0))
         fakes = list(f_fake.detach().split(1, dim=0))
         return preds, fakes
@@ -368,23 +366,19 @@ class MyHandler(object):
         finally:
             for p in d_params:
                 p.requires_grad_(True)
-        gen = -f_fake.sum() / plan.n_fake
-        if plan.n_vis > 0 and any(plan.vis):
-            y = torch.cat(ys, dim=0)
-            terms = self.supervised_terms(pred, y[:, 0:1], y[:, 1:2])          # per bag; the mean is over visible labels
-            if plan.vis_mask is not None:
-                terms = terms * plan.vis_mask
-            reg = terms.sum() / plan.n_vis
-        else:
-            reg = torch.zeros((), device=dev)
-        total = reg + self.coef_ganloss * gen if self.coef_ganloss != 0.0 else reg
+        # gen_total = recon_loss over the visible labels + coef * (-mean f_fake) (model_handler.py:468-486) as ONE launch that also
+        # yields the gradients w.r.t. pred and f_fake
+        y = torch.cat(ys, dim=0)
+        n_vis = plan.n_vis if (plan.n_vis > 0 and any(plan.vis)) else 0
+        rc = self._recon
+        total, st = ops.gan_g_loss(pred, f_fake, y[:, 0:1], y[:, 1:2], plan.vis_mask, rc["alpha"], rc["gamma"], rc["norm"],
+                                   self.coef_ganloss, plan.n_fake, n_vis)
         total.backward()
-        total = total.detach()
+        total = st[0]
         if self.coef_l1 > 1e-8:
             total = total + self.coef_l1 * ops.abs_sum(self.optimizerG.flat_param)[0]
-        self.log({"train_batch/netG/Loss_G_fake": gen.detach(), "train_batch/netG/Loss_G_time": reg.detach(),
-                  "train_batch/netG/Loss_G_total": total, "train_batch/netG/D_fake_avg": f_fake.detach().sum() / plan.n_fake,
-                  "i_batch": i_batch})
+        self.log({"train_batch/netG/Loss_G_fake": st[2], "train_batch/netG/Loss_G_time": st[1],
+                  "train_batch/netG/Loss_G_total": total, "train_batch/netG/D_fake_avg": -st[2], "i_batch": i_batch})
 
     def _gen_apply(self):
         self.dp.allreduce_(self.optimizerG.flat_grad)

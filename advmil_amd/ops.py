@@ -1132,3 +1132,66 @@ def gated_attn_pool_bf16(h, Wa, ba, Wb, bb, wc, bc, p=0.0, rng=None, tag="", seg
         seed = rng.seed
     pooled, A, s = GatedAttnPoolBf16Fn.apply(h, hb[0], hb[1], Wa, ba, Wb, bb, wc, bc, float(p), seed, sa, sb, seg)
     return (pooled[0] if seg is None else pooled), A, s
+
+
+# ---------------------------------------------------------------------------------------
+# the step's scalar losses: value + analytic gradient in one launch (advmil_gan_d_loss / advmil_gan_g_loss)
+# ---------------------------------------------------------------------------------------
+_WHICH = {"bce": 0, "hinge": 1, "wasserstein": 2}
+
+
+class GanDLossFn(torch.autograd.Function):
+    """loss = sum_i term_f(fake_i) / n_fake + sum_i mask_i term_r(real_i) / n_real; also returns sum mask*real and sum fake."""
+
+    @staticmethod
+    def forward(ctx, fake, real, mask, which, inv_nf, inv_nr):
+        fake = fake.contiguous().reshape(-1)
+        nr = 0 if real is None else real.numel()
+        real_c = None if real is None else real.contiguous().reshape(-1)
+        out = torch.empty(3, dtype=torch.float32, device=fake.device)
+        gf = torch.empty_like(fake)
+        gr = None if real is None else torch.empty_like(real_c)
+        _lib.check(_lib.lib().advmil_gan_d_loss(_p(fake), fake.numel(), _p(real_c), _p(mask), nr, which, inv_nf, inv_nr, _p(out), _p(gf),
+                                                _p(gr), _stream()), "gan_d_loss")
+        ctx.save_for_backward(gf, gr if gr is not None else gf)
+        ctx.has_real = real is not None
+        ctx.shapes = (fake.shape, None if real is None else real.shape)
+        ctx.mark_non_differentiable(out)
+        return out[0], out
+
+    @staticmethod
+    def backward(ctx, go, _):
+        gf, gr = ctx.saved_tensors
+        return gf * go, (gr * go).reshape(ctx.shapes[1]) if ctx.has_real else None, None, None, None, None
+
+
+def gan_d_loss(fake, real, real_mask, which, n_fake, n_real):
+    """-> (loss [0-dim, differentiable], stats[3] = {loss, sum mask*real, sum fake})."""
+    return GanDLossFn.apply(fake, real, real_mask, _WHICH[which], 1.0 / float(n_fake), (1.0 / float(n_real)) if n_real > 0 else 0.0)
+
+
+class GanGLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, fake, t, e, vis, alpha, gamma, l2, coef, inv_nf, inv_nv):
+        shape = pred.shape
+        pred_c, fake_c = pred.contiguous().reshape(-1), fake.contiguous().reshape(-1)
+        out = torch.empty(3, dtype=torch.float32, device=pred.device)
+        gp, gf = torch.empty_like(pred_c), torch.empty_like(fake_c)
+        t_c, e_c = t.contiguous().reshape(-1), e.contiguous().reshape(-1)      # named: a temporary's block would be reused at once
+        _lib.check(_lib.lib().advmil_gan_g_loss(_p(pred_c), _p(t_c), _p(e_c), _p(vis), _p(fake_c), pred_c.numel(), alpha, gamma, l2,
+                                                coef, inv_nf, inv_nv, _p(out), _p(gp), _p(gf), _stream()), "gan_g_loss")
+        ctx.save_for_backward(gp, gf)
+        ctx.shapes = (shape, fake.shape)
+        ctx.mark_non_differentiable(out)
+        return out[0], out
+
+    @staticmethod
+    def backward(ctx, go, _):
+        gp, gf = ctx.saved_tensors
+        return (gp * go).reshape(ctx.shapes[0]), (gf * go).reshape(ctx.shapes[1]), None, None, None, None, None, None, None, None, None
+
+
+def gan_g_loss(pred, fake, t, e, vis_mask, alpha, gamma, norm, coef, n_fake, n_vis):
+    """-> (total [0-dim, differentiable], stats[3] = {total, reg, gen}); reg = 0 when no label is visible (n_vis == 0)."""
+    return GanGLossFn.apply(pred, fake, t, e, vis_mask, float(alpha), float(gamma), 1 if norm == "l2" else 0, float(coef),
+                            1.0 / float(n_fake), (1.0 / float(n_vis)) if n_vis > 0 else 0.0)

@@ -243,6 +243,17 @@ int advmil_uniform_fill(float* out, int64_t n, const uint64_t* seed, uint64_t st
 int advmil_dropout_apply(const float* x, float* y, int64_t n, float p, const uint64_t* seed, uint64_t stream_id,
                          advmil_stream_t stream);
 int advmil_seed_advance(uint64_t* seed, uint64_t inc, advmil_stream_t stream);
+/* The step's two scalar losses over <= bp_every_batch values, value and analytic gradient in one launch each.
+ * D loss (loss/utils.py:182-203 real_fake_loss with the reference's means taken over the GLOBAL counts, model_handler.py:412):
+ *   which 0 = bce as shipped, 1 = hinge, 2 = wasserstein; real_mask selects the real pairs (event bags with a visible label);
+ *   out3 = {loss, sum mask*real, sum fake}; g_fake / g_real = d loss / d score.
+ * G loss (model_handler.py:468-486): total = reg + coef*gen, reg = inv_nv * sum vis*recon_term (loss/utils.py:21-41), gen = -inv_nf*sum fake;
+ *   out3 = {total, reg, gen}; g_pred / g_fake = d total / d (pred, fake). */
+int advmil_gan_d_loss(const float* fake, int nf, const float* real, const float* real_mask, int nr, int which, float inv_nf,
+                      float inv_nr, float* out3, float* g_fake, float* g_real, advmil_stream_t stream);
+int advmil_gan_g_loss(const float* pred, const float* t, const float* e, const float* vis_mask, const float* fake, int n, float alpha,
+                      float gamma, int l2, float coef, float inv_nf, float inv_nv, float* out3, float* g_pred, float* g_fake,
+                      advmil_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Evaluator: concordance index for right-censored data, eval/cindex.py:79-143 (`_get_comparable`,

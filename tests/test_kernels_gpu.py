@@ -369,3 +369,44 @@ def test_gemm_fused_gate_score(ops, mode, tile):
         assert float((got - want).abs().max()) < 2e-5, float((got - want).abs().max())
     finally:
         ops.set_gemm_mode(prev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["bce", "hinge", "wasserstein"])
+def test_fused_gan_losses_match_composed_torch(ops, which):
+    """advmil_gan_d_loss / advmil_gan_g_loss (value + analytic gradients in one launch) against the composed torch losses."""
+    from advmil_amd.loss.utils import real_fake_terms, recon_terms
+    g = torch.Generator(device="cuda").manual_seed(8)
+    nb = 16
+    fake = (torch.randn(nb, device="cuda", generator=g) * 2).requires_grad_(True)
+    real = (torch.randn(nb, device="cuda", generator=g) * 2).requires_grad_(True)
+    mask = (torch.rand(nb, device="cuda", generator=g) < 0.5).float()
+    n_real, n_fake = 11.0, 32.0           # global denominators differ from the local counts under bag-parallel
+    tr, tf = real_fake_terms(real, fake, which)
+    want = tf.sum() / n_fake + (tr * mask).sum() / n_real
+    want.backward()
+    wf, wr = fake.grad.clone(), real.grad.clone()
+    fake.grad = real.grad = None
+    got, st = ops.gan_d_loss(fake, real, mask, which, n_fake, n_real)
+    (got * 1.5).backward()
+    assert abs(float(got) - float(want)) < 1e-6 and abs(float(st[1]) - float((real * mask).sum())) < 1e-5
+    assert float((fake.grad / 1.5 - wf).abs().max()) < 1e-7 and float((real.grad / 1.5 - wr).abs().max()) < 1e-7
+    got2, _ = ops.gan_d_loss(fake.detach().requires_grad_(True), None, None, which, n_fake, 0)       # no real pair in the step
+    assert abs(float(got2) - float(tf.sum() / n_fake)) < 1e-6
+    # generator loss
+    for norm, alpha, gamma, vis in [("l1", 0.0, 0.0, None), ("l2", 0.3, 0.2, (torch.rand(nb, device="cuda", generator=g) < 0.6).float())]:
+        pred = torch.rand(nb, 1, device="cuda", generator=g).requires_grad_(True)
+        ff = torch.randn(nb, device="cuda", generator=g).requires_grad_(True)
+        t, e = torch.rand(nb, 1, device="cuda", generator=g), (torch.rand(nb, 1, device="cuda", generator=g) < 0.5).float()
+        terms = recon_terms(pred, t, e, alpha, gamma, norm)
+        n_vis = 9.0
+        reg = (terms if vis is None else terms * vis).sum() / n_vis
+        gen = -ff.sum() / n_fake
+        want = reg + 0.004 * gen
+        want.backward()
+        wp, wf = pred.grad.clone(), ff.grad.clone()
+        pred.grad = ff.grad = None
+        got, st = ops.gan_g_loss(pred, ff, t, e, vis, alpha, gamma, norm, 0.004, n_fake, n_vis)
+        got.backward()
+        assert abs(float(got) - float(want)) < 1e-6 and abs(float(st[1]) - float(reg)) < 1e-6 and abs(float(st[2]) - float(gen)) < 1e-6
+        assert float((pred.grad - wp).abs().max()) < 1e-7 and float((ff.grad - wf).abs().max()) < 1e-8
