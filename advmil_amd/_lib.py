@@ -90,6 +90,9 @@ SIGNATURES = {
     "advmil_uniform_fill": (c_int, [c_void_p, c_int64, c_void_p, c_uint64, c_void_p]),
     "advmil_dropout_apply": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_uint64, c_void_p]),
     "advmil_seed_advance": (c_int, [c_void_p, c_uint64, c_void_p]),
+    "advmil_skinny_linear_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "advmil_skinny_linear_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                         c_void_p, c_int, c_void_p]),
     "advmil_gan_d_loss": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "advmil_gan_g_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_int, c_float, c_float,
                                   c_float, c_void_p, c_void_p, c_void_p, c_void_p]),

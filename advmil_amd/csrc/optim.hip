@@ -215,3 +215,64 @@ extern "C" int advmil_gan_g_loss(const float* pred, const float* t, const float*
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }
+
+// =====================================================================================
+// Skinny Linear layers of the heads (in_features == 1: the first layer of the y-embedding, model_utils.py:178-186; out_features
+// == 1: the projection layer GANSurv.py:78-84 and the generator's output layer): y[b,n] = act(sum_k x[b,k] W[n,k] + bias[n]) for
+// B <= a step's bags. One launch forward; one launch backward producing dx, dW, dbias (accumulated into the caller's buffers).
+// =====================================================================================
+__global__ __launch_bounds__(256) void skinny_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                                const float* __restrict__ bias, int B, int K, int N, int act,
+                                                                float* __restrict__ y) {
+  for (int o = blockIdx.x * 256 + threadIdx.x; o < B * N; o += gridDim.x * 256) {
+    const int b = o / N, n = o % N;
+    float s = bias ? bias[n] : 0.0f;
+    for (int k = 0; k < K; ++k) s += x[(int64_t)b * K + k] * W[(int64_t)n * K + k];
+    y[o] = act_apply(act, s);
+  }
+}
+
+// outputs indexed 0..N*K-1: dW; N*K..N*K+N-1: dbias; then B*K: dx
+__global__ __launch_bounds__(256) void skinny_linear_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                                const float* __restrict__ y, const float* __restrict__ dy, int B,
+                                                                int K, int N, int act, float* __restrict__ dx,
+                                                                float* __restrict__ dW, float* __restrict__ dbias, int accumulate) {
+  const int nW = dW ? N * K : 0, nb = dbias ? N : 0, nx = dx ? B * K : 0;
+  for (int o = blockIdx.x * 256 + threadIdx.x; o < nW + nb + nx; o += gridDim.x * 256) {
+    if (o < nW) {
+      const int n = o / K, k = o % K;
+      float s = 0.0f;
+      for (int b = 0; b < B; ++b) s += dy[b * N + n] * act_grad_from_out(act, y[b * N + n]) * x[(int64_t)b * K + k];
+      dW[o] = accumulate ? dW[o] + s : s;
+    } else if (o < nW + nb) {
+      const int n = o - nW;
+      float s = 0.0f;
+      for (int b = 0; b < B; ++b) s += dy[b * N + n] * act_grad_from_out(act, y[b * N + n]);
+      dbias[n] = accumulate ? dbias[n] + s : s;
+    } else {
+      const int q = o - nW - nb, b = q / K, k = q % K;
+      float s = 0.0f;
+      for (int n = 0; n < N; ++n) s += dy[b * N + n] * act_grad_from_out(act, y[b * N + n]) * W[(int64_t)n * K + k];
+      dx[q] = s;
+    }
+  }
+}
+
+extern "C" int advmil_skinny_linear_fwd(const float* x, const float* W, const float* bias, int B, int K, int N, int act, float* y,
+                                        advmil_stream_t stream_) {
+  if (!x || !W || !y || B <= 0 || K <= 0 || N <= 0 || (int64_t)B * N > (1 << 20) || (K != 1 && N != 1)) return ADVMIL_EINVAL;
+  hipLaunchKernelGGL(skinny_linear_fwd_kernel, dim3((B * N + 255) / 256), dim3(256), 0, (hipStream_t)stream_, x, W, bias, B, K, N, act, y);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}
+
+extern "C" int advmil_skinny_linear_bwd(const float* x, const float* W, const float* y, const float* dy, int B, int K, int N, int act,
+                                        float* dx, float* dW, float* dbias, int accumulate, advmil_stream_t stream_) {
+  if (!x || !W || !y || !dy || B <= 0 || K <= 0 || N <= 0 || (K != 1 && N != 1)) return ADVMIL_EINVAL;
+  const int total = (dW ? N * K : 0) + (dbias ? N : 0) + (dx ? B * K : 0);
+  if (total == 0) return ADVMIL_OK;
+  hipLaunchKernelGGL(skinny_linear_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream_, x, W, y, dy, B, K, N, act,
+                     dx, dW, dbias, accumulate);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}

@@ -145,7 +145,8 @@ class PrjDiscriminator(_PairNet):
             out = (ins_mean * hid_t).sum(dim=-1, keepdim=True)
         if self.prj_layer is not None:
             src = hid_x if self.prj_path == "x" else hid_t
-            out = out + nn.functional.linear(src, self.prj_layer.weight, self.prj_layer.bias)
+            out = out + (ops.skinny_linear(src, self.prj_layer.weight, self.prj_layer.bias) if src.shape[0] <= 256
+                         else nn.functional.linear(src, self.prj_layer.weight, self.prj_layer.bias))
         return out
 
     def from_embedding(self, emb_ins, t):

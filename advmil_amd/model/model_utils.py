@@ -107,6 +107,14 @@ def run_mlp_small(seq, x, rng, tag):
                 x = ops.linear_act(x, m.weight, m.bias, act, p, rng, f"{tag}.{k - 1}")   # the Dropout module's index names the draw
                 j = k
                 continue
+            if x.dim() == 2 and x.is_cuda and (m.in_features == 1 or m.out_features == 1) and x.shape[0] <= 256:
+                # in/out width 1 (first layer of the y-embedding, output layers): one launch each way; a following ReLU rides along
+                act, k = "none", j + 1
+                if k < len(mods) and isinstance(mods[k], nn.ReLU):
+                    act, k = "relu", k + 1
+                x = ops.skinny_linear(x, m.weight, m.bias, act)
+                j = k
+                continue
             x = F.linear(x, m.weight, m.bias)
         elif isinstance(m, nn.LayerNorm):
             x = F.layer_norm(x, m.normalized_shape, m.weight, m.bias, m.eps)

@@ -1195,3 +1195,44 @@ def gan_g_loss(pred, fake, t, e, vis_mask, alpha, gamma, norm, coef, n_fake, n_v
     """-> (total [0-dim, differentiable], stats[3] = {total, reg, gen}); reg = 0 when no label is visible (n_vis == 0)."""
     return GanGLossFn.apply(pred, fake, t, e, vis_mask, float(alpha), float(gamma), 1 if norm == "l2" else 0, float(coef),
                             1.0 / float(n_fake), (1.0 / float(n_vis)) if n_vis > 0 else 0.0)
+
+
+class SkinnyLinearFn(torch.autograd.Function):
+    """y = act(x W^T + b) for in_features == 1 or out_features == 1 (advmil_skinny_linear_fwd/bwd): one launch each way, weight
+    and bias gradients accumulated straight into the optimizer arena when the parameters live there."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act):
+        x = x.contiguous()
+        W2 = W.detach().reshape(W.shape[0], -1).contiguous()
+        B, K = x.shape
+        N = W2.shape[0]
+        y = torch.empty(B, N, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().advmil_skinny_linear_fwd(_p(x), _p(W2), _p(b), B, K, N, act, _p(y), _stream()), "skinny_linear_fwd")
+        ctx.save_for_backward(x, W2, y)
+        ctx.cfg = (act, B, K, N, W.shape, b is not None)
+        ctx.gW, ctx.gb = _arena_grad(W), _arena_grad(b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W2, y = ctx.saved_tensors
+        act, B, K, N, wshape, has_b = ctx.cfg
+        dy = dy.contiguous()
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_b and ctx.needs_input_grad[2]
+        dx = torch.empty(B, K, dtype=torch.float32, device=dy.device) if need_x else None
+        arena = need_w and ctx.gW is not None and (not need_b or ctx.gb is not None)
+        if arena:
+            dW, db = ctx.gW, (ctx.gb if need_b else None)
+        else:
+            dW = torch.empty(N, K, dtype=torch.float32, device=dy.device) if need_w else None
+            db = torch.empty(N, dtype=torch.float32, device=dy.device) if need_b else None
+        _lib.check(_lib.lib().advmil_skinny_linear_bwd(_p(x), _p(W2), _p(y), _p(dy), B, K, N, act, _p(dx), _p(dW), _p(db),
+                                                       1 if arena else 0, _stream()), "skinny_linear_bwd")
+        if arena:
+            return dx, None, None, None
+        return dx, (None if dW is None else dW.reshape(wshape)), db, None
+
+
+def skinny_linear(x, W, b, act="none"):
+    return SkinnyLinearFn.apply(x, W, b, _ACT[act])

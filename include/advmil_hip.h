@@ -249,6 +249,13 @@ int advmil_seed_advance(uint64_t* seed, uint64_t inc, advmil_stream_t stream);
  *   out3 = {loss, sum mask*real, sum fake}; g_fake / g_real = d loss / d score.
  * G loss (model_handler.py:468-486): total = reg + coef*gen, reg = inv_nv * sum vis*recon_term (loss/utils.py:21-41), gen = -inv_nf*sum fake;
  *   out3 = {total, reg, gen}; g_pred / g_fake = d total / d (pred, fake). */
+/* Linear layers with in_features == 1 or out_features == 1 on [B, .] head tensors (first layer of make_embedding_y_layer,
+ * model_utils.py:178-186; prj_layer, GANSurv.py:78-84; the generator's output layer): y = act(x W^T + bias), x[B,K], W[N,K].
+ * bwd: dx (may be NULL), dW / dbias (may be NULL; accumulate != 0 adds into them), dpre = dy * act'(y). */
+int advmil_skinny_linear_fwd(const float* x, const float* W, const float* bias, int B, int K, int N, int act, float* y,
+                             advmil_stream_t stream);
+int advmil_skinny_linear_bwd(const float* x, const float* W, const float* y, const float* dy, int B, int K, int N, int act, float* dx,
+                             float* dW, float* dbias, int accumulate, advmil_stream_t stream);
 int advmil_gan_d_loss(const float* fake, int nf, const float* real, const float* real_mask, int nr, int which, float inv_nf,
                       float inv_nr, float* out3, float* g_fake, float* g_real, advmil_stream_t stream);
 int advmil_gan_g_loss(const float* pred, const float* t, const float* e, const float* vis_mask, const float* fake, int n, float alpha,

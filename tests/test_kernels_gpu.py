@@ -410,3 +410,23 @@ def test_fused_gan_losses_match_composed_torch(ops, which):
         got.backward()
         assert abs(float(got) - float(want)) < 1e-6 and abs(float(st[1]) - float(reg)) < 1e-6 and abs(float(st[2]) - float(gen)) < 1e-6
         assert float((pred.grad - wp).abs().max()) < 1e-7 and float((ff.grad - wf).abs().max()) < 1e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,K,N", [(16, 1, 64), (32, 128, 1), (5, 192, 1), (1, 1, 1)])
+@pytest.mark.parametrize("act", ["none", "relu"])
+def test_skinny_linear_fwd_bwd(ops, B, K, N, act):
+    g = torch.Generator(device="cuda").manual_seed(13)
+    x = torch.randn(B, K, device="cuda", generator=g).requires_grad_(True)
+    W = (torch.randn(N, K, device="cuda", generator=g) * 0.3).requires_grad_(True)
+    b = torch.randn(N, device="cuda", generator=g).requires_grad_(True)
+    w = torch.randn(B, N, device="cuda", generator=g)
+    y = ops.skinny_linear(x, W, b, act)
+    (y * w).sum().backward()
+    got = (y.detach().clone(), x.grad.clone(), W.grad.clone(), b.grad.clone())
+    x.grad = W.grad = b.grad = None
+    ref = torch.nn.functional.linear(x, W, b)
+    ref = torch.relu(ref) if act == "relu" else ref
+    (ref * w).sum().backward()
+    for a, c in zip(got, (ref.detach(), x.grad, W.grad, b.grad)):
+        assert float((a - c).abs().max()) < 1e-5 * (1.0 + float(c.abs().max()))
