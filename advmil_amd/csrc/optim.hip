@@ -224,6 +224,16 @@ extern "C" int advmil_gan_g_loss(const float* pred, const float* t, const float*
 __global__ __launch_bounds__(256) void skinny_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                                 const float* __restrict__ bias, int B, int K, int N, int act,
                                                                 float* __restrict__ y) {
+  if (N == 1) {             // one wave per row: lanes stride over k (a single thread walking K = 128..768 took 12-14 us)
+    const int lane = threadIdx.x & 63;
+    for (int b = blockIdx.x * 4 + (threadIdx.x >> 6); b < B; b += gridDim.x * 4) {
+      float s = 0.0f;
+      for (int k = lane; k < K; k += 64) s += x[(int64_t)b * K + k] * W[k];
+      s = wave_sum(s);
+      if (lane == 0) y[b] = act_apply(act, s + (bias ? bias[0] : 0.0f));
+    }
+    return;
+  }
   for (int o = blockIdx.x * 256 + threadIdx.x; o < B * N; o += gridDim.x * 256) {
     const int b = o / N, n = o % N;
     float s = bias ? bias[n] : 0.0f;
@@ -261,7 +271,8 @@ __global__ __launch_bounds__(256) void skinny_linear_bwd_kernel(const float* __r
 extern "C" int advmil_skinny_linear_fwd(const float* x, const float* W, const float* bias, int B, int K, int N, int act, float* y,
                                         advmil_stream_t stream_) {
   if (!x || !W || !y || B <= 0 || K <= 0 || N <= 0 || (int64_t)B * N > (1 << 20) || (K != 1 && N != 1)) return ADVMIL_EINVAL;
-  hipLaunchKernelGGL(skinny_linear_fwd_kernel, dim3((B * N + 255) / 256), dim3(256), 0, (hipStream_t)stream_, x, W, bias, B, K, N, act, y);
+  const int blocks = N == 1 ? (B + 3) / 4 : (B * N + 255) / 256;
+  hipLaunchKernelGGL(skinny_linear_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, x, W, bias, B, K, N, act, y);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }
