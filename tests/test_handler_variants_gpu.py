@@ -242,3 +242,45 @@ def test_forward_memo_is_consumed_and_cleared():
         assert len(ops.MEMO.store) == 0
     finally:
         ops.MEMO_MIN_ROWS = old
+
+
+def test_two_generator_updates_per_step():
+    """gen_updates = 2 (model_handler.py:341-342): the second generator update sees updated G weights, so the forward memo of the
+    eval pass must not be reused for it, and D stays frozen in both; compared with the oracle's update_gen applied twice."""
+    from advmil_amd.model import MyHandler
+    nb, lens = 3, (256, 128, 64)
+    h = MyHandler(default_cfg(bcb_mode="abmil", bp_every_batch=nb, gen_updates=2), device=DEV)
+    PG, PD = load_synth(h.netG, "G-abmil:"), load_synth(h.netD, "D-prj:")
+    zero_dropout(h.netG); zero_dropout(h.netD)
+    bags, loader = [], []
+    for i in range(nb):
+        x = H.bag(60 + i, 512)[:, :lens[i]].contiguous()
+        y = H.label(i)
+        bags.append((x, None, y)); loader.append((torch.tensor([[i]], dtype=torch.int), [x, torch.zeros(1, 1)], y))
+    nd = [[H.noise_tensor("gu_d", i, 192)] for i in range(nb)]
+    ng = [[H.noise_tensor("gu_g", i, 192)] for i in range(nb)]
+    h.noise_hook = lambda ph, i: [(nd if ph == "d" else ng)[i][0].to(DEV)]
+    from advmil_amd import ops
+    old = ops.MEMO_MIN_ROWS
+    ops.MEMO_MIN_ROWS = 1                                   # make the memo active at this size
+    try:
+        h._train_each_epoch(loader, "train", "wlabel")
+    finally:
+        ops.MEMO_MIN_ROWS = old
+    logs = h.pop_logs()
+    assert len(logs) == 3                                   # D, G, G
+    cfg = O.StepConfig(kind="abmil")
+    stG, stD = {}, {}
+    ld, gD, _, _ = O.update_disc(cfg, PG, PD, bags, nd, None, None)
+    PD2 = O.adam_step(PD, gD, stD, cfg.lr_d, 0.0, decay_filter=False)
+    oPG = PG
+    for k in range(2):
+        lg, gG, _ = O.update_gen(cfg, oPG, PD2, bags, ng, None)
+        oPG = O.adam_step(oPG, gG, stG, cfg.lr_g, cfg.wd_g, decay_filter=True)
+        got = {kk.split("/")[-1]: v for kk, v in logs[1 + k].items()}
+        for kk in ("Loss_G_fake", "Loss_G_time", "Loss_G_total"):
+            assert abs(got[kk] - lg[kk]) < 2e-5, (k, kk, got[kk], lg[kk])
+    for kk, v in h.netD.state_dict().items():               # D only moved by its own update
+        if kk.endswith("pool.fc2.bias"):
+            continue
+        assert float((v.cpu() - PD2[kk]).abs().max()) < 5e-5, kk
