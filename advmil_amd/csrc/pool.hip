@@ -230,6 +230,53 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restri
     *reinterpret_cast<float4*>(partial + ((int64_t)b * gridDim.x + blockIdx.x) * D + m.c4 * 4) = t;
 }
 
+// Same contract as pool_partial_kernel for D % 8 == 0: every thread owns 8 consecutive columns (two 16-byte loads per row), so at
+// D = 384 a workgroup walks 5 rows per pass with 240 of its 256 threads (the float4 mapping: 2 rows, 192 threads), and the row loop
+// is unrolled with predicates so that 4 rows of loads are in flight per thread. Measured on the 16 x 8192 x 384 slab: the pooling
+// call (statistics + this + merge) 61.9 us -> see DESIGN.md section 5 (pool_roofline of the bench line).
+__global__ __launch_bounds__(256) void pool_partial8_kernel(const float* __restrict__ s, const float* __restrict__ h, int64_t ldh,
+                                                            int64_t N, int64_t D, const int64_t* __restrict__ seg_ptr,
+                                                            const float* __restrict__ stats, float* __restrict__ A,
+                                                            float* __restrict__ partial, int rpb) {
+  __shared__ __attribute__((aligned(16))) float red[2048];      // rpp * D <= 256 / (D/8) * D = 2048 floats
+  const int cols8 = (int)(D >> 3), rpp = 256 / cols8;
+  const int c8 = threadIdx.x % cols8, rl = threadIdx.x / cols8;
+  const int b = blockIdx.y;
+  int64_t beg, end;
+  seg_range(seg_ptr, b, N, beg, end);
+  const float mx = stats[2 * b], inv = stats[2 * b + 1];
+  const int64_t r0 = beg + (int64_t)blockIdx.x * rpb;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (rl < rpp) {
+#pragma unroll 4
+    for (int r = rl; r < rpb; r += rpp) {
+      const int64_t n = r0 + r;
+      const bool ok = n < end;
+      const int64_t nn = ok ? n : beg;                     // predicated: keeps the unrolled loads independent of the bound
+      const float w = ok ? expf(s[nn] - mx) * inv : 0.f;
+      const float4 v0 = *reinterpret_cast<const float4*>(h + nn * ldh + c8 * 8);
+      const float4 v1 = *reinterpret_cast<const float4*>(h + nn * ldh + c8 * 8 + 4);
+      if (ok && c8 == 0) A[n] = w;
+      acc[0] += w * v0.x; acc[1] += w * v0.y; acc[2] += w * v0.z; acc[3] += w * v0.w;
+      acc[4] += w * v1.x; acc[5] += w * v1.y; acc[6] += w * v1.z; acc[7] += w * v1.w;
+    }
+    float* dst = red + (int64_t)rl * D + c8 * 8;
+    *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < (int)(D >> 2)) {                     // blocks past the segment's end contribute zeros
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < rpp; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(red + (int64_t)q * D + threadIdx.x * 4);
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    *reinterpret_cast<float4*>(partial + ((int64_t)b * gridDim.x + blockIdx.x) * D + threadIdx.x * 4) = t;
+  }
+}
+
 static inline int64_t pool_nblk(int64_t max_len) { const int r = rows_per_block(max_len); return (max_len + r - 1) / r; }
 
 extern "C" size_t advmil_softmax_pool_workspace_bytes(int64_t max_len, int64_t D, int nseg) {
@@ -252,8 +299,12 @@ extern "C" int advmil_softmax_pool_fwd(const float* s, const float* h, int64_t l
   const int nblk = (int)pool_nblk(max_len);
   hipLaunchKernelGGL(softmax_stats_kernel, dim3(nseg), dim3(1024), 0, stream, s, N, seg_ptr, stats);
   ADVMIL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(pool_partial_kernel, dim3(nblk, nseg), dim3(256), 0, stream, s, h, ldh, N, D, seg_ptr, stats, A, partial,
-                     rows_per_block(max_len));
+  if ((D & 7) == 0 && D >= 16)
+    hipLaunchKernelGGL(pool_partial8_kernel, dim3(nblk, nseg), dim3(256), 0, stream, s, h, ldh, N, D, seg_ptr, stats, A, partial,
+                       rows_per_block(max_len));
+  else
+    hipLaunchKernelGGL(pool_partial_kernel, dim3(nblk, nseg), dim3(256), 0, stream, s, h, ldh, N, D, seg_ptr, stats, A, partial,
+                       rows_per_block(max_len));
   ADVMIL_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_merge_kernel, dim3((unsigned)((D + 15) / 16), nseg), dim3(256), 0, stream, partial, nblk, D, D, pooled,
                      0, (int64_t)nblk * D, D);

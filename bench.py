@@ -357,6 +357,38 @@ def main():
         finally:
             ops.set_gemm_mode(args.gemm_mode)
 
+    # ---- the attention-pool kernels against the HBM roof (north star: ">= 50% of HBM3E roofline"): segmented softmax statistics +
+    # weighted row sum + merge over the step slab's hidden rows h[sum N, 384]; algorithmic bytes = h read once + scores read twice
+    # + attention weights written once. Slabs rotate so that h does not sit in the 256 MB Infinity Cache.
+    pool_roof = None
+    if rank == 0 and not args.no_roofline and args.mode == "abmil":
+        try:
+            Dh = 384
+            nrows = args.bags * args.patches
+            nbuf = max(2, int(600e6 // (4 * nrows * Dh)) + 1)
+            hs = [torch.randn(nrows, Dh, device=dev) for _ in range(nbuf)]
+            sc = torch.randn(nrows, device=dev)
+            seg_b = ops.Segments([args.patches] * args.bags, dev)
+            for k in range(3):
+                ops.softmax_pool(sc, hs[k % nbuf], nrows, Dh, seg_b)
+            torch.cuda.synchronize()
+            itp = 40
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for k in range(itp):
+                ops.softmax_pool(sc, hs[k % nbuf], nrows, Dh, seg_b)
+            e1.record()
+            torch.cuda.synchronize()
+            usp = e0.elapsed_time(e1) * 1e3 / itp
+            byt = 4.0 * nrows * Dh + 3 * 4.0 * nrows
+            pool_roof = {"bound": "hbm", "kernel": "softmax_stats + pool_partial + colsum_merge (advmil_softmax_pool_fwd)",
+                         "rows": nrows, "achieved": round(byt / usp / 1e3, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(byt / usp / 1e3 / 8000.0, 4), "avg_call_us": round(usp, 2), "algorithmic_bytes_per_call": byt,
+                         "method": "40 back-to-back calls (3 launches each) between two HIP events, rotating slabs > 256 MB"}
+            del hs
+        except Exception as exc:
+            pool_roof = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
+
     # ---- extra (single GPU): one bag per optimizer step (bp_every_batch = 1), the reading of the north star's "G+D steps/s"
     # (then steps/s == bags/s)
     bp1_extra = None
@@ -429,7 +461,7 @@ def main():
                        "launch": launch_note},
             "gd_steps_per_sec": round(args.steps / dt, 3), "losses_finite": bool(finite), "replicas_in_sync": in_sync,
             "host_submit_ms_per_step": round(1e3 * t_submit / args.steps, 3),
-            "roofline": roof, "cpu_baseline": cpu, "exact_f32_mfma_mode": exact_extra,
+            "roofline": roof, "pool_roofline": pool_roof, "cpu_baseline": cpu, "exact_f32_mfma_mode": exact_extra,
             "bp_every_batch_1": bp1_extra, "mixed_precision_bf16_generator": bf16_extra,
         }
         print(json.dumps(out), flush=True)
