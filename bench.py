@@ -248,6 +248,14 @@ def main():
     # (2) that exact launch is then timed back-to-back (queue kept full, so no host gaps pollute the per-launch time)
     #     between two HIP events on the same stream. achieved = algorithmic FLOPs per launch / that duration.
     roof = None
+    # The instrumented pass drives full optimizer steps, which contain the two gradient all-reduces: EVERY rank has to run it
+    # (rank 0 alone deadlocks the job at world > 1 -- observed: a 2-rank default-flag run hung until its 900 s timeout).
+    if world > 1 and not args.no_roofline and rank != 0:
+        cursor[0] = 0
+        for _ in range(max(1, min(2, args.steps))):
+            eager_step()
+        torch.cuda.synchronize()
+        h.history.clear()
     if rank == 0 and not args.no_roofline:
         ops.KERNEL_PROFILE = []
         nprof = max(1, min(2, args.steps))
@@ -439,7 +447,7 @@ def main():
             bf16_extra = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only; at N > 1 the other ranks would idle in the barrier
         cpu = cpu_baseline(args, torch)
 
     if rank == 0:

@@ -1,7 +1,9 @@
 #!/bin/bash
 # Exercise the multi-rank bench path (broadcast, global counts, 3-segment graphs, flat-arena all-reduce) with two
+# processes sharing ONE GPU over gloo, with bench.py's DEFAULT flags (what the driver passes at N > 1; an earlier version of this
+# script skipped the roofline / cpu-baseline legs and so never exercised the rank-0-only code that hung the job)
 # processes sharing ONE GPU over gloo (RCCL refuses two ranks on one device; the exchange layer is backend agnostic).
 set -e
 export ADVMIL_DIST_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 \
-    bench.py --gpus 2 --steps 4 --warmup 1 --patches 2048 --pool 8 --bags 4 --no-cpu-baseline --no-roofline
+    bench.py --gpus 2 --steps 4 --warmup 1 --patches 2048 --pool 8 --bags 4
