@@ -42,20 +42,16 @@ SIGNATURES = {
     "advmil_gemm_f32_plan_layout": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "advmil_gemm_f32_tiled": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                                       c_int64, ctypes.POINTER(Epilogue), c_int, c_int, c_void_p, c_size_t, c_void_p]),
-    "advmil_gemm_bf16_plan": (c_int, [c_int64, c_int64, c_int64, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
-    "advmil_gemm_bf16_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
-    "advmil_gemm_bf16_nt": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
-                                    c_int64, c_void_p, c_int64, ctypes.POINTER(Epilogue), c_int, c_int, c_void_p, c_size_t, c_void_p]),
-    "advmil_cast_bf16": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
-    "advmil_gemm_f32_batched": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
-                                        c_int64, c_void_p, c_int64, c_int64, c_int, c_float, c_int, c_void_p]),
-    "advmil_gemm_f32_batched2": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p,
-                                         c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_float,
-                                         c_int, c_void_p]),
-    "advmil_softmax_rows_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_float, c_void_p,
-                                        c_uint64, c_void_p]),
-    "advmil_softmax_rows_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_float, c_void_p,
-                                        c_uint64, c_void_p]),
+    "advmil_mha_fwd": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64, c_float, c_void_p, c_uint64, c_void_p,
+                               c_void_p, c_void_p, c_void_p]),
+    "advmil_mha_bwd_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "advmil_mha_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64, c_float,
+                               c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "advmil_add_dropout_ln_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int64, c_float, c_void_p,
+                                          c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "advmil_add_dropout_ln_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "advmil_add_dropout_ln_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p,
+                                          c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "advmil_gate_score_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_uint64, c_uint64, c_int64, c_int64,
                                       c_void_p, c_void_p]),
     "advmil_softmax_pool_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),

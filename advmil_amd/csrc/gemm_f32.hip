@@ -15,6 +15,7 @@
 //   k-contiguous source: unpadded [row][32] planes with XOR-swizzled 16-byte units, ds_read_b128 fragments;
 //   m-contiguous source: [k][rows+32] planes in source orientation, fragments through the LDS transpose read ds_read_b64_tr_b16.
 #include "common.h"
+#include "bf16split.h"
 #include "../../include/advmil_hip.h"
 
 #define BK 32          // k per chunk of the exact-fp32 variant (and the granularity of split-K chunking)
@@ -39,9 +40,6 @@ struct GemmArgs {
   float* ws;         // [splits][M][N] partials when splits > 1
   int splits;
   int mtiles, ntiles;
-  int64_t sA, sB, sC;   // per-batch element strides (gridDim.z = batch)
-  int nb1;              // inner batch count: z = z2 * nb1 + z1 uses z1 * s? + z2 * s?2 (heads inside bags)
-  int64_t sA2, sB2, sC2;
   advmil_epilogue_t epi;
 };
 
@@ -103,7 +101,6 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ s, int rbase
 // bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate), fp32 accumulate. The dropped terms are ~2^-17 of |a||b|
 // per product (fp32 MFMA: 2^-24), i.e. near-fp32 results at 3/16 of the matrix-pipe time. Operands stay fp32 in HBM; the split
 // happens once per staged element on the way into LDS, which holds two bf16 planes (hi, lo) per operand tile.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // Pre-split LDS image of a k-contiguous operand tile (bf16x3 mode): two bf16 planes [row][BKT], hi then lo, written once per
 // element when the tile is staged (every element is consumed by two waves, so splitting here halves the conversion work and
@@ -113,25 +110,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // 80-byte pitch measured 33% of LDS cycles as bank conflicts: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r01_pmc_sq_bf16x3.json.)
 #define PITCH_PS(BKT) (BKT)
 __device__ __forceinline__ int ps_unit(int row, int unit, int units_per_row) { return unit ^ ((row >> 2) & (units_per_row - 1)); }
-typedef unsigned short bf16raw;
-union Frag8 { uint4 u; bf16x8 v; };
-
-// hi/lo split of 4 consecutive floats into 4+4 bf16, converting PAIRS (one v_cvt_pk_bf16_f32 per two values; the scalar casts
-// compile to one cvt per value): 3 VALU per element instead of 4 in the staging path, which is what the bf16x3 loop is bound by.
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
-  union { bf16x2_t b; unsigned u; } h0, h1, l0, l1;
-  const f32x2_t a = {v.x, v.y}, c = {v.z, v.w};
-  h0.b = __builtin_convertvector(a, bf16x2_t);
-  h1.b = __builtin_convertvector(c, bf16x2_t);
-  const f32x2_t ra = {v.x - __uint_as_float(h0.u << 16), v.y - __uint_as_float(h0.u & 0xffff0000u)};
-  const f32x2_t rc = {v.z - __uint_as_float(h1.u << 16), v.w - __uint_as_float(h1.u & 0xffff0000u)};
-  l0.b = __builtin_convertvector(ra, bf16x2_t);
-  l1.b = __builtin_convertvector(rc, bf16x2_t);
-  hi = make_uint2(h0.u, h1.u);
-  lo = make_uint2(l0.u, l1.u);
-}
 
 template <int ROWS, int BKT, int NT>
 __device__ __forceinline__ void store_tile_presplit(bf16raw* __restrict__ planes, int tid, const float4 (&r)[ROWS * BKT / (4 * NT)]) {
@@ -167,8 +145,6 @@ __device__ __forceinline__ void read_frag_presplit(const bf16raw* __restrict__ p
 // tools/probe/tr_probe.hip). Two such reads give a lane the 8 consecutive k of its row that v_mfma_f32_32x32x16_bf16 wants, with no
 // per-element LDS traffic. Pitch = ROWS*2 + 64 bytes: the 4 k-rows of one read land in 4 different 64-byte bank quarters.
 #define PITCH_MC(ROWS) ((ROWS) + 32)
-typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4_t;
-#define LDS_AS __attribute__((address_space(3)))
 
 template <int ROWS, int BKT, int NT>
 __device__ __forceinline__ void store_tile_presplit_mc(bf16raw* __restrict__ planes, int tid, const float4 (&r)[ROWS * BKT / (4 * NT)]) {
@@ -333,12 +309,6 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 || TM * TN > 4 ? 1 : 2))
   }
   const int64_t m0 = (int64_t)mt_i * BM_, n0 = (int64_t)nt_i * BN_;
   const int z = blockIdx.y;
-  {                                     // batched heads (and bags): plain pointer offsets
-    const int z1 = (int)blockIdx.z % g.nb1, z2 = (int)blockIdx.z / g.nb1;
-    g.A += (int64_t)z1 * g.sA + (int64_t)z2 * g.sA2;
-    g.B += (int64_t)z1 * g.sB + (int64_t)z2 * g.sB2;
-    g.C += (int64_t)z1 * g.sC + (int64_t)z2 * g.sC2;
-  }
   const int64_t kbeg = (int64_t)z * g.k_chunk;
   const int64_t kend = (kbeg + g.k_chunk < g.K) ? kbeg + g.k_chunk : g.K;
 
@@ -354,10 +324,10 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 || TM * TN > 4 ? 1 : 2))
     // ---- bf16x3 main loop, LDS double-buffered; both operands live pre-split (hi/lo bf16 planes) in LDS
     OperandStage<A_KC, BM_, BKT, (PRE & 1) != 0, NT> ra;
     OperandStage<B_KC, BN_, BKT, (PRE & 2) != 0, NT> rb;
-    const bf16raw* const a_hi = reinterpret_cast<const bf16raw*>(g.epi.a_hi) + (int64_t)blockIdx.z * g.sA;
-    const bf16raw* const a_lo = reinterpret_cast<const bf16raw*>(g.epi.a_lo) + (int64_t)blockIdx.z * g.sA;
-    const bf16raw* const b_hi = reinterpret_cast<const bf16raw*>(g.epi.b_hi) + (int64_t)blockIdx.z * g.sB;
-    const bf16raw* const b_lo = reinterpret_cast<const bf16raw*>(g.epi.b_lo) + (int64_t)blockIdx.z * g.sB;
+    const bf16raw* const a_hi = reinterpret_cast<const bf16raw*>(g.epi.a_hi);
+    const bf16raw* const a_lo = reinterpret_cast<const bf16raw*>(g.epi.a_lo);
+    const bf16raw* const b_hi = reinterpret_cast<const bf16raw*>(g.epi.b_hi);
+    const bf16raw* const b_lo = reinterpret_cast<const bf16raw*>(g.epi.b_lo);
     auto fetch = [&](int64_t k0) {
       ra.load(g.A, a_hi, a_lo, g.lda, m0, g.M, k0, kend, tid);
       rb.load(g.B, b_hi, b_lo, g.ldb, n0, g.N, k0, kend, tid);
@@ -536,7 +506,7 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 || TM * TN > 4 ? 1 : 2))
             for (int t = 0; t < 4; ++t)      // static indices: a runtime-bounded loop would push v[] into scratch memory
               if (t < nvalid) c[t] = v[t];
           }
-          if (direct && e.c_hi) emit_planes4(e, (int64_t)blockIdx.z * g.sC + row * ldo + col, v, nvalid);
+          if (direct && e.c_hi) emit_planes4(e, row * ldo + col, v, nvalid);
         }
       }
       WAVE_LDS_SYNC();   // reads of this patch done before the next sub-tile overwrites it
@@ -741,7 +711,6 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
   g.splits = splits;
   g.ws = (float*)ws;
   g.epi = *epi;
-  g.sA = g.sB = g.sC = 0; g.nb1 = 1; g.sA2 = g.sB2 = g.sC2 = 0;
   if (splits > 1) {
     if (!ws || ws_bytes < advmil_gemm_f32_workspace_bytes(M, N, splits)) return ADVMIL_EWORKSPACE;
     if ((uintptr_t)ws & 15) return ADVMIL_EINVAL;
@@ -794,48 +763,6 @@ extern "C" int advmil_gemm_f32(int a_kc, int b_kc, int64_t M, int64_t N, int64_t
                                const float* B, int64_t ldb, float* C, int64_t ldc, const advmil_epilogue_t* epi,
                                int splits, void* ws, size_t ws_bytes, advmil_stream_t stream) {
   return advmil_gemm_f32_tiled(a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, epi, splits, 0, ws, ws_bytes, stream);
-}
-
-// Batched form (gridDim.z = batch * batch2): operand/result pointers advance by element strides per inner batch (attention
-// head) and per outer batch (bag). The heads are strided slices of the packed qkv[L, 3d] and of O[L, d], the bags are row blocks
-// of the slab -- no gather/permute copies, one launch per attention stage for all equal-length bags of a step.
-extern "C" int advmil_gemm_f32_batched2(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
-                                        int64_t strideA, int64_t strideA2, const float* B, int64_t ldb, int64_t strideB,
-                                        int64_t strideB2, float* C, int64_t ldc, int64_t strideC, int64_t strideC2, int batch,
-                                        int batch2, float alpha, int accumulate, advmil_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch2 <= 0 || (int64_t)batch * batch2 > 65535) return ADVMIL_EINVAL;
-  if ((lda & 3) || (ldb & 3) || (strideA & 3) || (strideB & 3) || (strideA2 & 3) || (strideB2 & 3)) return ADVMIL_EINVAL;
-  if (a_kc ? (K & 3) : (M & 3)) return ADVMIL_EINVAL;
-  if (b_kc ? (K & 3) : (N & 3)) return ADVMIL_EINVAL;
-  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return ADVMIL_EINVAL;
-  GemmArgs g;
-  g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
-  g.k_chunk = ((K + BK - 1) / BK) * BK;
-  g.splits = 1; g.ws = nullptr;
-  g.sA = strideA; g.sB = strideB; g.sC = strideC;
-  g.nb1 = batch; g.sA2 = strideA2; g.sB2 = strideB2; g.sC2 = strideC2;
-  advmil_epilogue_t e = {};      // every optional field (planes included) off
-  e.act0 = e.act1 = ACT_NONE; e.act_split = 1 << 30; e.mask_scale = 1.f; e.accumulate = accumulate; e.alpha = alpha;
-  g.epi = e;
-  // small per-head problems: 64x64 tiles unless the batch already fills the chip with 64x128
-  const int tile = (n_tiles(12, M, N) * batch * batch2 >= 512) ? 12 : 11;
-  const int tm = tile / 10, tn = tile % 10;
-  g.mtiles = (int)((M + 64 * tm - 1) / (64 * tm));
-  const int ntiles = (int)((N + 64 * tn - 1) / (64 * tn));
-  g.ntiles = ntiles;
-  dim3 grid(g.mtiles * ntiles, 1, batch * batch2);
-  if (tile == 12) launch_tile<1, 2, false>(a_kc, b_kc, grid, stream, g, 0);
-  else launch_tile<1, 1, false>(a_kc, b_kc, grid, stream, g, 0);
-  ADVMIL_LAUNCH_CHECK();
-  return ADVMIL_OK;
-}
-
-extern "C" int advmil_gemm_f32_batched(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
-                                       int64_t strideA, const float* B, int64_t ldb, int64_t strideB, float* C, int64_t ldc,
-                                       int64_t strideC, int batch, float alpha, int accumulate, advmil_stream_t stream_) {
-  return advmil_gemm_f32_batched2(a_kc, b_kc, M, N, K, A, lda, strideA, 0, B, ldb, strideB, 0, C, ldc, strideC, 0, batch, 1, alpha,
-                                  accumulate, stream_);
 }
 
 // ---- fp32 matrix -> bf16 planes (hi = bf16(x), lo = bf16(x - hi)); the same rounding the staging path applies on the fly

@@ -784,77 +784,153 @@ extern "C" int advmil_ln_relu_bwd(const float* dout, const float* y, const float
 }
 
 // =====================================================================================
-// Row softmax with dropout for the ESAT attention probabilities: one wave per row of S[R, C].
-//   P = softmax(S) (pre-dropout, kept for the backward); Pd = P * keep  (what multiplies V)
-//   bwd: dPp = dPd * keep; dS = P * (dPp - sum_j dPp_j P_j)
-// dropout element index = r*C + j  (r = head*L + query) -- the [H, L, L] layout of nn.MultiheadAttention's dropout.
+// Post-norm residual of the ESAT transformer layer (nn.TransformerEncoderLayer, norm_first = False; reference
+// model/backbone_utils.py:113-127):   y = LayerNorm(x + dropout(o))   one wave per row, lane owns columns lane, lane+64, ...
+//   fwd also stores z = x + dropout(o) and the row statistics for the backward; dropout index = row*d + col on `stream_id`
+//   (the flat index of advmil_dropout_apply, so the host regenerates the mask the same way).
+//   bwd: dz = LayerNorm'(dy); dx = dz; do = dz * keep; dgamma += sum_rows dy*xhat; dbeta += sum_rows dy.
 // =====================================================================================
-// R rows of pitch C; only the first Cv columns are real keys (the rest are alignment padding -> probability 0).
-// Lq = rows per head (padded query count). RNG index = ((r / Lq) * Cv + r % Lq) * Cv + j, i.e. the un-padded [H, L, L] layout.
-__global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(const float* __restrict__ S, float* __restrict__ P,
-                                                               float* __restrict__ Pd, int64_t R, int64_t C, int64_t Cv,
-                                                               int64_t Lq, float p, const uint64_t* seed, uint64_t stream_id) {
-  const int lane = threadIdx.x & 63;
-  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= R) return;
-  const float* row = S + r * C;
-  float mx = -INFINITY;
-  for (int64_t j = lane; j < Cv; j += 64) mx = fmaxf(mx, row[j]);
-  mx = wave_max(mx);
-  float sum = 0.f;
-  for (int64_t j = lane; j < Cv; j += 64) sum += expf(row[j] - mx);
-  const float inv = 1.f / wave_sum(sum);
-  const bool drop = Pd && seed && p > 0.f;
-  uint64_t key = 0;
-  float ik = 1.f;
-  if (drop) { key = rng_key(*seed, stream_id); ik = 1.f / (1.f - p); }
-  const uint64_t base = (uint64_t)(((r / Lq) * Cv + (r % Lq)) * Cv);
-  for (int64_t j = lane; j < C; j += 64) {
-    const float v = j < Cv ? expf(row[j] - mx) * inv : 0.f;
-    P[r * C + j] = v;
-    if (Pd) Pd[r * C + j] = (drop && j < Cv) ? v * rng_keep(key, base + (uint64_t)j, p, ik) : v;
-  }
-}
-
-__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ P, const float* __restrict__ dPd,
-                                                               float* __restrict__ dS, int64_t R, int64_t C, int64_t Cv,
-                                                               int64_t Lq, float p, const uint64_t* seed, uint64_t stream_id) {
-  const int lane = threadIdx.x & 63;
-  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= R) return;
+__global__ __launch_bounds__(256) void add_dropout_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ o,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float eps, int64_t R, int64_t d, float p, const uint64_t* seed,
+                                                                 uint64_t stream_id, float* __restrict__ z, float* __restrict__ y,
+                                                                 float* __restrict__ mean, float* __restrict__ rstd) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int Q = (int)((d + 63) / 64);
   const bool drop = seed && p > 0.f;
   uint64_t key = 0;
   float ik = 1.f;
   if (drop) { key = rng_key(*seed, stream_id); ik = 1.f / (1.f - p); }
-  const uint64_t base = (uint64_t)(((r / Lq) * Cv + (r % Lq)) * Cv);
-  float c = 0.f;
-  for (int64_t j = lane; j < Cv; j += 64) {
-    float g = dPd[r * C + j];
-    if (drop) g *= rng_keep(key, base + (uint64_t)j, p, ik);
-    c += g * P[r * C + j];
-  }
-  c = wave_sum(c);
-  for (int64_t j = lane; j < C; j += 64) {
-    float g = j < Cv ? dPd[r * C + j] : 0.f;
-    if (drop && j < Cv) g *= rng_keep(key, base + (uint64_t)j, p, ik);
-    dS[r * C + j] = j < Cv ? P[r * C + j] * (g - c) : 0.f;
+  const float invd = 1.f / (float)d;
+  for (int rr = 0; rr < 4; ++rr) {
+    const int64_t n = (int64_t)blockIdx.x * 16 + w * 4 + rr;
+    if (n >= R) break;
+    float v[LN_MAXQ];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < LN_MAXQ; ++q) {
+      const int64_t j = lane + 64 * q;
+      const bool ok = q < Q && j < d;
+      float t = 0.f;
+      if (ok) {
+        float ov = o[n * d + j];
+        if (drop) ov *= rng_keep(key, (uint64_t)(n * d + j), p, ik);
+        t = x[n * d + j] + ov;
+        z[n * d + j] = t;
+      }
+      v[q] = t;
+      s += t;
+    }
+    const float mu = wave_sum(s) * invd;
+    float s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < LN_MAXQ; ++q) {
+      const int64_t j = lane + 64 * q;
+      const float c = (q < Q && j < d) ? v[q] - mu : 0.f;
+      s2 += c * c;
+    }
+    const float rs = rsqrtf(wave_sum(s2) * invd + eps);
+    if (lane == 0) { mean[n] = mu; rstd[n] = rs; }
+#pragma unroll
+    for (int q = 0; q < LN_MAXQ; ++q) {
+      const int64_t j = lane + 64 * q;
+      if (q < Q && j < d) y[n * d + j] = (v[q] - mu) * rs * gamma[j] + beta[j];
+    }
   }
 }
 
-extern "C" int advmil_softmax_rows_fwd(const float* S, float* P, float* Pd, int64_t R, int64_t C, int64_t Cv, int64_t Lq,
-                                       float drop_p, const uint64_t* seed, uint64_t stream_id, advmil_stream_t stream) {
-  if (!S || !P || R <= 0 || C <= 0 || Cv <= 0 || Cv > C || Lq <= 0) return ADVMIL_EINVAL;
-  hipLaunchKernelGGL(softmax_rows_fwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, P, Pd, R, C,
-                     Cv, Lq, drop_p, seed, stream_id);
+__global__ __launch_bounds__(256) void add_dropout_ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, int64_t R, int64_t d, float p,
+                                                                 const uint64_t* seed, uint64_t stream_id, float* __restrict__ dx,
+                                                                 float* __restrict__ dob, float* __restrict__ partial) {
+  __shared__ float red[4 * 1024];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t g = blockIdx.x;
+  const int Q = (int)((d + 63) / 64);
+  const bool drop = seed && p > 0.f;
+  uint64_t key = 0;
+  float ik = 1.f;
+  if (drop) { key = rng_key(*seed, stream_id); ik = 1.f / (1.f - p); }
+  float gm[LN_MAXQ], ag[LN_MAXQ], abt[LN_MAXQ];
+#pragma unroll
+  for (int q = 0; q < LN_MAXQ; ++q) {
+    const int64_t j = lane + 64 * q;
+    gm[q] = (q < Q && j < d) ? gamma[j] : 0.f;
+    ag[q] = 0.f; abt[q] = 0.f;
+  }
+  const float invd = 1.f / (float)d;
+  for (int rr = 0; rr < 4; ++rr) {
+    const int64_t n = g * 16 + w * 4 + rr;
+    if (n >= R) break;
+    const float mu = mean[n], rs = rstd[n];
+    float xh[LN_MAXQ], dxh[LN_MAXQ];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < LN_MAXQ; ++q) {
+      const int64_t j = lane + 64 * q;
+      const bool ok = q < Q && j < d;
+      xh[q] = ok ? (z[n * d + j] - mu) * rs : 0.f;
+      const float g_ = ok ? dy[n * d + j] : 0.f;
+      dxh[q] = g_ * gm[q];
+      ag[q] += g_ * xh[q];
+      abt[q] += g_;
+      c1 += dxh[q];
+      c2 += dxh[q] * xh[q];
+    }
+    c1 = wave_sum(c1) * invd;
+    c2 = wave_sum(c2) * invd;
+#pragma unroll
+    for (int q = 0; q < LN_MAXQ; ++q) {
+      const int64_t j = lane + 64 * q;
+      if (q < Q && j < d) {
+        const float dz = rs * (dxh[q] - c1 - xh[q] * c2);
+        dx[n * d + j] = dz;
+        if (dob) dob[n * d + j] = drop ? dz * rng_keep(key, (uint64_t)(n * d + j), p, ik) : dz;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < LN_MAXQ; ++q) {
+    const int64_t j = lane + 64 * q;
+    if (q < Q && j < d) { red[w * 1024 + j] = ag[q]; red[w * 1024 + 512 + j] = abt[q]; }
+  }
+  __syncthreads();
+  for (int64_t j = threadIdx.x; j < d; j += 256) {
+    partial[g * 2 * d + j] = red[j] + red[1024 + j] + red[2048 + j] + red[3072 + j];
+    partial[g * 2 * d + d + j] = red[512 + j] + red[1536 + j] + red[2560 + j] + red[3584 + j];
+  }
+}
+
+extern "C" int advmil_add_dropout_ln_fwd(const float* x, const float* o, const float* gamma, const float* beta, float eps,
+                                         int64_t R, int64_t d, float drop_p, const uint64_t* seed, uint64_t stream_id, float* z,
+                                         float* y, float* mean, float* rstd, advmil_stream_t stream) {
+  if (!x || !o || !gamma || !beta || !z || !y || !mean || !rstd || R <= 0 || d <= 0 || d > 512) return ADVMIL_EINVAL;
+  if (drop_p < 0.f || drop_p >= 1.f) return ADVMIL_EINVAL;
+  hipLaunchKernelGGL(add_dropout_ln_fwd_kernel, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, (hipStream_t)stream, x, o, gamma,
+                     beta, eps, R, d, drop_p, seed, stream_id, z, y, mean, rstd);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }
 
-extern "C" int advmil_softmax_rows_bwd(const float* P, const float* dPd, float* dS, int64_t R, int64_t C, int64_t Cv, int64_t Lq,
-                                       float drop_p, const uint64_t* seed, uint64_t stream_id, advmil_stream_t stream) {
-  if (!P || !dPd || !dS || R <= 0 || C <= 0 || Cv <= 0 || Cv > C || Lq <= 0) return ADVMIL_EINVAL;
-  hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, P, dPd, dS, R, C,
-                     Cv, Lq, drop_p, seed, stream_id);
+extern "C" size_t advmil_add_dropout_ln_bwd_workspace_bytes(int64_t R, int64_t d) {
+  return (size_t)(((R + 15) / 16) * 2 * d) * sizeof(float);
+}
+
+extern "C" int advmil_add_dropout_ln_bwd(const float* dy, const float* z, const float* gamma, const float* mean, const float* rstd,
+                                         int64_t R, int64_t d, float drop_p, const uint64_t* seed, uint64_t stream_id, float* dx,
+                                         float* dob, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes,
+                                         advmil_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!dy || !z || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !ws || R <= 0 || d <= 0 || d > 512) return ADVMIL_EINVAL;
+  if (ws_bytes < advmil_add_dropout_ln_bwd_workspace_bytes(R, d)) return ADVMIL_EWORKSPACE;
+  const int nb = (int)((R + 15) / 16);
+  float* partial = (float*)ws;
+  hipLaunchKernelGGL(add_dropout_ln_bwd_kernel, dim3(nb), dim3(256), 0, stream, dy, z, gamma, mean, rstd, R, d, drop_p, seed,
+                     stream_id, dx, dob, partial);
+  ADVMIL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial, nb, 2 * d, d, dgamma, accumulate);
+  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial + d, nb, 2 * d, d, dbeta, accumulate);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }

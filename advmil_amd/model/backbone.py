@@ -57,12 +57,7 @@ class ABMIL(nn.Module):
         (everything before `rho`). One FC GEMM, one gate GEMM and one segmented softmax-pool for the whole step batch."""
         rng = _rng_of(self, X)
         fc, p = self.attention_net[0], (self.attention_net[2].p if self.training else 0.0)
-        if getattr(self, "gemm_dtype", "f32") == "bf16":
-            # mixed precision: bf16 MFMA operands (X's bf16 images come from the handler's slab cache), fp32 accumulate;
-            # the FC emits the bf16 images of h that the gate contractions consume
-            h = ops.linear_act_bf16(X, getattr(X, "_adv_bf16", None), fc.weight, fc.bias, "relu", p, rng, "abmil_fc", emit=True)
-        else:
-            h = ops.linear_act(X, fc.weight, fc.bias, "relu", p, rng, "abmil_fc")   # [N_total, hid]
+        h = ops.linear_act(X, fc.weight, fc.bias, "relu", p, rng, "abmil_fc")   # [N_total, hid]
         pooled, A, _ = self.attention_net[3].pool(h, seg)
         self.last_attention = A.detach()
         return pooled.unsqueeze(0) if seg is None else pooled

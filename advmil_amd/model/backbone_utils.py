@@ -43,9 +43,8 @@ class Attn_Net_Gated(nn.Module):
         """Fused scorer + softmax over instances + weighted sum: x[N,D] -> (pooled[D], A[N], raw scores[N]).
         With `seg` (ops.Segments) the rows are a slab of B bags and pooled is [B, D] (softmax per bag)."""
         p = self.drop_p if self.training else 0.0
-        fn = ops.gated_attn_pool_bf16 if getattr(self, "gemm_dtype", "f32") == "bf16" else ops.gated_attn_pool
-        return fn(x, self.attention_a[0].weight, self.attention_a[0].bias, self.attention_b[0].weight,
-                  self.attention_b[0].bias, self.attention_c.weight, self.attention_c.bias, p, _rng_of(self, x), "gate_", seg)
+        return ops.gated_attn_pool(x, self.attention_a[0].weight, self.attention_a[0].bias, self.attention_b[0].weight,
+                                   self.attention_b[0].bias, self.attention_c.weight, self.attention_c.bias, p, _rng_of(self, x), "gate_", seg)
 
     def forward(self, x):
         """Reference contract: (A[N,1] raw scores, x)."""

@@ -4,14 +4,12 @@ nn.TransformerEncoderLayer(d_model, nhead, dim_feedforward=d_model, dropout, rel
 same initialisation: nn.MultiheadAttention / nn.Linear / nn.LayerNorm are kept as parameter holders.
 
 Dense projections (in-proj, out-proj, FFN) run on the HIP GEMM engine; the attention core
-(QK^T -> softmax -> dropout -> PV) runs in ops.mha.
+(QK^T -> softmax -> dropout -> PV) is the fused flash-style kernel behind ops.mha (csrc/attn.hip); the two post-norm
+residuals LayerNorm(x + dropout(.)) are one launch each (ops.add_dropout_layer_norm).
 """
-import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import ops
-from ..utils.func import dropout_small
 
 
 class HipTransformerEncoderLayer(nn.Module):
@@ -33,22 +31,17 @@ class HipTransformerEncoderLayer(nn.Module):
         rng = getattr(self, "rng", None) or ops.default_rng(x2.device)
         tr = self.training
         sa = self.self_attn
-        d = x2.shape[1]
         qkv = ops.linear_act(x2, sa.in_proj_weight, sa.in_proj_bias, "none")           # [L_total, 3d]
-        p_att = sa.dropout if tr else 0.0
-        if seg is None:
-            o = ops.mha(qkv, self.nhead, p_att, rng)
-        elif len(set(seg.lens)) == 1 and seg.lens[0] % 4 == 0:     # equal-length bags: every attention stage is ONE launch
-            o = ops.mha(qkv, self.nhead, p_att, rng, bags=seg.nseg)
-        else:
-            o = torch.cat([ops.mha(qkv[seg.offsets[b]:seg.offsets[b + 1]], self.nhead, p_att, rng) for b in range(seg.nseg)], dim=0)
+        # attention core: one fused launch for all (ragged) bags of the slab; `rng_rowoff` (set by the handler under
+        # bag-parallel) addresses the dropout row ids of the single-process run
+        o = ops.mha(qkv, self.nhead, sa.dropout if tr else 0.0, rng, seg=seg, rowoff=getattr(seg, "rng_rowoff", None))
         o = ops.linear_act(o, sa.out_proj.weight, sa.out_proj.bias, "none")
-        o = dropout_small(o, self.dropout1.p, tr, rng, "esat_drop1")
-        x2 = F.layer_norm(x2 + o, (d,), self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x2 = ops.add_dropout_layer_norm(x2, o, self.norm1.weight, self.norm1.bias, self.norm1.eps,
+                                        self.dropout1.p if tr else 0.0, rng, "esat_drop1")
         f = ops.linear_act(x2, self.linear1.weight, self.linear1.bias, "relu", self.dropout.p if tr else 0.0, rng, "esat_ffn")
         f = ops.linear_act(f, self.linear2.weight, self.linear2.bias, "none")
-        f = dropout_small(f, self.dropout2.p, tr, rng, "esat_drop2")
-        return F.layer_norm(x2 + f, (d,), self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        return ops.add_dropout_layer_norm(x2, f, self.norm2.weight, self.norm2.bias, self.norm2.eps,
+                                          self.dropout2.p if tr else 0.0, rng, "esat_drop2")
 
     def forward(self, x):
         if x.dim() != 3 or x.shape[0] != 1:

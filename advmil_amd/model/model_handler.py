@@ -85,17 +85,10 @@ class MyHandler(object):
         self.netD = self.netD.to(self.device)
         for m in list(self.netG.modules()) + list(self.netD.modules()):
             m.rng = self.rng
-        # generator contraction precision: "f32" (exact fp32 MFMA, default) or "bf16" (bf16 MFMA operands, fp32 accumulate;
-        # ABMIL backbone). The discriminator always runs fp32: its logit moves 2.7e-4 under bf16 operands (> 1e-4 contract).
         # arithmetic of the fp32 contraction engine (process-wide switch in the library): "exact" = fp32 MFMA,
         # "bf16x3" = split-bf16 on the bf16 matrix pipe with fp32 accumulate (near-fp32: ~2^-17 per product). None = leave as is.
         if cfg.get("gemm_mode") is not None:
             ops.set_gemm_mode(cfg["gemm_mode"])
-        self.gen_gemm_dtype = cfg.get("gen_gemm_dtype", "f32")
-        assert self.gen_gemm_dtype in ("f32", "bf16")
-        for m in self.netG.modules():
-            m.gemm_dtype = self.gen_gemm_dtype
-        self._slab_bf16 = {}
         if self.dp.world > 1:                              # replicas start identical
             for net in (self.netG, self.netD):
                 for p in net.parameters():
@@ -257,24 +250,7 @@ class MyHandler(object):
                 ptr += r * c * 4
         X = (x0.as_strided((sum(rows), c), (c, 1), x0.storage_offset()) if ok
              else torch.cat([x[0].reshape(-1, c) for x in xs], dim=0))
-        if self.gen_gemm_dtype == "bf16" and self.bcb not in ("patch", "cluster", "graph"):
-            X._adv_bf16 = self._bf16_images(X, cacheable=ok)
         return X
-
-    def _bf16_images(self, X, cacheable):
-        """(bf16, transposed bf16) images of a step slab. Resident slabs (zero-copy views of a staging/pool buffer) are cast
-        once and reused until the buffer is written again (tensor version counter); a slab assembled by a copy is cast per use."""
-        if not cacheable:
-            return ops.cast_bf16(X, True, True)
-        key = (X.data_ptr(), tuple(X.shape))
-        ent = self._slab_bf16.get(key)
-        ver = X._version
-        if ent is None or ent[0] != ver:
-            if len(self._slab_bf16) >= 8:
-                self._slab_bf16.pop(next(iter(self._slab_bf16)))
-            ent = (ver, ops.cast_bf16(X, True, True))
-            self._slab_bf16[key] = ent
-        return ent[1]
 
     @staticmethod
     def _stack_noise(noise):

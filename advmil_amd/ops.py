@@ -674,89 +674,110 @@ def gate_scores(h, Wa, ba, Wb, bb, wc, bc, p=0.0, rng=None, tag=""):
     return GateScoreFn.apply(h, Wa, ba, Wb, bb, wc, bc, float(p), seed, sa, sb)
 
 
-def gemm_batched(A, B, a_kc, b_kc, M, N, K, lda, sA, ldb, sB, C, ldc, sC, batch, alpha=1.0, accumulate=False, batch2=1,
-                 sA2=0, sB2=0, sC2=0):
-    """batch (heads) x batch2 (equal-length bags) strided contractions in one launch."""
-    _lib.check(_lib.lib().advmil_gemm_f32_batched2(1 if a_kc else 0, 1 if b_kc else 0, M, N, K, _p(A), lda, sA, sA2, _p(B), ldb, sB,
-                                                   sB2, _p(C), ldc, sC, sC2, batch, batch2, float(alpha), 1 if accumulate else 0,
-                                                   _stream()), f"gemm_f32_batched[{batch2}x{batch}x{M}x{N}x{K}]")
-    return C
-
-
-def _off(t, n):
-    """View of a flat-addressable tensor starting n elements in (pointer arithmetic for strided heads)."""
-    return t.reshape(-1)[n:]
-
-
 class MhaFn(torch.autograd.Function):
-    """Self-attention core of the ESAT layer: packed qkv[G*L, 3d] of G equal-length bags -> O[G*L, d]; attention never crosses
-    a bag. Per bag g and head h (strided slices, no permute copies):  S = Q K^T / sqrt(hd)  (one batched MFMA GEMM launch over
-    all G*nhead pairs) -> P = dropout(softmax(S)) (row kernel, counter RNG index ((g*nhead + h)*L + i)*L + j) -> O = P V
-    (batched GEMM, written straight into O[:, h*hd:(h+1)*hd]).  Backward = four more batched GEMMs + one row kernel.
-    The token axis is padded to a multiple of 4 (16 B operand alignment) when G == 1; padded keys get probability 0."""
+    """Self-attention core of the ESAT layer (nn.MultiheadAttention inside nn.TransformerEncoderLayer, reference
+    model/backbone_utils.py:113-127): packed qkv[L_total, 3d] of a slab of bags (`seg`; None = one bag) -> O[L_total, d]; attention
+    never crosses a bag. ONE fused launch (advmil_mha_fwd: QK^T, online softmax, dropout, PV on the matrix pipe; no [H, L, L]
+    tensor exists), three for the backward (advmil_mha_bwd). Ragged bags and any bag length are handled inside the kernels."""
 
     @staticmethod
-    def forward(ctx, qkv, nhead, p, seed, sid, G):
+    def forward(ctx, qkv, nhead, p, seed, sid, seg, rowoff):
         _chk(qkv, "qkv")
-        L, d3 = qkv.shape[0] // G, qkv.shape[1]
-        Lp = (L + 3) // 4 * 4
-        assert G == 1 or Lp == L
-        qkv = qkv.contiguous() if Lp == L else torch.nn.functional.pad(qkv, (0, 0, 0, Lp - L)).contiguous()
+        qkv = qkv.contiguous()
+        Lt, d3 = qkv.shape
         d = d3 // 3
         hd = d // nhead
         dev = qkv.device
-        scale = 1.0 / float(hd) ** 0.5
-        S = torch.empty(G * nhead, Lp, Lp, dtype=torch.float32, device=dev)
-        LL, bag = Lp * Lp, Lp * d3
-        gemm_batched(qkv, _off(qkv, d), True, True, Lp, Lp, hd, d3, hd, d3, hd, S, Lp, LL, nhead, alpha=scale, batch2=G,
-                     sA2=bag, sB2=bag, sC2=nhead * LL)
-        P = torch.empty_like(S)
-        Pd = torch.empty_like(S) if p > 0.0 else None
-        _lib.check(_lib.lib().advmil_softmax_rows_fwd(_p(S), _p(P), _p(Pd), G * nhead * Lp, Lp, L, Lp, p,
-                                                      _p(seed if p > 0.0 else None), sid, _stream()), "softmax_rows_fwd")
-        O = torch.empty(G * Lp, d, dtype=torch.float32, device=dev)
-        gemm_batched(Pd if Pd is not None else P, _off(qkv, 2 * d), True, False, Lp, hd, Lp, Lp, LL, d3, hd, O, d, hd, nhead,
-                     batch2=G, sA2=nhead * LL, sB2=bag, sC2=Lp * d)
-        ctx.save_for_backward(qkv, P, Pd if Pd is not None else P)
-        ctx.cfg = (nhead, p, seed, sid, L, Lp, d, hd, scale, G)
-        return O[:L] if G == 1 else O
+        out = torch.empty(Lt, d, dtype=torch.float32, device=dev)
+        lse = torch.empty(Lt, nhead, dtype=torch.float32, device=dev)
+        nseg = 1 if seg is None else seg.nseg
+        mlen = Lt if seg is None else seg.max_len
+        ptr = None if seg is None else seg.ptr
+        _lib.check(_lib.lib().advmil_mha_fwd(_p(qkv), Lt, nhead, hd, nseg, _p(ptr), mlen, p, _p(seed if p > 0.0 else None), sid,
+                                             _p(rowoff), _p(out), _p(lse), _stream()), "mha_fwd")
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.cfg = (nhead, hd, p, seed, sid, seg, rowoff)
+        return out
 
     @staticmethod
     def backward(ctx, dO):
-        qkv, P, Pd = ctx.saved_tensors
-        nhead, p, seed, sid, L, Lp, d, hd, scale, G = ctx.cfg
-        d3 = 3 * d
-        dev = qkv.device
-        dO = dO.contiguous() if Lp == L else torch.nn.functional.pad(dO, (0, 0, 0, Lp - L)).contiguous()
-        dqkv = torch.empty(G * Lp, d3, dtype=torch.float32, device=dev)
-        LL, bag, hb = Lp * Lp, Lp * d3, nhead * Lp * Lp
-        # dPd = dO V^T                 [L, L]  (A = dO_h [L,hd] k-contig, B = V_h [L,hd] k-contig)
-        dPd = torch.empty(G * nhead, Lp, Lp, dtype=torch.float32, device=dev)
-        gemm_batched(dO, _off(qkv, 2 * d), True, True, Lp, Lp, hd, d, hd, d3, hd, dPd, Lp, LL, nhead, batch2=G, sA2=Lp * d, sB2=bag,
-                     sC2=hb)
-        # dV = Pd^T dO                 [L, hd] (A = Pd_h [K=L, M=L] m-contig, B = dO_h [K=L, N=hd] n-contig)
-        gemm_batched(Pd, dO, False, False, Lp, hd, Lp, Lp, LL, d, hd, _off(dqkv, 2 * d), d3, hd, nhead, batch2=G, sA2=hb, sB2=Lp * d,
-                     sC2=bag)
-        dS = torch.empty_like(dPd)
-        _lib.check(_lib.lib().advmil_softmax_rows_bwd(_p(P), _p(dPd), _p(dS), G * nhead * Lp, Lp, L, Lp, p,
-                                                      _p(seed if p > 0.0 else None), sid, _stream()), "softmax_rows_bwd")
-        # dQ = scale * dS K            (A = dS_h [L, L] k-contig, B = K_h [K=L, N=hd] n-contig)
-        gemm_batched(dS, _off(qkv, d), True, False, Lp, hd, Lp, Lp, LL, d3, hd, dqkv, d3, hd, nhead, alpha=scale, batch2=G, sA2=hb,
-                     sB2=bag, sC2=bag)
-        # dK = scale * dS^T Q          (A = dS_h [K=L, M=L] m-contig, B = Q_h [K=L, N=hd] n-contig)
-        gemm_batched(dS, qkv, False, False, Lp, hd, Lp, Lp, LL, d3, hd, _off(dqkv, d), d3, hd, nhead, alpha=scale, batch2=G, sA2=hb,
-                     sB2=bag, sC2=bag)
-        return (dqkv[:L] if G == 1 else dqkv), None, None, None, None, None
+        qkv, out, lse = ctx.saved_tensors
+        nhead, hd, p, seed, sid, seg, rowoff = ctx.cfg
+        Lt = qkv.shape[0]
+        L = _lib.lib()
+        dO = dO.contiguous()
+        dqkv = torch.empty_like(qkv)
+        nseg = 1 if seg is None else seg.nseg
+        mlen = Lt if seg is None else seg.max_len
+        ptr = None if seg is None else seg.ptr
+        wsb = L.advmil_mha_bwd_workspace_bytes(Lt, nhead)
+        ws = _ws(wsb, qkv.device)
+        _lib.check(L.advmil_mha_bwd(_p(qkv), _p(out), _p(dO), _p(lse), Lt, nhead, hd, nseg, _p(ptr), mlen, p,
+                                    _p(seed if p > 0.0 else None), sid, _p(rowoff), _p(dqkv), _p(ws), wsb, _stream()), "mha_bwd")
+        return dqkv, None, None, None, None, None, None
 
 
-def mha(qkv, nhead, p=0.0, rng=None, bags=1):
-    """qkv[bags*L, 3d]: `bags` equal-length bags stacked by rows (L a multiple of 4 when bags > 1)."""
+def mha(qkv, nhead, p=0.0, rng=None, seg=None, rowoff=None):
+    """qkv[L_total, 3d]; `seg` (ops.Segments) partitions the rows into bags. `rowoff`: optional int64 device tensor [nseg] added
+    to each bag's local region rows to form the dropout stream's row ids (bag-parallel world-size invariance)."""
     sid, seed = 0, None
     if p > 0.0:
         rng = rng or default_rng(qkv.device)
-        L = qkv.shape[0] // bags
-        sid, seed = rng.site("mha_attn", (bags * nhead, L, L) if bags > 1 else (nhead, L, L), p), rng.seed
-    return MhaFn.apply(qkv, nhead, float(p), seed, sid, bags)
+        sid, seed = rng.site("mha_attn", (qkv.shape[0], nhead), p), rng.seed
+    return MhaFn.apply(qkv, nhead, float(p), seed, sid, seg, rowoff)
+
+
+class AddDropoutLayerNormFn(torch.autograd.Function):
+    """y = LayerNorm(x + dropout(o)): the two post-norm residuals of the ESAT layer (reference model/backbone_utils.py:113-127,
+    nn.TransformerEncoderLayer with norm_first=False) as one launch each way; dropout index = row*d + col on stream `sid`."""
+
+    @staticmethod
+    def forward(ctx, x, o, gamma, beta, eps, p, seed, sid):
+        _chk(x, "x"); _chk(o, "o")
+        x, o = x.contiguous(), o.contiguous()
+        R, d = x.shape
+        dev = x.device
+        z = torch.empty_like(x)
+        y = torch.empty_like(x)
+        mean = torch.empty(R, dtype=torch.float32, device=dev)
+        rstd = torch.empty(R, dtype=torch.float32, device=dev)
+        g_, b_ = gamma.detach(), beta.detach()
+        _lib.check(_lib.lib().advmil_add_dropout_ln_fwd(_p(x), _p(o), _p(g_), _p(b_), eps, R, d, p, _p(seed if p > 0.0 else None), sid,
+                                                        _p(z), _p(y), _p(mean), _p(rstd), _stream()), "add_dropout_ln_fwd")
+        ctx.save_for_backward(z, g_, mean, rstd)
+        ctx.cfg = (p, seed, sid)
+        gg, gb = _arena_grad(gamma), _arena_grad(beta)
+        ctx.arena = (gg, gb) if (gg is not None and gb is not None) else None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, gamma, mean, rstd = ctx.saved_tensors
+        p, seed, sid = ctx.cfg
+        R, d = z.shape
+        L = _lib.lib()
+        dy = dy.contiguous()
+        dx = torch.empty_like(z)
+        do = torch.empty_like(z) if p > 0.0 else None
+        acc = ctx.arena is not None
+        dg = ctx.arena[0] if acc else torch.empty(d, dtype=torch.float32, device=z.device)
+        db = ctx.arena[1] if acc else torch.empty(d, dtype=torch.float32, device=z.device)
+        wsb = L.advmil_add_dropout_ln_bwd_workspace_bytes(R, d)
+        ws = _ws(wsb, z.device)
+        _lib.check(L.advmil_add_dropout_ln_bwd(_p(dy), _p(z), _p(gamma), _p(mean), _p(rstd), R, d, p, _p(seed if p > 0.0 else None),
+                                               sid, _p(dx), _p(do), _p(dg), _p(db), 1 if acc else 0, _p(ws), wsb, _stream()),
+                   "add_dropout_ln_bwd")
+        if do is None:
+            do = dx
+        return (dx, do, None, None, None, None, None, None) if acc else (dx, do, dg, db, None, None, None, None)
+
+
+def add_dropout_layer_norm(x, o, gamma, beta, eps=1e-5, p=0.0, rng=None, tag=""):
+    sid, seed = 0, None
+    if p > 0.0:
+        rng = rng or default_rng(x.device)
+        sid, seed = rng.site(tag, tuple(o.shape), p), rng.seed
+    return AddDropoutLayerNormFn.apply(x, o, gamma, beta, float(eps), float(p), seed, sid)
 
 
 class SegMeanFn(torch.autograd.Function):
@@ -917,221 +938,6 @@ class GenConvAggFn(torch.autograd.Function):
 
 def genconv_aggregate(x, t, csr, eps=1e-7):
     return GenConvAggFn.apply(x, t, csr, eps)
-
-
-# ---------------------------------------------------------------------------------------
-# bf16-operand engine (generator contractions): raw launches
-# ---------------------------------------------------------------------------------------
-_PLAN_CACHE_H = {}
-
-
-def gemm_bf16_plan(M, N, K):
-    key = (M, N, K)
-    if key not in _PLAN_CACHE_H:
-        t, sp = ctypes.c_int(0), ctypes.c_int(0)
-        _lib.check(_lib.lib().advmil_gemm_bf16_plan(M, N, K, ctypes.byref(t), ctypes.byref(sp)), "gemm_bf16_plan")
-        _PLAN_CACHE_H[key] = (t.value, sp.value)
-    return _PLAN_CACHE_H[key]
-
-
-def cast_bf16(src, want=True, want_t=False):
-    """fp32 [R, C] -> (bf16 [R, C] | None, bf16 [C, R] | None) in one pass."""
-    _chk(src, "src")
-    R, C = src.shape
-    dst = torch.empty(R, C, dtype=torch.bfloat16, device=src.device) if want else None
-    dstT = torch.empty(C, R, dtype=torch.bfloat16, device=src.device) if want_t else None
-    _lib.check(_lib.lib().advmil_cast_bf16(_p(src), src.stride(0), R, C, _p(dst), C, _p(dstT), R, _stream()), "cast_bf16")
-    return dst, dstT
-
-
-def gemm_bf16(A, B, M, N, K, out=None, ldc=None, want_f32=True, want_bf16=False, want_bf16_t=False, bias=None, act0=0,
-              act1=None, act_split=None, drop_p=0.0, seed=None, stream_id=0, rowv=None, colv=None, rowseg=None, maskref=None,
-              mask_scale=1.0, accumulate=False, alpha=1.0, splits=None, tile=0):
-    """epilogue(alpha * A[M,K] B[N,K]^T) with bf16 operands, fp32 accumulate. Returns (C fp32 | None, Cb bf16 | None, Ct bf16^T | None)."""
-    if A.dtype != torch.bfloat16 or B.dtype != torch.bfloat16 or not A.is_cuda:
-        raise TypeError("gemm_bf16: device bf16 operands expected")
-    dev = A.device
-    C = out
-    if C is None and want_f32:
-        C = torch.empty(M, N, dtype=torch.float32, device=dev)
-        ldc = N
-    elif C is not None and ldc is None:
-        ldc = C.stride(0)
-    Cb = torch.empty(M, N, dtype=torch.bfloat16, device=dev) if want_bf16 else None
-    Ct = torch.empty(N, M, dtype=torch.bfloat16, device=dev) if want_bf16_t else None
-    e = Epilogue()
-    e.bias = None if bias is None else bias.data_ptr()
-    e.act0 = act0
-    e.act1 = act0 if act1 is None else act1
-    e.act_split = (1 << 30) if act_split is None else act_split
-    e.drop_p = float(drop_p)
-    e.seed = None if (seed is None or drop_p <= 0.0) else seed.data_ptr()
-    e.stream_id = stream_id
-    e.rowv = None if rowv is None else rowv.data_ptr()
-    e.colv = None if colv is None else colv.data_ptr()
-    e.rowseg = None if rowseg is None else rowseg.data_ptr()
-    e.maskref = None if maskref is None else maskref.data_ptr()
-    e.ldmask = 0 if maskref is None else maskref.stride(0)
-    e.mask_scale = float(mask_scale)
-    e.accumulate = 1 if accumulate else 0
-    e.alpha = float(alpha)
-    if splits is None:
-        ptile, splits = gemm_bf16_plan(M, N, K)
-        if tile == 0:
-            tile = ptile
-        if Cb is not None or Ct is not None:
-            splits = 1
-    L = _lib.lib()
-    wsb = L.advmil_gemm_bf16_workspace_bytes(M, N, splits)
-    ws = _ws(wsb, dev) if wsb else None
-    prof = KERNEL_PROFILE
-    if prof is not None:
-        e0 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-    _lib.check(L.advmil_gemm_bf16_nt(M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(C), ldc or 0, _p(Cb), N, _p(Ct), M,
-                                     ctypes.byref(e), splits, tile, _p(ws), wsb, _stream()), f"gemm_bf16_nt[{M}x{N}x{K}]")
-    if prof is not None:
-        e1 = torch.cuda.Event(enable_timing=True)
-        e1.record()
-        prof.append(("gemm_bf16_nt_kernel<1,1>", (M, N, K, splits), 2.0 * M * N * K, e0, e1))
-    return C, Cb, Ct
-
-
-# ---------------------------------------------------------------------------------------
-# bf16-operand autograd Functions (generator backbone in mixed precision: bf16 MFMA operands, fp32 accumulate,
-# fp32 activations kept for the element-wise backward; weight gradients accumulate in fp32)
-# ---------------------------------------------------------------------------------------
-def _bf16_pair(t):
-    """(bf16 copy, transposed bf16 copy) attached to a tensor by its producer, or None."""
-    return getattr(t, "_adv_bf16", None)
-
-
-class LinearActBf16Fn(torch.autograd.Function):
-    """y = dropout(act(x W^T + b)) with bf16 operands. x_bf[M,K] / x_T[K,M] are the bf16 images of x (row-major and
-    transposed); the transposed one feeds dW = dpre^T x as an NT contraction. emit=True also returns bf16 images of y."""
-
-    @staticmethod
-    def forward(ctx, x, x_bf, x_T, W, b, act, p, seed, sid, emit):
-        M, K = x_bf.shape
-        W2 = W.detach().reshape(W.shape[0], -1)
-        N = W2.shape[0]
-        Wb, _ = cast_bf16(W2, True, False)
-        y, yb, yT = gemm_bf16(x_bf, Wb, M, N, K, bias=b, act0=act, drop_p=p, seed=seed, stream_id=sid, want_bf16=emit,
-                              want_bf16_t=emit)
-        ctx.save_for_backward(x_T, W2, y)
-        ctx.cfg = (act, p, seed, sid, M, N, K, W.shape, b is not None)
-        ctx.gW, ctx.gb = _arena_grad(W), _arena_grad(b)
-        if not emit:
-            yb = yT = torch.empty(0, dtype=torch.bfloat16, device=y.device)
-        ctx.mark_non_differentiable(yb, yT)
-        return y, yb, yT
-
-    @staticmethod
-    def backward(ctx, dy, _g1, _g2):
-        x_T, W2, y = ctx.saved_tensors
-        act, p, seed, sid, M, N, K, wshape, has_b = ctx.cfg
-        dy = dy.contiguous()
-        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[3]
-        need_b = has_b and ctx.needs_input_grad[4]
-        db = None
-        if act == ACT_NONE and p <= 0.0:
-            dpre = dy
-            if need_b:
-                db = colsum(dy, M, N, out=ctx.gb)
-        else:
-            dpre, db = act_dropout_bwd(dy, y, act, M, N, p, seed, sid, want_bias=need_b, db_out=ctx.gb if need_b else None)
-        dW = dx = None
-        if need_w or need_x:
-            dpre_b, dpre_T = cast_bf16(dpre, need_x, need_w)
-        if need_w:                                            # dW[N,K] = dpre_T[N,M] . x_T[K,M]^T
-            if ctx.gW is not None:
-                gemm_bf16(dpre_T, x_T, N, K, M, out=ctx.gW.view(N, K), ldc=K, accumulate=True)
-            else:
-                dW = gemm_bf16(dpre_T, x_T, N, K, M)[0].reshape(wshape)
-        if need_x:                                            # dx[M,K] = dpre[M,N] . (W^T)[K,N]^T
-            _, W_T = cast_bf16(W2, False, True)
-            dx = gemm_bf16(dpre_b, W_T, M, K, N)[0]
-        return dx, None, None, dW, (None if ctx.gb is not None else db), None, None, None, None, None
-
-
-def linear_act_bf16(x, xb, W, b, act="none", p=0.0, rng=None, tag="", emit=False):
-    """bf16-operand form of linear_act for 2-D x. xb = (x_bf16, x_T_bf16) or None (cast here)."""
-    if xb is None:
-        xb = cast_bf16(x.contiguous(), True, True)
-    sid, seed = 0, None
-    if p > 0.0:
-        rng = rng or default_rng(x.device)
-        sid, seed = rng.site(tag, (x.shape[0], W.shape[0]), p), rng.seed
-    y, yb, yT = LinearActBf16Fn.apply(x, xb[0], xb[1], W, b, _ACT[act], float(p), seed, sid, emit)
-    if emit:
-        y._adv_bf16 = (yb, yT)
-    return y
-
-
-class GatedAttnPoolBf16Fn(torch.autograd.Function):
-    """GatedAttnPoolFn with bf16 MFMA operands for its three contractions (gates, dh, dWab). h_bf / h_T are the bf16
-    images of h; scores, softmax, pooling and every element-wise derivative stay fp32."""
-
-    @staticmethod
-    def forward(ctx, h, h_bf, h_T, Wa, ba, Wb, bb, wc, bc, p, seed, sa, sb, seg):
-        h = h.contiguous()
-        N, D = h.shape
-        Wab, _ = _stack2(Wa, Wb, D, D)
-        bab, _ = _stack2(ba, bb, D, 0)
-        Wab_b, Wab_T = cast_bf16(Wab, True, True)            # [2D, D] and [D, 2D]
-        ab = gemm_bf16(h_bf, Wab_b, N, 2 * D, D, bias=bab, act0=ACT_TANH, act1=ACT_SIGMOID, act_split=D)[0]
-        wcv = wc.detach().reshape(-1)
-        s = gate_score(ab, wcv, bc, N, D, p, seed, sa, sb)
-        A, pooled = softmax_pool(s, h, N, D, seg)
-        ctx.save_for_backward(h, h_T, Wab_T, ab, A, wcv)
-        ctx.cfg = (p, seed, sa, sb, N, D, wc.shape, seg)
-        gs = [_arena_grad(t) for t in (Wa, ba, Wb, bb, wc, bc)]
-        ctx.arena = None
-        if all(g is not None for g in gs) and _adjacent(gs[0], gs[2]) and _adjacent(gs[1], gs[3]):
-            ctx.arena = (gs[0].as_strided((2 * D, D), (D, 1), gs[0].storage_offset()),
-                         gs[1].as_strided((2 * D,), (1,), gs[1].storage_offset()), gs[4].view(-1), gs[5])
-        ctx.mark_non_differentiable(s)
-        ctx.set_materialize_grads(False)
-        return pooled, A, s
-
-    @staticmethod
-    def backward(ctx, dpooled, dA, _ds_unused):
-        h, h_T, Wab_T, ab, A, wcv = ctx.saved_tensors
-        p, seed, sa, sb, N, D, wcshape, seg = ctx.cfg
-        nseg = 1 if seg is None else seg.nseg
-        dpooled = (torch.zeros(nseg, D, dtype=torch.float32, device=h.device) if dpooled is None
-                   else dpooled.contiguous().reshape(nseg, D))
-        dA_ = None if dA is None else dA.contiguous()
-        ds = softmax_pool_bwd(dpooled, dA_, A, h, N, D, seg)
-        if ctx.arena is not None:
-            gWab, gbab, gwc, gbc = ctx.arena
-            dG, _, _, _ = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb, dwc=gwc, dbc=gbc, dbias=gbab)
-        else:
-            dG, dwc, dbc, dbias = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb)
-        need_h = ctx.needs_input_grad[0]
-        dG_b, dG_T = cast_bf16(dG, need_h, True)
-        dh = None
-        if need_h:   # dh[N,D] = dG[N,2D] . (Wab^T)[D,2D]^T + A[n] * dpooled[bag(n)]
-            dh = gemm_bf16(dG_b, Wab_T, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg)[0]
-        nones = (None,) * 5
-        if ctx.arena is not None:                             # dWab[2D,D] = dG_T[2D,N] . h_T[D,N]^T
-            gemm_bf16(dG_T, h_T, 2 * D, D, N, out=gWab, ldc=D, accumulate=True)
-            return (dh, None, None, None, None, None, None, None, None) + nones
-        dWab = gemm_bf16(dG_T, h_T, 2 * D, D, N)[0]
-        return (dh, None, None, dWab[:D], dbias[:D], dWab[D:], dbias[D:], dwc.reshape(wcshape), dbc) + nones
-
-
-def gated_attn_pool_bf16(h, Wa, ba, Wb, bb, wc, bc, p=0.0, rng=None, tag="", seg=None):
-    hb = _bf16_pair(h) or cast_bf16(h.contiguous(), True, True)
-    sa = sb = 0
-    seed = None
-    if p > 0.0:
-        rng = rng or default_rng(h.device)
-        sa = rng.site(tag + "att_a", tuple(h.shape), p)
-        sb = rng.site(tag + "att_b", tuple(h.shape), p)
-        seed = rng.seed
-    pooled, A, s = GatedAttnPoolBf16Fn.apply(h, hb[0], hb[1], Wa, ba, Wb, bb, wc, bc, float(p), seed, sa, sb, seg)
-    return (pooled[0] if seg is None else pooled), A, s
 
 
 # ---------------------------------------------------------------------------------------

@@ -45,10 +45,8 @@ def parse():
     ap.add_argument("--gemm-mode", default="bf16x3", choices=["bf16x3", "exact"],
                     help="arithmetic of the fp32 contraction engine: bf16x3 = split-bf16 products on the bf16 matrix pipe with fp32 "
                          "accumulate (near-fp32, parity-tested); exact = fp32 MFMA")
-    ap.add_argument("--gen-dtype", default="f32", choices=["f32", "bf16"],
-                    help="generator contraction operands: f32 (exact) or bf16 MFMA (mixed precision, D stays f32)")
     ap.add_argument("--eager", action="store_true", help="drive the step eagerly instead of replaying HIP graphs")
-    ap.add_argument("--no-bf16-extra", action="store_true", help="skip the extra measurements (exact-fp32 mode, mixed-precision bf16 generator)")
+    ap.add_argument("--no-bf16-extra", action="store_true", help="skip the extra measurements (exact-fp32 mode, one bag per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-bags", type=int, default=4, help="bags in the CPU-baseline sample")
@@ -165,8 +163,7 @@ def main():
     dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
 
-    cfg = default_cfg(bcb_mode=args.mode, bp_every_batch=args.bags, cuda_id=dev.index, gen_gemm_dtype=args.gen_dtype,
-                      gemm_mode=args.gemm_mode)
+    cfg = default_cfg(bcb_mode=args.mode, bp_every_batch=args.bags, cuda_id=dev.index, gemm_mode=args.gemm_mode)
     if args.mode == "graph":            # PatchGCN dims of the reference's model_stats.py:63
         cfg.update(bcb_dims="1024-128-128", gen_dims="128-1")
     h = MyHandler(cfg, device=dev)
@@ -306,9 +303,7 @@ def main():
         if ent:
             traffic = ent["hbm_bytes_per_launch"]
         total_gemm_ms = sum(v["ms"] for v in agg.values()) / nprof
-        if kname.startswith("gemm_bf16"):
-            peak, peak_note = PEAK_BF16_MFMA_TFLOPS, "dense bf16 MFMA peak"
-        elif args.gemm_mode == "bf16x3":
+        if args.gemm_mode == "bf16x3":
             peak, peak_note = PEAK_BF16X3_TFLOPS, ("bf16x3: 3 bf16 MFMAs per fp32-equivalent product -> roof = dense bf16 MFMA peak / 3 "
                                                    "in algorithmic 2MNK flops (the fp32 MFMA roof would be 157.3)")
         else:
@@ -419,33 +414,6 @@ def main():
         except Exception as exc:
             bp1_extra = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
 
-    # ---- extra (single GPU, f32 runs only): the same step with bf16 MFMA operands in the generator's contractions
-    bf16_extra = None
-    if world == 1 and args.gen_dtype == "f32" and args.gemm_mode == "exact" and args.mode == "abmil" and not args.no_bf16_extra and not args.eager:
-        try:
-            from advmil_amd.graphed import GraphedStep
-            h2 = MyHandler(default_cfg(bcb_mode=args.mode, bp_every_batch=args.bags, cuda_id=dev.index, gen_gemm_dtype="bf16"), device=dev)
-            g2 = []
-            for g0 in range(0, n_pool - args.bags + 1, args.bags):
-                idx = list(range(g0, g0 + args.bags))
-                g2.append(GraphedStep(h2, [xs[i] for i in idx], [ys[i] for i in idx], [ys_host[i] for i in idx], warmup=1))
-            for k in range(args.warmup):
-                g2[k % len(g2)].replay()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for k in range(args.steps):
-                g2[k % len(g2)].replay()
-            torch.cuda.synchronize()
-            dt2 = time.perf_counter() - t1
-            bf16_extra = {"value": round(args.bags * args.steps / dt2, 3), "unit": "bags/s", "ms_per_step": round(1e3 * dt2 / args.steps, 3),
-                          "dtype": "bf16 MFMA operands for the generator's contractions, fp32 accumulate; discriminator and all element-wise math fp32",
-                          "parity": "tests/test_parity_gpu.py::test_bf16_generator_mode_meets_the_contract: from identical weights y/f/losses "
-                                    "within 1e-4 of the reference; after an Adam step on bf16-operand gradients per-bag outputs drift to ~4e-4 "
-                                    "(not the headline for that reason)"}
-            del g2, h2
-        except Exception as exc:
-            bf16_extra = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
-
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only; at N > 1 the other ranks would idle in the barrier
         cpu = cpu_baseline(args, torch)
@@ -456,21 +424,19 @@ def main():
             "metric": "WSI bags/sec (full G+D step)", "value": round(bags_total / dt, 3), "unit": "bags/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("bf16(generator contractions)+f32" if args.gen_dtype != "f32" else
-                      ("bf16x3 (fp32 operands split hi+lo in registers, 3 bf16 MFMAs per product, fp32 accumulate; fp32 storage)"
-                       if args.gemm_mode == "bf16x3" else "f32")), "data": "synthetic",
+            "dtype": ("bf16x3 (fp32 operands split hi+lo in registers, 3 bf16 MFMAs per product, fp32 accumulate; fp32 storage)"
+                      if args.gemm_mode == "bf16x3" else "f32"), "data": "synthetic",
             "config": {"workload": f"{args.mode.upper()}+AdvMIL(RLIP prj discriminator), {args.patches}-patch x 1024 fp32 bags "
                                    f"(BASELINE.json configs[1] shape; fp32 storage, "
-                                   + ("bf16 MFMA operands in the generator)" if args.gen_dtype != "f32" else
-                                      ("bf16x3 split arithmetic: >= the bf16 the config names, within 2e-5 of the fp32 reference)"
-                                       if args.gemm_mode == "bf16x3" else "exact fp32 MFMA arithmetic)")),
+                                   + ("bf16x3 split arithmetic: >= the bf16 the config names, within 2e-5 of the fp32 reference)"
+                                      if args.gemm_mode == "bf16x3" else "exact fp32 MFMA arithmetic)"),
                        "bags_per_step_per_gpu": args.bags, "global_bags_per_step": args.bags * world, "gen_updates": 1,
                        "distinct_resident_bags_per_gpu": n_pool, "parallelism": f"bag-parallel dp{world}", "dropout": "shipped rates",
                        "launch": launch_note},
             "gd_steps_per_sec": round(args.steps / dt, 3), "losses_finite": bool(finite), "replicas_in_sync": in_sync,
             "host_submit_ms_per_step": round(1e3 * t_submit / args.steps, 3),
             "roofline": roof, "pool_roofline": pool_roof, "cpu_baseline": cpu, "exact_f32_mfma_mode": exact_extra,
-            "bp_every_batch_1": bp1_extra, "mixed_precision_bf16_generator": bf16_extra,
+            "bp_every_batch_1": bp1_extra,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

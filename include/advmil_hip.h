@@ -109,41 +109,40 @@ int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, c
                           int splits, int tile, void* ws, size_t ws_bytes, advmil_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * bf16-operand / fp32-accumulate engine (v_mfma_f32_32x32x16_bf16): C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T), both
- * operands k-contiguous bf16 (uint16 storage; lda/ldb/K multiples of 8). Same epilogue as advmil_gemm_f32. Outputs, any
- * subset: C fp32 [M,N]; Cb bf16 [M,N]; Ct bf16 TRANSPOSED [N][ldct] -- the transposed copy is what lets the backward
- * contractions (dW = dY^T X, dX = dY W) run in this same NT form. splits > 1: fp32 C only. tile as in advmil_gemm_f32_tiled
- * (22/12/11; 0 = advmil_gemm_bf16_plan). Used for the GENERATOR's contractions; the discriminator stays fp32 (DESIGN.md §4:
- * its logit moves 2.7e-4 under bf16 operands, above the 1e-4 parity contract; y and the attention weights move < 2e-6). */
-int advmil_gemm_bf16_plan(int64_t M, int64_t N, int64_t K, int* tile, int* splits);
-size_t advmil_gemm_bf16_workspace_bytes(int64_t M, int64_t N, int splits);
-int advmil_gemm_bf16_nt(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, float* C,
-                        int64_t ldc, void* Cb, int64_t ldcb, void* Ct, int64_t ldct, const advmil_epilogue_t* epi, int splits,
-                        int tile, void* ws, size_t ws_bytes, advmil_stream_t stream);
-/* fp32 [R,C] (row pitch ld_src) -> bf16 [R,C] (dst, may be NULL) and/or bf16 transposed [C,R] (dstT, may be NULL). */
-int advmil_cast_bf16(const float* src, int64_t ld_src, int64_t R, int64_t C, void* dst, int64_t ld_dst, void* dstT,
-                     int64_t ld_dstT, advmil_stream_t stream);
-
-/* Batched form for the ESAT attention heads (nn.MultiheadAttention inside nn.TransformerEncoderLayer,
- * model/backbone_utils.py:113-127): batch b uses A + b*strideA, B + b*strideB, C + b*strideC (element strides), so the
- * heads are read as strided slices of the packed qkv[L,3d] and written straight into O[L,d]. C = alpha*op(A)op(B) (+C). */
-int advmil_gemm_f32_batched(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
-                            int64_t strideA, const float* B, int64_t ldb, int64_t strideB, float* C, int64_t ldc,
-                            int64_t strideC, int batch, float alpha, int accumulate, advmil_stream_t stream);
-/* Two batch levels: z = z2*batch + z1 uses X + z1*strideX + z2*strideX2 -- z1 the attention head, z2 the bag of a step slab whose
- * bags have equal length (the reference loops over bags, one nn.MultiheadAttention call each: model_handler.py:352, batch_size 1). */
-int advmil_gemm_f32_batched2(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t strideA,
-                             int64_t strideA2, const float* B, int64_t ldb, int64_t strideB, int64_t strideB2, float* C,
-                             int64_t ldc, int64_t strideC, int64_t strideC2, int batch, int batch2, float alpha, int accumulate,
-                             advmil_stream_t stream);
-/* Row softmax of the attention scores S[R,C] with dropout on the probabilities: P = softmax(S) (kept for backward),
- * Pd = P*keep (NULL = eval). bwd: dS = P * (dPd*keep - sum_j dPd_j*keep_j*P_j).
- * C = row pitch, Cv <= C = number of real keys (columns >= Cv are alignment padding and get probability 0),
- * Lq = rows per head. Dropout index ((r / Lq)*Cv + r % Lq)*Cv + j: the un-padded [H, L, L] layout. */
-int advmil_softmax_rows_fwd(const float* S, float* P, float* Pd, int64_t R, int64_t C, int64_t Cv, int64_t Lq, float drop_p,
-                            const uint64_t* seed, uint64_t stream_id, advmil_stream_t stream);
-int advmil_softmax_rows_bwd(const float* P, const float* dPd, float* dS, int64_t R, int64_t C, int64_t Cv, int64_t Lq,
-                            float drop_p, const uint64_t* seed, uint64_t stream_id, advmil_stream_t stream);
+ * Fused self-attention core of the ESAT layer (nn.MultiheadAttention inside nn.TransformerEncoderLayer,
+ * model/backbone_utils.py:113-127, reached from DualTrans_HS.forward, model/backbone.py:188-196; the reference runs one
+ * call per bag, model_handler.py:352, batch_size 1):  O = dropout(softmax(Q K^T / sqrt(head_dim))) V  per (bag, head).
+ * Flash-style: the [L, L] scores never exist in HBM; the backward recomputes them from `lse`.
+ *   qkv  [Ltot, 3*nhead*head_dim]  packed in-projection output (q | k | v); head h of q at columns h*head_dim ...
+ *   out  [Ltot, nhead*head_dim];  lse [Ltot, nhead] = log2-domain log-sum-exp of the scaled scores (opaque to the caller)
+ *   Rows are a slab of `nseg` bags, bag b = rows [ptr[b], ptr[b+1]) (device int64; NULL = one bag), max_len = longest bag;
+ *   attention never crosses a bag. Any bag length >= 1 (ragged tails are masked). head_dim must be 48 (d_model 384 / 8 heads,
+ *   the only shape load_backbone builds: model/backbone.py:30-33).
+ * Dropout on the probabilities (train mode; NULL seed or p == 0 = off): keep(i, j) = hash32(rowkey + j*0x9E3779B9) >= p*2^32,
+ *   rowkey = high 32 bits of splitmix64(key(seed, stream_id) + (ptr[b] + rng_rowoff[b] + i)*nhead + h); rng_rowoff (device int64
+ *   [nseg], NULL = zeros) lets a rank of a bag-parallel job address the row ids the single-process run would use.
+ *   Host restatement: advmil_amd/synth.py::attn_dropout_keep.
+ * Arithmetic: split-bf16 ("bf16x3": hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate) in BOTH modes of
+ *   advmil_set_gemm_mode -- ~2^-17 relative per product; softmax statistics and exponentials in fp32.
+ * bwd: dqkv [Ltot, 3*nhead*head_dim] (every element written); ws >= advmil_mha_bwd_workspace_bytes. Deterministic (no atomics). */
+int advmil_mha_fwd(const float* qkv, int64_t Ltot, int nhead, int head_dim, int nseg, const int64_t* ptr, int64_t max_len,
+                   float drop_p, const uint64_t* seed, uint64_t stream_id, const int64_t* rng_rowoff, float* out, float* lse,
+                   advmil_stream_t stream);
+size_t advmil_mha_bwd_workspace_bytes(int64_t Ltot, int nhead);
+int advmil_mha_bwd(const float* qkv, const float* out, const float* dout, const float* lse, int64_t Ltot, int nhead, int head_dim,
+                   int nseg, const int64_t* ptr, int64_t max_len, float drop_p, const uint64_t* seed, uint64_t stream_id,
+                   const int64_t* rng_rowoff, float* dqkv, void* ws, size_t ws_bytes, advmil_stream_t stream);
+/* Post-norm residual of the same layer (norm_first = False):  y = LayerNorm(x + dropout(o)) over rows of width d <= 512.
+ * fwd also writes z = x + dropout(o), mean[R], rstd[R] for the backward; dropout element index = row*d + col on `stream_id`.
+ * bwd: dx = LayerNorm'(dy); dob (may be NULL) = dx * keep; dgamma / dbeta = column sums (accumulate != 0 adds into them).
+ * ws >= advmil_add_dropout_ln_bwd_workspace_bytes. */
+int advmil_add_dropout_ln_fwd(const float* x, const float* o, const float* gamma, const float* beta, float eps, int64_t R,
+                              int64_t d, float drop_p, const uint64_t* seed, uint64_t stream_id, float* z, float* y, float* mean,
+                              float* rstd, advmil_stream_t stream);
+size_t advmil_add_dropout_ln_bwd_workspace_bytes(int64_t R, int64_t d);
+int advmil_add_dropout_ln_bwd(const float* dy, const float* z, const float* gamma, const float* mean, const float* rstd, int64_t R,
+                              int64_t d, float drop_p, const uint64_t* seed, uint64_t stream_id, float* dx, float* dob,
+                              float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, advmil_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Gated-attention MIL pooling (Attn_Net_Gated + softmax + mm: model/backbone_utils.py:11-29,

@@ -191,53 +191,6 @@ def test_adam_matches_oracle(ops):
     assert int(step.item()) == 3
 
 
-@pytest.mark.parametrize("L,p", [(32, 0.0), (512, 0.25), (210, 0.25), (70, 0.0)])
-def test_mha_batched_heads(ops, L, p):
-    """ESAT attention core: batched-head MFMA GEMMs + row softmax/dropout vs float64 torch (masks regenerated on host)."""
-    H_, d = 8, 384
-    qkv = rnd(f"mq{L}", L, 3 * d, scale=0.5); go = rnd(f"mg{L}", L, d)
-    q = qkv.clone().to(DEV).requires_grad_(True)
-    rng = ops.DeviceRng(DEV, seed=31)
-    o = ops.mha(q, H_, p, rng)
-    (o * go.to(DEV)).sum().backward()
-    r = qkv.clone().double().requires_grad_(True)
-    qq, kk, vv = (t.reshape(L, H_, 48).transpose(0, 1) for t in r.split(d, dim=1))
-    pr = torch.softmax(qq @ kk.transpose(-1, -2) / 48 ** 0.5, dim=-1)
-    if p > 0:
-        pr = pr * H.T(synth.dropout_keep(31, 1, H_ * L * L, p).reshape(H_, L, L)).double() / (1 - p)
-    orf = (pr @ vv).transpose(0, 1).reshape(L, d)
-    (orf * go.double()).sum().backward()
-    assert relerr(o, orf) < 1e-5
-    assert relerr(q.grad, r.grad) < 5e-5
-
-
-def _bf(t):
-    return t.bfloat16().double()
-
-
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 104), (1024, 384, 1024), (384, 1024, 4096), (64, 64, 8)])
-def test_gemm_bf16_nt(ops, M, N, K):
-    """bf16-operand MFMA engine vs float64 on the SAME bf16-rounded operands (isolates the kernel from the rounding)."""
-    A = rnd(f"hA{M}{K}", M, K); B = rnd(f"hB{N}{K}", N, K); bias = rnd("hb", N)
-    Ab, Bb = A.to(DEV).bfloat16(), B.to(DEV).bfloat16()
-    ref = torch.relu(_bf(A) @ _bf(B).t() + bias.double())
-    for tile in (0, 22, 12, 11):
-        for splits in ((1, 2) if K >= 128 else (1,)):
-            both = splits == 1
-            C, Cb, Ct = ops.gemm_bf16(Ab, Bb, M, N, K, bias=bias.to(DEV), act0=1, want_bf16=both, want_bf16_t=both,
-                                      splits=splits, tile=tile)
-            assert relerr(C, ref) < 2e-6, (tile, splits, relerr(C, ref))
-            if both:
-                assert relerr(Cb.float(), ref) < 5e-3 and relerr(Ct.float().t(), ref) < 5e-3
-                assert torch.equal(Cb, C.bfloat16()) and torch.equal(Ct.t().contiguous(), C.bfloat16())
-
-
-def test_cast_bf16_and_transpose(ops):
-    x = rnd("cb", 200, 136)
-    d, dT = ops.cast_bf16(x.to(DEV), True, True)
-    assert torch.equal(d.cpu(), x.bfloat16()) and torch.equal(dT.cpu(), x.bfloat16().t().contiguous())
-
-
 @pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, False)])
 def test_gemm_split_bf16x3_mode(ops, a_kc, b_kc):
     """bf16x3 arithmetic of the fp32 engine: products of the hi/lo bf16 splits on the bf16 matrix pipe, fp32 accumulate.
@@ -319,30 +272,6 @@ def test_gemm_bf16x3_eight_wave_tiles(ops, a_kc, b_kc, tile):
             assert torch.equal(g2, r2)
     finally:
         ops.set_gemm_mode(prev)
-
-
-@pytest.mark.gpu
-def test_mha_bag_batched_equals_per_bag(ops):
-    """Equal-length bags of a slab go through the attention core in one launch per stage (two-level batched GEMM): forward and
-    input gradient equal the per-bag calls bit for bit (same products, same order)."""
-    G, L, d, nh = 3, 128, 384, 8
-    g = torch.Generator(device="cuda").manual_seed(3)
-    qkv = torch.randn(G * L, 3 * d, device="cuda", generator=g)
-    w = torch.randn(G * L, d, device="cuda", generator=g)
-    a = qkv.clone().requires_grad_(True)
-    oa = ops.mha(a, nh, 0.0, None, bags=G)
-    (oa * w).sum().backward()
-    b = qkv.clone().requires_grad_(True)
-    ob = torch.cat([ops.mha(b[i * L:(i + 1) * L], nh, 0.0, None) for i in range(G)], dim=0)
-    (ob * w).sum().backward()
-    assert torch.equal(oa, ob)
-    assert torch.equal(a.grad, b.grad)
-    # train-mode dropout: self-consistent (finite, right keep rate), masks differ from the per-bag draws by design
-    rng = ops.DeviceRng("cuda", seed=5)
-    c = qkv.clone().requires_grad_(True)
-    oc = ops.mha(c, nh, 0.25, rng, bags=G)
-    (oc * w).sum().backward()
-    assert torch.isfinite(oc).all() and torch.isfinite(c.grad).all()
 
 
 @pytest.mark.gpu

@@ -212,7 +212,9 @@ def test_train_mode_dropout_parity_vs_oracle(kind):
         ga = [e for e in ents if e[2] == (L, 384)]
         assert len(ga) == 2
         mk = lambda e: H.T(synth.dropout_keep(2024, e[1], int(np.prod(e[2])), e[3]).reshape(e[2]).astype(np.float32) / (1 - e[3]))
-        mg = {"attn": small("mha_attn", 0.25).reshape(1, 8, L, L), "drop1": small("esat_drop1", 0.25).reshape(1, L, 384),
+        (_, sid_att, _, _), = [e for e in rng.log if e[0] == "mha_attn"]
+        att = np.stack([synth.attn_dropout_keep(2024, sid_att, np.arange(L), 8, hh, L, 0.25) for hh in range(8)])
+        mg = {"attn": H.T(att.astype(np.float32) / 0.75).reshape(1, 8, L, L), "drop1": small("esat_drop1", 0.25).reshape(1, L, 384),
               "ffn": mask("esat_ffn").reshape(1, L, 384), "drop2": small("esat_drop2", 0.25).reshape(1, L, 384),
               "pool_a": mk(ga[0]).reshape(1, L, 384), "pool_b": mk(ga[1]).reshape(1, L, 384)}
     mg["mlp0"] = small("gen_mlp0.2", 0.6).reshape(1, 192)
@@ -379,52 +381,6 @@ def test_slab_features_equal_per_bag_features(kind):
         single = torch.cat([bb.features_multi(x, None, None if exts is None else [exts[i]]) for i, x in enumerate(xs)], dim=0)
     assert multi.shape == single.shape == (3, dims[1])
     close(multi, single, 1e-5)
-
-
-def test_bf16_generator_mode_meets_the_contract(golden):
-    """gen_gemm_dtype=bf16 (bf16 MFMA operands in the generator's contractions, fp32 everywhere else) against the
-    reference goldens at the CONTRACT tolerance 1e-4: predictions, attention weights, logits and the logged losses of
-    two optimizer steps; generator gradients stay within 2 % of the fp32 path."""
-    kind = "abmil"
-    # eval forward at 8192 (G1)
-    g = build_generator(kind).eval()
-    load_synth(g, f"G-{kind}:")
-    for m in g.modules():
-        m.gemm_dtype = "bf16"
-    x = H.bag(0, 8192, DEV)
-    with torch.no_grad():
-        y = g(x, None, zero_noise=True)
-    A = g.backbone.last_attention.reshape(-1)
-    close(y, golden["G1_abmil_8192_y"], CONTRACT_TOL)
-    close(A[::32], golden["G1_abmil_8192_A_strided"], 1e-6)
-    # two optimizer steps through the handler (G4)
-    h, PG0, PD0 = make_handler(kind, gen_gemm_dtype="bf16")
-    zero_dropout(h.netG); zero_dropout(h.netD)
-    nb = 32
-    h.patient_id["label_visible"] = h.patient_id["train"] = [str(i) for i in range(nb)]
-    h.noise_hook = lambda ph, i: [H.noise_tensor(f"G4{ph}:{kind}", i, 192, DEV)]
-    loader = [(torch.tensor([[i]], dtype=torch.int), [H.bag(i, 512), torch.zeros(1, 1)], H.label(i)) for i in range(nb)]
-    cl = h._train_each_epoch(loader, "train")
-    logs = h.pop_logs()
-    ref = golden[f"G4_{kind}_logs"]
-    for s in range(2):
-        d, gl = logs[2 * s], logs[2 * s + 1]
-        got = [d["train_batch/netD/Loss_D"], d["train_batch/netD/D_real"], d["train_batch/netD/D_fake"],
-               gl["train_batch/netG/Loss_G_fake"], gl["train_batch/netG/Loss_G_time"], gl["train_batch/netG/Loss_G_total"],
-               gl["train_batch/netG/D_fake_avg"]]
-        close(torch.tensor(got), ref[s], CONTRACT_TOL)
-    # step 1 starts from identical weights: per-bag predictions and logits inside the contract
-    d1y = close(cl["y_hat"][:16], golden[f"G4_{kind}_y_hat"][:16], CONTRACT_TOL)
-    d1f = close(cl["f_fake"][:16], golden[f"G4_{kind}_f_fake"][:16], CONTRACT_TOL)
-    # step 2 runs on weights updated from bf16-operand gradients: Adam's first update is lr*sign(g), so gradient noise on
-    # near-zero components flips 2*lr steps; the per-bag outputs drift to the few-1e-4 level (the means in the logs stay < 1e-4)
-    d2y = close(cl["y_hat"][16:], golden[f"G4_{kind}_y_hat"][16:], 1e-3)
-    d2f = close(cl["f_fake"][16:], golden[f"G4_{kind}_f_fake"][16:], 1e-3)
-    print(f"bf16 mode deviations: step1 y {d1y:.2e} f {d1f:.2e}; step2 y {d2y:.2e} f {d2f:.2e}")
-    gk = [str(k) for k in golden[f"G4_{kind}_gradG2_keys"]]
-    named = dict(h.netG.named_parameters())
-    gn = np.array([float((named[k].grad.double() + 1e-5 * torch.sign(named[k].detach().double())).norm()) for k in gk])
-    assert np.allclose(gn, golden[f"G4_{kind}_gradG2_norm"], rtol=6e-2, atol=1e-5)   # step-2 gradients: bf16 operand rounding + the drifted weights
 
 
 # ---------------------------------------------------------------------------------------------------------------------
