@@ -12,9 +12,14 @@ runs its own bags, one RCCL all-reduce of each network's flat gradient arena per
 global step batch = bags x N).
 
 Prints ONE JSON line (rank 0). Extra objects:
-  roofline     : the dominant kernel (by summed device time) of the step, HIP-event bracketed per launch on the
-                 launch stream in a second, instrumented pass over the same steps; algorithmic FLOPs / duration
-                 against the fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md).
+  roofline     : the dominant kernel of the step. ABMIL / DeepAttMISL / PatchGCN: the contraction (kernel, shape) that owns the
+                 most device time in an instrumented pass (HIP events around every launch on the launch stream), then timed as 50
+                 back-to-back launches; algorithmic 2MNK flops / duration against the MFMA roof of the arithmetic mode.
+                 ESAT (--mode patch): the fused attention core (advmil_mha_fwd + advmil_mha_bwd, csrc/attn.hip) on the step's
+                 region slab against the same bf16x3 MFMA roof; the dominant contraction is kept beside it as `gemm_roofline`.
+  pool_roofline: the attention-pool call against the HBM roof, at the step slab and at one bag.
+  sizes        : (1 GPU) the same step at the other sizes north_star names -- ABMIL 1k / 32k patches, ESAT 8k / 32k patches
+                 (bags/s, and for ESAT the attention-core roofline) -- plus the exact-fp32 arithmetic mode and one bag per step.
   cpu_baseline : the oracle (pure PyTorch CPU restatement of the reference schedule, pinned against the
                  reference to <=1e-6) timed on this box's host cores over a bounded sample of the same workload.
 """
@@ -36,7 +41,7 @@ PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0   # so its roof in ALGORITHMIC 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bags", type=int, default=16, help="bags per optimizer step per GPU (bp_every_batch)")
     ap.add_argument("--patches", type=int, default=8192)
@@ -46,7 +51,8 @@ def parse():
                     help="arithmetic of the fp32 contraction engine: bf16x3 = split-bf16 products on the bf16 matrix pipe with fp32 "
                          "accumulate (near-fp32, parity-tested); exact = fp32 MFMA")
     ap.add_argument("--eager", action="store_true", help="drive the step eagerly instead of replaying HIP graphs")
-    ap.add_argument("--no-bf16-extra", action="store_true", help="skip the extra measurements (exact-fp32 mode, one bag per step)")
+    ap.add_argument("--no-extras", "--no-bf16-extra", dest="no_extras", action="store_true",
+                    help="skip the extra measurements (other sizes / backbones, exact-fp32 mode, one bag per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-bags", type=int, default=4, help="bags in the CPU-baseline sample")
@@ -149,13 +155,149 @@ def cpu_baseline(args, torch):
                       f"oracle/advmil_oracle.py::train_step, torch {torch.__version__} CPU, {nthreads} threads of {os.cpu_count()} cpus"}
 
 
+class Case:
+    """One workload on this rank: a handler, its resident bag pool and one captured HIP graph per group of `bags` bags."""
+
+    def __init__(self, torch, dev, mode, patches, bags, pool, gemm_mode, seed, eager=False, world=1):
+        from advmil_amd.config import default_cfg
+        from advmil_amd.model import MyHandler
+        self.torch, self.dev, self.mode, self.patches, self.bags, self.world = torch, dev, mode, patches, bags, world
+        cfg = default_cfg(bcb_mode=mode, bp_every_batch=bags, cuda_id=dev.index, gemm_mode=gemm_mode)
+        if mode == "graph":            # PatchGCN dims of the reference's model_stats.py:63
+            cfg.update(bcb_dims="1024-128-128", gen_dims="128-1")
+        self.h = MyHandler(cfg, device=dev)
+        self.n_pool = max(pool, bags)
+        self.xs, self.ys, self.ys_host = make_pool(torch, dev, mode, self.n_pool, patches, seed=seed, group=bags)
+        self.cursor = 0
+        self.graphs = []
+        self.launch_note = "eager"
+        if not eager:
+            from advmil_amd.graphed import GraphedStep
+            try:
+                for g0 in range(0, self.n_pool - bags + 1, bags):
+                    idx = list(range(g0, g0 + bags))
+                    self.graphs.append(GraphedStep(self.h, [self.xs[i] for i in idx], [self.ys[i] for i in idx],
+                                                   [self.ys_host[i] for i in idx], warmup=1))
+                self.launch_note = (f"hipGraph replay ({len(self.graphs)} captured bag groups"
+                                    + (", 3 segments around the 2 all-reduces)" if world > 1 else ")"))
+            except Exception as exc:          # never lose the run to a capture problem: the eager schedule is the same step
+                self.graphs = []
+                torch.cuda.synchronize()
+                self.launch_note = f"eager (graph capture failed: {type(exc).__name__}: {str(exc)[:120]})"
+
+    def eager_step(self):
+        i0, nb, h = self.cursor, self.bags, self.h
+        idx = [(i0 + j) % self.n_pool for j in range(nb)]
+        self.cursor = (i0 + nb) % self.n_pool
+        bx, by, bh = [self.xs[i] for i in idx], [self.ys[i] for i in idx], [self.ys_host[i] for i in idx]
+        h._update_disc(0, bx, by, "wlabel", None, ys_host=bh)
+        h._update_gen(0, bx, by, "wlabel", None, ys_host=bh)
+        h.rng.advance(1)
+        if len(h.history) > 64:
+            h.history.clear()
+
+    def step(self):
+        if not self.graphs:
+            return self.eager_step()
+        self.graphs[self.cursor % len(self.graphs)].replay()
+        self.cursor += 1
+
+    def timed(self, steps, warmup, barrier):
+        for _ in range(warmup):
+            self.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        t_submit = time.perf_counter() - t0     # host time to enqueue all K steps (== dt when the host is the bottleneck)
+        barrier()
+        return time.perf_counter() - t0, t_submit
+
+    def logs_finite(self):
+        h = self.h
+        logs = h.pop_logs() if not self.graphs else [{k: float(v) for k, v in d.items() if k != "i_batch"}
+                                                     for g in self.graphs for d in g.logs]
+        return all(v == v and abs(v) != float("inf") for d in logs for v in d.values())
+
+    def free(self):
+        self.graphs, self.xs, self.ys, self.h = [], None, None, None
+        import gc
+        gc.collect()
+        self.torch.cuda.empty_cache()
+
+
+def event_time_us(torch, fn, iters, warm=3):
+    """Average duration of fn() over `iters` back-to-back calls between two HIP events on the launch stream (queue kept full)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def attention_roofline(torch, ops, dev, L, bags, p=0.25, iters=20):
+    """The fused ESAT attention core on the step's region slab (bags x L tokens, 8 heads x 48): forward and backward launches
+    timed back to back. Algorithmic flops: forward 4 L^2 d per bag (QK^T, PV), backward 10 L^2 d (five contractions), d = 384.
+    Roof: dense bf16 MFMA / 3 (three bf16 MFMAs per fp32-equivalent product)."""
+    d, nh = 384, 8
+    qkv = torch.randn(bags * L, 3 * d, device=dev, requires_grad=True)
+    go = torch.randn(bags * L, d, device=dev)
+    seg = ops.Segments([L] * bags, dev)
+    rng = ops.DeviceRng(dev, seed=1)
+    with torch.no_grad():
+        us_f = event_time_us(torch, lambda: ops.mha(qkv, nh, p, rng, seg=seg), iters)
+    o = ops.mha(qkv, nh, p, rng, seg=seg)
+
+    def bwd():
+        qkv.grad = None
+        o.backward(go, retain_graph=True)
+
+    us_b = event_time_us(torch, bwd, iters)
+    ff, fb = 4.0 * L * L * d * bags, 10.0 * L * L * d * bags
+    ach = (ff + fb) / (us_f + us_b) / 1e6
+    return {"bound": "mfma", "kernel": "attn_fwd_kernel<48,drop> + attn_bwd_dq_kernel + attn_bwd_dkv_kernel (csrc/attn.hip)",
+            "tokens_per_bag": L, "bags": bags, "heads": nh, "head_dim": 48, "attn_dropout": p,
+            "achieved": round(ach, 2), "peak": round(PEAK_BF16X3_TFLOPS, 1), "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16X3_TFLOPS, 4),
+            "peak_note": "bf16x3: 3 bf16 MFMAs per fp32-equivalent product -> roof = dense bf16 MFMA peak / 3 in algorithmic flops",
+            "traffic": None, "fwd_launch_us": round(us_f, 1), "fwd_tflops": round(ff / us_f / 1e6, 1),
+            "bwd_launches_us": round(us_b, 1), "bwd_tflops": round(fb / us_b / 1e6, 1),
+            "flops_per_launch": {"fwd": ff, "bwd": fb},
+            "algorithmic_bytes_per_launch": {"fwd": 4.0 * bags * L * (4 * d + nh), "bwd": 4.0 * bags * L * (9 * d + 2 * nh)},
+            "method": f"{iters} back-to-back launches between two HIP events on the launch stream"}
+
+
+def pool_roofline(torch, ops, dev, patches, bags, iters=40):
+    Dh = 384
+    nrows = bags * patches
+    nbuf = max(2, int(600e6 // (4 * nrows * Dh)) + 1)          # rotate slabs past the 256 MB Infinity Cache
+    hs = [torch.randn(nrows, Dh, device=dev) for _ in range(nbuf)]
+    sc = torch.randn(nrows, device=dev)
+    seg_b = ops.Segments([patches] * bags, dev)
+    k = [0]
+
+    def call():
+        ops.softmax_pool(sc, hs[k[0] % nbuf], nrows, Dh, seg_b)
+        k[0] += 1
+
+    usp = event_time_us(torch, call, iters)
+    byt = 4.0 * nrows * Dh + 3 * 4.0 * nrows
+    return {"bound": "hbm", "kernel": "softmax_stats + pool_partial8 + colsum_merge (advmil_softmax_pool_fwd, 3 launches)",
+            "rows": nrows, "bags": bags, "achieved": round(byt / usp / 1e3, 1), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(byt / usp / 1e3 / 8000.0, 4), "avg_call_us": round(usp, 2), "algorithmic_bytes_per_call": byt,
+            "rotating_slabs": nbuf,
+            "method": f"{iters} back-to-back calls between two HIP events, rotating slabs > 256 MB; per-kernel durations: profiles/ (rocprofv3 --kernel-trace)"}
+
+
 def main():
     args = parse()
     import torch
     import torch.distributed as dist
     from advmil_amd import ops, parallel
-    from advmil_amd.config import default_cfg
-    from advmil_amd.model import MyHandler
 
     rank, world, local = parallel.init_from_env()
     if world != args.gpus and world > 1:
@@ -163,72 +305,24 @@ def main():
     dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
 
-    cfg = default_cfg(bcb_mode=args.mode, bp_every_batch=args.bags, cuda_id=dev.index, gemm_mode=args.gemm_mode)
-    if args.mode == "graph":            # PatchGCN dims of the reference's model_stats.py:63
-        cfg.update(bcb_dims="1024-128-128", gen_dims="128-1")
-    h = MyHandler(cfg, device=dev)
-    n_pool = max(args.pool, args.bags)
-    xs, ys, ys_host = make_pool(torch, dev, args.mode, n_pool, args.patches, seed=1234 + rank, group=args.bags)
-    cursor = [0]
-
-    def eager_step():
-        i0 = cursor[0]
-        idx = [(i0 + j) % n_pool for j in range(args.bags)]
-        cursor[0] = (i0 + args.bags) % n_pool
-        bx, by, bh = [xs[i] for i in idx], [ys[i] for i in idx], [ys_host[i] for i in idx]
-        h._update_disc(0, bx, by, "wlabel", None, ys_host=bh)
-        h._update_gen(0, bx, by, "wlabel", None, ys_host=bh)
-        h.rng.advance(1)
-        if len(h.history) > 64:
-            h.history.clear()
-
-    # HIP graphs: one captured step per group of resident bags (the pool is cut into n_pool/bags groups)
-    graphs = []
-    launch_note = "eager"
-    if not args.eager:
-        from advmil_amd.graphed import GraphedStep
-        try:
-            for g0 in range(0, n_pool - args.bags + 1, args.bags):
-                idx = list(range(g0, g0 + args.bags))
-                graphs.append(GraphedStep(h, [xs[i] for i in idx], [ys[i] for i in idx], [ys_host[i] for i in idx], warmup=1))
-            launch_note = f"hipGraph replay ({len(graphs)} captured bag groups" + (", 3 segments around the 2 all-reduces)" if world > 1 else ")")
-        except Exception as exc:          # never lose the run to a capture problem: the eager schedule is the same step
-            graphs = []
-            torch.cuda.synchronize()
-            launch_note = f"eager (graph capture failed: {type(exc).__name__}: {str(exc)[:120]})"
-    ok = torch.tensor([1.0 if (graphs or args.eager) else 0.0], device=dev)
-    if world > 1:                          # all ranks must take the same path
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if float(ok.item()) == 0.0:
-        graphs = []
-
-    def graph_step():
-        g = graphs[cursor[0] % len(graphs)]
-        cursor[0] += 1
-        g.replay()
-
-    step = graph_step if graphs else eager_step
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    t_submit = time.perf_counter() - t0     # host time to enqueue all K steps (== dt when the host is the bottleneck)
-    barrier()
-    dt = time.perf_counter() - t0
+    case = Case(torch, dev, args.mode, args.patches, args.bags, args.pool, args.gemm_mode, 1234 + rank, args.eager, world)
+    ok = torch.tensor([1.0 if (case.graphs or args.eager) else 0.0], device=dev)
+    if world > 1:                          # all ranks must take the same path
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if float(ok.item()) == 0.0:
+        case.graphs = []
+    h = case.h
+    dt, t_submit = case.timed(args.steps, args.warmup, barrier)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    logs = h.pop_logs() if not graphs else [{k: float(v) for k, v in d.items() if k != "i_batch"} for g in graphs for d in g.logs]
-    finite = all(v == v and abs(v) != float("inf") for d in logs for v in d.values())
+    finite = case.logs_finite()
 
     # replicas must hold bit-identical weights after the timed steps (same reduced gradients, same Adam)
     in_sync = True
@@ -239,29 +333,25 @@ def main():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         in_sync = bool(torch.equal(hi, lo))
 
-    # ---- roofline of the dominant kernel.
+    # ---- roofline of the dominant contraction.
     # (1) an instrumented eager pass over the same steps brackets every GEMM launch with HIP events on the launch
     #     stream to find which (kernel, shape) owns the most device time;
     # (2) that exact launch is then timed back-to-back (queue kept full, so no host gaps pollute the per-launch time)
     #     between two HIP events on the same stream. achieved = algorithmic FLOPs per launch / that duration.
-    roof = None
+    gemm_roof = None
+    nprof = max(1, min(2, args.steps))
     # The instrumented pass drives full optimizer steps, which contain the two gradient all-reduces: EVERY rank has to run it
     # (rank 0 alone deadlocks the job at world > 1 -- observed: a 2-rank default-flag run hung until its 900 s timeout).
-    if world > 1 and not args.no_roofline and rank != 0:
-        cursor[0] = 0
-        for _ in range(max(1, min(2, args.steps))):
-            eager_step()
+    if not args.no_roofline:
+        if rank == 0:
+            ops.KERNEL_PROFILE = []
+        case.cursor = 0
+        for _ in range(nprof):
+            case.eager_step()
         torch.cuda.synchronize()
         h.history.clear()
     if rank == 0 and not args.no_roofline:
-        ops.KERNEL_PROFILE = []
-        nprof = max(1, min(2, args.steps))
-        cursor[0] = 0
-        for _ in range(nprof):
-            eager_step()
-        torch.cuda.synchronize()
         prof, ops.KERNEL_PROFILE = ops.KERNEL_PROFILE, None
-        h.history.clear()
         agg = {}
         for name, shape, flops, e0, e1 in prof:
             M, N, K, sp = shape
@@ -280,139 +370,130 @@ def main():
         A = torch.randn((M, K) if a_kc else (K, M), device=dev)
         B = torch.randn((N, K) if b_kc else (K, N), device=dev)
         out = torch.empty(M, N, device=dev)
-        for _ in range(3):
-            ops.gemm(A, B, a_kc, b_kc, M, N, K, out=out)
-        torch.cuda.synchronize()
-        iters = 50
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            ops.gemm(A, B, a_kc, b_kc, M, N, K, out=out)
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / iters
+        us = event_time_us(torch, lambda: ops.gemm(A, B, a_kc, b_kc, M, N, K, out=out), 50)
         flops = 2.0 * M * N * K
         achieved = flops / us / 1e6
-        pmc = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")))
+        traffic, traffic_src = None, None
+        try:      # PMC passes are separate runs (profiles/README.md); only a measurement of THIS kernel + shape + mode counts
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_gemm.json")))
+            ent = pmc.get("launches", {}).get(f"{M}x{N}x{K}")
+            if ent and ent.get("kernel") == kname and ent.get("gemm_mode") == args.gemm_mode:
+                traffic, traffic_src = ent["hbm_bytes_per_launch"], "profiles/r02_pmc_gemm.json"
         except Exception:
             pass
-        traffic = None
-        ent = (pmc or {}).get("launches", {}).get(f"{M}x{N}x{K}")       # PMC passes are separate runs (profiles/README.md)
-        if ent:
-            traffic = ent["hbm_bytes_per_launch"]
         total_gemm_ms = sum(v["ms"] for v in agg.values()) / nprof
         if args.gemm_mode == "bf16x3":
             peak, peak_note = PEAK_BF16X3_TFLOPS, ("bf16x3: 3 bf16 MFMAs per fp32-equivalent product -> roof = dense bf16 MFMA peak / 3 "
                                                    "in algorithmic 2MNK flops (the fp32 MFMA roof would be 157.3)")
         else:
             peak, peak_note = PEAK_F32_MFMA_TFLOPS, "fp32 MFMA peak"
-        roof = {"bound": "mfma", "kernel": kname, "shape_MNK": [M, N, K], "achieved": round(achieved, 2),
-                "peak": round(peak, 1), "peak_note": peak_note, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "traffic": traffic, "avg_launch_us": round(us, 2), "flops_per_launch": flops,
-                "algorithmic_bytes_per_launch": 4.0 * (M * K + N * K + M * N),
-                "launches_per_step": top["n"] // nprof, "share_of_gemm_time_eager": round(top["ms"] / nprof / total_gemm_ms, 3),
-                "method": "50 back-to-back launches between two HIP events on the launch stream",
-                "eager_event_bracketed_us": {f"{k[0]} {list(k[1][:3])}": round(1e3 * v["ms"] / v["n"], 1)
-                                             for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]}}
+        gemm_roof = {"bound": "mfma", "kernel": kname, "shape_MNK": [M, N, K], "achieved": round(achieved, 2),
+                     "peak": round(peak, 1), "peak_note": peak_note, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                     "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": round(us, 2), "flops_per_launch": flops,
+                     "algorithmic_bytes_per_launch": 4.0 * (M * K + N * K + M * N),
+                     "launches_per_step": top["n"] // nprof, "share_of_gemm_time_eager": round(top["ms"] / nprof / total_gemm_ms, 3),
+                     "method": "50 back-to-back launches between two HIP events on the launch stream",
+                     "eager_event_bracketed_us": {f"{k[0]} {list(k[1][:3])}": round(1e3 * v["ms"] / v["n"], 1)
+                                                  for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]}}
+        del A, B, out
 
-    # ---- extra (single GPU): the same step with EXACT fp32 MFMA arithmetic
-    exact_extra = None
-    if world == 1 and args.gemm_mode == "bf16x3" and not args.eager and graphs and not args.no_bf16_extra:
+    roof = gemm_roof
+    if rank == 0 and not args.no_roofline and args.mode == "patch":
         try:
-            from advmil_amd.graphed import GraphedStep
-            ops.set_gemm_mode("exact")
-            g3 = []
-            for g0 in range(0, n_pool - args.bags + 1, args.bags):
-                idx = list(range(g0, g0 + args.bags))
-                g3.append(GraphedStep(h, [xs[i] for i in idx], [ys[i] for i in idx], [ys_host[i] for i in idx], warmup=1))
-            for k in range(args.warmup):
-                g3[k % len(g3)].replay()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for k in range(args.steps):
-                g3[k % len(g3)].replay()
-            torch.cuda.synchronize()
-            dt3 = time.perf_counter() - t1
-            A_ = torch.randn(131072 if args.patches * args.bags >= 131072 else args.patches * args.bags, 1024, device=dev)
-            B_ = torch.randn(384, 1024, device=dev)
-            Mx = A_.shape[0]
-            o_ = torch.empty(Mx, 384, device=dev)
-            for _ in range(3):
-                ops.gemm(A_, B_, True, True, Mx, 384, 1024, out=o_)
-            torch.cuda.synchronize()
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
-            for _ in range(20):
-                ops.gemm(A_, B_, True, True, Mx, 384, 1024, out=o_)
-            ev1.record(); torch.cuda.synchronize()
-            usx = ev0.elapsed_time(ev1) * 50
-            tfx = 2.0 * Mx * 384 * 1024 / usx / 1e6
-            exact_extra = {"value": round(args.bags * args.steps / dt3, 3), "unit": "bags/s", "ms_per_step": round(1e3 * dt3 / args.steps, 3),
-                           "dtype": "f32 (v_mfma_f32_32x32x2_f32)",
-                           "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel<1,1,2,2> exact", "shape_MNK": [Mx, 384, 1024],
-                                        "achieved": round(tfx, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                        "frac": round(tfx / PEAK_F32_MFMA_TFLOPS, 4), "avg_launch_us": round(usx, 2)}}
-            del g3
+            roof = attention_roofline(torch, ops, dev, args.patches // 16, args.bags)
         except Exception as exc:
-            exact_extra = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
-        finally:
-            ops.set_gemm_mode(args.gemm_mode)
+            roof = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
 
     # ---- the attention-pool kernels against the HBM roof (north star: ">= 50% of HBM3E roofline"): segmented softmax statistics +
-    # weighted row sum + merge over the step slab's hidden rows h[sum N, 384]; algorithmic bytes = h read once + scores read twice
-    # + attention weights written once. Slabs rotate so that h does not sit in the 256 MB Infinity Cache.
+    # weighted row sum + merge over the hidden rows h[sum N, 384]; algorithmic bytes = h read once + scores read twice + attention
+    # weights written once; at the step slab and at one bag (bp_every_batch = 1).
     pool_roof = None
     if rank == 0 and not args.no_roofline and args.mode == "abmil":
         try:
-            Dh = 384
-            nrows = args.bags * args.patches
-            nbuf = max(2, int(600e6 // (4 * nrows * Dh)) + 1)
-            hs = [torch.randn(nrows, Dh, device=dev) for _ in range(nbuf)]
-            sc = torch.randn(nrows, device=dev)
-            seg_b = ops.Segments([args.patches] * args.bags, dev)
-            for k in range(3):
-                ops.softmax_pool(sc, hs[k % nbuf], nrows, Dh, seg_b)
-            torch.cuda.synchronize()
-            itp = 40
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for k in range(itp):
-                ops.softmax_pool(sc, hs[k % nbuf], nrows, Dh, seg_b)
-            e1.record()
-            torch.cuda.synchronize()
-            usp = e0.elapsed_time(e1) * 1e3 / itp
-            byt = 4.0 * nrows * Dh + 3 * 4.0 * nrows
-            pool_roof = {"bound": "hbm", "kernel": "softmax_stats + pool_partial + colsum_merge (advmil_softmax_pool_fwd)",
-                         "rows": nrows, "achieved": round(byt / usp / 1e3, 1), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(byt / usp / 1e3 / 8000.0, 4), "avg_call_us": round(usp, 2), "algorithmic_bytes_per_call": byt,
-                         "method": "40 back-to-back calls (3 launches each) between two HIP events, rotating slabs > 256 MB"}
-            del hs
+            pool_roof = pool_roofline(torch, ops, dev, args.patches, args.bags)
+            pool_roof["one_bag"] = pool_roofline(torch, ops, dev, args.patches, 1)
         except Exception as exc:
             pool_roof = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
 
-    # ---- extra (single GPU): one bag per optimizer step (bp_every_batch = 1), the reading of the north star's "G+D steps/s"
-    # (then steps/s == bags/s)
-    bp1_extra = None
-    if world == 1 and not args.eager and graphs and not args.no_bf16_extra and args.bags > 1:
-        try:
-            from advmil_amd.graphed import GraphedStep
-            g1 = [GraphedStep(h, [xs[i]], [ys[i]], [ys_host[i]], warmup=1) for i in range(min(8, n_pool))]
+    # ---- extras (single GPU): one bag per optimizer step in both arithmetic modes, the exact-fp32 step, the other sizes / backbone
+    sizes = None
+    exact_extra = bp1_extra = None
+    if world == 1 and rank == 0 and not args.eager and case.graphs and not args.no_extras:
+        from advmil_amd.graphed import GraphedStep
+
+        def sync_barrier():
+            torch.cuda.synchronize()
+
+        def bp1(n1=200):
+            g1 = [GraphedStep(h, [case.xs[i]], [case.ys[i]], [case.ys_host[i]], warmup=1) for i in range(min(8, case.n_pool))]
             for k in range(8):
                 g1[k % len(g1)].replay()
             torch.cuda.synchronize()
-            n1 = 200
             t1 = time.perf_counter()
             for k in range(n1):
                 g1[k % len(g1)].replay()
             torch.cuda.synchronize()
-            dt1 = time.perf_counter() - t1
-            bp1_extra = {"value": round(n1 / dt1, 2), "unit": "G+D steps/s (1 bag of %d patches per step)" % args.patches,
-                         "ms_per_step": round(1e3 * dt1 / n1, 3), "steps": n1}
-            del g1
+            d1 = time.perf_counter() - t1
+            return {"value": round(n1 / d1, 2), "unit": "G+D steps/s (1 bag of %d patches per step)" % args.patches,
+                    "ms_per_step": round(1e3 * d1 / n1, 3), "steps": n1}
+
+        try:
+            if args.bags > 1:
+                bp1_extra = {args.gemm_mode: bp1()}
         except Exception as exc:
             bp1_extra = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
+        if args.gemm_mode == "bf16x3":
+            try:
+                ops.set_gemm_mode("exact")
+                n3 = max(10, args.steps // 4)
+                g3 = []
+                for g0 in range(0, case.n_pool - args.bags + 1, args.bags):
+                    idx = list(range(g0, g0 + args.bags))
+                    g3.append(GraphedStep(h, [case.xs[i] for i in idx], [case.ys[i] for i in idx], [case.ys_host[i] for i in idx], warmup=1))
+                for k in range(args.warmup):
+                    g3[k % len(g3)].replay()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for k in range(n3):
+                    g3[k % len(g3)].replay()
+                torch.cuda.synchronize()
+                dt3 = time.perf_counter() - t1
+                Mx = min(131072, args.patches * args.bags)
+                A_, B_, o_ = torch.randn(Mx, 1024, device=dev), torch.randn(384, 1024, device=dev), torch.empty(Mx, 384, device=dev)
+                usx = event_time_us(torch, lambda: ops.gemm(A_, B_, True, True, Mx, 384, 1024, out=o_), 20)
+                tfx = 2.0 * Mx * 384 * 1024 / usx / 1e6
+                exact_extra = {"value": round(args.bags * n3 / dt3, 3), "unit": "bags/s", "ms_per_step": round(1e3 * dt3 / n3, 3), "steps": n3,
+                               "dtype": "f32 (v_mfma_f32_32x32x2_f32)",
+                               "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel<1,1,2,2> exact", "shape_MNK": [Mx, 384, 1024],
+                                            "achieved": round(tfx, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                            "frac": round(tfx / PEAK_F32_MFMA_TFLOPS, 4), "avg_launch_us": round(usx, 2)}}
+                del g3, A_, B_, o_
+                if args.bags > 1 and isinstance(bp1_extra, dict) and "error" not in bp1_extra:
+                    bp1_extra["exact"] = bp1()
+            except Exception as exc:
+                exact_extra = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
+            finally:
+                ops.set_gemm_mode(args.gemm_mode)
+        # other sizes / the ESAT backbone (north_star: N in {1k, 8k, 32k}; configs[3] = ESAT at 32k patches)
+        case.free()
+        sizes = {}
+        for tag, mode_, patches_, bags_, pool_, steps_ in (("abmil_1024", "abmil", 1024, 16, 128, 60), ("abmil_32768", "abmil", 32768, 16, 16, 12),
+                                                          ("esat_8192", "patch", 8192, 16, 64, 30), ("esat_32768", "patch", 32768, 16, 16, 12)):
+            if mode_ == args.mode and patches_ == args.patches:
+                continue
+            try:
+                c2 = Case(torch, dev, mode_, patches_, bags_, pool_, args.gemm_mode, 4321)
+                d2, _ = c2.timed(steps_, 2, sync_barrier)
+                ent = {"value": round(bags_ * steps_ / d2, 2), "unit": "bags/s", "ms_per_step": round(1e3 * d2 / steps_, 3), "steps": steps_,
+                       "bags_per_step": bags_, "distinct_resident_bags": c2.n_pool, "losses_finite": c2.logs_finite(), "launch": c2.launch_note}
+                c2.free()
+                del c2
+                if mode_ == "patch":
+                    ent["roofline"] = attention_roofline(torch, ops, dev, patches_ // 16, bags_, iters=10)
+                sizes[tag] = ent
+            except Exception as exc:
+                sizes[tag] = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
+                torch.cuda.synchronize()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only; at N > 1 the other ranks would idle in the barrier
@@ -420,23 +501,26 @@ def main():
 
     if rank == 0:
         bags_total = args.bags * world * args.steps
+        names = {"abmil": "ABMIL", "patch": "ESAT (DualTrans_HS)", "cluster": "DeepAttMISL", "graph": "PatchGCN"}
         out = {
             "metric": "WSI bags/sec (full G+D step)", "value": round(bags_total / dt, 3), "unit": "bags/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("bf16x3 (fp32 operands split hi+lo in registers, 3 bf16 MFMAs per product, fp32 accumulate; fp32 storage)"
+            "dtype": ("bf16x3 (fp32 operands split hi+lo, 3 bf16 MFMAs per product, fp32 accumulate; fp32 storage)"
                       if args.gemm_mode == "bf16x3" else "f32"), "data": "synthetic",
-            "config": {"workload": f"{args.mode.upper()}+AdvMIL(RLIP prj discriminator), {args.patches}-patch x 1024 fp32 bags "
-                                   f"(BASELINE.json configs[1] shape; fp32 storage, "
+            "config": {"workload": f"{names[args.mode]}+AdvMIL(RLIP prj discriminator), {args.patches}-patch x 1024 fp32 bags "
+                                   + ("(BASELINE.json configs[1] shape; " if (args.mode == "abmil" and args.patches == 8192) else
+                                      ("(BASELINE.json configs[3] shape; " if (args.mode == "patch" and args.patches == 32768) else "("))
+                                   + "fp32 storage, "
                                    + ("bf16x3 split arithmetic: >= the bf16 the config names, within 2e-5 of the fp32 reference)"
                                       if args.gemm_mode == "bf16x3" else "exact fp32 MFMA arithmetic)"),
                        "bags_per_step_per_gpu": args.bags, "global_bags_per_step": args.bags * world, "gen_updates": 1,
-                       "distinct_resident_bags_per_gpu": n_pool, "parallelism": f"bag-parallel dp{world}", "dropout": "shipped rates",
-                       "launch": launch_note},
+                       "distinct_resident_bags_per_gpu": case.n_pool, "parallelism": f"bag-parallel dp{world}", "dropout": "shipped rates",
+                       "launch": case.launch_note},
             "gd_steps_per_sec": round(args.steps / dt, 3), "losses_finite": bool(finite), "replicas_in_sync": in_sync,
             "host_submit_ms_per_step": round(1e3 * t_submit / args.steps, 3),
-            "roofline": roof, "pool_roofline": pool_roof, "cpu_baseline": cpu, "exact_f32_mfma_mode": exact_extra,
-            "bp_every_batch_1": bp1_extra,
+            "roofline": roof, "gemm_roofline": (gemm_roof if roof is not gemm_roof else None), "pool_roofline": pool_roof,
+            "cpu_baseline": cpu, "exact_f32_mfma_mode": exact_extra, "bp_every_batch_1": bp1_extra, "sizes": sizes,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -16,3 +16,11 @@ def pytest_configure(config):
 def golden():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden2():
+    """Round-2 fixtures at the BASELINE sizes (tests/golden/gen_golden_r2.py): 32768-patch ESAT eval forward, optimizer steps at
+    8192 / 32768 patches through the reference's own handler."""
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "golden_v2.npz"))

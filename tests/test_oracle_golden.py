@@ -128,3 +128,46 @@ def test_G5_losses(golden):
 def test_first_step_loss_d_quirk(golden):
     # bce D loss is -mean(1 - log s(fake)) - mean(log s(real)); first step ~ -1
     assert -1.2 < golden["G4_abmil_logs"][0][0] < -0.8
+
+
+# ---- round-2 fixtures at the BASELINE sizes (tests/golden/gen_golden_r2.py)
+def test_pin_report_r2_is_tight():
+    meta = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ORACLE_PIN_r2.json")))
+    assert meta["worst"] < 5e-6 and meta["worst_post_adam_weights"] < 2.5 * 8e-5
+    assert set(meta["oracle_vs_reference_maxabs"]) == {"G1/patch/32768", "G4L_abmil_8192", "G4L_patch_8192", "G4L_patch_32768"}
+
+
+def test_G1_patch_32768_eval_forward(golden2):
+    """configs[3]'s size: one 32768-patch bag -> 2048 region tokens through the ESAT layer."""
+    P = H.synth_params(H.shapes_generator("patch"), "G-patch:")
+    with torch.no_grad():
+        y, A, Hh = O.generator(P, H.bag(0, 32768), None, "patch", (0, 1), None, None, "sigmoid", return_attn=True)
+    close(y, golden2["G1_patch_32768_y"])
+    close(Hh, golden2["G1_patch_32768_H"], 5e-6)
+    close(A.reshape(-1), golden2["G1_patch_32768_A"], 1e-7)
+
+
+@pytest.mark.parametrize("name", ["G4L_abmil_8192", "G4L_patch_8192"])
+def test_G4L_full_size_optimizer_steps(golden2, name):
+    kind = name.split("_")[1]
+    N, bpb, nsteps, i0 = (int(v) for v in golden2[name + "_case"])
+    PG = H.synth_params(H.shapes_generator(kind), f"G-{kind}:")
+    PD = H.synth_params(H.shapes_disc(), "D-prj:")
+    cfg = O.StepConfig(kind=kind)
+    nb = bpb * nsteps
+    bags = [(H.bag(i0 + j, N), None, H.label(i0 + j)) for j in range(nb)]
+    nd = [[H.noise_tensor(f"{name}d", j, 192)] for j in range(nb)]
+    ng = [[H.noise_tensor(f"{name}g", j, 192)] for j in range(nb)]
+    stG, stD, ys, fs = {}, {}, [], []
+    for s in range(nsteps):
+        sl = slice(bpb * s, bpb * (s + 1))
+        PG, PD, lg, yh, ff, gG, gD = O.train_step(cfg, PG, PD, stG, stD, bags[sl], nd[sl], ng[sl])
+        got = [lg[k] for k in ("Loss_D", "D_real", "D_fake", "Loss_G_fake", "Loss_G_time", "Loss_G_total", "D_fake_avg")]
+        close(got, golden2[name + "_logs"][s])
+        ys.append(yh); fs.append(ff)
+    close(torch.cat(ys), golden2[name + "_y_hat"])
+    close(torch.cat(fs), golden2[name + "_f_fake"])
+    gk = [str(k) for k in golden2[name + "_gradG_keys"]]
+    gn = np.array([float(gG[k].double().norm()) for k in gk])
+    # atol: parameters whose true gradient is ~0 (a softmax-invariant bias) hold only round-off plus the L1 term's 1e-5 * sign(W)
+    assert np.allclose(gn, golden2[name + "_gradG_last_norm"], rtol=1e-4, atol=2e-8)
