@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Copy the rocprofv3 summaries produced by tools/profile_round.sh (gpurun_out/prof_r02/...) into profiles/ (tracked) and
+assemble the PMC JSONs bench.py / DESIGN.md cite. FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KB; on gfx950 FETCH_SIZE
+counts wide coalesced reads at half their bytes (MI355X_MICROARCH.md, HBM section) -> doubled here, stated per entry."""
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import prof_summary  # noqa: E402
+import csv  # noqa: E402
+
+SRC = os.path.join(ROOT, "gpurun_out", "prof_r02")
+DST = os.path.join(ROOT, "profiles")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+
+
+def first(pattern):
+    f = sorted(glob.glob(os.path.join(SRC, pattern), recursive=True))
+    return f[0] if f else None
+
+
+def counter(run, name):
+    agg = {}
+    for f in sorted(glob.glob(os.path.join(SRC, run, "**", "*counter_collection.csv"), recursive=True)):
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") != name:
+                continue
+            a = agg.setdefault(row["Kernel_Name"].split("(")[0].replace("void ", ""), {})
+            a[row["Dispatch_Id"]] = a.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+    return {k: (len(v), sum(v.values()) / len(v)) for k, v in agg.items()}
+
+
+def stats_avg(run):
+    f = first(f"{run}/**/*kernel_stats.csv")
+    out = {}
+    if f:
+        for row in csv.DictReader(open(f)):
+            out[row["Name"].split("(")[0].replace("void ", "")] = (int(row["Calls"]), float(row["AverageNs"]) / 1e3)
+    return out
+
+
+for run in ("bench_abmil", "bench_esat32k", "pool16", "pool1", "attn2048"):
+    f = first(f"{run}/**/*kernel_stats.csv")
+    if f:
+        shutil.copy(f, os.path.join(DST, f"{TAG}_{run}_kernel_stats.csv"))
+    lg = os.path.join(SRC, run + ".log")
+    if os.path.exists(lg) and run.startswith("bench"):
+        shutil.copy(lg, os.path.join(DST, f"{TAG}_{run}.log"))
+
+# ---- attention-pool kernels: HBM bytes per launch vs algorithmic bytes, per kernel, both slab sizes
+fe, wr = counter("pool16_fetch", "FETCH_SIZE"), counter("pool16_write", "WRITE_SIZE")
+if fe:
+    rows, D = 131072, 384
+    st16, st1 = stats_avg("pool16"), stats_avg("pool1")
+    out = {"command": "rocprofv3 --pmc FETCH_SIZE -- python3 tools/pool_bench.py 8192 16 12 ; separate --pmc WRITE_SIZE pass; "
+                      "durations: rocprofv3 --kernel-trace --stats -- python3 tools/pool_bench.py 8192 16 40 (and 8192 1 200)",
+           "units": "FETCH_SIZE / WRITE_SIZE are KB; FETCH_SIZE x2 (gfx950: wide coalesced reads tallied at half their bytes)",
+           "rows": rows, "D": D, "kernels": {}}
+    for k in ("pool_partial8_kernel", "pool_bwd_dot_kernel", "softmax_stats_kernel", "pool_bwd_ds_kernel", "colsum_merge_kernel"):
+        if k not in fe:
+            continue
+        fetched = 2.0 * fe[k][1] * 1024
+        written = wr.get(k, (0, 0.0))[1] * 1024
+        alg = {"pool_partial8_kernel": 4.0 * rows * D + 4.0 * rows, "pool_bwd_dot_kernel": 4.0 * rows * D + 8.0 * rows}.get(k)
+        ent = {"fetch_bytes_per_launch": fetched, "write_bytes_per_launch": written, "hbm_bytes_per_launch": fetched + written,
+               "algorithmic_bytes_per_launch": alg}
+        if k in st16:
+            ent["avg_us_16_bags"] = st16[k][1]
+            if alg:
+                ent["GBps_16_bags"] = alg / st16[k][1] / 1e3
+                ent["frac_of_8TBps_16_bags"] = alg / st16[k][1] / 1e3 / 8000.0
+        if k in st1:
+            ent["avg_us_1_bag"] = st1[k][1]
+            if alg:
+                ent["frac_of_8TBps_1_bag"] = (alg / 16.0) / st1[k][1] / 1e3 / 8000.0
+        out["kernels"][k] = ent
+    json.dump(out, open(os.path.join(DST, f"{TAG}_pmc_pool.json"), "w"), indent=1)
+
+# ---- attention core: instruction mix
+va, mf, mb = counter("attn2048_sq", "SQ_INSTS_VALU"), counter("attn2048_sq", "SQ_INSTS_MFMA"), counter("attn2048_sq", "SQ_VALU_MFMA_BUSY_CYCLES")
+if va:
+    st = stats_avg("attn2048")
+    out = {"command": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -- python3 tools/attn_bench.py 2048 16 0.25 4",
+           "shape": "16 bags x 2048 tokens x 8 heads x 48, attention dropout 0.25", "kernels": {}}
+    for k in va:
+        if not k.startswith("attn_"):
+            continue
+        ent = {"valu_insts": va[k][1], "mfma_insts": mf.get(k, (0, 0))[1], "mfma_busy_cycles": mb.get(k, (0, 0))[1]}
+        if ent["mfma_insts"]:
+            ent["valu_per_mfma"] = ent["valu_insts"] / ent["mfma_insts"]
+        if k in st:
+            ent["avg_us"] = st[k][1]
+            ent["mfma_pipe_busy_frac_at_2.4GHz"] = ent["mfma_busy_cycles"] / (st[k][1] * 1e-6 * 2.4e9 * 1024)
+        out["kernels"][k] = ent
+    json.dump(out, open(os.path.join(DST, f"{TAG}_pmc_attn.json"), "w"), indent=1)
+
+# ---- dominant contraction: HBM traffic per launch for the tile bench.py names
+launches = {}
+for shape in ("131072x768x384", "131072x384x1024"):
+    fe, wr = counter(f"gemm_{shape}_fetch", "FETCH_SIZE"), counter(f"gemm_{shape}_write", "WRITE_SIZE")
+    ks = [k for k in fe if k.startswith("gemm_f32_kernel")]
+    if not ks:
+        continue
+    k = max(ks, key=lambda n: fe[n][0])
+    M, N, K = (int(v) for v in shape.split("x"))
+    fetched, written = 2.0 * fe[k][1] * 1024, wr.get(k, (0, 0.0))[1] * 1024
+    tmpl = k[k.index("<") + 1:k.index(">")].split(", ")        # A_KC, B_KC, TM, TN, SPLIT, PRE, BKT, WR, WC
+    name = "gemm_f32_kernel<%d,%d,%s,%s>" % (tmpl[0] == "true", tmpl[1] == "true", int(tmpl[2]) * (int(tmpl[7]) // 2), int(tmpl[3]) * (int(tmpl[8]) // 2))
+    launches[shape] = {"kernel": name, "kernel_symbol": k, "gemm_mode": "bf16x3", "fetch_bytes_per_launch": fetched,
+                       "write_bytes_per_launch": written, "hbm_bytes_per_launch": fetched + written,
+                       "algorithmic_bytes_per_launch": 4.0 * (M * K + N * K + M * N), "dispatches": fe[k][0]}
+if launches:
+    json.dump({"command": "ADVMIL_GEMM_MODE=bf16x3 rocprofv3 --pmc FETCH_SIZE -- python3 tools/pmc_gemm.py M N K 1 1 8 ; separate --pmc WRITE_SIZE pass",
+               "units": "KB counters; FETCH_SIZE x2 (gfx950 correction)", "launches": launches},
+              open(os.path.join(DST, f"{TAG}_pmc_gemm.json"), "w"), indent=1)
+print(sorted(os.listdir(DST)))
