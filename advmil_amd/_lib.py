@@ -25,7 +25,8 @@ class Epilogue(ctypes.Structure):
                 ("seed", c_void_p), ("stream_id", c_uint64), ("rowv", c_void_p), ("colv", c_void_p), ("rowseg", c_void_p),
                 ("maskref", c_void_p), ("ldmask", c_int), ("mask_scale", c_float), ("accumulate", c_int),
                 ("alpha", c_float), ("a_hi", c_void_p), ("a_lo", c_void_p), ("b_hi", c_void_p), ("b_lo", c_void_p),
-                ("c_hi", c_void_p), ("c_lo", c_void_p), ("gate_wc", c_void_p), ("gate_out", c_void_p), ("gate_np", c_int)]
+                ("c_hi", c_void_p), ("c_lo", c_void_p), ("gate_wc", c_void_p), ("gate_out", c_void_p), ("gate_np", c_int),
+                ("rng_row", c_void_p)]
 
 
 # name -> (restype, argtypes); must list every symbol include/advmil_hip.h declares
@@ -48,12 +49,13 @@ SIGNATURES = {
     "advmil_mha_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64, c_float,
                                c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "advmil_add_dropout_ln_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int64, c_float, c_void_p,
-                                          c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                          c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "advmil_add_dropout_ln_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "advmil_add_dropout_ln_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p,
-                                          c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+                                          c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
+                                          c_void_p]),
     "advmil_gate_score_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_uint64, c_uint64, c_int64, c_int64,
-                                      c_void_p, c_void_p]),
+                                      c_void_p, c_void_p, c_void_p]),
     "advmil_softmax_pool_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "advmil_softmax_pool_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p,
                                         c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -61,10 +63,10 @@ SIGNATURES = {
                                         c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "advmil_gate_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "advmil_gate_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_uint64, c_uint64, c_int64, c_int64,
-                                c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "advmil_colsum_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "advmil_act_dropout_bwd": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_uint64, c_int64, c_int64, c_void_p,
-                                       c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+                                       c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "advmil_colsum": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "advmil_ln_relu_mean16_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int64, c_void_p, c_void_p,
                                           c_void_p, c_void_p]),
@@ -83,8 +85,8 @@ SIGNATURES = {
                                  c_float, c_float, c_float, c_void_p, c_void_p]),
     "advmil_abs_sum": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "advmil_abs_sum_workspace_bytes": (c_size_t, [c_int64]),
-    "advmil_uniform_fill": (c_int, [c_void_p, c_int64, c_void_p, c_uint64, c_void_p]),
-    "advmil_dropout_apply": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_uint64, c_void_p]),
+    "advmil_uniform_fill": (c_int, [c_void_p, c_int64, c_void_p, c_uint64, c_void_p, c_int64, c_void_p]),
+    "advmil_dropout_apply": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_uint64, c_void_p, c_int64, c_void_p]),
     "advmil_seed_advance": (c_int, [c_void_p, c_uint64, c_void_p]),
     "advmil_skinny_linear_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "advmil_skinny_linear_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,

@@ -49,7 +49,7 @@ __device__ __forceinline__ float epilogue_elem(const advmil_epilogue_t& e, float
   if (e.bias) v += e.bias[n];
   if (e.rowv) v += e.rowv[m] * e.colv[(e.rowseg ? (int64_t)e.rowseg[m] * N : 0) + n];
   v = act_apply(n < e.act_split ? e.act0 : e.act1, v);
-  if (e.seed && e.drop_p > 0.0f) v *= rng_keep(key, (uint64_t)(m * N + n), e.drop_p, inv_keep);
+  if (e.seed && e.drop_p > 0.0f) v *= rng_keep(key, (uint64_t)((e.rng_row ? e.rng_row[m] : m) * N + n), e.drop_p, inv_keep);
   if (e.maskref) v *= (e.maskref[m * (int64_t)e.ldmask + n] > 0.0f ? e.mask_scale : 0.0f);
   return v;
 }
@@ -483,6 +483,7 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 || TM * TN > 4 ? 1 : 2))
           if (direct) {
             float r1 = 0.f;
             const float* cv = nullptr;
+            const int64_t grow = (e.seed && e.rng_row) ? e.rng_row[row] : row;      // the row's index in the dropout stream
             if (e.rowv) {
               r1 = e.rowv[row];
               cv = e.colv + (e.rowseg ? (int64_t)e.rowseg[row] * g.N : 0) + col;
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 || TM * TN > 4 ? 1 : 2))
                 float x = v[t] * e.alpha + bias4[t];
                 if (cv) x += r1 * cv[t];
                 x = act_apply(same_act ? act4[0] : act4[t], x);
-                if (e.seed && e.drop_p > 0.0f) x *= rng_keep(key, (uint64_t)(row * g.N + col + t), e.drop_p, inv_keep);
+                if (e.seed && e.drop_p > 0.0f) x *= rng_keep(key, (uint64_t)(grow * g.N + col + t), e.drop_p, inv_keep);
                 if (e.maskref) x *= (e.maskref[row * (int64_t)e.ldmask + col + t] > 0.0f ? e.mask_scale : 0.0f);
                 if (e.accumulate) x += c[t];
                 v[t] = x;

@@ -72,16 +72,23 @@ extern "C" int advmil_abs_sum(const float* p, int64_t n, float* out, void* ws, s
   return ADVMIL_OK;
 }
 
-__global__ __launch_bounds__(256) void uniform_fill_kernel(float* __restrict__ out, int64_t n, const uint64_t* seed, uint64_t stream_id) {
+// rng_row (optional, with the row width `width`): element i of the flat tensor belongs to row i / width, whose draws are indexed
+// as row rng_row[i / width] -- the row it would occupy in the single-process run (bag-parallel world-size invariance)
+__device__ __forceinline__ uint64_t rng_flat_index(int64_t i, const int64_t* rng_row, int64_t width) {
+  return rng_row ? (uint64_t)(rng_row[i / width] * width + i % width) : (uint64_t)i;
+}
+__global__ __launch_bounds__(256) void uniform_fill_kernel(float* __restrict__ out, int64_t n, const uint64_t* seed, uint64_t stream_id,
+                                                           const int64_t* __restrict__ rng_row, int64_t width) {
   const uint64_t key = rng_key(*seed, stream_id);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    out[i] = rng_uniform(key, (uint64_t)i);
+    out[i] = rng_uniform(key, rng_flat_index(i, rng_row, width));
 }
-extern "C" int advmil_uniform_fill(float* out, int64_t n, const uint64_t* seed, uint64_t stream_id, advmil_stream_t stream_) {
-  if (!out || !seed || n <= 0) return ADVMIL_EINVAL;
+extern "C" int advmil_uniform_fill(float* out, int64_t n, const uint64_t* seed, uint64_t stream_id, const int64_t* rng_row,
+                                   int64_t width, advmil_stream_t stream_) {
+  if (!out || !seed || n <= 0 || (rng_row && width <= 0)) return ADVMIL_EINVAL;
   int blocks = (int)((n + 255) / 256);
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(uniform_fill_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, out, n, seed, stream_id);
+  hipLaunchKernelGGL(uniform_fill_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, out, n, seed, stream_id, rng_row, width);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }
@@ -89,18 +96,19 @@ extern "C" int advmil_uniform_fill(float* out, int64_t n, const uint64_t* seed, 
 // y[i] = x[i] * (u(seed, stream, i) >= p ? 1/(1-p) : 0): the dropout of the [B, d]-sized head tensors (and, applied to dy, its
 // backward) as ONE launch; same draw as the GEMM epilogue's dropout and synth.dropout_keep.
 __global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float p,
-                                                            const uint64_t* seed, uint64_t stream_id) {
+                                                            const uint64_t* seed, uint64_t stream_id,
+                                                            const int64_t* __restrict__ rng_row, int64_t width) {
   const uint64_t key = rng_key(*seed, stream_id);
   const float inv = 1.0f / (1.0f - p);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    y[i] = x[i] * rng_keep(key, (uint64_t)i, p, inv);
+    y[i] = x[i] * rng_keep(key, rng_flat_index(i, rng_row, width), p, inv);
 }
 extern "C" int advmil_dropout_apply(const float* x, float* y, int64_t n, float p, const uint64_t* seed, uint64_t stream_id,
-                                    advmil_stream_t stream_) {
-  if (!x || !y || !seed || n <= 0 || !(p >= 0.0f && p < 1.0f)) return ADVMIL_EINVAL;
+                                    const int64_t* rng_row, int64_t width, advmil_stream_t stream_) {
+  if (!x || !y || !seed || n <= 0 || !(p >= 0.0f && p < 1.0f) || (rng_row && width <= 0)) return ADVMIL_EINVAL;
   int blocks = (int)((n + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(dropout_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, x, y, n, p, seed, stream_id);
+  hipLaunchKernelGGL(dropout_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, x, y, n, p, seed, stream_id, rng_row, width);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void colsum_merge_kernel(const float* __restri
 __global__ __launch_bounds__(256) void gate_score_kernel(const float* __restrict__ ab, const float* __restrict__ wc,
                                                          const float* __restrict__ bc, float p, const uint64_t* seed,
                                                          uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D,
-                                                         float* __restrict__ s) {
+                                                         float* __restrict__ s, const int64_t* __restrict__ rng_row) {
   const int lane = threadIdx.x & 63;
   const bool drop = seed && p > 0.f;
   uint64_t ka = 0, kb = 0;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void gate_score_kernel(const float* __restrict
         if (q < D4) {
           float4 a = ra[q], b = rb[q];
           if (drop) {
-            const uint64_t base = (uint64_t)(n * D + q * 4);
+            const uint64_t base = (uint64_t)((rng_row ? rng_row[n] : n) * D + q * 4);
             a.x *= rng_keep(ka, base, p, inv);     b.x *= rng_keep(kb, base, p, inv);
             a.y *= rng_keep(ka, base + 1, p, inv); b.y *= rng_keep(kb, base + 1, p, inv);
             a.z *= rng_keep(ka, base + 2, p, inv); b.z *= rng_keep(kb, base + 2, p, inv);
@@ -142,8 +142,9 @@ __global__ __launch_bounds__(256) void gate_score_kernel(const float* __restrict
     for (int64_t j = lane; j < D; j += 64) {
       float a = row[j], b = row[D + j];
       if (drop) {
-        a *= rng_keep(ka, (uint64_t)(n * D + j), p, inv);
-        b *= rng_keep(kb, (uint64_t)(n * D + j), p, inv);
+        const uint64_t idx = (uint64_t)((rng_row ? rng_row[n] : n) * D + j);
+        a *= rng_keep(ka, idx, p, inv);
+        b *= rng_keep(kb, idx, p, inv);
       }
       acc += a * b * wc[j];
     }
@@ -154,12 +155,12 @@ __global__ __launch_bounds__(256) void gate_score_kernel(const float* __restrict
 
 extern "C" int advmil_gate_score_fwd(const float* ab, const float* wc, const float* bc, float drop_p, const uint64_t* seed,
                                      uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D, float* s,
-                                     advmil_stream_t stream) {
+                                     const int64_t* rng_row, advmil_stream_t stream) {
   if (!ab || !wc || !bc || !s || N <= 0 || D <= 0) return ADVMIL_EINVAL;
   int64_t blocks = (N + 3) / 4;
   if (blocks > 8192) blocks = 8192;          // grid-stride over rows: 32 workgroups per CU
   hipLaunchKernelGGL(gate_score_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ab, wc, bc,
-                     drop_p, seed, stream_a, stream_b, N, D, s);
+                     drop_p, seed, stream_a, stream_b, N, D, s, rng_row);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }
@@ -391,7 +392,8 @@ extern "C" int advmil_softmax_pool_bwd(const float* dpooled, const float* dA, co
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ ab, const float* __restrict__ ds,
                                                        const float* __restrict__ wc, float p, const uint64_t* seed,
                                                        uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D,
-                                                       float* __restrict__ dG, float* __restrict__ partial, int rpb) {
+                                                       float* __restrict__ dG, float* __restrict__ partial, int rpb,
+                                                       const int64_t* __restrict__ rng_row) {
   __shared__ __attribute__((aligned(16))) float red[1024];
   const RowColMap m = make_map(D);
   const bool drop = seed && p > 0.f;
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
       for (int q = 0; q < 4; ++q) {
         float fa = 1.f, fb = 1.f;
         if (drop) {
-          const uint64_t idx = (uint64_t)(n * D + m.c4 * 4 + q);
+          const uint64_t idx = (uint64_t)((rng_row ? rng_row[n] : n) * D + m.c4 * 4 + q);
           fa = rng_keep(ka, idx, p, inv);
           fb = rng_keep(kb, idx, p, inv);
         }
@@ -461,7 +463,8 @@ extern "C" size_t advmil_gate_bwd_workspace_bytes(int64_t N, int64_t D) {
 
 extern "C" int advmil_gate_bwd(const float* ab, const float* ds, const float* wc, float drop_p, const uint64_t* seed,
                                uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D, float* dG, float* dwc,
-                               float* dbc, float* dbias, int accumulate, void* ws, size_t ws_bytes, advmil_stream_t stream_) {
+                               float* dbc, float* dbias, int accumulate, const int64_t* rng_row, void* ws, size_t ws_bytes,
+                               advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!ab || !ds || !wc || !dG || !dwc || !dbc || !dbias || !ws || N <= 0 || D <= 0 || (D & 3) || D > 1024)
     return ADVMIL_EINVAL;
@@ -471,7 +474,7 @@ extern "C" int advmil_gate_bwd(const float* ab, const float* ds, const float* wc
   float* partial = (float*)ws;
   const int64_t stride = 3 * D + 4;
   hipLaunchKernelGGL(gate_bwd_kernel, dim3(nblk), dim3(256), 0, stream, ab, ds, wc, drop_p, seed, stream_a, stream_b, N, D,
-                     dG, partial, rpb);
+                     dG, partial, rpb, rng_row);
   ADVMIL_LAUNCH_CHECK();
   // dwc | dbias(a) | dbias(b) | dbc are adjacent in the partial rows: one merge launch over 3D+1 columns into a
   // scratch row, then scattered by the three tiny copies below would cost more launches; instead merge each target.
@@ -489,7 +492,7 @@ __global__ __launch_bounds__(256) void act_dropout_bwd_kernel(const float* __res
                                                               int act, float p, const uint64_t* seed, uint64_t stream_id,
                                                               int64_t M, int64_t N, int64_t c0, int64_t W,
                                                               float* __restrict__ dpre, float* __restrict__ partial,
-                                                              int64_t pstride, int rpb) {
+                                                              int64_t pstride, int rpb, const int64_t* __restrict__ rng_row) {
   __shared__ __attribute__((aligned(16))) float red[1024];
   const RowColMap m = make_map(W);
   const bool drop = seed && p > 0.f;
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(256) void act_dropout_bwd_kernel(const float* __res
       for (int q = 0; q < 4; ++q) {
         float f = 1.f, yy = yv[q];
         if (drop) {
-          f = rng_keep(key, (uint64_t)(off + q), p, inv);
+          f = rng_keep(key, (uint64_t)((rng_row ? rng_row[row] * N + c0 + m.c4 * 4 : off) + q), p, inv);
           yy *= keep_scale;   // undo the 1/(1-p) on kept elements (dropped ones get f = 0 anyway)
         }
         o[q] = gv[q] * f * act_grad_from_out(act, yy);
@@ -534,7 +537,7 @@ extern "C" size_t advmil_colsum_workspace_bytes(int64_t M, int64_t N) {
 
 extern "C" int advmil_act_dropout_bwd(const float* dy, const float* y, int act, float drop_p, const uint64_t* seed,
                                       uint64_t stream_id, int64_t M, int64_t N, float* dpre, float* dbias, int accumulate,
-                                      void* ws, size_t ws_bytes, advmil_stream_t stream_) {
+                                      const int64_t* rng_row, void* ws, size_t ws_bytes, advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!dy || !y || !dpre || M <= 0 || N <= 0 || (N & 3)) return ADVMIL_EINVAL;
   if (dbias && (!ws || ws_bytes < advmil_colsum_workspace_bytes(M, N))) return ADVMIL_EWORKSPACE;
@@ -544,7 +547,7 @@ extern "C" int advmil_act_dropout_bwd(const float* dy, const float* y, int act, 
   for (int64_t c0 = 0; c0 < N; c0 += 1024) {
     const int64_t W = (N - c0 < 1024) ? (N - c0) : 1024;
     hipLaunchKernelGGL(act_dropout_bwd_kernel, dim3(nblk), dim3(256), 0, stream, dy, y, act, drop_p, seed, stream_id, M, N,
-                       c0, W, dpre, partial, N, rpb);
+                       c0, W, dpre, partial, N, rpb, rng_row);
   }
   ADVMIL_LAUNCH_CHECK();
   if (dbias) {
@@ -794,7 +797,8 @@ __global__ __launch_bounds__(256) void add_dropout_ln_fwd_kernel(const float* __
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  float eps, int64_t R, int64_t d, float p, const uint64_t* seed,
                                                                  uint64_t stream_id, float* __restrict__ z, float* __restrict__ y,
-                                                                 float* __restrict__ mean, float* __restrict__ rstd) {
+                                                                 float* __restrict__ mean, float* __restrict__ rstd,
+                                                                 const int64_t* __restrict__ rng_row) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int Q = (int)((d + 63) / 64);
   const bool drop = seed && p > 0.f;
@@ -814,7 +818,7 @@ __global__ __launch_bounds__(256) void add_dropout_ln_fwd_kernel(const float* __
       float t = 0.f;
       if (ok) {
         float ov = o[n * d + j];
-        if (drop) ov *= rng_keep(key, (uint64_t)(n * d + j), p, ik);
+        if (drop) ov *= rng_keep(key, (uint64_t)((rng_row ? rng_row[n] : n) * d + j), p, ik);
         t = x[n * d + j] + ov;
         z[n * d + j] = t;
       }
@@ -843,7 +847,8 @@ __global__ __launch_bounds__(256) void add_dropout_ln_bwd_kernel(const float* __
                                                                  const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd, int64_t R, int64_t d, float p,
                                                                  const uint64_t* seed, uint64_t stream_id, float* __restrict__ dx,
-                                                                 float* __restrict__ dob, float* __restrict__ partial) {
+                                                                 float* __restrict__ dob, float* __restrict__ partial,
+                                                                 const int64_t* __restrict__ rng_row) {
   __shared__ float red[4 * 1024];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t g = blockIdx.x;
@@ -886,7 +891,7 @@ __global__ __launch_bounds__(256) void add_dropout_ln_bwd_kernel(const float* __
       if (q < Q && j < d) {
         const float dz = rs * (dxh[q] - c1 - xh[q] * c2);
         dx[n * d + j] = dz;
-        if (dob) dob[n * d + j] = drop ? dz * rng_keep(key, (uint64_t)(n * d + j), p, ik) : dz;
+        if (dob) dob[n * d + j] = drop ? dz * rng_keep(key, (uint64_t)((rng_row ? rng_row[n] : n) * d + j), p, ik) : dz;
       }
     }
   }
@@ -903,12 +908,13 @@ __global__ __launch_bounds__(256) void add_dropout_ln_bwd_kernel(const float* __
 }
 
 extern "C" int advmil_add_dropout_ln_fwd(const float* x, const float* o, const float* gamma, const float* beta, float eps,
-                                         int64_t R, int64_t d, float drop_p, const uint64_t* seed, uint64_t stream_id, float* z,
-                                         float* y, float* mean, float* rstd, advmil_stream_t stream) {
+                                         int64_t R, int64_t d, float drop_p, const uint64_t* seed, uint64_t stream_id,
+                                         const int64_t* rng_row, float* z, float* y, float* mean, float* rstd,
+                                         advmil_stream_t stream) {
   if (!x || !o || !gamma || !beta || !z || !y || !mean || !rstd || R <= 0 || d <= 0 || d > 512) return ADVMIL_EINVAL;
   if (drop_p < 0.f || drop_p >= 1.f) return ADVMIL_EINVAL;
   hipLaunchKernelGGL(add_dropout_ln_fwd_kernel, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, (hipStream_t)stream, x, o, gamma,
-                     beta, eps, R, d, drop_p, seed, stream_id, z, y, mean, rstd);
+                     beta, eps, R, d, drop_p, seed, stream_id, z, y, mean, rstd, rng_row);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }
@@ -918,16 +924,16 @@ extern "C" size_t advmil_add_dropout_ln_bwd_workspace_bytes(int64_t R, int64_t d
 }
 
 extern "C" int advmil_add_dropout_ln_bwd(const float* dy, const float* z, const float* gamma, const float* mean, const float* rstd,
-                                         int64_t R, int64_t d, float drop_p, const uint64_t* seed, uint64_t stream_id, float* dx,
-                                         float* dob, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes,
-                                         advmil_stream_t stream_) {
+                                         int64_t R, int64_t d, float drop_p, const uint64_t* seed, uint64_t stream_id,
+                                         const int64_t* rng_row, float* dx, float* dob, float* dgamma, float* dbeta,
+                                         int accumulate, void* ws, size_t ws_bytes, advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!dy || !z || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !ws || R <= 0 || d <= 0 || d > 512) return ADVMIL_EINVAL;
   if (ws_bytes < advmil_add_dropout_ln_bwd_workspace_bytes(R, d)) return ADVMIL_EWORKSPACE;
   const int nb = (int)((R + 15) / 16);
   float* partial = (float*)ws;
   hipLaunchKernelGGL(add_dropout_ln_bwd_kernel, dim3(nb), dim3(256), 0, stream, dy, z, gamma, mean, rstd, R, d, drop_p, seed,
-                     stream_id, dx, dob, partial);
+                     stream_id, dx, dob, partial, rng_row);
   ADVMIL_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial, nb, 2 * d, d, dgamma, accumulate);
   hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial + d, nb, 2 * d, d, dbeta, accumulate);

@@ -31,22 +31,25 @@ class GraphedStep:
         self.preds, self.fakes = self.h._disc_backward(0, self.xs, self.ys, self.plan)
 
     def _seg_mid(self):
+        self.h._log_d()                      # after the exchange: the logged statistics are the reduced ones
         self.h.optimizerD.step()
         self.h._gen_backward(0, self.xs, self.ys, self.plan)
 
     def _seg_end(self):
+        self.h._log_g()
         self.h.optimizerG.step()
         self.h.rng.advance(1)
 
     def _eager(self):
         self._seg_disc()
-        self.h.dp.allreduce_(self.h.optimizerD.flat_grad)
+        self.h._reduce_d()
         self._seg_mid()
-        self.h.dp.allreduce_(self.h.optimizerG.flat_grad)
+        self.h._reduce_g()
         self._seg_end()
 
     def _capture(self, warmup):
         h = self.h
+        saved = list(h.history)              # the caller's pending eager logs survive warm-up and capture (also on a re-capture)
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
@@ -55,7 +58,7 @@ class GraphedStep:
                 self._eager()
         cur.wait_stream(side)
         torch.cuda.synchronize()
-        h.history.clear()
+        del h.history[:]                     # the warm-up steps' own logs are dry runs
         pool = torch.cuda.graph_pool_handle()
         if h.dp.world > 1 or self.force_segments:
             parts = (self._seg_disc, self._seg_mid, self._seg_end)
@@ -68,7 +71,8 @@ class GraphedStep:
                 fn()
             self.segments.append(g)
         self.logs = list(h.history)                          # device scalars rewritten by every replay
-        h.history.clear()
+        h.history[:] = saved
+        self._st_d, self._st_g = h._st_d, h._st_g            # the statistics tensors this graph writes (reduced between segments)
 
     def replay(self):
         if self._lrs() != self.lrs:                          # lr is a launch constant: re-capture after a scheduler step
@@ -79,7 +83,8 @@ class GraphedStep:
             segs[0].replay()
             return
         segs[0].replay()
-        self.h.dp.allreduce_(self.h.optimizerD.flat_grad)
+        self.h._st_d, self.h._st_g = self._st_d, self._st_g      # this graph's statistics tensors (another group may have run since)
+        self.h._reduce_d()
         segs[1].replay()
-        self.h.dp.allreduce_(self.h.optimizerG.flat_grad)
+        self.h._reduce_g()
         segs[2].replay()

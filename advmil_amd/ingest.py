@@ -19,6 +19,7 @@ class SlabStager:
         self.host = [None, None]
         self.dev = [None, None]
         self.free_evt = [None, None]      # recorded on the compute stream when the step reading pair k is enqueued
+        self.h2d_evt = [None, None]       # recorded on the copy stream when pair k's H2D copies are all enqueued
         self.k = 1
         self.rows = 0
         self.views = []
@@ -30,6 +31,10 @@ class SlabStager:
         new_cap = max(rows, int(cap * 1.5), 1024)
         host = torch.empty(new_cap, self.channels, dtype=self.dtype).pin_memory()
         dev = torch.empty(new_cap, self.channels, dtype=self.dtype, device=self.device)
+        # the block comes from the COMPUTE stream's allocator pool: kernels already enqueued there may still be using it, and the
+        # copy stream is about to write it -> order the copy stream behind them, and tell the allocator about the second user
+        self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
+        dev.record_stream(self.copy_stream)
         if self.rows and self.dev[k] is not None:               # growing in the middle of a batch: keep what is staged
             self.copy_stream.synchronize()
             host[:self.rows].copy_(self.host[k][:self.rows])
@@ -41,6 +46,8 @@ class SlabStager:
     def begin(self):
         """Start staging a new step batch into the other buffer pair."""
         self.k ^= 1
+        if self.h2d_evt[self.k] is not None:                     # the pinned slab / kept loader tensors of this pair may still be DMA sources
+            self.h2d_evt[self.k].synchronize()
         self.rows = 0
         self.views = []
         self._spans = []
@@ -73,6 +80,7 @@ class SlabStager:
         """Make the compute stream wait for the staged copies; returns the per-bag device views of this batch."""
         evt = torch.cuda.Event()
         evt.record(self.copy_stream)
+        self.h2d_evt[self.k] = evt
         torch.cuda.current_stream(self.device).wait_event(evt)
         return list(self.views)
 

@@ -153,7 +153,9 @@ class MyHandler(object):
     # ------------------------------------------------------------------------------------------
     def _train_each_epoch(self, train_loader, name_loader, mode="wlabel"):
         """Same contract as the reference (model_handler.py:301-347). Bags arriving as CPU tensors are staged through the
-        double-buffered pinned slab (advmil_amd/ingest.py): async H2D on a copy stream, the step batch contiguous in HBM."""
+        double-buffered pinned slab (advmil_amd/ingest.py): async H2D on a copy stream, the step batch contiguous in HBM.
+        Under bag-parallel every rank walks its own shard of the loader (bag i of the global step batch on rank i mod W) and the
+        returned collector is all-gathered back into global bag order (model_handler.py:333-339 semantics)."""
         bp_every_batch = self.cfg["bp_every_batch"]
         num_update_gen = self.cfg["gen_updates"]
         ys_all, yhat_all, ffake_all = [], [], []
@@ -187,9 +189,10 @@ class MyHandler(object):
                 if self.noise_hook is not None:
                     nz_d = [self.noise_hook("d", int(ix.reshape(-1)[0])) for ix in i_col]
                     nz_g = [self.noise_hook("g", int(ix.reshape(-1)[0])) for ix in i_col]
-                preds, fakes = self._update_disc(i_batch, x_col, y_col, mode, mask, ys_host=ys_host, noise=nz_d)
+                plan = self._plan(x_col, y_col, mode, mask, ys_host)      # ONE plan per step batch, shared by the D and G updates
+                preds, fakes = self._update_disc(i_batch, x_col, y_col, mode, mask, ys_host=ys_host, noise=nz_d, plan=plan)
                 for _ in range(num_update_gen):
-                    self._update_gen(i_batch, x_col, y_col, mode, mask, ys_host=ys_host, noise=nz_g)
+                    self._update_gen(i_batch, x_col, y_col, mode, mask, ys_host=ys_host, noise=nz_g, plan=plan)
                 if staged:
                     stager.release()
                     staged = False
@@ -198,36 +201,73 @@ class MyHandler(object):
                 i_col, x_col, y_col, yh_col = [], [], [], []
         cltor = {"y": None, "y_hat": None, "f_fake": None}
         if ys_all:                                      # one D2H per epoch instead of one per step
-            cltor = agg_tensor(cltor, {"y": torch.cat(ys_all).cpu(), "y_hat": torch.cat(yhat_all).cpu(),
-                                       "f_fake": torch.cat(ffake_all).cpu()})
+            gather = self.dp.allgather_cat                # identity at world == 1; global bag order (j * W + r) otherwise
+            cltor = agg_tensor(cltor, {"y": gather(torch.cat(ys_all)).cpu(), "y_hat": gather(torch.cat(yhat_all)).cpu(),
+                                       "f_fake": gather(torch.cat(ffake_all)).cpu()})
         return cltor
 
     # ------------------------------------------------------------------------------------------
-    def _update_disc(self, i_batch, xs, ys, mode="wlabel", label_visible_mask=None, ys_host=None, noise=None):
+    def _update_disc(self, i_batch, xs, ys, mode="wlabel", label_visible_mask=None, ys_host=None, noise=None, plan=None):
         """netD.train(), netG.eval(); real pairs only for event bags with a visible label, fake pairs for all.
-        `noise`: optional per-bag injected generator noise (tests). Returns (pred_collector, fake_collector)."""
-        plan = self._plan(xs, ys, mode, label_visible_mask, ys_host)
+        `noise`: optional per-bag injected generator noise (tests). `plan`: the step plan (`_plan`) when the caller already built
+        it for this step batch. Returns (pred_collector, fake_collector)."""
+        if plan is None:
+            plan = self._plan(xs, ys, mode, label_visible_mask, ys_host)
         preds, fakes = self._disc_backward(i_batch, xs, ys, plan, noise)
         self._disc_apply()
         return preds, fakes
 
     def _plan(self, xs, ys, mode, label_visible_mask, ys_host):
-        """Host-side facts of a step batch (built OUTSIDE HIP-graph capture: it does small H2D copies): which bags feed
-        a real pair / the supervised loss, the GLOBAL denominators of the reference's means (one tiny all-reduce under
-        bag-parallel), and the row segments of the step slab."""
+        """Host-side facts of a step batch (built OUTSIDE HIP-graph capture): which bags feed a real pair / the supervised loss,
+        the GLOBAL denominators of the reference's means, the row segments of the step slab and -- under bag-parallel -- the maps
+        from this rank's rows to the rows of the single-process slab that index every dropout / noise draw. All device arrays are
+        assembled on the host and sent with asynchronous copies from pinned memory: no stream synchronisation at world == 1, one
+        tiny all-gather (counts + bag lengths) at world > 1."""
+        import numpy as np
         n = len(xs)
+        dev = self.device
         vis = self._vis(mode, n, label_visible_mask)
         if ys_host is None:
             ys_host = [y.cpu() for y in ys]             # fallback: one sync (the epoch loop passes host labels)
         is_real = [bool(float(yh[0, 1]) == 1.0) and vis[i] for i, yh in enumerate(ys_host)]
-        n_real, n_fake, n_vis = self.dp.global_counts([sum(is_real), n, sum(vis)], self.device)
-        vis_mask = None if all(vis) else torch.tensor([float(v) for v in vis], device=self.device)
-        real_mask = torch.tensor([1.0 if r else 0.0 for r in is_real], device=self.device)
-        seg = ops.Segments([self._rows(x[0]) for x in xs], self.device)
+        lens = [self._rows(x[0]) for x in xs]
+        W, r = self.dp.world, self.dp.rank
+        counts = [sum(is_real), n, sum(vis)]
+        rng_rows = rowoff16 = None
+        if W > 1:
+            allv = self.dp.allgather_ints(counts + lens, dev)
+            n_real, n_fake, n_vis = (sum(v[k] for v in allv) for k in range(3))
+            rng_rows, rowoff16 = self._rng_row_maps([v[3:] for v in allv], lens, n, W, r)
+        else:
+            n_real, n_fake, n_vis = counts
+        masks = torch.empty(2 * n, dtype=torch.float32, pin_memory=True)
+        mv = masks.numpy()
+        mv[:n] = [1.0 if q else 0.0 for q in is_real]
+        mv[n:] = [1.0 if v else 0.0 for v in vis]
+        masks_d = masks.to(dev, non_blocking=True)
+        seg = ops.Segments(lens, dev)
         seg16 = seg.div(16)                              # D's region embedding needs N % 16 == 0 (backbone_utils.py:65)
         seg16.twice()                                    # (built here: the D update stacks its fake and real passes)
-        return SimpleNamespace(vis=vis, is_real=is_real, n_real=n_real, n_fake=n_fake, n_vis=n_vis, vis_mask=vis_mask,
-                               real_mask=real_mask, seg=seg, seg16=seg16)
+        seg16.rng_rowoff = rowoff16
+        self._plan_count = getattr(self, "_plan_count", 0) + 1
+        return SimpleNamespace(vis=vis, is_real=is_real, n_real=n_real, n_fake=n_fake, n_vis=n_vis,
+                               vis_mask=None if all(vis) else masks_d[n:], real_mask=masks_d[:n], seg=seg, seg16=seg16,
+                               rng_rows=rng_rows, token=self._plan_count, _keep=(masks, masks_d))
+
+    def _rng_row_maps(self, all_lens, lens, n, W, r):
+        """Bag-parallel: upload parallel.rng_row_maps (local row -> row in the single-process slab, for every row count a slab-level
+        tensor of the step can have) as ONE pinned buffer / one asynchronous copy -> (ops.DeviceRng.rows, Segments.rng_rowoff)."""
+        from ..parallel import rng_row_maps
+        maps, off16 = rng_row_maps(all_lens, W, r, cluster=self.bcb == "cluster")
+        keys = list(maps)
+        host = torch.empty(sum(keys) + n, dtype=torch.int64, pin_memory=True)
+        hv, o, spans = host.numpy(), 0, {}
+        for k in keys:
+            hv[o:o + k] = maps[k]; spans[k] = (o, o + k); o += k
+        hv[o:o + n] = off16
+        devbuf = host.to(self.device, non_blocking=True)
+        self._rng_keep = (host, devbuf)
+        return {k: devbuf[a_:b_] for k, (a_, b_) in spans.items()}, devbuf[o:o + n]
 
     @staticmethod
     def _rows(x):
@@ -270,11 +310,11 @@ class MyHandler(object):
         heads and tails run once on [B,d] stacks."""
         self.netD.train()
         self.netG.eval()
-        dev = self.device
+        self.rng.rows = plan.rng_rows
         self.optimizerD.zero_grad()
         X = self._slab(xs)
         y = torch.cat(ys, dim=0)
-        ops.MEMO.begin("record", ("G", id(self.netG), getattr(self.optimizerG, "n_updates", 0)), X)
+        ops.MEMO.begin("record", ("G", id(self.netG), getattr(self.optimizerG, "n_updates", 0), plan.token), X)
         try:
             with torch.no_grad():                                              # the reference builds, then detaches (400)
                 pred = self.netG.finish(self._gen_features(X, plan, xs), noise=self._stack_noise(noise))     # [B,1]
@@ -282,7 +322,7 @@ class MyHandler(object):
             ops.MEMO.end()
         emb = self.netD.embed_rows(X)                                          # shared by the real and the fake pairs
         f_real = None
-        if any(plan.is_real):
+        if plan.n_real > 0:                  # GLOBAL count: every rank of a bag-parallel step takes the same branch / draws
             # The fake pairs (all bags) and the real pairs go through the region-level network and the tail as ONE stacked batch:
             # rows [0, L) are the fake pass, rows [L, 2L) the real pass (its own dropout draw, as a separate forward has, because
             # the draw is indexed by row). Every kernel of the tail -- ~120 launches per pass -- runs once instead of twice; real
@@ -298,20 +338,31 @@ class MyHandler(object):
         # d loss / d score; the real pairs are selected by a 0/1 mask (same sum as f_real[event & visible], no index backward)
         loss, st = ops.gan_d_loss(f_fake, f_real, None if f_real is None else plan.real_mask, self.which_loss, plan.n_fake, plan.n_real)
         loss.backward()
-        self.log({"train_batch/netD/Loss_D": st[0], "train_batch/netD/D_real": st[1] / max(plan.n_real, 1),
-                  "train_batch/netD/D_fake": st[2] / plan.n_fake, "i_batch": i_batch})
+        self._st_d = (st, plan, i_batch)     # this rank's partial sums over the global denominators; reduced + logged in _disc_apply
         preds = list(pred.split(1, dim=0))
         fakes = list(f_fake.detach().split(1, dim=0))
         return preds, fakes
 
-    def _disc_apply(self):
+    def _reduce_d(self):
+        """Bag-parallel exchange of the D update: the flat gradient arena and the step's three loss statistics."""
         self.dp.allreduce_(self.optimizerD.flat_grad)
+        self.dp.allreduce_(self._st_d[0])
+
+    def _log_d(self):
+        st, plan, i_batch = self._st_d
+        self.log({"train_batch/netD/Loss_D": st[0], "train_batch/netD/D_real": st[1] / max(plan.n_real, 1),
+                  "train_batch/netD/D_fake": st[2] / plan.n_fake, "i_batch": i_batch})
+
+    def _disc_apply(self):
+        self._reduce_d()
+        self._log_d()
         self.optimizerD.step()
 
     # ------------------------------------------------------------------------------------------
-    def _update_gen(self, i_batch, xs, ys, mode="wlabel", label_visible_mask=None, ys_host=None, noise=None):
+    def _update_gen(self, i_batch, xs, ys, mode="wlabel", label_visible_mask=None, ys_host=None, noise=None, plan=None):
         """netD.eval(), netG.train(); gen_total = t_reg + coef * (-mean f_fake) + l1 * sum|W_G|."""
-        plan = self._plan(xs, ys, mode, label_visible_mask, ys_host)
+        if plan is None:
+            plan = self._plan(xs, ys, mode, label_visible_mask, ys_host)
         self._gen_backward(i_batch, xs, ys, plan, noise)
         self._gen_apply()
 
@@ -319,11 +370,12 @@ class MyHandler(object):
         """Capturable: zero G grads, forward of the step slab, ONE backward of the G loss."""
         self.netD.eval()
         self.netG.train()
-        dev = self.device
+        self.rng.rows = plan.rng_rows
         self.optimizerG.zero_grad()
         X = self._slab(xs)
-        # row-sized pre-dropout layer outputs of the eval forward in _disc_backward are reused (same rows, same G weights)
-        ops.MEMO.begin("replay", ("G", id(self.netG), getattr(self.optimizerG, "n_updates", 0)), X)
+        # row-sized pre-dropout layer outputs of the eval forward in _disc_backward are reused -- only when this call belongs to
+        # the SAME step plan (token) and the generator has not been updated since (n_updates); an unpaired call recomputes
+        ops.MEMO.begin("replay", ("G", id(self.netG), getattr(self.optimizerG, "n_updates", 0), plan.token), X)
         try:
             feats = self._gen_features(X, plan, xs)
         finally:
@@ -346,18 +398,29 @@ class MyHandler(object):
         # yields the gradients w.r.t. pred and f_fake
         y = torch.cat(ys, dim=0)
         n_vis = plan.n_vis if (plan.n_vis > 0 and any(plan.vis)) else 0
+        if self.dp.world > 1:
+            n_vis = plan.n_vis
         rc = self._recon
         total, st = ops.gan_g_loss(pred, f_fake, y[:, 0:1], y[:, 1:2], plan.vis_mask, rc["alpha"], rc["gamma"], rc["norm"],
                                    self.coef_ganloss, plan.n_fake, n_vis)
         total.backward()
+        self._st_g = (st, i_batch)
+
+    def _reduce_g(self):
+        self.dp.allreduce_(self.optimizerG.flat_grad)
+        self.dp.allreduce_(self._st_g[0])
+
+    def _log_g(self):
+        st, i_batch = self._st_g
         total = st[0]
-        if self.coef_l1 > 1e-8:
+        if self.coef_l1 > 1e-8:              # added once, after the reduce: the L1 term is not a per-bag sum
             total = total + self.coef_l1 * ops.abs_sum(self.optimizerG.flat_param)[0]
         self.log({"train_batch/netG/Loss_G_fake": st[2], "train_batch/netG/Loss_G_time": st[1],
                   "train_batch/netG/Loss_G_total": total, "train_batch/netG/D_fake_avg": -st[2], "i_batch": i_batch})
 
     def _gen_apply(self):
-        self.dp.allreduce_(self.optimizerG.flat_grad)
+        self._reduce_g()
+        self._log_g()
         self.optimizerG.step()                                                 # L1 sub-gradient folded in
 
     # ------------------------------------------------------------------------------------------
@@ -422,6 +485,7 @@ class MyHandler(object):
         d = torch.load(self._prefixed(pd, run_name), map_location=self.device)
         self.netG.load_state_dict(g["model"]); self.optimizerG.load_state_dict(g["optimizer"])
         self.netD.load_state_dict(d["model"]); self.optimizerD.load_state_dict(d["optimizer"])
+        ops.MEMO.end(clear=True)             # nothing recorded under the old weights may be replayed
 
     # ---- orchestration around the step is the reference's own (dataset / evaluator / wandb): INTEGRATION.md
     def exec(self):

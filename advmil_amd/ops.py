@@ -54,6 +54,10 @@ class DeviceRng:
         self.counter = 0
         self.record = False
         self.log = []
+        # Bag-parallel: {row count of a slab-level tensor: int64 device tensor of the rows those rows occupy in the SINGLE-PROCESS
+        # step slab}. Every dropout / noise draw of a tensor with that many rows is indexed through it (rng_row arguments of the
+        # C ABI), so the masks do not depend on the world size. None = single process (identity).
+        self.rows = None
         self.reset(seed)
 
     def reset(self, seed):
@@ -76,10 +80,16 @@ class DeviceRng:
         """seed += inc on the device (capturable)."""
         _lib.check(_lib.lib().advmil_seed_advance(_p(self.seed), inc, _stream()), "seed_advance")
 
-    def uniform(self, n, tag="noise"):
+    def row_map(self, n_rows):
+        return None if self.rows is None else self.rows.get(int(n_rows))
+
+    def uniform(self, n, tag="noise", width=None):
+        """n uniforms at flat indices 0..n-1 of a fresh stream; `width`: the tensor is [n / width, width] (rows = bags), which
+        lets the bag-parallel row map address the single-process rows."""
         out = torch.empty(n, dtype=torch.float32, device=self.device)
         sid = self.site(tag, (n,), None)
-        _lib.check(_lib.lib().advmil_uniform_fill(_p(out), n, _p(self.seed), sid, _stream()), "uniform_fill")
+        rr = self.row_map(n // width) if width else None
+        _lib.check(_lib.lib().advmil_uniform_fill(_p(out), n, _p(self.seed), sid, _p(rr), width or 0, _stream()), "uniform_fill")
         return out
 
 
@@ -154,7 +164,7 @@ def split_planes(x, out=None):
 
 def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=None, act_split=None, drop_p=0.0,
          seed=None, stream_id=0, rowv=None, colv=None, rowseg=None, maskref=None, mask_scale=1.0, accumulate=False,
-         alpha=1.0, splits=None, tile=0, a_planes=None, b_planes=None, c_planes=None, gate_wc=None):
+         alpha=1.0, splits=None, tile=0, a_planes=None, b_planes=None, c_planes=None, gate_wc=None, rng_row=None):
     """C[M,N] = epilogue(alpha * op(A) op(B)); see include/advmil_hip.h::advmil_gemm_f32. a_planes / b_planes: optional
     Planes of A / B; c_planes: Planes to receive the split of the final C (pitch ldc)."""
     _chk(A, "A"); _chk(B, "B")
@@ -188,6 +198,7 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
     e.mask_scale = float(mask_scale)
     e.accumulate = 1 if accumulate else 0
     e.alpha = float(alpha)
+    e.rng_row = None if (rng_row is None or e.seed is None) else rng_row.data_ptr()
     if a_planes is not None:
         e.a_hi, e.a_lo = a_planes.hi.data_ptr(), a_planes.lo.data_ptr()
     if b_planes is not None:
@@ -216,19 +227,21 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
     return gate_out if gate_wc is not None else out
 
 
-def gate_score(ab, wc, bc, N, D, p=0.0, seed=None, stream_a=0, stream_b=0):
+def gate_score(ab, wc, bc, N, D, p=0.0, seed=None, stream_a=0, stream_b=0, rng_row=None):
     s = torch.empty(N, dtype=torch.float32, device=ab.device)
     sd = seed if p > 0.0 else None
     _lib.check(_lib.lib().advmil_gate_score_fwd(_p(ab), _p(wc), _p(bc), p, _p(sd), stream_a, stream_b, N, D, _p(s),
-                                                _stream()), "gate_score_fwd")
+                                                _p(rng_row if sd is not None else None), _stream()), "gate_score_fwd")
     return s
 
 
 class Segments:
-    """Row partition of a step slab: bag b owns rows [ptr[b], ptr[b+1]). Holds the device arrays the segmented kernels
-    read (built with small H2D copies, so construct it OUTSIDE HIP-graph capture)."""
+    """Row partition of a step slab: bag b owns rows [ptr[b], ptr[b+1]). Holds the device arrays the segmented kernels read.
+    Both arrays are assembled on the host in ONE pinned buffer and sent with ONE asynchronous copy (no stream sync); construct
+    it OUTSIDE HIP-graph capture."""
 
     def __init__(self, lens, device):
+        import numpy as np
         self.lens = [int(v) for v in lens]
         self.nseg = len(self.lens)
         self.total = sum(self.lens)
@@ -238,11 +251,22 @@ class Segments:
         for v in self.lens:
             offs.append(offs[-1] + v)
         self.offsets = offs
-        self.ptr = torch.tensor(offs, dtype=torch.int64, device=self.device)
-        self.rowseg = torch.repeat_interleave(torch.arange(self.nseg, dtype=torch.int32, device=self.device),
-                                              torch.tensor(self.lens, device=self.device)).contiguous()
-        self.rowseg_long = self.rowseg.to(torch.long)
+        nb = (8 * (self.nseg + 1) + 15) // 16 * 16
+        host = torch.empty(nb + 4 * self.total, dtype=torch.uint8, pin_memory=self.device.type == "cuda")
+        hv = host.numpy()
+        hv[:8 * (self.nseg + 1)].view(np.int64)[:] = offs
+        hv[nb:].view(np.int32)[:] = np.repeat(np.arange(self.nseg, dtype=np.int32), self.lens)
+        buf = host.to(self.device, non_blocking=True)
+        self._host, self._buf = host, buf
+        self.ptr = buf[:8 * (self.nseg + 1)].view(torch.int64)
+        self.rowseg = buf[nb:].view(torch.int32)
         self._div = {}
+
+    @property
+    def rowseg_long(self):
+        if "long" not in self._div:
+            self._div["long"] = self.rowseg.to(torch.long)
+        return self._div["long"]
 
     def div(self, k):
         """Segments of the k-fold pooled rows (regions of 16 patches)."""
@@ -291,7 +315,7 @@ def softmax_pool_bwd(dpooled, dA, A, h, N, D, seg=None):
     return ds
 
 
-def gate_bwd(ab, ds, wc, N, D, p=0.0, seed=None, stream_a=0, stream_b=0, dwc=None, dbc=None, dbias=None):
+def gate_bwd(ab, ds, wc, N, D, p=0.0, seed=None, stream_a=0, stream_b=0, dwc=None, dbc=None, dbias=None, rng_row=None):
     """dwc/dbc/dbias given -> gradients are ADDED into them (views of the gradient arena)."""
     L = _lib.lib()
     dev = ab.device
@@ -305,11 +329,11 @@ def gate_bwd(ab, ds, wc, N, D, p=0.0, seed=None, stream_a=0, stream_b=0, dwc=Non
     ws = _ws(wsb, dev)
     sd = seed if p > 0.0 else None
     _lib.check(L.advmil_gate_bwd(_p(ab), _p(ds), _p(wc), p, _p(sd), stream_a, stream_b, N, D, _p(dG), _p(dwc), _p(dbc),
-                                 _p(dbias), 1 if acc else 0, _p(ws), wsb, _stream()), "gate_bwd")
+                                 _p(dbias), 1 if acc else 0, _p(rng_row if sd is not None else None), _p(ws), wsb, _stream()), "gate_bwd")
     return dG, dwc, dbc, dbias
 
 
-def act_dropout_bwd(dy, y, act, M, N, p=0.0, seed=None, stream_id=0, want_bias=True, db_out=None):
+def act_dropout_bwd(dy, y, act, M, N, p=0.0, seed=None, stream_id=0, want_bias=True, db_out=None, rng_row=None):
     L = _lib.lib()
     dpre = torch.empty(M, N, dtype=torch.float32, device=dy.device)
     acc = db_out is not None
@@ -319,7 +343,7 @@ def act_dropout_bwd(dy, y, act, M, N, p=0.0, seed=None, stream_id=0, want_bias=T
     ws = _ws(wsb, dy.device) if need else None
     sd = seed if p > 0.0 else None
     _lib.check(L.advmil_act_dropout_bwd(_p(dy), _p(y), act, p, _p(sd), stream_id, M, N, _p(dpre), _p(db), 1 if acc else 0,
-                                        _p(ws), wsb, _stream()), "act_dropout_bwd")
+                                        _p(rng_row if sd is not None else None), _p(ws), wsb, _stream()), "act_dropout_bwd")
     return dpre, db
 
 
@@ -405,20 +429,21 @@ class DropoutFn(torch.autograd.Function):
     """nn.Dropout on a small dense tensor as one launch each way (flat index i on stream `sid`)."""
 
     @staticmethod
-    def forward(ctx, x, p, seed, sid):
+    def forward(ctx, x, p, seed, sid, rr=None):
         x = x.contiguous()
         y = torch.empty_like(x)
-        _lib.check(_lib.lib().advmil_dropout_apply(_p(x), _p(y), x.numel(), p, _p(seed), sid, _stream()), "dropout_apply")
-        ctx.cfg = (p, seed, sid)
+        w = x.shape[-1] if rr is not None else 0
+        _lib.check(_lib.lib().advmil_dropout_apply(_p(x), _p(y), x.numel(), p, _p(seed), sid, _p(rr), w, _stream()), "dropout_apply")
+        ctx.cfg = (p, seed, sid, rr, w)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        p, seed, sid = ctx.cfg
+        p, seed, sid, rr, w = ctx.cfg
         dy = dy.contiguous()
         dx = torch.empty_like(dy)
-        _lib.check(_lib.lib().advmil_dropout_apply(_p(dy), _p(dx), dy.numel(), p, _p(seed), sid, _stream()), "dropout_apply")
-        return dx, None, None, None
+        _lib.check(_lib.lib().advmil_dropout_apply(_p(dy), _p(dx), dy.numel(), p, _p(seed), sid, _p(rr), w, _stream()), "dropout_apply")
+        return dx, None, None, None, None
 
 
 def dropout(x, p, rng, tag=""):
@@ -427,34 +452,34 @@ def dropout(x, p, rng, tag=""):
         return x
     _chk(x, "x")
     sid = rng.site(tag, tuple(x.shape), p)
-    return DropoutFn.apply(x, float(p), rng.seed, sid)
+    return DropoutFn.apply(x, float(p), rng.seed, sid, rng.row_map(x.numel() // x.shape[-1]))
 
 
 class LinearActFn(torch.autograd.Function):
     """y = dropout(act(x W^T + b)); x[M,K], W[N,K]. Dropout index = m*N + n on stream `sid`."""
 
     @staticmethod
-    def forward(ctx, x, W, b, act, p, seed, sid, y0=None):
+    def forward(ctx, x, W, b, act, p, seed, sid, y0=None, rr=None):
         _chk(x, "x"); _chk(W, "weight")
         x = x.contiguous()
         W2 = W.detach().reshape(W.shape[0], -1)
         M, K = x.shape
         N = W2.shape[0]
         if y0 is None:
-            y = gemm(x, W2, True, True, M, N, K, bias=b, act0=act, drop_p=p, seed=seed, stream_id=sid)
+            y = gemm(x, W2, True, True, M, N, K, bias=b, act0=act, drop_p=p, seed=seed, stream_id=sid, rng_row=rr)
         elif p > 0.0:       # memoized act(x W^T + b) of the eval forward: only this forward's dropout draw is new
-            y, _ = act_dropout_bwd(y0, y0, ACT_NONE, M, N, p, seed, sid, want_bias=False)
+            y, _ = act_dropout_bwd(y0, y0, ACT_NONE, M, N, p, seed, sid, want_bias=False, rng_row=rr)
         else:
             y = y0
         ctx.save_for_backward(x, W2, y)
-        ctx.cfg = (act, p, seed, sid, M, N, K, W.shape, b is not None)
+        ctx.cfg = (act, p, seed, sid, M, N, K, W.shape, b is not None, rr)
         ctx.gW, ctx.gb = _arena_grad(W), _arena_grad(b)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, W2, y = ctx.saved_tensors
-        act, p, seed, sid, M, N, K, wshape, has_b = ctx.cfg
+        act, p, seed, sid, M, N, K, wshape, has_b, rr = ctx.cfg
         dy = dy.contiguous()
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_b = has_b and ctx.needs_input_grad[2]
@@ -464,7 +489,7 @@ class LinearActFn(torch.autograd.Function):
             if need_b:
                 db = colsum(dy, M, N, out=ctx.gb)
         else:
-            dpre, db = act_dropout_bwd(dy, y, act, M, N, p, seed, sid, want_bias=need_b, db_out=ctx.gb if need_b else None)
+            dpre, db = act_dropout_bwd(dy, y, act, M, N, p, seed, sid, want_bias=need_b, db_out=ctx.gb if need_b else None, rng_row=rr)
         dW = None
         if need_w:                                           # dpre^T x
             if ctx.gW is not None:
@@ -472,7 +497,7 @@ class LinearActFn(torch.autograd.Function):
             else:
                 dW = gemm(dpre, x, False, False, N, K, M).reshape(wshape)
         dx = gemm(dpre, W2, True, False, M, K, N) if need_x else None                   # dpre W
-        return dx, dW, (None if ctx.gb is not None else db), None, None, None, None, None
+        return dx, dW, (None if ctx.gb is not None else db), None, None, None, None, None, None
 
 
 class ForwardMemo:
@@ -510,18 +535,20 @@ def linear_act(x, W, b, act="none", p=0.0, rng=None, tag=""):
     """x[..., K] -> [..., N] through the HIP GEMM (any leading dims are flattened)."""
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])
-    sid, seed = 0, None
+    sid, seed, rr = 0, None, None
     if p > 0.0:
         rng = rng or default_rng(x.device)
         N = W.shape[0]
-        sid, seed = rng.site(tag, (x2.shape[0], N), p), rng.seed
+        sid, seed, rr = rng.site(tag, (x2.shape[0], N), p), rng.seed, rng.row_map(x2.shape[0])
     memo = MEMO if (MEMO.mode is not None and x2.data_ptr() == MEMO.rows_ptr and x2.shape[0] >= MEMO_MIN_ROWS
                     and not x2.requires_grad) else None
-    key = (x2.data_ptr(), tuple(x2.shape), W.data_ptr(), act) if memo is not None else None
+    # W._version: load_state_dict / any in-place torch write to the weight invalidates the entry (the fused Adam kernel writes
+    # through raw pointers, which the memo's token -- the optimizer's update count -- covers)
+    key = (x2.data_ptr(), tuple(x2.shape), W.data_ptr(), W._version, act) if memo is not None else None
     y0 = None
     if memo is not None and memo.mode == "replay":
         y0 = memo.store.pop(key, None)
-    y = LinearActFn.apply(x2, W, b, _ACT[act], float(p), seed, sid, y0)
+    y = LinearActFn.apply(x2, W, b, _ACT[act], float(p), seed, sid, y0, rr)
     if memo is not None and memo.mode == "record" and p <= 0.0 and not torch.is_grad_enabled():
         memo.store[key] = y
     return y.reshape(*lead, y.shape[-1])
@@ -533,7 +560,7 @@ class GatedAttnPoolFn(torch.autograd.Function):
     model/backbone.py:81-85) and GAPool (model/backbone_utils.py:47-56): the pooled tensor is the scored tensor in every use."""
 
     @staticmethod
-    def forward(ctx, h, Wa, ba, Wb, bb, wc, bc, p, seed, sa, sb, seg, nograd=False):
+    def forward(ctx, h, Wa, ba, Wb, bb, wc, bc, p, seed, sa, sb, seg, nograd=False, rr=None):
         _chk(h, "h")
         h = h.contiguous()
         N, D = h.shape
@@ -550,10 +577,10 @@ class GatedAttnPoolFn(torch.autograd.Function):
         Wab, _ = _stack2(Wa, Wb, D, D)                       # [2D, D]: a view when the two live side by side in the arena
         bab, _ = _stack2(ba, bb, D, 0)
         ab = gemm(h, Wab, True, True, N, 2 * D, D, bias=bab, act0=ACT_TANH, act1=ACT_SIGMOID, act_split=D)
-        s = gate_score(ab, wcv, bc, N, D, p, seed, sa, sb)
+        s = gate_score(ab, wcv, bc, N, D, p, seed, sa, sb, rr)
         A, pooled = softmax_pool(s, h, N, D, seg)
         ctx.save_for_backward(h, Wab, ab, A, wcv)
-        ctx.cfg = (p, seed, sa, sb, N, D, wc.shape, seg)
+        ctx.cfg = (p, seed, sa, sb, N, D, wc.shape, seg, rr)
         # fused weight-gradient accumulation needs every parameter's arena slot, with the a|b pairs adjacent
         gs = [_arena_grad(t) for t in (Wa, ba, Wb, bb, wc, bc)]
         ctx.arena = None
@@ -567,7 +594,7 @@ class GatedAttnPoolFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dpooled, dA, _ds_unused):
         h, Wab, ab, A, wcv = ctx.saved_tensors
-        p, seed, sa, sb, N, D, wcshape, seg = ctx.cfg
+        p, seed, sa, sb, N, D, wcshape, seg, rr = ctx.cfg
         nseg = 1 if seg is None else seg.nseg
         dpooled = (torch.zeros(nseg, D, dtype=torch.float32, device=h.device) if dpooled is None
                    else dpooled.contiguous().reshape(nseg, D))
@@ -575,14 +602,14 @@ class GatedAttnPoolFn(torch.autograd.Function):
         ds = softmax_pool_bwd(dpooled, dA_, A, h, N, D, seg)
         if ctx.arena is not None:
             gWab, gbab, gwc, gbc = ctx.arena
-            dG, _, _, _ = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb, dwc=gwc, dbc=gbc, dbias=gbab)
+            dG, _, _, _ = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb, dwc=gwc, dbc=gbc, dbias=gbab, rng_row=rr)
         else:
-            dG, dwc, dbc, dbias = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb)
+            dG, dwc, dbc, dbias = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb, rng_row=rr)
         dh = None
         if ctx.needs_input_grad[0]:
             # dG [N,2D] . Wab [2D,D]  +  A[n] * dpooled[bag(n), d]   (pooling's direct path, rank-1 per bag)
             dh = gemm(dG, Wab, True, False, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg)
-        nones = (None,) * 6
+        nones = (None,) * 7
         if ctx.arena is not None:
             gemm(dG, h, False, False, 2 * D, D, N, out=gWab, ldc=D, accumulate=True)       # dG^T h
             return (dh, None, None, None, None, None, None) + nones
@@ -593,15 +620,15 @@ class GatedAttnPoolFn(torch.autograd.Function):
 def gated_attn_pool(h, Wa, ba, Wb, bb, wc, bc, p=0.0, rng=None, tag="", seg=None):
     """Returns (pooled [nseg, D] -- [D] when seg is None --, A[N], raw scores[N])."""
     sa = sb = 0
-    seed = None
+    seed = rr = None
     if p > 0.0:
         rng = rng or default_rng(h.device)
         sa = rng.site(tag + "att_a", tuple(h.shape), p)
         sb = rng.site(tag + "att_b", tuple(h.shape), p)
-        seed = rng.seed
+        seed, rr = rng.seed, rng.row_map(h.shape[0])
     # grad mode is always off INSIDE Function.forward, so "nothing here will be differentiated" is decided out here
     nograd = not torch.is_grad_enabled() or not any(t.requires_grad for t in (h, Wa, ba, Wb, bb, wc, bc))
-    pooled, A, s = GatedAttnPoolFn.apply(h, Wa, ba, Wb, bb, wc, bc, float(p), seed, sa, sb, seg, nograd)
+    pooled, A, s = GatedAttnPoolFn.apply(h, Wa, ba, Wb, bb, wc, bc, float(p), seed, sa, sb, seg, nograd, rr)
     return (pooled[0] if seg is None else pooled), A, s
 
 
@@ -732,7 +759,7 @@ class AddDropoutLayerNormFn(torch.autograd.Function):
     nn.TransformerEncoderLayer with norm_first=False) as one launch each way; dropout index = row*d + col on stream `sid`."""
 
     @staticmethod
-    def forward(ctx, x, o, gamma, beta, eps, p, seed, sid):
+    def forward(ctx, x, o, gamma, beta, eps, p, seed, sid, rr=None):
         _chk(x, "x"); _chk(o, "o")
         x, o = x.contiguous(), o.contiguous()
         R, d = x.shape
@@ -743,9 +770,10 @@ class AddDropoutLayerNormFn(torch.autograd.Function):
         rstd = torch.empty(R, dtype=torch.float32, device=dev)
         g_, b_ = gamma.detach(), beta.detach()
         _lib.check(_lib.lib().advmil_add_dropout_ln_fwd(_p(x), _p(o), _p(g_), _p(b_), eps, R, d, p, _p(seed if p > 0.0 else None), sid,
-                                                        _p(z), _p(y), _p(mean), _p(rstd), _stream()), "add_dropout_ln_fwd")
+                                                        _p(rr if p > 0.0 else None), _p(z), _p(y), _p(mean), _p(rstd), _stream()),
+                   "add_dropout_ln_fwd")
         ctx.save_for_backward(z, g_, mean, rstd)
-        ctx.cfg = (p, seed, sid)
+        ctx.cfg = (p, seed, sid, rr)
         gg, gb = _arena_grad(gamma), _arena_grad(beta)
         ctx.arena = (gg, gb) if (gg is not None and gb is not None) else None
         return y
@@ -753,7 +781,7 @@ class AddDropoutLayerNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         z, gamma, mean, rstd = ctx.saved_tensors
-        p, seed, sid = ctx.cfg
+        p, seed, sid, rr = ctx.cfg
         R, d = z.shape
         L = _lib.lib()
         dy = dy.contiguous()
@@ -765,19 +793,19 @@ class AddDropoutLayerNormFn(torch.autograd.Function):
         wsb = L.advmil_add_dropout_ln_bwd_workspace_bytes(R, d)
         ws = _ws(wsb, z.device)
         _lib.check(L.advmil_add_dropout_ln_bwd(_p(dy), _p(z), _p(gamma), _p(mean), _p(rstd), R, d, p, _p(seed if p > 0.0 else None),
-                                               sid, _p(dx), _p(do), _p(dg), _p(db), 1 if acc else 0, _p(ws), wsb, _stream()),
-                   "add_dropout_ln_bwd")
+                                               sid, _p(rr if p > 0.0 else None), _p(dx), _p(do), _p(dg), _p(db), 1 if acc else 0, _p(ws),
+                                               wsb, _stream()), "add_dropout_ln_bwd")
         if do is None:
             do = dx
-        return (dx, do, None, None, None, None, None, None) if acc else (dx, do, dg, db, None, None, None, None)
+        return (dx, do, None, None, None, None, None, None, None) if acc else (dx, do, dg, db, None, None, None, None, None)
 
 
 def add_dropout_layer_norm(x, o, gamma, beta, eps=1e-5, p=0.0, rng=None, tag=""):
-    sid, seed = 0, None
+    sid, seed, rr = 0, None, None
     if p > 0.0:
         rng = rng or default_rng(x.device)
-        sid, seed = rng.site(tag, tuple(o.shape), p), rng.seed
-    return AddDropoutLayerNormFn.apply(x, o, gamma, beta, float(eps), float(p), seed, sid)
+        sid, seed, rr = rng.site(tag, tuple(o.shape), p), rng.seed, rng.row_map(o.shape[0])
+    return AddDropoutLayerNormFn.apply(x, o, gamma, beta, float(eps), float(p), seed, sid, rr)
 
 
 class SegMeanFn(torch.autograd.Function):

@@ -8,7 +8,10 @@ The reference has no distributed path (0 collectives). World-size
    one tiny all-reduce of the integer counts before the step;
  * gradients are summed, never averaged; the L1 sub-gradient is added after the reduce, identically on all ranks
    (inside the fused Adam kernel);
- * per-bag dropout/noise streams derive from (seed, global bag index), not from the rank.
+ * every dropout / noise draw is indexed by the row its element occupies in the SINGLE-PROCESS step slab (bags in global order
+   i = local_index * W + rank): the handler's step plan all-gathers the bag lengths and hands the kernels per-row maps
+   (ops.DeviceRng.rows, the rng_row arguments of the C ABI), so a W-rank step draws exactly the masks of the 1-rank step;
+ * the epoch collector (y, y_hat, f_fake) is all-gathered back into global bag order; logged losses are all-reduced.
 This module is compute-agnostic (it only sees flat tensors), so the gloo tests drive it on CPU.
 """
 import os
@@ -49,6 +52,15 @@ class BagParallel:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return [int(round(v)) for v in t.tolist()]
 
+    def allgather_ints(self, vals, device="cpu"):
+        """Every rank's list of small integers (equal lengths) -> [W][len] python lists (one tiny all-gather)."""
+        if not (self.enabled and self.world > 1):
+            return [[int(v) for v in vals]]
+        t = torch.tensor([int(v) for v in vals], dtype=torch.int64, device=device)
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(outs, t, group=self.group)
+        return [o.tolist() for o in outs]
+
     def allgather_cat(self, t: torch.Tensor) -> torch.Tensor:
         """Concatenate equally-shaped per-rank tensors in global bag order (for the epoch collector)."""
         if not (self.enabled and self.world > 1):
@@ -61,6 +73,40 @@ class BagParallel:
         if self.enabled and self.world > 1:
             dist.broadcast(flat, src=src, group=self.group)
         return flat
+
+
+def rng_row_maps(all_lens, W, r, cluster=False):
+    """Host side of the world-size-invariant randomness. `all_lens[q][j]` = patch rows of rank q's j-th bag of the step; this
+    rank's bag j is bag j*W + r of the global step batch, whose single-process slab stacks the bags in global order.
+    Returns ({row count: int64 array local row -> single-process row}, per-bag region-row offsets for the attention kernels).
+    Keys: sum N (patch rows), sum N/16 (region rows), 2 * sum N/16 (the D update's stacked fake|real region rows), n (bag rows),
+    2n (the stacked tail rows), 8n (DeepAttMISL's cluster rows)."""
+    import numpy as np
+    lens = list(all_lens[r])
+    n = len(lens)
+    G = n * W
+    glens = [all_lens[gi % W][gi // W] for gi in range(G)]
+    goff = np.concatenate([[0], np.cumsum(glens)]).astype(np.int64)
+    gi = [j * W + r for j in range(n)]
+    patch = np.concatenate([goff[gi[j]] + np.arange(lens[j], dtype=np.int64) for j in range(n)])
+    region = np.concatenate([goff[gi[j]] // 16 + np.arange(lens[j] // 16, dtype=np.int64) for j in range(n)])
+    bags = np.asarray(gi, dtype=np.int64)
+    SLg = int(goff[-1]) // 16
+    maps = {}
+
+    def put(arr):
+        k = int(arr.shape[0])
+        if k in maps and not np.array_equal(maps[k], arr):
+            raise NotImplementedError("bag-parallel RNG row maps are ambiguous for this step batch (two slab-level tensors of "
+                                      f"{k} rows with different layouts): bags this small are not supported at world > 1")
+        maps[k] = arr
+
+    put(patch); put(region); put(np.concatenate([region, SLg + region])); put(bags); put(np.concatenate([bags, G + bags]))
+    if cluster:
+        put(np.concatenate([8 * g_ + np.arange(8, dtype=np.int64) for g_ in gi]))
+    loc16 = np.concatenate([[0], np.cumsum([v // 16 for v in lens])])[:-1]
+    off16 = np.asarray([goff[gi[j]] // 16 - loc16[j] for j in range(n)], dtype=np.int64)
+    return maps, off16
 
 
 def init_from_env(backend=None):

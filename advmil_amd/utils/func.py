@@ -15,10 +15,11 @@ def generate_noise(*dims, to_device="cuda", distribution="uniform", rng=None):
     assert distribution in ["uniform", "gaussian"]
     rng = rng or ops.default_rng(to_device)
     n = int(np.prod(dims))
+    w = int(dims[-1])
     if distribution == "uniform":
-        return rng.uniform(n, "noise").reshape(*dims)
-    u1 = rng.uniform(n, "noise_u1").clamp_min(2.0 ** -24)
-    u2 = rng.uniform(n, "noise_u2")
+        return rng.uniform(n, "noise", width=w).reshape(*dims)
+    u1 = rng.uniform(n, "noise_u1", width=w).clamp_min(2.0 ** -24)
+    u2 = rng.uniform(n, "noise_u2", width=w)
     return (torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(2.0 * np.pi * u2)).reshape(*dims)
 
 

@@ -190,8 +190,9 @@ class Case:
         idx = [(i0 + j) % self.n_pool for j in range(nb)]
         self.cursor = (i0 + nb) % self.n_pool
         bx, by, bh = [self.xs[i] for i in idx], [self.ys[i] for i in idx], [self.ys_host[i] for i in idx]
-        h._update_disc(0, bx, by, "wlabel", None, ys_host=bh)
-        h._update_gen(0, bx, by, "wlabel", None, ys_host=bh)
+        plan = h._plan(bx, by, "wlabel", None, bh)
+        h._update_disc(0, bx, by, "wlabel", None, ys_host=bh, plan=plan)
+        h._update_gen(0, bx, by, "wlabel", None, ys_host=bh, plan=plan)
         h.rng.advance(1)
         if len(h.history) > 64:
             h.history.clear()

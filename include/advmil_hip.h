@@ -81,6 +81,10 @@ typedef struct {
   const float* gate_wc;
   float* gate_out;
   int gate_np;
+  /* Optional [M] device array: row m draws its dropout as row rng_row[m] (element index rng_row[m]*N + n). Under bag-parallel a
+   * rank passes the rows its bags occupy in the single-process step slab, which makes the masks independent of the world size;
+   * NULL = identity. The same optional argument exists on every entry point below that draws dropout / noise. */
+  const int64_t* rng_row;
 } advmil_epilogue_t;
 
 size_t advmil_gemm_f32_workspace_bytes(int64_t M, int64_t N, int splits);
@@ -137,12 +141,13 @@ int advmil_mha_bwd(const float* qkv, const float* out, const float* dout, const 
  * bwd: dx = LayerNorm'(dy); dob (may be NULL) = dx * keep; dgamma / dbeta = column sums (accumulate != 0 adds into them).
  * ws >= advmil_add_dropout_ln_bwd_workspace_bytes. */
 int advmil_add_dropout_ln_fwd(const float* x, const float* o, const float* gamma, const float* beta, float eps, int64_t R,
-                              int64_t d, float drop_p, const uint64_t* seed, uint64_t stream_id, float* z, float* y, float* mean,
-                              float* rstd, advmil_stream_t stream);
+                              int64_t d, float drop_p, const uint64_t* seed, uint64_t stream_id, const int64_t* rng_row, float* z,
+                              float* y, float* mean, float* rstd, advmil_stream_t stream);
 size_t advmil_add_dropout_ln_bwd_workspace_bytes(int64_t R, int64_t d);
 int advmil_add_dropout_ln_bwd(const float* dy, const float* z, const float* gamma, const float* mean, const float* rstd, int64_t R,
-                              int64_t d, float drop_p, const uint64_t* seed, uint64_t stream_id, float* dx, float* dob,
-                              float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, advmil_stream_t stream);
+                              int64_t d, float drop_p, const uint64_t* seed, uint64_t stream_id, const int64_t* rng_row, float* dx,
+                              float* dob, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes,
+                              advmil_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Gated-attention MIL pooling (Attn_Net_Gated + softmax + mm: model/backbone_utils.py:11-29,
@@ -161,7 +166,8 @@ int advmil_add_dropout_ln_bwd(const float* dy, const float* z, const float* gamm
  *   destination instead of overwriting it -- the destinations are then views of the flat gradient arena, which
  *   removes the per-parameter accumulate launches autograd would issue for every bag. */
 int advmil_gate_score_fwd(const float* ab, const float* wc, const float* bc, float drop_p, const uint64_t* seed,
-                          uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D, float* s, advmil_stream_t stream);
+                          uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D, float* s, const int64_t* rng_row,
+                          advmil_stream_t stream);
 /* Segmented form: the N rows are a ragged slab of `nseg` bags, bag b = rows [seg_ptr[b], seg_ptr[b+1]) (device int64
  * array; NULL = one segment), max_len = longest segment. pooled / dpooled are [nseg, D]; A, s, ds are [N]. */
 size_t advmil_softmax_pool_workspace_bytes(int64_t max_len, int64_t D, int nseg);
@@ -174,7 +180,7 @@ int advmil_softmax_pool_bwd(const float* dpooled, const float* dA, const float* 
 size_t advmil_gate_bwd_workspace_bytes(int64_t N, int64_t D);
 int advmil_gate_bwd(const float* ab, const float* ds, const float* wc, float drop_p, const uint64_t* seed,
                     uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D, float* dG, float* dwc, float* dbc,
-                    float* dbias, int accumulate, void* ws, size_t ws_bytes, advmil_stream_t stream);
+                    float* dbias, int accumulate, const int64_t* rng_row, void* ws, size_t ws_bytes, advmil_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Backward of y = dropout(act(pre)) for the Linear layers: dpre = dy * keep * act'(y) and
@@ -183,7 +189,7 @@ int advmil_gate_bwd(const float* ab, const float* ds, const float* wc, float dro
 size_t advmil_colsum_workspace_bytes(int64_t M, int64_t N);
 int advmil_act_dropout_bwd(const float* dy, const float* y, int act, float drop_p, const uint64_t* seed,
                            uint64_t stream_id, int64_t M, int64_t N, float* dpre, float* dbias, int accumulate,
-                           void* ws, size_t ws_bytes, advmil_stream_t stream);
+                           const int64_t* rng_row, void* ws, size_t ws_bytes, advmil_stream_t stream);
 /* out[n] (+)= sum_m x[m,n] */
 int advmil_colsum(const float* x, int64_t M, int64_t N, float* out, int accumulate, void* ws, size_t ws_bytes,
                   advmil_stream_t stream);
@@ -235,12 +241,15 @@ int advmil_abs_sum(const float* p, int64_t n, float* out, void* ws, size_t ws_by
 size_t advmil_abs_sum_workspace_bytes(int64_t n);
 
 /* fill out[i] = U[0,1) from the counter RNG (generator noise, utils/func.py:154-164) */
-int advmil_uniform_fill(float* out, int64_t n, const uint64_t* seed, uint64_t stream_id, advmil_stream_t stream);
+int advmil_uniform_fill(float* out, int64_t n, const uint64_t* seed, uint64_t stream_id, const int64_t* rng_row, int64_t width,
+                        advmil_stream_t stream);
 /* seed[0] += inc  (advance the step seed between graph replays) */
 /* y = x * keep/(1-p) with keep drawn at flat index i of (seed, stream_id): nn.Dropout on the [B, d]-sized head tensors
- * (model/model_utils.py:106-176 make_mlp_layer; applied to dy it is the backward). In place (y == x) allowed. */
+ * (model/model_utils.py:106-176 make_mlp_layer; applied to dy it is the backward). In place (y == x) allowed.
+ * rng_row / width (here and in advmil_uniform_fill): optional row map, the flat tensor is [n / width, width] and row r draws as
+ * row rng_row[r] (see advmil_epilogue_t.rng_row); NULL = identity. */
 int advmil_dropout_apply(const float* x, float* y, int64_t n, float p, const uint64_t* seed, uint64_t stream_id,
-                         advmil_stream_t stream);
+                         const int64_t* rng_row, int64_t width, advmil_stream_t stream);
 int advmil_seed_advance(uint64_t* seed, uint64_t inc, advmil_stream_t stream);
 /* The step's two scalar losses over <= bp_every_batch values, value and analytic gradient in one launch each.
  * D loss (loss/utils.py:182-203 real_fake_loss with the reference's means taken over the GLOBAL counts, model_handler.py:412):

@@ -1,0 +1,58 @@
+"""One rank of the bag-parallel product-handler test (tests/test_parallel_gpu.py): MyHandler on cuda:0 with dropout ON, this rank's
+shard of the global step batches (bag i on rank i mod W), two optimizer steps through _train_each_epoch; rank 0 saves what the
+single-process run is compared with. usage: python -m tests.dp_worker RANK WORLD PORT OUT KIND"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+LENS = (256, 128, 64, 192, 320, 96, 160, 224)       # 2 steps x 4 bags (global), ragged, multiples of 16
+
+
+def build_loader(kind, idxs):
+    from advmil_amd import synth
+    from tests import helpers as H
+    loader = []
+    for i in idxs:
+        x = H.bag(300 + i, 512)[:, :LENS[i]].contiguous()
+        ext = H.T(synth.cluster_ids(0, 300 + i, LENS[i])) if kind == "cluster" else torch.zeros(1, 1)
+        loader.append((torch.tensor([[i]], dtype=torch.int), [x, ext], H.label(300 + i)))
+    return loader
+
+
+def run(kind, world, rank, dp=None):
+    from advmil_amd import synth
+    from advmil_amd.config import default_cfg
+    from advmil_amd.model import MyHandler
+    from tests import helpers as H
+    h = MyHandler(default_cfg(bcb_mode=kind, bp_every_batch=4 // world), device="cuda:0", parallel=dp)
+    for net, prefix in ((h.netG, f"G-{kind}:"), (h.netD, "D-prj:")):
+        sd = {k: H.T(synth.param(H.PARAM_SEED, prefix + k, tuple(v.shape))) for k, v in net.state_dict().items()}
+        net.load_state_dict(sd, strict=True)
+    h.rng.reset(4321)
+    idxs = [i for i in range(len(LENS)) if i % world == rank]
+    cl = h._train_each_epoch(build_loader(kind, idxs), "train", "wlabel")
+    logs = h.pop_logs()
+    return {"cl": cl, "logs": logs, "G": {k: v.detach().cpu() for k, v in h.netG.state_dict().items()},
+            "D": {k: v.detach().cpu() for k, v in h.netD.state_dict().items()}}
+
+
+def main():
+    rank, world, port, out, kind = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from advmil_amd import parallel
+    parallel.init_from_env(backend="gloo")           # two ranks on ONE GPU: RCCL refuses that, the exchange layer is backend agnostic
+    res = run(kind, world, rank, parallel.BagParallel())
+    if rank == 0:
+        torch.save(res, out)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

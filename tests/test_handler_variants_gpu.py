@@ -232,13 +232,21 @@ def test_forward_memo_is_consumed_and_cleared():
         h = MyHandler(default_cfg(bcb_mode="abmil", bp_every_batch=2), device=DEV)
         xs = [[H.bag(90 + i, 256).to(DEV), None] for i in range(2)]
         ys = [H.label(i).to(DEV) for i in range(2)]
-        h._update_disc(1, xs, ys)
+        plan = h._plan(xs, ys, "wlabel", None, None)
+        h._update_disc(1, xs, ys, plan=plan)
         assert len(ops.MEMO.store) == 1 and ops.MEMO.mode is None          # the FC output of the eval forward
-        h._update_gen(1, xs, ys)
+        h._update_gen(1, xs, ys, plan=plan)                                 # same step plan: replayed and consumed
         assert len(ops.MEMO.store) == 0
-        h._update_disc(2, xs, ys)
+        plan = h._plan(xs, ys, "wlabel", None, None)
+        h._update_disc(2, xs, ys, plan=plan)
         h.optimizerG.step()                                                 # weights moved: the stale entry must not be used
-        h._update_gen(2, xs, ys)
+        h._update_gen(2, xs, ys, plan=plan)
+        assert len(ops.MEMO.store) == 0
+        # unpaired calls (each builds its own plan -> its own token): the eval forward's entry is never replayed into another
+        # step's train forward, even though slab address, shape and weights coincide
+        h._update_disc(3, xs, ys)
+        assert len(ops.MEMO.store) == 1
+        h._update_gen(3, xs, ys)
         assert len(ops.MEMO.store) == 0
     finally:
         ops.MEMO_MIN_ROWS = old

@@ -48,6 +48,8 @@ def _worker(rank, world, port, q):
     flatg = torch.cat([gG[k].reshape(-1) for k in keysg])
     dp.allreduce_(flatg)
     yh = dp.allgather_cat(torch.cat(preds))            # epoch collector in global bag order
+    lens_all = dp.allgather_ints([100 + rank, 7 * (rank + 1)])
+    assert lens_all == [[100, 7], [101, 14]]
     if rank == 0:
         q.put({"flat_d": flat.numpy().copy(), "flat_g": flatg.numpy().copy(), "loss_d": float(loss), "y_hat": yh.numpy().copy()})
     dist.barrier()
@@ -86,3 +88,37 @@ def test_two_rank_step_equals_single_rank():
     assert float((got["flat_d"] - flat).abs().max()) < 1e-6 * (1 + float(flat.abs().max()))
     assert float((got["flat_g"] - flatg).abs().max()) < 1e-6 * (1 + float(flatg.abs().max()))
     assert float((got["y_hat"].reshape(-1) - torch.cat(preds).reshape(-1)).abs().max()) < 1e-6
+
+
+def test_rng_row_maps_cover_the_single_process_slab():
+    """parallel.rng_row_maps: the ranks' local rows map onto a partition of the single-process slab's rows, bag j of rank r being
+    global bag j*W + r; the stacked (fake | real) layouts map half by half; the attention kernels' per-bag offsets agree."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from advmil_amd.parallel import rng_row_maps
+    W = 2
+    all_lens = [[256, 64, 128], [32, 512, 96]]          # rank 0's and rank 1's bags of one step (global order interleaves them)
+    glob = [all_lens[g % W][g // W] for g in range(6)]   # 256, 32, 64, 512, 128, 96
+    goff = np.concatenate([[0], np.cumsum(glob)])
+    seen_patch, seen_region, seen_bag = [], [], []
+    for r in range(W):
+        maps, off16 = rng_row_maps(all_lens, W, r, cluster=True)
+        lens = all_lens[r]
+        n, SN, SL = len(lens), sum(lens), sum(lens) // 16
+        assert set(maps) == {SN, SL, 2 * SL, n, 2 * n, 8 * n}
+        o = 0
+        for j, L in enumerate(lens):                      # local bag j = global bag j*W + r, rows in order
+            g = j * W + r
+            assert np.array_equal(maps[SN][o:o + L], goff[g] + np.arange(L))
+            assert off16[j] == goff[g] // 16 - o // 16
+            o += L
+        assert np.array_equal(maps[2 * SL][:SL], maps[SL]) and np.array_equal(maps[2 * SL][SL:], maps[SL] + goff[-1] // 16)
+        assert np.array_equal(maps[n], [j * W + r for j in range(n)])
+        assert np.array_equal(maps[2 * n][n:], maps[n] + 6)
+        assert np.array_equal(maps[8 * n].reshape(n, 8), 8 * maps[n][:, None] + np.arange(8)[None, :])
+        seen_patch.append(maps[SN]); seen_region.append(maps[SL]); seen_bag.append(maps[n])
+    assert np.array_equal(np.sort(np.concatenate(seen_patch)), np.arange(goff[-1]))
+    assert np.array_equal(np.sort(np.concatenate(seen_region)), np.arange(goff[-1] // 16))
+    assert np.array_equal(np.sort(np.concatenate(seen_bag)), np.arange(6))
+    with pytest.raises(NotImplementedError):              # 2 regions per bag: [2n] stacked-tail rows and region rows collide
+        rng_row_maps([[32, 32], [32, 32]], 2, 0)
