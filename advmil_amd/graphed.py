@@ -6,8 +6,9 @@ with torch.cuda.graph (hipGraph underneath) and replayed. The ctypes launches go
 the hand-written kernels are captured exactly like torch's own. Dropout/noise stay fresh across replays because
 the kernels read the step seed from device memory and the graph itself bumps it.
 
-Under bag-parallel (world > 1) the collectives stay OUTSIDE the graphs (three segments with the two RCCL
-all-reduces between them), so capture never depends on RCCL's graph support.
+Under bag-parallel (world > 1) the collectives stay OUTSIDE the graphs (four segments: D backward | G backbone forward | D Adam + G
+loss/backward | G Adam), so capture never depends on RCCL's graph support; D's all-reduce is started asynchronously before the
+G-forward segment and waited for after it, so the exchange runs under that segment's kernels.
 """
 import torch
 
@@ -30,10 +31,13 @@ class GraphedStep:
     def _seg_disc(self):
         self.preds, self.fakes = self.h._disc_backward(0, self.xs, self.ys, self.plan)
 
+    def _seg_gfwd(self):
+        self.h._gen_forward(self.xs, self.plan)              # independent of D: overlaps D's gradient exchange
+
     def _seg_mid(self):
         self.h._log_d()                      # after the exchange: the logged statistics are the reduced ones
         self.h.optimizerD.step()
-        self.h._gen_backward(0, self.xs, self.ys, self.plan)
+        self.h._gen_finish(0, self.xs, self.ys, self.plan)
 
     def _seg_end(self):
         self.h._log_g()
@@ -42,7 +46,10 @@ class GraphedStep:
 
     def _eager(self):
         self._seg_disc()
-        self.h._reduce_d()
+        pend = self.h.dp.allreduce_async(self.h.optimizerD.flat_grad, self.h._st_d[0])
+        self._seg_gfwd()
+        for w in pend:
+            w.wait()
         self._seg_mid()
         self.h._reduce_g()
         self._seg_end()
@@ -61,9 +68,9 @@ class GraphedStep:
         del h.history[:]                     # the warm-up steps' own logs are dry runs
         pool = torch.cuda.graph_pool_handle()
         if h.dp.world > 1 or self.force_segments:
-            parts = (self._seg_disc, self._seg_mid, self._seg_end)
+            parts = (self._seg_disc, self._seg_gfwd, self._seg_mid, self._seg_end)
         else:
-            parts = (lambda: (self._seg_disc(), self._seg_mid(), self._seg_end()),)
+            parts = (lambda: (self._seg_disc(), self._seg_gfwd(), self._seg_mid(), self._seg_end()),)
         for fn in parts:
             g = torch.cuda.CUDAGraph()
             # thread_local: RCCL's watchdog thread may query events while this thread captures
@@ -84,7 +91,10 @@ class GraphedStep:
             return
         segs[0].replay()
         self.h._st_d, self.h._st_g = self._st_d, self._st_g      # this graph's statistics tensors (another group may have run since)
-        self.h._reduce_d()
-        segs[1].replay()
-        self.h._reduce_g()
+        pend = self.h.dp.allreduce_async(self.h.optimizerD.flat_grad, self._st_d[0])     # D's exchange ...
+        segs[1].replay()                                                                 # ... under the generator's backbone forward
+        for w in pend:
+            w.wait()
         segs[2].replay()
+        self.h._reduce_g()
+        segs[3].replay()

@@ -190,7 +190,10 @@ class MyHandler(object):
                     nz_d = [self.noise_hook("d", int(ix.reshape(-1)[0])) for ix in i_col]
                     nz_g = [self.noise_hook("g", int(ix.reshape(-1)[0])) for ix in i_col]
                 plan = self._plan(x_col, y_col, mode, mask, ys_host)      # ONE plan per step batch, shared by the D and G updates
-                preds, fakes = self._update_disc(i_batch, x_col, y_col, mode, mask, ys_host=ys_host, noise=nz_d, plan=plan)
+                # bag-parallel: D's gradient exchange is started asynchronously and completed inside the first generator update, after
+                # the generator's backbone forward (which does not depend on D) has been enqueued -> the two overlap
+                overlap = self.dp.world > 1 and num_update_gen > 0
+                preds, fakes = self._update_disc(i_batch, x_col, y_col, mode, mask, ys_host=ys_host, noise=nz_d, plan=plan, defer_apply=overlap)
                 for _ in range(num_update_gen):
                     self._update_gen(i_batch, x_col, y_col, mode, mask, ys_host=ys_host, noise=nz_g, plan=plan)
                 if staged:
@@ -207,14 +210,19 @@ class MyHandler(object):
         return cltor
 
     # ------------------------------------------------------------------------------------------
-    def _update_disc(self, i_batch, xs, ys, mode="wlabel", label_visible_mask=None, ys_host=None, noise=None, plan=None):
+    def _update_disc(self, i_batch, xs, ys, mode="wlabel", label_visible_mask=None, ys_host=None, noise=None, plan=None,
+                     defer_apply=False):
         """netD.train(), netG.eval(); real pairs only for event bags with a visible label, fake pairs for all.
         `noise`: optional per-bag injected generator noise (tests). `plan`: the step plan (`_plan`) when the caller already built
-        it for this step batch. Returns (pred_collector, fake_collector)."""
+        it for this step batch. `defer_apply`: only start D's gradient exchange; the next `_update_gen` completes the D update
+        (reduce wait, log, Adam) behind its backbone forward. Returns (pred_collector, fake_collector)."""
         if plan is None:
             plan = self._plan(xs, ys, mode, label_visible_mask, ys_host)
         preds, fakes = self._disc_backward(i_batch, xs, ys, plan, noise)
-        self._disc_apply()
+        if defer_apply:
+            self._pending_d = self.dp.allreduce_async(self.optimizerD.flat_grad, self._st_d[0])
+        else:
+            self._disc_apply()
         return preds, fakes
 
     def _plan(self, xs, ys, mode, label_visible_mask, ys_host):
@@ -358,16 +366,33 @@ class MyHandler(object):
         self._log_d()
         self.optimizerD.step()
 
+    def _disc_finish_deferred(self):
+        """Complete a D update whose exchange `_update_disc(defer_apply=True)` started."""
+        pend = self.__dict__.pop("_pending_d", None)
+        if pend is None:
+            return
+        for w in pend:
+            w.wait()
+        self._log_d()
+        self.optimizerD.step()
+
     # ------------------------------------------------------------------------------------------
     def _update_gen(self, i_batch, xs, ys, mode="wlabel", label_visible_mask=None, ys_host=None, noise=None, plan=None):
         """netD.eval(), netG.train(); gen_total = t_reg + coef * (-mean f_fake) + l1 * sum|W_G|."""
         if plan is None:
             plan = self._plan(xs, ys, mode, label_visible_mask, ys_host)
-        self._gen_backward(i_batch, xs, ys, plan, noise)
+        self._gen_forward(xs, plan, noise)
+        self._disc_finish_deferred()         # D's exchange ran under the generator's backbone forward; D must be stepped before it scores
+        self._gen_finish(i_batch, xs, ys, plan)
         self._gen_apply()
 
     def _gen_backward(self, i_batch, xs, ys, plan, noise=None):
         """Capturable: zero G grads, forward of the step slab, ONE backward of the G loss."""
+        self._gen_forward(xs, plan, noise)
+        self._gen_finish(i_batch, xs, ys, plan)
+
+    def _gen_forward(self, xs, plan, noise=None):
+        """The part of the generator update that does not depend on D: zero G grads, backbone + head forward (graph kept)."""
         self.netD.eval()
         self.netG.train()
         self.rng.rows = plan.rng_rows
@@ -380,7 +405,11 @@ class MyHandler(object):
             feats = self._gen_features(X, plan, xs)
         finally:
             ops.MEMO.end(clear=True)
-        pred = self.netG.finish(feats, noise=self._stack_noise(noise))         # [B,1], graph kept
+        self._g_fwd = (X, self.netG.finish(feats, noise=self._stack_noise(noise)))      # pred [B,1], graph kept
+
+    def _gen_finish(self, i_batch, xs, ys, plan):
+        """D's score of the predictions (updated D, frozen), the G loss and its ONE backward."""
+        X, pred = self.__dict__.pop("_g_fwd")
         with torch.no_grad():                                                  # nothing of D(x) depends on G
             eb, im = self.netD.bag_features_multi(self.netD.embed_rows(X), plan.seg16)
         # The generator loss only needs d f / d pred. The reference lets autograd also fill netD's weight gradients here and

@@ -44,6 +44,13 @@ class BagParallel:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         return flat
 
+    def allreduce_async(self, *tensors):
+        """Start SUM all-reduces and return their work handles: with RCCL they run on the communicator's own stream, `wait()`
+        then only makes the current compute stream wait (no host block), so kernels enqueued in between overlap the exchange."""
+        if not (self.enabled and self.world > 1):
+            return []
+        return [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for t in tensors]
+
     def global_counts(self, counts, device="cpu"):
         """Sum small integer counters ([n_real, n_fake, n_visible]) across ranks -> python ints."""
         if not (self.enabled and self.world > 1):

@@ -179,7 +179,7 @@ class Case:
                     self.graphs.append(GraphedStep(self.h, [self.xs[i] for i in idx], [self.ys[i] for i in idx],
                                                    [self.ys_host[i] for i in idx], warmup=1))
                 self.launch_note = (f"hipGraph replay ({len(self.graphs)} captured bag groups"
-                                    + (", 3 segments around the 2 all-reduces)" if world > 1 else ")"))
+                                    + (", 4 segments: the 2 all-reduces stay outside capture, D's overlaps the G-forward segment)" if world > 1 else ")"))
             except Exception as exc:          # never lose the run to a capture problem: the eager schedule is the same step
                 self.graphs = []
                 torch.cuda.synchronize()
