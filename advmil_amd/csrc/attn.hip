@@ -224,14 +224,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float alpha = __builtin_amdgcn_exp2f(m_run - mx);
+    const float alpha = hw_exp2(m_run - mx);
     m_run = mx;
     float psum = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float p = __builtin_amdgcn_exp2f(s[t][r] - mx);
+        float p = hw_exp2(s[t][r] - mx);
         psum += p;
         if (DROP && !attn_keep(rk, (uint32_t)(kb + 32 * t + ACC_ROW(r, half)), a.drop_thr)) p = 0.f;
         s[t][r] = p;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (qok) {
-    const float inv = (DROP ? a.inv_keep : 1.f) / l_tot;
+    const float inv = (DROP ? a.inv_keep : 1.f) * hw_rcp(l_tot);
     float* const orow = a.out + (row0 + q) * D + h * HD;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
           *reinterpret_cast<float4*>(orow + d) =
               make_float4(o[dt][4 * rg] * inv, o[dt][4 * rg + 1] * inv, o[dt][4 * rg + 2] * inv, o[dt][4 * rg + 3] * inv);
       }
-    if (half == 0) a.lse[(row0 + q) * H + h] = m_run + __builtin_amdgcn_logf(l_tot);   // v_log_f32 = log2
+    if (half == 0) a.lse[(row0 + q) * H + h] = m_run + hw_log2(l_tot);
   }
 }
 
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t key = kb + 32 * t + ACC_ROW(r, half);
-        float p = __builtin_amdgcn_exp2f(s[t][r] - lse_q);
+        float p = hw_exp2(s[t][r] - lse_q);
         if (tail && key >= Lg) p = 0.f;
         float g_ = dp[t][r] * ik;
         if (DROP && !attn_keep(rk, (uint32_t)key, a.drop_thr)) g_ = 0.f;
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int r = 4 * rg + u;
-          const float p = __builtin_amdgcn_exp2f(s[r] - lv[u]);
+          const float p = hw_exp2(s[r] - lv[u]);
           const bool keep = !DROP || attn_keep(kv[u], (uint32_t)key, a.drop_thr);
           pd[r] = keep ? p * ik : 0.f;
           s[r] = p * ((keep ? dp[r] * ik : 0.f) - dvv[u]);    // dS[q, key]

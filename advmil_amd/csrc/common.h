@@ -35,6 +35,41 @@ __device__ __forceinline__ float rng_keep(uint64_t key, uint64_t idx, float p, f
   return rng_uniform(key, idx) >= p ? inv_keep : 0.0f;
 }
 
+// ---- hardware transcendentals with the result made safe to consume (every kernel of this library takes exp / log / rcp / rsq /
+// sqrt through these wrappers; each is ~1 ulp, i.e. ~1e-7 relative, far inside the path's tolerances).
+// v_exp_f32 / v_rcp_f32 run on the quarter-rate transcendental pipe (four 16-lane passes). In the fused gate-score epilogue of the
+// bf16x3 contraction kernels the instruction that consumed such a result directly behind it read STALE values in lanes 48-63 (the
+// last pass) in ~0.1 % of the wavefronts -- timing dependent, only with two waves per SIMD, invisible to small tests
+// (tools/gate_stress.py reproduces it at 131072 rows). hipcc (ROCm 7.2) does not pad this trans -> VALU use on gfx950, so the
+// padding is explicit: the op and two wait states travel together in one asm statement.
+__device__ __forceinline__ float hw_exp2(float x) {
+  float r;
+  asm volatile("v_exp_f32 %0, %1\n\ts_nop 1" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ __forceinline__ float hw_rcp(float x) {
+  float r;
+  asm volatile("v_rcp_f32 %0, %1\n\ts_nop 1" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ __forceinline__ float hw_exp(float x) { return hw_exp2(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float hw_log2(float x) {
+  float r;
+  asm volatile("v_log_f32 %0, %1\n\ts_nop 1" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ __forceinline__ float hw_log(float x) { return hw_log2(x) * 0.693147180559945309f; }
+__device__ __forceinline__ float hw_rsq(float x) {
+  float r;
+  asm volatile("v_rsq_f32 %0, %1\n\ts_nop 1" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ __forceinline__ float hw_sqrt(float x) {
+  float r;
+  asm volatile("v_sqrt_f32 %0, %1\n\ts_nop 1" : "=v"(r) : "v"(x));
+  return r;
+}
+
 // ---- activations ----
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3 };
 
@@ -44,10 +79,10 @@ __device__ __forceinline__ float act_apply(int act, float v) {
     // hardware exp2/rcp forms (v_exp_f32, v_rcp_f32: ~1 ulp each): abs error <= ~2e-7 against libm, a handful of instructions
     // instead of ~40 (tanhf) + a full-precision divide -- the gate contraction's epilogue evaluates 100 M of these per launch
     case ACT_TANH: {
-      const float t = __expf(-2.0f * fabsf(v));
-      return copysignf((1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t), v);
+      const float t = hw_exp(-2.0f * fabsf(v));
+      return copysignf((1.0f - t) * hw_rcp(1.0f + t), v);
     }
-    case ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+    case ACT_SIGMOID: return hw_rcp(1.0f + hw_exp(-v));
     default: return v;
   }
 }

@@ -14,6 +14,7 @@
 // bf16x3 mode, two bf16 planes (hi, lo) per operand tile, double-buffered (one barrier per chunk):
 //   k-contiguous source: unpadded [row][32] planes with XOR-swizzled 16-byte units, ds_read_b128 fragments;
 //   m-contiguous source: [k][rows+32] planes in source orientation, fragments through the LDS transpose read ds_read_b64_tr_b16.
+#include <cstdlib>
 #include "common.h"
 #include "bf16split.h"
 #include "../../include/advmil_hip.h"
@@ -257,6 +258,123 @@ struct OperandStage {
   }
 };
 
+// ---- epilogue (shared by the contraction kernels). MFMA C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5). Each 32x32
+// accumulator tile goes through a per-wave LDS patch ([32][36] floats, carved from the operand buffers) so that the math below runs
+// once per float4 in a compact loop and the global stores are 16 B per lane along the row.
+template <int TM, int TN, int WR, int WC>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[TM][TN], float* smem, int wave, int lane, int wr, int wc,
+                                              int64_t m0, int64_t n0, int z, int nt_i) {
+  const int i = lane & 31, hi = lane >> 5;
+  const advmil_epilogue_t& e = g.epi;
+  const bool direct = (g.splits == 1);
+  uint64_t key = 0;
+  float inv_keep = 1.0f;
+  if (direct && e.seed && e.drop_p > 0.0f) {
+    key = rng_key(*e.seed, e.stream_id);
+    inv_keep = 1.0f / (1.0f - e.drop_p);
+  }
+  float* const out = direct ? g.C : g.ws + (int64_t)z * g.M * g.N;
+  const int64_t ldo = direct ? g.ldc : g.N;
+  const bool vec_ok = ((ldo & 3) == 0) && (((uintptr_t)out & 15) == 0);
+  float* const patch = smem + wave * (32 * PITCH_KC);
+  __syncthreads();   // every wave is done reading the operand tiles
+  // Gate-score mode (e.gate_wc): the columns are the interleaved branches of the gated attention scorer, col 2j = a_j (tanh),
+  // col 2j+1 = b_j (sigmoid). Instead of storing C, each row's  sum_j tanh(.)_j * sigmoid(.)_j * wc_j  over this workgroup's
+  // columns is reduced in registers / across the 8 lanes of a row and written to gate_out[row * gate_np + column-block]: the
+  // no-grad generator pass then never writes (and gate_score never re-reads) the [rows, 2D] activations.
+  const bool gate_mode = direct && e.gate_wc != nullptr;
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * PITCH_KC + i] = acc[a][b][r];
+      WAVE_LDS_SYNC();   // the patch is private to this wave: order its LDS writes before the reads below, no block barrier
+      const int64_t rbase = m0 + wr * 32 * TM + a * 32;
+      if (gate_mode) {
+        const int64_t col = n0 + wc * 32 * TN + b * 32 + (lane & 7) * 4;      // N % 4 == 0 in this mode: whole float4 or nothing
+        float w0 = 0.f, w1 = 0.f;
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col < g.N) {
+          w0 = e.gate_wc[col >> 1]; w1 = e.gate_wc[(col >> 1) + 1];
+          if (e.bias) b4 = *reinterpret_cast<const float4*>(e.bias + col);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int pr = q * 8 + (lane >> 3);
+          const float4 v4 = *reinterpret_cast<const float4*>(patch + pr * PITCH_KC + (lane & 7) * 4);
+          const float t0 = act_apply(ACT_TANH, v4.x * e.alpha + b4.x), s0 = act_apply(ACT_SIGMOID, v4.y * e.alpha + b4.y);
+          const float t1 = act_apply(ACT_TANH, v4.z * e.alpha + b4.z), s1 = act_apply(ACT_SIGMOID, v4.w * e.alpha + b4.w);
+          gsum[q] += t0 * s0 * w0 + t1 * s1 * w1;
+        }
+        WAVE_LDS_SYNC();
+        continue;
+      }
+      // a lane stores columns col..col+3 of rows rbase + (lane >> 3) + 8q: everything that depends on the column only (bias,
+      // which activation) is fetched once per sub-tile, not once per element inside the row loop
+      const int64_t col = n0 + wc * 32 * TN + b * 32 + (lane & 7) * 4;
+      const int nvalid = col >= g.N ? 0 : ((g.N - col >= 4) ? 4 : (int)(g.N - col));
+      float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+      int act4[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (direct && e.bias && t < nvalid) bias4[t] = e.bias[col + t];
+        act4[t] = (col + t) < e.act_split ? e.act0 : e.act1;
+      }
+      const bool same_act = act4[0] == act4[3];
+#pragma unroll 1
+      for (int q = 0; q < 4; ++q) {
+        const int pr = q * 8 + (lane >> 3);
+        const int64_t row = rbase + pr;
+        const float4 v4 = *reinterpret_cast<const float4*>(patch + pr * PITCH_KC + (lane & 7) * 4);
+        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        if (row < g.M && nvalid > 0) {
+          float* c = out + row * ldo + col;
+          if (direct) {
+            float r1 = 0.f;
+            const float* cv = nullptr;
+            const int64_t grow = (e.seed && e.rng_row) ? e.rng_row[row] : row;      // the row's index in the dropout stream
+            if (e.rowv) {
+              r1 = e.rowv[row];
+              cv = e.colv + (e.rowseg ? (int64_t)e.rowseg[row] * g.N : 0) + col;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              if (t < nvalid) {
+                float x = v[t] * e.alpha + bias4[t];
+                if (cv) x += r1 * cv[t];
+                x = act_apply(same_act ? act4[0] : act4[t], x);
+                if (e.seed && e.drop_p > 0.0f) x *= rng_keep(key, (uint64_t)(grow * g.N + col + t), e.drop_p, inv_keep);
+                if (e.maskref) x *= (e.maskref[row * (int64_t)e.ldmask + col + t] > 0.0f ? e.mask_scale : 0.0f);
+                if (e.accumulate) x += c[t];
+                v[t] = x;
+              }
+          }
+          if (nvalid == 4 && vec_ok) {
+            *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)      // static indices: a runtime-bounded loop would push v[] into scratch memory
+              if (t < nvalid) c[t] = v[t];
+          }
+          if (direct && e.c_hi) emit_planes4(e, row * ldo + col, v, nvalid);
+        }
+      }
+      WAVE_LDS_SYNC();   // reads of this patch done before the next sub-tile overwrites it
+    }
+    if (gate_mode) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float t = gsum[q];
+        t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64);     // the 8 lanes that share a row
+        const int64_t row = m0 + wr * 32 * TM + a * 32 + q * 8 + (lane >> 3);
+        if ((lane & 7) == 0 && row < g.M) e.gate_out[row * e.gate_np + nt_i * WC + wc] = t;
+      }
+    }
+  }
+}
+
 // WR x WC waves per workgroup (2x2 = the 256-thread tiles; 4x2 = the 512-thread 256x192 / 256x128 tiles of the bf16x3 variant, whose
 // time is set by how many operand bytes a CU pulls through its L1 per flop: ~11 B/clk/CU whatever the inner loop looks like).
 template <bool A_KC, bool B_KC, int TM, int TN, bool SPLIT, int PRE, int BKT, int WR, int WC>
@@ -411,117 +529,109 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 || TM * TN > 4 ? 1 : 2))
     }
   }
 
-  // ---- epilogue. MFMA C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5). Each 32x32 accumulator
-  // tile goes through a per-wave LDS patch ([32][36] floats, carved from the operand buffers) so that the math
-  // below runs once per float4 in a compact loop and the global stores are 16 B per lane along the row.
-  const advmil_epilogue_t& e = g.epi;
-  const bool direct = (g.splits == 1);
-  uint64_t key = 0;
-  float inv_keep = 1.0f;
-  if (direct && e.seed && e.drop_p > 0.0f) {
-    key = rng_key(*e.seed, e.stream_id);
-    inv_keep = 1.0f / (1.0f - e.drop_p);
-  }
-  float* const out = direct ? g.C : g.ws + (int64_t)z * g.M * g.N;
-  const int64_t ldo = direct ? g.ldc : g.N;
-  const bool vec_ok = ((ldo & 3) == 0) && (((uintptr_t)out & 15) == 0);
-  float* const patch = smem + wave * (32 * PITCH_KC);
-  __syncthreads();   // every wave is done reading the operand tiles
-  // Gate-score mode (e.gate_wc): the columns are the interleaved branches of the gated attention scorer, col 2j = a_j (tanh),
-  // col 2j+1 = b_j (sigmoid). Instead of storing C, each row's  sum_j tanh(.)_j * sigmoid(.)_j * wc_j  over this workgroup's
-  // columns is reduced in registers / across the 8 lanes of a row and written to gate_out[row * gate_np + column-block]: the
-  // no-grad generator pass then never writes (and gate_score never re-reads) the [rows, 2D] activations.
-  const bool gate_mode = direct && e.gate_wc != nullptr;
-#pragma unroll
-  for (int a = 0; a < TM; ++a) {
-    float gsum[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * PITCH_KC + i] = acc[a][b][r];
-      WAVE_LDS_SYNC();   // the patch is private to this wave: order its LDS writes before the reads below, no block barrier
-      const int64_t rbase = m0 + wr * 32 * TM + a * 32;
-      if (gate_mode) {
-        const int64_t col = n0 + wc * 32 * TN + b * 32 + (lane & 7) * 4;      // N % 4 == 0 in this mode: whole float4 or nothing
-        float w0 = 0.f, w1 = 0.f;
-        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (col < g.N) {
-          w0 = e.gate_wc[col >> 1]; w1 = e.gate_wc[(col >> 1) + 1];
-          if (e.bias) b4 = *reinterpret_cast<const float4*>(e.bias + col);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int pr = q * 8 + (lane >> 3);
-          const float4 v4 = *reinterpret_cast<const float4*>(patch + pr * PITCH_KC + (lane & 7) * 4);
-          const float t0 = act_apply(ACT_TANH, v4.x * e.alpha + b4.x), s0 = act_apply(ACT_SIGMOID, v4.y * e.alpha + b4.y);
-          const float t1 = act_apply(ACT_TANH, v4.z * e.alpha + b4.z), s1 = act_apply(ACT_SIGMOID, v4.w * e.alpha + b4.w);
-          gsum[q] += t0 * s0 * w0 + t1 * s1 * w1;
-        }
-        WAVE_LDS_SYNC();
-        continue;
-      }
-      // a lane stores columns col..col+3 of rows rbase + (lane >> 3) + 8q: everything that depends on the column only (bias,
-      // which activation) is fetched once per sub-tile, not once per element inside the row loop
-      const int64_t col = n0 + wc * 32 * TN + b * 32 + (lane & 7) * 4;
-      const int nvalid = col >= g.N ? 0 : ((g.N - col >= 4) ? 4 : (int)(g.N - col));
-      float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-      int act4[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        if (direct && e.bias && t < nvalid) bias4[t] = e.bias[col + t];
-        act4[t] = (col + t) < e.act_split ? e.act0 : e.act1;
-      }
-      const bool same_act = act4[0] == act4[3];
-#pragma unroll 1
-      for (int q = 0; q < 4; ++q) {
-        const int pr = q * 8 + (lane >> 3);
-        const int64_t row = rbase + pr;
-        const float4 v4 = *reinterpret_cast<const float4*>(patch + pr * PITCH_KC + (lane & 7) * 4);
-        float v[4] = {v4.x, v4.y, v4.z, v4.w};
-        if (row < g.M && nvalid > 0) {
-          float* c = out + row * ldo + col;
-          if (direct) {
-            float r1 = 0.f;
-            const float* cv = nullptr;
-            const int64_t grow = (e.seed && e.rng_row) ? e.rng_row[row] : row;      // the row's index in the dropout stream
-            if (e.rowv) {
-              r1 = e.rowv[row];
-              cv = e.colv + (e.rowseg ? (int64_t)e.rowseg[row] * g.N : 0) + col;
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-              if (t < nvalid) {
-                float x = v[t] * e.alpha + bias4[t];
-                if (cv) x += r1 * cv[t];
-                x = act_apply(same_act ? act4[0] : act4[t], x);
-                if (e.seed && e.drop_p > 0.0f) x *= rng_keep(key, (uint64_t)(grow * g.N + col + t), e.drop_p, inv_keep);
-                if (e.maskref) x *= (e.maskref[row * (int64_t)e.ldmask + col + t] > 0.0f ? e.mask_scale : 0.0f);
-                if (e.accumulate) x += c[t];
-                v[t] = x;
-              }
-          }
-          if (nvalid == 4 && vec_ok) {
-            *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)      // static indices: a runtime-bounded loop would push v[] into scratch memory
-              if (t < nvalid) c[t] = v[t];
-          }
-          if (direct && e.c_hi) emit_planes4(e, row * ldo + col, v, nvalid);
-        }
-      }
-      WAVE_LDS_SYNC();   // reads of this patch done before the next sub-tile overwrites it
-    }
-    if (gate_mode) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float t = gsum[q];
-        t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64);     // the 8 lanes that share a row
-        const int64_t row = m0 + wr * 32 * TM + a * 32 + q * 8 + (lane >> 3);
-        if ((lane & 7) == 0 && row < g.M) e.gate_out[row * e.gate_np + nt_i * WC + wc] = t;
-      }
+  gemm_epilogue<TM, TN, WR, WC>(g, acc, smem, wave, lane, wr, wc, m0, n0, z, nt_i);
+}
+
+// =====================================================================================
+// NT contraction over operands that ALREADY live in HBM as bf16 planes (hi, lo): C = epi(A B^T), A[M,K], B[N,K], both k-contiguous.
+// This is the form of every forward layer applied to a step slab (embedding FCs, gate branches: A = the slab's rows or its hidden
+// rows, B = a weight matrix). With both operands pre-split there is nothing to convert, so the tile goes global -> LDS by the
+// gfx950 LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane, no VGPR round trip, no VALU), the inner loop is ds_read_b128 + MFMA
+// only, and the next chunk's DMA flies under the current chunk's 36-48 MFMAs per wave.
+//   workgroup = 8 waves (4 x 2), tile 256 x (64*TN'), TN' = 2*TN in 32-column MFMA tiles per wave pair -> 256x128 / 256x192 / 256x256;
+//   k walked in chunks of 32 (same accumulation order as gemm_f32_kernel's bf16x3 loop -> bit-identical results);
+//   LDS: 2 buffers x [A hi | A lo | B hi | B lo] planes of [row][32] bf16, 16-byte units XOR-swizzled by (row >> 2) & 3 (ps_unit):
+//     the DMA writes lane-linear (piece base + 16 * lane), so the swizzle is applied to each lane's SOURCE address: the lane that
+//     fills stored position q of row r fetches unit q ^ ((r >> 2) & 3) of that row (same involution as the fragment reads);
+//   one piece = 16 rows x 64 B = one wave-instruction; a chunk is 2 * (256 + BN) / 16 pieces = 6-8 per wave.
+// Requirements (checked by the host): M % 256 == 0, N % BN == 0, K % 32 == 0, planes 16-byte aligned with ld % 8 == 0, splits == 1.
+// =====================================================================================
+#define GLB_AS __attribute__((address_space(1)))
+template <int TN>
+__global__ __launch_bounds__(512, 2) void gemm_nt_planes_kernel(GemmArgs g) {
+  constexpr int TM = 2, WR = 4, WC = 2, BKT = 32;
+  constexpr int BM_ = 256, BN_ = 64 * TN;
+  constexpr int ROWS_ALL = 2 * (BM_ + BN_);            // plane rows per buffer: A hi, A lo, B hi, B lo
+  constexpr int NPIECE = ROWS_ALL / 16, PPW = NPIECE / 8;   // 16-row pieces per buffer, per wave
+  constexpr int BUF_HW = ROWS_ALL * BKT;               // halfwords per buffer
+  constexpr int PATCH_FLOATS = WR * WC * 32 * PITCH_KC;
+  constexpr int SMEM_FLOATS = (2 * BUF_HW / 2 > PATCH_FLOATS) ? 2 * BUF_HW / 2 : PATCH_FLOATS;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+  bf16raw* const lds = reinterpret_cast<bf16raw*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, hi = lane >> 5;
+  const int wr = wave / WC, wc = wave % WC;
+  const int bid = blockIdx.x;
+  int mt_i, nt_i;
+  {   // XCD-aware tile order (see gemm_f32_kernel): the n-tiles of one A row panel run on one XCD, back to back
+    const int inner = g.ntiles, outer = g.mtiles;
+    const int per_group = 8 * inner, full = (outer / 8) * per_group;
+    if (bid < full) {
+      const int r = bid % per_group;
+      mt_i = (bid / per_group) * 8 + (r & 7);
+      nt_i = r >> 3;
+    } else {
+      const int rem = outer - (outer / 8) * 8, r = bid - full;
+      mt_i = (outer / 8) * 8 + r % rem;
+      nt_i = r / rem;
     }
   }
+  const int64_t m0 = (int64_t)mt_i * BM_, n0 = (int64_t)nt_i * BN_;
+  // per-lane DMA sources: piece p = wave + 8*it covers plane rows [16p, 16p + 16) of the buffer image
+  const bf16raw* src[PPW];
+#pragma unroll
+  for (int it = 0; it < PPW; ++it) {
+    const int prow = (wave + 8 * it) * 16 + (lane >> 2);   // row in the buffer image
+    const bf16raw* base;
+    int r;                                                 // tile-local row of its operand
+    int64_t ld, row0;
+    if (prow < BM_) { base = reinterpret_cast<const bf16raw*>(g.epi.a_hi); r = prow; ld = g.lda; row0 = m0; }
+    else if (prow < 2 * BM_) { base = reinterpret_cast<const bf16raw*>(g.epi.a_lo); r = prow - BM_; ld = g.lda; row0 = m0; }
+    else if (prow < 2 * BM_ + BN_) { base = reinterpret_cast<const bf16raw*>(g.epi.b_hi); r = prow - 2 * BM_; ld = g.ldb; row0 = n0; }
+    else { base = reinterpret_cast<const bf16raw*>(g.epi.b_lo); r = prow - 2 * BM_ - BN_; ld = g.ldb; row0 = n0; }
+    src[it] = base + (row0 + r) * ld + (((lane & 3) ^ ((r >> 2) & 3)) * 8);
+  }
+  auto dma = [&](int buf, int64_t k0) {
+#pragma unroll
+    for (int it = 0; it < PPW; ++it)
+      __builtin_amdgcn_global_load_lds((const GLB_AS void*)(src[it] + k0), (LDS_AS void*)(lds + buf * BUF_HW + (wave + 8 * it) * 16 * BKT), 16, 0, 0);
+  };
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  const int64_t K = g.K;
+  dma(0, 0);
+  int cur = 0;
+  for (int64_t k0 = 0; k0 < K; k0 += BKT) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of chunk k0 have landed
+    __syncthreads();                                    // everyone's have; and everyone is done reading buffer cur^1
+    if (k0 + BKT < K) dma(cur ^ 1, k0 + BKT);
+    const bf16raw* cA = lds + cur * BUF_HW;
+    const bf16raw* cB = cA + 2 * BM_ * BKT;
+#pragma unroll
+    for (int ks = 0; ks < BKT / 16; ++ks) {
+      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) read_frag_presplit<BM_, BKT>(cA, wr * 32 * TM + a * 32, ks, i, hi, ah[a], al[a]);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) read_frag_presplit<BN_, BKT>(cB, wc * 32 * TN + b * 32, ks, i, hi, bh[b], bl[b]);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    cur ^= 1;
+  }
+  gemm_epilogue<TM, TN, WR, WC>(g, acc, smem, wave, lane, wr, wc, m0, n0, 0, nt_i);
 }
 
 // split-K reduction + epilogue; one thread per 4 consecutive columns
@@ -571,6 +681,7 @@ extern "C" size_t advmil_gemm_f32_workspace_bytes(int64_t M, int64_t N, int spli
 
 // 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = split-bf16 ("bf16x3") on the bf16 matrix pipe
 static int g_gemm_mode = 0;
+static int g_nt_planes = []() { const char* e = getenv("ADVMIL_NT_PLANES"); return (e && e[0] == '0') ? 0 : 1; }();
 extern "C" int advmil_set_gemm_mode(int mode) {
   if (mode != 0 && mode != 1) return ADVMIL_EINVAL;
   g_gemm_mode = mode;
@@ -652,6 +763,18 @@ extern "C" int advmil_gemm_f32_plan_layout(int a_kc, int b_kc, int64_t M, int64_
   return plan_exact(M, N, K, tile, splits);
 }
 
+// Tile of the plane-fed NT kernel for this shape (82 / 83 / 84), or 0 when the shape does not qualify (then the generic kernel runs).
+extern "C" int advmil_gemm_f32_plan_planes(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, int* tile) {
+  if (!tile) return ADVMIL_EINVAL;
+  *tile = 0;
+  if (g_gemm_mode != 1 || !g_nt_planes || !a_kc || !b_kc || M < 4096 || (M % 256) || (K % 32) || (N % 128)) return ADVMIL_OK;
+  const char* force = getenv("ADVMIL_NT_PLANES_TN");
+  int tnp = (N % 256 == 0 && N % 192 != 0) ? 4 : ((N % 192 == 0) ? 3 : 2);
+  if (force && (force[0] == '2' || force[0] == '3' || force[0] == '4') && N % (64 * (force[0] - '0')) == 0) tnp = force[0] - '0';
+  *tile = 80 + tnp;
+  return ADVMIL_OK;
+}
+
 extern "C" int advmil_gemm_f32_plan(int64_t M, int64_t N, int64_t K, int* tile, int* splits) {
   return advmil_gemm_f32_plan_layout(1, 1, M, N, K, tile, splits);
 }
@@ -684,6 +807,7 @@ static int plan_exact(int64_t M, int64_t N, int64_t K, int* tile, int* splits) {
 // waves along N of a tile code: 2 for the 256-thread tiles and 43/42, 4 for the 2 x 4 wave grids 34/24
 static int tile_wc(int tile) { return (tile == 34 || tile == 24) ? 4 : 2; }
 extern "C" int advmil_gemm_f32_gate_blocks(int tile, int64_t N) {
+  if (tile >= 82 && tile <= 84) return (int)(N / (64 * (tile - 80))) * 2;      // plane-fed NT kernel: 2 waves along N
   if (g_gemm_mode != 1) {
     if (tile / 10 == 4) tile = 20 + tile % 10;
     else if (tile % 10 == 4) tile = (tile / 10 == 3) ? 23 : 22;
@@ -736,6 +860,22 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
   if (epi->gate_wc) {       // fused gate score: no split-K, no dropout, whole float4 column groups, one partial per 32*TN*... block
     if (splits != 1 || !epi->gate_out || (N & 3) || epi->drop_p > 0.0f) return ADVMIL_EINVAL;
     if (epi->gate_np != advmil_gemm_f32_gate_blocks(tile, N)) return ADVMIL_EINVAL;
+  }
+  // NT form with both operands as planes: the LDS-DMA kernel (tile codes 82 / 83 / 84 = 256 x 128 / 192 / 256, 8 waves). The plan
+  // (advmil_gemm_f32_plan_planes, or tile 0 here) picks it whenever the shape qualifies; ADVMIL_NT_PLANES=0 turns it off.
+  if (tile == 0 && pre == 3 && splits == 1) { int t = 0; advmil_gemm_f32_plan_planes(a_kc, b_kc, M, N, K, &t); if (t) tile = t; }
+  if (tile >= 82 && tile <= 84) {
+    const int tnp = tile - 80;
+    if (g_gemm_mode != 1 || !a_kc || !b_kc || pre != 3 || splits != 1 || (M % 256) || (K % 32) || (N % (64 * tnp))) return ADVMIL_EINVAL;
+    if (epi->gate_wc && (!epi->gate_out || epi->drop_p > 0.0f || epi->gate_np != advmil_gemm_f32_gate_blocks(tile, N))) return ADVMIL_EINVAL;
+    g.mtiles = (int)(M / 256);
+    g.ntiles = (int)(N / (64 * tnp));
+    dim3 pgrid(g.mtiles * g.ntiles);
+    if (tnp == 4) hipLaunchKernelGGL((gemm_nt_planes_kernel<4>), pgrid, dim3(512), 0, stream, g);
+    else if (tnp == 3) hipLaunchKernelGGL((gemm_nt_planes_kernel<3>), pgrid, dim3(512), 0, stream, g);
+    else hipLaunchKernelGGL((gemm_nt_planes_kernel<2>), pgrid, dim3(512), 0, stream, g);
+    ADVMIL_LAUNCH_CHECK();
+    return ADVMIL_OK;
   }
   switch (tile) {
     case 23: launch_tile<2, 3, false>(a_kc, b_kc, grid, stream, g, pre); break;

@@ -28,14 +28,15 @@ __global__ __launch_bounds__(256) void genconv_fwd_kernel(const float* __restric
     for (int e = e0; e < e1; ++e) {
       const float v = x[(int64_t)col[e] * C + c];
       const float m = (v > 0.f ? v : 0.f) + eps;
-      const float w = expf(t * m - mx);
+      const float w = hw_exp(t * m - mx);
       den += w; a1 += w * m; a2 += w * m * m;
     }
     const bool has = e1 > e0;
-    const float agg = has ? a1 / den : 0.f;
+    const float iden = has ? hw_rcp(den) : 0.f;
+    const float agg = a1 * iden;
     out[i * C + c] = agg + x[i * C + c];
-    lse[i * C + c] = has ? mx + logf(den) : 0.f;
-    m2[i * C + c] = has ? a2 / den : 0.f;
+    lse[i * C + c] = has ? mx + hw_log(den) : 0.f;
+    m2[i * C + c] = a2 * iden;
   }
 }
 
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void genconv_bwd_kernel(const float* __restric
     for (int e = e0; e < e1; ++e) {
       const int64_t i = col_s[e];
       const float agg = out[i * C + c] - x[i * C + c];
-      const float w = expf(t * m - lse[i * C + c]);
+      const float w = hw_exp(t * m - lse[i * C + c]);
       g += dout[i * C + c] * w * (1.f + t * (m - agg));
     }
     dx[j * C + c] = dout[j * C + c] + (xj > 0.f ? g : 0.f);

@@ -8,12 +8,13 @@ extern "C" int advmil_version(void) { return 100; }
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ m,
                                                    float* __restrict__ v, const float* __restrict__ wd, int64_t n, float lr,
                                                    float b1, float b2, float eps, float gscale, float l1,
-                                                   const int32_t* __restrict__ step) {
+                                                   const int32_t* __restrict__ step, unsigned short* __restrict__ p_hi,
+                                                   unsigned short* __restrict__ p_lo) {
   const int t = *step + 1;   // the launcher bumps *step after this kernel
-  const float bc1 = 1.f - powf(b1, (float)t);
-  const float bc2 = 1.f - powf(b2, (float)t);
-  const float step_size = lr / bc1;
-  const float inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+  const float bc1 = 1.f - hw_exp2((float)t * hw_log2(b1));      // 1 - b1^t
+  const float bc2 = 1.f - hw_exp2((float)t * hw_log2(b2));
+  const float step_size = lr * hw_rcp(bc1);
+  const float inv_sqrt_bc2 = hw_rsq(bc2);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float w = p[i];
     float g = grad[i] * gscale;
@@ -23,20 +24,27 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     const float vi = b2 * v[i] + (1.f - b2) * g * g;
     m[i] = mi;
     v[i] = vi;
-    p[i] = w - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    const float wn = w - step_size * mi * hw_rcp(hw_sqrt(vi) * inv_sqrt_bc2 + eps);
+    p[i] = wn;
+    if (p_hi) {   // bf16x3 operand planes of the updated weights (hi = bf16(w), lo = bf16(w - hi)): the contractions read these
+      const __bf16 h = (__bf16)wn;
+      const __bf16 l = (__bf16)(wn - (float)h);
+      p_hi[i] = *reinterpret_cast<const unsigned short*>(&h);
+      p_lo[i] = *reinterpret_cast<const unsigned short*>(&l);
+    }
   }
 }
 __global__ void step_inc_kernel(int32_t* step) { *step += 1; }
 
 extern "C" int advmil_adam_step(float* p, const float* grad, float* m, float* v, const float* wd, int64_t n, float lr,
                                 float beta1, float beta2, float eps, float grad_scale, float l1_coef, int32_t* step,
-                                advmil_stream_t stream_) {
+                                void* p_hi, void* p_lo, advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!p || !grad || !m || !v || !step || n <= 0) return ADVMIL_EINVAL;
+  if (!p || !grad || !m || !v || !step || n <= 0 || ((p_hi != nullptr) != (p_lo != nullptr))) return ADVMIL_EINVAL;
   int blocks = (int)((n + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, p, grad, m, v, wd, n, lr, beta1, beta2, eps, grad_scale,
-                     l1_coef, step);
+                     l1_coef, step, (unsigned short*)p_hi, (unsigned short*)p_lo);
   hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, stream, step);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
@@ -136,8 +144,8 @@ __global__ __launch_bounds__(256) void gan_d_loss_kernel(const float* __restrict
   //  term = -r was hoisted into a block that path never executes; <= bp_every_batch elements, so evaluating all forms is free)
   for (int i = threadIdx.x; i < nf; i += 256) {
     const float f = fake[i];
-    const float sg = 1.0f / (1.0f + expf(-f));
-    const float t_bce = -(1.0f - logf(sg + 1e-8f)), d_bce = sg * (1.0f - sg) / (sg + 1e-8f);
+    const float sg = hw_rcp(1.0f + hw_exp(-f));
+    const float t_bce = -(1.0f - hw_log(sg + 1e-8f)), d_bce = sg * (1.0f - sg) * hw_rcp(sg + 1e-8f);
     const float t_hin = fmaxf(1.0f + f, 0.0f), d_hin = (1.0f + f > 0.0f) ? 1.0f : 0.0f;
     const float term = which == 0 ? t_bce : (which == 1 ? t_hin : f);
     const float d = which == 0 ? d_bce : (which == 1 ? d_hin : 1.0f);
@@ -146,8 +154,8 @@ __global__ __launch_bounds__(256) void gan_d_loss_kernel(const float* __restrict
   }
   for (int i = threadIdx.x; i < nr; i += 256) {
     const float r = real[i], m = mask ? mask[i] : 1.0f;
-    const float sg = 1.0f / (1.0f + expf(-r));
-    const float t_bce = -logf(sg + 1e-8f), d_bce = -sg * (1.0f - sg) / (sg + 1e-8f);
+    const float sg = hw_rcp(1.0f + hw_exp(-r));
+    const float t_bce = -hw_log(sg + 1e-8f), d_bce = -sg * (1.0f - sg) * hw_rcp(sg + 1e-8f);
     const float t_hin = fmaxf(1.0f - r, 0.0f), d_hin = (1.0f - r > 0.0f) ? -1.0f : 0.0f;
     const float term = which == 0 ? t_bce : (which == 1 ? t_hin : -r);
     const float d = which == 0 ? d_bce : (which == 1 ? d_hin : -1.0f);

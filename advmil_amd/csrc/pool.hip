@@ -191,7 +191,7 @@ __global__ __launch_bounds__(1024) void softmax_stats_kernel(const float* __rest
   for (int k = 1; k < 16; ++k) mx = fmaxf(mx, red[k]);
   __syncthreads();
   float sum = 0.f;
-  for (int64_t n = beg + tid; n < end; n += 1024) sum += expf(s[n] - mx);
+  for (int64_t n = beg + tid; n < end; n += 1024) sum += hw_exp(s[n] - mx);
   sum = wave_sum(sum);
   if (lane == 0) red[w] = sum;
   __syncthreads();
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(1024) void softmax_stats_kernel(const float* __rest
     float t = 0.f;
     for (int k = 0; k < 16; ++k) t += red[k];
     stats[2 * blockIdx.x] = mx;
-    stats[2 * blockIdx.x + 1] = 1.f / t;
+    stats[2 * blockIdx.x + 1] = hw_rcp(t);
   }
 }
 
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restri
     for (int r = m.r; r < rpb; r += m.rpp) {
       const int64_t n = r0 + r;
       if (n >= end) break;
-      const float w = expf(s[n] - mx) * inv;
+      const float w = hw_exp(s[n] - mx) * inv;
       if (m.c4 == 0) A[n] = w;
       const float4 v = *reinterpret_cast<const float4*>(h + n * ldh + m.c4 * 4);
       acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void pool_partial8_kernel(const float* __restr
       const int64_t n = r0 + r;
       const bool ok = n < end;
       const int64_t nn = ok ? n : beg;                     // predicated: keeps the unrolled loads independent of the bound
-      const float w = ok ? expf(s[nn] - mx) * inv : 0.f;
+      const float w = ok ? hw_exp(s[nn] - mx) * inv : 0.f;
       const float4 v0 = *reinterpret_cast<const float4*>(h + nn * ldh + c8 * 8);
       const float4 v1 = *reinterpret_cast<const float4*>(h + nn * ldh + c8 * 8 + 4);
       if (ok && c8 == 0) A[n] = w;
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256) void ln_relu_mean16_fwd_kernel(const float* __
       const float c = (q < Q && j < d) ? v[q] - mu : 0.f;
       s2 += c * c;
     }
-    const float rs = rsqrtf(wave_sum(s2) * invd + eps);
+    const float rs = hw_rsq(wave_sum(s2) * invd + eps);
     if (lane == 0) { mean[n] = mu; rstd[n] = rs; }
 #pragma unroll
     for (int q = 0; q < LN_MAXQ; ++q) {
@@ -833,7 +833,7 @@ __global__ __launch_bounds__(256) void add_dropout_ln_fwd_kernel(const float* __
       const float c = (q < Q && j < d) ? v[q] - mu : 0.f;
       s2 += c * c;
     }
-    const float rs = rsqrtf(wave_sum(s2) * invd + eps);
+    const float rs = hw_rsq(wave_sum(s2) * invd + eps);
     if (lane == 0) { mean[n] = mu; rstd[n] = rs; }
 #pragma unroll
     for (int q = 0; q < LN_MAXQ; ++q) {

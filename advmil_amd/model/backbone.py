@@ -57,7 +57,8 @@ class ABMIL(nn.Module):
         (everything before `rho`). One FC GEMM, one gate GEMM and one segmented softmax-pool for the whole step batch."""
         rng = _rng_of(self, X)
         fc, p = self.attention_net[0], (self.attention_net[2].p if self.training else 0.0)
-        h = ops.linear_act(X, fc.weight, fc.bias, "relu", p, rng, "abmil_fc")   # [N_total, hid]
+        # the epilogue also emits h's operand planes: the gate contraction below reads them through the plane-fed kernel
+        h = ops.linear_act(X, fc.weight, fc.bias, "relu", p, rng, "abmil_fc", emit_planes=True)   # [N_total, hid]
         pooled, A, _ = self.attention_net[3].pool(h, seg)
         self.last_attention = A.detach()
         return pooled.unsqueeze(0) if seg is None else pooled

@@ -298,7 +298,27 @@ class MyHandler(object):
                 ptr += r * c * 4
         X = (x0.as_strided((sum(rows), c), (c, 1), x0.storage_offset()) if ok
              else torch.cat([x[0].reshape(-1, c) for x in xs], dim=0))
+        self._slab_planes(X, x0 if ok else None)
         return X
+
+    def _slab_planes(self, X, anchor):
+        """bf16x3 mode: the slab's operand planes (hi = bf16(x), lo = bf16(x - hi); the same 4 bytes per element as the fp32 rows).
+        Every contraction that reads X (the generator's and the discriminator's embedding FCs, twice per step each) then takes the
+        plane-fed LDS-DMA kernel instead of re-splitting the rows in every workgroup. A resident slab (zero-copy view starting at
+        the first bag's tensor `anchor`: the loader's staging buffer / the bench's pool) is split ONCE: the planes are kept on the
+        anchor tensor object and reused until its storage is written again (version counter); a slab assembled by a copy
+        (anchor None) is split per step."""
+        if X.shape[0] < 4096 or not ops.USE_PLANES or ops.get_gemm_mode() != "bf16x3":
+            return
+        if anchor is None:
+            X._advmil_planes = ops.split_planes(X)
+            return
+        cache = anchor.__dict__.setdefault("_advmil_slab_planes", {})
+        ent = cache.get(X.shape[0])
+        if ent is None or ent[0] != X._version:
+            ent = (X._version, ops.split_planes(X, out=None if ent is None else ent[1]))
+            cache[X.shape[0]] = ent
+        X._advmil_planes = ent[1]
 
     @staticmethod
     def _stack_noise(noise):

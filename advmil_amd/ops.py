@@ -131,6 +131,16 @@ def gemm_plan(M, N, K, a_kc=True, b_kc=True):
     return _PLAN_CACHE[key]
 
 
+def gemm_plan_planes(M, N, K, a_kc=True, b_kc=True):
+    """Tile code (82 / 83 / 84) of the plane-fed LDS-DMA kernel for an NT contraction whose operands both come as Planes, or 0."""
+    key = ("pl", M, N, K, bool(a_kc), bool(b_kc), _lib.lib().advmil_get_gemm_mode())
+    if key not in _PLAN_CACHE:
+        t = ctypes.c_int(0)
+        _lib.check(_lib.lib().advmil_gemm_f32_plan_planes(1 if a_kc else 0, 1 if b_kc else 0, M, N, K, ctypes.byref(t)), "gemm_plan_planes")
+        _PLAN_CACHE[key] = t.value
+    return _PLAN_CACHE[key]
+
+
 def auto_splits(M, N, K):
     return gemm_plan(M, N, K)[1]
 
@@ -153,6 +163,35 @@ class Planes:
         return Planes(self.hi[r0:r1], self.lo[r0:r1])
 
 
+# Operand planes of tensors that several contractions read (bf16x3 mode). They always travel as an ATTRIBUTE of the tensor object
+# they describe (never keyed by address: the allocator reuses addresses), so they die with it:
+#   * a step slab X: attribute set by the handler (MyHandler._slab_planes), which keeps the planes of a resident slab on the first
+#     bag's tensor object for as long as its storage is unchanged (version counter);
+#   * an activation emitted with its planes by the producing contraction's epilogue: attribute `_advmil_planes` on the result;
+#   * a weight living in a FlatAdam arena: attribute `_advmil_planes` on the parameter, kept current by the Adam kernel and
+#     re-derived when torch writes the parameter (its version counter moves: load_state_dict, copy_).
+USE_PLANES = os.environ.get("ADVMIL_PLANES", "1") != "0"
+
+
+def planes_of(x):
+    """Planes of an activation / slab tensor, or None."""
+    return getattr(x, "_advmil_planes", None) if USE_PLANES else None
+
+
+def weight_planes(W):
+    """Planes of a parameter held in a FlatAdam arena ([N, K] view), or None."""
+    if not USE_PLANES:
+        return None
+    ent = getattr(W, "_advmil_planes", None)
+    if ent is None:
+        return None
+    owner, ver, pl = ent
+    if ver != W._version:                    # torch wrote the parameter since the planes were derived: refresh the whole arena
+        owner.refresh_planes()
+        owner, ver, pl = W._advmil_planes
+    return pl
+
+
 def split_planes(x, out=None):
     """x (fp32, dense storage) -> Planes(hi, lo)."""
     _chk(x, "x")
@@ -168,6 +207,10 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
     """C[M,N] = epilogue(alpha * op(A) op(B)); see include/advmil_hip.h::advmil_gemm_f32. a_planes / b_planes: optional
     Planes of A / B; c_planes: Planes to receive the split of the final C (pitch ldc)."""
     _chk(A, "A"); _chk(B, "B")
+    if tile == 0 and a_planes is not None and b_planes is not None and (splits is None or splits == 1):
+        ptile = gemm_plan_planes(M, N, K, a_kc, b_kc)          # both operands pre-split: the plane-fed LDS-DMA kernel, if the shape fits
+        if ptile:
+            tile, splits = ptile, 1
     if gate_wc is not None:
         # fused gate score (advmil_epilogue_t.gate_wc): B / bias hold the INTERLEAVED branches; returns per-row partial scores
         # [M, column blocks] instead of C
@@ -223,7 +266,9 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        prof.append(("gemm_f32_kernel<%d,%d>" % (bool(a_kc), bool(b_kc)), (M, N, K, splits), 2.0 * M * N * K, e0, e1))
+        name = ("gemm_nt_planes_kernel<%d>" % (tile - 80)) if 82 <= tile <= 84 else \
+            "gemm_f32_kernel<%d,%d,%d,%d>" % (bool(a_kc), bool(b_kc), tile // 10, tile % 10)
+        prof.append((name, (M, N, K, splits), 2.0 * M * N * K, e0, e1))
     return gate_out if gate_wc is not None else out
 
 
@@ -382,10 +427,12 @@ def ln_relu_mean16_bwd(demb, y, gamma, beta, mean, rstd, N, d, dg_out=None, db_o
     return dy, dg, db
 
 
-def adam_step(p, grad, m, v, wd, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, l1_coef=0.0):
-    """In place over flat fp32 arenas; `step` is an int32 device tensor bumped by the kernel."""
+def adam_step(p, grad, m, v, wd, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, l1_coef=0.0, planes=None):
+    """In place over flat fp32 arenas; `step` is an int32 device tensor bumped by the kernel. `planes`: Planes arenas that receive
+    the bf16x3 operand planes of the updated weights."""
     _lib.check(_lib.lib().advmil_adam_step(_p(p), _p(grad), _p(m), _p(v), _p(wd), p.numel(), lr, beta1, beta2, eps,
-                                           grad_scale, l1_coef, _p(step), _stream()), "adam_step")
+                                           grad_scale, l1_coef, _p(step), _p(None if planes is None else planes.hi),
+                                           _p(None if planes is None else planes.lo), _stream()), "adam_step")
 
 
 def abs_sum(p):
@@ -410,9 +457,9 @@ def _arena_grad(p):
     return None
 
 
-def _adjacent(a, b):
+def _adjacent(a, b, itemsize=4):
     return (a is not None and b is not None and a.is_contiguous() and b.is_contiguous()
-            and b.data_ptr() == a.data_ptr() + a.numel() * 4
+            and b.data_ptr() == a.data_ptr() + a.numel() * itemsize
             and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr())     # same arena, not allocator luck
 
 
@@ -457,20 +504,26 @@ def dropout(x, p, rng, tag=""):
 
 class LinearActFn(torch.autograd.Function):
     """y = dropout(act(x W^T + b)); x[M,K], W[N,K]. Dropout index = m*N + n on stream `sid`."""
+    last_planes = None       # planes of the y just produced (side channel to linear_act: Function outputs are re-wrapped)
 
     @staticmethod
-    def forward(ctx, x, W, b, act, p, seed, sid, y0=None, rr=None):
+    def forward(ctx, x, W, b, act, p, seed, sid, y0=None, rr=None, xpl=None, wpl=None, emit=False):
         _chk(x, "x"); _chk(W, "weight")
         x = x.contiguous()
         W2 = W.detach().reshape(W.shape[0], -1)
         M, K = x.shape
         N = W2.shape[0]
+        cpl = None
         if y0 is None:
-            y = gemm(x, W2, True, True, M, N, K, bias=b, act0=act, drop_p=p, seed=seed, stream_id=sid, rng_row=rr)
+            if emit and get_gemm_mode() == "bf16x3":
+                cpl = Planes(torch.empty(M, N, dtype=torch.bfloat16, device=x.device), torch.empty(M, N, dtype=torch.bfloat16, device=x.device))
+            y = gemm(x, W2, True, True, M, N, K, bias=b, act0=act, drop_p=p, seed=seed, stream_id=sid, rng_row=rr,
+                     a_planes=xpl, b_planes=wpl, c_planes=cpl, splits=1 if cpl is not None else None)
         elif p > 0.0:       # memoized act(x W^T + b) of the eval forward: only this forward's dropout draw is new
             y, _ = act_dropout_bwd(y0, y0, ACT_NONE, M, N, p, seed, sid, want_bias=False, rng_row=rr)
         else:
             y = y0
+        LinearActFn.last_planes = cpl
         ctx.save_for_backward(x, W2, y)
         ctx.cfg = (act, p, seed, sid, M, N, K, W.shape, b is not None, rr)
         ctx.gW, ctx.gb = _arena_grad(W), _arena_grad(b)
@@ -497,7 +550,7 @@ class LinearActFn(torch.autograd.Function):
             else:
                 dW = gemm(dpre, x, False, False, N, K, M).reshape(wshape)
         dx = gemm(dpre, W2, True, False, M, K, N) if need_x else None                   # dpre W
-        return dx, dW, (None if ctx.gb is not None else db), None, None, None, None, None, None
+        return dx, dW, (None if ctx.gb is not None else db), None, None, None, None, None, None, None, None, None
 
 
 class ForwardMemo:
@@ -531,10 +584,12 @@ MEMO = ForwardMemo()
 MEMO_MIN_ROWS = int(os.environ.get("ADVMIL_MEMO_MIN_ROWS", "4096"))
 
 
-def linear_act(x, W, b, act="none", p=0.0, rng=None, tag=""):
-    """x[..., K] -> [..., N] through the HIP GEMM (any leading dims are flattened)."""
+def linear_act(x, W, b, act="none", p=0.0, rng=None, tag="", emit_planes=False):
+    """x[..., K] -> [..., N] through the HIP GEMM (any leading dims are flattened). In bf16x3 mode the operands' bf16 planes are
+    used when they exist (slab registered by the handler / producer-emitted activation planes / arena weight planes), and
+    `emit_planes` makes the epilogue also write the planes of y (attribute `_advmil_planes`) for the contraction that reads it."""
     lead = x.shape[:-1]
-    x2 = x.reshape(-1, x.shape[-1])
+    x2 = x if x.dim() == 2 else x.reshape(-1, x.shape[-1])        # (a 2-D input keeps its object: operand planes are attributes)
     sid, seed, rr = 0, None, None
     if p > 0.0:
         rng = rng or default_rng(x.device)
@@ -548,10 +603,19 @@ def linear_act(x, W, b, act="none", p=0.0, rng=None, tag=""):
     y0 = None
     if memo is not None and memo.mode == "replay":
         y0 = memo.store.pop(key, None)
-    y = LinearActFn.apply(x2, W, b, _ACT[act], float(p), seed, sid, y0, rr)
+    xpl = wpl = None
+    if y0 is None and x2.shape[0] >= 4096 and get_gemm_mode() == "bf16x3":
+        xpl, wpl = planes_of(x2), weight_planes(W)
+        if wpl is not None:
+            wpl = Planes(wpl.hi.reshape(W.shape[0], -1), wpl.lo.reshape(W.shape[0], -1))
+    y = LinearActFn.apply(x2, W, b, _ACT[act], float(p), seed, sid, y0, rr, xpl, wpl, bool(emit_planes) and x2.shape[0] >= 4096)
+    cpl, LinearActFn.last_planes = LinearActFn.last_planes, None
     if memo is not None and memo.mode == "record" and p <= 0.0 and not torch.is_grad_enabled():
         memo.store[key] = y
-    return y.reshape(*lead, y.shape[-1])
+    out = y if len(lead) == 1 else y.reshape(*lead, y.shape[-1])
+    if cpl is not None:
+        out._advmil_planes = cpl
+    return out
 
 
 class GatedAttnPoolFn(torch.autograd.Function):
@@ -560,7 +624,7 @@ class GatedAttnPoolFn(torch.autograd.Function):
     model/backbone.py:81-85) and GAPool (model/backbone_utils.py:47-56): the pooled tensor is the scored tensor in every use."""
 
     @staticmethod
-    def forward(ctx, h, Wa, ba, Wb, bb, wc, bc, p, seed, sa, sb, seg, nograd=False, rr=None):
+    def forward(ctx, h, Wa, ba, Wb, bb, wc, bc, p, seed, sa, sb, seg, nograd=False, rr=None, hpl=None):
         _chk(h, "h")
         h = h.contiguous()
         N, D = h.shape
@@ -570,13 +634,21 @@ class GatedAttnPoolFn(torch.autograd.Function):
             # activations, so the contraction reduces the score in its epilogue from interleaved branch rows and never stores them
             Wi = torch.stack((Wa.detach(), Wb.detach()), dim=1).reshape(2 * D, D)
             bi = torch.stack((ba.detach(), bb.detach()), dim=1).reshape(2 * D)
-            s = gemm(h, Wi, True, True, N, 2 * D, D, bias=bi, gate_wc=wcv).sum(dim=1) + bc.detach()
+            wipl = split_planes(Wi) if hpl is not None else None          # 2D x D: one tiny launch
+            s = gemm(h, Wi, True, True, N, 2 * D, D, bias=bi, gate_wc=wcv, a_planes=hpl, b_planes=wipl).sum(dim=1) + bc.detach()
             A, pooled = softmax_pool(s, h, N, D, seg)
             ctx.mark_non_differentiable(s)
             return pooled, A, s
         Wab, _ = _stack2(Wa, Wb, D, D)                       # [2D, D]: a view when the two live side by side in the arena
         bab, _ = _stack2(ba, bb, D, 0)
-        ab = gemm(h, Wab, True, True, N, 2 * D, D, bias=bab, act0=ACT_TANH, act1=ACT_SIGMOID, act_split=D)
+        wabpl = None
+        if hpl is not None:
+            pa_, pb_ = weight_planes(Wa), weight_planes(Wb)
+            if pa_ is not None and pb_ is not None and _adjacent(pa_.hi, pb_.hi, 2) and _adjacent(pa_.lo, pb_.lo, 2):
+                wabpl = Planes(pa_.hi.as_strided((2 * D, D), (D, 1), pa_.hi.storage_offset()),
+                               pa_.lo.as_strided((2 * D, D), (D, 1), pa_.lo.storage_offset()))
+        ab = gemm(h, Wab, True, True, N, 2 * D, D, bias=bab, act0=ACT_TANH, act1=ACT_SIGMOID, act_split=D,
+                  a_planes=hpl if wabpl is not None else None, b_planes=wabpl)
         s = gate_score(ab, wcv, bc, N, D, p, seed, sa, sb, rr)
         A, pooled = softmax_pool(s, h, N, D, seg)
         ctx.save_for_backward(h, Wab, ab, A, wcv)
@@ -609,7 +681,7 @@ class GatedAttnPoolFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # dG [N,2D] . Wab [2D,D]  +  A[n] * dpooled[bag(n), d]   (pooling's direct path, rank-1 per bag)
             dh = gemm(dG, Wab, True, False, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg)
-        nones = (None,) * 7
+        nones = (None,) * 8
         if ctx.arena is not None:
             gemm(dG, h, False, False, 2 * D, D, N, out=gWab, ldc=D, accumulate=True)       # dG^T h
             return (dh, None, None, None, None, None, None) + nones
@@ -628,7 +700,8 @@ def gated_attn_pool(h, Wa, ba, Wb, bb, wc, bc, p=0.0, rng=None, tag="", seg=None
         seed, rr = rng.seed, rng.row_map(h.shape[0])
     # grad mode is always off INSIDE Function.forward, so "nothing here will be differentiated" is decided out here
     nograd = not torch.is_grad_enabled() or not any(t.requires_grad for t in (h, Wa, ba, Wb, bb, wc, bc))
-    pooled, A, s = GatedAttnPoolFn.apply(h, Wa, ba, Wb, bb, wc, bc, float(p), seed, sa, sb, seg, nograd, rr)
+    hpl = planes_of(h) if (h.shape[0] >= 4096 and h.is_contiguous() and get_gemm_mode() == "bf16x3") else None
+    pooled, A, s = GatedAttnPoolFn.apply(h, Wa, ba, Wb, bb, wc, bc, float(p), seed, sa, sb, seg, nograd, rr, hpl)
     return (pooled[0] if seg is None else pooled), A, s
 
 

@@ -58,6 +58,9 @@ class FlatAdam(torch.optim.Optimizer):
         self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_wd = torch.zeros(total, dtype=torch.float32, device=dev)
         self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)
+        # bf16x3 operand planes of the weights (hi = bf16(w), lo = bf16(w - hi)), same layout as the arena: written by the Adam
+        # kernel with every update, so no contraction ever re-splits a weight (ops.weight_planes)
+        self.planes = ops.Planes(torch.zeros(total, dtype=torch.bfloat16, device=dev), torch.zeros(total, dtype=torch.bfloat16, device=dev))
         self._views = []
         with torch.no_grad():
             for (n, p), o in zip(ordered, offs):
@@ -74,6 +77,14 @@ class FlatAdam(torch.optim.Optimizer):
                     self.state[p] = {"step": torch.zeros((), dtype=torch.float32), "exp_avg": self.flat_m[o:o + k].view(p.shape),
                                      "exp_avg_sq": self.flat_v[o:o + k].view(p.shape)}
         self._has_wd = bool(self.flat_wd.abs().max().item() > 0)
+        self.refresh_planes()
+
+    def refresh_planes(self):
+        """Re-derive the weight planes from the arena (construction, load_state_dict, any torch-side write to a parameter) and
+        stamp every parameter with its current version counter."""
+        ops.split_planes(self.flat_param, out=self.planes)
+        for p, o, k in self._views:
+            p._advmil_planes = (self, p._version, ops.Planes(self.planes.hi[o:o + k].view(p.shape), self.planes.lo[o:o + k].view(p.shape)))
 
     def zero_grad(self, set_to_none: bool = False):
         self.flat_grad.zero_()
@@ -88,7 +99,7 @@ class FlatAdam(torch.optim.Optimizer):
         b1, b2 = g0["betas"]
         self.n_updates = getattr(self, "n_updates", 0) + 1      # host-side version of the parameters (forward memo key)
         ops.adam_step(self.flat_param, self.flat_grad, self.flat_m, self.flat_v, self.flat_wd if self._has_wd else None,
-                      self.step_t, g0["lr"], b1, b2, g0["eps"], grad_scale, self.l1_coef)
+                      self.step_t, g0["lr"], b1, b2, g0["eps"], grad_scale, self.l1_coef, planes=self.planes)
 
     def state_dict(self):
         n = float(self.step_t.item())
@@ -113,3 +124,4 @@ class FlatAdam(torch.optim.Optimizer):
                     o, k = next((o, k) for q, o, k in self._views if q is p)
                     self.flat_wd[o:o + k] = g["weight_decay"]
         self._has_wd = bool(self.flat_wd.abs().max().item() > 0)
+        self.refresh_planes()

@@ -355,10 +355,7 @@ def main():
         prof, ops.KERNEL_PROFILE = ops.KERNEL_PROFILE, None
         agg = {}
         for name, shape, flops, e0, e1 in prof:
-            M, N, K, sp = shape
-            lay = name.split("<")[1].rstrip(">").split(",")
-            tile, _ = ops.gemm_plan(M, N, K, lay[0] == "1", lay[1] == "1")
-            key = (f"{name[:-1]},{tile // 10},{tile % 10}>", shape)
+            key = (name, shape)               # the kernel + tile ops.gemm actually launched
             a = agg.setdefault(key, {"ms": 0.0, "n": 0, "flops": flops})
             a["ms"] += e0.elapsed_time(e1); a["n"] += 1
         if os.environ.get("ADVMIL_BENCH_TABLE"):   # per-step GEMM table (launch, shape, count, ms) on stderr
@@ -367,11 +364,18 @@ def main():
                       f"us/launch={1e3 * v['ms'] / v['n']:.1f}  TF={v['flops'] * v['n'] / v['ms'] / 1e9:.0f}", file=sys.stderr)
         (kname, shape), top = max(agg.items(), key=lambda kv: kv[1]["ms"])
         M, N, K, sp = shape
-        a_kc, b_kc = kname.split("<")[1].startswith("1"), kname.split("<")[1].split(",")[1].startswith("1")
+        planes_kernel = kname.startswith("gemm_nt_planes")
+        if planes_kernel:                     # NT form, both operands arrive as bf16 planes (hi, lo): the same 4 bytes per element
+            a_kc = b_kc = True
+        else:
+            a_kc, b_kc = kname.split("<")[1].startswith("1"), kname.split("<")[1].split(",")[1].startswith("1")
         A = torch.randn((M, K) if a_kc else (K, M), device=dev)
         B = torch.randn((N, K) if b_kc else (K, N), device=dev)
         out = torch.empty(M, N, device=dev)
-        us = event_time_us(torch, lambda: ops.gemm(A, B, a_kc, b_kc, M, N, K, out=out), 50)
+        kw = dict(a_planes=ops.split_planes(A), b_planes=ops.split_planes(B)) if planes_kernel else {}
+        if not planes_kernel:
+            kw["tile"] = int(kname.rstrip(">").split(",")[2]) * 10 + int(kname.rstrip(">").split(",")[3])
+        us = event_time_us(torch, lambda: ops.gemm(A, B, a_kc, b_kc, M, N, K, out=out, **kw), 50)
         flops = 2.0 * M * N * K
         achieved = flops / us / 1e6
         traffic, traffic_src = None, None

@@ -105,6 +105,11 @@ int advmil_gemm_f32_plan(int64_t M, int64_t N, int64_t K, int* tile, int* splits
 /* Same, knowing the operand layouts (the best tile differs between the NT forward form and the NN / TN backward forms; this is what
  * advmil_gemm_f32 itself uses). advmil_gemm_f32_plan is the a_kc = b_kc = 1 case. */
 int advmil_gemm_f32_plan_layout(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, int* tile, int* splits);
+/* bf16x3 mode, NT form (a_kc = b_kc = 1) with BOTH operands supplied as planes (a_hi..b_lo): the tile of the plane-fed kernel that
+ * stages global -> LDS by LDS-DMA (82 / 83 / 84 = 256 x 128 / 192 / 256, 8 waves; M % 256 == 0, K % 32 == 0, N % tile width == 0,
+ * splits = 1), or 0 when the shape does not qualify. advmil_gemm_f32_tiled(tile = 0) makes the same choice; callers of the fused
+ * gate-score mode need the tile up front for advmil_gemm_f32_gate_blocks. Results are bit-identical to the generic kernel's. */
+int advmil_gemm_f32_plan_planes(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, int* tile);
 /* Same, with an explicit block tile: tile = 10*TM + TN selects (64*TM) x (64*TN) output tiles
  * (22 = 128x128, 23 = 128x192, 13 = 64x192, 12 = 64x128, 11 = 64x64; 43 = 256x192, 42 = 256x128, 34 = 192x256, 24 = 128x256 with 512 threads,
  * bf16x3 mode only -- in exact mode they fall back to 23 / 22); 0 = the plan's choice (what advmil_gemm_f32 uses). */
@@ -232,10 +237,11 @@ int advmil_genconv_bwd(const float* dout, const float* x, const float* out, cons
  * Optimizer + regulariser over a flat parameter arena (torch.optim.Adam, L2-in-grad weight decay:
  * optim/optim_factory.py:25-37,76-77; model/model_handler.py:104-107; L1: loss/utils.py:6-14).
  *   g = grad*grad_scale + l1_coef*sign(p) + wd[i]*p ; Adam(m, v) ; p -= lr/(1-b1^t) * m/(sqrt(v)/sqrt(1-b2^t)+eps)
- * `step` is a device int32 incremented by the kernel (graph-replay safe). wd may be NULL.
+ * `step` is a device int32 incremented by the kernel (graph-replay safe). wd may be NULL. p_hi / p_lo (both or neither): bf16 arenas of
+ * n elements that receive the bf16x3 operand planes of the UPDATED weights, so the contractions never re-split a weight.
  * abs_sum: out[0] = sum |p| (for the logged Loss_G_total). */
 int advmil_adam_step(float* p, const float* grad, float* m, float* v, const float* wd, int64_t n, float lr,
-                     float beta1, float beta2, float eps, float grad_scale, float l1_coef, int32_t* step,
+                     float beta1, float beta2, float eps, float grad_scale, float l1_coef, int32_t* step, void* p_hi, void* p_lo,
                      advmil_stream_t stream);
 int advmil_abs_sum(const float* p, int64_t n, float* out, void* ws, size_t ws_bytes, advmil_stream_t stream);
 size_t advmil_abs_sum_workspace_bytes(int64_t n);
