@@ -64,10 +64,11 @@ SIGNATURES = {
                                         c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "advmil_gate_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "advmil_gate_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_uint64, c_uint64, c_int64, c_int64,
-                                c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                c_void_p]),
     "advmil_colsum_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "advmil_act_dropout_bwd": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_uint64, c_int64, c_int64, c_void_p,
-                                       c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                       c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "advmil_colsum": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "advmil_ln_relu_mean16_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int64, c_void_p, c_void_p,
                                           c_void_p, c_void_p]),

@@ -769,7 +769,7 @@ extern "C" int advmil_gemm_f32_plan_planes(int a_kc, int b_kc, int64_t M, int64_
   *tile = 0;
   if (g_gemm_mode != 1 || !g_nt_planes || !a_kc || !b_kc || M < 4096 || (M % 256) || (K % 32) || (N % 128)) return ADVMIL_OK;
   const char* force = getenv("ADVMIL_NT_PLANES_TN");
-  int tnp = (N % 256 == 0 && N % 192 != 0) ? 4 : ((N % 192 == 0) ? 3 : 2);
+  int tnp = (N % 256 == 0) ? 4 : ((N % 192 == 0) ? 3 : 2);      // widest tile that divides N: most flops per staged byte
   if (force && (force[0] == '2' || force[0] == '3' || force[0] == '4') && N % (64 * (force[0] - '0')) == 0) tnp = force[0] - '0';
   *tile = 80 + tnp;
   return ADVMIL_OK;

@@ -4,6 +4,7 @@
 // one-wave-per-row with 256 B coalesced segments; reductions are deterministic two-stage (per-workgroup
 // partials in a caller workspace, then a merge launch) -- no float atomics.
 #include "common.h"
+#include "bf16split.h"
 #include "../../include/advmil_hip.h"
 
 #define ROWS_PER_BLOCK 32
@@ -393,7 +394,8 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ wc, float p, const uint64_t* seed,
                                                        uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D,
                                                        float* __restrict__ dG, float* __restrict__ partial, int rpb,
-                                                       const int64_t* __restrict__ rng_row) {
+                                                       const int64_t* __restrict__ rng_row, bf16raw* __restrict__ g_hi,
+                                                       bf16raw* __restrict__ g_lo) {
   __shared__ __attribute__((aligned(16))) float red[1024];
   const RowColMap m = make_map(D);
   const bool drop = seed && p > 0.f;
@@ -433,6 +435,15 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
       }
       *reinterpret_cast<float4*>(dG + n * 2 * D + m.c4 * 4) = make_float4(ga[0], ga[1], ga[2], ga[3]);
       *reinterpret_cast<float4*>(dG + n * 2 * D + D + m.c4 * 4) = make_float4(gb[0], gb[1], gb[2], gb[3]);
+      if (g_hi) {   // bf16x3 operand planes of dG for the contractions that read it (dh = dG Wab, dWab = dG^T h)
+        uint2 hh, ll;
+        split4(make_float4(ga[0], ga[1], ga[2], ga[3]), hh, ll);
+        *reinterpret_cast<uint2*>(g_hi + n * 2 * D + m.c4 * 4) = hh;
+        *reinterpret_cast<uint2*>(g_lo + n * 2 * D + m.c4 * 4) = ll;
+        split4(make_float4(gb[0], gb[1], gb[2], gb[3]), hh, ll);
+        *reinterpret_cast<uint2*>(g_hi + n * 2 * D + D + m.c4 * 4) = hh;
+        *reinterpret_cast<uint2*>(g_lo + n * 2 * D + D + m.c4 * 4) = ll;
+      }
       s_wc.x += gw[0]; s_wc.y += gw[1]; s_wc.z += gw[2]; s_wc.w += gw[3];
       s_a.x += ga[0]; s_a.y += ga[1]; s_a.z += ga[2]; s_a.w += ga[3];
       s_b.x += gb[0]; s_b.y += gb[1]; s_b.z += gb[2]; s_b.w += gb[3];
@@ -463,8 +474,8 @@ extern "C" size_t advmil_gate_bwd_workspace_bytes(int64_t N, int64_t D) {
 
 extern "C" int advmil_gate_bwd(const float* ab, const float* ds, const float* wc, float drop_p, const uint64_t* seed,
                                uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D, float* dG, float* dwc,
-                               float* dbc, float* dbias, int accumulate, const int64_t* rng_row, void* ws, size_t ws_bytes,
-                               advmil_stream_t stream_) {
+                               float* dbc, float* dbias, int accumulate, const int64_t* rng_row, void* dG_hi, void* dG_lo, void* ws,
+                               size_t ws_bytes, advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!ab || !ds || !wc || !dG || !dwc || !dbc || !dbias || !ws || N <= 0 || D <= 0 || (D & 3) || D > 1024)
     return ADVMIL_EINVAL;
@@ -474,7 +485,7 @@ extern "C" int advmil_gate_bwd(const float* ab, const float* ds, const float* wc
   float* partial = (float*)ws;
   const int64_t stride = 3 * D + 4;
   hipLaunchKernelGGL(gate_bwd_kernel, dim3(nblk), dim3(256), 0, stream, ab, ds, wc, drop_p, seed, stream_a, stream_b, N, D,
-                     dG, partial, rpb, rng_row);
+                     dG, partial, rpb, rng_row, (bf16raw*)dG_hi, (bf16raw*)dG_lo);
   ADVMIL_LAUNCH_CHECK();
   // dwc | dbias(a) | dbias(b) | dbc are adjacent in the partial rows: one merge launch over 3D+1 columns into a
   // scratch row, then scattered by the three tiny copies below would cost more launches; instead merge each target.
@@ -492,7 +503,8 @@ __global__ __launch_bounds__(256) void act_dropout_bwd_kernel(const float* __res
                                                               int act, float p, const uint64_t* seed, uint64_t stream_id,
                                                               int64_t M, int64_t N, int64_t c0, int64_t W,
                                                               float* __restrict__ dpre, float* __restrict__ partial,
-                                                              int64_t pstride, int rpb, const int64_t* __restrict__ rng_row) {
+                                                              int64_t pstride, int rpb, const int64_t* __restrict__ rng_row,
+                                                              bf16raw* __restrict__ o_hi, bf16raw* __restrict__ o_lo) {
   __shared__ __attribute__((aligned(16))) float red[1024];
   const RowColMap m = make_map(W);
   const bool drop = seed && p > 0.f;
@@ -521,6 +533,12 @@ __global__ __launch_bounds__(256) void act_dropout_bwd_kernel(const float* __res
         o[q] = gv[q] * f * act_grad_from_out(act, yy);
       }
       *reinterpret_cast<float4*>(dpre + off) = make_float4(o[0], o[1], o[2], o[3]);
+      if (o_hi) {
+        uint2 hh, ll;
+        split4(make_float4(o[0], o[1], o[2], o[3]), hh, ll);
+        *reinterpret_cast<uint2*>(o_hi + off) = hh;
+        *reinterpret_cast<uint2*>(o_lo + off) = ll;
+      }
       sum.x += o[0]; sum.y += o[1]; sum.z += o[2]; sum.w += o[3];
     }
   }
@@ -537,9 +555,10 @@ extern "C" size_t advmil_colsum_workspace_bytes(int64_t M, int64_t N) {
 
 extern "C" int advmil_act_dropout_bwd(const float* dy, const float* y, int act, float drop_p, const uint64_t* seed,
                                       uint64_t stream_id, int64_t M, int64_t N, float* dpre, float* dbias, int accumulate,
-                                      const int64_t* rng_row, void* ws, size_t ws_bytes, advmil_stream_t stream_) {
+                                      const int64_t* rng_row, void* out_hi, void* out_lo, void* ws, size_t ws_bytes,
+                                      advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!dy || !y || !dpre || M <= 0 || N <= 0 || (N & 3)) return ADVMIL_EINVAL;
+  if (!dy || !y || !dpre || M <= 0 || N <= 0 || (N & 3) || ((out_hi != nullptr) != (out_lo != nullptr))) return ADVMIL_EINVAL;
   if (dbias && (!ws || ws_bytes < advmil_colsum_workspace_bytes(M, N))) return ADVMIL_EWORKSPACE;
   const int rpb = rows_per_block(M);
   const int nblk = (int)((M + rpb - 1) / rpb);
@@ -547,7 +566,7 @@ extern "C" int advmil_act_dropout_bwd(const float* dy, const float* y, int act, 
   for (int64_t c0 = 0; c0 < N; c0 += 1024) {
     const int64_t W = (N - c0 < 1024) ? (N - c0) : 1024;
     hipLaunchKernelGGL(act_dropout_bwd_kernel, dim3(nblk), dim3(256), 0, stream, dy, y, act, drop_p, seed, stream_id, M, N,
-                       c0, W, dpre, partial, N, rpb, rng_row);
+                       c0, W, dpre, partial, N, rpb, rng_row, (bf16raw*)out_hi, (bf16raw*)out_lo);
   }
   ADVMIL_LAUNCH_CHECK();
   if (dbias) {

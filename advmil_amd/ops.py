@@ -360,7 +360,7 @@ def softmax_pool_bwd(dpooled, dA, A, h, N, D, seg=None):
     return ds
 
 
-def gate_bwd(ab, ds, wc, N, D, p=0.0, seed=None, stream_a=0, stream_b=0, dwc=None, dbc=None, dbias=None, rng_row=None):
+def gate_bwd(ab, ds, wc, N, D, p=0.0, seed=None, stream_a=0, stream_b=0, dwc=None, dbc=None, dbias=None, rng_row=None, planes=None):
     """dwc/dbc/dbias given -> gradients are ADDED into them (views of the gradient arena)."""
     L = _lib.lib()
     dev = ab.device
@@ -374,11 +374,13 @@ def gate_bwd(ab, ds, wc, N, D, p=0.0, seed=None, stream_a=0, stream_b=0, dwc=Non
     ws = _ws(wsb, dev)
     sd = seed if p > 0.0 else None
     _lib.check(L.advmil_gate_bwd(_p(ab), _p(ds), _p(wc), p, _p(sd), stream_a, stream_b, N, D, _p(dG), _p(dwc), _p(dbc),
-                                 _p(dbias), 1 if acc else 0, _p(rng_row if sd is not None else None), _p(ws), wsb, _stream()), "gate_bwd")
+                                 _p(dbias), 1 if acc else 0, _p(rng_row if sd is not None else None),
+                                 _p(None if planes is None else planes.hi), _p(None if planes is None else planes.lo), _p(ws), wsb,
+                                 _stream()), "gate_bwd")
     return dG, dwc, dbc, dbias
 
 
-def act_dropout_bwd(dy, y, act, M, N, p=0.0, seed=None, stream_id=0, want_bias=True, db_out=None, rng_row=None):
+def act_dropout_bwd(dy, y, act, M, N, p=0.0, seed=None, stream_id=0, want_bias=True, db_out=None, rng_row=None, planes=None):
     L = _lib.lib()
     dpre = torch.empty(M, N, dtype=torch.float32, device=dy.device)
     acc = db_out is not None
@@ -388,7 +390,8 @@ def act_dropout_bwd(dy, y, act, M, N, p=0.0, seed=None, stream_id=0, want_bias=T
     ws = _ws(wsb, dy.device) if need else None
     sd = seed if p > 0.0 else None
     _lib.check(L.advmil_act_dropout_bwd(_p(dy), _p(y), act, p, _p(sd), stream_id, M, N, _p(dpre), _p(db), 1 if acc else 0,
-                                        _p(rng_row if sd is not None else None), _p(ws), wsb, _stream()), "act_dropout_bwd")
+                                        _p(rng_row if sd is not None else None), _p(None if planes is None else planes.hi),
+                                        _p(None if planes is None else planes.lo), _p(ws), wsb, _stream()), "act_dropout_bwd")
     return dpre, db
 
 
@@ -520,7 +523,9 @@ class LinearActFn(torch.autograd.Function):
             y = gemm(x, W2, True, True, M, N, K, bias=b, act0=act, drop_p=p, seed=seed, stream_id=sid, rng_row=rr,
                      a_planes=xpl, b_planes=wpl, c_planes=cpl, splits=1 if cpl is not None else None)
         elif p > 0.0:       # memoized act(x W^T + b) of the eval forward: only this forward's dropout draw is new
-            y, _ = act_dropout_bwd(y0, y0, ACT_NONE, M, N, p, seed, sid, want_bias=False, rng_row=rr)
+            if emit and get_gemm_mode() == "bf16x3":
+                cpl = Planes(torch.empty(M, N, dtype=torch.bfloat16, device=x.device), torch.empty(M, N, dtype=torch.bfloat16, device=x.device))
+            y, _ = act_dropout_bwd(y0, y0, ACT_NONE, M, N, p, seed, sid, want_bias=False, rng_row=rr, planes=cpl)
         else:
             y = y0
         LinearActFn.last_planes = cpl
@@ -604,6 +609,8 @@ def linear_act(x, W, b, act="none", p=0.0, rng=None, tag="", emit_planes=False):
     if memo is not None and memo.mode == "replay":
         y0 = memo.store.pop(key, None)
     xpl = wpl = None
+    if y0 is not None and p <= 0.0 and emit_planes:
+        emit_planes = False                   # the memoized tensor is returned as is: its planes (if any) are already attached
     if y0 is None and x2.shape[0] >= 4096 and get_gemm_mode() == "bf16x3":
         xpl, wpl = planes_of(x2), weight_planes(W)
         if wpl is not None:
@@ -672,15 +679,26 @@ class GatedAttnPoolFn(torch.autograd.Function):
                    else dpooled.contiguous().reshape(nseg, D))
         dA_ = None if dA is None else dA.contiguous()
         ds = softmax_pool_bwd(dpooled, dA_, A, h, N, D, seg)
+        need_h = ctx.needs_input_grad[0]
+        # bf16x3: dh = dG Wab runs as an NT contraction of dG's planes (emitted by gate_bwd) with the planes of Wab^T (a 2D x D
+        # transpose + split: two tiny launches) through the plane-fed kernel, when the shape qualifies
+        gpl = None
+        if need_h and USE_PLANES and get_gemm_mode() == "bf16x3" and gemm_plan_planes(N, D, 2 * D):
+            gpl = Planes(torch.empty(N, 2 * D, dtype=torch.bfloat16, device=h.device), torch.empty(N, 2 * D, dtype=torch.bfloat16, device=h.device))
         if ctx.arena is not None:
             gWab, gbab, gwc, gbc = ctx.arena
-            dG, _, _, _ = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb, dwc=gwc, dbc=gbc, dbias=gbab, rng_row=rr)
+            dG, _, _, _ = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb, dwc=gwc, dbc=gbc, dbias=gbab, rng_row=rr, planes=gpl)
         else:
-            dG, dwc, dbc, dbias = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb, rng_row=rr)
+            dG, dwc, dbc, dbias = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb, rng_row=rr, planes=gpl)
         dh = None
-        if ctx.needs_input_grad[0]:
+        if need_h:
             # dG [N,2D] . Wab [2D,D]  +  A[n] * dpooled[bag(n), d]   (pooling's direct path, rank-1 per bag)
-            dh = gemm(dG, Wab, True, False, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg)
+            if gpl is not None:
+                WabT = Wab.t().contiguous()                                       # [D, 2D]: k (= 2D) contiguous
+                dh = gemm(dG, WabT, True, True, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg,
+                          a_planes=gpl, b_planes=split_planes(WabT))
+            else:
+                dh = gemm(dG, Wab, True, False, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg)
         nones = (None,) * 8
         if ctx.arena is not None:
             gemm(dG, h, False, False, 2 * D, D, N, out=gWab, ldc=D, accumulate=True)       # dG^T h

@@ -167,6 +167,8 @@ int advmil_add_dropout_ln_bwd(const float* dy, const float* z, const float* gamm
  *   dA may be NULL. (dh gets A[n]*dpooled[d] through the rank-1 term of the gemm epilogue.)
  * gate_bwd: from ds -> dG[N,2D] = grads wrt the two pre-activations, plus dwc[D], dbc[1], dbias[2D]
  *   (column sums of dG).
+ * dG_hi / dG_lo (gate_bwd), out_hi / out_lo (act_dropout_bwd): optional (both or neither) bf16 [rows, cols] buffers that also receive
+ *   the bf16x3 operand planes of the result, for the plane-fed contraction that reads it next.
  * `accumulate` (here and in the other backward entry points): non-zero ADDS the parameter gradients into the
  *   destination instead of overwriting it -- the destinations are then views of the flat gradient arena, which
  *   removes the per-parameter accumulate launches autograd would issue for every bag. */
@@ -185,7 +187,8 @@ int advmil_softmax_pool_bwd(const float* dpooled, const float* dA, const float* 
 size_t advmil_gate_bwd_workspace_bytes(int64_t N, int64_t D);
 int advmil_gate_bwd(const float* ab, const float* ds, const float* wc, float drop_p, const uint64_t* seed,
                     uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D, float* dG, float* dwc, float* dbc,
-                    float* dbias, int accumulate, const int64_t* rng_row, void* ws, size_t ws_bytes, advmil_stream_t stream);
+                    float* dbias, int accumulate, const int64_t* rng_row, void* dG_hi, void* dG_lo, void* ws, size_t ws_bytes,
+                    advmil_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Backward of y = dropout(act(pre)) for the Linear layers: dpre = dy * keep * act'(y) and
@@ -194,7 +197,7 @@ int advmil_gate_bwd(const float* ab, const float* ds, const float* wc, float dro
 size_t advmil_colsum_workspace_bytes(int64_t M, int64_t N);
 int advmil_act_dropout_bwd(const float* dy, const float* y, int act, float drop_p, const uint64_t* seed,
                            uint64_t stream_id, int64_t M, int64_t N, float* dpre, float* dbias, int accumulate,
-                           const int64_t* rng_row, void* ws, size_t ws_bytes, advmil_stream_t stream);
+                           const int64_t* rng_row, void* out_hi, void* out_lo, void* ws, size_t ws_bytes, advmil_stream_t stream);
 /* out[n] (+)= sum_m x[m,n] */
 int advmil_colsum(const float* x, int64_t M, int64_t N, float* out, int accumulate, void* ws, size_t ws_bytes,
                   advmil_stream_t stream);
