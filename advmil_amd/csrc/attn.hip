@@ -26,11 +26,12 @@
 // Workgroup -> (bag, tile, head) with head = blockIdx % nhead: for nhead = 8 every XCD (blockIdx % 8) serves one head, so the K/V
 // panel of a (bag, head) is fetched into exactly one L2.
 //
-// Dropout on the attention probabilities (train mode): keep(i, j) = hash32(rowkey(i) + j * 0x9E3779B9) >= p * 2^32 with
-// rowkey(i) = high word of splitmix64(key(seed, stream) + (global region row of query i) * nhead + head); restated on the host in
-// advmil_amd/synth.py::attn_dropout_keep. A per-row 64-bit mix + a 32-bit finaliser per element costs ~9 VALU per probability
-// (a splitmix64 per element would cost ~4x the MFMA time of the tile) and is layout independent, which the key-stationary
-// backward needs (there a lane walks queries, not keys).
+// Dropout on the attention probabilities (train mode): keep(i, j) = 16-bit half (j & 1) of hash32(rowkey(i) + (j >> 1) * 0x9E3779B9)
+// >= floor(p * 2^16), rowkey(i) = high word of splitmix64(key(seed, stream) + (global region row of query i) * nhead + head);
+// restated on the host in advmil_amd/synth.py::attn_dropout_keep. A per-row 64-bit mix + one 32-bit finaliser per key PAIR costs
+// ~5 VALU per probability where a lane walks keys (forward, dQ) -- a splitmix64 per element would cost ~4x the MFMA time of the
+// tile -- and is layout independent, which the key-stationary backward needs (there a lane walks queries and hashes per element).
+// The drop probability is thereby quantised to 1/65536 (0.25 is exact).
 #include "common.h"
 #include "bf16split.h"
 #include "../../include/advmil_hip.h"
@@ -54,19 +55,23 @@ struct AttnArgs {
   int nseg, ntile, H;
   float scale_log2e;  // log2(e) / sqrt(head_dim)
   float scale;        // 1 / sqrt(head_dim)
-  uint32_t drop_thr;  // p * 2^32
+  uint32_t drop_thr;  // floor(p * 2^16)
   float inv_keep;     // 1 / (1 - p)
   const uint64_t* seed;
   uint64_t stream_id;
 };
 
 __device__ __forceinline__ uint32_t attn_row_key(uint64_t key, uint64_t row_id) { return (uint32_t)(splitmix64(key + row_id) >> 32); }
-__device__ __forceinline__ bool attn_keep(uint32_t rk, uint32_t j, uint32_t thr) {
-  uint32_t x = rk + j * 0x9E3779B9u;
+// one 32-bit hash serves the key PAIR (2m, 2m+1): 16 bits each, compared with floor(p * 2^16)
+__device__ __forceinline__ uint32_t attn_hash(uint32_t rk, uint32_t jpair) {
+  uint32_t x = rk + jpair * 0x9E3779B9u;
   x ^= x >> 16; x *= 0x7feb352du;
   x ^= x >> 15; x *= 0x846ca68bu;
   x ^= x >> 16;
-  return x >= thr;
+  return x;
+}
+__device__ __forceinline__ bool attn_keep(uint32_t rk, uint32_t j, uint32_t thr) {
+  return ((attn_hash(rk, j >> 1) >> ((j & 1u) * 16u)) & 0xffffu) >= thr;
 }
 
 // ---- staging: [64 rows][HD] fp32 from global -> registers -> two bf16 planes in LDS
@@ -224,23 +229,40 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float alpha = hw_exp2(m_run - mx);
-    m_run = mx;
+    // rescale the running state only when some query of this wave saw a new maximum (after the first tiles it rarely moves)
+    const bool moved = __any(mx != m_run);
+    float alpha = 1.f;
+    if (moved) {
+      alpha = hw_exp2(m_run - mx);
+      m_run = mx;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
     float psum = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float p = hw_exp2(s[t][r] - mx);
+        const float p = hw_exp2(s[t][r] - mx);
         psum += p;
-        if (DROP && !attn_keep(rk, (uint32_t)(kb + 32 * t + ACC_ROW(r, half)), a.drop_thr)) p = 0.f;
         s[t][r] = p;
       }
+    if (DROP) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {       // 4 consecutive keys per register group = 2 hashes
+          const uint32_t jp = (uint32_t)(kb + 32 * t + 8 * rg + 4 * half) >> 1;
+          const uint32_t h0 = attn_hash(rk, jp), h1 = attn_hash(rk, jp + 1);
+          if ((h0 & 0xffffu) < a.drop_thr) s[t][4 * rg] = 0.f;
+          if ((h0 >> 16) < a.drop_thr) s[t][4 * rg + 1] = 0.f;
+          if ((h1 & 0xffffu) < a.drop_thr) s[t][4 * rg + 2] = 0.f;
+          if ((h1 >> 16) < a.drop_thr) s[t][4 * rg + 3] = 0.f;
+        }
+    }
     l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
     // ---- O^T[d, q] += V^T[d, key] . P^T[key, q]
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -347,6 +369,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
       }
     }
     const bool tail = kb + AT_KT > Lg;
+    if (DROP) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const uint32_t jp = (uint32_t)(kb + 32 * t + 8 * rg + 4 * half) >> 1;
+          const uint32_t h0 = attn_hash(rk, jp), h1 = attn_hash(rk, jp + 1);
+          if ((h0 & 0xffffu) < a.drop_thr) dp[t][4 * rg] = 0.f;
+          if ((h0 >> 16) < a.drop_thr) dp[t][4 * rg + 1] = 0.f;
+          if ((h1 & 0xffffu) < a.drop_thr) dp[t][4 * rg + 2] = 0.f;
+          if ((h1 >> 16) < a.drop_thr) dp[t][4 * rg + 3] = 0.f;
+        }
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -354,9 +389,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         const int64_t key = kb + 32 * t + ACC_ROW(r, half);
         float p = hw_exp2(s[t][r] - lse_q);
         if (tail && key >= Lg) p = 0.f;
-        float g_ = dp[t][r] * ik;
-        if (DROP && !attn_keep(rk, (uint32_t)key, a.drop_thr)) g_ = 0.f;
-        s[t][r] = p * (g_ - d_q);                            // dS^T
+        s[t][r] = p * (dp[t][r] * ik - d_q);                 // dS^T
       }
     // dQ^T[d, q] += K^T[d, key] . dS^T[key, q]
 #pragma unroll
@@ -563,8 +596,7 @@ static int attn_args(AttnArgs& a, const float* qkv, int64_t Ltot, int nhead, int
   const bool drop = seed && drop_p > 0.f;
   a.seed = drop ? seed : nullptr;
   a.stream_id = stream_id;
-  double thr = (double)drop_p * 4294967296.0;
-  a.drop_thr = drop ? (thr >= 4294967295.0 ? 0xffffffffu : (uint32_t)thr) : 0u;
+  a.drop_thr = drop ? (uint32_t)((double)drop_p * 65536.0) : 0u;
   a.inv_keep = drop ? 1.0f / (1.0f - drop_p) : 1.0f;
   return ADVMIL_OK;
 }

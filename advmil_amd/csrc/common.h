@@ -44,29 +44,29 @@ __device__ __forceinline__ float rng_keep(uint64_t key, uint64_t idx, float p, f
 // padding is explicit: the op and two wait states travel together in one asm statement.
 __device__ __forceinline__ float hw_exp2(float x) {
   float r;
-  asm volatile("v_exp_f32 %0, %1\n\ts_nop 1" : "=v"(r) : "v"(x));
+  asm("v_exp_f32 %0, %1\n\ts_nop 1" : "=v"(r) : "v"(x));
   return r;
 }
 __device__ __forceinline__ float hw_rcp(float x) {
   float r;
-  asm volatile("v_rcp_f32 %0, %1\n\ts_nop 1" : "=v"(r) : "v"(x));
+  asm("v_rcp_f32 %0, %1\n\ts_nop 1" : "=v"(r) : "v"(x));
   return r;
 }
 __device__ __forceinline__ float hw_exp(float x) { return hw_exp2(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float hw_log2(float x) {
   float r;
-  asm volatile("v_log_f32 %0, %1\n\ts_nop 1" : "=v"(r) : "v"(x));
+  asm("v_log_f32 %0, %1\n\ts_nop 1" : "=v"(r) : "v"(x));
   return r;
 }
 __device__ __forceinline__ float hw_log(float x) { return hw_log2(x) * 0.693147180559945309f; }
 __device__ __forceinline__ float hw_rsq(float x) {
   float r;
-  asm volatile("v_rsq_f32 %0, %1\n\ts_nop 1" : "=v"(r) : "v"(x));
+  asm("v_rsq_f32 %0, %1\n\ts_nop 1" : "=v"(r) : "v"(x));
   return r;
 }
 __device__ __forceinline__ float hw_sqrt(float x) {
   float r;
-  asm volatile("v_sqrt_f32 %0, %1\n\ts_nop 1" : "=v"(r) : "v"(x));
+  asm("v_sqrt_f32 %0, %1\n\ts_nop 1" : "=v"(r) : "v"(x));
   return r;
 }
 

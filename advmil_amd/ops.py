@@ -171,6 +171,12 @@ class Planes:
 #   * a weight living in a FlatAdam arena: attribute `_advmil_planes` on the parameter, kept current by the Adam kernel and
 #     re-derived when torch writes the parameter (its version counter moves: load_state_dict, copy_).
 USE_PLANES = os.environ.get("ADVMIL_PLANES", "1") != "0"
+# Measured same-box (tools/ab_bench.sh, 16 x 8k ABMIL step): planes for the slab, the weights and the eval-pass h pay (+2.6 %: the
+# embedding FCs and the fused gate score run on the plane-fed kernel); emitting planes of dG to run dh as an NT plane contraction
+# costs 2 % (the extra 403 MB of plane writes outweigh the staging they save) and planes of the memo-replayed (dropped) h are
+# neutral -> both off unless asked for.
+DH_PLANES = os.environ.get("ADVMIL_DH_PLANES", "0") != "0"
+MEMO_PLANES = os.environ.get("ADVMIL_MEMO_PLANES", "0") != "0"
 
 
 def planes_of(x):
@@ -523,7 +529,7 @@ class LinearActFn(torch.autograd.Function):
             y = gemm(x, W2, True, True, M, N, K, bias=b, act0=act, drop_p=p, seed=seed, stream_id=sid, rng_row=rr,
                      a_planes=xpl, b_planes=wpl, c_planes=cpl, splits=1 if cpl is not None else None)
         elif p > 0.0:       # memoized act(x W^T + b) of the eval forward: only this forward's dropout draw is new
-            if emit and get_gemm_mode() == "bf16x3":
+            if emit and MEMO_PLANES and get_gemm_mode() == "bf16x3":
                 cpl = Planes(torch.empty(M, N, dtype=torch.bfloat16, device=x.device), torch.empty(M, N, dtype=torch.bfloat16, device=x.device))
             y, _ = act_dropout_bwd(y0, y0, ACT_NONE, M, N, p, seed, sid, want_bias=False, rng_row=rr, planes=cpl)
         else:
@@ -683,7 +689,7 @@ class GatedAttnPoolFn(torch.autograd.Function):
         # bf16x3: dh = dG Wab runs as an NT contraction of dG's planes (emitted by gate_bwd) with the planes of Wab^T (a 2D x D
         # transpose + split: two tiny launches) through the plane-fed kernel, when the shape qualifies
         gpl = None
-        if need_h and USE_PLANES and get_gemm_mode() == "bf16x3" and gemm_plan_planes(N, D, 2 * D):
+        if need_h and USE_PLANES and DH_PLANES and get_gemm_mode() == "bf16x3" and gemm_plan_planes(N, D, 2 * D):
             gpl = Planes(torch.empty(N, 2 * D, dtype=torch.bfloat16, device=h.device), torch.empty(N, 2 * D, dtype=torch.bfloat16, device=h.device))
         if ctx.arena is not None:
             gWab, gbab, gwc, gbc = ctx.arena

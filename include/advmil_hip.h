@@ -127,7 +127,8 @@ int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, c
  *   Rows are a slab of `nseg` bags, bag b = rows [ptr[b], ptr[b+1]) (device int64; NULL = one bag), max_len = longest bag;
  *   attention never crosses a bag. Any bag length >= 1 (ragged tails are masked). head_dim must be 48 (d_model 384 / 8 heads,
  *   the only shape load_backbone builds: model/backbone.py:30-33).
- * Dropout on the probabilities (train mode; NULL seed or p == 0 = off): keep(i, j) = hash32(rowkey + j*0x9E3779B9) >= p*2^32,
+ * Dropout on the probabilities (train mode; NULL seed or p == 0 = off): keep(i, j) = 16-bit half (j & 1) of
+ *   hash32(rowkey + (j >> 1)*0x9E3779B9) >= floor(p*2^16)  (p quantised to 1/65536; 0.25 is exact),
  *   rowkey = high 32 bits of splitmix64(key(seed, stream_id) + (ptr[b] + rng_rowoff[b] + i)*nhead + h); rng_rowoff (device int64
  *   [nseg], NULL = zeros) lets a rank of a bag-parallel job address the row ids the single-process run would use.
  *   Host restatement: advmil_amd/synth.py::attn_dropout_keep.
