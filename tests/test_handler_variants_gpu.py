@@ -33,8 +33,9 @@ def run_case(kind="abmil", lens=(256, 512, 128, 64), events=None, visible=None, 
             y = H.label(i)
             if events is not None:
                 y[0, 1] = float(events[j])
-            bags_all.append((x, None, y))
-            loader.append((torch.tensor([[i]], dtype=torch.int), [x, torch.zeros(1, 1)], y))
+            ext = H.T(synth.cluster_ids(0, 40 + i, n)) if kind == "cluster" else None      # DeepAttMISL: a cluster id per patch
+            bags_all.append((x, ext, y))
+            loader.append((torch.tensor([[i]], dtype=torch.int), [x, ext if ext is not None else torch.zeros(1, 1)], y))
     nd = [[H.noise_tensor("var_d", i, 192)] for i in range(steps * nb)]
     ng = [[H.noise_tensor("var_g", i, 192)] for i in range(steps * nb)]
     h.noise_hook = lambda ph, i: [(nd if ph == "d" else ng)[i][0].to(DEV)]
@@ -72,6 +73,19 @@ def run_case(kind="abmil", lens=(256, 512, 128, 64), events=None, visible=None, 
 @pytest.mark.parametrize("kind", ["abmil", "patch"])
 def test_ragged_bags_in_one_step(kind):
     run_case(kind=kind, lens=(256, 512, 128, 64, 208, 16))
+
+
+@pytest.mark.parametrize("gemm_mode", ["exact", "bf16x3"])
+def test_cluster_backbone_through_the_adversarial_step(gemm_mode):
+    """DeepAttMISL through _update_disc / _update_gen against the oracle, two optimizer steps, ragged bags (the reference's own
+    handler cannot run this combination on this torch: model/backbone.py:112 raises IndexError on the float cluster ids, so the
+    oracle -- pinned on the backbone's forward by golden G1 -- is the comparison)."""
+    from advmil_amd import ops
+    prev = ops.get_gemm_mode()
+    try:
+        run_case(kind="cluster", lens=(256, 512, 128, 64), gemm_mode=gemm_mode)
+    finally:
+        ops.set_gemm_mode(prev)
 
 
 def test_step_without_event_bags_has_no_real_pairs():

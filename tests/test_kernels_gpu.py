@@ -267,6 +267,10 @@ def test_gemm_bf16x3_eight_wave_tiles(ops, a_kc, b_kc, tile):
             ref = ops.gemm(A, B, a_kc, b_kc, M, N, K, bias=bias, act0=1, tile=22)
             got = ops.gemm(A, B, a_kc, b_kc, M, N, K, bias=bias, act0=1, tile=tile)
             assert torch.equal(got, ref), (M, N, K, float((got - ref).abs().max()))
+            # and independently: float64 on the host (the split-bf16 products drop ~2^-17 relative per product)
+            A64, B64 = A.cpu().double(), B.cpu().double()
+            want = torch.relu((A64 if a_kc else A64.t()) @ (B64.t() if b_kc else B64) + bias.cpu().double())
+            assert relerr(got, want) < 2e-5, (M, N, K, relerr(got, want))
             r2 = ops.gemm(A, B, a_kc, b_kc, M, N, K, splits=3, tile=22)
             g2 = ops.gemm(A, B, a_kc, b_kc, M, N, K, splits=3, tile=tile)
             assert torch.equal(g2, r2)
@@ -296,6 +300,12 @@ def test_gemm_fused_gate_score(ops, mode, tile):
         part = ops.gemm(h, Wi, True, True, N, 2 * D, D, bias=bi, gate_wc=wc, tile=tile)
         got = part.sum(dim=1) + bc
         assert float((got - want).abs().max()) < 2e-5, float((got - want).abs().max())
+        # and independently: float64 on the host
+        h64 = h.cpu().double()
+        a64 = torch.tanh(h64 @ Wa.cpu().double().t() + ba.cpu().double())
+        b64 = torch.sigmoid(h64 @ Wb.cpu().double().t() + bb.cpu().double())
+        want64 = (a64 * b64) @ wc.cpu().double() + bc.cpu().double()
+        assert float((got.cpu().double() - want64).abs().max()) < 2e-5
     finally:
         ops.set_gemm_mode(prev)
 
@@ -311,11 +321,12 @@ def test_fused_gan_losses_match_composed_torch(ops, which):
     real = (torch.randn(nb, device="cuda", generator=g) * 2).requires_grad_(True)
     mask = (torch.rand(nb, device="cuda", generator=g) < 0.5).float()
     n_real, n_fake = 11.0, 32.0           # global denominators differ from the local counts under bag-parallel
-    tr, tf = real_fake_terms(real, fake, which)
-    want = tf.sum() / n_fake + (tr * mask).sum() / n_real
+    # the composed reference runs on the HOST in float64 (same formulas, torch CPU): independent of every device kernel
+    fake_c, real_c = fake.detach().cpu().double().requires_grad_(True), real.detach().cpu().double().requires_grad_(True)
+    tr, tf = real_fake_terms(real_c, fake_c, which)
+    want = tf.sum() / n_fake + (tr * mask.cpu().double()).sum() / n_real
     want.backward()
-    wf, wr = fake.grad.clone(), real.grad.clone()
-    fake.grad = real.grad = None
+    wf, wr = fake_c.grad.float().to("cuda"), real_c.grad.float().to("cuda")
     got, st = ops.gan_d_loss(fake, real, mask, which, n_fake, n_real)
     (got * 1.5).backward()
     assert abs(float(got) - float(want)) < 1e-6 and abs(float(st[1]) - float((real * mask).sum())) < 1e-5
@@ -327,14 +338,14 @@ def test_fused_gan_losses_match_composed_torch(ops, which):
         pred = torch.rand(nb, 1, device="cuda", generator=g).requires_grad_(True)
         ff = torch.randn(nb, device="cuda", generator=g).requires_grad_(True)
         t, e = torch.rand(nb, 1, device="cuda", generator=g), (torch.rand(nb, 1, device="cuda", generator=g) < 0.5).float()
-        terms = recon_terms(pred, t, e, alpha, gamma, norm)
+        pred_c, ff_c = pred.detach().cpu().double().requires_grad_(True), ff.detach().cpu().double().requires_grad_(True)
+        terms = recon_terms(pred_c, t.cpu().double(), e.cpu().double(), alpha, gamma, norm)
         n_vis = 9.0
-        reg = (terms if vis is None else terms * vis).sum() / n_vis
-        gen = -ff.sum() / n_fake
+        reg = (terms if vis is None else terms * vis.cpu().double()).sum() / n_vis
+        gen = -ff_c.sum() / n_fake
         want = reg + 0.004 * gen
         want.backward()
-        wp, wf = pred.grad.clone(), ff.grad.clone()
-        pred.grad = ff.grad = None
+        wp, wf = pred_c.grad.float().to("cuda"), ff_c.grad.float().to("cuda")
         got, st = ops.gan_g_loss(pred, ff, t, e, vis, alpha, gamma, norm, 0.004, n_fake, n_vis)
         got.backward()
         assert abs(float(got) - float(want)) < 1e-6 and abs(float(st[1]) - float(reg)) < 1e-6 and abs(float(st[2]) - float(gen)) < 1e-6
@@ -353,9 +364,10 @@ def test_skinny_linear_fwd_bwd(ops, B, K, N, act):
     y = ops.skinny_linear(x, W, b, act)
     (y * w).sum().backward()
     got = (y.detach().clone(), x.grad.clone(), W.grad.clone(), b.grad.clone())
-    x.grad = W.grad = b.grad = None
-    ref = torch.nn.functional.linear(x, W, b)
+    # reference on the HOST in float64
+    xc, Wc, bc_ = (t.detach().cpu().double().requires_grad_(True) for t in (x, W, b))
+    ref = torch.nn.functional.linear(xc, Wc, bc_)
     ref = torch.relu(ref) if act == "relu" else ref
-    (ref * w).sum().backward()
-    for a, c in zip(got, (ref.detach(), x.grad, W.grad, b.grad)):
-        assert float((a - c).abs().max()) < 1e-5 * (1.0 + float(c.abs().max()))
+    (ref * w.cpu().double()).sum().backward()
+    for a, c in zip(got, (ref.detach(), xc.grad, Wc.grad, bc_.grad)):
+        assert float((a.cpu().double() - c).abs().max()) < 1e-5 * (1.0 + float(c.abs().max()))
