@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Launch ONE GEMM shape N times (for `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, run separately).
-usage: pmc_gemm.py M N K a_kc b_kc [iters]"""
+"""Launch ONE GEMM shape N times (for `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` / SQ passes, run separately).
+usage: pmc_gemm.py M N K a_kc b_kc [iters] [planes]   (planes = 1: operands arrive as bf16 planes -> the plane-fed LDS-DMA kernel)"""
 import os
 import sys
 
@@ -11,13 +11,19 @@ from advmil_amd import ops  # noqa: E402
 
 M, N, K, a_kc, b_kc = (int(v) for v in sys.argv[1:6])
 iters = int(sys.argv[6]) if len(sys.argv) > 6 else 20
+planes = len(sys.argv) > 7 and sys.argv[7] == "1"
 dev = "cuda:0"
 # a pool of distinct operands larger than the 256 MB Infinity Cache so that reads come from HBM
 npool = max(2, int(400e6 // (4 * M * K)) + 1)
 As = [torch.randn((M, K) if a_kc else (K, M), device=dev) for _ in range(npool)]
 B = torch.randn((N, K) if b_kc else (K, N), device=dev)
 out = torch.empty(M, N, device=dev)
+pas = [ops.split_planes(a) for a in As] if planes else None
+pb = ops.split_planes(B) if planes else None
 for i in range(iters):
-    ops.gemm(As[i % npool], B, bool(a_kc), bool(b_kc), M, N, K, out=out)
+    if planes:
+        ops.gemm(As[i % npool], B, bool(a_kc), bool(b_kc), M, N, K, out=out, a_planes=pas[i % npool], b_planes=pb)
+    else:
+        ops.gemm(As[i % npool], B, bool(a_kc), bool(b_kc), M, N, K, out=out)
 torch.cuda.synchronize()
 print("done", M, N, K, ops.gemm_plan(M, N, K))

@@ -98,23 +98,54 @@ if va:
         out["kernels"][k] = ent
     json.dump(out, open(os.path.join(DST, f"{TAG}_pmc_attn.json"), "w"), indent=1)
 
-# ---- dominant contraction: HBM traffic per launch for the tile bench.py names
-launches = {}
+# ---- slab contractions: HBM traffic per launch + instruction mix, generic (on-the-fly split) and plane-fed kernels
+def kname(sym):
+    if sym.startswith("gemm_nt_planes_kernel"):
+        return "gemm_nt_planes_kernel<%s>" % sym[sym.index("<") + 1:sym.index(">")]
+    t = sym[sym.index("<") + 1:sym.index(">")].split(", ")       # A_KC, B_KC, TM, TN, SPLIT, PRE, BKT, WR, WC
+    return "gemm_f32_kernel<%d,%d,%s,%s>" % (t[0] == "true", t[1] == "true", int(t[2]) * (int(t[7]) // 2), int(t[3]) * (int(t[8]) // 2))
+
+
+launches, planes_launches = {}, {}
 for shape in ("131072x768x384", "131072x384x1024"):
-    fe, wr = counter(f"gemm_{shape}_fetch", "FETCH_SIZE"), counter(f"gemm_{shape}_write", "WRITE_SIZE")
-    ks = [k for k in fe if k.startswith("gemm_f32_kernel")]
-    if not ks:
-        continue
-    k = max(ks, key=lambda n: fe[n][0])
     M, N, K = (int(v) for v in shape.split("x"))
-    fetched, written = 2.0 * fe[k][1] * 1024, wr.get(k, (0, 0.0))[1] * 1024
-    tmpl = k[k.index("<") + 1:k.index(">")].split(", ")        # A_KC, B_KC, TM, TN, SPLIT, PRE, BKT, WR, WC
-    name = "gemm_f32_kernel<%d,%d,%s,%s>" % (tmpl[0] == "true", tmpl[1] == "true", int(tmpl[2]) * (int(tmpl[7]) // 2), int(tmpl[3]) * (int(tmpl[8]) // 2))
-    launches[shape] = {"kernel": name, "kernel_symbol": k, "gemm_mode": "bf16x3", "fetch_bytes_per_launch": fetched,
-                       "write_bytes_per_launch": written, "hbm_bytes_per_launch": fetched + written,
-                       "algorithmic_bytes_per_launch": 4.0 * (M * K + N * K + M * N), "dispatches": fe[k][0]}
-if launches:
-    json.dump({"command": "ADVMIL_GEMM_MODE=bf16x3 rocprofv3 --pmc FETCH_SIZE -- python3 tools/pmc_gemm.py M N K 1 1 8 ; separate --pmc WRITE_SIZE pass",
-               "units": "KB counters; FETCH_SIZE x2 (gfx950 correction)", "launches": launches},
+    for prefix, dest in (("gemm", launches), ("gemmpl", planes_launches)):
+        fe = counter(f"{prefix}_{shape}_fetch", "FETCH_SIZE")
+        wr = counter(f"{prefix}_{shape}_write", "WRITE_SIZE")
+        va, mf = counter(f"{prefix}_{shape}_sq", "SQ_INSTS_VALU"), counter(f"{prefix}_{shape}_sq", "SQ_INSTS_MFMA")
+        mb, ld = counter(f"{prefix}_{shape}_sq", "SQ_VALU_MFMA_BUSY_CYCLES"), counter(f"{prefix}_{shape}_sq", "SQ_INSTS_LDS")
+        st = stats_avg(f"{prefix}_{shape}_stats")
+        src = fe or va or {}
+        ks = [k for k in src if k.startswith("gemm_f32_kernel") or k.startswith("gemm_nt_planes_kernel")]
+        if not ks:
+            continue
+        k = max(ks, key=lambda n: src[n][0])
+        ent = {"kernel": kname(k), "kernel_symbol": k, "gemm_mode": "bf16x3", "algorithmic_bytes_per_launch": 4.0 * (M * K + N * K + M * N),
+               "flops_per_launch": 2.0 * M * N * K}
+        if k in fe:
+            ent["fetch_bytes_per_launch"] = 2.0 * fe[k][1] * 1024
+            ent["dispatches"] = fe[k][0]
+        if k in wr:
+            ent["write_bytes_per_launch"] = wr[k][1] * 1024
+        if "fetch_bytes_per_launch" in ent and "write_bytes_per_launch" in ent:
+            ent["hbm_bytes_per_launch"] = ent["fetch_bytes_per_launch"] + ent["write_bytes_per_launch"]
+        if k in va:
+            ent.update(valu_insts=va[k][1], mfma_insts=mf.get(k, (0, 0))[1], lds_insts=ld.get(k, (0, 0))[1],
+                       mfma_busy_cycles=mb.get(k, (0, 0))[1])
+            if ent["mfma_insts"]:
+                ent["valu_per_mfma"] = ent["valu_insts"] / ent["mfma_insts"]
+        if k in st:
+            ent["avg_us"] = st[k][1]
+            ent["tflops"] = ent["flops_per_launch"] / st[k][1] / 1e6
+            ent["frac_of_bf16x3_roof"] = ent["tflops"] / (2500.0 / 3.0)
+            if "mfma_busy_cycles" in ent:
+                ent["mfma_pipe_busy_frac_at_2.4GHz"] = ent["mfma_busy_cycles"] / (st[k][1] * 1e-6 * 2.4e9 * 1024)
+            # operand bytes staged into LDS per CU clock (A and B tiles of every workgroup; what the per-CU load path carries)
+        dest[shape] = ent
+if launches or planes_launches:
+    json.dump({"command": "ADVMIL_GEMM_MODE=bf16x3 rocprofv3 --pmc FETCH_SIZE -- python3 tools/pmc_gemm.py M N K 1 1 8 [1 = operands as planes]; "
+                          "separate --pmc WRITE_SIZE, --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS and "
+                          "--kernel-trace --stats passes (tools/profile_round.sh gemm)",
+               "units": "KB counters; FETCH_SIZE x2 (gfx950 correction)", "launches": launches, "planes_kernel_launches": planes_launches},
               open(os.path.join(DST, f"{TAG}_pmc_gemm.json"), "w"), indent=1)
 print(sorted(os.listdir(DST)))
