@@ -771,6 +771,7 @@ extern "C" int advmil_gemm_f32_plan_planes(int a_kc, int b_kc, int64_t M, int64_
   const char* force = getenv("ADVMIL_NT_PLANES_TN");
   int tnp = (N % 256 == 0) ? 4 : ((N % 192 == 0) ? 3 : 2);      // widest tile that divides N: most flops per staged byte
   if (force && (force[0] == '2' || force[0] == '3' || force[0] == '4') && N % (64 * (force[0] - '0')) == 0) tnp = force[0] - '0';
+  if ((M / 256) * (N / (64 * tnp)) < 384) return ADVMIL_OK;      // one 8-wave workgroup per CU: fewer than ~1.5 waves of them lose to the small tiles
   *tile = 80 + tnp;
   return ADVMIL_OK;
 }

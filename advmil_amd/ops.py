@@ -617,11 +617,14 @@ def linear_act(x, W, b, act="none", p=0.0, rng=None, tag="", emit_planes=False):
     xpl = wpl = None
     if y0 is not None and p <= 0.0 and emit_planes:
         emit_planes = False                   # the memoized tensor is returned as is: its planes (if any) are already attached
-    if y0 is None and x2.shape[0] >= 4096 and get_gemm_mode() == "bf16x3":
+    big = x2.shape[0] >= 4096 and get_gemm_mode() == "bf16x3"
+    if y0 is None and big and gemm_plan_planes(x2.shape[0], W.shape[0], x2.shape[1]):
         xpl, wpl = planes_of(x2), weight_planes(W)
         if wpl is not None:
             wpl = Planes(wpl.hi.reshape(W.shape[0], -1), wpl.lo.reshape(W.shape[0], -1))
-    y = LinearActFn.apply(x2, W, b, _ACT[act], float(p), seed, sid, y0, rr, xpl, wpl, bool(emit_planes) and x2.shape[0] >= 4096)
+    # emit y's planes only when the contraction that reads y (the gate branches: N' = 2N columns over K' = N) will take them
+    emit = bool(emit_planes) and big and bool(gemm_plan_planes(x2.shape[0], 2 * W.shape[0], W.shape[0]))
+    y = LinearActFn.apply(x2, W, b, _ACT[act], float(p), seed, sid, y0, rr, xpl, wpl, emit)
     cpl, LinearActFn.last_planes = LinearActFn.last_planes, None
     if memo is not None and memo.mode == "record" and p <= 0.0 and not torch.is_grad_enabled():
         memo.store[key] = y
@@ -724,7 +727,8 @@ def gated_attn_pool(h, Wa, ba, Wb, bb, wc, bc, p=0.0, rng=None, tag="", seg=None
         seed, rr = rng.seed, rng.row_map(h.shape[0])
     # grad mode is always off INSIDE Function.forward, so "nothing here will be differentiated" is decided out here
     nograd = not torch.is_grad_enabled() or not any(t.requires_grad for t in (h, Wa, ba, Wb, bb, wc, bc))
-    hpl = planes_of(h) if (h.shape[0] >= 4096 and h.is_contiguous() and get_gemm_mode() == "bf16x3") else None
+    hpl = planes_of(h) if (h.shape[0] >= 4096 and h.is_contiguous() and get_gemm_mode() == "bf16x3"
+                           and gemm_plan_planes(h.shape[0], 2 * h.shape[1], h.shape[1])) else None
     pooled, A, s = GatedAttnPoolFn.apply(h, Wa, ba, Wb, bb, wc, bc, float(p), seed, sa, sb, seg, nograd, rr, hpl)
     return (pooled[0] if seg is None else pooled), A, s
 
