@@ -20,6 +20,8 @@ Prints ONE JSON line (rank 0). Extra objects:
   pool_roofline: the attention-pool call against the HBM roof, at the step slab and at one bag.
   sizes        : (1 GPU) the same step at the other sizes north_star names -- ABMIL 1k / 32k patches, ESAT 8k / 32k patches
                  (bags/s, and for ESAT the attention-core roofline) -- plus the exact-fp32 arithmetic mode and one bag per step.
+  train_each_epoch_eager_ragged : (1 GPU) the product loop itself -- MyHandler._train_each_epoch, eager, ragged pinned host bags
+                 through the staging slab (PCIe-inclusive) -- next to the graph-replay `value`.
   cpu_baseline : the oracle (pure PyTorch CPU restatement of the reference schedule, pinned against the
                  reference to <=1e-6) timed on this box's host cores over a bounded sample of the same workload.
 """
@@ -500,6 +502,39 @@ def main():
                 sizes[tag] = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
                 torch.cuda.synchronize()
 
+    # ---- extra (single GPU): the PRODUCT loop -- MyHandler._train_each_epoch, eager launches, RAGGED bags arriving as pinned host
+    # tensors through the staging slab (advmil_amd/ingest.py): PCIe-inclusive, one step plan per batch, no HIP graph (ragged segments
+    # change every step). Reported next to the graph-replay number, never as `value`.
+    epoch_extra = None
+    if world == 1 and rank == 0 and not args.no_extras and args.mode in ("abmil", "patch"):
+        try:
+            from advmil_amd.config import default_cfg
+            from advmil_amd.model import MyHandler
+            if "case" in dir() and case is not None and case.h is not None:
+                case.free()
+            hh = MyHandler(default_cfg(bcb_mode=args.mode, bp_every_batch=args.bags, cuda_id=dev.index, gemm_mode=args.gemm_mode), device=dev)
+            gcpu = torch.Generator().manual_seed(7)
+            nsteps, base = 6, args.patches
+            lens = [int(base * f) // 16 * 16 for f in (0.75, 1.0, 1.25, 0.5, 1.5, 1.0, 0.875, 1.125)]     # ragged: 0.5x .. 1.5x the nominal size
+            hostpool = [torch.randn(1, n, 1024, generator=gcpu).pin_memory() for n in lens]
+            loader = [(torch.tensor([[i]], dtype=torch.int), [hostpool[i % len(hostpool)], torch.zeros(1, 1)],
+                       torch.tensor([[0.3 + 0.01 * (i % 50), float(i % 2)]])) for i in range(args.bags * (nsteps + 2))]
+            hh._train_each_epoch(loader[:2 * args.bags], "train")          # warm-up: allocates the pinned + device slabs
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            hh._train_each_epoch(loader[2 * args.bags:], "train")
+            torch.cuda.synchronize()
+            dte = time.perf_counter() - t1
+            rows = sum(lens[i % len(lens)] for i in range(args.bags * nsteps))
+            epoch_extra = {"value": round(args.bags * nsteps / dte, 2), "unit": "bags/s", "ms_per_step": round(1e3 * dte / nsteps, 3), "steps": nsteps,
+                           "patches_per_bag": "ragged %d..%d (mean %d)" % (min(lens), max(lens), rows // (args.bags * nsteps)),
+                           "h2d_mb_per_step": round(rows * 4096 / nsteps / 1e6, 1),
+                           "path": "MyHandler._train_each_epoch, eager launches, pinned host bags -> SlabStager (copy stream) -> step slab, "
+                                   "one step plan per batch; PCIe-inclusive"}
+            del hh, hostpool, loader
+        except Exception as exc:
+            epoch_extra = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only; at N > 1 the other ranks would idle in the barrier
         cpu = cpu_baseline(args, torch)
@@ -526,6 +561,7 @@ def main():
             "host_submit_ms_per_step": round(1e3 * t_submit / args.steps, 3),
             "roofline": roof, "gemm_roofline": (gemm_roof if roof is not gemm_roof else None), "pool_roofline": pool_roof,
             "cpu_baseline": cpu, "exact_f32_mfma_mode": exact_extra, "bp_every_batch_1": bp1_extra, "sizes": sizes,
+            "train_each_epoch_eager_ragged": epoch_extra,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
