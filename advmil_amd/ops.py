@@ -213,7 +213,9 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
     """C[M,N] = epilogue(alpha * op(A) op(B)); see include/advmil_hip.h::advmil_gemm_f32. a_planes / b_planes: optional
     Planes of A / B; c_planes: Planes to receive the split of the final C (pitch ldc)."""
     _chk(A, "A"); _chk(B, "B")
-    if tile == 0 and a_planes is not None and b_planes is not None and (splits is None or splits == 1):
+    if (tile == 0 and a_planes is not None and b_planes is not None and (splits is None or splits == 1)
+            and not ((a_planes.hi.data_ptr() | a_planes.lo.data_ptr() | b_planes.hi.data_ptr() | b_planes.lo.data_ptr()) & 15)
+            and a_planes.hi.stride(0) % 8 == 0 and b_planes.hi.stride(0) % 8 == 0):
         ptile = gemm_plan_planes(M, N, K, a_kc, b_kc)          # both operands pre-split: the plane-fed LDS-DMA kernel, if the shape fits
         if ptile:
             tile, splits = ptile, 1

@@ -47,11 +47,11 @@ class FlatAdam(torch.optim.Optimizer):
         super().__init__(groups, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.l1_coef = float(l1_coef)
         self.names = [n for n, _ in ordered]
-        # ---- arenas (each tensor 4-float aligned so views stay 16 B aligned for the kernels)
+        # ---- arenas (each tensor 8-element aligned: fp32 views are 32 B aligned, the bf16 operand planes' views 16 B aligned)
         offs, total = [], 0
         for _, p in ordered:
             offs.append(total)
-            total += (p.numel() + 3) // 4 * 4
+            total += (p.numel() + 7) // 8 * 8
         self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)

@@ -117,3 +117,26 @@ def test_attention_every_entry_at_configs3_size(ops):
         (o * go).sum().backward()
         assert float((o.double() - orf).abs().max()) < 1e-5 * float(orf.abs().max())
         assert float((a.grad.double() - r.grad).abs().max()) < 5e-5 * float(r.grad.abs().max())
+
+
+def test_plane_fed_kernel_race_screen(ops):
+    """The LDS-DMA staged NT kernel (global_load_lds into two LDS buffers, one barrier per 32-deep chunk) against the register-staged
+    generic kernel: bit-identical on every element, repeated launches at the slab shapes (a DMA / ds_read ordering slip would show as
+    rare wrong tiles that come and go between runs)."""
+    prev = ops.get_gemm_mode()
+    ops.set_gemm_mode("bf16x3")
+    try:
+        g = torch.Generator(device=DEV).manual_seed(4)
+        for M, N, K in ((131072, 384, 1024), (131072, 768, 384), (131072, 128, 1024), (32768, 1152, 384)):
+            A = torch.randn(M, K, device=DEV, generator=g)
+            B = torch.randn(N, K, device=DEV, generator=g)
+            bias = torch.randn(N, device=DEV, generator=g)
+            ref = ops.gemm(A, B, True, True, M, N, K, bias=bias, act0=1)
+            pa, pb = ops.split_planes(A), ops.split_planes(B)
+            tiles = [t for t in (82, 83, 84) if N % (64 * (t - 80)) == 0]
+            for t in tiles:
+                for _ in range(4):
+                    got = ops.gemm(A, B, True, True, M, N, K, bias=bias, act0=1, a_planes=pa, b_planes=pb, tile=t, splits=1)
+                    assert torch.equal(got, ref), (M, N, K, t, int((got != ref).sum()))
+    finally:
+        ops.set_gemm_mode(prev)
