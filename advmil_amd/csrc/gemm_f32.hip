@@ -547,7 +547,7 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 || TM * TN > 4 ? 1 : 2))
 // Requirements (checked by the host): M % 256 == 0, N % BN == 0, K % 32 == 0, planes 16-byte aligned with ld % 8 == 0, splits == 1.
 // =====================================================================================
 #define GLB_AS __attribute__((address_space(1)))
-template <int TN>
+template <int TN, int NBUF>
 __global__ __launch_bounds__(512, 2) void gemm_nt_planes_kernel(GemmArgs g) {
   constexpr int TM = 2, WR = 4, WC = 2, BKT = 32;
   constexpr int BM_ = 256, BN_ = 64 * TN;
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_planes_kernel(GemmArgs g) {
   constexpr int NPIECE = ROWS_ALL / 16, PPW = NPIECE / 8;   // 16-row pieces per buffer, per wave
   constexpr int BUF_HW = ROWS_ALL * BKT;               // halfwords per buffer
   constexpr int PATCH_FLOATS = WR * WC * 32 * PITCH_KC;
-  constexpr int SMEM_FLOATS = (2 * BUF_HW / 2 > PATCH_FLOATS) ? 2 * BUF_HW / 2 : PATCH_FLOATS;
+  constexpr int SMEM_FLOATS = (NBUF * BUF_HW / 2 > PATCH_FLOATS) ? NBUF * BUF_HW / 2 : PATCH_FLOATS;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
   bf16raw* const lds = reinterpret_cast<bf16raw*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -606,11 +606,27 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_planes_kernel(GemmArgs g) {
 
   const int64_t K = g.K;
   dma(0, 0);
+  if (NBUF == 3 && BKT < K) dma(1, BKT);               // three buffers: two chunks in flight
   int cur = 0;
   for (int64_t k0 = 0; k0 < K; k0 += BKT) {
+    if constexpr (NBUF == 3) {
+      // counted wait: this wave's pieces of chunk k0 have landed, the younger chunk's PPW pieces may still fly across the barrier
+      // (a raw s_barrier: __syncthreads would drain vmcnt to 0 because an LDS-DMA is a pending LDS write)
+      if (k0 + BKT < K) {
+        if constexpr (PPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (PPW == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (k0 + 2 * BKT < K) dma((cur + 2) % 3, k0 + 2 * BKT);
+    } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of chunk k0 have landed
     __syncthreads();                                    // everyone's have; and everyone is done reading buffer cur^1
     if (k0 + BKT < K) dma(cur ^ 1, k0 + BKT);
+    }
     const bf16raw* cA = lds + cur * BUF_HW;
     const bf16raw* cB = cA + 2 * BM_ * BKT;
 #pragma unroll
@@ -629,7 +645,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_planes_kernel(GemmArgs g) {
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
         }
     }
-    cur ^= 1;
+    if (NBUF == 3) cur = cur == 2 ? 0 : cur + 1; else cur ^= 1;
   }
   gemm_epilogue<TM, TN, WR, WC>(g, acc, smem, wave, lane, wr, wc, m0, n0, 0, nt_i);
 }
@@ -872,9 +888,11 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
     g.mtiles = (int)(M / 256);
     g.ntiles = (int)(N / (64 * tnp));
     dim3 pgrid(g.mtiles * g.ntiles);
-    if (tnp == 4) hipLaunchKernelGGL((gemm_nt_planes_kernel<4>), pgrid, dim3(512), 0, stream, g);
-    else if (tnp == 3) hipLaunchKernelGGL((gemm_nt_planes_kernel<3>), pgrid, dim3(512), 0, stream, g);
-    else hipLaunchKernelGGL((gemm_nt_planes_kernel<2>), pgrid, dim3(512), 0, stream, g);
+    static const int nbuf3 = []() { const char* e = getenv("ADVMIL_NT_PLANES_NBUF"); return (e && e[0] == '2') ? 0 : 1; }();
+    if (tnp == 4) hipLaunchKernelGGL((gemm_nt_planes_kernel<4, 2>), pgrid, dim3(512), 0, stream, g);
+    else if (tnp == 3) hipLaunchKernelGGL((gemm_nt_planes_kernel<3, 2>), pgrid, dim3(512), 0, stream, g);
+    else if (nbuf3) hipLaunchKernelGGL((gemm_nt_planes_kernel<2, 3>), pgrid, dim3(512), 0, stream, g);    // 3 x 48 KB: two chunks in flight
+    else hipLaunchKernelGGL((gemm_nt_planes_kernel<2, 2>), pgrid, dim3(512), 0, stream, g);
     ADVMIL_LAUNCH_CHECK();
     return ADVMIL_OK;
   }
