@@ -271,7 +271,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[T
   float inv_keep = 1.0f;
   if (direct && e.seed && e.drop_p > 0.0f) {
     key = rng_key(*e.seed, e.stream_id);
-    inv_keep = 1.0f / (1.0f - e.drop_p);
+    inv_keep = hw_rcp(1.0f - e.drop_p);
   }
   float* const out = direct ? g.C : g.ws + (int64_t)z * g.M * g.N;
   const int64_t ldo = direct ? g.ldc : g.N;
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g) {
   float inv_keep = 1.0f;
   if (e.seed && e.drop_p > 0.0f) {
     key = rng_key(*e.seed, e.stream_id);
-    inv_keep = 1.0f / (1.0f - e.drop_p);
+    inv_keep = hw_rcp(1.0f - e.drop_p);
   }
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t m = idx / n4, n = (idx % n4) * 4;

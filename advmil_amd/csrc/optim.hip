@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restr
                                                             const uint64_t* seed, uint64_t stream_id,
                                                             const int64_t* __restrict__ rng_row, int64_t width) {
   const uint64_t key = rng_key(*seed, stream_id);
-  const float inv = 1.0f / (1.0f - p);
+  const float inv = hw_rcp(1.0f - p);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     y[i] = x[i] * rng_keep(key, rng_flat_index(i, rng_row, width), p, inv);
 }

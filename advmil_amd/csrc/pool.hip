@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void gate_score_kernel(const float* __restrict
   float inv = 1.f;
   if (drop) {
     const uint64_t sd = *seed;
-    ka = rng_key(sd, stream_a); kb = rng_key(sd, stream_b); inv = 1.f / (1.f - p);
+    ka = rng_key(sd, stream_a); kb = rng_key(sd, stream_b); inv = hw_rcp(1.f - p);
   }
   // one wave per row, grid-stride over rows; 16-byte loads (D % 4 == 0 on this path), wc kept in registers across rows
   const int64_t D4 = D >> 2;
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
   float inv = 1.f;
   if (drop) {
     const uint64_t sd = *seed;
-    ka = rng_key(sd, stream_a); kb = rng_key(sd, stream_b); inv = 1.f / (1.f - p);
+    ka = rng_key(sd, stream_a); kb = rng_key(sd, stream_b); inv = hw_rcp(1.f - p);
   }
   const int64_t r0 = (int64_t)blockIdx.x * rpb;
   float4 s_wc = make_float4(0.f, 0.f, 0.f, 0.f), s_a = s_wc, s_b = s_wc;
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(256) void act_dropout_bwd_kernel(const float* __res
   const bool drop = seed && p > 0.f;
   uint64_t key = 0;
   float inv = 1.f;
-  if (drop) { key = rng_key(*seed, stream_id); inv = 1.f / (1.f - p); }
+  if (drop) { key = rng_key(*seed, stream_id); inv = hw_rcp(1.f - p); }
   const float keep_scale = 1.f - p;
   const int64_t r0 = (int64_t)blockIdx.x * rpb;
   float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256) void ln_relu_mean16_fwd_kernel(const float* __
     const bool ok = q < Q && j < d;
     gm[q] = ok ? gamma[j] : 0.f; bt[q] = ok ? beta[j] : 0.f; acc[q] = 0.f;
   }
-  const float invd = 1.f / (float)d;
+  const float invd = hw_rcp((float)d);
   for (int rr = 0; rr < 4; ++rr) {
     const int64_t n = g * 16 + w * 4 + rr;
     if (n >= N) break;
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(256) void ln_relu_mean16_bwd_kernel(const float* __
     de[q] = (ok && pool16) ? demb[g * d + j] * (1.f / 16.f) : 0.f;
     ag[q] = 0.f; abt[q] = 0.f;
   }
-  const float invd = 1.f / (float)d;
+  const float invd = hw_rcp((float)d);
   for (int rr = 0; rr < 4; ++rr) {
     const int64_t n = g * 16 + w * 4 + rr;
     if (n >= N) break;
@@ -823,8 +823,8 @@ __global__ __launch_bounds__(256) void add_dropout_ln_fwd_kernel(const float* __
   const bool drop = seed && p > 0.f;
   uint64_t key = 0;
   float ik = 1.f;
-  if (drop) { key = rng_key(*seed, stream_id); ik = 1.f / (1.f - p); }
-  const float invd = 1.f / (float)d;
+  if (drop) { key = rng_key(*seed, stream_id); ik = hw_rcp(1.f - p); }
+  const float invd = hw_rcp((float)d);
   for (int rr = 0; rr < 4; ++rr) {
     const int64_t n = (int64_t)blockIdx.x * 16 + w * 4 + rr;
     if (n >= R) break;
@@ -875,7 +875,7 @@ __global__ __launch_bounds__(256) void add_dropout_ln_bwd_kernel(const float* __
   const bool drop = seed && p > 0.f;
   uint64_t key = 0;
   float ik = 1.f;
-  if (drop) { key = rng_key(*seed, stream_id); ik = 1.f / (1.f - p); }
+  if (drop) { key = rng_key(*seed, stream_id); ik = hw_rcp(1.f - p); }
   float gm[LN_MAXQ], ag[LN_MAXQ], abt[LN_MAXQ];
 #pragma unroll
   for (int q = 0; q < LN_MAXQ; ++q) {
@@ -883,7 +883,7 @@ __global__ __launch_bounds__(256) void add_dropout_ln_bwd_kernel(const float* __
     gm[q] = (q < Q && j < d) ? gamma[j] : 0.f;
     ag[q] = 0.f; abt[q] = 0.f;
   }
-  const float invd = 1.f / (float)d;
+  const float invd = hw_rcp((float)d);
   for (int rr = 0; rr < 4; ++rr) {
     const int64_t n = g * 16 + w * 4 + rr;
     if (n >= R) break;

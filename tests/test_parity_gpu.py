@@ -235,7 +235,9 @@ def test_train_mode_dropout_parity_vs_oracle(kind):
             if want is None:
                 continue
             scale = float(want.abs().max()) + 1e-12
-            assert float((p.grad.cpu() - want).abs().max()) <= 2e-4 * scale + 1e-7, (kind, k)
+            # (absolute floor: parameters whose true gradient is 0 -- the pooling scorer's output bias under the softmax -- hold
+            # only round-off, ~1e-7 on both sides)
+            assert float((p.grad.cpu() - want).abs().max()) <= 2e-4 * scale + 5e-7, (kind, k)
 
 
 def test_config1_smoke_32_bags_of_512_default_dropout():
