@@ -615,7 +615,17 @@ extern "C" int advmil_colsum(const float* x, int64_t M, int64_t N, float* out, i
 // wave w owns rows 4w..4w+3, lane owns columns lane, lane+64, ... (d <= 512).
 // =====================================================================================
 #define LN_MAXQ 8
+// the region-embedding kernels are instantiated for the widths of the path (128: discriminator / PatchGCN, 256: GENConv MLP, 384:
+// generator) so that a lane carries exactly d/64 columns; any other d <= 512 takes the 8-group instantiation
+#define LN_DISPATCH(d, kernel, grid, stream, ...)                                                         \
+  do {                                                                                                    \
+    if ((d) <= 128) hipLaunchKernelGGL((kernel<2>), grid, dim3(256), 0, stream, __VA_ARGS__);             \
+    else if ((d) <= 256) hipLaunchKernelGGL((kernel<4>), grid, dim3(256), 0, stream, __VA_ARGS__);        \
+    else if ((d) <= 384) hipLaunchKernelGGL((kernel<6>), grid, dim3(256), 0, stream, __VA_ARGS__);        \
+    else hipLaunchKernelGGL((kernel<8>), grid, dim3(256), 0, stream, __VA_ARGS__);                        \
+  } while (0)
 
+template <int QT>
 __global__ __launch_bounds__(256) void ln_relu_mean16_fwd_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, float eps, int64_t N,
                                                                  int64_t d, float* __restrict__ emb,
@@ -624,10 +634,10 @@ __global__ __launch_bounds__(256) void ln_relu_mean16_fwd_kernel(const float* __
   __shared__ float red[4 * 512];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t g = blockIdx.x;
-  const int Q = (int)((d + 63) / 64);
-  float gm[LN_MAXQ], bt[LN_MAXQ], acc[LN_MAXQ];
+  constexpr int Q = QT;      // 64-column groups per row (d <= 64 * QT)
+  float gm[QT], bt[QT], acc[QT];
 #pragma unroll
-  for (int q = 0; q < LN_MAXQ; ++q) {
+  for (int q = 0; q < QT; ++q) {
     const int64_t j = lane + 64 * q;
     const bool ok = q < Q && j < d;
     gm[q] = ok ? gamma[j] : 0.f; bt[q] = ok ? beta[j] : 0.f; acc[q] = 0.f;
@@ -637,10 +647,10 @@ __global__ __launch_bounds__(256) void ln_relu_mean16_fwd_kernel(const float* __
     const int64_t n = g * 16 + w * 4 + rr;
     if (n >= N) break;
     const float* row = y + n * d;
-    float v[LN_MAXQ];
+    float v[QT];
     float s = 0.f;
 #pragma unroll
-    for (int q = 0; q < LN_MAXQ; ++q) {
+    for (int q = 0; q < QT; ++q) {
       const int64_t j = lane + 64 * q;
       v[q] = (q < Q && j < d) ? row[j] : 0.f;
       s += v[q];
@@ -648,7 +658,7 @@ __global__ __launch_bounds__(256) void ln_relu_mean16_fwd_kernel(const float* __
     const float mu = wave_sum(s) * invd;
     float s2 = 0.f;
 #pragma unroll
-    for (int q = 0; q < LN_MAXQ; ++q) {
+    for (int q = 0; q < QT; ++q) {
       const int64_t j = lane + 64 * q;
       const float c = (q < Q && j < d) ? v[q] - mu : 0.f;
       s2 += c * c;
@@ -656,7 +666,7 @@ __global__ __launch_bounds__(256) void ln_relu_mean16_fwd_kernel(const float* __
     const float rs = hw_rsq(wave_sum(s2) * invd + eps);
     if (lane == 0) { mean[n] = mu; rstd[n] = rs; }
 #pragma unroll
-    for (int q = 0; q < LN_MAXQ; ++q) {
+    for (int q = 0; q < QT; ++q) {
       const float z = (v[q] - mu) * rs * gm[q] + bt[q];
       const float zr = z > 0.f ? z : 0.f;
       acc[q] += zr;
@@ -666,7 +676,7 @@ __global__ __launch_bounds__(256) void ln_relu_mean16_fwd_kernel(const float* __
   }
   if (!pool16) return;
 #pragma unroll
-  for (int q = 0; q < LN_MAXQ; ++q) {
+  for (int q = 0; q < QT; ++q) {
     const int64_t j = lane + 64 * q;
     if (q < Q && j < d) red[w * 512 + j] = acc[q];
   }
@@ -678,8 +688,7 @@ __global__ __launch_bounds__(256) void ln_relu_mean16_fwd_kernel(const float* __
 extern "C" int advmil_ln_relu_mean16_fwd(const float* y, const float* gamma, const float* beta, float eps, int64_t N,
                                          int64_t d, float* emb, float* mean, float* rstd, advmil_stream_t stream) {
   if (!y || !gamma || !beta || !emb || !mean || !rstd || N <= 0 || (N & 15) || d <= 0 || d > 512) return ADVMIL_EINVAL;
-  hipLaunchKernelGGL(ln_relu_mean16_fwd_kernel, dim3((unsigned)(N / 16)), dim3(256), 0, (hipStream_t)stream, y, gamma, beta,
-                     eps, N, d, emb, mean, rstd, 1);
+  LN_DISPATCH(d, ln_relu_mean16_fwd_kernel, dim3((unsigned)(N / 16)), (hipStream_t)stream, y, gamma, beta, eps, N, d, emb, mean, rstd, 1);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }
@@ -687,12 +696,12 @@ extern "C" int advmil_ln_relu_mean16_fwd(const float* y, const float* gamma, con
 extern "C" int advmil_ln_relu_fwd(const float* y, const float* gamma, const float* beta, float eps, int64_t N, int64_t d,
                                   float* out, float* mean, float* rstd, advmil_stream_t stream) {
   if (!y || !gamma || !beta || !out || !mean || !rstd || N <= 0 || d <= 0 || d > 512) return ADVMIL_EINVAL;
-  hipLaunchKernelGGL(ln_relu_mean16_fwd_kernel, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, (hipStream_t)stream, y, gamma,
-                     beta, eps, N, d, out, mean, rstd, 0);
+  LN_DISPATCH(d, ln_relu_mean16_fwd_kernel, dim3((unsigned)((N + 15) / 16)), (hipStream_t)stream, y, gamma, beta, eps, N, d, out, mean, rstd, 0);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }
 
+template <int QT>
 __global__ __launch_bounds__(256) void ln_relu_mean16_bwd_kernel(const float* __restrict__ demb, const float* __restrict__ y,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -700,18 +709,27 @@ __global__ __launch_bounds__(256) void ln_relu_mean16_bwd_kernel(const float* __
                                                                  float* __restrict__ partial, int pool16) {
   __shared__ float red[4 * 1024];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t g = blockIdx.x;
-  const int Q = (int)((d + 63) / 64);
-  float gm[LN_MAXQ], bt[LN_MAXQ], de[LN_MAXQ], ag[LN_MAXQ], abt[LN_MAXQ];
+  constexpr int Q = QT;      // 64-column groups per row (d <= 64 * QT)
+  float gm[QT], bt[QT], de[QT], ag[QT], abt[QT];
 #pragma unroll
-  for (int q = 0; q < LN_MAXQ; ++q) {
+  for (int q = 0; q < QT; ++q) {
     const int64_t j = lane + 64 * q;
     const bool ok = q < Q && j < d;
     gm[q] = ok ? gamma[j] : 0.f; bt[q] = ok ? beta[j] : 0.f;
-    de[q] = (ok && pool16) ? demb[g * d + j] * (1.f / 16.f) : 0.f;
-    ag[q] = 0.f; abt[q] = 0.f;
+    de[q] = 0.f; ag[q] = 0.f; abt[q] = 0.f;
   }
   const float invd = hw_rcp((float)d);
+  const int64_t nreg = (N + 15) / 16;
+  // a workgroup walks the 16-row regions blockIdx.x, + gridDim.x, ... and leaves ONE row of gamma / beta partials: the merge then
+  // reads <= 2048 rows whatever the slab size (a 32768-patch step slab used to leave 32768 of them)
+  for (int64_t g = blockIdx.x; g < nreg; g += gridDim.x) {
+  if (pool16) {
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+      const int64_t j = lane + 64 * q;
+      de[q] = (q < Q && j < d) ? demb[g * d + j] * (1.f / 16.f) : 0.f;
+    }
+  }
   for (int rr = 0; rr < 4; ++rr) {
     const int64_t n = g * 16 + w * 4 + rr;
     if (n >= N) break;
@@ -719,15 +737,15 @@ __global__ __launch_bounds__(256) void ln_relu_mean16_bwd_kernel(const float* __
     const float mu = mean[n], rs = rstd[n];
     if (!pool16) {
 #pragma unroll
-      for (int q = 0; q < LN_MAXQ; ++q) {
+      for (int q = 0; q < QT; ++q) {
         const int64_t j = lane + 64 * q;
         de[q] = (q < Q && j < d) ? demb[n * d + j] : 0.f;
       }
     }
-    float xh[LN_MAXQ], dxh[LN_MAXQ];
+    float xh[QT], dxh[QT];
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-    for (int q = 0; q < LN_MAXQ; ++q) {
+    for (int q = 0; q < QT; ++q) {
       const int64_t j = lane + 64 * q;
       const bool ok = q < Q && j < d;
       xh[q] = ok ? (row[j] - mu) * rs : 0.f;
@@ -742,25 +760,30 @@ __global__ __launch_bounds__(256) void ln_relu_mean16_bwd_kernel(const float* __
     c1 = wave_sum(c1) * invd;
     c2 = wave_sum(c2) * invd;
 #pragma unroll
-    for (int q = 0; q < LN_MAXQ; ++q) {
+    for (int q = 0; q < QT; ++q) {
       const int64_t j = lane + 64 * q;
       if (q < Q && j < d) dy[n * d + j] = rs * (dxh[q] - c1 - xh[q] * c2);
     }
   }
+  }
 #pragma unroll
-  for (int q = 0; q < LN_MAXQ; ++q) {
+  for (int q = 0; q < QT; ++q) {
     const int64_t j = lane + 64 * q;
     if (q < Q && j < d) { red[w * 1024 + j] = ag[q]; red[w * 1024 + 512 + j] = abt[q]; }
   }
   __syncthreads();
+  const int64_t gp = blockIdx.x;
   for (int64_t j = threadIdx.x; j < d; j += 256) {
-    partial[g * 2 * d + j] = red[j] + red[1024 + j] + red[2048 + j] + red[3072 + j];
-    partial[g * 2 * d + d + j] = red[512 + j] + red[1536 + j] + red[2560 + j] + red[3584 + j];
+    partial[gp * 2 * d + j] = red[j] + red[1024 + j] + red[2048 + j] + red[3072 + j];
+    partial[gp * 2 * d + d + j] = red[512 + j] + red[1536 + j] + red[2560 + j] + red[3584 + j];
   }
 }
 
+#define LN_BWD_MAXBLK 2048
+static inline int ln_bwd_blocks(int64_t nreg) { return (int)(nreg < LN_BWD_MAXBLK ? nreg : LN_BWD_MAXBLK); }
+
 extern "C" size_t advmil_ln_relu_mean16_bwd_workspace_bytes(int64_t N, int64_t d) {
-  return (size_t)((N / 16) * 2 * d) * sizeof(float);
+  return (size_t)(ln_bwd_blocks(N / 16) * 2 * d) * sizeof(float);
 }
 
 extern "C" int advmil_ln_relu_mean16_bwd(const float* demb, const float* y, const float* gamma, const float* beta,
@@ -772,10 +795,9 @@ extern "C" int advmil_ln_relu_mean16_bwd(const float* demb, const float* y, cons
       d > 512)
     return ADVMIL_EINVAL;
   if (ws_bytes < advmil_ln_relu_mean16_bwd_workspace_bytes(N, d)) return ADVMIL_EWORKSPACE;
-  const int L = (int)(N / 16);
+  const int L = ln_bwd_blocks(N / 16);
   float* partial = (float*)ws;
-  hipLaunchKernelGGL(ln_relu_mean16_bwd_kernel, dim3(L), dim3(256), 0, stream, demb, y, gamma, beta, mean, rstd, N, d, dy,
-                     partial, 1);
+  LN_DISPATCH(d, ln_relu_mean16_bwd_kernel, dim3(L), stream, demb, y, gamma, beta, mean, rstd, N, d, dy, partial, 1);
   ADVMIL_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial, L, 2 * d, d, dgamma, accumulate);
   hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial + d, L, 2 * d, d, dbeta, accumulate);
@@ -784,7 +806,7 @@ extern "C" int advmil_ln_relu_mean16_bwd(const float* demb, const float* y, cons
 }
 
 extern "C" size_t advmil_ln_relu_bwd_workspace_bytes(int64_t N, int64_t d) {
-  return (size_t)(((N + 15) / 16) * 2 * d) * sizeof(float);
+  return (size_t)(ln_bwd_blocks((N + 15) / 16) * 2 * d) * sizeof(float);
 }
 
 extern "C" int advmil_ln_relu_bwd(const float* dout, const float* y, const float* gamma, const float* beta, const float* mean,
@@ -794,10 +816,9 @@ extern "C" int advmil_ln_relu_bwd(const float* dout, const float* y, const float
   if (!dout || !y || !gamma || !beta || !mean || !rstd || !dy || !dgamma || !dbeta || !ws || N <= 0 || d <= 0 || d > 512)
     return ADVMIL_EINVAL;
   if (ws_bytes < advmil_ln_relu_bwd_workspace_bytes(N, d)) return ADVMIL_EWORKSPACE;
-  const int L = (int)((N + 15) / 16);
+  const int L = ln_bwd_blocks((N + 15) / 16);
   float* partial = (float*)ws;
-  hipLaunchKernelGGL(ln_relu_mean16_bwd_kernel, dim3(L), dim3(256), 0, stream, dout, y, gamma, beta, mean, rstd, N, d, dy,
-                     partial, 0);
+  LN_DISPATCH(d, ln_relu_mean16_bwd_kernel, dim3(L), stream, dout, y, gamma, beta, mean, rstd, N, d, dy, partial, 0);
   ADVMIL_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial, L, 2 * d, d, dgamma, accumulate);
   hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial + d, L, 2 * d, d, dbeta, accumulate);
