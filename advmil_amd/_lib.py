@@ -8,7 +8,8 @@ import ctypes
 import os
 from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libadvmil_hip.so")
+# ADVMIL_HIP_LIB: load another build of the same library (kernel A/B probes under tools/probe); there is still no fallback
+LIB_PATH = os.environ.get("ADVMIL_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libadvmil_hip.so")
 
 
 class HipLibraryMissing(RuntimeError):

@@ -261,6 +261,137 @@ struct OperandStage {
 // ---- epilogue (shared by the contraction kernels). MFMA C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5). Each 32x32
 // accumulator tile goes through a per-wave LDS patch ([32][36] floats, carved from the operand buffers) so that the math below runs
 // once per float4 in a compact loop and the global stores are 16 B per lane along the row.
+// Per-wave LDS area of the epilogue: the [32][36] accumulator patch + the streaming form's column / row side data.
+#define EPI_WAVE_FLOATS(TM, TN) (32 * PITCH_KC + 32 * ((TN) + 2 * (TM)))
+
+// Streaming form of the epilogue for launches that cover M and N with whole tiles (M % tile height == 0, N % tile width == 0, one
+// activation per 32 columns, 16-byte aligned operands, at most one of the rank-1 / mask / accumulate modes).
+// vmcnt counts loads AND stores in issue order on gfx950, so a global load whose result is waited for behind a store drains every
+// older store first: with the bias / row vectors fetched inside the tile loop the workgroup had one sub-tile (4 KB per wave) of C
+// in flight at a time and the epilogue alone ran at ~2 TB/s (403 MB of gate activations: 209 us, tools/probe/ablate_gemm.sh
+// noloop). Here the store stream never waits on a load issued behind it:
+//   * the wave's bias slice and its rows' data (dropout stream row, rank-1 row factor, bag index) are fetched once, before the
+//     first store, and parked in the wave's LDS side area: inside the loop they come back through lgkmcnt, not vmcnt;
+//   * the per-element operand of the rank-1 / mask / accumulate mode (one of colv, maskref, C) is fetched one sub-tile ahead, issued
+//     after the current sub-tile's math and before its stores.
+// The plain bias + activation (+ dropout, + planes) modes then have no global load inside the loop at all.
+template <int TM, int TN, int WR, int WC>
+__device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (&acc)[TM][TN], float* patch, int lane, int wr, int wc,
+                                                     int64_t m0, int64_t n0, uint64_t key, float inv_keep) {
+  const advmil_epilogue_t& e = g.epi;
+  const int i = lane & 31, hi = lane >> 5;
+  const int c4 = (lane & 7) * 4, rq = lane >> 3;
+  const int64_t N = g.N, ldo = g.ldc;
+  float* const out = g.C;
+  const bool drop = e.seed && e.drop_p > 0.0f;
+  const bool mapped = drop && e.rng_row;
+  const int kind = e.rowv ? 1 : (e.maskref ? 2 : (e.accumulate ? 3 : 0));     // which per-element operand is fetched one sub-tile ahead
+  const float* const xbase = kind == 1 ? e.colv : (kind == 2 ? e.maskref : out);
+  const int64_t xld = kind == 1 ? N : (kind == 2 ? (int64_t)e.ldmask : ldo);
+  const int64_t rbase = m0 + wr * 32 * TM, cbase = n0 + wc * 32 * TN;
+  // ---- side data -> LDS: sbias[32*TN] | srow_i[32*TM] (bag index, or dropout stream row: never both in one launch) | srow_f[32*TM]
+  float* const sbias = patch + 32 * PITCH_KC;
+  int* const srow_i = reinterpret_cast<int*>(sbias + 32 * TN);
+  float* const srow_f = sbias + 32 * TN + 32 * TM;
+  {
+    float bv[(32 * TN + 63) / 64];
+    int iv[(32 * TM + 63) / 64];
+    float fv[(32 * TM + 63) / 64];
+#pragma unroll
+    for (int u = 0; u < (32 * TN + 63) / 64; ++u) {
+      const int c = u * 64 + lane;
+      bv[u] = (e.bias && c < 32 * TN) ? e.bias[cbase + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < (32 * TM + 63) / 64; ++u) {
+      const int r = u * 64 + lane;
+      const bool ok = r < 32 * TM;
+      iv[u] = !ok ? 0 : (kind == 1 ? (e.rowseg ? e.rowseg[rbase + r] : 0) : (mapped ? (int)e.rng_row[rbase + r] : 0));
+      fv[u] = (ok && kind == 1) ? e.rowv[rbase + r] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < (32 * TN + 63) / 64; ++u)
+      if (u * 64 + lane < 32 * TN) sbias[u * 64 + lane] = bv[u];
+#pragma unroll
+    for (int u = 0; u < (32 * TM + 63) / 64; ++u)
+      if (u * 64 + lane < 32 * TM) { srow_i[u * 64 + lane] = iv[u]; srow_f[u * 64 + lane] = fv[u]; }
+    WAVE_LDS_SYNC();
+  }
+  float4 ext[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) ext[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#define ADVMIL_EPI_PREFETCH(a_, b_)                                                                             \
+  do {                                                                                                          \
+    if (kind != 0) {                                                                                            \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                           \
+        const int rr_ = (a_) * 32 + q * 8 + rq;                                                                 \
+        const int64_t xrow_ = kind == 1 ? (int64_t)srow_i[rr_] : rbase + rr_;                                   \
+        ext[q] = *reinterpret_cast<const float4*>(xbase + xrow_ * xld + cbase + (b_) * 32 + c4);                \
+      }                                                                                                         \
+    }                                                                                                           \
+  } while (0)
+  ADVMIL_EPI_PREFETCH(0, 0);
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int64_t col = cbase + b * 32 + c4;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * PITCH_KC + i] = acc[a][b][r];
+      WAVE_LDS_SYNC();
+      float res[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v4 = *reinterpret_cast<const float4*>(patch + (q * 8 + rq) * PITCH_KC + c4);
+        res[q][0] = v4.x; res[q][1] = v4.y; res[q][2] = v4.z; res[q][3] = v4.w;
+      }
+      const float4 b4 = *reinterpret_cast<const float4*>(sbias + b * 32 + c4);
+      WAVE_LDS_SYNC();   // the reads have landed: the next sub-tile may overwrite the patch
+      const int act = cbase + b * 32 < e.act_split ? e.act0 : e.act1;
+      const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float xe[4] = {ext[q].x, ext[q].y, ext[q].z, ext[q].w};
+        const int64_t srow = mapped ? (int64_t)srow_i[a * 32 + q * 8 + rq] : rbase + a * 32 + q * 8 + rq;
+        const float r1 = kind == 1 ? srow_f[a * 32 + q * 8 + rq] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float x = res[q][t] * e.alpha + bb[t];
+          if (kind == 1) x += r1 * xe[t];
+          x = act_apply(act, x);
+          if (drop) x *= rng_keep(key, (uint64_t)(srow * N + col + t), e.drop_p, inv_keep);
+          if (kind == 2) x *= (xe[t] > 0.0f ? e.mask_scale : 0.0f);
+          if (kind == 3) x += xe[t];
+          res[q][t] = x;
+        }
+      }
+      // next sub-tile's per-element operand: behind this sub-tile's math (the registers are free again), ahead of its stores
+      if (b + 1 < TN) ADVMIL_EPI_PREFETCH(a, b + 1);
+      else if (a + 1 < TM) ADVMIL_EPI_PREFETCH(a + 1, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t off = (rbase + a * 32 + q * 8 + rq) * ldo + col;
+        *reinterpret_cast<float4*>(out + off) = make_float4(res[q][0], res[q][1], res[q][2], res[q][3]);
+      }
+      if (e.c_hi) {      // planes of the final values (off % 4 == 0 here: two 8-byte stores per float4)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t off = (rbase + a * 32 + q * 8 + rq) * ldo + col;
+          union { __bf16 b[4]; uint2 u; } h, l;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            h.b[t] = (__bf16)res[q][t];
+            l.b[t] = (__bf16)(res[q][t] - (float)h.b[t]);
+          }
+          *reinterpret_cast<uint2*>(reinterpret_cast<bf16raw*>(e.c_hi) + off) = h.u;
+          *reinterpret_cast<uint2*>(reinterpret_cast<bf16raw*>(e.c_lo) + off) = l.u;
+        }
+      }
+    }
+  }
+#undef ADVMIL_EPI_PREFETCH
+}
+
 template <int TM, int TN, int WR, int WC>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[TM][TN], float* smem, int wave, int lane, int wr, int wc,
                                               int64_t m0, int64_t n0, int z, int nt_i) {
@@ -276,13 +407,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[T
   float* const out = direct ? g.C : g.ws + (int64_t)z * g.M * g.N;
   const int64_t ldo = direct ? g.ldc : g.N;
   const bool vec_ok = ((ldo & 3) == 0) && (((uintptr_t)out & 15) == 0);
-  float* const patch = smem + wave * (32 * PITCH_KC);
+  float* const patch = smem + wave * EPI_WAVE_FLOATS(TM, TN);
   __syncthreads();   // every wave is done reading the operand tiles
   // Gate-score mode (e.gate_wc): the columns are the interleaved branches of the gated attention scorer, col 2j = a_j (tanh),
   // col 2j+1 = b_j (sigmoid). Instead of storing C, each row's  sum_j tanh(.)_j * sigmoid(.)_j * wc_j  over this workgroup's
   // columns is reduced in registers / across the 8 lanes of a row and written to gate_out[row * gate_np + column-block]: the
   // no-grad generator pass then never writes (and gate_score never re-reads) the [rows, 2D] activations.
   const bool gate_mode = direct && e.gate_wc != nullptr;
+  if constexpr (TM * TN >= 4) {   // the slab-sized tiles (the 64x64 ... 64x192 tiles serve launch-bound shapes: generic path only)
+    const int nmode = (e.rowv ? 1 : 0) + (e.maskref ? 1 : 0) + (e.accumulate ? 1 : 0);
+    const bool stream = direct && !gate_mode && vec_ok && (g.N % (32 * TN * WC)) == 0 && (g.M % (32 * TM * WR)) == 0 && (e.act_split & 31) == 0 &&
+                        nmode <= 1 && !(e.rowv && e.seed && e.rng_row) && (!e.bias || ((uintptr_t)e.bias & 15) == 0) && (!e.rowv || ((uintptr_t)e.colv & 15) == 0) &&
+                        (!e.maskref || ((e.ldmask & 3) == 0 && ((uintptr_t)e.maskref & 15) == 0)) &&
+                        (!e.c_hi || ((((uintptr_t)e.c_hi) | ((uintptr_t)e.c_lo)) & 7) == 0);
+    if (stream) {
+      gemm_epilogue_stream<TM, TN, WR, WC>(g, acc, patch, lane, wr, wc, m0, n0, key, inv_keep);
+      return;
+    }
+  }
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
     float gsum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -392,7 +534,7 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 || TM * TN > 4 ? 1 : 2))
   // The exact variant stays single-buffered: there the doubled LDS footprint costs co-resident workgroups and measured slower.
   constexpr int NBUF = SPLIT ? 2 : 1;
   constexpr int BUF_FLOATS = TILEF_A + TILEF_B;
-  constexpr int PATCH_FLOATS = WR * WC * 32 * PITCH_KC;   // the epilogue's per-wave patches reuse the operand buffers
+  constexpr int PATCH_FLOATS = WR * WC * EPI_WAVE_FLOATS(TM, TN);   // the epilogue's per-wave areas reuse the operand buffers
   __shared__ __attribute__((aligned(16))) float smem[NBUF * BUF_FLOATS > PATCH_FLOATS ? NBUF * BUF_FLOATS : PATCH_FLOATS];
   float* const sA = smem;
   float* const sB = smem + TILEF_A;
@@ -547,14 +689,14 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 || TM * TN > 4 ? 1 : 2))
 // Requirements (checked by the host): M % 256 == 0, N % BN == 0, K % 32 == 0, planes 16-byte aligned with ld % 8 == 0, splits == 1.
 // =====================================================================================
 #define GLB_AS __attribute__((address_space(1)))
-template <int TN, int NBUF>
+template <int TN, int NBUF, bool STAG = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_planes_kernel(GemmArgs g) {
   constexpr int TM = 2, WR = 4, WC = 2, BKT = 32;
   constexpr int BM_ = 256, BN_ = 64 * TN;
   constexpr int ROWS_ALL = 2 * (BM_ + BN_);            // plane rows per buffer: A hi, A lo, B hi, B lo
   constexpr int NPIECE = ROWS_ALL / 16, PPW = NPIECE / 8;   // 16-row pieces per buffer, per wave
   constexpr int BUF_HW = ROWS_ALL * BKT;               // halfwords per buffer
-  constexpr int PATCH_FLOATS = WR * WC * 32 * PITCH_KC;
+  constexpr int PATCH_FLOATS = WR * WC * EPI_WAVE_FLOATS(TM, TN);
   constexpr int SMEM_FLOATS = (NBUF * BUF_HW / 2 > PATCH_FLOATS) ? NBUF * BUF_HW / 2 : PATCH_FLOATS;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
   bf16raw* const lds = reinterpret_cast<bf16raw*>(smem);
@@ -596,6 +738,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_planes_kernel(GemmArgs g) {
     for (int it = 0; it < PPW; ++it)
       __builtin_amdgcn_global_load_lds((const GLB_AS void*)(src[it] + k0), (LDS_AS void*)(lds + buf * BUF_HW + (wave + 8 * it) * 16 * BKT), 16, 0, 0);
   };
+  constexpr int PH = (PPW + 1) / 2;                     // pieces in the first of a wave's two DMA doses
+  auto dma_lo = [&](int buf, int64_t k0) {
+#pragma unroll
+    for (int it = 0; it < PH; ++it)
+      __builtin_amdgcn_global_load_lds((const GLB_AS void*)(src[it] + k0), (LDS_AS void*)(lds + buf * BUF_HW + (wave + 8 * it) * 16 * BKT), 16, 0, 0);
+  };
+  auto dma_hi = [&](int buf, int64_t k0) {
+#pragma unroll
+    for (int it = PH; it < PPW; ++it)
+      __builtin_amdgcn_global_load_lds((const GLB_AS void*)(src[it] + k0), (LDS_AS void*)(lds + buf * BUF_HW + (wave + 8 * it) * 16 * BKT), 16, 0, 0);
+  };
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int a = 0; a < TM; ++a)
@@ -605,6 +758,97 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_planes_kernel(GemmArgs g) {
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
   const int64_t K = g.K;
+  if constexpr (STAG) {
+    // Two wave groups in anti-phase. Waves w and w + 4 share a SIMD; group 1 (waves 4-7) runs one barrier behind group 0, so in
+    // every interval between two consecutive workgroup barriers one group issues its fragment reads (and its share of the next
+    // chunk's LDS-DMA) while the other owns the SIMD's matrix pipe with the 6*TN MFMAs of a 16-deep k step:
+    //   phase (chunk c, half s):  ds_reads(c, s) | barrier A | MFMAs(c, s) | barrier B
+    //   interval I(n) = between barriers n-1 and n:  group 0 reads phase p in I(2p+1), multiplies in I(2p+2); group 1 one later.
+    // Buffer of chunk c: last read retires (lgkmcnt(0) behind barrier A) at the start of I(4c+5), so it may be refilled from
+    // I(4c+6) on, and the chunk that reuses it (c + NBUF) is first read NBUF*4 - 1 intervals later. The LDS-DMA pieces of a wave
+    // go out in two doses at the two earliest legal points (a burst of 8 blocks the issuing wave for ~1000 cycles; 3-4 pieces
+    // behind a barrier, while the wave's own fragment reads are still landing, cost nothing -- tools/probe/mfma_probe.hip):
+    //   group 1: read interval of phase (c+1, 0), then behind barrier A of that phase;
+    //   group 0: behind barrier A of phase (c+1, 0), then in the read interval of phase (c+1, 1).
+    // Chunk c+1 is first read in I(4c+5) (group 0): every wave waits for its own pieces (counted vmcnt: with 3 buffers the younger
+    // chunk stays in flight) before barrier 4c+4 -- group 0 behind the MFMAs of phase (c, 1), group 1 at the end of its reads of
+    // phase (c, 1).
+    const int grp = wave >> 2;
+    const int nchunk = (int)(K / BKT);
+    dma(0, 0);
+    if (NBUF == 3 && nchunk > 1) dma(1, BKT);
+    if (NBUF == 3 && nchunk > 1) {
+      if constexpr (PPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if constexpr (PPW == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    for (int c = 0; c < nchunk; ++c) {
+      const bf16raw* cA = lds + cur * BUF_HW;
+      const bf16raw* cB = cA + 2 * BM_ * BKT;
+      const bool more = c + NBUF - 1 < nchunk;                       // a chunk to prefetch into the buffer chunk c-1 used
+      const int nbuf = cur == 0 ? NBUF - 1 : cur - 1;
+      const int64_t nk0 = (int64_t)(c + NBUF - 1) * BKT;
+#pragma unroll
+      for (int ks = 0; ks < BKT / 16; ++ks) {
+        bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) read_frag_presplit<BM_, BKT>(cA, wr * 32 * TM + a * 32, ks, i, hi, ah[a], al[a]);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) read_frag_presplit<BN_, BKT>(cB, wc * 32 * TN + b * 32, ks, i, hi, bh[b], bl[b]);
+        if (ks == 0 && grp == 1 && more) dma_lo(nbuf, nk0);
+        if (ks == 1 && grp == 0 && more) dma_hi(nbuf, nk0);
+        if (ks == 1 && grp == 1) {                                   // chunk c+1 is read from the next interval on
+          if (NBUF == 3 && c + 2 < nchunk) {
+            if constexpr (PPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if constexpr (PPW == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                                // A
+        asm volatile("" ::: "memory");
+        if (ks == 0 && more) {
+          if (grp == 0) dma_lo(nbuf, nk0);
+          else dma_hi(nbuf, nk0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+          }
+        __builtin_amdgcn_s_setprio(0);
+        if (ks == 1 && grp == 0) {
+          if (NBUF == 3 && c + 2 < nchunk) {
+            if constexpr (PPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if constexpr (PPW == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                                // B
+        asm volatile("" ::: "memory");
+      }
+      cur = cur == NBUF - 1 ? 0 : cur + 1;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    gemm_epilogue<TM, TN, WR, WC>(g, acc, smem, wave, lane, wr, wc, m0, n0, 0, nt_i);
+    return;
+  }
   dma(0, 0);
   if (NBUF == 3 && BKT < K) dma(1, BKT);               // three buffers: two chunks in flight
   int cur = 0;
@@ -889,6 +1133,14 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
     g.ntiles = (int)(N / (64 * tnp));
     dim3 pgrid(g.mtiles * g.ntiles);
     static const int nbuf3 = []() { const char* e = getenv("ADVMIL_NT_PLANES_NBUF"); return (e && e[0] == '2') ? 0 : 1; }();
+    static const int stag = []() { const char* e = getenv("ADVMIL_NT_PLANES_STAG"); return (e && e[0] == '1') ? 1 : 0; }();
+    if (stag) {
+      if (tnp == 4) hipLaunchKernelGGL((gemm_nt_planes_kernel<4, 2, true>), pgrid, dim3(512), 0, stream, g);
+      else if (tnp == 3) hipLaunchKernelGGL((gemm_nt_planes_kernel<3, 2, true>), pgrid, dim3(512), 0, stream, g);
+      else hipLaunchKernelGGL((gemm_nt_planes_kernel<2, 3, true>), pgrid, dim3(512), 0, stream, g);
+      ADVMIL_LAUNCH_CHECK();
+      return ADVMIL_OK;
+    }
     if (tnp == 4) hipLaunchKernelGGL((gemm_nt_planes_kernel<4, 2>), pgrid, dim3(512), 0, stream, g);
     else if (tnp == 3) hipLaunchKernelGGL((gemm_nt_planes_kernel<3, 2>), pgrid, dim3(512), 0, stream, g);
     else if (nbuf3) hipLaunchKernelGGL((gemm_nt_planes_kernel<2, 3>), pgrid, dim3(512), 0, stream, g);    // 3 x 48 KB: two chunks in flight

@@ -18,14 +18,20 @@ DST = os.path.join(ROOT, "profiles")
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
-def first(pattern):
-    f = sorted(glob.glob(os.path.join(SRC, pattern), recursive=True))
-    return f[0] if f else None
+def newest(pattern):
+    """gpurun merges every call's outputs into the same tree, so a run directory can hold CSVs of several calls (one per profiled
+    pid): only the newest one describes the current kernels."""
+    f = sorted(glob.glob(os.path.join(SRC, pattern), recursive=True), key=os.path.getmtime)
+    return f[-1] if f else None
+
+
+first = newest
 
 
 def counter(run, name):
     agg = {}
-    for f in sorted(glob.glob(os.path.join(SRC, run, "**", "*counter_collection.csv"), recursive=True)):
+    f = newest(os.path.join(run, "**", "*counter_collection.csv"))
+    if f:
         for row in csv.DictReader(open(f)):
             if row.get("Counter_Name") != name:
                 continue
