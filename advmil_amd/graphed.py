@@ -6,6 +6,9 @@ with torch.cuda.graph (hipGraph underneath) and replayed. The ctypes launches go
 the hand-written kernels are captured exactly like torch's own. Dropout/noise stay fresh across replays because
 the kernels read the step seed from device memory and the graph itself bumps it.
 
+Single process: ONE graph (optionally with the generator's training forward as a parallel branch: MyHandler.overlap_gfwd, measured
+slower, off by default).
+
 Under bag-parallel (world > 1) the collectives stay OUTSIDE the graphs (four segments: D backward | G backbone forward | D Adam + G
 loss/backward | G Adam), so capture never depends on RCCL's graph support; D's all-reduce is started asynchronously before the
 G-forward segment and waited for after it, so the exchange runs under that segment's kernels.
@@ -17,6 +20,8 @@ class GraphedStep:
     def __init__(self, handler, xs, ys, ys_host, mode="wlabel", label_visible_mask=None, warmup=2, force_segments=False):
         self.force_segments = force_segments
         self.h = handler
+        if handler.dp.world > 1 or force_segments:
+            handler.overlap_gfwd = False     # the segments are separate graphs: a fork event cannot cross from one capture into another
         self.xs, self.ys = xs, ys
         self.plan = handler._plan(xs, ys, mode, label_visible_mask, ys_host)   # python ints: baked into the graph
         self.lrs = self._lrs()

@@ -57,6 +57,14 @@ class MyHandler(object):
         seed_everything(cfg["seed"])
         self.rng = ops.default_rng(self.device)
         self.dp = parallel or BagParallel()
+        # ADVMIL_OVERLAP_GFWD=1: the generator's training forward depends on the generator alone, so from the point where the
+        # discriminator update has its predictions it can run on a second stream (a parallel branch of the step graph), beside the
+        # discriminator's forward / backward / Adam. Python issue order -- hence every dropout site id -- is unchanged and the
+        # results are identical. Measured on the 16 x 8192 step: 3.85 ms against 3.79 ms serial -- the slab kernels of both
+        # branches each want every CU's LDS, so they time-slice and the short launches gain nothing. Off by default.
+        self.overlap_gfwd = os.environ.get("ADVMIL_OVERLAP_GFWD", "0") == "1"
+        self._side_stream = None
+        self._fork_evt = self._join_evt = None
         self.cfg = cfg
         self.bcb = cfg["bcb_mode"]
         self.task = cfg["task"]
@@ -348,6 +356,9 @@ class MyHandler(object):
                 pred = self.netG.finish(self._gen_features(X, plan, xs), noise=self._stack_noise(noise))     # [B,1]
         finally:
             ops.MEMO.end()
+        if self.overlap_gfwd and self.dp.world == 1:      # everything _gen_forward reads exists from here on
+            self._fork_evt = torch.cuda.Event()
+            self._fork_evt.record()
         emb = self.netD.embed_rows(X)                                          # shared by the real and the fake pairs
         f_real = None
         if plan.n_real > 0:                  # GLOBAL count: every rank of a bag-parallel step takes the same branch / draws
@@ -416,20 +427,37 @@ class MyHandler(object):
         self.netD.eval()
         self.netG.train()
         self.rng.rows = plan.rng_rows
-        self.optimizerG.zero_grad()
-        X = self._slab(xs)
-        # row-sized pre-dropout layer outputs of the eval forward in _disc_backward are reused -- only when this call belongs to
-        # the SAME step plan (token) and the generator has not been updated since (n_updates); an unpaired call recomputes
-        ops.MEMO.begin("replay", ("G", id(self.netG), getattr(self.optimizerG, "n_updates", 0), plan.token), X)
-        try:
-            feats = self._gen_features(X, plan, xs)
-        finally:
-            ops.MEMO.end(clear=True)
-        self._g_fwd = (X, self.netG.finish(feats, noise=self._stack_noise(noise)))      # pred [B,1], graph kept
+        fork, self._fork_evt = self._fork_evt, None
+        main = torch.cuda.current_stream()
+        side = main
+        if fork is not None:
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=self.device)
+            side = self._side_stream
+            side.wait_event(fork)
+        with torch.cuda.stream(side):
+            self.optimizerG.zero_grad()
+            X = self._slab(xs)
+            # row-sized pre-dropout layer outputs of the eval forward in _disc_backward are reused -- only when this call belongs
+            # to the SAME step plan (token) and the generator has not been updated since (n_updates); an unpaired call recomputes
+            ops.MEMO.begin("replay", ("G", id(self.netG), getattr(self.optimizerG, "n_updates", 0), plan.token), X)
+            try:
+                feats = self._gen_features(X, plan, xs)
+            finally:
+                ops.MEMO.end(clear=True)
+            pred = self.netG.finish(feats, noise=self._stack_noise(noise))               # pred [B,1], graph kept
+            if side is not main:
+                pred.record_stream(main)
+                self._join_evt = torch.cuda.Event()
+                self._join_evt.record(side)
+        self._g_fwd = (X, pred)
 
     def _gen_finish(self, i_batch, xs, ys, plan):
         """D's score of the predictions (updated D, frozen), the G loss and its ONE backward."""
         X, pred = self.__dict__.pop("_g_fwd")
+        join, self._join_evt = self._join_evt, None
+        if join is not None:
+            torch.cuda.current_stream().wait_event(join)
         with torch.no_grad():                                                  # nothing of D(x) depends on G
             eb, im = self.netD.bag_features_multi(self.netD.embed_rows(X), plan.seg16)
         # The generator loss only needs d f / d pred. The reference lets autograd also fill netD's weight gradients here and

@@ -616,6 +616,8 @@ def linear_act(x, W, b, act="none", p=0.0, rng=None, tag="", emit_planes=False):
     y0 = None
     if memo is not None and memo.mode == "replay":
         y0 = memo.store.pop(key, None)
+        if y0 is not None:
+            y0.record_stream(torch.cuda.current_stream())      # recorded on one stream, replayed (and released) on another
     xpl = wpl = None
     if y0 is not None and p <= 0.0 and emit_planes:
         emit_planes = False                   # the memoized tensor is returned as is: its planes (if any) are already attached

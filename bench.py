@@ -349,9 +349,11 @@ def main():
         if rank == 0:
             ops.KERNEL_PROFILE = []
         case.cursor = 0
+        ov, h.overlap_gfwd = h.overlap_gfwd, False        # one stream: a bracketed launch must not share the chip with another branch
         for _ in range(nprof):
             case.eager_step()
         torch.cuda.synchronize()
+        h.overlap_gfwd = ov
         h.history.clear()
     if rank == 0 and not args.no_roofline:
         prof, ops.KERNEL_PROFILE = ops.KERNEL_PROFILE, None
