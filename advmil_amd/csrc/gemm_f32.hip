@@ -110,7 +110,11 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ s, int rbase
 // then cover all 64 banks, and the 8-byte staging stores of a 16-lane group cover two whole rows = 32 distinct banks. (A padded
 // 80-byte pitch measured 33% of LDS cycles as bank conflicts: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r01_pmc_sq_bf16x3.json.)
 #define PITCH_PS(BKT) (BKT)
-__device__ __forceinline__ int ps_unit(int row, int unit, int units_per_row) { return unit ^ ((row >> 2) & (units_per_row - 1)); }
+// (two units per row, k chunks of 16: rows of 32 B -> the 16 lanes of a b128 group {0-3,12-15,20-27} cover all 64 banks when the
+// halves swap every 8 rows, not every 4)
+__device__ __forceinline__ int ps_unit(int row, int unit, int units_per_row) {
+  return units_per_row == 2 ? (unit ^ ((row >> 3) & 1)) : (unit ^ ((row >> 2) & (units_per_row - 1)));
+}
 
 template <int ROWS, int BKT, int NT>
 __device__ __forceinline__ void store_tile_presplit(bf16raw* __restrict__ planes, int tid, const float4 (&r)[ROWS * BKT / (4 * NT)]) {
@@ -679,24 +683,34 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 || TM * TN > 4 ? 1 : 2))
 // This is the form of every forward layer applied to a step slab (embedding FCs, gate branches: A = the slab's rows or its hidden
 // rows, B = a weight matrix). With both operands pre-split there is nothing to convert, so the tile goes global -> LDS by the
 // gfx950 LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane, no VGPR round trip, no VALU), the inner loop is ds_read_b128 + MFMA
-// only, and the next chunk's DMA flies under the current chunk's 36-48 MFMAs per wave.
-//   workgroup = 8 waves (4 x 2), tile 256 x (64*TN'), TN' = 2*TN in 32-column MFMA tiles per wave pair -> 256x128 / 256x192 / 256x256;
-//   k walked in chunks of 32 (same accumulation order as gemm_f32_kernel's bf16x3 loop -> bit-identical results);
-//   LDS: 2 buffers x [A hi | A lo | B hi | B lo] planes of [row][32] bf16, 16-byte units XOR-swizzled by (row >> 2) & 3 (ps_unit):
+// only, and the next chunk's DMA flies under the current chunk's MFMAs.
+//   workgroup = WR x 2 waves, each wave a 64 x (32*TN) accumulator block -> tile (64*WR) x (64*TN):
+//     WR = 4 (8 waves, ONE workgroup per CU):  256x128 / 256x192 / 256x256, k chunks of 32;
+//     WR = 2 (4 waves, TWO workgroups per CU): 128x128 (k 32) / 128x192 / 128x256 (k 16) -- the two workgroups of a CU run out of
+//       phase, so one's prologue (first DMA latency) and epilogue (LDS transposition + stores) hide under the other's K loop; with
+//       one workgroup per CU those phases run with the matrix pipe idle (tools/probe/stamp_gemm.sh: 5 + 20 of 55 us per tile);
+//   same accumulation order as gemm_f32_kernel's bf16x3 loop -> bit-identical results;
+//   LDS: NBUF buffers x [A hi | A lo | B hi | B lo] planes of [row][BKT] bf16, 16-byte units XOR-swizzled (ps_unit):
 //     the DMA writes lane-linear (piece base + 16 * lane), so the swizzle is applied to each lane's SOURCE address: the lane that
-//     fills stored position q of row r fetches unit q ^ ((r >> 2) & 3) of that row (same involution as the fragment reads);
-//   one piece = 16 rows x 64 B = one wave-instruction; a chunk is 2 * (256 + BN) / 16 pieces = 6-8 per wave.
-// Requirements (checked by the host): M % 256 == 0, N % BN == 0, K % 32 == 0, planes 16-byte aligned with ld % 8 == 0, splits == 1.
+//     fills stored position q of row r fetches unit ps_unit(r, q) of that row (same involution as the fragment reads);
+//   one piece = 1 KB = one wave-instruction = 16 rows x 64 B (k 32) or 32 rows x 32 B (k 16).
+// Requirements (checked by the host): M % (64*WR) == 0, N % (64*TN) == 0, K % BKT == 0, planes 16-byte aligned with ld % 8 == 0,
+// splits == 1.
 // =====================================================================================
 #define GLB_AS __attribute__((address_space(1)))
-template <int TN, int NBUF, bool STAG = false>
-__global__ __launch_bounds__(512, 2) void gemm_nt_planes_kernel(GemmArgs g) {
-  constexpr int TM = 2, WR = 4, WC = 2, BKT = 32;
-  constexpr int BM_ = 256, BN_ = 64 * TN;
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int TN, int NBUF, int WR, int BKT>
+__global__ __launch_bounds__(128 * WR, 2) void gemm_nt_planes_kernel(GemmArgs g) {
+  constexpr int TM = 2, WC = 2, NW = WR * WC;
+  constexpr int BM_ = 64 * WR, BN_ = 64 * TN;
   constexpr int ROWS_ALL = 2 * (BM_ + BN_);            // plane rows per buffer: A hi, A lo, B hi, B lo
-  constexpr int NPIECE = ROWS_ALL / 16, PPW = NPIECE / 8;   // 16-row pieces per buffer, per wave
+  constexpr int RPP = 512 / BKT, LPR = BKT / 8;        // rows per 1 KB piece, lanes (16-byte units) per row
+  constexpr int NPIECE = ROWS_ALL / RPP, PPW = NPIECE / NW;
+  static_assert(NPIECE % NW == 0, "pieces must divide evenly over the waves");
   constexpr int BUF_HW = ROWS_ALL * BKT;               // halfwords per buffer
-  constexpr int PATCH_FLOATS = WR * WC * EPI_WAVE_FLOATS(TM, TN);
+  constexpr int PATCH_FLOATS = NW * EPI_WAVE_FLOATS(TM, TN);
   constexpr int SMEM_FLOATS = (NBUF * BUF_HW / 2 > PATCH_FLOATS) ? NBUF * BUF_HW / 2 : PATCH_FLOATS;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
   bf16raw* const lds = reinterpret_cast<bf16raw*>(smem);
@@ -719,11 +733,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_planes_kernel(GemmArgs g) {
     }
   }
   const int64_t m0 = (int64_t)mt_i * BM_, n0 = (int64_t)nt_i * BN_;
-  // per-lane DMA sources: piece p = wave + 8*it covers plane rows [16p, 16p + 16) of the buffer image
+  // per-lane DMA sources: piece p = wave + NW*it covers plane rows [RPP*p, RPP*p + RPP) of the buffer image
   const bf16raw* src[PPW];
 #pragma unroll
   for (int it = 0; it < PPW; ++it) {
-    const int prow = (wave + 8 * it) * 16 + (lane >> 2);   // row in the buffer image
+    const int prow = (wave + NW * it) * RPP + lane / LPR;  // row in the buffer image
     const bf16raw* base;
     int r;                                                 // tile-local row of its operand
     int64_t ld, row0;
@@ -731,23 +745,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_planes_kernel(GemmArgs g) {
     else if (prow < 2 * BM_) { base = reinterpret_cast<const bf16raw*>(g.epi.a_lo); r = prow - BM_; ld = g.lda; row0 = m0; }
     else if (prow < 2 * BM_ + BN_) { base = reinterpret_cast<const bf16raw*>(g.epi.b_hi); r = prow - 2 * BM_; ld = g.ldb; row0 = n0; }
     else { base = reinterpret_cast<const bf16raw*>(g.epi.b_lo); r = prow - 2 * BM_ - BN_; ld = g.ldb; row0 = n0; }
-    src[it] = base + (row0 + r) * ld + (((lane & 3) ^ ((r >> 2) & 3)) * 8);
+    src[it] = base + (row0 + r) * ld + ps_unit(r, lane % LPR, LPR) * 8;
   }
   auto dma = [&](int buf, int64_t k0) {
 #pragma unroll
     for (int it = 0; it < PPW; ++it)
-      __builtin_amdgcn_global_load_lds((const GLB_AS void*)(src[it] + k0), (LDS_AS void*)(lds + buf * BUF_HW + (wave + 8 * it) * 16 * BKT), 16, 0, 0);
-  };
-  constexpr int PH = (PPW + 1) / 2;                     // pieces in the first of a wave's two DMA doses
-  auto dma_lo = [&](int buf, int64_t k0) {
-#pragma unroll
-    for (int it = 0; it < PH; ++it)
-      __builtin_amdgcn_global_load_lds((const GLB_AS void*)(src[it] + k0), (LDS_AS void*)(lds + buf * BUF_HW + (wave + 8 * it) * 16 * BKT), 16, 0, 0);
-  };
-  auto dma_hi = [&](int buf, int64_t k0) {
-#pragma unroll
-    for (int it = PH; it < PPW; ++it)
-      __builtin_amdgcn_global_load_lds((const GLB_AS void*)(src[it] + k0), (LDS_AS void*)(lds + buf * BUF_HW + (wave + 8 * it) * 16 * BKT), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const GLB_AS void*)(src[it] + k0), (LDS_AS void*)(lds + buf * BUF_HW + (wave + NW * it) * 512), 16, 0, 0);
   };
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -758,97 +761,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_planes_kernel(GemmArgs g) {
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
   const int64_t K = g.K;
-  if constexpr (STAG) {
-    // Two wave groups in anti-phase. Waves w and w + 4 share a SIMD; group 1 (waves 4-7) runs one barrier behind group 0, so in
-    // every interval between two consecutive workgroup barriers one group issues its fragment reads (and its share of the next
-    // chunk's LDS-DMA) while the other owns the SIMD's matrix pipe with the 6*TN MFMAs of a 16-deep k step:
-    //   phase (chunk c, half s):  ds_reads(c, s) | barrier A | MFMAs(c, s) | barrier B
-    //   interval I(n) = between barriers n-1 and n:  group 0 reads phase p in I(2p+1), multiplies in I(2p+2); group 1 one later.
-    // Buffer of chunk c: last read retires (lgkmcnt(0) behind barrier A) at the start of I(4c+5), so it may be refilled from
-    // I(4c+6) on, and the chunk that reuses it (c + NBUF) is first read NBUF*4 - 1 intervals later. The LDS-DMA pieces of a wave
-    // go out in two doses at the two earliest legal points (a burst of 8 blocks the issuing wave for ~1000 cycles; 3-4 pieces
-    // behind a barrier, while the wave's own fragment reads are still landing, cost nothing -- tools/probe/mfma_probe.hip):
-    //   group 1: read interval of phase (c+1, 0), then behind barrier A of that phase;
-    //   group 0: behind barrier A of phase (c+1, 0), then in the read interval of phase (c+1, 1).
-    // Chunk c+1 is first read in I(4c+5) (group 0): every wave waits for its own pieces (counted vmcnt: with 3 buffers the younger
-    // chunk stays in flight) before barrier 4c+4 -- group 0 behind the MFMAs of phase (c, 1), group 1 at the end of its reads of
-    // phase (c, 1).
-    const int grp = wave >> 2;
-    const int nchunk = (int)(K / BKT);
-    dma(0, 0);
-    if (NBUF == 3 && nchunk > 1) dma(1, BKT);
-    if (NBUF == 3 && nchunk > 1) {
-      if constexpr (PPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else if constexpr (PPW == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (grp == 1) __builtin_amdgcn_s_barrier();
-    int cur = 0;
-    for (int c = 0; c < nchunk; ++c) {
-      const bf16raw* cA = lds + cur * BUF_HW;
-      const bf16raw* cB = cA + 2 * BM_ * BKT;
-      const bool more = c + NBUF - 1 < nchunk;                       // a chunk to prefetch into the buffer chunk c-1 used
-      const int nbuf = cur == 0 ? NBUF - 1 : cur - 1;
-      const int64_t nk0 = (int64_t)(c + NBUF - 1) * BKT;
-#pragma unroll
-      for (int ks = 0; ks < BKT / 16; ++ks) {
-        bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-        for (int a = 0; a < TM; ++a) read_frag_presplit<BM_, BKT>(cA, wr * 32 * TM + a * 32, ks, i, hi, ah[a], al[a]);
-#pragma unroll
-        for (int b = 0; b < TN; ++b) read_frag_presplit<BN_, BKT>(cB, wc * 32 * TN + b * 32, ks, i, hi, bh[b], bl[b]);
-        if (ks == 0 && grp == 1 && more) dma_lo(nbuf, nk0);
-        if (ks == 1 && grp == 0 && more) dma_hi(nbuf, nk0);
-        if (ks == 1 && grp == 1) {                                   // chunk c+1 is read from the next interval on
-          if (NBUF == 3 && c + 2 < nchunk) {
-            if constexpr (PPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if constexpr (PPW == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-          } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();                                // A
-        asm volatile("" ::: "memory");
-        if (ks == 0 && more) {
-          if (grp == 0) dma_lo(nbuf, nk0);
-          else dma_hi(nbuf, nk0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int b = 0; b < TN; ++b) {
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-          }
-        __builtin_amdgcn_s_setprio(0);
-        if (ks == 1 && grp == 0) {
-          if (NBUF == 3 && c + 2 < nchunk) {
-            if constexpr (PPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if constexpr (PPW == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-          } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();                                // B
-        asm volatile("" ::: "memory");
-      }
-      cur = cur == NBUF - 1 ? 0 : cur + 1;
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();
-    gemm_epilogue<TM, TN, WR, WC>(g, acc, smem, wave, lane, wr, wc, m0, n0, 0, nt_i);
-    return;
-  }
   dma(0, 0);
   if (NBUF == 3 && BKT < K) dma(1, BKT);               // three buffers: two chunks in flight
   int cur = 0;
@@ -856,20 +768,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_planes_kernel(GemmArgs g) {
     if constexpr (NBUF == 3) {
       // counted wait: this wave's pieces of chunk k0 have landed, the younger chunk's PPW pieces may still fly across the barrier
       // (a raw s_barrier: __syncthreads would drain vmcnt to 0 because an LDS-DMA is a pending LDS write)
-      if (k0 + BKT < K) {
-        if constexpr (PPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if constexpr (PPW == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      if (k0 + BKT < K) wait_vmcnt<PPW>();
+      else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (k0 + 2 * BKT < K) dma((cur + 2) % 3, k0 + 2 * BKT);
+      if (k0 + 2 * BKT < K) dma(cur == 0 ? 2 : cur - 1, k0 + 2 * BKT);
     } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of chunk k0 have landed
-    __syncthreads();                                    // everyone's have; and everyone is done reading buffer cur^1
-    if (k0 + BKT < K) dma(cur ^ 1, k0 + BKT);
+      wait_vmcnt<0>();                                   // this wave's pieces of chunk k0 have landed
+      __syncthreads();                                   // everyone's have; and everyone is done reading buffer cur^1
+      if (k0 + BKT < K) dma(cur ^ 1, k0 + BKT);
     }
     const bf16raw* cA = lds + cur * BUF_HW;
     const bf16raw* cB = cA + 2 * BM_ * BKT;
@@ -1068,7 +975,7 @@ static int plan_exact(int64_t M, int64_t N, int64_t K, int* tile, int* splits) {
 // waves along N of a tile code: 2 for the 256-thread tiles and 43/42, 4 for the 2 x 4 wave grids 34/24
 static int tile_wc(int tile) { return (tile == 34 || tile == 24) ? 4 : 2; }
 extern "C" int advmil_gemm_f32_gate_blocks(int tile, int64_t N) {
-  if (tile >= 82 && tile <= 84) return (int)(N / (64 * (tile - 80))) * 2;      // plane-fed NT kernel: 2 waves along N
+  if ((tile >= 82 && tile <= 84) || (tile >= 92 && tile <= 94)) return (int)(N / (64 * (tile % 10))) * 2;      // plane-fed NT kernel: 2 waves along N
   if (g_gemm_mode != 1) {
     if (tile / 10 == 4) tile = 20 + tile % 10;
     else if (tile % 10 == 4) tile = (tile / 10 == 3) ? 23 : 22;
@@ -1125,26 +1032,21 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
   // NT form with both operands as planes: the LDS-DMA kernel (tile codes 82 / 83 / 84 = 256 x 128 / 192 / 256, 8 waves). The plan
   // (advmil_gemm_f32_plan_planes, or tile 0 here) picks it whenever the shape qualifies; ADVMIL_NT_PLANES=0 turns it off.
   if (tile == 0 && pre == 3 && splits == 1) { int t = 0; advmil_gemm_f32_plan_planes(a_kc, b_kc, M, N, K, &t); if (t) tile = t; }
-  if (tile >= 82 && tile <= 84) {
-    const int tnp = tile - 80;
-    if (g_gemm_mode != 1 || !a_kc || !b_kc || pre != 3 || splits != 1 || (M % 256) || (K % 32) || (N % (64 * tnp))) return ADVMIL_EINVAL;
+  if ((tile >= 82 && tile <= 84) || (tile >= 92 && tile <= 94)) {
+    const int tnp = tile % 10, bm = tile >= 92 ? 128 : 256, bkt = (tile == 93 || tile == 94) ? 16 : 32;
+    if (g_gemm_mode != 1 || !a_kc || !b_kc || pre != 3 || splits != 1 || (M % bm) || (K % bkt) || (N % (64 * tnp))) return ADVMIL_EINVAL;
     if (epi->gate_wc && (!epi->gate_out || epi->drop_p > 0.0f || epi->gate_np != advmil_gemm_f32_gate_blocks(tile, N))) return ADVMIL_EINVAL;
-    g.mtiles = (int)(M / 256);
+    g.mtiles = (int)(M / bm);
     g.ntiles = (int)(N / (64 * tnp));
     dim3 pgrid(g.mtiles * g.ntiles);
-    static const int nbuf3 = []() { const char* e = getenv("ADVMIL_NT_PLANES_NBUF"); return (e && e[0] == '2') ? 0 : 1; }();
-    static const int stag = []() { const char* e = getenv("ADVMIL_NT_PLANES_STAG"); return (e && e[0] == '1') ? 1 : 0; }();
-    if (stag) {
-      if (tnp == 4) hipLaunchKernelGGL((gemm_nt_planes_kernel<4, 2, true>), pgrid, dim3(512), 0, stream, g);
-      else if (tnp == 3) hipLaunchKernelGGL((gemm_nt_planes_kernel<3, 2, true>), pgrid, dim3(512), 0, stream, g);
-      else hipLaunchKernelGGL((gemm_nt_planes_kernel<2, 3, true>), pgrid, dim3(512), 0, stream, g);
-      ADVMIL_LAUNCH_CHECK();
-      return ADVMIL_OK;
+    switch (tile) {
+      case 84: hipLaunchKernelGGL((gemm_nt_planes_kernel<4, 2, 4, 32>), pgrid, dim3(512), 0, stream, g); break;   // 2 x 64 KB
+      case 83: hipLaunchKernelGGL((gemm_nt_planes_kernel<3, 2, 4, 32>), pgrid, dim3(512), 0, stream, g); break;   // 2 x 56 KB
+      case 82: hipLaunchKernelGGL((gemm_nt_planes_kernel<2, 3, 4, 32>), pgrid, dim3(512), 0, stream, g); break;   // 3 x 48 KB: two chunks in flight
+      case 94: hipLaunchKernelGGL((gemm_nt_planes_kernel<4, 3, 2, 16>), pgrid, dim3(256), 0, stream, g); break;   // 3 x 24 KB, two workgroups per CU
+      case 93: hipLaunchKernelGGL((gemm_nt_planes_kernel<3, 3, 2, 16>), pgrid, dim3(256), 0, stream, g); break;   // 3 x 20 KB
+      default: hipLaunchKernelGGL((gemm_nt_planes_kernel<2, 2, 2, 32>), pgrid, dim3(256), 0, stream, g); break;   // 92: 2 x 32 KB
     }
-    if (tnp == 4) hipLaunchKernelGGL((gemm_nt_planes_kernel<4, 2>), pgrid, dim3(512), 0, stream, g);
-    else if (tnp == 3) hipLaunchKernelGGL((gemm_nt_planes_kernel<3, 2>), pgrid, dim3(512), 0, stream, g);
-    else if (nbuf3) hipLaunchKernelGGL((gemm_nt_planes_kernel<2, 3>), pgrid, dim3(512), 0, stream, g);    // 3 x 48 KB: two chunks in flight
-    else hipLaunchKernelGGL((gemm_nt_planes_kernel<2, 2>), pgrid, dim3(512), 0, stream, g);
     ADVMIL_LAUNCH_CHECK();
     return ADVMIL_OK;
   }
@@ -1156,8 +1058,16 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
     case 11: launch_tile<1, 1, true>(a_kc, b_kc, grid, stream, g, pre); break;
     case 43: launch_tile_m<2, 3, true, 0, 4, 2>(a_kc, b_kc, grid, stream, g); break;   // 256x192, 8 waves
     case 42: launch_tile_m<2, 2, true, 0, 4, 2>(a_kc, b_kc, grid, stream, g); break;   // 256x128, 8 waves
-    case 34: launch_tile_m<3, 2, true, 0, 2, 4>(a_kc, b_kc, grid, stream, g); break;   // 192x256, 8 waves (2 x 4)
-    case 24: launch_tile_m<2, 2, true, 0, 2, 4>(a_kc, b_kc, grid, stream, g); break;   // 128x256, 8 waves (2 x 4)
+    // 192x256 / 128x256, 8 waves (2 x 4): the weight-gradient contractions dY^T X over the slab rows. With the slab's planes at
+    // hand (B = X: 3/4 to 9/10 of the staged elements) that operand is staged without any conversion work.
+    case 34:
+      if (pre == 2 && !a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 3, 2, true, 2, 32, 2, 4>), grid, dim3(512), 0, stream, g);
+      else launch_tile_m<3, 2, true, 0, 2, 4>(a_kc, b_kc, grid, stream, g);
+      break;
+    case 24:
+      if (pre == 2 && !a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 2, 2, true, 2, 32, 2, 4>), grid, dim3(512), 0, stream, g);
+      else launch_tile_m<2, 2, true, 0, 2, 4>(a_kc, b_kc, grid, stream, g);
+      break;
     default: return ADVMIL_EINVAL;
   }
   ADVMIL_LAUNCH_CHECK();

@@ -643,18 +643,26 @@ __global__ __launch_bounds__(256) void ln_relu_mean16_fwd_kernel(const float* __
     gm[q] = ok ? gamma[j] : 0.f; bt[q] = ok ? beta[j] : 0.f; acc[q] = 0.f;
   }
   const float invd = hw_rcp((float)d);
+  // the wave's four rows are independent: all their loads go out before the first reduction (one row at a time left a single
+  // 256-byte request per wave in flight: 1.9 TB/s at d = 128)
+  float va[4][QT];
+#pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
     const int64_t n = g * 16 + w * 4 + rr;
-    if (n >= N) break;
-    const float* row = y + n * d;
-    float v[QT];
-    float s = 0.f;
 #pragma unroll
     for (int q = 0; q < QT; ++q) {
       const int64_t j = lane + 64 * q;
-      v[q] = (q < Q && j < d) ? row[j] : 0.f;
-      s += v[q];
+      va[rr][q] = (n < N && q < Q && j < d) ? y[n * d + j] : 0.f;
     }
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int64_t n = g * 16 + w * 4 + rr;
+    if (n >= N) break;
+    float (&v)[QT] = va[rr];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < QT; ++q) s += v[q];
     const float mu = wave_sum(s) * invd;
     float s2 = 0.f;
 #pragma unroll
@@ -730,11 +738,24 @@ __global__ __launch_bounds__(256) void ln_relu_mean16_bwd_kernel(const float* __
       de[q] = (q < Q && j < d) ? demb[g * d + j] * (1.f / 16.f) : 0.f;
     }
   }
+  // the wave's four rows are independent: all their loads go out before the first reduction
+  float ya[4][QT], mua[4], rsa[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int64_t n = g * 16 + w * 4 + rr;
+    mua[rr] = n < N ? mean[n] : 0.f;
+    rsa[rr] = n < N ? rstd[n] : 0.f;
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+      const int64_t j = lane + 64 * q;
+      ya[rr][q] = (n < N && q < Q && j < d) ? y[n * d + j] : 0.f;
+    }
+  }
+#pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
     const int64_t n = g * 16 + w * 4 + rr;
     if (n >= N) break;
-    const float* row = y + n * d;
-    const float mu = mean[n], rs = rstd[n];
+    const float mu = mua[rr], rs = rsa[rr];
     if (!pool16) {
 #pragma unroll
       for (int q = 0; q < QT; ++q) {
@@ -748,7 +769,7 @@ __global__ __launch_bounds__(256) void ln_relu_mean16_bwd_kernel(const float* __
     for (int q = 0; q < QT; ++q) {
       const int64_t j = lane + 64 * q;
       const bool ok = q < Q && j < d;
-      xh[q] = ok ? (row[j] - mu) * rs : 0.f;
+      xh[q] = ok ? (ya[rr][q] - mu) * rs : 0.f;
       const float z = xh[q] * gm[q] + bt[q];
       const float dz = (ok && z > 0.f) ? de[q] : 0.f;
       dxh[q] = dz * gm[q];

@@ -176,6 +176,8 @@ USE_PLANES = os.environ.get("ADVMIL_PLANES", "1") != "0"
 # costs 2 % (the extra 403 MB of plane writes outweigh the staging they save) and planes of the memo-replayed (dropped) h are
 # neutral -> both off unless asked for.
 DH_PLANES = os.environ.get("ADVMIL_DH_PLANES", "0") != "0"
+# weight gradients dY^T X of the layers applied to the slab: X's planes (already resident for the forward) feed the B operand
+DW_PLANES = os.environ.get("ADVMIL_DW_PLANES", "1") != "0"
 MEMO_PLANES = os.environ.get("ADVMIL_MEMO_PLANES", "0") != "0"
 
 
@@ -274,7 +276,7 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        name = ("gemm_nt_planes_kernel<%d>" % (tile - 80)) if 82 <= tile <= 84 else \
+        name = ("gemm_nt_planes_kernel<%d%s>" % (tile % 10, "" if tile < 90 else ",4w")) if (82 <= tile <= 84 or 92 <= tile <= 94) else \
             "gemm_f32_kernel<%d,%d,%d,%d>" % (bool(a_kc), bool(b_kc), tile // 10, tile % 10)
         prof.append((name, (M, N, K, splits), 2.0 * M * N * K, e0, e1))
     return gate_out if gate_wc is not None else out
@@ -540,6 +542,7 @@ class LinearActFn(torch.autograd.Function):
         ctx.save_for_backward(x, W2, y)
         ctx.cfg = (act, p, seed, sid, M, N, K, W.shape, b is not None, rr)
         ctx.gW, ctx.gb = _arena_grad(W), _arena_grad(b)
+        ctx.xpl = xpl if xpl is not None else (planes_of(x) if M >= 4096 else None)     # the weight gradient's big operand, pre-split
         return y
 
     @staticmethod
@@ -558,10 +561,11 @@ class LinearActFn(torch.autograd.Function):
             dpre, db = act_dropout_bwd(dy, y, act, M, N, p, seed, sid, want_bias=need_b, db_out=ctx.gb if need_b else None, rng_row=rr)
         dW = None
         if need_w:                                           # dpre^T x
+            xpl = ctx.xpl if (DW_PLANES and get_gemm_mode() == "bf16x3") else None
             if ctx.gW is not None:
-                gemm(dpre, x, False, False, N, K, M, out=ctx.gW.view(N, K), ldc=K, accumulate=True)
+                gemm(dpre, x, False, False, N, K, M, out=ctx.gW.view(N, K), ldc=K, accumulate=True, b_planes=xpl)
             else:
-                dW = gemm(dpre, x, False, False, N, K, M).reshape(wshape)
+                dW = gemm(dpre, x, False, False, N, K, M, b_planes=xpl).reshape(wshape)
         dx = gemm(dpre, W2, True, False, M, K, N) if need_x else None                   # dpre W
         return dx, dW, (None if ctx.gb is not None else db), None, None, None, None, None, None, None, None, None
 
