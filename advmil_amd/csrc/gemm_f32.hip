@@ -685,10 +685,10 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 || TM * TN > 4 ? 1 : 2))
 // gfx950 LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane, no VGPR round trip, no VALU), the inner loop is ds_read_b128 + MFMA
 // only, and the next chunk's DMA flies under the current chunk's MFMAs.
 //   workgroup = WR x 2 waves, each wave a 64 x (32*TN) accumulator block -> tile (64*WR) x (64*TN):
-//     WR = 4 (8 waves, ONE workgroup per CU):  256x128 / 256x192 / 256x256, k chunks of 32;
-//     WR = 2 (4 waves, TWO workgroups per CU): 128x128 (k 32) / 128x192 / 128x256 (k 16) -- the two workgroups of a CU run out of
-//       phase, so one's prologue (first DMA latency) and epilogue (LDS transposition + stores) hide under the other's K loop; with
-//       one workgroup per CU those phases run with the matrix pipe idle (tools/probe/stamp_gemm.sh: 5 + 20 of 55 us per tile);
+//     WR = 4 (8 waves, one workgroup per CU): 256x128 / 256x192 / 256x256, k chunks of 32 -- the instantiated forms;
+//     WR = 2 (4 waves, two workgroups per CU, whose prologue / epilogue would hide under the other's K loop): 128x128 (k 32)
+//       measured equal, 128x192 / 128x256 (k 16, 32-byte DMA rows) 10-15 % slower than the 8-wave forms on every slab shape, so
+//       they are not built (tools/gemm_planes_check.py history in DESIGN.md);
 //   same accumulation order as gemm_f32_kernel's bf16x3 loop -> bit-identical results;
 //   LDS: NBUF buffers x [A hi | A lo | B hi | B lo] planes of [row][BKT] bf16, 16-byte units XOR-swizzled (ps_unit):
 //     the DMA writes lane-linear (piece base + 16 * lane), so the swizzle is applied to each lane's SOURCE address: the lane that
@@ -975,7 +975,7 @@ static int plan_exact(int64_t M, int64_t N, int64_t K, int* tile, int* splits) {
 // waves along N of a tile code: 2 for the 256-thread tiles and 43/42, 4 for the 2 x 4 wave grids 34/24
 static int tile_wc(int tile) { return (tile == 34 || tile == 24) ? 4 : 2; }
 extern "C" int advmil_gemm_f32_gate_blocks(int tile, int64_t N) {
-  if ((tile >= 82 && tile <= 84) || (tile >= 92 && tile <= 94)) return (int)(N / (64 * (tile % 10))) * 2;      // plane-fed NT kernel: 2 waves along N
+  if (tile >= 82 && tile <= 84) return (int)(N / (64 * (tile % 10))) * 2;      // plane-fed NT kernel: 2 waves along N
   if (g_gemm_mode != 1) {
     if (tile / 10 == 4) tile = 20 + tile % 10;
     else if (tile % 10 == 4) tile = (tile / 10 == 3) ? 23 : 22;
@@ -1032,8 +1032,8 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
   // NT form with both operands as planes: the LDS-DMA kernel (tile codes 82 / 83 / 84 = 256 x 128 / 192 / 256, 8 waves). The plan
   // (advmil_gemm_f32_plan_planes, or tile 0 here) picks it whenever the shape qualifies; ADVMIL_NT_PLANES=0 turns it off.
   if (tile == 0 && pre == 3 && splits == 1) { int t = 0; advmil_gemm_f32_plan_planes(a_kc, b_kc, M, N, K, &t); if (t) tile = t; }
-  if ((tile >= 82 && tile <= 84) || (tile >= 92 && tile <= 94)) {
-    const int tnp = tile % 10, bm = tile >= 92 ? 128 : 256, bkt = (tile == 93 || tile == 94) ? 16 : 32;
+  if (tile >= 82 && tile <= 84) {
+    const int tnp = tile % 10, bm = 256, bkt = 32;
     if (g_gemm_mode != 1 || !a_kc || !b_kc || pre != 3 || splits != 1 || (M % bm) || (K % bkt) || (N % (64 * tnp))) return ADVMIL_EINVAL;
     if (epi->gate_wc && (!epi->gate_out || epi->drop_p > 0.0f || epi->gate_np != advmil_gemm_f32_gate_blocks(tile, N))) return ADVMIL_EINVAL;
     g.mtiles = (int)(M / bm);
@@ -1043,9 +1043,7 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
       case 84: hipLaunchKernelGGL((gemm_nt_planes_kernel<4, 2, 4, 32>), pgrid, dim3(512), 0, stream, g); break;   // 2 x 64 KB
       case 83: hipLaunchKernelGGL((gemm_nt_planes_kernel<3, 2, 4, 32>), pgrid, dim3(512), 0, stream, g); break;   // 2 x 56 KB
       case 82: hipLaunchKernelGGL((gemm_nt_planes_kernel<2, 3, 4, 32>), pgrid, dim3(512), 0, stream, g); break;   // 3 x 48 KB: two chunks in flight
-      case 94: hipLaunchKernelGGL((gemm_nt_planes_kernel<4, 3, 2, 16>), pgrid, dim3(256), 0, stream, g); break;   // 3 x 24 KB, two workgroups per CU
-      case 93: hipLaunchKernelGGL((gemm_nt_planes_kernel<3, 3, 2, 16>), pgrid, dim3(256), 0, stream, g); break;   // 3 x 20 KB
-      default: hipLaunchKernelGGL((gemm_nt_planes_kernel<2, 2, 2, 32>), pgrid, dim3(256), 0, stream, g); break;   // 92: 2 x 32 KB
+      default: return ADVMIL_EINVAL;
     }
     ADVMIL_LAUNCH_CHECK();
     return ADVMIL_OK;

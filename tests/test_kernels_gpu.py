@@ -280,6 +280,68 @@ def test_gemm_bf16x3_eight_wave_tiles(ops, a_kc, b_kc, tile):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["exact", "bf16x3"])
+@pytest.mark.parametrize("tile", [22, 23, 43, 84])
+def test_gemm_streaming_epilogue_modes(ops, mode, tile):
+    """Whole-tile launches of the 128x128+ tiles take the streaming epilogue (side data parked in LDS, per-element operand one
+    sub-tile ahead). Every mode it serves is checked against float64 on the host -- dropout masks regenerated from the counter
+    RNG through a shuffled row map -- and bit for bit against the 64x64 tile, which always takes the generic epilogue."""
+    if tile == 84 and mode != "bf16x3":
+        pytest.skip("the plane-fed kernel is the bf16x3 path")
+    prev = ops.get_gemm_mode()
+    ops.set_gemm_mode(mode)
+    try:
+        M, N, K, p = 768, 768, 96, 0.25
+        tol = 3e-5 if mode == "bf16x3" else 5e-6       # (hardware exp / rcp in tanh and sigmoid: ~1 ulp each)
+        g = torch.Generator(device="cuda").manual_seed(5)
+        A = 0.1 * torch.randn(M, K, device="cuda", generator=g); W = torch.randn(N, K, device="cuda", generator=g)
+        bias = torch.randn(N, device="cuda", generator=g)
+        pre = A.cpu().double() @ W.cpu().double().t()          # ~N(0, 1): errors are judged on the scale of the activations' range
+        kw = dict(a_planes=ops.split_planes(A), b_planes=ops.split_planes(W)) if tile == 84 else {}
+
+        def both(**e):
+            outs = []
+            for t in (tile, 11):
+                if "out" in e:
+                    e["out"] = e["out0"].clone()
+                outs.append(ops.gemm(A, W, True, True, M, N, K, tile=t, splits=1, **{k: v for k, v in e.items() if k != "out0"},
+                                     **(kw if t == tile else {})))
+            assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+            return outs[0]
+
+        # bias + two activations split at a 32-column boundary, planes of the result
+        cpl = ops.Planes(torch.empty(M, N, dtype=torch.bfloat16, device="cuda"), torch.empty(M, N, dtype=torch.bfloat16, device="cuda"))
+        y = ops.gemm(A, W, True, True, M, N, K, bias=bias, act0=2, act1=3, act_split=384, alpha=0.5, tile=tile, splits=1, c_planes=cpl, **kw)
+        want = 0.5 * pre + bias.cpu().double()
+        want = torch.cat([torch.tanh(want[:, :384]), torch.sigmoid(want[:, 384:])], dim=1)
+        assert relerr(y, want) < tol
+        assert torch.equal(y, both(bias=bias, act0=2, act1=3, act_split=384, alpha=0.5))
+        ref_pl = ops.split_planes(y)
+        assert torch.equal(cpl.hi, ref_pl.hi) and torch.equal(cpl.lo, ref_pl.lo)
+        # relu + dropout through a row map (bag-parallel form)
+        rng = ops.DeviceRng("cuda", seed=77)
+        sid = rng.site("t")
+        rmap = torch.randperm(M, generator=torch.Generator().manual_seed(3)).to(torch.int64)
+        y = both(bias=bias, act0=1, drop_p=p, seed=rng.seed, stream_id=sid, rng_row=rmap.cuda())
+        keep = H.T(synth.dropout_keep(77, sid, M * N, p).reshape(M, N)).double()[rmap]
+        assert relerr(y, torch.relu(pre + bias.cpu().double()) * keep / (1 - p)) < tol
+        # rank-1 term per bag: + rowv[m] * colv[rowseg[m], n]
+        rowv = torch.randn(M, device="cuda", generator=g); colv = torch.randn(4, N, device="cuda", generator=g)
+        rowseg = torch.arange(M, device="cuda", dtype=torch.int32) // (M // 4)
+        y = both(rowv=rowv, colv=colv, rowseg=rowseg)
+        assert relerr(y, pre + rowv.cpu().double()[:, None] * colv.cpu().double()[rowseg.cpu().long()]) < tol
+        # mask of a reference activation, and accumulation into the output
+        mref = torch.randn(M, N, device="cuda", generator=g)
+        y = both(maskref=mref, mask_scale=1.25)
+        assert relerr(y, pre * (mref.cpu().double() > 0) * 1.25) < tol
+        C0 = torch.randn(M, N, device="cuda", generator=g)
+        y = both(out=None, out0=C0, accumulate=True, bias=bias)
+        assert relerr(y, pre + bias.cpu().double() + C0.cpu().double()) < tol
+    finally:
+        ops.set_gemm_mode(prev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["exact", "bf16x3"])
 @pytest.mark.parametrize("tile", [0, 22, 23, 12, 11, 43])
 def test_gemm_fused_gate_score(ops, mode, tile):
     """Gate-score mode of the contraction (interleaved branch rows, score reduced in the epilogue, no [N,2D] store) equals the

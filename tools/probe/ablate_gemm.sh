@@ -2,6 +2,7 @@
 # Dev probe: where does the plane-fed contraction kernel's time go? Builds variants of libadvmil_hip.so from a patched COPY of
 # gemm_f32.hip (the product source carries no ablation switches) and times them in one call:
 #   base | noepi (epilogue replaced by a sink) | nodma (no LDS-DMA inside the K loop) | noepi+nodma (LDS reads + MFMA + barriers only)
+#   | noloop (one k chunk: prologue + epilogue only)
 # usage (on the GPU box): bash tools/probe/ablate_gemm.sh build   (here, cross-compile)  /  bash tools/probe/ablate_gemm.sh run
 set -e
 cd "$(dirname "$0")/../.."
@@ -11,7 +12,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$C -mllvm -pragma-
 if [ "$1" = build ]; then
   mkdir -p $P
   make -s -C $C
-  for v in base noepi noloop; do
+  for v in base noepi nodma noepi_nodma noloop; do
     cp $C/gemm_f32.hip $P/gemm_$v.hip
     case $v in *noepi*)
       python3 - $P/gemm_$v.hip <<'PY'
@@ -37,9 +38,7 @@ PY
       python3 - $P/gemm_$v.hip <<'PY'
 import sys
 p=sys.argv[1]; s=open(p).read()
-for old in ("      if (k0 + 2 * BKT < K) dma((cur + 2) % 3, k0 + 2 * BKT);\n", "    if (k0 + BKT < K) dma(cur ^ 1, k0 + BKT);\n",
-            "        if (ks == 0 && grp == 1 && more) dma_lo(nbuf, nk0);\n", "        if (ks == 1 && grp == 0 && more) dma_hi(nbuf, nk0);\n",
-            "          if (grp == 0) dma_lo(nbuf, nk0);\n          else dma_hi(nbuf, nk0);\n"):
+for old in ("      if (k0 + 2 * BKT < K) dma(cur == 0 ? 2 : cur - 1, k0 + 2 * BKT);\n", "      if (k0 + BKT < K) dma(cur ^ 1, k0 + BKT);\n"):
     assert old in s
     s=s.replace(old, "")
 open(p,"w").write(s)
@@ -49,19 +48,9 @@ PY
       python3 - $P/gemm_$v.hip <<'PY'
 import sys
 p=sys.argv[1]; s=open(p).read()
-old="  const int64_t K = g.K;\n  if constexpr (STAG) {"
+old="  const int64_t K = g.K;\n  dma(0, 0);"
 assert old in s
-s=s.replace(old,"  const int64_t K = 32;\n  if constexpr (STAG) {")
-open(p,"w").write(s)
-PY
-    ;; esac
-    case $v in *nolds*)
-      python3 - $P/gemm_$v.hip <<'PY'
-import sys
-p=sys.argv[1]; s=open(p).read()
-old="      const bf16raw* cA = lds + cur * BUF_HW;\n      const bf16raw* cB = cA + 2 * BM_ * BKT;\n      const bool more"
-assert old in s
-s=s.replace(old,"      const bf16raw* cA = lds;\n      const bf16raw* cB = cA + 2 * BM_ * BKT;\n      const bool more")
+s=s.replace(old,"  const int64_t K = 32;\n  dma(0, 0);")
 open(p,"w").write(s)
 PY
     ;; esac
@@ -71,7 +60,7 @@ PY
   done
   ls -la $P
 else
-  for v in base noepi noloop; do
+  for v in base noepi nodma noepi_nodma noloop; do
     echo "== $v"
     ADVMIL_HIP_LIB=$PWD/$P/lib_$v.so python3 tools/probe/ablate_gemm_time.py
   done

@@ -32,5 +32,5 @@ PY
   rm -f $P/gemm_stamp.hip
   ls -la $P/lib_stamp.so
 else
-  ADVMIL_HIP_LIB=$PWD/$P/lib_stamp.so ADVMIL_NT_PLANES_STAG=0 python3 tools/probe/stamp_gemm_time.py
+  ADVMIL_HIP_LIB=$PWD/$P/lib_stamp.so python3 tools/probe/stamp_gemm_time.py
 fi
