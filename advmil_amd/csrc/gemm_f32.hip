@@ -353,6 +353,56 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
       WAVE_LDS_SYNC();   // the reads have landed: the next sub-tile may overwrite the patch
       const int act = cbase + b * 32 < e.act_split ? e.act0 : e.act1;
       const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+      if (!drop && kind == 0) {
+        // plain bias + activation (the forward layers): the launch-uniform tests are taken once per sub-tile, not once per element
+        // (16 elements x 5 scalar branches per sub-tile made this path 1.6x slower than its stores alone, tools/probe/store_probe.hip)
+        const float al = e.alpha;
+        if (act == ACT_RELU) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) res[q][t] = fmaxf(res[q][t] * al + bb[t], 0.0f);
+        } else if (act == ACT_NONE) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) res[q][t] = res[q][t] * al + bb[t];
+        } else if (act == ACT_TANH) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) res[q][t] = act_apply(ACT_TANH, res[q][t] * al + bb[t]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) res[q][t] = act_apply(ACT_SIGMOID, res[q][t] * al + bb[t]);
+        }
+      } else if (!drop && kind == 1 && act == ACT_NONE) {
+        // rank-1 term per bag (dh = dG Wab + A[n] dpooled[bag(n)]), no activation
+        const float al = e.alpha;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float r1 = srow_f[a * 32 + q * 8 + rq];
+          const float xe[4] = {ext[q].x, ext[q].y, ext[q].z, ext[q].w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) res[q][t] = res[q][t] * al + bb[t] + r1 * xe[t];
+        }
+      } else if (drop && kind == 0 && (act == ACT_RELU || act == ACT_NONE)) {
+        // (ReLU +) dropout from the counter RNG (train-mode forward layers)
+        const float al = e.alpha;
+        const bool relu = act == ACT_RELU;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t srow = mapped ? (int64_t)srow_i[a * 32 + q * 8 + rq] : rbase + a * 32 + q * 8 + rq;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            float x = res[q][t] * al + bb[t];
+            x = relu ? fmaxf(x, 0.0f) : x;
+            res[q][t] = x * rng_keep(key, (uint64_t)(srow * N + col + t), e.drop_p, inv_keep);
+          }
+        }
+      } else
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float xe[4] = {ext[q].x, ext[q].y, ext[q].z, ext[q].w};
@@ -396,9 +446,12 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
 #undef ADVMIL_EPI_PREFETCH
 }
 
-template <int TM, int TN, int WR, int WC>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[TM][TN], float* smem, int wave, int lane, int wr, int wc,
-                                              int64_t m0, int64_t n0, int z, int nt_i) {
+// RAWBAR: the caller has LDS-DMA in flight (persistent plane-fed kernel): the opening barrier must not drain vmcnt.
+// Returns a LOWER bound of the vector-memory operations this wave issued and did not wait for (the streaming form's stores), which
+// the persistent kernel uses as the count of operations younger than its cross-tile prefetch.
+template <int TM, int TN, int WR, int WC, bool RAWBAR = false, bool NOSTREAM = false>
+__device__ __forceinline__ int gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[TM][TN], float* smem, int wave, int lane, int wr, int wc,
+                                             int64_t m0, int64_t n0, int z, int nt_i) {
   const int i = lane & 31, hi = lane >> 5;
   const advmil_epilogue_t& e = g.epi;
   const bool direct = (g.splits == 1);
@@ -412,13 +465,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[T
   const int64_t ldo = direct ? g.ldc : g.N;
   const bool vec_ok = ((ldo & 3) == 0) && (((uintptr_t)out & 15) == 0);
   float* const patch = smem + wave * EPI_WAVE_FLOATS(TM, TN);
-  __syncthreads();   // every wave is done reading the operand tiles
+  if constexpr (RAWBAR) {   // every wave is done reading the operand tiles (its fragment reads were consumed by its MFMAs)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  } else {
+    __syncthreads();
+  }
   // Gate-score mode (e.gate_wc): the columns are the interleaved branches of the gated attention scorer, col 2j = a_j (tanh),
   // col 2j+1 = b_j (sigmoid). Instead of storing C, each row's  sum_j tanh(.)_j * sigmoid(.)_j * wc_j  over this workgroup's
   // columns is reduced in registers / across the 8 lanes of a row and written to gate_out[row * gate_np + column-block]: the
   // no-grad generator pass then never writes (and gate_score never re-reads) the [rows, 2D] activations.
   const bool gate_mode = direct && e.gate_wc != nullptr;
-  if constexpr (TM * TN >= 4) {   // the slab-sized tiles (the 64x64 ... 64x192 tiles serve launch-bound shapes: generic path only)
+  if constexpr (TM * TN >= 4 && !NOSTREAM) {   // the slab-sized tiles (the 64x64 ... 64x192 tiles serve launch-bound shapes: generic path only)
     const int nmode = (e.rowv ? 1 : 0) + (e.maskref ? 1 : 0) + (e.accumulate ? 1 : 0);
     const bool stream = direct && !gate_mode && vec_ok && (g.N % (32 * TN * WC)) == 0 && (g.M % (32 * TM * WR)) == 0 && (e.act_split & 31) == 0 &&
                         nmode <= 1 && !(e.rowv && e.seed && e.rng_row) && (!e.bias || ((uintptr_t)e.bias & 15) == 0) && (!e.rowv || ((uintptr_t)e.colv & 15) == 0) &&
@@ -426,7 +485,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[T
                         (!e.c_hi || ((((uintptr_t)e.c_hi) | ((uintptr_t)e.c_lo)) & 7) == 0);
     if (stream) {
       gemm_epilogue_stream<TM, TN, WR, WC>(g, acc, patch, lane, wr, wc, m0, n0, key, inv_keep);
-      return;
+      return nmode == 0 ? TM * TN * 4 : 0;      // (with a prefetched per-element operand the stores are partly waited for)
     }
   }
 #pragma unroll
@@ -519,6 +578,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[T
       }
     }
   }
+  return 0;
 }
 
 // WR x WC waves per workgroup (2x2 = the 256-thread tiles; 4x2 = the 512-thread 256x192 / 256x128 tiles of the bf16x3 variant, whose
@@ -685,7 +745,7 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 || TM * TN > 4 ? 1 : 2))
 // gfx950 LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane, no VGPR round trip, no VALU), the inner loop is ds_read_b128 + MFMA
 // only, and the next chunk's DMA flies under the current chunk's MFMAs.
 //   workgroup = WR x 2 waves, each wave a 64 x (32*TN) accumulator block -> tile (64*WR) x (64*TN):
-//     WR = 4 (8 waves, one workgroup per CU): 256x128 / 256x192 / 256x256, k chunks of 32 -- the instantiated forms;
+//     WR = 4 (8 waves, one workgroup per CU): 256x128 / 256x192, k chunks of 32 -- the instantiated forms (256x256 measured equal);
 //     WR = 2 (4 waves, two workgroups per CU, whose prologue / epilogue would hide under the other's K loop): 128x128 (k 32)
 //       measured equal, 128x192 / 128x256 (k 16, 32-byte DMA rows) 10-15 % slower than the 8-wave forms on every slab shape, so
 //       they are not built (tools/gemm_planes_check.py history in DESIGN.md);
@@ -701,7 +761,15 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 || TM * TN > 4 ? 1 : 2))
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int TN, int NBUF, int WR, int BKT>
+// PERSISTENT: the grid is one workgroup per CU and each walks the tiles bid, bid + grid, ... (the same XCD-aware order as before:
+// the 256 workgroups in flight at any time hold consecutive tile ids). The k-chunk ring runs ACROSS tiles: the last NBUF-1 loop
+// iterations of a tile already fetch the next tile's first chunks (same per-lane source pointers plus a uniform row delta), the
+// epilogue works in the ring slot of the chunk just consumed, and the next tile's first wait is a counted one that leaves the
+// epilogue's stores in flight. Per tile this removes the cold start (first-chunk latency + workgroup launch: 5 of 55 us on the gate
+// contraction, tools/probe/stamp_gemm.sh) and lets the C stores drain under the next tile's K loop instead of at workgroup exit.
+// GATEONLY: instantiated for the fused gate score alone (its epilogue stores one partial per row and column block, no C): the
+// 256x256 form, which beside the streaming epilogue would not fit the register file.
+template <int TN, int NBUF, int WR, int BKT, bool GATEONLY = false>
 __global__ __launch_bounds__(128 * WR, 2) void gemm_nt_planes_kernel(GemmArgs g) {
   constexpr int TM = 2, WC = 2, NW = WR * WC;
   constexpr int BM_ = 64 * WR, BN_ = 64 * TN;
@@ -711,94 +779,138 @@ __global__ __launch_bounds__(128 * WR, 2) void gemm_nt_planes_kernel(GemmArgs g)
   static_assert(NPIECE % NW == 0, "pieces must divide evenly over the waves");
   constexpr int BUF_HW = ROWS_ALL * BKT;               // halfwords per buffer
   constexpr int PATCH_FLOATS = NW * EPI_WAVE_FLOATS(TM, TN);
-  constexpr int SMEM_FLOATS = (NBUF * BUF_HW / 2 > PATCH_FLOATS) ? NBUF * BUF_HW / 2 : PATCH_FLOATS;
-  __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+  static_assert(PATCH_FLOATS <= BUF_HW / 2, "the epilogue area must fit one ring slot");
+  constexpr int EST = TM * TN * 4;                     // stores per wave of the streaming epilogue (its lower bound)
+  static_assert(EST + PPW <= 63, "counted waits are 6-bit");
+  __shared__ __attribute__((aligned(16))) float smem[NBUF * BUF_HW / 2];
   bf16raw* const lds = reinterpret_cast<bf16raw*>(smem);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);     // uniform: lives in an SGPR
   const int wr = wave / WC, wc = wave % WC;
-  const int bid = blockIdx.x;
-  int mt_i, nt_i;
-  {   // XCD-aware tile order (see gemm_f32_kernel): the n-tiles of one A row panel run on one XCD, back to back
+  const int ntile = g.mtiles * g.ntiles, G = (int)gridDim.x;
+  auto tile_of = [&](int v, int& mt, int& nt) {   // XCD-aware tile order (see gemm_f32_kernel): the n-tiles of one A row panel run on one XCD
     const int inner = g.ntiles, outer = g.mtiles;
     const int per_group = 8 * inner, full = (outer / 8) * per_group;
-    if (bid < full) {
-      const int r = bid % per_group;
-      mt_i = (bid / per_group) * 8 + (r & 7);
-      nt_i = r >> 3;
+    if (v < full) {
+      const int r = v % per_group;
+      mt = (v / per_group) * 8 + (r & 7);
+      nt = r >> 3;
     } else {
-      const int rem = outer - (outer / 8) * 8, r = bid - full;
-      mt_i = (outer / 8) * 8 + r % rem;
-      nt_i = r / rem;
+      const int rem = outer - (outer / 8) * 8, r = v - full;
+      mt = (outer / 8) * 8 + r % rem;
+      nt = r / rem;
     }
-  }
-  const int64_t m0 = (int64_t)mt_i * BM_, n0 = (int64_t)nt_i * BN_;
-  // per-lane DMA sources: piece p = wave + NW*it covers plane rows [RPP*p, RPP*p + RPP) of the buffer image
-  const bf16raw* src[PPW];
-#pragma unroll
-  for (int it = 0; it < PPW; ++it) {
-    const int prow = (wave + NW * it) * RPP + lane / LPR;  // row in the buffer image
-    const bf16raw* base;
-    int r;                                                 // tile-local row of its operand
-    int64_t ld, row0;
-    if (prow < BM_) { base = reinterpret_cast<const bf16raw*>(g.epi.a_hi); r = prow; ld = g.lda; row0 = m0; }
-    else if (prow < 2 * BM_) { base = reinterpret_cast<const bf16raw*>(g.epi.a_lo); r = prow - BM_; ld = g.lda; row0 = m0; }
-    else if (prow < 2 * BM_ + BN_) { base = reinterpret_cast<const bf16raw*>(g.epi.b_hi); r = prow - 2 * BM_; ld = g.ldb; row0 = n0; }
-    else { base = reinterpret_cast<const bf16raw*>(g.epi.b_lo); r = prow - 2 * BM_ - BN_; ld = g.ldb; row0 = n0; }
-    src[it] = base + (row0 + r) * ld + ps_unit(r, lane % LPR, LPR) * 8;
-  }
-  auto dma = [&](int buf, int64_t k0) {
-#pragma unroll
-    for (int it = 0; it < PPW; ++it)
-      __builtin_amdgcn_global_load_lds((const GLB_AS void*)(src[it] + k0), (LDS_AS void*)(lds + buf * BUF_HW + (wave + NW * it) * 512), 16, 0, 0);
   };
-  f32x16 acc[TM][TN];
+  int v = (int)blockIdx.x;
+  int mt_i, nt_i;
+  tile_of(v, mt_i, nt_i);
+  // per-lane DMA sources: piece p = wave + NW*it covers plane rows [RPP*p, RPP*p + RPP) of the buffer image; which operand a piece
+  // belongs to is wave-uniform
+  // per-lane DMA sources: piece p = wave + NW*it covers plane rows [RPP*p, RPP*p + RPP) of the buffer image. Which plane a piece
+  // reads is wave-uniform, so a lane keeps one 32-bit byte offset per piece (planes < 4 GB: host check) and the plane's base, the
+  // k offset and the tile-to-tile row delta are added on the scalar side.
+  uint32_t soff[PPW];
+  // (recomputed for every tile instead of carried across the epilogue: there the accumulators + the streaming epilogue's operands
+  // already fill the register file)
+  auto set_src = [&](int mt, int nt, int lane) {
 #pragma unroll
-  for (int a = 0; a < TM; ++a)
+    for (int it = 0; it < PPW; ++it) {
+      const int prow = (wave + NW * it) * RPP + lane / LPR;  // row in the buffer image
+      int r;                                                 // tile-local row of its operand
+      int64_t ld, row0;
+      if (prow < BM_) { r = prow; ld = g.lda; row0 = (int64_t)mt * BM_; }
+      else if (prow < 2 * BM_) { r = prow - BM_; ld = g.lda; row0 = (int64_t)mt * BM_; }
+      else if (prow < 2 * BM_ + BN_) { r = prow - 2 * BM_; ld = g.ldb; row0 = (int64_t)nt * BN_; }
+      else { r = prow - 2 * BM_ - BN_; ld = g.ldb; row0 = (int64_t)nt * BN_; }
+      soff[it] = (uint32_t)(((row0 + r) * ld + ps_unit(r, lane % LPR, LPR) * 8) * 2);
+    }
+  };
+  set_src(mt_i, nt_i, (int)threadIdx.x & 63);
+  int64_t dA = 0, dB = 0;                                  // element offsets from this tile's rows to the next tile's
+  auto dma = [&](int buf, int64_t k0, bool next) {
 #pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-
+    for (int it = 0; it < PPW; ++it) {
+      const int p0 = (wave + NW * it) * RPP;               // uniform
+      const char* base = reinterpret_cast<const char*>(p0 < BM_ ? g.epi.a_hi : (p0 < 2 * BM_ ? g.epi.a_lo : (p0 < 2 * BM_ + BN_ ? g.epi.b_hi : g.epi.b_lo)));
+      base += (k0 + (next ? (p0 < 2 * BM_ ? dA : dB) : 0)) * 2;
+      __builtin_amdgcn_global_load_lds((const GLB_AS void*)(base + soff[it]), (LDS_AS void*)(lds + buf * BUF_HW + (wave + NW * it) * 512), 16, 0, 0);
+    }
+  };
   const int64_t K = g.K;
-  dma(0, 0);
-  if (NBUF == 3 && BKT < K) dma(1, BKT);               // three buffers: two chunks in flight
+  const int C = (int)(K / BKT);                            // >= NBUF - 1 (host check)
+  dma(0, 0, false);
+  if (NBUF == 3) dma(1, BKT, false);
   int cur = 0;
-  for (int64_t k0 = 0; k0 < K; k0 += BKT) {
-    if constexpr (NBUF == 3) {
-      // counted wait: this wave's pieces of chunk k0 have landed, the younger chunk's PPW pieces may still fly across the barrier
+  int young = 0;                                           // stores of the previous tile's epilogue still allowed in flight
+  for (; v < ntile; v += G) {
+    // Every per-lane constant of a tile (fragment addresses, epilogue geometry) is re-derived from an opaque copy of the lane id, so
+    // none of them is carried in a register across the epilogue of the previous tile (where the file is full: carried, they spilled)
+    int lane = (int)threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    const int i = lane & 31, hi = lane >> 5;
+    const bool has_next = v + G < ntile;
+    const int64_t m0 = (int64_t)mt_i * BM_, n0 = (int64_t)nt_i * BN_;
+    int mt_n = mt_i, nt_n = nt_i;
+    if (has_next) tile_of(v + G, mt_n, nt_n);
+    dA = (int64_t)(mt_n - mt_i) * BM_ * g.lda;
+    dB = (int64_t)(nt_n - nt_i) * BN_ * g.ldb;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    for (int c = 0; c < C; ++c) {
+      // counted wait: this wave's pieces of chunk c have landed; what may stay in flight is everything issued after them -- the
+      // younger chunk's PPW pieces (three buffers) and, in the first NBUF-1 iterations of a tile, the previous epilogue's stores
       // (a raw s_barrier: __syncthreads would drain vmcnt to 0 because an LDS-DMA is a pending LDS write)
-      if (k0 + BKT < K) wait_vmcnt<PPW>();
-      else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
+      const bool more = c + 1 < C || has_next;             // a younger chunk was issued (three buffers)
+      if constexpr (NBUF == 3) {
+        const bool st = young && c < 2;
+        if (more) { if (st) wait_vmcnt<PPW + EST>(); else wait_vmcnt<PPW>(); }
+        else { if (st) wait_vmcnt<EST>(); else wait_vmcnt<0>(); }
+      } else {
+        if (young && c == 0) wait_vmcnt<EST>(); else wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_s_barrier();                        // everyone's pieces have; and everyone is done with the slot refilled next
       asm volatile("" ::: "memory");
-      if (k0 + 2 * BKT < K) dma(cur == 0 ? 2 : cur - 1, k0 + 2 * BKT);
-    } else {
-      wait_vmcnt<0>();                                   // this wave's pieces of chunk k0 have landed
-      __syncthreads();                                   // everyone's have; and everyone is done reading buffer cur^1
-      if (k0 + BKT < K) dma(cur ^ 1, k0 + BKT);
+      {
+        const int pc = c + NBUF - 1;                       // chunk to prefetch, into the slot of chunk c - 1
+        const int pbuf = cur == 0 ? NBUF - 1 : cur - 1;
+        if (pc < C) dma(pbuf, (int64_t)pc * BKT, false);
+        else if (has_next) dma(pbuf, (int64_t)(pc - C) * BKT, true);
+      }
+      const bf16raw* cA = lds + cur * BUF_HW;
+      const bf16raw* cB = cA + 2 * BM_ * BKT;
+#pragma unroll
+      for (int ks = 0; ks < BKT / 16; ++ks) {
+        bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) read_frag_presplit<BM_, BKT>(cA, wr * 32 * TM + a * 32, ks, i, hi, ah[a], al[a]);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) read_frag_presplit<BN_, BKT>(cB, wc * 32 * TN + b * 32, ks, i, hi, bh[b], bl[b]);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+          }
+      }
+      cur = cur == NBUF - 1 ? 0 : cur + 1;
     }
-    const bf16raw* cA = lds + cur * BUF_HW;
-    const bf16raw* cB = cA + 2 * BM_ * BKT;
-#pragma unroll
-    for (int ks = 0; ks < BKT / 16; ++ks) {
-      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-      for (int a = 0; a < TM; ++a) read_frag_presplit<BM_, BKT>(cA, wr * 32 * TM + a * 32, ks, i, hi, ah[a], al[a]);
-#pragma unroll
-      for (int b = 0; b < TN; ++b) read_frag_presplit<BN_, BKT>(cB, wc * 32 * TN + b * 32, ks, i, hi, bh[b], bl[b]);
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-        }
+    // the epilogue's LDS area: the ring slot of the chunk just consumed (the other slots hold / receive the next tile's chunks; the
+    // slot is refilled only behind the next tile's first barrier, which every wave reaches after it has left the epilogue)
+    const int last = cur == 0 ? NBUF - 1 : cur - 1;
+    young = gemm_epilogue<TM, TN, WR, WC, true, GATEONLY>(g, acc, smem + last * (BUF_HW / 2), wave, lane, wr, wc, m0, n0, 0, nt_i);
+    mt_i = mt_n; nt_i = nt_n;
+    if (has_next) {
+      int lane2 = (int)threadIdx.x & 63;
+      asm volatile("" : "+v"(lane2));
+      set_src(mt_i, nt_i, lane2);
     }
-    if (NBUF == 3) cur = cur == 2 ? 0 : cur + 1; else cur ^= 1;
   }
-  gemm_epilogue<TM, TN, WR, WC>(g, acc, smem, wave, lane, wr, wc, m0, n0, 0, nt_i);
 }
 
 // split-K reduction + epilogue; one thread per 4 consecutive columns
@@ -930,14 +1042,17 @@ extern "C" int advmil_gemm_f32_plan_layout(int a_kc, int b_kc, int64_t M, int64_
   return plan_exact(M, N, K, tile, splits);
 }
 
-// Tile of the plane-fed NT kernel for this shape (82 / 83 / 84), or 0 when the shape does not qualify (then the generic kernel runs).
+// Tile of the plane-fed NT kernel for this shape (82 / 83), or 0 when the shape does not qualify (then the generic kernel runs).
 extern "C" int advmil_gemm_f32_plan_planes(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, int* tile) {
   if (!tile) return ADVMIL_EINVAL;
   *tile = 0;
   if (g_gemm_mode != 1 || !g_nt_planes || !a_kc || !b_kc || M < 4096 || (M % 256) || (K % 32) || (N % 128)) return ADVMIL_OK;
   const char* force = getenv("ADVMIL_NT_PLANES_TN");
-  int tnp = (N % 256 == 0) ? 4 : ((N % 192 == 0) ? 3 : 2);      // widest tile that divides N: most flops per staged byte
-  if (force && (force[0] == '2' || force[0] == '3' || force[0] == '4') && N % (64 * (force[0] - '0')) == 0) tnp = force[0] - '0';
+  // widest tile that divides N: most flops per staged byte. (A 256x256 form measured equal to 256x192 on every slab shape and, as a
+  // persistent kernel, no longer fits the register file beside the streaming epilogue: not built.)
+  int tnp = (N % 192 == 0) ? 3 : 2;
+  if (force && (force[0] == '2' || force[0] == '3') && N % (64 * (force[0] - '0')) == 0) tnp = force[0] - '0';
+  if (K < 64 || (uint64_t)M * (uint64_t)K * 2 >= (1ull << 32) || (uint64_t)N * (uint64_t)K * 2 >= (1ull << 32)) return ADVMIL_OK;
   if ((M / 256) * (N / (64 * tnp)) < 384) return ADVMIL_OK;      // one 8-wave workgroup per CU: fewer than ~1.5 waves of them lose to the small tiles
   *tile = 80 + tnp;
   return ADVMIL_OK;
@@ -1029,18 +1144,23 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
     if (splits != 1 || !epi->gate_out || (N & 3) || epi->drop_p > 0.0f) return ADVMIL_EINVAL;
     if (epi->gate_np != advmil_gemm_f32_gate_blocks(tile, N)) return ADVMIL_EINVAL;
   }
-  // NT form with both operands as planes: the LDS-DMA kernel (tile codes 82 / 83 / 84 = 256 x 128 / 192 / 256, 8 waves). The plan
+  // NT form with both operands as planes: the LDS-DMA kernel (tile codes 82 / 83 = 256 x 128 / 192, 8 waves). The plan
   // (advmil_gemm_f32_plan_planes, or tile 0 here) picks it whenever the shape qualifies; ADVMIL_NT_PLANES=0 turns it off.
   if (tile == 0 && pre == 3 && splits == 1) { int t = 0; advmil_gemm_f32_plan_planes(a_kc, b_kc, M, N, K, &t); if (t) tile = t; }
   if (tile >= 82 && tile <= 84) {
     const int tnp = tile % 10, bm = 256, bkt = 32;
+    if (tile == 84 && !epi->gate_wc) return ADVMIL_EINVAL;        // 256x256: the fused gate score only
     if (g_gemm_mode != 1 || !a_kc || !b_kc || pre != 3 || splits != 1 || (M % bm) || (K % bkt) || (N % (64 * tnp))) return ADVMIL_EINVAL;
     if (epi->gate_wc && (!epi->gate_out || epi->drop_p > 0.0f || epi->gate_np != advmil_gemm_f32_gate_blocks(tile, N))) return ADVMIL_EINVAL;
+    if (K < 64) return ADVMIL_EINVAL;                   // the three-slot ring prefetches two chunks ahead, across tiles
+    if ((uint64_t)M * (uint64_t)lda * 2 >= (1ull << 32) || (uint64_t)N * (uint64_t)ldb * 2 >= (1ull << 32)) return ADVMIL_EINVAL;   // 32-bit plane offsets
     g.mtiles = (int)(M / bm);
     g.ntiles = (int)(N / (64 * tnp));
-    dim3 pgrid(g.mtiles * g.ntiles);
+    static const int ncu = []() { int dev = 0, n = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    const int ntile_all = g.mtiles * g.ntiles;
+    dim3 pgrid(ntile_all < ncu ? ntile_all : ncu);        // persistent: one workgroup per CU walks its share of the tiles
     switch (tile) {
-      case 84: hipLaunchKernelGGL((gemm_nt_planes_kernel<4, 2, 4, 32>), pgrid, dim3(512), 0, stream, g); break;   // 2 x 64 KB
+      case 84: hipLaunchKernelGGL((gemm_nt_planes_kernel<4, 2, 4, 32, true>), pgrid, dim3(512), 0, stream, g); break;   // 2 x 64 KB
       case 83: hipLaunchKernelGGL((gemm_nt_planes_kernel<3, 2, 4, 32>), pgrid, dim3(512), 0, stream, g); break;   // 2 x 56 KB
       case 82: hipLaunchKernelGGL((gemm_nt_planes_kernel<2, 3, 4, 32>), pgrid, dim3(512), 0, stream, g); break;   // 3 x 48 KB: two chunks in flight
       default: return ADVMIL_EINVAL;

@@ -132,7 +132,7 @@ def gemm_plan(M, N, K, a_kc=True, b_kc=True):
 
 
 def gemm_plan_planes(M, N, K, a_kc=True, b_kc=True):
-    """Tile code (82 / 83 / 84) of the plane-fed LDS-DMA kernel for an NT contraction whose operands both come as Planes, or 0."""
+    """Tile code (82 / 83) of the plane-fed LDS-DMA kernel for an NT contraction whose operands both come as Planes, or 0."""
     key = ("pl", M, N, K, bool(a_kc), bool(b_kc), _lib.lib().advmil_get_gemm_mode())
     if key not in _PLAN_CACHE:
         t = ctypes.c_int(0)
@@ -221,6 +221,8 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
         ptile = gemm_plan_planes(M, N, K, a_kc, b_kc)          # both operands pre-split: the plane-fed LDS-DMA kernel, if the shape fits
         if ptile:
             tile, splits = ptile, 1
+            if gate_wc is not None and N % 256 == 0 and (M // 256) * (N // 256) >= 384:
+                tile = 84                                      # the fused gate score's own 256x256 form
     if gate_wc is not None:
         # fused gate score (advmil_epilogue_t.gate_wc): B / bias hold the INTERLEAVED branches; returns per-row partial scores
         # [M, column blocks] instead of C

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """bf16x3 mode: the slab-sized NT contractions with operands split on the fly (generic kernel) vs taken from pre-split planes
-through the plane-fed LDS-DMA kernel (tile 82/83/84), incl. bit-identity of the results and the fused gate-score mode."""
+through the plane-fed LDS-DMA kernel (tile 82/83), incl. bit-identity of the results and the fused gate-score mode."""
 import os
 import sys
 
@@ -39,7 +39,7 @@ for name, M, N, K in SHAPES:
     row = [name, f"plan={ops.gemm_plan(M, N, K)} planes_tile={ops.gemm_plan_planes(M, N, K)}"]
     us0 = bench(lambda: ops.gemm(A, B, True, True, M, N, K, out=out0, bias=bias, act0=1))
     row.append(f"fly {us0:.0f}us {2.0 * M * N * K / us0 / 1e6:.0f}TF")
-    for t in (82, 83, 84):
+    for t in (82, 83):
         if N % (64 * (t % 10)):
             continue
         ops.gemm(A, B, True, True, M, N, K, out=out1, bias=bias, act0=1, a_planes=pa, b_planes=pb, tile=t, splits=1)

@@ -15,16 +15,16 @@ p=sys.argv[1]; s=open(p).read()
 s=s.replace("#define GLB_AS __attribute__((address_space(1)))", '''#define GLB_AS __attribute__((address_space(1)))
 __device__ unsigned long long g_stamps[4 * 4096];
 extern "C" int advmil_debug_stamps(unsigned long long* dst, int n) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), (size_t)n * 8); }
-#define STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)''')
-old="  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;\n  const int i = lane & 31, hi = lane >> 5;\n  const int wr = wave / WC, wc = wave % WC;\n  const int bid = blockIdx.x;\n  int mt_i, nt_i;\n  {   // XCD-aware tile order (see gemm_f32_kernel): the n-tiles of one A row panel"
+#define STAMP(slot, k) do { if (threadIdx.x == 0 && (slot) < 4096) g_stamps[(slot) * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)''')
+old="    const int i = lane & 31, hi = lane >> 5;\n    const bool has_next = v + G < ntile;"
 assert old in s
-s=s.replace(old, "  STAMP(0);\n"+old)
-old="  dma(0, 0);\n  if (NBUF == 3 && BKT < K) dma(1, BKT);               // three buffers: two chunks in flight\n  int cur = 0;\n  for (int64_t k0 = 0; k0 < K; k0 += BKT) {"
+s=s.replace(old, "    STAMP(v, 0);\n"+old)
+old="      cur = cur == NBUF - 1 ? 0 : cur + 1;\n    }\n"
 assert old in s
-s=s.replace(old, old+"\n    if (k0 == BKT) STAMP(1);")
-old="    if (NBUF == 3) cur = cur == 2 ? 0 : cur + 1; else cur ^= 1;\n  }\n  gemm_epilogue<TM, TN, WR, WC>(g, acc, smem, wave, lane, wr, wc, m0, n0, 0, nt_i);\n}"
+s=s.replace(old, "      if (c == 0) STAMP(v, 1);\n"+old+"    STAMP(v, 2);\n")
+old="    mt_i = mt_n; nt_i = nt_n;\n    if (has_next) {"
 assert old in s
-s=s.replace(old, "    if (NBUF == 3) cur = cur == 2 ? 0 : cur + 1; else cur ^= 1;\n  }\n  STAMP(2);\n  gemm_epilogue<TM, TN, WR, WC>(g, acc, smem, wave, lane, wr, wc, m0, n0, 0, nt_i);\n  asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n  STAMP(3);\n}")
+s=s.replace(old, "    STAMP(v, 3);\n"+old)
 open(p,"w").write(s)
 PY
   /opt/rocm/bin/hipcc $FLAGS -c $P/gemm_stamp.hip -o $P/gemm_stamp.o
