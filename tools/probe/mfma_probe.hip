@@ -20,7 +20,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 union Frag { uint4 u; bf16x8 v; };
 
-template <int MODE, int WAVES>
+template <int MODE, int WAVES, int SRC = 0>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void probe(const uint4* __restrict__ src, float* __restrict__ out, int phases, const uint4* __restrict__ big) {
   __shared__ __attribute__((aligned(16))) uint4 lds[8192];   // 128 KB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -37,9 +37,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void probe(const uint4* __re
   const int grp = wave >> 2;
   constexpr bool STAGM = (MODE == 3 || MODE == 6 || MODE == 7);
   // DMA: the workgroup's private 64 KB region of `big` (L2 resident), 1 KB per piece, landing in the upper 64 KB of lds
-  const uint4* gsrc = big + (size_t)blockIdx.x * 4096 + wave * 512 + lane;
+  // SRC 0: a piece = 1 KB contiguous; SRC 1: 16 rows x 64 B out of 2 KB rows (the product kernel's pieces: half cache lines);
+  // SRC 2: 8 rows x 128 B out of 2 KB rows (full cache lines). The workgroup's region stays L2-sized in every form.
+  const uint4* gsrc = SRC == 0 ? big + (size_t)blockIdx.x * 4096 + wave * 512 + lane
+                    : SRC == 1 ? big + (size_t)blockIdx.x * 4096 * 4 + (size_t)(wave * 16 + (lane >> 2)) * 128 + (lane & 3)
+                               : big + (size_t)blockIdx.x * 4096 * 4 + (size_t)(wave * 8 + (lane >> 3)) * 128 + (lane & 7);
   auto piece = [&](int j) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + j * 64),
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + (SRC == 0 ? j * 64 : (SRC == 1 ? j * 4 : j * 8))),
                                      (__attribute__((address_space(3))) void*)(lds + 4096 + wave * 512 + j * 64), 16, 0, 0);
   };
   if (STAGM && grp == 1) __builtin_amdgcn_s_barrier();
@@ -87,15 +91,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void probe(const uint4* __re
   if (s == 1.2345f) out[tid] = s;
 }
 
-template <int MODE, int WAVES>
+template <int MODE, int WAVES, int SRC = 0>
 void run(const char* name, const uint4* src, float* out, int blocks, const uint4* big) {
   const int phases = 4096;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL((probe<MODE, WAVES>), dim3(blocks), dim3(64 * WAVES), 0, 0, src, out, 64, big);
+  hipLaunchKernelGGL((probe<MODE, WAVES, SRC>), dim3(blocks), dim3(64 * WAVES), 0, 0, src, out, 64, big);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  hipLaunchKernelGGL((probe<MODE, WAVES>), dim3(blocks), dim3(64 * WAVES), 0, 0, src, out, phases, big);
+  hipLaunchKernelGGL((probe<MODE, WAVES, SRC>), dim3(blocks), dim3(64 * WAVES), 0, 0, src, out, phases, big);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0.f;
@@ -108,7 +112,7 @@ void run(const char* name, const uint4* src, float* out, int blocks, const uint4
 int main() {
   uint4* src; float* out;
   hipMalloc(&src, 8192 * 16); hipMalloc(&out, 4096);
-  uint4* big; hipMalloc(&big, (size_t)256 * 65536); hipMemset(big, 0, (size_t)256 * 65536);
+  uint4* big; hipMalloc(&big, (size_t)256 * 65536 * 4); hipMemset(big, 0, (size_t)256 * 65536 * 4);
   for (int data = 0; data < 2; ++data) {
     std::vector<uint32_t> h(8192 * 4);
     uint32_t x = 12345;
@@ -127,6 +131,10 @@ int main() {
     run<3, 8>("two groups in anti-phase (2 barriers / phase)", src, out, 256, big);
     run<4, 8>("lockstep + DMA burst behind barrier", src, out, 256, big);
     run<5, 8>("lockstep + DMA 2 pieces / 12 MFMA", src, out, 256, big);
+    run<4, 8, 1>("lockstep + DMA burst, 16 rows x 64 B pieces", src, out, 256, big);
+    run<4, 8, 2>("lockstep + DMA burst, 8 rows x 128 B pieces", src, out, 256, big);
+    run<5, 8, 1>("lockstep + DMA spread, 16 rows x 64 B pieces", src, out, 256, big);
+    run<5, 8, 2>("lockstep + DMA spread, 8 rows x 128 B pieces", src, out, 256, big);
     run<6, 8>("anti-phase + 4 pieces in read interval", src, out, 256, big);
     run<7, 8>("anti-phase + 4 pieces behind barrier A", src, out, 256, big);
     run<1, 4>("MFMA + reads, 1 wave/SIMD", src, out, 256, big);

@@ -25,6 +25,7 @@ if [ "$what" = all ] || [ "$what" = gemm ]; then
     ADVMIL_GEMM_MODE=bf16x3 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS --output-format csv -d $O/gemm_${tag}_sq -- python3 tools/pmc_gemm.py $shape 1 1 6 > $O/gemm_${tag}_sq.log 2>&1
     ADVMIL_GEMM_MODE=bf16x3 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS --output-format csv -d $O/gemmpl_${tag}_sq -- python3 tools/pmc_gemm.py $shape 1 1 6 1 > $O/gemmpl_${tag}_sq.log 2>&1
     ADVMIL_GEMM_MODE=bf16x3 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/gemmpl_${tag}_fetch -- python3 tools/pmc_gemm.py $shape 1 1 8 1 > $O/gemmpl_${tag}_fetch.log 2>&1
+    ADVMIL_GEMM_MODE=bf16x3 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/gemmpl_${tag}_write -- python3 tools/pmc_gemm.py $shape 1 1 8 1 > $O/gemmpl_${tag}_write.log 2>&1
     ADVMIL_GEMM_MODE=bf16x3 rocprofv3 --kernel-trace --stats --output-format csv -d $O/gemm_${tag}_stats -- python3 tools/pmc_gemm.py $shape 1 1 12 > $O/gemm_${tag}_stats.log 2>&1
     ADVMIL_GEMM_MODE=bf16x3 rocprofv3 --kernel-trace --stats --output-format csv -d $O/gemmpl_${tag}_stats -- python3 tools/pmc_gemm.py $shape 1 1 12 1 > $O/gemmpl_${tag}_stats.log 2>&1
   done
