@@ -106,9 +106,11 @@ int advmil_gemm_f32_plan(int64_t M, int64_t N, int64_t K, int* tile, int* splits
  * advmil_gemm_f32 itself uses). advmil_gemm_f32_plan is the a_kc = b_kc = 1 case. */
 int advmil_gemm_f32_plan_layout(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, int* tile, int* splits);
 /* bf16x3 mode, NT form (a_kc = b_kc = 1) with BOTH operands supplied as planes (a_hi..b_lo): the tile of the plane-fed kernel that
- * stages global -> LDS by LDS-DMA (82 / 83 / 84 = 256 x 128 / 192 / 256, 8 waves; M % 256 == 0, K % 32 == 0, N % tile width == 0,
- * splits = 1), or 0 when the shape does not qualify. advmil_gemm_f32_tiled(tile = 0) makes the same choice; callers of the fused
- * gate-score mode need the tile up front for advmil_gemm_f32_gate_blocks. Results are bit-identical to the generic kernel's. */
+ * stages global -> LDS by LDS-DMA as a persistent kernel (82 / 83 = 256 x 128 / 192, 8 waves, one workgroup per CU walking the
+ * tiles; M % 256 == 0, K % 32 == 0 and K >= 64, N % tile width == 0, planes < 4 GB each, splits = 1), or 0 when the shape does not
+ * qualify. advmil_gemm_f32_tiled(tile = 0) makes the same choice; callers of the fused gate-score mode need the tile up front for
+ * advmil_gemm_f32_gate_blocks and may pass 84 (256 x 256, instantiated for that mode only) when N % 256 == 0. Results are
+ * bit-identical to the generic kernel's. */
 int advmil_gemm_f32_plan_planes(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, int* tile);
 /* Same, with an explicit block tile: tile = 10*TM + TN selects (64*TM) x (64*TN) output tiles
  * (22 = 128x128, 23 = 128x192, 13 = 64x192, 12 = 64x128, 11 = 64x64; 43 = 256x192, 42 = 256x128, 34 = 192x256, 24 = 128x256 with 512 threads,
