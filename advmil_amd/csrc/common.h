@@ -16,7 +16,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// ---- counter RNG: splitmix64(key + idx); restated on the host in advmil_amd/synth.py ----
+// ---- counter RNG: key = splitmix64 mix of (seed, stream), element = rng_hash32(key, idx); restated on the host in advmil_amd/synth.py ----
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   uint64_t z = x + 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -26,9 +26,23 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 __device__ __forceinline__ uint64_t rng_key(uint64_t seed, uint64_t stream) {
   return splitmix64(seed ^ splitmix64(stream));
 }
+// Per-element hash of (stream key, element index) -> 32 bits. The key of a call site is still a full splitmix64 mix of (seed,
+// stream) -- once per kernel --, but the per-ELEMENT function is 32-bit: a splitmix64 per element is two 64-bit multiplies = eight
+// quarter-rate 32-bit multiplies, which made gate_score (two draws per gate element, 10^8 per launch) and gate_bwd instruction-bound
+// instead of HBM-bound. Two rounds of a multiply-xorshift mixer (constants of the "lowbias32" family), the key's low word added
+// before the first round and its high word (and the index's high word, for tensors beyond 2^32 elements) folded in between the
+// rounds, so two streams are not index-shifted copies of each other. Restated on the host in advmil_amd/synth.py::kernel_hash32.
+__device__ __forceinline__ uint32_t rng_hash32(uint64_t key, uint64_t idx) {
+  uint32_t x = (uint32_t)idx + (uint32_t)key;
+  x ^= x >> 16; x *= 0x21f0aaadu;
+  x ^= (uint32_t)(key >> 32) ^ ((uint32_t)(idx >> 32) * 0x85ebca77u);
+  x ^= x >> 15; x *= 0x735a2d97u;
+  x ^= x >> 15;
+  return x;
+}
 // U[0,1) with 24 random bits
 __device__ __forceinline__ float rng_uniform(uint64_t key, uint64_t idx) {
-  return (float)(uint32_t)(splitmix64(key + idx) >> 40) * 5.9604644775390625e-8f;
+  return (float)(rng_hash32(key, idx) >> 8) * 5.9604644775390625e-8f;
 }
 // multiplicative dropout factor: 0 or 1/(1-p)
 __device__ __forceinline__ float rng_keep(uint64_t key, uint64_t idx, float p, float inv_keep) {

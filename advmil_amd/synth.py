@@ -56,14 +56,33 @@ def normal(key, n):
     return (np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)).astype(np.float32)
 
 
+def kernel_hash32(key, n, offset=0):
+    """csrc/common.h::rng_hash32 for the element indices offset .. offset+n-1 of the stream `key` (uint64) -> uint32 array."""
+    key = int(key) & 0xFFFFFFFFFFFFFFFF
+    klo, khi = np.uint32(key & 0xFFFFFFFF), np.uint32(key >> 32)
+    idx = np.arange(offset, offset + n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32) + klo
+        x ^= x >> np.uint32(16); x *= np.uint32(0x21F0AAAD)
+        x ^= khi ^ ((idx >> np.uint64(32)).astype(np.uint32) * np.uint32(0x85EBCA77))
+        x ^= x >> np.uint32(15); x *= np.uint32(0x735A2D97)
+        x ^= x >> np.uint32(15)
+    return x
+
+
+def kernel_uniform01(key, n, offset=0):
+    """float32 U[0,1) of the kernels' per-element draw: (rng_hash32 >> 8) * 2^-24."""
+    return (kernel_hash32(key, n, offset) >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
+
+
 def dropout_keep(seed, stream, n, p, offset=0):
     """Host restatement of the kernels' dropout decision: keep element i iff u_i >= p.
 
     `seed` is the step seed held in device memory, `stream` the per-call-site stream id;
-    the kernel hashes `mix(seed, stream) + i` (see csrc/rng.h: rng_key / rng_uniform).
+    the kernel hashes (mix(seed, stream), i) with the 32-bit element mixer (csrc/common.h: rng_key / rng_hash32 / rng_uniform).
     """
     key = rng_key(seed, stream)
-    return uniform01(key, n, offset) >= np.float32(p)
+    return kernel_uniform01(key, n, offset) >= np.float32(p)
 
 
 def rng_key(seed, stream) -> np.uint64:
@@ -91,8 +110,15 @@ def attn_dropout_keep(seed, stream, row_ids, nhead, head, n_keys, p):
     return half >= np.uint32(int(float(np.float32(p)) * 65536.0))
 
 
+def kernel_uniform(seed, stream, n, offset=0):
+    """U[0,1) exactly as the kernels draw it (generator noise, `utils/func.py:154-164`; advmil_uniform_fill)."""
+    return kernel_uniform01(rng_key(seed, stream), n, offset)
+
+
 def device_uniform(seed, stream, n, offset=0):
-    """U[0,1) exactly as the kernels draw it (generator noise, `utils/func.py:154-164`)."""
+    """U[0,1) vectors the golden fixtures were generated from (injected generator noise, C-index inputs): splitmix64 per element,
+    which is what the kernels drew in round 1. Kept bit for bit -- the fixtures' inputs are regenerated from it; the kernels' own
+    draw is `kernel_uniform`."""
     return uniform01(rng_key(seed, stream), n, offset)
 
 

@@ -37,7 +37,7 @@ def test_synth_is_deterministic_and_well_distributed():
     assert not np.array_equal(a, synth.bag(0, 4, 512))
     y = synth.label(0, 5)
     assert y.shape == (1, 2) and y[0, 1] == 1.0 and 0.05 <= y[0, 0] <= 0.95
-    u = synth.device_uniform(7, 3, 100000)
+    u = synth.kernel_uniform(7, 3, 100000)
     assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.01
     keep = synth.dropout_keep(7, 3, 100000, 0.25)
     assert abs(keep.mean() - 0.75) < 0.01

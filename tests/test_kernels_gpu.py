@@ -165,10 +165,10 @@ def test_colsum_and_abs_sum_and_uniform(ops):
     assert relerr(ops.abs_sum(x.to(DEV).reshape(-1)), x.double().abs().sum().reshape(1)) < 1e-5
     rng = ops.DeviceRng(DEV, seed=99)
     u = rng.uniform(1000)
-    assert np.array_equal(u.cpu().numpy(), synth.device_uniform(99, 1, 1000))
+    assert np.array_equal(u.cpu().numpy(), synth.kernel_uniform(99, 1, 1000))
     rng.advance(3)
     u2 = rng.uniform(10)
-    assert np.array_equal(u2.cpu().numpy(), synth.device_uniform(102, 2, 10))
+    assert np.array_equal(u2.cpu().numpy(), synth.kernel_uniform(102, 2, 10))
 
 
 def test_adam_matches_oracle(ops):

@@ -198,7 +198,7 @@ def test_train_mode_dropout_parity_vs_oracle(kind):
         ent = [e for e in rng.log if e[0] == tag]
         assert len(ent) == 1, (tag, [e[0] for e in rng.log])
         _, sid, shape, _ = ent[0]
-        u = synth.device_uniform(2024, sid, int(np.prod(shape))).reshape(shape)
+        u = synth.kernel_uniform(2024, sid, int(np.prod(shape))).reshape(shape)
         return H.T((u >= np.float32(p)).astype(np.float32) / (1 - p))
 
     L = N // 16
@@ -343,7 +343,7 @@ def test_patchgcn_vs_oracle(p_on):
             return H.T(synth.dropout_keep(77, e[1], int(np.prod(e[2])), e[3]).reshape(e[2]).astype(np.float32) / (1 - e[3]))
         def small(tag, p, shape):
             e = [e for e in rng.log if e[0] == tag][0]
-            u = synth.device_uniform(77, e[1], int(np.prod(shape))).reshape(shape)
+            u = synth.kernel_uniform(77, e[1], int(np.prod(shape))).reshape(shape)
             return H.T((u >= np.float32(p)).astype(np.float32) / (1 - p))
         masks = {"fc": mk("gcn_fc"), "phi": mk("gcn_phi"), "att_a": mk("gate_att_a"), "att_b": mk("gate_att_b"),
                  "mlp0": small("gen_mlp0.2", 0.6, (1, 64))}
