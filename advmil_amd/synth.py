@@ -3,8 +3,9 @@
 Everything is a pure function of (seed, tag, element index) through splitmix64, so the
 CPU oracle, the golden-fixture generator (which runs beside the reference in the build
 container) and the GPU box all see bit-identical inputs without shipping 33 MB bags.
-The same mixer is restated in `csrc/rng.h` for in-kernel dropout / generator noise, which
-lets a parity test regenerate a kernel's dropout mask on the host.
+The kernels' own dropout / generator-noise draw (csrc/common.h: a splitmix64 key per call site, a
+32-bit mixer per element) is restated here as `kernel_hash32` / `dropout_keep` / `kernel_uniform`,
+which lets a parity test regenerate a kernel's dropout mask on the host.
 
 Bag layout follows the reference loader (`dataset/PatchWSI.py:70-83`): one sample is
 `(idx[1,1] int32, (x[1,N,1024] f32, ext), y[1,2] = (t, e) f32)`.

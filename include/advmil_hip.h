@@ -13,8 +13,9 @@
  *  - every call is asynchronous on `stream` (a hipStream_t), never allocates, never syncs; it is
  *    safe under hipStreamBeginCapture (HIP graphs).
  *  - return value: 0 = ok, <0 = ADVMIL_E* (bad argument), >0 = hipError_t of the launch.
- *  - randomness (dropout, generator noise) is counter based: u = splitmix64(key(seed, stream_id)
- *    + element_index); `seed` is a DEVICE pointer to a uint64 so a captured graph can be
+ *  - randomness (dropout, generator noise) is counter based: u = top 24 bits of hash32(key(seed, stream_id),
+ *    element_index), key = splitmix64 mix of seed and stream id, hash32 = a two-round 32-bit multiply-xorshift
+ *    mixer (csrc/common.h::rng_hash32); `seed` is a DEVICE pointer to a uint64 so a captured graph can be
  *    replayed with a fresh seed; `stream_id` distinguishes call sites. NULL seed or p == 0
  *    disables dropout. advmil_amd/synth.py restates the generator on the host.
  */
