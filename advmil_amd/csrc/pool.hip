@@ -710,21 +710,21 @@ extern "C" int advmil_ln_relu_fwd(const float* y, const float* gamma, const floa
 }
 
 template <int QT>
-__global__ __launch_bounds__(256) void ln_relu_mean16_bwd_kernel(const float* __restrict__ demb, const float* __restrict__ y,
+__global__ __launch_bounds__(256, (QT <= 6 ? 4 : 2)) void ln_relu_mean16_bwd_kernel(const float* __restrict__ demb, const float* __restrict__ y,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  int64_t N, int64_t d, float* __restrict__ dy,
                                                                  float* __restrict__ partial, int pool16) {
-  __shared__ float red[4 * 1024];
+  __shared__ float red[4 * 1536];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   constexpr int Q = QT;      // 64-column groups per row (d <= 64 * QT)
-  float gm[QT], bt[QT], de[QT], ag[QT], abt[QT];
+  float gm[QT], bt[QT], de[QT], ag[QT], abt[QT], ady[QT];
 #pragma unroll
   for (int q = 0; q < QT; ++q) {
     const int64_t j = lane + 64 * q;
     const bool ok = q < Q && j < d;
     gm[q] = ok ? gamma[j] : 0.f; bt[q] = ok ? beta[j] : 0.f;
-    de[q] = 0.f; ag[q] = 0.f; abt[q] = 0.f;
+    de[q] = 0.f; ag[q] = 0.f; abt[q] = 0.f; ady[q] = 0.f;
   }
   const float invd = hw_rcp((float)d);
   const int64_t nreg = (N + 15) / 16;
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(256) void ln_relu_mean16_bwd_kernel(const float* __
         de[q] = (q < Q && j < d) ? demb[n * d + j] : 0.f;
       }
     }
-    float xh[QT], dxh[QT];
+    float xh[QT];
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
     for (int q = 0; q < QT; ++q) {
@@ -772,31 +772,38 @@ __global__ __launch_bounds__(256) void ln_relu_mean16_bwd_kernel(const float* __
       xh[q] = ok ? (ya[rr][q] - mu) * rs : 0.f;
       const float z = xh[q] * gm[q] + bt[q];
       const float dz = (ok && z > 0.f) ? de[q] : 0.f;
-      dxh[q] = dz * gm[q];
+      const float dxh = dz * gm[q];
       ag[q] += dz * xh[q];
       abt[q] += dz;
-      c1 += dxh[q];
-      c2 += dxh[q] * xh[q];
+      c1 += dxh;
+      c2 += dxh * xh[q];
     }
     c1 = wave_sum(c1) * invd;
     c2 = wave_sum(c2) * invd;
 #pragma unroll
     for (int q = 0; q < QT; ++q) {
       const int64_t j = lane + 64 * q;
-      if (q < Q && j < d) dy[n * d + j] = rs * (dxh[q] - c1 - xh[q] * c2);
+      if (q < Q && j < d) {
+        // (dz * gamma recomputed instead of carried through the two reductions: six registers that decide 3 vs 4 waves per SIMD)
+        const float dxh = ((xh[q] * gm[q] + bt[q]) > 0.f ? de[q] : 0.f) * gm[q];
+        const float v = rs * (dxh - c1 - xh[q] * c2);
+        dy[n * d + j] = v;
+        ady[q] += v;            // column sums of dy = the bias gradient of the layer that produced y (no second pass over dy)
+      }
     }
   }
   }
 #pragma unroll
   for (int q = 0; q < QT; ++q) {
     const int64_t j = lane + 64 * q;
-    if (q < Q && j < d) { red[w * 1024 + j] = ag[q]; red[w * 1024 + 512 + j] = abt[q]; }
+    if (q < Q && j < d) { red[w * 1536 + j] = ag[q]; red[w * 1536 + 512 + j] = abt[q]; red[w * 1536 + 1024 + j] = ady[q]; }
   }
   __syncthreads();
   const int64_t gp = blockIdx.x;
   for (int64_t j = threadIdx.x; j < d; j += 256) {
-    partial[gp * 2 * d + j] = red[j] + red[1024 + j] + red[2048 + j] + red[3072 + j];
-    partial[gp * 2 * d + d + j] = red[512 + j] + red[1536 + j] + red[2560 + j] + red[3584 + j];
+    partial[gp * 3 * d + j] = red[j] + red[1536 + j] + red[3072 + j] + red[4608 + j];
+    partial[gp * 3 * d + d + j] = red[512 + j] + red[2048 + j] + red[3584 + j] + red[5120 + j];
+    partial[gp * 3 * d + 2 * d + j] = red[1024 + j] + red[2560 + j] + red[4096 + j] + red[5632 + j];
   }
 }
 
@@ -804,12 +811,12 @@ __global__ __launch_bounds__(256) void ln_relu_mean16_bwd_kernel(const float* __
 static inline int ln_bwd_blocks(int64_t nreg) { return (int)(nreg < LN_BWD_MAXBLK ? nreg : LN_BWD_MAXBLK); }
 
 extern "C" size_t advmil_ln_relu_mean16_bwd_workspace_bytes(int64_t N, int64_t d) {
-  return (size_t)(ln_bwd_blocks(N / 16) * 2 * d) * sizeof(float);
+  return (size_t)(ln_bwd_blocks(N / 16) * 3 * d) * sizeof(float);
 }
 
 extern "C" int advmil_ln_relu_mean16_bwd(const float* demb, const float* y, const float* gamma, const float* beta,
                                          const float* mean, const float* rstd, int64_t N, int64_t d, float* dy,
-                                         float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes,
+                                         float* dgamma, float* dbeta, int accumulate, float* dycol, void* ws, size_t ws_bytes,
                                          advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!demb || !y || !gamma || !beta || !mean || !rstd || !dy || !dgamma || !dbeta || !ws || N <= 0 || (N & 15) || d <= 0 ||
@@ -820,14 +827,16 @@ extern "C" int advmil_ln_relu_mean16_bwd(const float* demb, const float* y, cons
   float* partial = (float*)ws;
   LN_DISPATCH(d, ln_relu_mean16_bwd_kernel, dim3(L), stream, demb, y, gamma, beta, mean, rstd, N, d, dy, partial, 1);
   ADVMIL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial, L, 2 * d, d, dgamma, accumulate);
-  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial + d, L, 2 * d, d, dbeta, accumulate);
+  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial, L, 3 * d, d, dgamma, accumulate);
+  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial + d, L, 3 * d, d, dbeta, accumulate);
+  if (dycol)      // += column sums of dy (the bias gradient of the FC that produced y), straight into the caller's accumulator
+    hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial + 2 * d, L, 3 * d, d, dycol, 1);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }
 
 extern "C" size_t advmil_ln_relu_bwd_workspace_bytes(int64_t N, int64_t d) {
-  return (size_t)(ln_bwd_blocks((N + 15) / 16) * 2 * d) * sizeof(float);
+  return (size_t)(ln_bwd_blocks((N + 15) / 16) * 3 * d) * sizeof(float);
 }
 
 extern "C" int advmil_ln_relu_bwd(const float* dout, const float* y, const float* gamma, const float* beta, const float* mean,
@@ -841,8 +850,8 @@ extern "C" int advmil_ln_relu_bwd(const float* dout, const float* y, const float
   float* partial = (float*)ws;
   LN_DISPATCH(d, ln_relu_mean16_bwd_kernel, dim3(L), stream, dout, y, gamma, beta, mean, rstd, N, d, dy, partial, 0);
   ADVMIL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial, L, 2 * d, d, dgamma, accumulate);
-  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial + d, L, 2 * d, d, dbeta, accumulate);
+  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial, L, 3 * d, d, dgamma, accumulate);
+  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial + d, L, 3 * d, d, dbeta, accumulate);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }

@@ -100,7 +100,14 @@ class AVGPoolPatchEmbedding(nn.Module):
         """x2[N_total, C] -> [N_total/16, out_dim]; rows may be a slab of bags (each bag a multiple of 16 rows, so the
         16-row regions never straddle two bags)."""
         assert x2.shape[0] % (self.scale * self.scale) == 0
-        y = ops.linear_act(x2, self.conv.weight, self.conv.bias, "none")
+        b = self.conv.bias
+        gb = ops._arena_grad(b) if (b is not None and b.requires_grad and torch.is_grad_enabled()) else None
+        if gb is not None:
+            # the FC's bias gradient is the column sum of dy, which the LayerNorm backward produces while it writes dy: the FC
+            # itself sees a constant bias and never re-reads dy (805 MB at the 32768-patch slab) for it
+            y = ops.linear_act(x2, self.conv.weight, b.detach(), "none")
+            return ops.ln_relu_mean16(y, self.norm.weight, self.norm.bias, self.norm.eps, ycol_grad=gb.view(-1))
+        y = ops.linear_act(x2, self.conv.weight, b, "none")
         return ops.ln_relu_mean16(y, self.norm.weight, self.norm.bias, self.norm.eps)
 
     def forward(self, x):

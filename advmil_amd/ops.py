@@ -428,7 +428,8 @@ def ln_relu_mean16_fwd(y, gamma, beta, N, d, eps=1e-5):
     return emb, mean, rstd
 
 
-def ln_relu_mean16_bwd(demb, y, gamma, beta, mean, rstd, N, d, dg_out=None, db_out=None):
+def ln_relu_mean16_bwd(demb, y, gamma, beta, mean, rstd, N, d, dg_out=None, db_out=None, ycol_out=None):
+    """ycol_out: optional [d] accumulator that receives += column sums of dy (the bias gradient of the FC that produced y)."""
     L = _lib.lib()
     dev = y.device
     dy = torch.empty(N, d, dtype=torch.float32, device=dev)
@@ -438,7 +439,7 @@ def ln_relu_mean16_bwd(demb, y, gamma, beta, mean, rstd, N, d, dg_out=None, db_o
     wsb = L.advmil_ln_relu_mean16_bwd_workspace_bytes(N, d)
     ws = _ws(wsb, dev)
     _lib.check(L.advmil_ln_relu_mean16_bwd(_p(demb), _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), N, d, _p(dy), _p(dg),
-                                           _p(db), 1 if acc else 0, _p(ws), wsb, _stream()), "ln_relu_mean16_bwd")
+                                           _p(db), 1 if acc else 0, _p(ycol_out), _p(ws), wsb, _stream()), "ln_relu_mean16_bwd")
     return dy, dg, db
 
 
@@ -748,7 +749,7 @@ class LNReLUMean16Fn(torch.autograd.Function):
     (model/backbone_utils.py:161-167)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, eps):
+    def forward(ctx, y, gamma, beta, eps, ycol=None):
         _chk(y, "y")
         y = y.contiguous()
         N, d = y.shape
@@ -756,6 +757,7 @@ class LNReLUMean16Fn(torch.autograd.Function):
         ctx.save_for_backward(y, gamma.detach(), beta.detach(), mean, rstd)
         gg, gb = _arena_grad(gamma), _arena_grad(beta)
         ctx.arena = (gg, gb) if (gg is not None and gb is not None) else None
+        ctx.ycol = ycol
         return emb
 
     @staticmethod
@@ -763,14 +765,16 @@ class LNReLUMean16Fn(torch.autograd.Function):
         y, gamma, beta, mean, rstd = ctx.saved_tensors
         N, d = y.shape
         if ctx.arena is not None:
-            dy, _, _ = ln_relu_mean16_bwd(demb.contiguous(), y, gamma, beta, mean, rstd, N, d, ctx.arena[0], ctx.arena[1])
-            return dy, None, None, None
-        dy, dg, db = ln_relu_mean16_bwd(demb.contiguous(), y, gamma, beta, mean, rstd, N, d)
-        return dy, dg, db, None
+            dy, _, _ = ln_relu_mean16_bwd(demb.contiguous(), y, gamma, beta, mean, rstd, N, d, ctx.arena[0], ctx.arena[1], ctx.ycol)
+            return dy, None, None, None, None
+        dy, dg, db = ln_relu_mean16_bwd(demb.contiguous(), y, gamma, beta, mean, rstd, N, d, ycol_out=ctx.ycol)
+        return dy, dg, db, None, None
 
 
-def ln_relu_mean16(y, gamma, beta, eps=1e-5):
-    return LNReLUMean16Fn.apply(y, gamma, beta, eps)
+def ln_relu_mean16(y, gamma, beta, eps=1e-5, ycol_grad=None):
+    """`ycol_grad`: optional [d] gradient accumulator (an arena slot) that receives += column sums of dy in the backward -- the bias
+    gradient of the FC that produced y, for callers that hand that FC a detached bias."""
+    return LNReLUMean16Fn.apply(y, gamma, beta, eps, ycol_grad)
 
 
 class GateScoreFn(torch.autograd.Function):

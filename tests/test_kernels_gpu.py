@@ -139,6 +139,12 @@ def test_ln_relu_mean16(ops, N, d):
     assert relerr(emb, z) < 1e-5
     for got, want in zip(lv, rv):
         assert relerr(got.grad, want.grad) < 5e-5
+    # the same backward also hands out the column sums of dy (bias gradient of the FC that produced y), added into an accumulator
+    acc = torch.full((d,), 0.5, device=DEV)
+    lv2 = [t.clone().to(DEV).requires_grad_(True) for t in (y, g, b)]
+    (ops.ln_relu_mean16(*lv2, ycol_grad=acc) * ge.to(DEV)).sum().backward()
+    assert relerr(acc, rv[0].grad.sum(0) + 0.5) < 5e-5
+    assert torch.equal(lv2[0].grad, lv[0].grad)
 
 
 @pytest.mark.parametrize("act,p", [("relu", 0.25), ("tanh", 0.0), ("sigmoid", 0.25), ("none", 0.0), ("none", 0.5)])
