@@ -353,52 +353,47 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
       rK.load(Kb, a.ldq, kb + AT_KT, Lg, tid);
       rV.load(Vb, a.ldq, kb + AT_KT, Lg, tid);
     }
-    f32x16 s[2], dp[2];
+    // one 32-key sub-tile at a time through scores -> dS -> dQ: only one pair of 32x32 accumulators is live (both sub-tiles at once
+    // put the dropout instantiation 5 registers over the file: 20 bytes of scratch)
+    const bool tail = kb + AT_KT > Lg;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
+      f32x16 st, dpt;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[t][r] = 0.f; dp[t][r] = 0.f; }
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const bf16x8 kh = frag_rows(sK, 32 * t + j, 16 * ks + 8 * half);
         const bf16x8 kl = frag_rows(sK + AT_PLANE, 32 * t + j, 16 * ks + 8 * half);
-        MFMA3(s[t], kh, kl, qh[ks], ql[ks]);                 // S^T[key, q]
+        MFMA3(st, kh, kl, qh[ks], ql[ks]);                   // S^T[key, q]
         const bf16x8 vh = frag_rows(sV, 32 * t + j, 16 * ks + 8 * half);
         const bf16x8 vl = frag_rows(sV + AT_PLANE, 32 * t + j, 16 * ks + 8 * half);
-        MFMA3(dp[t], vh, vl, gh[ks], gl[ks]);                // dPd^T[key, q] = V . dO^T
+        MFMA3(dpt, vh, vl, gh[ks], gl[ks]);                  // dPd^T[key, q] = V . dO^T
       }
-    }
-    const bool tail = kb + AT_KT > Lg;
-    if (DROP) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
+      if (DROP) {
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const uint32_t jp = (uint32_t)(kb + 32 * t + 8 * rg + 4 * half) >> 1;
           const uint32_t h0 = attn_hash(rk, jp), h1 = attn_hash(rk, jp + 1);
-          if ((h0 & 0xffffu) < a.drop_thr) dp[t][4 * rg] = 0.f;
-          if ((h0 >> 16) < a.drop_thr) dp[t][4 * rg + 1] = 0.f;
-          if ((h1 & 0xffffu) < a.drop_thr) dp[t][4 * rg + 2] = 0.f;
-          if ((h1 >> 16) < a.drop_thr) dp[t][4 * rg + 3] = 0.f;
+          if ((h0 & 0xffffu) < a.drop_thr) dpt[4 * rg] = 0.f;
+          if ((h0 >> 16) < a.drop_thr) dpt[4 * rg + 1] = 0.f;
+          if ((h1 & 0xffffu) < a.drop_thr) dpt[4 * rg + 2] = 0.f;
+          if ((h1 >> 16) < a.drop_thr) dpt[4 * rg + 3] = 0.f;
         }
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t key = kb + 32 * t + ACC_ROW(r, half);
-        float p = hw_exp2(s[t][r] - lse_q);
+        float p = hw_exp2(st[r] - lse_q);
         if (tail && key >= Lg) p = 0.f;
-        s[t][r] = p * (dp[t][r] * ik - d_q);                 // dS^T
+        st[r] = p * (dpt[r] * ik - d_q);                     // dS^T
       }
-    // dQ^T[d, q] += K^T[d, key] . dS^T[key, q]
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
+      // dQ^T[d, q] += K^T[d, key] . dS^T[key, q]
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = s[t][8 * s2 + u];
+        for (int u = 0; u < 8; ++u) v[u] = st[8 * s2 + u];
         bf16x8 dh, dl;
         split8(v, dh, dl);
 #pragma unroll
@@ -408,6 +403,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
           MFMA3(dq[dt], kh, kl, dh, dl);
         }
       }
+    }
   }
   if (qok) {
     float* const drow = a.dqkv + (row0 + q) * a.ldq + h * HD;
