@@ -43,6 +43,20 @@ def _check_configs(cfg):
     assert cfg["gen_out_scale"] in ("sigmoid", "exp", "none", None)
 
 
+class LazyLog:
+    """A logged record whose numbers are derived on the host when the log is read: `tensors` are device tensors the step wrote
+    (a HIP-graph replay rewrites them in place), `fn(*lists)` maps their values to the record."""
+
+    def __init__(self, tensors, fn):
+        self.tensors, self.fn = tuple(tensors), fn
+
+    def resolve(self):
+        import numpy as np
+        vals = [np.asarray(t.detach().float().cpu().tolist(), dtype=np.float32) for t in self.tensors]     # fp32 arithmetic, as on the device
+        out = self.fn(*vals)
+        return {k: (float(v) if not isinstance(v, int) else v) for k, v in out.items()}
+
+
 class MyHandler(object):
     def __init__(self, cfg, device=None, parallel=None):
         _check_configs(cfg)
@@ -127,9 +141,18 @@ class MyHandler(object):
     def log(self, d):
         self.history.append(d)
 
+    @staticmethod
+    def resolve_log(d):
+        """One history entry -> dict of python numbers. An entry is a dict of device scalars, or a LazyLog: the step's statistics
+        tensor(s) plus the host arithmetic that turns them into the logged quantities (the divisions by the global counts, the
+        L1 term, the sign flip), evaluated here instead of as four or five one-element launches inside every optimizer step."""
+        if isinstance(d, LazyLog):
+            return d.resolve()
+        return {k: (float(v) if torch.is_tensor(v) else v) for k, v in d.items()}
+
     def pop_logs(self):
         """Device scalars -> python floats (one sync for the whole backlog)."""
-        out = [{k: (float(v) if torch.is_tensor(v) else v) for k, v in d.items()} for d in self.history]
+        out = [self.resolve_log(d) for d in self.history]
         self.history = []
         return out
 
@@ -266,7 +289,7 @@ class MyHandler(object):
         seg16.twice()                                    # (built here: the D update stacks its fake and real passes)
         seg16.rng_rowoff = rowoff16
         self._plan_count = getattr(self, "_plan_count", 0) + 1
-        return SimpleNamespace(vis=vis, is_real=is_real, n_real=n_real, n_fake=n_fake, n_vis=n_vis,
+        return SimpleNamespace(vis=vis, is_real=is_real, n_real=n_real, n_fake=n_fake, n_vis=n_vis, y=torch.cat(ys, dim=0),
                                vis_mask=None if all(vis) else masks_d[n:], real_mask=masks_d[:n], seg=seg, seg16=seg16,
                                rng_rows=rng_rows, token=self._plan_count, _keep=(masks, masks_d))
 
@@ -349,7 +372,7 @@ class MyHandler(object):
         self.rng.rows = plan.rng_rows
         self.optimizerD.zero_grad()
         X = self._slab(xs)
-        y = torch.cat(ys, dim=0)
+        y = plan.y                           # [B, 2] label stack, built once per step plan
         ops.MEMO.begin("record", ("G", id(self.netG), getattr(self.optimizerG, "n_updates", 0), plan.token), X)
         try:
             with torch.no_grad():                                              # the reference builds, then detaches (400)
@@ -375,12 +398,19 @@ class MyHandler(object):
             f_fake = self.netD.tail(eb, im, pred).view(-1)
         # real_fake_loss with the global denominators (loss/utils.py:182-203, model_handler.py:412) as ONE launch that also yields
         # d loss / d score; the real pairs are selected by a 0/1 mask (same sum as f_real[event & visible], no index backward)
-        loss, st = ops.gan_d_loss(f_fake, f_real, None if f_real is None else plan.real_mask, self.which_loss, plan.n_fake, plan.n_real)
-        loss.backward()
+        loss, st = ops.gan_d_loss(f_fake, f_real, None if f_real is None else plan.real_mask, self.which_loss, plan.n_fake, plan.n_real,
+                                  root=True)
+        torch.autograd.backward(loss, grad_tensors=self._one())      # (the root gradient is a cached 1: no fill launch per step)
         self._st_d = (st, plan, i_batch)     # this rank's partial sums over the global denominators; reduced + logged in _disc_apply
         preds = list(pred.split(1, dim=0))
         fakes = list(f_fake.detach().split(1, dim=0))
         return preds, fakes
+
+    def _one(self):
+        t = self.__dict__.get("_one_t")
+        if t is None:
+            t = self.__dict__["_one_t"] = torch.ones((), dtype=torch.float32, device=self.device)
+        return t
 
     def _reduce_d(self):
         """Bag-parallel exchange of the D update: the flat gradient arena and the step's three loss statistics."""
@@ -389,8 +419,9 @@ class MyHandler(object):
 
     def _log_d(self):
         st, plan, i_batch = self._st_d
-        self.log({"train_batch/netD/Loss_D": st[0], "train_batch/netD/D_real": st[1] / max(plan.n_real, 1),
-                  "train_batch/netD/D_fake": st[2] / plan.n_fake, "i_batch": i_batch})
+        nr, nf = max(plan.n_real, 1), plan.n_fake
+        self.log(LazyLog((st,), lambda v: {"train_batch/netD/Loss_D": v[0], "train_batch/netD/D_real": v[1] / nr,
+                                           "train_batch/netD/D_fake": v[2] / nf, "i_batch": i_batch}))
 
     def _disc_apply(self):
         self._reduce_d()
@@ -473,14 +504,14 @@ class MyHandler(object):
                 p.requires_grad_(True)
         # gen_total = recon_loss over the visible labels + coef * (-mean f_fake) (model_handler.py:468-486) as ONE launch that also
         # yields the gradients w.r.t. pred and f_fake
-        y = torch.cat(ys, dim=0)
+        y = plan.y
         n_vis = plan.n_vis if (plan.n_vis > 0 and any(plan.vis)) else 0
         if self.dp.world > 1:
             n_vis = plan.n_vis
         rc = self._recon
         total, st = ops.gan_g_loss(pred, f_fake, y[:, 0:1], y[:, 1:2], plan.vis_mask, rc["alpha"], rc["gamma"], rc["norm"],
-                                   self.coef_ganloss, plan.n_fake, n_vis)
-        total.backward()
+                                   self.coef_ganloss, plan.n_fake, n_vis, root=True)
+        torch.autograd.backward(total, grad_tensors=self._one())
         self._st_g = (st, i_batch)
 
     def _reduce_g(self):
@@ -489,11 +520,11 @@ class MyHandler(object):
 
     def _log_g(self):
         st, i_batch = self._st_g
-        total = st[0]
-        if self.coef_l1 > 1e-8:              # added once, after the reduce: the L1 term is not a per-bag sum
-            total = total + self.coef_l1 * ops.abs_sum(self.optimizerG.flat_param)[0]
-        self.log({"train_batch/netG/Loss_G_fake": st[2], "train_batch/netG/Loss_G_time": st[1],
-                  "train_batch/netG/Loss_G_total": total, "train_batch/netG/D_fake_avg": -st[2], "i_batch": i_batch})
+        c1 = self.coef_l1 if self.coef_l1 > 1e-8 else 0.0      # added once, after the reduce: the L1 term is not a per-bag sum
+        tens = (st, ops.abs_sum(self.optimizerG.flat_param)) if c1 else (st,)
+        self.log(LazyLog(tens, lambda v, a=None: {"train_batch/netG/Loss_G_fake": v[2], "train_batch/netG/Loss_G_time": v[1],
+                                                  "train_batch/netG/Loss_G_total": v[0] + (c1 * a[0] if a is not None else 0.0),
+                                                  "train_batch/netG/D_fake_avg": -v[2], "i_batch": i_batch}))
 
     def _gen_apply(self):
         self._reduce_g()

@@ -1093,7 +1093,8 @@ class GanDLossFn(torch.autograd.Function):
     """loss = sum_i term_f(fake_i) / n_fake + sum_i mask_i term_r(real_i) / n_real; also returns sum mask*real and sum fake."""
 
     @staticmethod
-    def forward(ctx, fake, real, mask, which, inv_nf, inv_nr):
+    def forward(ctx, fake, real, mask, which, inv_nf, inv_nr, root=False):
+        ctx.root = root
         fake = fake.contiguous().reshape(-1)
         nr = 0 if real is None else real.numel()
         real_c = None if real is None else real.contiguous().reshape(-1)
@@ -1111,17 +1112,22 @@ class GanDLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, go, _):
         gf, gr = ctx.saved_tensors
-        return gf * go, (gr * go).reshape(ctx.shapes[1]) if ctx.has_real else None, None, None, None, None
+        if ctx.root:          # the caller backpropagates from this loss itself (upstream gradient 1): the analytic gradients as they are
+            return gf, gr.reshape(ctx.shapes[1]) if ctx.has_real else None, None, None, None, None, None
+        return gf * go, (gr * go).reshape(ctx.shapes[1]) if ctx.has_real else None, None, None, None, None, None
 
 
-def gan_d_loss(fake, real, real_mask, which, n_fake, n_real):
-    """-> (loss [0-dim, differentiable], stats[3] = {loss, sum mask*real, sum fake})."""
-    return GanDLossFn.apply(fake, real, real_mask, _WHICH[which], 1.0 / float(n_fake), (1.0 / float(n_real)) if n_real > 0 else 0.0)
+def gan_d_loss(fake, real, real_mask, which, n_fake, n_real, root=False):
+    """-> (loss [0-dim, differentiable], stats[3] = {loss, sum mask*real, sum fake}). root=True: the loss is what the caller calls
+    backward on (upstream gradient 1), so the backward hands out the analytic gradients without two multiply launches."""
+    return GanDLossFn.apply(fake, real, real_mask, _WHICH[which], 1.0 / float(n_fake), (1.0 / float(n_real)) if n_real > 0 else 0.0,
+                            root)
 
 
 class GanGLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, fake, t, e, vis, alpha, gamma, l2, coef, inv_nf, inv_nv):
+    def forward(ctx, pred, fake, t, e, vis, alpha, gamma, l2, coef, inv_nf, inv_nv, root=False):
+        ctx.root = root
         shape = pred.shape
         pred_c, fake_c = pred.contiguous().reshape(-1), fake.contiguous().reshape(-1)
         out = torch.empty(3, dtype=torch.float32, device=pred.device)
@@ -1137,13 +1143,15 @@ class GanGLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, go, _):
         gp, gf = ctx.saved_tensors
-        return (gp * go).reshape(ctx.shapes[0]), (gf * go).reshape(ctx.shapes[1]), None, None, None, None, None, None, None, None, None
+        if ctx.root:
+            return (gp.reshape(ctx.shapes[0]), gf.reshape(ctx.shapes[1])) + (None,) * 10
+        return ((gp * go).reshape(ctx.shapes[0]), (gf * go).reshape(ctx.shapes[1])) + (None,) * 10
 
 
-def gan_g_loss(pred, fake, t, e, vis_mask, alpha, gamma, norm, coef, n_fake, n_vis):
+def gan_g_loss(pred, fake, t, e, vis_mask, alpha, gamma, norm, coef, n_fake, n_vis, root=False):
     """-> (total [0-dim, differentiable], stats[3] = {total, reg, gen}); reg = 0 when no label is visible (n_vis == 0)."""
     return GanGLossFn.apply(pred, fake, t, e, vis_mask, float(alpha), float(gamma), 1 if norm == "l2" else 0, float(coef),
-                            1.0 / float(n_fake), (1.0 / float(n_vis)) if n_vis > 0 else 0.0)
+                            1.0 / float(n_fake), (1.0 / float(n_vis)) if n_vis > 0 else 0.0, root)
 
 
 class SkinnyLinearFn(torch.autograd.Function):

@@ -218,9 +218,8 @@ class Case:
 
     def logs_finite(self):
         h = self.h
-        logs = h.pop_logs() if not self.graphs else [{k: float(v) for k, v in d.items() if k != "i_batch"}
-                                                     for g in self.graphs for d in g.logs]
-        return all(v == v and abs(v) != float("inf") for d in logs for v in d.values())
+        logs = h.pop_logs() if not self.graphs else [h.resolve_log(d) for g in self.graphs for d in g.logs]
+        return all(v == v and abs(v) != float("inf") for d in logs for k, v in d.items() if k != "i_batch")
 
     def free(self):
         self.graphs, self.xs, self.ys, self.h = [], None, None, None
