@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256) void act_dropout_bwd_kernel(const float* __res
                                                               int64_t M, int64_t N, int64_t c0, int64_t W,
                                                               float* __restrict__ dpre, float* __restrict__ partial,
                                                               int64_t pstride, int rpb, const int64_t* __restrict__ rng_row,
-                                                              bf16raw* __restrict__ o_hi, bf16raw* __restrict__ o_lo) {
+                                                              bf16raw* __restrict__ o_hi, bf16raw* __restrict__ o_lo, int direct) {
   __shared__ __attribute__((aligned(16))) float red[1024];
   const RowColMap m = make_map(W);
   const bool drop = seed && p > 0.f;
@@ -543,8 +543,13 @@ __global__ __launch_bounds__(256) void act_dropout_bwd_kernel(const float* __res
     }
   }
   if (partial) {
-    const float4 t = reduce_rows(sum, m, red);
-    if (m.active && m.r == 0) *reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * pstride + c0 + m.c4 * 4) = t;
+    float4 t = reduce_rows(sum, m, red);
+    // direct (a single block covers every row: the [B, d] layers): `partial` IS the bias-gradient buffer (1: store, 2: add into)
+    if (m.active && m.r == 0) {
+      float4* dst = reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * pstride + c0 + m.c4 * 4);
+      if (direct == 2) { const float4 o = *dst; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+      *dst = t;
+    }
   }
 }
 
@@ -562,14 +567,15 @@ extern "C" int advmil_act_dropout_bwd(const float* dy, const float* y, int act, 
   if (dbias && (!ws || ws_bytes < advmil_colsum_workspace_bytes(M, N))) return ADVMIL_EWORKSPACE;
   const int rpb = rows_per_block(M);
   const int nblk = (int)((M + rpb - 1) / rpb);
-  float* partial = dbias ? (float*)ws : nullptr;
+  const bool direct = dbias && nblk == 1 && (((uintptr_t)dbias) & 15) == 0;      // one block sees every row: no partials, no merge launch
+  float* partial = dbias ? (direct ? dbias : (float*)ws) : nullptr;
   for (int64_t c0 = 0; c0 < N; c0 += 1024) {
     const int64_t W = (N - c0 < 1024) ? (N - c0) : 1024;
     hipLaunchKernelGGL(act_dropout_bwd_kernel, dim3(nblk), dim3(256), 0, stream, dy, y, act, drop_p, seed, stream_id, M, N,
-                       c0, W, dpre, partial, N, rpb, rng_row, (bf16raw*)out_hi, (bf16raw*)out_lo);
+                       c0, W, dpre, partial, N, rpb, rng_row, (bf16raw*)out_hi, (bf16raw*)out_lo, direct ? (accumulate ? 2 : 1) : 0);
   }
   ADVMIL_LAUNCH_CHECK();
-  if (dbias) {
+  if (dbias && !direct) {
     hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(N), dim3(256), 0, stream, partial, nblk, N, N, dbias, accumulate);
     ADVMIL_LAUNCH_CHECK();
   }
@@ -577,7 +583,7 @@ extern "C" int advmil_act_dropout_bwd(const float* dy, const float* y, int act, 
 }
 
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int64_t M, int64_t N, int64_t c0,
-                                                             int64_t W, float* __restrict__ partial, int rpb) {
+                                                             int64_t W, float* __restrict__ partial, int rpb, int direct) {
   __shared__ __attribute__((aligned(16))) float red[1024];
   const RowColMap m = make_map(W);
   const int64_t r0 = (int64_t)blockIdx.x * rpb;
@@ -590,8 +596,12 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
       sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
     }
   }
-  const float4 t = reduce_rows(sum, m, red);
-  if (m.active && m.r == 0) *reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * N + c0 + m.c4 * 4) = t;
+  float4 t = reduce_rows(sum, m, red);
+  if (m.active && m.r == 0) {
+    float4* dst = reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * N + c0 + m.c4 * 4);
+    if (direct == 2) { const float4 o = *dst; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+    *dst = t;
+  }
 }
 
 extern "C" int advmil_colsum(const float* x, int64_t M, int64_t N, float* out, int accumulate, void* ws, size_t ws_bytes,
@@ -601,11 +611,13 @@ extern "C" int advmil_colsum(const float* x, int64_t M, int64_t N, float* out, i
   if (ws_bytes < advmil_colsum_workspace_bytes(M, N)) return ADVMIL_EWORKSPACE;
   const int rpb = rows_per_block(M);
   const int nblk = (int)((M + rpb - 1) / rpb);
+  const bool direct = nblk == 1 && (((uintptr_t)out) & 15) == 0;
   for (int64_t c0 = 0; c0 < N; c0 += 1024) {
     const int64_t W = (N - c0 < 1024) ? (N - c0) : 1024;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, x, M, N, c0, W, (float*)ws, rpb);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, x, M, N, c0, W, direct ? out : (float*)ws, rpb,
+                       direct ? (accumulate ? 2 : 1) : 0);
   }
-  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(N), dim3(256), 0, stream, (const float*)ws, nblk, N, N, out, accumulate);
+  if (!direct) hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(N), dim3(256), 0, stream, (const float*)ws, nblk, N, N, out, accumulate);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }
