@@ -27,7 +27,7 @@ class Epilogue(ctypes.Structure):
                 ("maskref", c_void_p), ("ldmask", c_int), ("mask_scale", c_float), ("accumulate", c_int),
                 ("alpha", c_float), ("a_hi", c_void_p), ("a_lo", c_void_p), ("b_hi", c_void_p), ("b_lo", c_void_p),
                 ("c_hi", c_void_p), ("c_lo", c_void_p), ("gate_wc", c_void_p), ("gate_out", c_void_p), ("gate_np", c_int),
-                ("rng_row", c_void_p)]
+                ("rng_row", c_void_p), ("c2", c_void_p), ("ldc2", c_int64), ("n_split", c_int64), ("bias2", c_void_p)]
 
 
 # name -> (restype, argtypes); must list every symbol include/advmil_hip.h declares

@@ -279,7 +279,9 @@ struct OperandStage {
 //   * the per-element operand of the rank-1 / mask / accumulate mode (one of colv, maskref, C) is fetched one sub-tile ahead, issued
 //     after the current sub-tile's math and before its stores.
 // The plain bias + activation (+ dropout, + planes) modes then have no global load inside the loop at all.
-template <int TM, int TN, int WR, int WC>
+// PLAIN: instantiated for launches that are known to be bias + activation (+ planes) only (the caller checks): no dropout, no
+// per-element operand -- 30 registers less, which is what lets the 256x256 persistent tile carry this epilogue.
+template <int TM, int TN, int WR, int WC, bool PLAIN = false>
 __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (&acc)[TM][TN], float* patch, int lane, int wr, int wc,
                                                      int64_t m0, int64_t n0, uint64_t key, float inv_keep) {
   const advmil_epilogue_t& e = g.epi;
@@ -287,12 +289,13 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
   const int c4 = (lane & 7) * 4, rq = lane >> 3;
   const int64_t N = g.N, ldo = g.ldc;
   float* const out = g.C;
-  const bool drop = e.seed && e.drop_p > 0.0f;
+  const bool drop = !PLAIN && e.seed && e.drop_p > 0.0f;
   const bool mapped = drop && e.rng_row;
-  const int kind = e.rowv ? 1 : (e.maskref ? 2 : (e.accumulate ? 3 : 0));     // which per-element operand is fetched one sub-tile ahead
+  const int kind = PLAIN ? 0 : (e.rowv ? 1 : (e.maskref ? 2 : (e.accumulate ? 3 : 0)));     // which per-element operand is fetched one sub-tile ahead
   const float* const xbase = kind == 1 ? e.colv : (kind == 2 ? e.maskref : out);
   const int64_t xld = kind == 1 ? N : (kind == 2 ? (int64_t)e.ldmask : ldo);
   const int64_t rbase = m0 + wr * 32 * TM, cbase = n0 + wc * 32 * TN;
+  const int64_t nsp = (PLAIN && e.c2) ? e.n_split : N;          // columns >= nsp belong to the launch's second layer (two-layer form)
   // ---- side data -> LDS: sbias[32*TN] | srow_i[32*TM] (bag index, or dropout stream row: never both in one launch) | srow_f[32*TM]
   float* const sbias = patch + 32 * PITCH_KC;
   int* const srow_i = reinterpret_cast<int*>(sbias + 32 * TN);
@@ -304,7 +307,8 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
 #pragma unroll
     for (int u = 0; u < (32 * TN + 63) / 64; ++u) {
       const int c = u * 64 + lane;
-      bv[u] = (e.bias && c < 32 * TN) ? e.bias[cbase + c] : 0.f;
+      const int64_t cg = cbase + c;
+      bv[u] = c >= 32 * TN ? 0.f : (cg < nsp ? (e.bias ? e.bias[cg] : 0.f) : (e.bias2 ? e.bias2[cg - nsp] : 0.f));
     }
 #pragma unroll
     for (int u = 0; u < (32 * TM + 63) / 64; ++u) {
@@ -422,6 +426,13 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
       // next sub-tile's per-element operand: behind this sub-tile's math (the registers are free again), ahead of its stores
       if (b + 1 < TN) ADVMIL_EPI_PREFETCH(a, b + 1);
       else if (a + 1 < TM) ADVMIL_EPI_PREFETCH(a + 1, 0);
+      if (PLAIN && cbase + b * 32 >= nsp) {     // second layer's 32 columns (wave-uniform): its own output, no planes
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(e.c2 + (rbase + a * 32 + q * 8 + rq) * e.ldc2 + (col - nsp)) =
+              make_float4(res[q][0], res[q][1], res[q][2], res[q][3]);
+        continue;
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int64_t off = (rbase + a * 32 + q * 8 + rq) * ldo + col;
@@ -449,7 +460,7 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
 // RAWBAR: the caller has LDS-DMA in flight (persistent plane-fed kernel): the opening barrier must not drain vmcnt.
 // Returns a LOWER bound of the vector-memory operations this wave issued and did not wait for (the streaming form's stores), which
 // the persistent kernel uses as the count of operations younger than its cross-tile prefetch.
-template <int TM, int TN, int WR, int WC, bool RAWBAR = false, bool NOSTREAM = false>
+template <int TM, int TN, int WR, int WC, bool RAWBAR = false, int EPI = 0>      // EPI: 0 all forms, 1 no streaming form, 2 streaming form for plain launches only
 __device__ __forceinline__ int gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[TM][TN], float* smem, int wave, int lane, int wr, int wc,
                                              int64_t m0, int64_t n0, int z, int nt_i) {
   const int i = lane & 31, hi = lane >> 5;
@@ -477,15 +488,23 @@ __device__ __forceinline__ int gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[TM
   // columns is reduced in registers / across the 8 lanes of a row and written to gate_out[row * gate_np + column-block]: the
   // no-grad generator pass then never writes (and gate_score never re-reads) the [rows, 2D] activations.
   const bool gate_mode = direct && e.gate_wc != nullptr;
-  if constexpr (TM * TN >= 4 && !NOSTREAM) {   // the slab-sized tiles (the 64x64 ... 64x192 tiles serve launch-bound shapes: generic path only)
+  if constexpr (TM * TN >= 4 && EPI != 1) {   // the slab-sized tiles (the 64x64 ... 64x192 tiles serve launch-bound shapes: generic path only)
     const int nmode = (e.rowv ? 1 : 0) + (e.maskref ? 1 : 0) + (e.accumulate ? 1 : 0);
     const bool stream = direct && !gate_mode && vec_ok && (g.N % (32 * TN * WC)) == 0 && (g.M % (32 * TM * WR)) == 0 && (e.act_split & 31) == 0 &&
                         nmode <= 1 && !(e.rowv && e.seed && e.rng_row) && (!e.bias || ((uintptr_t)e.bias & 15) == 0) && (!e.rowv || ((uintptr_t)e.colv & 15) == 0) &&
                         (!e.maskref || ((e.ldmask & 3) == 0 && ((uintptr_t)e.maskref & 15) == 0)) &&
-                        (!e.c_hi || ((((uintptr_t)e.c_hi) | ((uintptr_t)e.c_lo)) & 7) == 0);
+                        (!e.c_hi || ((((uintptr_t)e.c_hi) | ((uintptr_t)e.c_lo)) & 7) == 0) &&
+                        (!e.c2 || ((((uintptr_t)e.c2) & 15) == 0 && (e.ldc2 & 3) == 0 && (e.n_split & 31) == 0));
     if (stream) {
-      gemm_epilogue_stream<TM, TN, WR, WC>(g, acc, patch, lane, wr, wc, m0, n0, key, inv_keep);
-      return nmode == 0 ? TM * TN * 4 : 0;      // (with a prefetched per-element operand the stores are partly waited for)
+      if constexpr (EPI == 2) {
+        if (nmode == 0 && !(e.seed && e.drop_p > 0.0f)) {
+          gemm_epilogue_stream<TM, TN, WR, WC, true>(g, acc, patch, lane, wr, wc, m0, n0, key, inv_keep);
+          return TM * TN * 4;
+        }
+      } else {
+        gemm_epilogue_stream<TM, TN, WR, WC>(g, acc, patch, lane, wr, wc, m0, n0, key, inv_keep);
+        return nmode == 0 ? TM * TN * 4 : 0;      // (with a prefetched per-element operand the stores are partly waited for)
+      }
     }
   }
 #pragma unroll
@@ -767,9 +786,9 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // epilogue works in the ring slot of the chunk just consumed, and the next tile's first wait is a counted one that leaves the
 // epilogue's stores in flight. Per tile this removes the cold start (first-chunk latency + workgroup launch: 5 of 55 us on the gate
 // contraction, tools/probe/stamp_gemm.sh) and lets the C stores drain under the next tile's K loop instead of at workgroup exit.
-// GATEONLY: instantiated for the fused gate score alone (its epilogue stores one partial per row and column block, no C): the
-// 256x256 form, which beside the streaming epilogue would not fit the register file.
-template <int TN, int NBUF, int WR, int BKT, bool GATEONLY = false>
+// EPI = 1: instantiated for the fused gate score alone (its epilogue stores one partial per row and column block, no C): the
+// 256x256 form, which beside the full streaming epilogue would not fit the register file. EPI = 2: 256x256 with the PLAIN streaming form.
+template <int TN, int NBUF, int WR, int BKT, int EPI = 0>
 __global__ __launch_bounds__(128 * WR, 2) void gemm_nt_planes_kernel(GemmArgs g) {
   constexpr int TM = 2, WC = 2, NW = WR * WC;
   constexpr int BM_ = 64 * WR, BN_ = 64 * TN;
@@ -903,7 +922,7 @@ __global__ __launch_bounds__(128 * WR, 2) void gemm_nt_planes_kernel(GemmArgs g)
     // the epilogue's LDS area: the ring slot of the chunk just consumed (the other slots hold / receive the next tile's chunks; the
     // slot is refilled only behind the next tile's first barrier, which every wave reaches after it has left the epilogue)
     const int last = cur == 0 ? NBUF - 1 : cur - 1;
-    young = gemm_epilogue<TM, TN, WR, WC, true, GATEONLY>(g, acc, smem + last * (BUF_HW / 2), wave, lane, wr, wc, m0, n0, 0, nt_i);
+    young = gemm_epilogue<TM, TN, WR, WC, true, EPI>(g, acc, smem + last * (BUF_HW / 2), wave, lane, wr, wc, m0, n0, 0, nt_i);
     mt_i = mt_n; nt_i = nt_n;
     if (has_next) {
       int lane2 = (int)threadIdx.x & 63;
@@ -1147,9 +1166,15 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
   // NT form with both operands as planes: the LDS-DMA kernel (tile codes 82 / 83 = 256 x 128 / 192, 8 waves). The plan
   // (advmil_gemm_f32_plan_planes, or tile 0 here) picks it whenever the shape qualifies; ADVMIL_NT_PLANES=0 turns it off.
   if (tile == 0 && pre == 3 && splits == 1) { int t = 0; advmil_gemm_f32_plan_planes(a_kc, b_kc, M, N, K, &t); if (t) tile = t; }
-  if (tile >= 82 && tile <= 84) {
-    const int tnp = tile % 10, bm = 256, bkt = 32;
+  if (tile >= 82 && tile <= 85) {
+    const int tnp = tile == 85 ? 4 : tile % 10, bm = 256, bkt = 32;
     if (tile == 84 && !epi->gate_wc) return ADVMIL_EINVAL;        // 256x256: the fused gate score only
+    if (tile == 85 && (epi->gate_wc || epi->rowv || epi->maskref || epi->accumulate || (epi->seed && epi->drop_p > 0.0f))) return ADVMIL_EINVAL;
+    if (epi->c2) {      // two layers in one launch: the plain 256x256 form only, split on a 32-column boundary inside N
+      if (tile != 85 || epi->n_split <= 0 || epi->n_split >= N || (epi->n_split & 31) || (epi->ldc2 & 3) || ((uintptr_t)epi->c2 & 15) ||
+          epi->act_split != epi->n_split)
+        return ADVMIL_EINVAL;
+    }
     if (g_gemm_mode != 1 || !a_kc || !b_kc || pre != 3 || splits != 1 || (M % bm) || (K % bkt) || (N % (64 * tnp))) return ADVMIL_EINVAL;
     if (epi->gate_wc && (!epi->gate_out || epi->drop_p > 0.0f || epi->gate_np != advmil_gemm_f32_gate_blocks(tile, N))) return ADVMIL_EINVAL;
     if (K < 64) return ADVMIL_EINVAL;                   // the three-slot ring prefetches two chunks ahead, across tiles
@@ -1160,7 +1185,8 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
     const int ntile_all = g.mtiles * g.ntiles;
     dim3 pgrid(ntile_all < ncu ? ntile_all : ncu);        // persistent: one workgroup per CU walks its share of the tiles
     switch (tile) {
-      case 84: hipLaunchKernelGGL((gemm_nt_planes_kernel<4, 2, 4, 32, true>), pgrid, dim3(512), 0, stream, g); break;   // 2 x 64 KB
+      case 84: hipLaunchKernelGGL((gemm_nt_planes_kernel<4, 2, 4, 32, 1>), pgrid, dim3(512), 0, stream, g); break;   // 2 x 64 KB
+      case 85: hipLaunchKernelGGL((gemm_nt_planes_kernel<4, 2, 4, 32, 2>), pgrid, dim3(512), 0, stream, g); break;   // EXPERIMENT
       case 83: hipLaunchKernelGGL((gemm_nt_planes_kernel<3, 2, 4, 32>), pgrid, dim3(512), 0, stream, g); break;   // 2 x 56 KB
       case 82: hipLaunchKernelGGL((gemm_nt_planes_kernel<2, 3, 4, 32>), pgrid, dim3(512), 0, stream, g); break;   // 3 x 48 KB: two chunks in flight
       default: return ADVMIL_EINVAL;

@@ -358,6 +358,24 @@ class MyHandler(object):
             return None
         return [torch.cat([nb[j] for nb in noise], dim=0) for j in range(len(noise[0]))]
 
+    def _prefill_first_layers(self, X):
+        """The generator's eval forward and the discriminator's forward of the D update both start with a Linear over the step
+        slab X (model/backbone.py:60-66 / backbone_utils.py:158-168; model_utils.py:130-140): ops.prefill_two_layers runs the two
+        as one plane-fed launch. Layer lookup is by backbone kind; anything else simply takes the ordinary path."""
+        bb = self.netG.backbone
+        if self.bcb == "abmil" and hasattr(bb, "attention_net"):
+            fc = bb.attention_net[0]
+            l1 = (fc.weight, fc.bias, "relu", True)
+        elif self.bcb == "patch" and hasattr(bb, "patch_embedding_layer") and hasattr(bb.patch_embedding_layer, "conv"):
+            cv = bb.patch_embedding_layer.conv
+            l1 = (cv.weight, cv.bias, "none", False)
+        else:
+            return False
+        emb = getattr(getattr(self.netD, "net_pair_one", None), "embedding", None)
+        if emb is None or not hasattr(emb, "conv"):
+            return False
+        return ops.prefill_two_layers(X, l1, (emb.conv.weight, emb.conv.bias, "none", False))
+
     def _gen_features(self, X, plan, xs):
         """Generator backbone over the whole step slab -> [B, d]. `patch` mode skips coords (model_handler.py:390)."""
         exts = [x[1] for x in xs] if self.bcb in ("cluster", "graph") else None
@@ -373,6 +391,7 @@ class MyHandler(object):
         self.optimizerD.zero_grad()
         X = self._slab(xs)
         y = plan.y                           # [B, 2] label stack, built once per step plan
+        self._prefill_first_layers(X)          # G's and D's first layers over the slab from one launch (X staged once), when possible
         ops.MEMO.begin("record", ("G", id(self.netG), getattr(self.optimizerG, "n_updates", 0), plan.token), X)
         try:
             with torch.no_grad():                                              # the reference builds, then detaches (400)
@@ -398,6 +417,7 @@ class MyHandler(object):
             f_fake = self.netD.tail(eb, im, pred).view(-1)
         # real_fake_loss with the global denominators (loss/utils.py:182-203, model_handler.py:412) as ONE launch that also yields
         # d loss / d score; the real pairs are selected by a 0/1 mask (same sum as f_real[event & visible], no index backward)
+        ops.PREFILL.clear()                  # (anything the two forwards did not take is stale from here on)
         loss, st = ops.gan_d_loss(f_fake, f_real, None if f_real is None else plan.real_mask, self.which_loss, plan.n_fake, plan.n_real,
                                   root=True)
         torch.autograd.backward(loss, grad_tensors=self._one())      # (the root gradient is a cached 1: no fill launch per step)

@@ -86,6 +86,15 @@ typedef struct {
    * rank passes the rows its bags occupy in the single-process step slab, which makes the masks independent of the world size;
    * NULL = identity. The same optional argument exists on every entry point below that draws dropout / noise. */
   const int64_t* rng_row;
+  /* Two layers over the same rows in one launch (plane-fed NT form, tile 85 only): B holds both layers' weight rows stacked
+   * ([N, K]: layer 1 first); columns [0, n_split) of the product are layer 1 -- bias, output C (pitch ldc), planes c_hi/c_lo --,
+   * columns [n_split, N) are layer 2 -- bias2[n - n_split], output c2[m*ldc2 + n - n_split], no planes. act_split = n_split selects
+   * the two activations. n_split % 32 == 0; c2 = NULL = an ordinary launch. The generator's and the discriminator's first layers
+   * over the step slab read X once this way (model/backbone.py:60-66 + model/model_utils.py:130-140). */
+  float* c2;
+  int64_t ldc2;
+  int64_t n_split;
+  const float* bias2;
 } advmil_epilogue_t;
 
 size_t advmil_gemm_f32_workspace_bytes(int64_t M, int64_t N, int splits);

@@ -274,6 +274,52 @@ def test_parallel_generator_forward_branch_is_bitwise_neutral(graph):
             assert torch.equal(sa[k], sb[k]), k
 
 
+@pytest.mark.parametrize("kind", ["abmil", "patch"])
+def test_two_layer_launch_is_bitwise_neutral(kind):
+    """The D update runs the generator's and the discriminator's first layer over the step slab as ONE plane-fed launch
+    (ops.prefill_two_layers: X staged once). Same products in the same order: two optimizer steps with it must equal two steps with
+    the layers launched separately, bit for bit (dropout ON, bf16x3 arithmetic, slab-sized bags)."""
+    from advmil_amd import ops
+    from advmil_amd.model import MyHandler
+
+    def run(two):
+        old = ops.TWO_LAYERS
+        ops.TWO_LAYERS = two
+        try:
+            nb, n = 8, 16384                                  # 131072 rows: the size class where the slab keeps resident planes
+            calls = []
+            real = ops.gemm_two_layers
+            ops.gemm_two_layers = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+            h = MyHandler(default_cfg(bcb_mode=kind, bp_every_batch=nb, gemm_mode="bf16x3"), device=DEV)
+            load_synth(h.netG, f"G-{kind}:"); load_synth(h.netD, "D-prj:")
+            h.optimizerG.refresh_planes(); h.optimizerD.refresh_planes()
+            h.rng.reset(99)
+            X = torch.randn(nb * n, 1024, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+            xs = [[X[i * n:(i + 1) * n].unsqueeze(0), torch.zeros(1, 1)] for i in range(nb)]
+            ys = [H.label(i).to(DEV) for i in range(nb)]
+            ys_host = [H.label(i) for i in range(nb)]
+            for i in range(2):
+                plan = h._plan(xs, ys, "wlabel", None, ys_host)
+                h._update_disc(i, xs, ys, "wlabel", None, ys_host=ys_host, plan=plan)
+                h._update_gen(i, xs, ys, "wlabel", None, ys_host=ys_host, plan=plan)
+                h.rng.advance(1)
+            torch.cuda.synchronize()
+            assert len(calls) == (2 if two else 0), calls      # one fused launch per D update -- or none
+            return h.pop_logs(), {k: v.clone() for k, v in h.netG.state_dict().items()}, {k: v.clone() for k, v in h.netD.state_dict().items()}
+        finally:
+            ops.TWO_LAYERS = old
+            ops.gemm_two_layers = real
+            ops.set_gemm_mode("exact")
+
+    a, b = run(True), run(False)
+    for la, lb in zip(a[0], b[0]):
+        for k in la:
+            assert float(la[k]) == float(lb[k]), k
+    for sa, sb in ((a[1], b[1]), (a[2], b[2])):
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), k
+
+
 def test_forward_memo_is_consumed_and_cleared():
     from advmil_amd import ops
     from advmil_amd.model import MyHandler

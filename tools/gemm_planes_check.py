@@ -12,7 +12,7 @@ from advmil_amd import ops  # noqa: E402
 ops.set_gemm_mode("bf16x3")
 dev = "cuda:0"
 SHAPES = [("embedG", 131072, 384, 1024), ("gates", 131072, 768, 384), ("embedD", 131072, 128, 1024), ("dh_nt", 131072, 384, 768),
-          ("embedG32k", 524288, 384, 1024), ("small", 8192, 384, 1024)]
+          ("embedG32k", 524288, 384, 1024), ("small", 8192, 384, 1024), ("embedGD", 131072, 512, 1024)]
 
 
 def bench(fn, iters=20):
@@ -39,8 +39,8 @@ for name, M, N, K in SHAPES:
     row = [name, f"plan={ops.gemm_plan(M, N, K)} planes_tile={ops.gemm_plan_planes(M, N, K)}"]
     us0 = bench(lambda: ops.gemm(A, B, True, True, M, N, K, out=out0, bias=bias, act0=1))
     row.append(f"fly {us0:.0f}us {2.0 * M * N * K / us0 / 1e6:.0f}TF")
-    for t in (82, 83):
-        if N % (64 * (t % 10)):
+    for t in (82, 83, 85):
+        if N % (64 * (4 if t == 85 else t % 10)):
             continue
         ops.gemm(A, B, True, True, M, N, K, out=out1, bias=bias, act0=1, a_planes=pa, b_planes=pb, tile=t, splits=1)
         same = torch.equal(out0, out1)
