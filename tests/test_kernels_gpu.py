@@ -347,6 +347,37 @@ def test_gemm_streaming_epilogue_modes(ops, mode, tile):
 
 
 @pytest.mark.gpu
+def test_gemm_two_layers_in_one_launch(ops):
+    """advmil_epilogue_t's two-layer form (tile 85): act1(x W1^T + b1) and act2(x W2^T + b2) from one plane-fed launch over stacked
+    weight planes, two outputs, planes of the first. Bit-identical to the two separate plane-fed launches, and within the bf16x3
+    tolerance of float64 on the host; bad arguments are refused."""
+    from advmil_amd._lib import AdvmilHipError
+    prev = ops.get_gemm_mode()
+    ops.set_gemm_mode("bf16x3")
+    try:
+        M, K, N1, N2 = 65536, 256, 384, 128
+        assert ops.gemm_two_layers_ok(M, N1, N2, K)
+        g = torch.Generator(device="cuda").manual_seed(2)
+        x = torch.randn(M, K, device="cuda", generator=g)
+        W1 = 0.1 * torch.randn(N1, K, device="cuda", generator=g); W2 = 0.1 * torch.randn(N2, K, device="cuda", generator=g)
+        b1 = torch.randn(N1, device="cuda", generator=g); b2 = torch.randn(N2, device="cuda", generator=g)
+        xpl, p1, p2 = ops.split_planes(x), ops.split_planes(W1), ops.split_planes(W2)
+        y1, y2, cpl = ops.gemm_two_layers(x, xpl, W1, p1, b1, 1, W2, p2, b2, 0, True)
+        c1 = ops.Planes(torch.empty(M, N1, dtype=torch.bfloat16, device="cuda"), torch.empty(M, N1, dtype=torch.bfloat16, device="cuda"))
+        r1 = ops.gemm(x, W1, True, True, M, N1, K, bias=b1, act0=1, a_planes=xpl, b_planes=p1, c_planes=c1, tile=83, splits=1)
+        r2 = ops.gemm(x, W2, True, True, M, N2, K, bias=b2, act0=0, a_planes=xpl, b_planes=p2, tile=82, splits=1)
+        assert torch.equal(y1, r1) and torch.equal(y2, r2) and torch.equal(cpl.hi, c1.hi) and torch.equal(cpl.lo, c1.lo)
+        rows = torch.arange(0, M, 997, device="cuda")
+        x64 = x[rows].cpu().double()
+        assert relerr(y1[rows], torch.relu(x64 @ W1.cpu().double().t() + b1.cpu().double())) < 2e-5
+        assert relerr(y2[rows], x64 @ W2.cpu().double().t() + b2.cpu().double()) < 2e-5
+        with pytest.raises(AdvmilHipError):       # the two-layer form exists for the plain 256x256 tile only
+            ops.gemm(x, W1, True, True, M, N1, K, a_planes=xpl, b_planes=p1, tile=85, splits=1, drop_p=0.5, seed=ops.DeviceRng("cuda", 1).seed)
+    finally:
+        ops.set_gemm_mode(prev)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["exact", "bf16x3"])
 @pytest.mark.parametrize("tile", [0, 22, 23, 12, 11, 43])
 def test_gemm_fused_gate_score(ops, mode, tile):
