@@ -173,12 +173,13 @@ class Planes:
 USE_PLANES = os.environ.get("ADVMIL_PLANES", "1") != "0"
 # Measured same-box (tools/ab_bench.sh, 16 x 8k ABMIL step): planes for the slab, the weights and the eval-pass h pay (+2.6 %: the
 # embedding FCs and the fused gate score run on the plane-fed kernel); emitting planes of dG to run dh as an NT plane contraction
-# costs 2 % (the extra 403 MB of plane writes outweigh the staging they save) and planes of the memo-replayed (dropped) h are
-# neutral -> both off unless asked for.
+# costs 2 % (the extra 403 MB of plane writes outweigh the staging they save) -> off unless asked for. Planes of the
+# memo-replayed (dropped) h were neutral while the training-pass gate contraction took the 256x192 tile with the old epilogue; with
+# the persistent 256x256 tile and the plain streaming epilogue they pay (+0.4-0.8 %, two same-box A/B runs) -> on.
 DH_PLANES = os.environ.get("ADVMIL_DH_PLANES", "0") != "0"
 # weight gradients dY^T X of the layers applied to the slab: X's planes (already resident for the forward) feed the B operand
 DW_PLANES = os.environ.get("ADVMIL_DW_PLANES", "1") != "0"
-MEMO_PLANES = os.environ.get("ADVMIL_MEMO_PLANES", "0") != "0"
+MEMO_PLANES = os.environ.get("ADVMIL_MEMO_PLANES", "1") != "0"
 
 
 def planes_of(x):
@@ -223,6 +224,9 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
             tile, splits = ptile, 1
             if gate_wc is not None and N % 256 == 0 and (M // 256) * (N // 256) >= 384:
                 tile = 84                                      # the fused gate score's own 256x256 form
+            elif (gate_wc is None and N % 256 == 0 and (M // 256) * (N // 256) >= 384 and rowv is None and maskref is None
+                  and not accumulate and (drop_p <= 0.0 or seed is None)):
+                tile = 85                                      # plain bias + activation (+ planes): the 256x256 form (9 % over 256x192)
     if gate_wc is not None:
         # fused gate score (advmil_epilogue_t.gate_wc): B / bias hold the INTERLEAVED branches; returns per-row partial scores
         # [M, column blocks] instead of C
