@@ -282,7 +282,7 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        name = ("gemm_nt_planes_kernel<%d>" % (tile - 80)) if 82 <= tile <= 84 else \
+        name = ("gemm_nt_planes_kernel<%d>" % (tile - 80)) if 82 <= tile <= 84 else "gemm_nt_planes_kernel<4,plain>" if tile == 85 else \
             "gemm_f32_kernel<%d,%d,%d,%d>" % (bool(a_kc), bool(b_kc), tile // 10, tile % 10)
         prof.append((name, (M, N, K, splits), 2.0 * M * N * K, e0, e1))
     return gate_out if gate_wc is not None else out

@@ -113,7 +113,7 @@ def kname(sym):
 
 
 launches, planes_launches = {}, {}
-for shape in ("131072x768x384", "131072x384x1024"):
+for shape in ("131072x768x384", "131072x384x1024", "131072x512x1024"):
     M, N, K = (int(v) for v in shape.split("x"))
     for prefix, dest in (("gemm", launches), ("gemmpl", planes_launches)):
         fe = counter(f"{prefix}_{shape}_fetch", "FETCH_SIZE")

@@ -18,7 +18,7 @@ if [ "$what" = all ] || [ "$what" = pool ]; then
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pool16_write -- python3 tools/pool_bench.py 8192 16 12 > $O/pool16_write.log 2>&1
 fi
 if [ "$what" = all ] || [ "$what" = gemm ]; then
-  for shape in "131072 768 384" "131072 384 1024"; do
+  for shape in "131072 768 384" "131072 384 1024" "131072 512 1024"; do
     tag=$(echo $shape | tr ' ' x)
     ADVMIL_GEMM_MODE=bf16x3 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/gemm_${tag}_fetch -- python3 tools/pmc_gemm.py $shape 1 1 8 > $O/gemm_${tag}_fetch.log 2>&1
     ADVMIL_GEMM_MODE=bf16x3 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/gemm_${tag}_write -- python3 tools/pmc_gemm.py $shape 1 1 8 > $O/gemm_${tag}_write.log 2>&1
