@@ -38,7 +38,8 @@
 
 #define AT_PITCH 72   // halfwords per plane row
 #define AT_KT 64      // streamed rows per LDS tile
-#define AT_QB 128     // stationary rows per workgroup (4 waves x 32)
+// stationary rows per workgroup = 32 * NW (NW = 4 or 8 waves): a (bag, head)'s streamed K/V (or Q/dO) panel is re-read by every
+// such workgroup, so 8 waves halve that traffic and the staging work per stationary row; the host takes 8 when the bags are long
 #define AT_PLANE (AT_KT * AT_PITCH)
 
 struct AttnArgs {
@@ -75,23 +76,25 @@ __device__ __forceinline__ bool attn_keep(uint32_t rk, uint32_t j, uint32_t thr)
 }
 
 // ---- staging: [64 rows][HD] fp32 from global -> registers -> two bf16 planes in LDS
-template <int HD>
+template <int HD, int NT>
 struct TileRegs {
-  static constexpr int NP = AT_KT * (HD / 4) / 256;
+  static constexpr int NE = AT_KT * (HD / 4);          // float4 elements of a streamed tile
+  static constexpr int NP = (NE + NT - 1) / NT;
   float4 f[NP];
   __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int64_t row0, int64_t row_end, int tid) {
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      const int e = p * 256 + tid;
+      const int e = p * NT + tid;
       const int64_t row = row0 + e / (HD / 4);
       const int c4 = e % (HD / 4);
-      f[p] = row < row_end ? *reinterpret_cast<const float4*>(base + row * ld + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      f[p] = (e < NE && row < row_end) ? *reinterpret_cast<const float4*>(base + row * ld + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   __device__ __forceinline__ void store(bf16raw* __restrict__ planes, int tid, float mul) const {
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      const int e = p * 256 + tid;
+      const int e = p * NT + tid;
+      if (NE % NT != 0 && e >= NE) break;
       const int off = (e / (HD / 4)) * AT_PITCH + (e % (HD / 4)) * 4;
       uint2 h, l;
       split4(make_float4(f[p].x * mul, f[p].y * mul, f[p].z * mul, f[p].w * mul), h, l);
@@ -145,8 +148,8 @@ __device__ __forceinline__ void load_row_frags(const float* __restrict__ row, bo
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);  \
   } while (0)
 
-__device__ __forceinline__ void zero_lds(bf16raw* smem, int halfwords, int tid) {
-  for (int e = tid * 8; e < halfwords; e += 256 * 8) *reinterpret_cast<uint4*>(smem + e) = make_uint4(0u, 0u, 0u, 0u);
+__device__ __forceinline__ void zero_lds(bf16raw* smem, int halfwords, int tid, int nt) {
+  for (int e = tid * 8; e < halfwords; e += nt * 8) *reinterpret_cast<uint4*>(smem + e) = make_uint4(0u, 0u, 0u, 0u);
 }
 // row of accumulator register r in a 32x32 tile: (r & 3) + 8 * (r >> 2) + 4 * half
 #define ACC_ROW(r, half) (((r) & 3) + 8 * ((r) >> 2) + 4 * (half))
@@ -154,8 +157,9 @@ __device__ __forceinline__ void zero_lds(bf16raw* smem, int halfwords, int tid) 
 // =====================================================================================
 // forward
 // =====================================================================================
-template <int HD, bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+template <int HD, bool DROP, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnArgs a) {
+  constexpr int NT = 64 * NW, AT_QB = 32 * NW;
   constexpr int KS = HD / 16, DT = (HD + 31) / 32;
   __shared__ __attribute__((aligned(16))) bf16raw smem[4 * AT_PLANE];   // K hi | K lo | V hi | V lo
   bf16raw* const sK = smem;
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   const float* const Qb = a.qkv + row0 * a.ldq + h * HD;
   const float* const Kb = Qb + D;
   const float* const Vb = Qb + 2 * D;
-  zero_lds(smem, 4 * AT_PLANE, tid);   // pad columns [HD, 72) stay zero: the transposed reads of the last head-dim tile cover [32, 64)
+  zero_lds(smem, 4 * AT_PLANE, tid, NT);   // pad columns [HD, 72) stay zero: the transposed reads of the last head-dim tile cover [32, 64)
 
   const int64_t q = (int64_t)qt * AT_QB + wave * 32 + j;
   const bool qok = q < Lg;
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  TileRegs<HD> rK, rV;
+  TileRegs<HD, NT> rK, rV;
   rK.load(Kb, a.ldq, 0, Lg, tid);
   rV.load(Vb, a.ldq, 0, Lg, tid);
   for (int64_t kb = 0; kb < Lg; kb += AT_KT) {
@@ -301,8 +305,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 // =====================================================================================
 // backward, queries stationary: dQ = scale * dS K
 // =====================================================================================
-template <int HD, bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
+template <int HD, bool DROP, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(AttnArgs a) {
+  constexpr int NT = 64 * NW, AT_QB = 32 * NW;
   constexpr int KS = HD / 16, DT = (HD + 31) / 32;
   __shared__ __attribute__((aligned(16))) bf16raw smem[4 * AT_PLANE];   // K hi | K lo | V hi | V lo
   bf16raw* const sK = smem;
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   const float* const Qb = a.qkv + row0 * a.ldq + h * HD;
   const float* const Kb = Qb + D;
   const float* const Vb = Qb + 2 * D;
-  zero_lds(smem, 4 * AT_PLANE, tid);
+  zero_lds(smem, 4 * AT_PLANE, tid, NT);
 
   const int64_t q = (int64_t)qt * AT_QB + wave * 32 + j;
   const bool qok = q < Lg;
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
 
-  TileRegs<HD> rK, rV;
+  TileRegs<HD, NT> rK, rV;
   rK.load(Kb, a.ldq, 0, Lg, tid);
   rV.load(Vb, a.ldq, 0, Lg, tid);
   for (int64_t kb = 0; kb < Lg; kb += AT_KT) {
@@ -422,8 +427,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 // =====================================================================================
 // backward, keys stationary: dV = Pd^T dO, dK = scale * dS^T Q
 // =====================================================================================
-template <int HD, bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
+template <int HD, bool DROP, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
+  constexpr int NT = 64 * NW, AT_QB = 32 * NW;
   constexpr int KS = HD / 16, DT = (HD + 31) / 32;
   // Q' hi | Q' lo | dO hi | dO lo | lse[64] | D[64] | rowkey[64]
   __shared__ __attribute__((aligned(16))) bf16raw smem[4 * AT_PLANE + 3 * AT_KT * 2];
@@ -445,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   const float* const Kb = Qb + D;
   const float* const Vb = Qb + 2 * D;
   const float* const Gb = a.dout + row0 * D + h * HD;
-  zero_lds(smem, 4 * AT_PLANE, tid);
+  zero_lds(smem, 4 * AT_PLANE, tid, NT);
 
   const int64_t key = (int64_t)kt * AT_QB + wave * 32 + j;
   const bool kok = key < Lg;
@@ -462,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
 
-  TileRegs<HD> rQ, rG;
+  TileRegs<HD, NT> rQ, rG;
   rQ.load(Qb, a.ldq, 0, Lg, tid);
   rG.load(Gb, D, 0, Lg, tid);
   for (int64_t qb = 0; qb < Lg; qb += AT_KT) {
@@ -576,13 +582,16 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const float* __restr
 // C ABI
 // =====================================================================================
 static int attn_args(AttnArgs& a, const float* qkv, int64_t Ltot, int nhead, int head_dim, int nseg, const int64_t* ptr,
-                     int64_t max_len, float drop_p, const uint64_t* seed, uint64_t stream_id, const int64_t* rng_rowoff) {
+                     int64_t max_len, float drop_p, const uint64_t* seed, uint64_t stream_id, const int64_t* rng_rowoff, int& nw) {
   if (!qkv || Ltot <= 0 || nhead <= 0 || nseg <= 0 || max_len <= 0 || max_len > Ltot) return ADVMIL_EINVAL;
   if (head_dim != 48) return ADVMIL_EINVAL;                 // the ESAT layer: d_model 384 / 8 heads (model/backbone.py:30-33)
   if (nseg > 1 && !ptr) return ADVMIL_EINVAL;
   if (drop_p < 0.f || drop_p >= 1.f) return ADVMIL_EINVAL;
   if ((uintptr_t)qkv & 15) return ADVMIL_EINVAL;
-  const int64_t ntile = (max_len + AT_QB - 1) / AT_QB;
+  // 8-wave workgroups (256 stationary rows) when the bags are long enough to still fill the chip: half the streamed-panel re-reads
+  static const int force_nw = []() { const char* e = getenv("ADVMIL_ATTN_WAVES"); return e ? atoi(e) : 0; }();
+  nw = (force_nw == 4 || force_nw == 8) ? force_nw : ((max_len >= 1024 && (max_len / 256) * nseg * nhead >= 512) ? 8 : 4);
+  const int64_t ntile = (max_len + 32 * nw - 1) / (32 * nw);
   if (ntile * nseg * nhead > 0x7fffffffLL) return ADVMIL_EINVAL;
   a.qkv = qkv; a.ldq = 3 * (int64_t)nhead * head_dim;
   a.out = nullptr; a.lse = nullptr; a.dout = nullptr; a.dsum = nullptr; a.dqkv = nullptr;
@@ -601,13 +610,19 @@ extern "C" int advmil_mha_fwd(const float* qkv, int64_t Ltot, int nhead, int hea
                               int64_t max_len, float drop_p, const uint64_t* seed, uint64_t stream_id,
                               const int64_t* rng_rowoff, float* out, float* lse, advmil_stream_t stream_) {
   AttnArgs a;
-  const int rc = attn_args(a, qkv, Ltot, nhead, head_dim, nseg, ptr, max_len, drop_p, seed, stream_id, rng_rowoff);
+  int nw = 4;
+  const int rc = attn_args(a, qkv, Ltot, nhead, head_dim, nseg, ptr, max_len, drop_p, seed, stream_id, rng_rowoff, nw);
   if (rc) return rc;
   if (!out || !lse || ((uintptr_t)out & 15)) return ADVMIL_EINVAL;
   a.out = out; a.lse = lse;
   const dim3 grid((unsigned)(a.ntile * nseg * nhead));
-  if (a.seed) hipLaunchKernelGGL((attn_fwd_kernel<48, true>), grid, dim3(256), 0, (hipStream_t)stream_, a);
-  else hipLaunchKernelGGL((attn_fwd_kernel<48, false>), grid, dim3(256), 0, (hipStream_t)stream_, a);
+  if (nw == 8) {
+    if (a.seed) hipLaunchKernelGGL((attn_fwd_kernel<48, true, 8>), grid, dim3(512), 0, (hipStream_t)stream_, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<48, false, 8>), grid, dim3(512), 0, (hipStream_t)stream_, a);
+  } else {
+    if (a.seed) hipLaunchKernelGGL((attn_fwd_kernel<48, true, 4>), grid, dim3(256), 0, (hipStream_t)stream_, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<48, false, 4>), grid, dim3(256), 0, (hipStream_t)stream_, a);
+  }
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }
@@ -620,7 +635,8 @@ extern "C" int advmil_mha_bwd(const float* qkv, const float* out, const float* d
                               advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   AttnArgs a;
-  const int rc = attn_args(a, qkv, Ltot, nhead, head_dim, nseg, ptr, max_len, drop_p, seed, stream_id, rng_rowoff);
+  int nw = 4;
+  const int rc = attn_args(a, qkv, Ltot, nhead, head_dim, nseg, ptr, max_len, drop_p, seed, stream_id, rng_rowoff, nw);
   if (rc) return rc;
   if (!out || !dout || !lse || !dqkv || !ws) return ADVMIL_EINVAL;
   if (((uintptr_t)out & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 15) || ((uintptr_t)ws & 15)) return ADVMIL_EINVAL;
@@ -631,12 +647,20 @@ extern "C" int advmil_mha_bwd(const float* qkv, const float* out, const float* d
   ADVMIL_LAUNCH_CHECK();
   a.lse = const_cast<float*>(lse); a.dout = dout; a.dsum = dsum; a.dqkv = dqkv;
   const dim3 grid((unsigned)(a.ntile * nseg * nhead));
-  if (a.seed) {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<48, true>), grid, dim3(256), 0, stream, a);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<48, true>), grid, dim3(256), 0, stream, a);
+  if (nw == 8) {
+    if (a.seed) {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<48, true, 8>), grid, dim3(512), 0, stream, a);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<48, true, 8>), grid, dim3(512), 0, stream, a);
+    } else {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<48, false, 8>), grid, dim3(512), 0, stream, a);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<48, false, 8>), grid, dim3(512), 0, stream, a);
+    }
+  } else if (a.seed) {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<48, true, 4>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<48, true, 4>), grid, dim3(256), 0, stream, a);
   } else {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<48, false>), grid, dim3(256), 0, stream, a);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<48, false>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<48, false, 4>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<48, false, 4>), grid, dim3(256), 0, stream, a);
   }
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
