@@ -1200,7 +1200,12 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
     case 13: launch_tile<1, 3, false>(a_kc, b_kc, grid, stream, g, pre); break;
     case 12: launch_tile<1, 2, true>(a_kc, b_kc, grid, stream, g, pre); break;
     case 11: launch_tile<1, 1, true>(a_kc, b_kc, grid, stream, g, pre); break;
-    case 43: launch_tile_m<2, 3, true, 0, 4, 2>(a_kc, b_kc, grid, stream, g); break;   // 256x192, 8 waves
+    case 43:                                                                               // 256x192, 8 waves
+      // A operand from caller-held planes (dG written as planes by the gate backward): dh = dG Wab (NN), dWab = dG^T h (TN)
+      if (pre == 1 && a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, false, 2, 3, true, 1, 32, 4, 2>), grid, dim3(512), 0, stream, g);
+      else if (pre == 1 && !a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 2, 3, true, 1, 32, 4, 2>), grid, dim3(512), 0, stream, g);
+      else launch_tile_m<2, 3, true, 0, 4, 2>(a_kc, b_kc, grid, stream, g);
+      break;
     case 42: launch_tile_m<2, 2, true, 0, 4, 2>(a_kc, b_kc, grid, stream, g); break;   // 256x128, 8 waves
     // 192x256 / 128x256, 8 waves (2 x 4): the weight-gradient contractions dY^T X over the slab rows. With the slab's planes at
     // hand (B = X: 3/4 to 9/10 of the staged elements) that operand is staged without any conversion work.

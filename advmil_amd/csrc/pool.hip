@@ -433,8 +433,10 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
         ga[q] = d * wv[q] * bd * fa * (1.f - av[q] * av[q]);   // d pre_a  (tanh')
         gb[q] = d * wv[q] * ad * fb * bv[q] * (1.f - bv[q]);   // d pre_b  (sigmoid')
       }
-      *reinterpret_cast<float4*>(dG + n * 2 * D + m.c4 * 4) = make_float4(ga[0], ga[1], ga[2], ga[3]);
-      *reinterpret_cast<float4*>(dG + n * 2 * D + D + m.c4 * 4) = make_float4(gb[0], gb[1], gb[2], gb[3]);
+      if (dG) {    // (NULL: the caller keeps dG as planes only -- its two consumers are bf16x3 contractions that would split it anyway)
+        *reinterpret_cast<float4*>(dG + n * 2 * D + m.c4 * 4) = make_float4(ga[0], ga[1], ga[2], ga[3]);
+        *reinterpret_cast<float4*>(dG + n * 2 * D + D + m.c4 * 4) = make_float4(gb[0], gb[1], gb[2], gb[3]);
+      }
       if (g_hi) {   // bf16x3 operand planes of dG for the contractions that read it (dh = dG Wab, dWab = dG^T h)
         uint2 hh, ll;
         split4(make_float4(ga[0], ga[1], ga[2], ga[3]), hh, ll);
@@ -477,7 +479,8 @@ extern "C" int advmil_gate_bwd(const float* ab, const float* ds, const float* wc
                                float* dbc, float* dbias, int accumulate, const int64_t* rng_row, void* dG_hi, void* dG_lo, void* ws,
                                size_t ws_bytes, advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!ab || !ds || !wc || !dG || !dwc || !dbc || !dbias || !ws || N <= 0 || D <= 0 || (D & 3) || D > 1024)
+  if (!ab || !ds || !wc || (!dG && !dG_hi) || !dwc || !dbc || !dbias || !ws || N <= 0 || D <= 0 || (D & 3) || D > 1024 ||
+      ((dG_hi != nullptr) != (dG_lo != nullptr)))
     return ADVMIL_EINVAL;
   if (ws_bytes < advmil_gate_bwd_workspace_bytes(N, D)) return ADVMIL_EWORKSPACE;
   const int rpb = rows_per_block(N);

@@ -177,6 +177,8 @@ USE_PLANES = os.environ.get("ADVMIL_PLANES", "1") != "0"
 # memo-replayed (dropped) h were neutral while the training-pass gate contraction took the 256x192 tile with the old epilogue; with
 # the persistent 256x256 tile and the plain streaming epilogue they pay (+0.4-0.8 %, two same-box A/B runs) -> on.
 DH_PLANES = os.environ.get("ADVMIL_DH_PLANES", "0") != "0"
+# dG of the gate backward as planes ONLY (no fp32 copy): its two consumers take the A operand pre-split (-30 us each, no extra bytes)
+DG_PLANES_ONLY = os.environ.get("ADVMIL_DG_PLANES_ONLY", "1") != "0"
 # weight gradients dY^T X of the layers applied to the slab: X's planes (already resident for the forward) feed the B operand
 DW_PLANES = os.environ.get("ADVMIL_DW_PLANES", "1") != "0"
 MEMO_PLANES = os.environ.get("ADVMIL_MEMO_PLANES", "1") != "0"
@@ -210,12 +212,25 @@ def split_planes(x, out=None):
     return out
 
 
+def pre_a_tile_ok(tile, a_kc, b_kc):
+    """Is the contraction kernel of this tile built for an A operand that arrives as planes only (csrc/gemm_f32.hip dispatch)?"""
+    return tile in (22, 12, 11) or (tile == 43 and not b_kc)
+
+
 def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=None, act_split=None, drop_p=0.0,
          seed=None, stream_id=0, rowv=None, colv=None, rowseg=None, maskref=None, mask_scale=1.0, accumulate=False,
          alpha=1.0, splits=None, tile=0, a_planes=None, b_planes=None, c_planes=None, gate_wc=None, rng_row=None):
     """C[M,N] = epilogue(alpha * op(A) op(B)); see include/advmil_hip.h::advmil_gemm_f32. a_planes / b_planes: optional
     Planes of A / B; c_planes: Planes to receive the split of the final C (pitch ldc)."""
-    _chk(A, "A"); _chk(B, "B")
+    planes_only_a = A is None
+    if planes_only_a:
+        # A exists as planes only (dG of the gate backward): the launch must land on a kernel instantiated for a pre-split A operand
+        if a_planes is None or get_gemm_mode() != "bf16x3" or b_planes is not None:
+            raise ValueError("gemm(A=None) needs a_planes in bf16x3 mode")
+        A = a_planes.hi                       # (pointer and pitch only: never read as fp32)
+    else:
+        _chk(A, "A")
+    _chk(B, "B")
     if (tile == 0 and a_planes is not None and b_planes is not None and (splits is None or splits == 1)
             and not ((a_planes.hi.data_ptr() | a_planes.lo.data_ptr() | b_planes.hi.data_ptr() | b_planes.lo.data_ptr()) & 15)
             and a_planes.hi.stride(0) % 8 == 0 and b_planes.hi.stride(0) % 8 == 0):
@@ -270,6 +285,8 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
         ptile, splits = gemm_plan(M, N, K, a_kc, b_kc)
         if tile == 0:
             tile = ptile
+    if planes_only_a and not pre_a_tile_ok(tile if tile else gemm_plan(M, N, K, a_kc, b_kc)[0], a_kc, b_kc):
+        raise ValueError(f"gemm(A=None): tile {tile} has no pre-split-A instantiation for this layout")
     L = _lib.lib()
     wsb = L.advmil_gemm_f32_workspace_bytes(M, N, splits)
     ws = _ws(wsb, A.device) if wsb else None
@@ -418,12 +435,14 @@ def softmax_pool_bwd(dpooled, dA, A, h, N, D, seg=None):
     return ds
 
 
-def gate_bwd(ab, ds, wc, N, D, p=0.0, seed=None, stream_a=0, stream_b=0, dwc=None, dbc=None, dbias=None, rng_row=None, planes=None):
-    """dwc/dbc/dbias given -> gradients are ADDED into them (views of the gradient arena)."""
+def gate_bwd(ab, ds, wc, N, D, p=0.0, seed=None, stream_a=0, stream_b=0, dwc=None, dbc=None, dbias=None, rng_row=None, planes=None,
+             planes_only=False):
+    """dwc/dbc/dbias given -> gradients are ADDED into them (views of the gradient arena). planes_only: dG is written as its
+    bf16x3 operand planes alone (returned dG is None)."""
     L = _lib.lib()
     dev = ab.device
     acc = dwc is not None
-    dG = torch.empty(N, 2 * D, dtype=torch.float32, device=dev)
+    dG = None if (planes_only and planes is not None) else torch.empty(N, 2 * D, dtype=torch.float32, device=dev)
     if not acc:
         dwc = torch.empty(D, dtype=torch.float32, device=dev)
         dbc = torch.empty(1, dtype=torch.float32, device=dev)
@@ -789,25 +808,35 @@ class GatedAttnPoolFn(torch.autograd.Function):
         gpl = None
         if need_h and USE_PLANES and DH_PLANES and get_gemm_mode() == "bf16x3" and gemm_plan_planes(N, D, 2 * D):
             gpl = Planes(torch.empty(N, 2 * D, dtype=torch.bfloat16, device=h.device), torch.empty(N, 2 * D, dtype=torch.bfloat16, device=h.device))
+        # bf16x3, slab-sized: dG is consumed by exactly two contractions (dh = dG Wab, dWab = dG^T h) that would split it into hi + lo
+        # anyway -> the gate backward writes the planes INSTEAD of the fp32 values (same bytes) and both take their A operand pre-split
+        only = (gpl is None and DG_PLANES_ONLY and USE_PLANES and get_gemm_mode() == "bf16x3" and N >= 4096 and (2 * D) % 8 == 0
+                and pre_a_tile_ok(gemm_plan(2 * D, D, N, False, False)[0], False, False)
+                and (not need_h or pre_a_tile_ok(gemm_plan(N, D, 2 * D, True, False)[0], True, False)))
+        if only:
+            gpl = Planes(torch.empty(N, 2 * D, dtype=torch.bfloat16, device=h.device), torch.empty(N, 2 * D, dtype=torch.bfloat16, device=h.device))
         if ctx.arena is not None:
             gWab, gbab, gwc, gbc = ctx.arena
-            dG, _, _, _ = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb, dwc=gwc, dbc=gbc, dbias=gbab, rng_row=rr, planes=gpl)
+            dG, _, _, _ = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb, dwc=gwc, dbc=gbc, dbias=gbab, rng_row=rr, planes=gpl, planes_only=only)
         else:
-            dG, dwc, dbc, dbias = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb, rng_row=rr, planes=gpl)
+            dG, dwc, dbc, dbias = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb, rng_row=rr, planes=gpl, planes_only=only)
         dh = None
         if need_h:
             # dG [N,2D] . Wab [2D,D]  +  A[n] * dpooled[bag(n), d]   (pooling's direct path, rank-1 per bag)
-            if gpl is not None:
+            if only:
+                dh = gemm(None, Wab, True, False, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg, a_planes=gpl)
+            elif gpl is not None:
                 WabT = Wab.t().contiguous()                                       # [D, 2D]: k (= 2D) contiguous
                 dh = gemm(dG, WabT, True, True, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg,
                           a_planes=gpl, b_planes=split_planes(WabT))
             else:
                 dh = gemm(dG, Wab, True, False, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg)
         nones = (None,) * 8
+        apl = gpl if only else None
         if ctx.arena is not None:
-            gemm(dG, h, False, False, 2 * D, D, N, out=gWab, ldc=D, accumulate=True)       # dG^T h
+            gemm(dG, h, False, False, 2 * D, D, N, out=gWab, ldc=D, accumulate=True, a_planes=apl)       # dG^T h
             return (dh, None, None, None, None, None, None) + nones
-        dWab = gemm(dG, h, False, False, 2 * D, D, N)
+        dWab = gemm(dG, h, False, False, 2 * D, D, N, a_planes=apl)
         return (dh, dWab[:D], dbias[:D], dWab[D:], dbias[D:], dwc.reshape(wcshape), dbc) + nones
 
 
