@@ -210,7 +210,9 @@ __device__ __forceinline__ void emit_planes4(const advmil_epilogue_t& e, int64_t
 template <bool KC, int ROWS, int BKT, bool PRE, int NT>
 struct OperandStage {
   static constexpr int NF4 = ROWS * BKT / (4 * NT);   // float4 per thread (fp32 source)
-  static constexpr int NP = ROWS * BKT / (8 * NT);    // 16-byte pieces per thread and plane (plane source)
+  static constexpr int NPIECE = ROWS * BKT / 8;       // 16-byte pieces per plane
+  static constexpr int NP = (NPIECE + NT - 1) / NT;   // per thread (the 192-row tile on 512 threads: 1.5 -> 2, the tail predicated)
+  static constexpr bool FULL = NPIECE % NT == 0;
   float4 f[PRE ? 1 : NF4];
   uint4 ph[PRE ? NP : 1], pl[PRE ? NP : 1];
 
@@ -226,11 +228,11 @@ struct OperandStage {
         bool ok;
         if (KC) {   // [row][k]: BKT/8 pieces per row
           const int64_t row = row0 + e / (BKT / 8), k = k0 + (e % (BKT / 8)) * 8;
-          ok = row < rows && k < kend;
+          ok = row < rows && k < kend && (FULL || e < NPIECE);
           off = row * ld + k;
         } else {    // [k][m]: ROWS/8 pieces per k
           const int64_t k = k0 + e / (ROWS / 8), m = row0 + (e % (ROWS / 8)) * 8;
-          ok = k < kend && m < rows;
+          ok = k < kend && m < rows && (FULL || e < NPIECE);
           off = k * ld + m;
         }
         ph[p] = ok ? *reinterpret_cast<const uint4*>(hi + off) : make_uint4(0u, 0u, 0u, 0u);
@@ -247,6 +249,7 @@ struct OperandStage {
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         const int e = p * NT + tid;
+        if (!FULL && e >= NPIECE) break;
         if (KC) {
           const int row = e / (BKT / 8);
           bf16raw* d = planes + row * PITCH_PS(BKT) + ps_unit(row, e % (BKT / 8), BKT / 8) * 8;
@@ -1211,10 +1214,12 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
     // hand (B = X: 3/4 to 9/10 of the staged elements) that operand is staged without any conversion work.
     case 34:
       if (pre == 2 && !a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 3, 2, true, 2, 32, 2, 4>), grid, dim3(512), 0, stream, g);
+      else if (pre == 3 && !a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 3, 2, true, 3, 32, 2, 4>), grid, dim3(512), 0, stream, g);   // dY as planes too
       else launch_tile_m<3, 2, true, 0, 2, 4>(a_kc, b_kc, grid, stream, g);
       break;
     case 24:
       if (pre == 2 && !a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 2, 2, true, 2, 32, 2, 4>), grid, dim3(512), 0, stream, g);
+      else if (pre == 3 && !a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 2, 2, true, 3, 32, 2, 4>), grid, dim3(512), 0, stream, g);
       else launch_tile_m<2, 2, true, 0, 2, 4>(a_kc, b_kc, grid, stream, g);
       break;
     default: return ADVMIL_EINVAL;

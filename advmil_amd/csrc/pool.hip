@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256) void act_dropout_bwd_kernel(const float* __res
         }
         o[q] = gv[q] * f * act_grad_from_out(act, yy);
       }
-      *reinterpret_cast<float4*>(dpre + off) = make_float4(o[0], o[1], o[2], o[3]);
+      if (dpre) *reinterpret_cast<float4*>(dpre + off) = make_float4(o[0], o[1], o[2], o[3]);     // (NULL: planes only)
       if (o_hi) {
         uint2 hh, ll;
         split4(make_float4(o[0], o[1], o[2], o[3]), hh, ll);
@@ -566,7 +566,7 @@ extern "C" int advmil_act_dropout_bwd(const float* dy, const float* y, int act, 
                                       const int64_t* rng_row, void* out_hi, void* out_lo, void* ws, size_t ws_bytes,
                                       advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!dy || !y || !dpre || M <= 0 || N <= 0 || (N & 3) || ((out_hi != nullptr) != (out_lo != nullptr))) return ADVMIL_EINVAL;
+  if (!dy || !y || (!dpre && !out_hi) || M <= 0 || N <= 0 || (N & 3) || ((out_hi != nullptr) != (out_lo != nullptr))) return ADVMIL_EINVAL;
   if (dbias && (!ws || ws_bytes < advmil_colsum_workspace_bytes(M, N))) return ADVMIL_EWORKSPACE;
   const int rpb = rows_per_block(M);
   const int nblk = (int)((M + rpb - 1) / rpb);

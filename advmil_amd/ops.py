@@ -212,9 +212,9 @@ def split_planes(x, out=None):
     return out
 
 
-def pre_a_tile_ok(tile, a_kc, b_kc):
+def pre_a_tile_ok(tile, a_kc, b_kc, b_planes=False):
     """Is the contraction kernel of this tile built for an A operand that arrives as planes only (csrc/gemm_f32.hip dispatch)?"""
-    return tile in (22, 12, 11) or (tile == 43 and not b_kc)
+    return tile in (22, 12, 11) or (tile == 43 and not b_kc and not b_planes) or (tile in (34, 24) and not a_kc and not b_kc and b_planes)
 
 
 def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=None, act_split=None, drop_p=0.0,
@@ -225,7 +225,7 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
     planes_only_a = A is None
     if planes_only_a:
         # A exists as planes only (dG of the gate backward): the launch must land on a kernel instantiated for a pre-split A operand
-        if a_planes is None or get_gemm_mode() != "bf16x3" or b_planes is not None:
+        if a_planes is None or get_gemm_mode() != "bf16x3":
             raise ValueError("gemm(A=None) needs a_planes in bf16x3 mode")
         A = a_planes.hi                       # (pointer and pitch only: never read as fp32)
     else:
@@ -285,7 +285,7 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
         ptile, splits = gemm_plan(M, N, K, a_kc, b_kc)
         if tile == 0:
             tile = ptile
-    if planes_only_a and not pre_a_tile_ok(tile if tile else gemm_plan(M, N, K, a_kc, b_kc)[0], a_kc, b_kc):
+    if planes_only_a and not pre_a_tile_ok(tile if tile else gemm_plan(M, N, K, a_kc, b_kc)[0], a_kc, b_kc, b_planes is not None):
         raise ValueError(f"gemm(A=None): tile {tile} has no pre-split-A instantiation for this layout")
     L = _lib.lib()
     wsb = L.advmil_gemm_f32_workspace_bytes(M, N, splits)
@@ -457,9 +457,10 @@ def gate_bwd(ab, ds, wc, N, D, p=0.0, seed=None, stream_a=0, stream_b=0, dwc=Non
     return dG, dwc, dbc, dbias
 
 
-def act_dropout_bwd(dy, y, act, M, N, p=0.0, seed=None, stream_id=0, want_bias=True, db_out=None, rng_row=None, planes=None):
+def act_dropout_bwd(dy, y, act, M, N, p=0.0, seed=None, stream_id=0, want_bias=True, db_out=None, rng_row=None, planes=None,
+                    planes_only=False):
     L = _lib.lib()
-    dpre = torch.empty(M, N, dtype=torch.float32, device=dy.device)
+    dpre = None if (planes_only and planes is not None) else torch.empty(M, N, dtype=torch.float32, device=dy.device)
     acc = db_out is not None
     db = db_out if acc else (torch.empty(N, dtype=torch.float32, device=dy.device) if want_bias else None)
     need = acc or want_bias
@@ -626,7 +627,20 @@ class LinearActFn(torch.autograd.Function):
             if need_b:
                 db = colsum(dy, M, N, out=ctx.gb)
         else:
-            dpre, db = act_dropout_bwd(dy, y, act, M, N, p, seed, sid, want_bias=need_b, db_out=ctx.gb if need_b else None, rng_row=rr)
+            # slab layer whose input needs no gradient (the first layer): dpre is consumed by the weight-gradient contraction alone,
+            # which splits it into hi + lo anyway -> written as planes only, and the contraction takes both operands pre-split
+            xpl0 = ctx.xpl if (DW_PLANES and get_gemm_mode() == "bf16x3") else None
+            only = (DG_PLANES_ONLY and need_w and not need_x and xpl0 is not None and M >= 4096 and N % 8 == 0
+                    and pre_a_tile_ok(gemm_plan(N, K, M, False, False)[0], False, False, True))
+            dpl = Planes(torch.empty(M, N, dtype=torch.bfloat16, device=dy.device), torch.empty(M, N, dtype=torch.bfloat16, device=dy.device)) if only else None
+            dpre, db = act_dropout_bwd(dy, y, act, M, N, p, seed, sid, want_bias=need_b, db_out=ctx.gb if need_b else None, rng_row=rr,
+                                       planes=dpl, planes_only=only)
+            if only:
+                if ctx.gW is not None:
+                    gemm(None, x, False, False, N, K, M, out=ctx.gW.view(N, K), ldc=K, accumulate=True, a_planes=dpl, b_planes=xpl0)
+                    return None, None, (None if ctx.gb is not None else db), None, None, None, None, None, None, None, None, None
+                dW = gemm(None, x, False, False, N, K, M, a_planes=dpl, b_planes=xpl0).reshape(wshape)
+                return None, dW, (None if ctx.gb is not None else db), None, None, None, None, None, None, None, None, None
         dW = None
         if need_w:                                           # dpre^T x
             xpl = ctx.xpl if (DW_PLANES and get_gemm_mode() == "bf16x3") else None

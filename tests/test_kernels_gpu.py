@@ -257,6 +257,36 @@ def test_gemm_planes_bit_identical_to_on_the_fly_split(ops, a_kc, b_kc, shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tile,N,K,R", [(34, 384, 1024, 8192), (34, 192, 264, 4104), (24, 128, 1024, 8192), (24, 136, 520, 4104)])
+@pytest.mark.parametrize("p", [0.0, 0.25])
+def test_weight_gradient_from_planes_only_activation_backward(ops, tile, N, K, R, p):
+    """First-layer weight gradient dpre^T X with dpre written as hi/lo planes ONLY by the activation backward (no fp32 copy) and the
+    contraction taking both operands pre-split (tiles 34 / 24, [k][m] layout on both sides; the 192-row tile stages 1.5 pieces per
+    thread): bit-identical to the fp32 dpre split on the fly, ragged edges included."""
+    prev = ops.get_gemm_mode()
+    ops.set_gemm_mode("bf16x3")
+    try:
+        g = torch.Generator(device="cuda").manual_seed(17)
+        X = torch.randn(R, K, device="cuda", generator=g)
+        dy = torch.randn(R, N, device="cuda", generator=g)
+        y = torch.relu(torch.randn(R, N, device="cuda", generator=g))
+        seed = torch.tensor([77], dtype=torch.int64, device="cuda") if p else None
+        dpre, db0 = ops.act_dropout_bwd(dy, y, ops.ACT_RELU, R, N, p, seed, 5)
+        pl = ops.Planes(torch.empty(R, N, dtype=torch.bfloat16, device="cuda"), torch.empty(R, N, dtype=torch.bfloat16, device="cuda"))
+        none, db1 = ops.act_dropout_bwd(dy, y, ops.ACT_RELU, R, N, p, seed, 5, planes=pl, planes_only=True)
+        assert none is None and torch.equal(db0, db1)
+        want = ops.split_planes(dpre)
+        assert torch.equal(pl.hi, want.hi) and torch.equal(pl.lo, want.lo)
+        px = ops.split_planes(X)
+        for splits in (1, 4):
+            ref = ops.gemm(dpre, X, False, False, N, K, R, tile=tile, splits=splits)
+            got = ops.gemm(None, X, False, False, N, K, R, tile=tile, splits=splits, a_planes=pl, b_planes=px)
+            assert torch.isfinite(got).all() and torch.equal(got, ref), splits
+    finally:
+        ops.set_gemm_mode(prev)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, False), (False, True)])
 @pytest.mark.parametrize("tile", [43, 42, 34, 24])
 def test_gemm_bf16x3_eight_wave_tiles(ops, a_kc, b_kc, tile):
