@@ -94,6 +94,9 @@ SIGNATURES = {
     "advmil_skinny_linear_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "advmil_skinny_linear_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                          c_void_p, c_int, c_void_p]),
+    "advmil_prj_head_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "advmil_prj_head_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_int, c_void_p]),
     "advmil_gan_d_loss": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "advmil_gan_g_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_int, c_float, c_float,
                                   c_float, c_void_p, c_void_p, c_void_p, c_void_p]),

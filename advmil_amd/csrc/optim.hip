@@ -303,3 +303,65 @@ extern "C" int advmil_skinny_linear_bwd(const float* x, const float* W, const fl
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }
+
+// ---- projection head of the discriminator (GANSurv.py:78-105): out[b] = <u[b], t[b]> + <src[b], w> + bias -- the (region-level)
+// inner product with the label embedding plus the width-1 projection layer, [B, d] head tensors: one launch each way instead of
+// mul + sum + linear + add (and their four backward launches). One wave per row.
+__global__ __launch_bounds__(64) void prj_head_fwd_kernel(const float* __restrict__ u, const float* __restrict__ t,
+                                                          const float* __restrict__ src, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, int d, float* __restrict__ out) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float s = 0.f;
+  for (int j = lane; j < d; j += 64) {
+    s += u[(int64_t)b * d + j] * t[(int64_t)b * d + j];
+    if (src) s += src[(int64_t)b * d + j] * w[j];
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[b] = s + ((src && bias) ? bias[0] : 0.f);
+}
+// blocks 0..B-1: du[b] = dout[b] t[b], dt[b] = dout[b] u[b], dsrc[b] = dout[b] w; block B: dw[j] = sum_b dout[b] src[b][j], dbias = sum_b dout[b]
+// (rows in index order: deterministic). accumulate != 0 adds into dw / dbias (the optimizer's gradient arena).
+__global__ __launch_bounds__(256) void prj_head_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ u,
+                                                           const float* __restrict__ t, const float* __restrict__ src,
+                                                           const float* __restrict__ w, int B, int d, float* __restrict__ du,
+                                                           float* __restrict__ dt, float* __restrict__ dsrc, float* __restrict__ dw,
+                                                           float* __restrict__ dbias, int accumulate) {
+  const int b = blockIdx.x;
+  if (b < B) {
+    const float g = dout[b];
+    for (int j = threadIdx.x; j < d; j += 256) {
+      const int64_t o = (int64_t)b * d + j;
+      if (du) du[o] = g * t[o];
+      if (dt) dt[o] = g * u[o];
+      if (dsrc) dsrc[o] = g * w[j];
+    }
+    return;
+  }
+  if (dw)
+    for (int j = threadIdx.x; j < d; j += 256) {
+      float s = 0.f;
+      for (int r = 0; r < B; ++r) s += dout[r] * src[(int64_t)r * d + j];
+      dw[j] = accumulate ? dw[j] + s : s;
+    }
+  if (dbias && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int r = 0; r < B; ++r) s += dout[r];
+    dbias[0] = accumulate ? dbias[0] + s : s;
+  }
+}
+extern "C" int advmil_prj_head_fwd(const float* u, const float* t, const float* src, const float* w, const float* bias, int B, int d,
+                                   float* out, advmil_stream_t stream_) {
+  if (!u || !t || !out || B <= 0 || d <= 0 || ((src != nullptr) != (w != nullptr))) return ADVMIL_EINVAL;
+  hipLaunchKernelGGL(prj_head_fwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream_, u, t, src, w, bias, d, out);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}
+extern "C" int advmil_prj_head_bwd(const float* dout, const float* u, const float* t, const float* src, const float* w, int B, int d,
+                                   float* du, float* dt, float* dsrc, float* dw, float* dbias, int accumulate, advmil_stream_t stream_) {
+  if (!dout || !u || !t || B <= 0 || d <= 0 || ((dsrc || dw) && (!src || !w))) return ADVMIL_EINVAL;
+  const int extra = (dw || dbias) ? 1 : 0;
+  hipLaunchKernelGGL(prj_head_bwd_kernel, dim3(B + extra), dim3(256), 0, (hipStream_t)stream_, dout, u, t, src, w, B, d, du, dt, dsrc,
+                     dw, dbias, accumulate);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}

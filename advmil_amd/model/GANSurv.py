@@ -139,6 +139,11 @@ class PrjDiscriminator(_PairNet):
         rng = _rng_of(self, t)
         hid_x = run_mlp_small(self.net_pair_one.fc2, emb_bag, rng, "dx_fc2")
         hid_t = run_mlp_small(self.net_pair_two, t, rng, "dy")
+        if hid_x.shape[0] <= 256 and hid_x.is_cuda and hid_x.dtype == torch.float32:      # [B, d] head: one launch each way
+            u = hid_x if self.inner_product == "bag" else ins_mean
+            if self.prj_layer is None:
+                return ops.prj_head(u, hid_t)
+            return ops.prj_head(u, hid_t, hid_x if self.prj_path == "x" else hid_t, self.prj_layer.weight, self.prj_layer.bias)
         if self.inner_product == "bag":
             out = (hid_t * hid_x).sum(dim=-1, keepdim=True)
         else:

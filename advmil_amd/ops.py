@@ -1320,3 +1320,48 @@ class SkinnyLinearFn(torch.autograd.Function):
 
 def skinny_linear(x, W, b, act="none"):
     return SkinnyLinearFn.apply(x, W, b, _ACT[act])
+
+
+class PrjHeadFn(torch.autograd.Function):
+    """out[B,1] = <u, t> + src w^T + bias (advmil_prj_head_fwd/bwd): the projection discriminator's head (reference GANSurv.py:96-105),
+    one launch each way; w / bias gradients accumulated straight into the optimizer arena when the parameters live there."""
+
+    @staticmethod
+    def forward(ctx, u, t, src, W, b):
+        u, t = u.contiguous(), t.contiguous()
+        B, d = u.shape
+        src_ = None if src is None else src.contiguous()
+        w = None if W is None else W.detach().reshape(-1).contiguous()
+        out = torch.empty(B, 1, dtype=torch.float32, device=u.device)
+        _lib.check(_lib.lib().advmil_prj_head_fwd(_p(u), _p(t), _p(src_), _p(w), _p(None if b is None else b.detach()), B, d, _p(out),
+                                                  _stream()), "prj_head_fwd")
+        ctx.save_for_backward(u, t, src_, w)
+        ctx.cfg = (B, d, None if W is None else W.shape, b is not None)
+        ctx.gW, ctx.gb = _arena_grad(W), _arena_grad(b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        u, t, src, w = ctx.saved_tensors
+        B, d, wshape, has_b = ctx.cfg
+        dout = dout.contiguous()
+        nu, nt, ns, nw = ctx.needs_input_grad[0], ctx.needs_input_grad[1], src is not None and ctx.needs_input_grad[2], \
+            src is not None and ctx.needs_input_grad[3]
+        nb = src is not None and has_b and ctx.needs_input_grad[4]
+        new = lambda: torch.empty(B, d, dtype=torch.float32, device=dout.device)  # noqa: E731
+        du, dt, ds = (new() if nu else None), (new() if nt else None), (new() if ns else None)
+        arena = (nw or nb) and (not nw or ctx.gW is not None) and (not nb or ctx.gb is not None)
+        if arena:
+            dw, db = (ctx.gW if nw else None), (ctx.gb if nb else None)
+        else:
+            dw = torch.empty(d, dtype=torch.float32, device=dout.device) if nw else None
+            db = torch.empty(1, dtype=torch.float32, device=dout.device) if nb else None
+        _lib.check(_lib.lib().advmil_prj_head_bwd(_p(dout), _p(u), _p(t), _p(src), _p(w), B, d, _p(du), _p(dt), _p(ds), _p(dw), _p(db),
+                                                  1 if arena else 0, _stream()), "prj_head_bwd")
+        if arena:
+            return du, dt, ds, None, None
+        return du, dt, ds, (None if dw is None else dw.reshape(wshape)), db
+
+
+def prj_head(u, t, src=None, W=None, b=None):
+    return PrjHeadFn.apply(u, t, src, W, b)

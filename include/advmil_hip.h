@@ -287,6 +287,13 @@ int advmil_skinny_linear_fwd(const float* x, const float* W, const float* bias, 
                              advmil_stream_t stream);
 int advmil_skinny_linear_bwd(const float* x, const float* W, const float* y, const float* dy, int B, int K, int N, int act, float* dx,
                              float* dW, float* dbias, int accumulate, advmil_stream_t stream);
+/* Projection head of the discriminator (reference model/GANSurv.py:78-105, PrjDiscriminator.forward): out[b] = <u[b], t[b]> + <src[b], w> + bias[0]
+ * for [B, d] head tensors -- u = the (region-mean) x embedding, t = the label embedding, src = the prj_layer's input (NULL: no projection
+ * layer). bwd: du / dt / dsrc [B, d], dw [d], dbias [1] (each may be NULL; accumulate != 0 adds into dw / dbias). */
+int advmil_prj_head_fwd(const float* u, const float* t, const float* src, const float* w, const float* bias, int B, int d, float* out,
+                        advmil_stream_t stream);
+int advmil_prj_head_bwd(const float* dout, const float* u, const float* t, const float* src, const float* w, int B, int d, float* du,
+                        float* dt, float* dsrc, float* dw, float* dbias, int accumulate, advmil_stream_t stream);
 int advmil_gan_d_loss(const float* fake, int nf, const float* real, const float* real_mask, int nr, int which, float inv_nf,
                       float inv_nr, float* out3, float* g_fake, float* g_real, advmil_stream_t stream);
 int advmil_gan_g_loss(const float* pred, const float* t, const float* e, const float* vis_mask, const float* fake, int n, float alpha,

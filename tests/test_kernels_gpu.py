@@ -482,6 +482,41 @@ def test_fused_gan_losses_match_composed_torch(ops, which):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,d", [(16, 128), (32, 128), (3, 200), (1, 1)])
+@pytest.mark.parametrize("mode", ["instance_x", "bag_x", "instance_y", "none"])
+def test_prj_head_fwd_bwd(ops, B, d, mode):
+    """out = <u, t> + prj_layer(src) in one launch each way (GANSurv.py:96-105) against the float64 composition on the host; `bag_x`
+    passes the same tensor as u and src (autograd sums the two gradients), `instance_y` projects the label embedding."""
+    g = torch.Generator(device="cuda").manual_seed(29)
+    hx = torch.randn(B, d, device="cuda", generator=g).requires_grad_(True)
+    ins = torch.randn(B, d, device="cuda", generator=g).requires_grad_(True)
+    ht = torch.randn(B, d, device="cuda", generator=g).requires_grad_(True)
+    W = (torch.randn(1, d, device="cuda", generator=g) * 0.3).requires_grad_(True)
+    b = torch.randn(1, device="cuda", generator=g).requires_grad_(True)
+    wgt = torch.randn(B, 1, device="cuda", generator=g)
+
+    def run(hx, ins, ht, W, b, f):
+        u = hx if mode.startswith("bag") else ins
+        if mode == "none":
+            return f(u, ht, None, None, None)
+        return f(u, ht, hx if mode.endswith("_x") else ht, W, b)
+
+    out = run(hx, ins, ht, W, b, ops.prj_head)
+    assert out.shape == (B, 1)
+    (out * wgt).sum().backward()
+    c = [t.detach().cpu().double().requires_grad_(True) for t in (hx, ins, ht, W, b)]
+    ref = run(*c, lambda u, t, src, W_, b_: (u * t).sum(-1, keepdim=True) + (0 if src is None else torch.nn.functional.linear(src, W_, b_)))
+    (ref * wgt.cpu().double()).sum().backward()
+    assert float((out.detach().cpu().double() - ref.detach()).abs().max()) < 1e-5 * (1.0 + float(ref.abs().max()))
+    for a, r in zip((hx, ins, ht, W, b), c):
+        if r.grad is None:
+            assert a.grad is None or float(a.grad.abs().max()) == 0.0
+            continue
+        assert a.grad is not None
+        assert float((a.grad.cpu().double() - r.grad).abs().max()) < 1e-5 * (1.0 + float(r.grad.abs().max()))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,K,N", [(16, 1, 64), (32, 128, 1), (5, 192, 1), (1, 1, 1)])
 @pytest.mark.parametrize("act", ["none", "relu"])
 def test_skinny_linear_fwd_bwd(ops, B, K, N, act):
