@@ -37,6 +37,8 @@ SIGNATURES = {
     "advmil_gemm_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                                 c_int64, ctypes.POINTER(Epilogue), c_int, c_void_p, c_size_t, c_void_p]),
     "advmil_split_planes": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "advmil_gate_interleave": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "advmil_gate_partial_sum": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
     "advmil_gemm_f32_gate_blocks": (c_int, [c_int, c_int64]),
     "advmil_set_gemm_mode": (c_int, [c_int]),
     "advmil_get_gemm_mode": (c_int, []),
@@ -85,7 +87,7 @@ SIGNATURES = {
     "advmil_genconv_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64,
                                    c_int64, c_void_p, c_void_p]),
     "advmil_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
-                                 c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                 c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "advmil_abs_sum": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "advmil_abs_sum_workspace_bytes": (c_size_t, [c_int64]),
     "advmil_uniform_fill": (c_int, [c_void_p, c_int64, c_void_p, c_uint64, c_void_p, c_int64, c_void_p]),

@@ -388,6 +388,62 @@ extern "C" int advmil_softmax_pool_bwd(const float* dpooled, const float* dA, co
 }
 
 // =====================================================================================
+// Glue of the fused gate score (the contraction that reduces sum_j wc_j tanh(a_j) sigmoid(b_j) in its epilogue):
+//   gate_interleave: rows a0, b0, a1, b1, ... of the two branch weights as one [2D, D] matrix (fp32 + its bf16x3 planes) and the
+//     interleaved bias, so that a branch pair lands in adjacent accumulator columns -- one launch instead of stack, stack, split;
+//   gate_partial_sum: s[n] = sum_j partial[n][j] + bc -- the per-column-block partials of that epilogue, one launch instead of sum + add.
+// =====================================================================================
+__global__ __launch_bounds__(256) void gate_interleave_kernel(const float* __restrict__ Wa, const float* __restrict__ Wb,
+                                                              const float* __restrict__ ba, const float* __restrict__ bb, int D,
+                                                              float* __restrict__ Wi, bf16raw* __restrict__ hi, bf16raw* __restrict__ lo,
+                                                              float* __restrict__ bi) {
+  const int q4 = D >> 2;                                    // float4 per row
+  const int64_t total = (int64_t)2 * D * q4;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int r = (int)(e / q4), c = (int)(e % q4) * 4;     // output row r = 2 j + branch
+    const float* src = (r & 1) ? Wb : Wa;
+    const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)(r >> 1) * D + c);
+    *reinterpret_cast<float4*>(Wi + (int64_t)r * D + c) = v;
+    if (hi) {
+      uint2 hh, ll;
+      split4(v, hh, ll);
+      *reinterpret_cast<uint2*>(hi + (int64_t)r * D + c) = hh;
+      *reinterpret_cast<uint2*>(lo + (int64_t)r * D + c) = ll;
+    }
+  }
+  if (blockIdx.x == 0)
+    for (int r = threadIdx.x; r < 2 * D; r += 256) bi[r] = (r & 1) ? bb[r >> 1] : ba[r >> 1];
+}
+__global__ __launch_bounds__(256) void gate_partial_sum_kernel(const float* __restrict__ partial, int np, const float* __restrict__ bc,
+                                                               int64_t N, float* __restrict__ s) {
+  const float b = bc ? bc[0] : 0.f;
+  for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256) {
+    float a = 0.f;
+    for (int j = 0; j < np; ++j) a += partial[n * np + j];     // column blocks in index order: same sum as torch.sum(dim=1) is NOT implied, see tests
+    s[n] = a + b;
+  }
+}
+extern "C" int advmil_gate_interleave(const float* Wa, const float* Wb, const float* ba, const float* bb, int D, float* Wi, void* Wi_hi,
+                                      void* Wi_lo, float* bi, advmil_stream_t stream_) {
+  if (!Wa || !Wb || !ba || !bb || !Wi || !bi || D <= 0 || (D & 3) || ((Wi_hi != nullptr) != (Wi_lo != nullptr))) return ADVMIL_EINVAL;
+  if (((uintptr_t)Wa & 15) || ((uintptr_t)Wb & 15) || ((uintptr_t)Wi & 15) || ((uintptr_t)Wi_hi & 7) || ((uintptr_t)Wi_lo & 7)) return ADVMIL_EINVAL;
+  int64_t blocks = ((int64_t)2 * D * (D >> 2) + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(gate_interleave_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, Wa, Wb, ba, bb, D, Wi,
+                     (bf16raw*)Wi_hi, (bf16raw*)Wi_lo, bi);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}
+extern "C" int advmil_gate_partial_sum(const float* partial, int np, const float* bc, int64_t N, float* s, advmil_stream_t stream_) {
+  if (!partial || !s || np <= 0 || N <= 0) return ADVMIL_EINVAL;
+  int64_t blocks = (N + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gate_partial_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, partial, np, bc, N, s);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}
+
+// =====================================================================================
 // gate backward: ds[N] -> dG[N,2D] (grads wrt the two pre-activations), dwc, dbc, dbias
 // =====================================================================================
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ ab, const float* __restrict__ ds,

@@ -509,12 +509,15 @@ def ln_relu_mean16_bwd(demb, y, gamma, beta, mean, rstd, N, d, dg_out=None, db_o
     return dy, dg, db
 
 
-def adam_step(p, grad, m, v, wd, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, l1_coef=0.0, planes=None):
+def adam_step(p, grad, m, v, wd, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, l1_coef=0.0, planes=None,
+              arrivals=None):
     """In place over flat fp32 arenas; `step` is an int32 device tensor bumped by the kernel. `planes`: Planes arenas that receive
-    the bf16x3 operand planes of the updated weights."""
+    the bf16x3 operand planes of the updated weights. arrivals: int32[1] device tensor,
+    zero between calls (lets the kernel bump `step` itself instead of a second launch)."""
     _lib.check(_lib.lib().advmil_adam_step(_p(p), _p(grad), _p(m), _p(v), _p(wd), p.numel(), lr, beta1, beta2, eps,
                                            grad_scale, l1_coef, _p(step), _p(None if planes is None else planes.hi),
-                                           _p(None if planes is None else planes.lo), _stream()), "adam_step")
+                                           _p(None if planes is None else planes.lo), _p(arrivals), _stream()),
+               "adam_step")
 
 
 def abs_sum(p):
@@ -776,10 +779,8 @@ class GatedAttnPoolFn(torch.autograd.Function):
         if FUSED_GATE_SCORE and p <= 0.0 and N >= 4096 and nograd:
             # no-grad pass (the generator's eval forward of the discriminator update, test_model): nothing needs the [N, 2D] gate
             # activations, so the contraction reduces the score in its epilogue from interleaved branch rows and never stores them
-            Wi = torch.stack((Wa.detach(), Wb.detach()), dim=1).reshape(2 * D, D)
-            bi = torch.stack((ba.detach(), bb.detach()), dim=1).reshape(2 * D)
-            wipl = split_planes(Wi) if hpl is not None else None          # 2D x D: one tiny launch
-            s = gemm(h, Wi, True, True, N, 2 * D, D, bias=bi, gate_wc=wcv, a_planes=hpl, b_planes=wipl).sum(dim=1) + bc.detach()
+            Wi, bi, wipl = gate_interleave(Wa.detach(), ba.detach(), Wb.detach(), bb.detach(), D, planes=hpl is not None)   # one tiny launch
+            s = gate_partial_sum(gemm(h, Wi, True, True, N, 2 * D, D, bias=bi, gate_wc=wcv, a_planes=hpl, b_planes=wipl), bc.detach())
             A, pooled = softmax_pool(s, h, N, D, seg)
             ctx.mark_non_differentiable(s)
             return pooled, A, s
@@ -1320,6 +1321,29 @@ class SkinnyLinearFn(torch.autograd.Function):
 
 def skinny_linear(x, W, b, act="none"):
     return SkinnyLinearFn.apply(x, W, b, _ACT[act])
+
+
+def gate_interleave(Wa, ba, Wb, bb, D, planes=False):
+    """Rows a0, b0, a1, b1, ... of the two attention branches as one [2D, D] matrix (+ its bf16x3 planes) and the interleaved bias:
+    the operand layout of the fused gate score (advmil_gate_interleave)."""
+    Wa, Wb, ba, bb = (t.contiguous() for t in (Wa, Wb, ba, bb))
+    dev = Wa.device
+    Wi = torch.empty(2 * D, D, dtype=torch.float32, device=dev)
+    bi = torch.empty(2 * D, dtype=torch.float32, device=dev)
+    pl = Planes(torch.empty(2 * D, D, dtype=torch.bfloat16, device=dev), torch.empty(2 * D, D, dtype=torch.bfloat16, device=dev)) if planes else None
+    _lib.check(_lib.lib().advmil_gate_interleave(_p(Wa), _p(Wb), _p(ba), _p(bb), D, _p(Wi), _p(None if pl is None else pl.hi),
+                                                 _p(None if pl is None else pl.lo), _p(bi), _stream()), "gate_interleave")
+    return Wi, bi, pl
+
+
+def gate_partial_sum(partial, bc=None):
+    """s[n] = sum_j partial[n, j] (+ bc): the fused gate score's per-column-block partials -> scores (advmil_gate_partial_sum)."""
+    partial = partial.contiguous()
+    N, npart = partial.shape
+    s = torch.empty(N, dtype=torch.float32, device=partial.device)
+    _lib.check(_lib.lib().advmil_gate_partial_sum(_p(partial), npart, _p(None if bc is None else bc.reshape(-1)), N, _p(s), _stream()),
+               "gate_partial_sum")
+    return s
 
 
 class PrjHeadFn(torch.autograd.Function):

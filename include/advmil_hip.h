@@ -105,6 +105,12 @@ int advmil_gemm_f32(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, const f
  * split into hi + lo bf16 in registers and a.b is formed as ah.bh + ah.bl + al.bh on the bf16 matrix pipe with fp32
  * accumulate -- dropped terms ~2^-17 |a||b| per product, 3/16 of the matrix-pipe time. Storage stays fp32 everywhere. */
 int advmil_split_planes(const float* src, int64_t n, void* hi, void* lo, advmil_stream_t stream);
+/* Glue of the fused gate score (epilogue.gate_wc): Wi[2D, D] = rows a0, b0, a1, b1, ... of the attention branches' weights Wa, Wb [D, D]
+ * (reference model/backbone_utils.py Attn_Net_Gated: attention_a / attention_b), its planes (Wi_hi / Wi_lo, both or neither) and the
+ * interleaved bias bi[2D]; and s[n] = sum_j partial[n][j] + bc[0] over the np per-column-block partials the epilogue wrote (bc may be NULL). */
+int advmil_gate_interleave(const float* Wa, const float* Wb, const float* ba, const float* bb, int D, float* Wi, void* Wi_hi, void* Wi_lo,
+                           float* bi, advmil_stream_t stream);
+int advmil_gate_partial_sum(const float* partial, int np, const float* bc, int64_t N, float* s, advmil_stream_t stream);
 /* column blocks a launch with this tile writes per row in gate-score mode (see advmil_epilogue_t.gate_wc) */
 int advmil_gemm_f32_gate_blocks(int tile, int64_t N);
 int advmil_set_gemm_mode(int mode);
@@ -254,12 +260,13 @@ int advmil_genconv_bwd(const float* dout, const float* x, const float* out, cons
  * Optimizer + regulariser over a flat parameter arena (torch.optim.Adam, L2-in-grad weight decay:
  * optim/optim_factory.py:25-37,76-77; model/model_handler.py:104-107; L1: loss/utils.py:6-14).
  *   g = grad*grad_scale + l1_coef*sign(p) + wd[i]*p ; Adam(m, v) ; p -= lr/(1-b1^t) * m/(sqrt(v)/sqrt(1-b2^t)+eps)
- * `step` is a device int32 incremented by the kernel (graph-replay safe). wd may be NULL. p_hi / p_lo (both or neither): bf16 arenas of
+ * `step` is a device int32 incremented by the kernel (graph-replay safe). wd may be NULL. arrivals: a device int32 that is 0 on
+ * entry and 0 again on exit (the last workgroup to finish bumps *step); NULL: a second one-thread launch bumps it. p_hi / p_lo (both or neither): bf16 arenas of
  * n elements that receive the bf16x3 operand planes of the UPDATED weights, so the contractions never re-split a weight.
  * abs_sum: out[0] = sum |p| (for the logged Loss_G_total). */
 int advmil_adam_step(float* p, const float* grad, float* m, float* v, const float* wd, int64_t n, float lr,
                      float beta1, float beta2, float eps, float grad_scale, float l1_coef, int32_t* step, void* p_hi, void* p_lo,
-                     advmil_stream_t stream);
+                     int32_t* arrivals, advmil_stream_t stream);
 int advmil_abs_sum(const float* p, int64_t n, float* out, void* ws, size_t ws_bytes, advmil_stream_t stream);
 size_t advmil_abs_sum_workspace_bytes(int64_t n);
 

@@ -482,6 +482,27 @@ def test_fused_gan_losses_match_composed_torch(ops, which):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("D", [384, 128, 20])
+def test_gate_interleave_and_partial_sum(ops, D):
+    """Operand layout of the fused gate score: interleaved branch rows (fp32 + planes) + interleaved bias in one launch; the epilogue's
+    per-column-block partials summed (+ bc) in one launch."""
+    g = torch.Generator(device="cuda").manual_seed(41)
+    Wa, Wb = torch.randn(D, D, device="cuda", generator=g), torch.randn(D, D, device="cuda", generator=g)
+    ba, bb = torch.randn(D, device="cuda", generator=g), torch.randn(D, device="cuda", generator=g)
+    Wi, bi, pl = ops.gate_interleave(Wa, ba, Wb, bb, D, planes=True)
+    assert torch.equal(Wi, torch.stack((Wa, Wb), dim=1).reshape(2 * D, D)) and torch.equal(bi, torch.stack((ba, bb), dim=1).reshape(2 * D))
+    want = ops.split_planes(Wi)
+    assert torch.equal(pl.hi, want.hi) and torch.equal(pl.lo, want.lo)
+    assert ops.gate_interleave(Wa, ba, Wb, bb, D)[2] is None
+    part = torch.randn(5000, 6, device="cuda", generator=g)
+    bc = torch.randn(1, device="cuda", generator=g)
+    s = ops.gate_partial_sum(part, bc)
+    ref = part.double().sum(dim=1) + bc.double()
+    assert float((s.double() - ref).abs().max()) < 1e-6 * (1.0 + float(ref.abs().max()))
+    assert float((ops.gate_partial_sum(part).double() - part.double().sum(dim=1)).abs().max()) < 1e-6 * (1.0 + float(ref.abs().max()))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,d", [(16, 128), (32, 128), (3, 200), (1, 1)])
 @pytest.mark.parametrize("mode", ["instance_x", "bag_x", "instance_y", "none"])
 def test_prj_head_fwd_bwd(ops, B, d, mode):
