@@ -8,9 +8,10 @@ extern "C" int advmil_version(void) { return 100; }
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ m,
                                                    float* __restrict__ v, const float* __restrict__ wd, int64_t n, float lr,
                                                    float b1, float b2, float eps, float gscale, float l1,
-                                                   int32_t* __restrict__ step, unsigned short* __restrict__ p_hi,
-                                                   unsigned short* __restrict__ p_lo, int32_t* __restrict__ arrivals) {
-  const int t = *step + 1;   // *step is bumped by the last workgroup to finish (arrivals) or by the launcher's second kernel
+                                                   const int32_t* __restrict__ step, unsigned short* __restrict__ p_hi,
+                                                   unsigned short* __restrict__ p_lo) {
+  const int t = *step + 1;   // the launcher bumps *step after this kernel (a last-workgroup-bumps-it form was measured: the
+                             // 2048 arrivals on one counter cost 15 us, the second launch 4)
   const float bc1 = 1.f - hw_exp2((float)t * hw_log2(b1));      // 1 - b1^t
   const float bc2 = 1.f - hw_exp2((float)t * hw_log2(b2));
   const float step_size = lr * hw_rcp(bc1);
@@ -33,27 +34,19 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
       p_lo[i] = *reinterpret_cast<const unsigned short*>(&l);
     }
   }
-  if (arrivals) {
-    // every workgroup read *step before its loop; the one that arrives last knows all of them have, bumps it and re-arms the counter
-    __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(arrivals, 1) == (int)gridDim.x - 1) {
-      *step = t;
-      *arrivals = 0;
-    }
-  }
 }
 __global__ void step_inc_kernel(int32_t* step) { *step += 1; }
 
 extern "C" int advmil_adam_step(float* p, const float* grad, float* m, float* v, const float* wd, int64_t n, float lr,
                                 float beta1, float beta2, float eps, float grad_scale, float l1_coef, int32_t* step,
-                                void* p_hi, void* p_lo, int32_t* arrivals, advmil_stream_t stream_) {
+                                void* p_hi, void* p_lo, advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!p || !grad || !m || !v || !step || n <= 0 || ((p_hi != nullptr) != (p_lo != nullptr))) return ADVMIL_EINVAL;
   int blocks = (int)((n + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, p, grad, m, v, wd, n, lr, beta1, beta2, eps, grad_scale,
-                     l1_coef, step, (unsigned short*)p_hi, (unsigned short*)p_lo, arrivals);
-  if (!arrivals) hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, stream, step);
+                     l1_coef, step, (unsigned short*)p_hi, (unsigned short*)p_lo);
+  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, stream, step);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }

@@ -509,14 +509,12 @@ def ln_relu_mean16_bwd(demb, y, gamma, beta, mean, rstd, N, d, dg_out=None, db_o
     return dy, dg, db
 
 
-def adam_step(p, grad, m, v, wd, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, l1_coef=0.0, planes=None,
-              arrivals=None):
+def adam_step(p, grad, m, v, wd, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, l1_coef=0.0, planes=None):
     """In place over flat fp32 arenas; `step` is an int32 device tensor bumped by the kernel. `planes`: Planes arenas that receive
-    the bf16x3 operand planes of the updated weights. arrivals: int32[1] device tensor,
-    zero between calls (lets the kernel bump `step` itself instead of a second launch)."""
+    the bf16x3 operand planes of the updated weights."""
     _lib.check(_lib.lib().advmil_adam_step(_p(p), _p(grad), _p(m), _p(v), _p(wd), p.numel(), lr, beta1, beta2, eps,
                                            grad_scale, l1_coef, _p(step), _p(None if planes is None else planes.hi),
-                                           _p(None if planes is None else planes.lo), _p(arrivals), _stream()),
+                                           _p(None if planes is None else planes.lo), _stream()),
                "adam_step")
 
 

@@ -58,7 +58,6 @@ class FlatAdam(torch.optim.Optimizer):
         self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_wd = torch.zeros(total, dtype=torch.float32, device=dev)
         self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)
-        self._arrivals = torch.zeros(1, dtype=torch.int32, device=dev)      # workgroup arrival counter of the Adam kernel (0 between calls)
 
         # bf16x3 operand planes of the weights (hi = bf16(w), lo = bf16(w - hi)), same layout as the arena: written by the Adam
         # kernel with every update, so no contraction ever re-splits a weight (ops.weight_planes)
@@ -101,8 +100,7 @@ class FlatAdam(torch.optim.Optimizer):
         b1, b2 = g0["betas"]
         self.n_updates = getattr(self, "n_updates", 0) + 1      # host-side version of the parameters (forward memo key)
         ops.adam_step(self.flat_param, self.flat_grad, self.flat_m, self.flat_v, self.flat_wd if self._has_wd else None,
-                      self.step_t, g0["lr"], b1, b2, g0["eps"], grad_scale, self.l1_coef, planes=self.planes,
-                      arrivals=self._arrivals)
+                      self.step_t, g0["lr"], b1, b2, g0["eps"], grad_scale, self.l1_coef, planes=self.planes)
 
     def state_dict(self):
         n = float(self.step_t.item())

@@ -260,13 +260,12 @@ int advmil_genconv_bwd(const float* dout, const float* x, const float* out, cons
  * Optimizer + regulariser over a flat parameter arena (torch.optim.Adam, L2-in-grad weight decay:
  * optim/optim_factory.py:25-37,76-77; model/model_handler.py:104-107; L1: loss/utils.py:6-14).
  *   g = grad*grad_scale + l1_coef*sign(p) + wd[i]*p ; Adam(m, v) ; p -= lr/(1-b1^t) * m/(sqrt(v)/sqrt(1-b2^t)+eps)
- * `step` is a device int32 incremented by the kernel (graph-replay safe). wd may be NULL. arrivals: a device int32 that is 0 on
- * entry and 0 again on exit (the last workgroup to finish bumps *step); NULL: a second one-thread launch bumps it. p_hi / p_lo (both or neither): bf16 arenas of
+ * `step` is a device int32 incremented by the kernel (graph-replay safe). wd may be NULL. p_hi / p_lo (both or neither): bf16 arenas of
  * n elements that receive the bf16x3 operand planes of the UPDATED weights, so the contractions never re-split a weight.
  * abs_sum: out[0] = sum |p| (for the logged Loss_G_total). */
 int advmil_adam_step(float* p, const float* grad, float* m, float* v, const float* wd, int64_t n, float lr,
                      float beta1, float beta2, float eps, float grad_scale, float l1_coef, int32_t* step, void* p_hi, void* p_lo,
-                     int32_t* arrivals, advmil_stream_t stream);
+                     advmil_stream_t stream);
 int advmil_abs_sum(const float* p, int64_t n, float* out, void* ws, size_t ws_bytes, advmil_stream_t stream);
 size_t advmil_abs_sum_workspace_bytes(int64_t n);
 
