@@ -53,7 +53,9 @@ __device__ __forceinline__ float4 reduce_rows(float4 v, const RowColMap& m, floa
 // loads in flight and the 16 row-lanes are folded through LDS, so the serial depth is nblk/256 (was nblk).
 __global__ __launch_bounds__(256) void colsum_merge_kernel(const float* __restrict__ partial, int nblk, int64_t stride,
                                                            int64_t ncols, float* __restrict__ out, int accumulate,
-                                                           int64_t seg_pstride = 0, int64_t seg_ostride = 0) {
+                                                           int64_t seg_pstride = 0, int64_t seg_ostride = 0,
+                                                           float* __restrict__ out1 = nullptr, int64_t c1 = 0,
+                                                           float* __restrict__ out2 = nullptr, int64_t c2 = 0) {
   __shared__ float red[16][17];
   partial += (int64_t)blockIdx.y * seg_pstride;      // gridDim.y = segments (bags of a step slab)
   out += (int64_t)blockIdx.y * seg_ostride;
@@ -82,7 +84,9 @@ __global__ __launch_bounds__(256) void colsum_merge_kernel(const float* __restri
     float t = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) t += red[r][cl];
-    out[c] = accumulate ? out[c] + t : t;
+    // up to three destinations for one partial row (the gate backward's dwc | dbias | dbc): columns >= c1 go to out1, >= c2 to out2
+    float* dst = (out2 && c >= c2) ? out2 + (c - c2) : (out1 && c >= c1) ? out1 + (c - c1) : out + c;
+    *dst = accumulate ? *dst + t : t;
   }
 }
 #define MERGE_GRID(ncols) dim3((unsigned)(((ncols) + 15) / 16))
@@ -546,11 +550,9 @@ extern "C" int advmil_gate_bwd(const float* ab, const float* ds, const float* wc
   hipLaunchKernelGGL(gate_bwd_kernel, dim3(nblk), dim3(256), 0, stream, ab, ds, wc, drop_p, seed, stream_a, stream_b, N, D,
                      dG, partial, rpb, rng_row, (bf16raw*)dG_hi, (bf16raw*)dG_lo);
   ADVMIL_LAUNCH_CHECK();
-  // dwc | dbias(a) | dbias(b) | dbc are adjacent in the partial rows: one merge launch over 3D+1 columns into a
-  // scratch row, then scattered by the three tiny copies below would cost more launches; instead merge each target.
-  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(D), dim3(256), 0, stream, partial, nblk, stride, D, dwc, accumulate);
-  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(2 * D), dim3(256), 0, stream, partial + D, nblk, stride, 2 * D, dbias, accumulate);
-  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(1), dim3(256), 0, stream, partial + 3 * D, nblk, stride, (int64_t)1, dbc, accumulate);
+  // dwc | dbias(a) | dbias(b) | dbc are adjacent in the partial rows: one merge launch over the 3D+1 columns, three destinations
+  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(3 * D + 1), dim3(256), 0, stream, partial, nblk, stride, 3 * D + 1, dwc, accumulate,
+                     (int64_t)0, (int64_t)0, dbias, D, dbc, 3 * D);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }

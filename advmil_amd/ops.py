@@ -40,6 +40,21 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_CONST_ZEROS = {}
+
+
+def _const_zeros(n, device):
+    """A read-only fp32 zero vector (the all-equal scores of the mean pool), kept per (n, device) instead of a fill launch per use.
+    Not cached while a graph is being captured: that allocation belongs to the graph's private pool."""
+    key = (int(n), str(device))
+    t = _CONST_ZEROS.get(key)
+    if t is None:
+        t = torch.zeros(n, dtype=torch.float32, device=device)
+        if not (t.is_cuda and torch.cuda.is_current_stream_capturing()):
+            _CONST_ZEROS[key] = t
+    return t
+
+
 def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 16) // 4 + 4, dtype=torch.float32, device=device)
 
@@ -1076,7 +1091,7 @@ class SegRowMeanFn(torch.autograd.Function):
     def forward(ctx, h, seg):
         h = h.contiguous()
         N, D = h.shape
-        A, pooled = softmax_pool(torch.zeros(N, dtype=torch.float32, device=h.device), h, N, D, seg)
+        A, pooled = softmax_pool(_const_zeros(N, h.device), h, N, D, seg)
         ctx.save_for_backward(A)
         ctx.seg = seg
         return pooled
@@ -1233,11 +1248,14 @@ class GanDLossFn(torch.autograd.Function):
         ctx.has_real = real is not None
         ctx.shapes = (fake.shape, None if real is None else real.shape)
         ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)      # no zeros[3] for the statistics output in the backward (one fill launch per step)
         return out[0], out
 
     @staticmethod
     def backward(ctx, go, _):
         gf, gr = ctx.saved_tensors
+        if go is None:
+            return (None,) * 7
         if ctx.root:          # the caller backpropagates from this loss itself (upstream gradient 1): the analytic gradients as they are
             return gf, gr.reshape(ctx.shapes[1]) if ctx.has_real else None, None, None, None, None, None
         return gf * go, (gr * go).reshape(ctx.shapes[1]) if ctx.has_real else None, None, None, None, None, None
@@ -1264,11 +1282,14 @@ class GanGLossFn(torch.autograd.Function):
         ctx.save_for_backward(gp, gf)
         ctx.shapes = (shape, fake.shape)
         ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)
         return out[0], out
 
     @staticmethod
     def backward(ctx, go, _):
         gp, gf = ctx.saved_tensors
+        if go is None:
+            return (None,) * 12
         if ctx.root:
             return (gp.reshape(ctx.shapes[0]), gf.reshape(ctx.shapes[1])) + (None,) * 10
         return ((gp * go).reshape(ctx.shapes[0]), (gf * go).reshape(ctx.shapes[1])) + (None,) * 10
