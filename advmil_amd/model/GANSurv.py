@@ -33,7 +33,12 @@ class Generator(nn.Module):
                 else:
                     n = generate_noise(*H.size(), to_device=H.device, distribution=self.noise_dist, rng=rng)
                 H = torch.cat([H, n], dim=1)
-            H = run_mlp_small(layer, H, rng, f"gen_mlp{i}")
+            if i == len(self.MLPs) - 1 and self.out_scale == "sigmoid":      # the output scale rides in the last layer's launch
+                H, done = run_mlp_small(layer, H, rng, f"gen_mlp{i}", final_act="sigmoid")
+                if done:
+                    return H
+            else:
+                H = run_mlp_small(layer, H, rng, f"gen_mlp{i}")
         if self.out_scale == "sigmoid":
             return torch.sigmoid(H)
         if self.out_scale == "exp":

@@ -87,11 +87,14 @@ def _fusable(lin, x):
     return x.dim() == 2 and x.is_cuda and lin.in_features % 4 == 0 and lin.out_features % 4 == 0
 
 
-def run_mlp_small(seq, x, rng, tag):
+def run_mlp_small(seq, x, rng, tag, final_act=None):
     """Apply a Sequential of Linear / LayerNorm / ReLU / Dropout holders to a [B, d]-sized tensor. Linear (+ReLU) (+Dropout)
     runs of a layer go through ONE contraction launch (bias, activation and dropout in its epilogue; in the backward the weight
-    and bias gradients are accumulated straight into the optimizer's arena), the rest stays a tiny device op each."""
+    and bias gradients are accumulated straight into the optimizer's arena), the rest stays a tiny device op each.
+    final_act ('sigmoid'): an activation the CALLER applies to the result (the generator's out_scale); when the Sequential ends in a
+    width-1 Linear it rides in that layer's launch. Then returns (x, applied)."""
     mods = list(seq)
+    applied = False
     j = 0
     while j < len(mods):
         m = mods[j]
@@ -112,6 +115,8 @@ def run_mlp_small(seq, x, rng, tag):
                 act, k = "none", j + 1
                 if k < len(mods) and isinstance(mods[k], nn.ReLU):
                     act, k = "relu", k + 1
+                elif k == len(mods) and final_act is not None:
+                    act, applied = final_act, True
                 x = ops.skinny_linear(x, m.weight, m.bias, act)
                 j = k
                 continue
@@ -127,7 +132,7 @@ def run_mlp_small(seq, x, rng, tag):
         else:
             raise NotImplementedError(type(m))
         j += 1
-    return x
+    return x if final_act is None else (x, applied)
 
 
 class EmbedXLayer(nn.Module):
