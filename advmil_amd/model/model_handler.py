@@ -289,7 +289,9 @@ class MyHandler(object):
         seg16.twice()                                    # (built here: the D update stacks its fake and real passes)
         seg16.rng_rowoff = rowoff16
         self._plan_count = getattr(self, "_plan_count", 0) + 1
-        return SimpleNamespace(vis=vis, is_real=is_real, n_real=n_real, n_fake=n_fake, n_vis=n_vis, y=torch.cat(ys, dim=0),
+        y = torch.cat(ys, dim=0)
+        return SimpleNamespace(vis=vis, is_real=is_real, n_real=n_real, n_fake=n_fake, n_vis=n_vis, y=y,
+                               y_t=y[:, 0:1].contiguous(), y_e=y[:, 1:2].contiguous(),     # label columns, contiguous once per plan
                                vis_mask=None if all(vis) else masks_d[n:], real_mask=masks_d[:n], seg=seg, seg16=seg16,
                                rng_rows=rng_rows, token=self._plan_count, _keep=(masks, masks_d))
 
@@ -402,7 +404,7 @@ class MyHandler(object):
             self._fork_evt = torch.cuda.Event()
             self._fork_evt.record()
         emb = self.netD.embed_rows(X)                                          # shared by the real and the fake pairs
-        f_real = None
+        f_real = f2 = None
         if plan.n_real > 0:                  # GLOBAL count: every rank of a bag-parallel step takes the same branch / draws
             # The fake pairs (all bags) and the real pairs go through the region-level network and the tail as ONE stacked batch:
             # rows [0, L) are the fake pass, rows [L, 2L) the real pass (its own dropout draw, as a separate forward has, because
@@ -410,16 +412,18 @@ class MyHandler(object):
             # scores of bags without a visible event are computed and dropped (B rows of [B,d] work).
             nb = len(xs)
             eb2, im2 = self.netD.bag_features_multi(torch.cat([emb, emb], dim=0), plan.seg16.twice())
-            f2 = self.netD.tail(eb2, im2, torch.cat([pred, y[:, 0:1]], dim=0)).view(-1)
-            f_fake, f_real = f2[:nb], f2[nb:]                                   # real scores of ALL bags; the mask picks the pairs
+            f2 = self.netD.tail(eb2, im2, torch.cat([pred, plan.y_t], dim=0)).view(-1)
+            f_fake = f2.detach()[:nb]                                           # (the loss takes f2 whole: no slice backward)
         else:
             eb, im = self.netD.bag_features_multi(emb, plan.seg16)
             f_fake = self.netD.tail(eb, im, pred).view(-1)
         # real_fake_loss with the global denominators (loss/utils.py:182-203, model_handler.py:412) as ONE launch that also yields
         # d loss / d score; the real pairs are selected by a 0/1 mask (same sum as f_real[event & visible], no index backward)
         ops.PREFILL.clear()                  # (anything the two forwards did not take is stale from here on)
-        loss, st = ops.gan_d_loss(f_fake, f_real, None if f_real is None else plan.real_mask, self.which_loss, plan.n_fake, plan.n_real,
-                                  root=True)
+        if f2 is not None:                   # rows [0, nb) fake, [nb, 2 nb) real scores of ALL bags; the mask picks the real pairs
+            loss, st = ops.gan_d_loss_stacked(f2, len(xs), plan.real_mask, self.which_loss, plan.n_fake, plan.n_real, root=True)
+        else:
+            loss, st = ops.gan_d_loss(f_fake, None, None, self.which_loss, plan.n_fake, plan.n_real, root=True)
         torch.autograd.backward(loss, grad_tensors=self._one())      # (the root gradient is a cached 1: no fill launch per step)
         self._st_d = (st, plan, i_batch)     # this rank's partial sums over the global denominators; reduced + logged in _disc_apply
         preds = list(pred.split(1, dim=0))
@@ -529,7 +533,7 @@ class MyHandler(object):
         if self.dp.world > 1:
             n_vis = plan.n_vis
         rc = self._recon
-        total, st = ops.gan_g_loss(pred, f_fake, y[:, 0:1], y[:, 1:2], plan.vis_mask, rc["alpha"], rc["gamma"], rc["norm"],
+        total, st = ops.gan_g_loss(pred, f_fake, plan.y_t, plan.y_e, plan.vis_mask, rc["alpha"], rc["gamma"], rc["norm"],
                                    self.coef_ganloss, plan.n_fake, n_vis, root=True)
         torch.autograd.backward(total, grad_tensors=self._one())
         self._st_g = (st, i_batch)

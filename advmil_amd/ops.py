@@ -1261,6 +1261,39 @@ class GanDLossFn(torch.autograd.Function):
         return gf * go, (gr * go).reshape(ctx.shapes[1]) if ctx.has_real else None, None, None, None, None, None
 
 
+class GanDLossStackedFn(torch.autograd.Function):
+    """GanDLossFn on ONE score vector f2 = [fake scores (nb) | real scores (nb)] (the stacked discriminator pass): its gradient leaves as
+    one vector too, so autograd runs no slice backward (two zero-fills, two copies and an add per step)."""
+
+    @staticmethod
+    def forward(ctx, f2, nb, mask, which, inv_nf, inv_nr, root=False):
+        ctx.root = root
+        f2c = f2.contiguous().reshape(-1)
+        out = torch.empty(3, dtype=torch.float32, device=f2.device)
+        g2 = torch.empty_like(f2c)
+        fake, real, gf, gr = f2c[:nb], f2c[nb:], g2[:nb], g2[nb:]
+        _lib.check(_lib.lib().advmil_gan_d_loss(_p(fake), nb, _p(real), _p(mask), real.numel(), which, inv_nf, inv_nr, _p(out), _p(gf),
+                                                _p(gr), _stream()), "gan_d_loss")
+        ctx.save_for_backward(g2)
+        ctx.shape = f2.shape
+        ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)
+        return out[0], out
+
+    @staticmethod
+    def backward(ctx, go, _):
+        (g2,) = ctx.saved_tensors
+        if go is None:
+            return (None,) * 7
+        return (g2 if ctx.root else g2 * go).reshape(ctx.shape), None, None, None, None, None, None
+
+
+def gan_d_loss_stacked(f2, nb, real_mask, which, n_fake, n_real, root=False):
+    """gan_d_loss(f2[:nb], f2[nb:], ...) without slicing f2 in autograd."""
+    return GanDLossStackedFn.apply(f2, int(nb), real_mask, _WHICH[which], 1.0 / float(n_fake), (1.0 / float(n_real)) if n_real > 0 else 0.0,
+                                   root)
+
+
 def gan_d_loss(fake, real, real_mask, which, n_fake, n_real, root=False):
     """-> (loss [0-dim, differentiable], stats[3] = {loss, sum mask*real, sum fake}). root=True: the loss is what the caller calls
     backward on (upstream gradient 1), so the backward hands out the analytic gradients without two multiply launches."""
