@@ -300,7 +300,8 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
         ptile, splits = gemm_plan(M, N, K, a_kc, b_kc)
         if tile == 0:
             tile = ptile
-    if planes_only_a and not pre_a_tile_ok(tile if tile else gemm_plan(M, N, K, a_kc, b_kc)[0], a_kc, b_kc, b_planes is not None):
+    if planes_only_a and not (82 <= tile <= 85) and not pre_a_tile_ok(tile if tile else gemm_plan(M, N, K, a_kc, b_kc)[0], a_kc, b_kc,
+                                                                     b_planes is not None):       # (82-85: plane-fed, reads planes only)
         raise ValueError(f"gemm(A=None): tile {tile} has no pre-split-A instantiation for this layout")
     L = _lib.lib()
     wsb = L.advmil_gemm_f32_workspace_bytes(M, N, splits)
@@ -834,14 +835,15 @@ class GatedAttnPoolFn(torch.autograd.Function):
         # bf16x3: dh = dG Wab runs as an NT contraction of dG's planes (emitted by gate_bwd) with the planes of Wab^T (a 2D x D
         # transpose + split: two tiny launches) through the plane-fed kernel, when the shape qualifies
         gpl = None
-        if need_h and USE_PLANES and DH_PLANES and get_gemm_mode() == "bf16x3" and gemm_plan_planes(N, D, 2 * D):
+        dh_nt = bool(need_h and USE_PLANES and DH_PLANES and get_gemm_mode() == "bf16x3" and gemm_plan_planes(N, D, 2 * D))
+        if dh_nt:
             gpl = Planes(torch.empty(N, 2 * D, dtype=torch.bfloat16, device=h.device), torch.empty(N, 2 * D, dtype=torch.bfloat16, device=h.device))
         # bf16x3, slab-sized: dG is consumed by exactly two contractions (dh = dG Wab, dWab = dG^T h) that would split it into hi + lo
         # anyway -> the gate backward writes the planes INSTEAD of the fp32 values (same bytes) and both take their A operand pre-split
-        only = (gpl is None and DG_PLANES_ONLY and USE_PLANES and get_gemm_mode() == "bf16x3" and N >= 4096 and (2 * D) % 8 == 0
+        only = (DG_PLANES_ONLY and USE_PLANES and get_gemm_mode() == "bf16x3" and N >= 4096 and (2 * D) % 8 == 0
                 and pre_a_tile_ok(gemm_plan(2 * D, D, N, False, False)[0], False, False)
-                and (not need_h or pre_a_tile_ok(gemm_plan(N, D, 2 * D, True, False)[0], True, False)))
-        if only:
+                and (not need_h or dh_nt or pre_a_tile_ok(gemm_plan(N, D, 2 * D, True, False)[0], True, False)))
+        if only and gpl is None:
             gpl = Planes(torch.empty(N, 2 * D, dtype=torch.bfloat16, device=h.device), torch.empty(N, 2 * D, dtype=torch.bfloat16, device=h.device))
         if ctx.arena is not None:
             gWab, gbab, gwc, gbc = ctx.arena
@@ -851,12 +853,12 @@ class GatedAttnPoolFn(torch.autograd.Function):
         dh = None
         if need_h:
             # dG [N,2D] . Wab [2D,D]  +  A[n] * dpooled[bag(n), d]   (pooling's direct path, rank-1 per bag)
-            if only:
-                dh = gemm(None, Wab, True, False, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg, a_planes=gpl)
-            elif gpl is not None:
+            if dh_nt:
                 WabT = Wab.t().contiguous()                                       # [D, 2D]: k (= 2D) contiguous
                 dh = gemm(dG, WabT, True, True, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg,
                           a_planes=gpl, b_planes=split_planes(WabT))
+            elif only:
+                dh = gemm(None, Wab, True, False, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg, a_planes=gpl)
             else:
                 dh = gemm(dG, Wab, True, False, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg)
         nones = (None,) * 8
