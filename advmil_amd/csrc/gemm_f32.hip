@@ -1091,6 +1091,18 @@ static int plan_exact(int64_t M, int64_t N, int64_t K, int* tile, int* splits) {
   const int64_t w11 = n_tiles(11, M, N);
   if (K >= 512 && w11 < 384 && (N & 3) == 0) {
     static const int sorder[3] = {22, 12, 11};
+    if (g_gemm_mode == 1) {
+      // bf16x3, deep K over a small [M, N] (region-level weight gradients, 384 x 384 x 32768 ...): the LARGEST of the 128x128 / 64x128
+      // tiles that still gives ~1.5 waves of workgroups (>= 256 of them, <= 64 splits, >= 256 of K each) -- the 64x64 tile the rule
+      // below would pick streams its operands at a third of the rate (tools/probe/splitk_sweep.py: 384x384x32768 97 -> 62 us,
+      // 256x128x65536 46 -> 40 us, 1152x384x32768 145 -> 125 us)
+      for (int c = 0; c < 2; ++c) {
+        const int64_t w = n_tiles(sorder[c], M, N);
+        int64_t sp = (384 + w - 1) / w;
+        if (sp > 64) sp = 64;
+        if (sp >= 2 && w * sp >= 256 && K / sp >= 256) { *tile = sorder[c]; *splits = (int)sp; return ADVMIL_OK; }
+      }
+    }
     for (int c = 0; c < 3; ++c) {
       const int64_t w = n_tiles(sorder[c], M, N);
       const int64_t sp = (768 + w - 1) / w;
