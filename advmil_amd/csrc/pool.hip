@@ -318,7 +318,10 @@ extern "C" int advmil_softmax_pool_fwd(const float* s, const float* h, int64_t l
   return ADVMIL_OK;
 }
 
-// backward stage 1: t[n] = dA[n] + dot(dpooled[seg], h[n]); partial[seg][wg] = sum over the wg's 4 rows of A[n] t[n]
+// backward stage 1: t[n] = dA[n] + dot(dpooled[seg], h[n]); partial[seg][wg] = sum over the wg's 16 rows of A[n] t[n].
+// One wave per FOUR rows, their loads issued together (one row per wave left a single 16-byte load in flight per lane: 0.52 of the
+// HBM roof at the 16-bag slab).
+#define PBD_ROWS 4
 __global__ __launch_bounds__(256) void pool_bwd_dot_kernel(const float* __restrict__ dp, const float* __restrict__ dA,
                                                            const float* __restrict__ A, const float* __restrict__ h,
                                                            int64_t ldh, int64_t N, int64_t D,
@@ -329,26 +332,42 @@ __global__ __launch_bounds__(256) void pool_bwd_dot_kernel(const float* __restri
   const int b = blockIdx.y;
   int64_t beg, end;
   seg_range(seg_ptr, b, N, beg, end);
-  const int64_t n = beg + (int64_t)blockIdx.x * 4 + w;
+  const int64_t n0 = beg + ((int64_t)blockIdx.x * 4 + w) * PBD_ROWS;
   const float* dpb = dp + (int64_t)b * D;
-  float contrib = 0.f;
-  if (n < end) {
-    const float* row = h + n * ldh;
-    float acc = 0.f;
-    if ((D & 3) == 0 && (ldh & 3) == 0) {            // 16-byte loads (one wave per row; D = 384 -> 96 float4, 1.5 per lane)
-      const float4* r4 = reinterpret_cast<const float4*>(row);
+  float acc[PBD_ROWS];
+#pragma unroll
+  for (int rr = 0; rr < PBD_ROWS; ++rr) acc[rr] = 0.f;
+  if (n0 < end) {
+    if ((D & 3) == 0 && (ldh & 3) == 0) {            // 16-byte loads (D = 384 -> 96 float4 per row, 1.5 per lane)
       const float4* d4 = reinterpret_cast<const float4*>(dpb);
       for (int64_t q = lane; q < (D >> 2); q += 64) {
-        const float4 a = d4[q], v = r4[q];
-        acc += a.x * v.x + a.y * v.y + a.z * v.z + a.w * v.w;
+        const float4 a = d4[q];
+        float4 v[PBD_ROWS];
+#pragma unroll
+        for (int rr = 0; rr < PBD_ROWS; ++rr)
+          v[rr] = (n0 + rr < end) ? reinterpret_cast<const float4*>(h + (n0 + rr) * ldh)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int rr = 0; rr < PBD_ROWS; ++rr) acc[rr] += a.x * v[rr].x + a.y * v[rr].y + a.z * v[rr].z + a.w * v[rr].w;
       }
     } else {
-      for (int64_t j = lane; j < D; j += 64) acc += dpb[j] * row[j];
+      for (int64_t j = lane; j < D; j += 64) {
+        const float a = dpb[j];
+#pragma unroll
+        for (int rr = 0; rr < PBD_ROWS; ++rr)
+          if (n0 + rr < end) acc[rr] += a * h[(n0 + rr) * ldh + j];
+      }
     }
-    acc = wave_sum(acc);
-    if (dA) acc += dA[n];
-    if (lane == 0) t[n] = acc;
-    contrib = A[n] * acc;
+  }
+  float contrib = 0.f;
+#pragma unroll
+  for (int rr = 0; rr < PBD_ROWS; ++rr) {
+    const int64_t n = n0 + rr;
+    float s = wave_sum(acc[rr]);
+    if (n < end) {
+      if (dA) s += dA[n];
+      if (lane == 0) t[n] = s;
+      contrib += A[n] * s;
+    }
   }
   if (lane == 0) red[w] = contrib;
   __syncthreads();
@@ -382,7 +401,7 @@ extern "C" int advmil_softmax_pool_bwd(const float* dpooled, const float* dA, co
   if (nseg < 1 || max_len <= 0) return ADVMIL_EINVAL;
   if (ws_bytes < advmil_softmax_pool_workspace_bytes(max_len, D, nseg)) return ADVMIL_EWORKSPACE;
   float* partial = (float*)ws + 4;
-  const int nwg = (int)((max_len + 3) / 4);
+  const int nwg = (int)((max_len + 4 * PBD_ROWS - 1) / (4 * PBD_ROWS));
   hipLaunchKernelGGL(pool_bwd_dot_kernel, dim3(nwg, nseg), dim3(256), 0, stream, dpooled, dA, A, h, ldh, N, D, seg_ptr, ds, partial);
   ADVMIL_LAUNCH_CHECK();
   hipLaunchKernelGGL(pool_bwd_ds_kernel, dim3((unsigned)((max_len + 255) / 256), nseg), dim3(256), 0, stream, A, partial, nwg, N,
