@@ -1139,6 +1139,8 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
   hipStream_t stream = (hipStream_t)stream_;
   if (!A || !B || !epi || (!C && !epi->gate_wc) || M <= 0 || N <= 0 || K <= 0) return ADVMIL_EINVAL;
   if ((lda & 3) || (ldb & 3)) return ADVMIL_EINVAL;
+  if (lda < (a_kc ? K : M) || ldb < (b_kc ? K : N)) return ADVMIL_EINVAL;          // a row pitch shorter than the row it strides
+  if (C && ldc < (epi->c2 ? (int64_t)epi->n_split : N)) return ADVMIL_EINVAL;      // (two-layer form: C holds the first n_split columns)
   if (a_kc ? (K & 3) : (M & 3)) return ADVMIL_EINVAL;
   if (b_kc ? (K & 3) : (N & 3)) return ADVMIL_EINVAL;
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return ADVMIL_EINVAL;

@@ -162,6 +162,7 @@ extern "C" int advmil_gate_score_fwd(const float* ab, const float* wc, const flo
                                      uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D, float* s,
                                      const int64_t* rng_row, advmil_stream_t stream) {
   if (!ab || !wc || !bc || !s || N <= 0 || D <= 0) return ADVMIL_EINVAL;
+  if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !seed)) return ADVMIL_EINVAL;
   int64_t blocks = (N + 3) / 4;
   if (blocks > 8192) blocks = 8192;          // grid-stride over rows: 32 workgroups per CU
   hipLaunchKernelGGL(gate_score_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ab, wc, bc,
@@ -297,8 +298,10 @@ extern "C" int advmil_softmax_pool_fwd(const float* s, const float* h, int64_t l
                                        size_t ws_bytes, advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!s || !h || !A || !pooled || !ws || N <= 0 || D <= 0 || (D & 3) || D > 1024 || (ldh & 3)) return ADVMIL_EINVAL;
+  if (ldh < D || ((uintptr_t)h & 15)) return ADVMIL_EINVAL;        // rows are read as 16-byte vectors
+  if (!seg_ptr && nseg > 1) return ADVMIL_EINVAL;                   // several bags need their row offsets
   if (!seg_ptr) { nseg = 1; max_len = N; }
-  if (nseg < 1 || max_len <= 0) return ADVMIL_EINVAL;
+  if (nseg < 1 || max_len <= 0 || max_len > N) return ADVMIL_EINVAL;
   if (ws_bytes < advmil_softmax_pool_workspace_bytes(max_len, D, nseg)) return ADVMIL_EWORKSPACE;
   float* stats = (float*)ws;
   float* partial = stats + 4 * nseg;
@@ -397,8 +400,10 @@ extern "C" int advmil_softmax_pool_bwd(const float* dpooled, const float* dA, co
                                        void* ws, size_t ws_bytes, advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!dpooled || !A || !h || !ds || !ws || N <= 0 || D <= 0) return ADVMIL_EINVAL;
+  if (ldh < D || (ldh & 3) || ((uintptr_t)h & 15)) return ADVMIL_EINVAL;
+  if (!seg_ptr && nseg > 1) return ADVMIL_EINVAL;
   if (!seg_ptr) { nseg = 1; max_len = N; }
-  if (nseg < 1 || max_len <= 0) return ADVMIL_EINVAL;
+  if (nseg < 1 || max_len <= 0 || max_len > N) return ADVMIL_EINVAL;
   if (ws_bytes < advmil_softmax_pool_workspace_bytes(max_len, D, nseg)) return ADVMIL_EWORKSPACE;
   float* partial = (float*)ws + 4;
   const int nwg = (int)((max_len + 4 * PBD_ROWS - 1) / (4 * PBD_ROWS));

@@ -89,3 +89,53 @@ class SlabStager:
         evt = torch.cuda.Event()
         evt.record(torch.cuda.current_stream(self.device))
         self.free_evt[self.k] = evt
+
+
+class BagCache:
+    """Device-resident bags across epochs (replaces the per-bag, per-EPOCH `.cuda()` of reference
+    model/model_handler.py:315 / dataset/PatchWSI.py:65-83): the first time a bag (keyed by the loader's patient index) comes
+    through the staging slab it is copied once more, device to device, into its own HBM allocation together with its bf16x3
+    operand planes (the same 4 B per element again); from the second epoch on a step batch is assembled from the cached bags by
+    one row gather each for the fp32 rows and the two planes -- no PCIe traffic, no per-step split. 288 GB hold a whole NLST-sized
+    cohort (8 B per element: ~4 000 bags of 8192 patches). LRU under a byte budget; a bag that does not fit is simply not kept."""
+
+    def __init__(self, device, budget_bytes, with_planes=True):
+        from collections import OrderedDict
+        self.device = torch.device(device)
+        self.budget = int(budget_bytes)
+        self.with_planes = with_planes
+        self.entries = OrderedDict()      # key -> (x [1, N, C] fp32 device tensor carrying `_advmil_bag_planes`, bytes)
+        self.bytes = 0
+        self.hits = self.misses = self.evictions = 0
+
+    def get(self, key):
+        ent = self.entries.get(key)
+        if ent is None:
+            self.misses += 1
+            return None
+        self.entries.move_to_end(key)
+        self.hits += 1
+        return ent[0]
+
+    def put(self, key, x_dev):
+        """Keep a private copy of the staged bag `x_dev` [1, N, C] (a view into the staging slab, valid on the current stream)."""
+        from . import ops
+        if key in self.entries or self.budget <= 0:
+            return
+        planes = self.with_planes and ops.USE_PLANES and ops.get_gemm_mode() == "bf16x3"
+        nbytes = x_dev.numel() * (8 if planes else 4)
+        if nbytes > self.budget:
+            return
+        while self.bytes + nbytes > self.budget and self.entries:
+            _, (_, b) = self.entries.popitem(last=False)
+            self.bytes -= b
+            self.evictions += 1
+        x = x_dev.clone()
+        if planes:
+            x._advmil_bag_planes = ops.split_planes(x.view(-1, x.shape[-1]))
+        self.entries[key] = (x, nbytes)
+        self.bytes += nbytes
+
+    def stats(self):
+        return {"bags": len(self.entries), "gb": round(self.bytes / 1e9, 3), "hits": self.hits, "misses": self.misses,
+                "evictions": self.evictions}

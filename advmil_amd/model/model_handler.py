@@ -26,7 +26,7 @@ import torch
 from .. import ops
 from ..loss.utils import fake_generator_loss, real_fake_loss, real_fake_terms, recon_loss, recon_terms
 from ..optim import FlatAdam, create_optimizer
-from ..ingest import SlabStager
+from ..ingest import BagCache, SlabStager
 from ..parallel import BagParallel
 from ..utils.func import agg_tensor, seed_everything, sparse_key, sparse_str
 from .backbone import load_backbone
@@ -132,6 +132,7 @@ class MyHandler(object):
         self.optimizerD = FlatAdam(self.netD, lr=cfg["opt_netD_lr"], betas=(0.9, 0.999), weight_decay=0.0)
         self.steplr = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizerG, mode="min", factor=0.5, patience=10)
 
+        self._one_t = torch.ones((), dtype=torch.float32, device=self.device)     # the root gradient of both losses
         self.patient_id = dict()
         self.history = []          # list of dicts of DEVICE scalars, flushed by pop_logs()
         self.epoch = 0
@@ -187,33 +188,47 @@ class MyHandler(object):
         double-buffered pinned slab (advmil_amd/ingest.py): async H2D on a copy stream, the step batch contiguous in HBM.
         Under bag-parallel every rank walks its own shard of the loader (bag i of the global step batch on rank i mod W) and the
         returned collector is all-gathered back into global bag order (model_handler.py:333-339 semantics)."""
-        bp_every_batch = self.cfg["bp_every_batch"]
+        # cfg['bp_every_batch'] is the GLOBAL step batch (cfg_nlst.yaml:71) at any world size: this rank steps every bp / W bags
+        bp_every_batch = self.dp.local_step_bags(self.cfg["bp_every_batch"])
         num_update_gen = self.cfg["gen_updates"]
+        if self.dp.world > 1 and hasattr(train_loader, "__len__"):
+            self.dp.check_equal(len(train_loader) // bp_every_batch, "the number of optimizer steps of this epoch", self.device)
         ys_all, yhat_all, ffake_all = [], [], []
         i_col, x_col, y_col, yh_col = [], [], [], []
         stager = None
         staged = False
+        cache = self._bag_cache_for(name_loader)
+        fresh = []                               # (cache key, index into x_col) of the bags of this step that came over PCIe
+        staged_pos = []                          # indices into x_col of the bags of this step that sit in the staging slab
         i_batch = 0
         for data_idx, data_x, data_y in train_loader:
             i_batch += 1
             yh_col.append(data_y if not data_y.is_cuda else None)
             x0 = data_x[0]
             if torch.is_tensor(x0) and not x0.is_cuda and self.bcb != "graph":
-                if stager is None:
-                    stager = self.__dict__.setdefault("_stager", None) or SlabStager(self.device, x0.shape[-1])
-                    self._stager = stager
-                if not staged:
-                    stager.begin()
-                    staged = True
-                data_x = [stager.add(x0)] + [dx.to(self.device, non_blocking=True) if torch.is_tensor(dx) else dx for dx in data_x[1:]]
+                key = int(data_idx.reshape(-1)[0]) if cache is not None else None
+                hit = cache.get(key) if cache is not None else None
+                if hit is not None:              # resident since an earlier epoch: no H2D for the bag
+                    data_x = [hit] + [dx.to(self.device, non_blocking=True) if torch.is_tensor(dx) else dx for dx in data_x[1:]]
+                else:
+                    if stager is None:
+                        stager = self.__dict__.setdefault("_stager", None) or SlabStager(self.device, x0.shape[-1])
+                        self._stager = stager
+                    if not staged:
+                        stager.begin()
+                        staged = True
+                    if cache is not None:
+                        fresh.append((key, len(x_col)))
+                    staged_pos.append(len(x_col))
+                    data_x = [stager.add(x0)] + [dx.to(self.device, non_blocking=True) if torch.is_tensor(dx) else dx for dx in data_x[1:]]
             else:
                 data_x = [dx.to(self.device, non_blocking=True) if torch.is_tensor(dx) else dx for dx in data_x]
             data_y = data_y.to(self.device, non_blocking=True)
             i_col.append(data_idx); x_col.append(data_x); y_col.append(data_y)
             if i_batch % bp_every_batch == 0:
                 if staged:                               # growth may have re-based the views: take the final ones
-                    for xc, v in zip(x_col, stager.ready()):
-                        xc[0] = v
+                    for j, v in zip(staged_pos, stager.ready()):
+                        x_col[j][0] = v
                 mask = self._get_label_visiable_mask(name_loader, i_col)
                 ys_host = None if any(h is None for h in yh_col) else yh_col
                 nz_d = nz_g = None
@@ -227,6 +242,9 @@ class MyHandler(object):
                 preds, fakes = self._update_disc(i_batch, x_col, y_col, mode, mask, ys_host=ys_host, noise=nz_d, plan=plan, defer_apply=overlap)
                 for _ in range(num_update_gen):
                     self._update_gen(i_batch, x_col, y_col, mode, mask, ys_host=ys_host, noise=nz_g, plan=plan)
+                for key, j in fresh:                     # first sight of these bags: keep them (and their operand planes) in HBM
+                    cache.put(key, x_col[j][0])
+                fresh, staged_pos = [], []
                 if staged:
                     stager.release()
                     staged = False
@@ -239,6 +257,18 @@ class MyHandler(object):
             cltor = agg_tensor(cltor, {"y": gather(torch.cat(ys_all)).cpu(), "y_hat": gather(torch.cat(yhat_all)).cpu(),
                                        "f_fake": gather(torch.cat(ffake_all)).cpu()})
         return cltor
+
+    def _bag_cache_for(self, name_loader):
+        """The device-resident bag cache of a loader (advmil_amd/ingest.py::BagCache), or None. Budget: cfg['bag_cache_gb'] /
+        ADVMIL_BAG_CACHE_GB (0 = off); default 45 % of the device's memory."""
+        caches = self.__dict__.setdefault("_bag_caches", {})
+        if name_loader not in caches:
+            gb = os.environ.get("ADVMIL_BAG_CACHE_GB", self.cfg.get("bag_cache_gb"))
+            if gb is None:
+                gb = 0.45 * torch.cuda.get_device_properties(self.device).total_memory / 1e9
+            gb = float(gb)
+            caches[name_loader] = BagCache(self.device, gb * 1e9) if gb > 0 else None
+        return caches[name_loader]
 
     # ------------------------------------------------------------------------------------------
     def _update_disc(self, i_batch, xs, ys, mode="wlabel", label_visible_mask=None, ys_host=None, noise=None, plan=None,
@@ -293,18 +323,20 @@ class MyHandler(object):
         return SimpleNamespace(vis=vis, is_real=is_real, n_real=n_real, n_fake=n_fake, n_vis=n_vis, y=y,
                                y_t=y[:, 0:1].contiguous(), y_e=y[:, 1:2].contiguous(),     # label columns, contiguous once per plan
                                vis_mask=None if all(vis) else masks_d[n:], real_mask=masks_d[:n], seg=seg, seg16=seg16,
-                               rng_rows=rng_rows, token=self._plan_count, _keep=(masks, masks_d))
+                               rng_rows=rng_rows, token=self._plan_count, _keep=(masks, masks_d), _X=None, _X_src=None)
 
     def _rng_row_maps(self, all_lens, lens, n, W, r):
-        """Bag-parallel: upload parallel.rng_row_maps (local row -> row in the single-process slab, for every row count a slab-level
-        tensor of the step can have) as ONE pinned buffer / one asynchronous copy -> (ops.DeviceRng.rows, Segments.rng_rowoff)."""
+        """Bag-parallel: upload parallel.rng_row_maps (local row -> row in the single-process slab, one map per row LAYOUT a
+        slab-level tensor of the step can have) as ONE pinned buffer / one asynchronous copy -> (ops.DeviceRng.rows keyed by layout
+        kind, Segments.rng_rowoff)."""
         from ..parallel import rng_row_maps
         maps, off16 = rng_row_maps(all_lens, W, r, cluster=self.bcb == "cluster")
-        keys = list(maps)
-        host = torch.empty(sum(keys) + n, dtype=torch.int64, pin_memory=True)
+        kinds = list(maps)
+        host = torch.empty(sum(int(maps[k].shape[0]) for k in kinds) + n, dtype=torch.int64, pin_memory=True)
         hv, o, spans = host.numpy(), 0, {}
-        for k in keys:
-            hv[o:o + k] = maps[k]; spans[k] = (o, o + k); o += k
+        for k in kinds:
+            m = int(maps[k].shape[0])
+            hv[o:o + m] = maps[k]; spans[k] = (o, o + m); o += m
         hv[o:o + n] = off16
         devbuf = host.to(self.device, non_blocking=True)
         self._rng_keep = (host, devbuf)
@@ -314,9 +346,18 @@ class MyHandler(object):
     def _rows(x):
         return x.shape[-2]
 
-    def _slab(self, xs):
+    def _slab(self, xs, plan=None):
         """The step's bags as ONE [N_total, C] matrix: a zero-copy view when they already sit back to back in one
-        allocation (the staging slab of the loader / the resident pool of the bench), else one concatenation."""
+        allocation (the staging slab of the loader / the resident pool of the bench), else one concatenation (kept on the step
+        plan: the D and the G update of a step read the same matrix, and the forward memo recognises it by its address)."""
+        if plan is not None and getattr(plan, "_X", None) is not None and plan._X_src == [id(x[0]) for x in xs]:
+            return plan._X
+        X = self._slab_build(xs)
+        if plan is not None:
+            plan._X, plan._X_src = X, [id(x[0]) for x in xs]
+        return X
+
+    def _slab_build(self, xs):
         x0 = xs[0][0]
         c = x0.shape[-1]
         rows = [self._rows(x[0]) for x in xs]
@@ -331,7 +372,13 @@ class MyHandler(object):
                 ptr += r * c * 4
         X = (x0.as_strided((sum(rows), c), (c, 1), x0.storage_offset()) if ok
              else torch.cat([x[0].reshape(-1, c) for x in xs], dim=0))
-        self._slab_planes(X, x0 if ok else None)
+        pls = None if ok else [getattr(x[0], "_advmil_bag_planes", None) for x in xs]
+        if (pls and all(p is not None for p in pls) and X.shape[0] >= 4096 and ops.USE_PLANES and ops.get_gemm_mode() == "bf16x3"
+                and ops.gemm_plan_planes(X.shape[0], 128, c)):
+            # bags from the device-resident cache carry their operand planes: the step's planes are a row gather, not a re-split
+            X._advmil_planes = ops.Planes(torch.cat([p.hi for p in pls], dim=0), torch.cat([p.lo for p in pls], dim=0))
+        else:
+            self._slab_planes(X, x0 if ok else None)
         return X
 
     def _slab_planes(self, X, anchor):
@@ -343,7 +390,8 @@ class MyHandler(object):
         (anchor None) is split per step."""
         if X.shape[0] < 4096 or not ops.USE_PLANES or ops.get_gemm_mode() != "bf16x3" or not ops.gemm_plan_planes(X.shape[0], 128, X.shape[1]):
             return                            # (small slabs: the plane-fed kernel's 256-row tiles would not fill the chip)
-        if anchor is None:
+        if anchor is None or not getattr(self, "resident_planes", True):
+            # (resident_planes = False: fp32-only residency -- the split is part of every step, also under HIP-graph replay)
             X._advmil_planes = ops.split_planes(X)
             return
         cache = anchor.__dict__.setdefault("_advmil_slab_planes", {})
@@ -389,9 +437,15 @@ class MyHandler(object):
         heads and tails run once on [B,d] stacks."""
         self.netD.train()
         self.netG.eval()
-        self.rng.rows = plan.rng_rows
+        self.rng.rows = plan.rng_rows          # (cleared again below: the process-wide rng must not carry this step's maps)
+        try:
+            return self._disc_backward_body(i_batch, xs, ys, plan, noise)
+        finally:
+            self.rng.rows = None
+
+    def _disc_backward_body(self, i_batch, xs, ys, plan, noise=None):
         self.optimizerD.zero_grad()
-        X = self._slab(xs)
+        X = self._slab(xs, plan)
         y = plan.y                           # [B, 2] label stack, built once per step plan
         self._prefill_first_layers(X)          # G's and D's first layers over the slab from one launch (X staged once), when possible
         ops.MEMO.begin("record", ("G", id(self.netG), getattr(self.optimizerG, "n_updates", 0), plan.token), X)
@@ -431,10 +485,7 @@ class MyHandler(object):
         return preds, fakes
 
     def _one(self):
-        t = self.__dict__.get("_one_t")
-        if t is None:
-            t = self.__dict__["_one_t"] = torch.ones((), dtype=torch.float32, device=self.device)
-        return t
+        return self._one_t               # made in __init__: a first use inside HIP-graph capture would put it into the graph's pool
 
     def _reduce_d(self):
         """Bag-parallel exchange of the D update: the flat gradient arena and the step's three loss statistics."""
@@ -482,6 +533,12 @@ class MyHandler(object):
         self.netD.eval()
         self.netG.train()
         self.rng.rows = plan.rng_rows
+        try:
+            self._gen_forward_body(xs, plan, noise)
+        finally:
+            self.rng.rows = None
+
+    def _gen_forward_body(self, xs, plan, noise=None):
         fork, self._fork_evt = self._fork_evt, None
         main = torch.cuda.current_stream()
         side = main
@@ -492,7 +549,7 @@ class MyHandler(object):
             side.wait_event(fork)
         with torch.cuda.stream(side):
             self.optimizerG.zero_grad()
-            X = self._slab(xs)
+            X = self._slab(xs, plan)
             # row-sized pre-dropout layer outputs of the eval forward in _disc_backward are reused -- only when this call belongs
             # to the SAME step plan (token) and the generator has not been updated since (n_updates); an unpaired call recomputes
             ops.MEMO.begin("replay", ("G", id(self.netG), getattr(self.optimizerG, "n_updates", 0), plan.token), X)
@@ -536,6 +593,11 @@ class MyHandler(object):
         total, st = ops.gan_g_loss(pred, f_fake, plan.y_t, plan.y_e, plan.vis_mask, rc["alpha"], rc["gamma"], rc["norm"],
                                    self.coef_ganloss, plan.n_fake, n_vis, root=True)
         torch.autograd.backward(total, grad_tensors=self._one())
+        if join is not None:
+            # the generator's forward ran on the side stream, so autograd ran its backward nodes there too; the weight gradients
+            # are added into the arena by raw kernels (no AccumulateGrad node -> the engine syncs nothing back): the optimizer step
+            # on this stream must wait for them
+            torch.cuda.current_stream().wait_stream(self._side_stream)
         self._st_g = (st, i_batch)
 
     def _reduce_g(self):

@@ -69,9 +69,10 @@ class DeviceRng:
         self.counter = 0
         self.record = False
         self.log = []
-        # Bag-parallel: {row count of a slab-level tensor: int64 device tensor of the rows those rows occupy in the SINGLE-PROCESS
-        # step slab}. Every dropout / noise draw of a tensor with that many rows is indexed through it (rng_row arguments of the
-        # C ABI), so the masks do not depend on the world size. None = single process (identity).
+        # Bag-parallel: {layout kind (parallel.rng_row_maps): int64 device tensor of the rows this rank's rows of that layout occupy
+        # in the SINGLE-PROCESS step slab}. Every dropout / noise draw is indexed through the map of its call site's layout
+        # (SITE_LAYOUTS; rng_row arguments of the C ABI), so the masks do not depend on the world size. None = single process
+        # (identity). Set by the handler for the duration of a step's forward and cleared behind it.
         self.rows = None
         self.reset(seed)
 
@@ -95,17 +96,52 @@ class DeviceRng:
         """seed += inc on the device (capturable)."""
         _lib.check(_lib.lib().advmil_seed_advance(_p(self.seed), inc, _stream()), "seed_advance")
 
-    def row_map(self, n_rows):
-        return None if self.rows is None else self.rows.get(int(n_rows))
+    def row_map(self, n_rows, tag=None):
+        """Bag-parallel row map of the call site `tag` for a tensor of n_rows rows (None in a single process). The site names the
+        layouts it can be fed (SITE_LAYOUTS); the one whose map has n_rows rows is taken. Anything else is an error: a silent
+        fall-back to local row numbers would draw masks that differ from the single-process run."""
+        if self.rows is None:
+            return None
+        kinds = site_layouts(tag)
+        if kinds is None:
+            raise RuntimeError(f"bag-parallel: dropout / noise site '{tag}' has no registered row layout (ops.SITE_LAYOUTS); its "
+                               "draws would not be world-size invariant")
+        for k in kinds:
+            m = self.rows.get(k)
+            if m is not None and m.shape[0] == int(n_rows):
+                return m
+        raise RuntimeError(f"bag-parallel: site '{tag}' was given {int(n_rows)} rows, none of its layouts {kinds} has that many "
+                           f"({ {k: int(v.shape[0]) for k, v in self.rows.items()} })")
 
     def uniform(self, n, tag="noise", width=None):
         """n uniforms at flat indices 0..n-1 of a fresh stream; `width`: the tensor is [n / width, width] (rows = bags), which
         lets the bag-parallel row map address the single-process rows."""
         out = torch.empty(n, dtype=torch.float32, device=self.device)
         sid = self.site(tag, (n,), None)
-        rr = self.row_map(n // width) if width else None
+        rr = self.row_map(n // width, tag) if width else None
         _lib.check(_lib.lib().advmil_uniform_fill(_p(out), n, _p(self.seed), sid, _p(rr), width or 0, _stream()), "uniform_fill")
         return out
+
+
+# Row layouts of the step slab a dropout / noise call site can be applied to, by tag prefix (longest prefix wins). The layouts of
+# one site never share a row count (L vs 2L, n vs 2n, sum N >= 16 n vs 8 n), so (site, row count) identifies the map even when
+# two DIFFERENT layouts of a step happen to have equally many rows (e.g. 2n == sum N / 16 for two 32-patch bags).
+SITE_LAYOUTS = {
+    "abmil_fc": ("patch",), "gcn_fc": ("patch",), "gcn_phi": ("patch",), "gate_": ("patch", "cluster"),
+    "abmil_rho": ("bag",), "misl_fc": ("cluster",), "gapool_": ("region", "region2"), "esat_": ("region",),
+    "dx_fc1": ("region", "region2"), "dx_fc2": ("bag", "bag2"), "dy": ("bag", "bag2"), "gen_mlp": ("bag",), "noise": ("bag",),
+    "surv_mlp": ("bag",),
+}
+
+
+def site_layouts(tag):
+    if not tag:
+        return None
+    best = None
+    for pre, kinds in SITE_LAYOUTS.items():
+        if tag.startswith(pre) and (best is None or len(pre) > len(best[0])):
+            best = (pre, kinds)
+    return None if best is None else best[1]
 
 
 _RNGS = {}
@@ -598,7 +634,7 @@ def dropout(x, p, rng, tag=""):
         return x
     _chk(x, "x")
     sid = rng.site(tag, tuple(x.shape), p)
-    return DropoutFn.apply(x, float(p), rng.seed, sid, rng.row_map(x.numel() // x.shape[-1]))
+    return DropoutFn.apply(x, float(p), rng.seed, sid, rng.row_map(x.numel() // x.shape[-1], tag))
 
 
 class LinearActFn(torch.autograd.Function):
@@ -741,7 +777,7 @@ def linear_act(x, W, b, act="none", p=0.0, rng=None, tag="", emit_planes=False):
     if p > 0.0:
         rng = rng or default_rng(x.device)
         N = W.shape[0]
-        sid, seed, rr = rng.site(tag, (x2.shape[0], N), p), rng.seed, rng.row_map(x2.shape[0])
+        sid, seed, rr = rng.site(tag, (x2.shape[0], N), p), rng.seed, rng.row_map(x2.shape[0], tag)
     memo = MEMO if (MEMO.mode is not None and x2.data_ptr() == MEMO.rows_ptr and x2.shape[0] >= MEMO_MIN_ROWS
                     and not x2.requires_grad) else None
     # W._version: load_state_dict / any in-place torch write to the weight invalidates the entry (the fused Adam kernel writes
@@ -878,7 +914,7 @@ def gated_attn_pool(h, Wa, ba, Wb, bb, wc, bc, p=0.0, rng=None, tag="", seg=None
         rng = rng or default_rng(h.device)
         sa = rng.site(tag + "att_a", tuple(h.shape), p)
         sb = rng.site(tag + "att_b", tuple(h.shape), p)
-        seed, rr = rng.seed, rng.row_map(h.shape[0])
+        seed, rr = rng.seed, rng.row_map(h.shape[0], tag + "att_a")
     # grad mode is always off INSIDE Function.forward, so "nothing here will be differentiated" is decided out here
     nograd = not torch.is_grad_enabled() or not any(t.requires_grad for t in (h, Wa, ba, Wb, bb, wc, bc))
     hpl = planes_of(h) if (h.shape[0] >= 4096 and h.is_contiguous() and get_gemm_mode() == "bf16x3"
@@ -1062,7 +1098,7 @@ def add_dropout_layer_norm(x, o, gamma, beta, eps=1e-5, p=0.0, rng=None, tag="")
     sid, seed, rr = 0, None, None
     if p > 0.0:
         rng = rng or default_rng(x.device)
-        sid, seed, rr = rng.site(tag, tuple(o.shape), p), rng.seed, rng.row_map(o.shape[0])
+        sid, seed, rr = rng.site(tag, tuple(o.shape), p), rng.seed, rng.row_map(o.shape[0], tag)
     return AddDropoutLayerNormFn.apply(x, o, gamma, beta, float(eps), float(p), seed, sid, rr)
 
 

@@ -10,7 +10,8 @@ The reference has no distributed path (0 collectives). World-size
    (inside the fused Adam kernel);
  * every dropout / noise draw is indexed by the row its element occupies in the SINGLE-PROCESS step slab (bags in global order
    i = local_index * W + rank): the handler's step plan all-gathers the bag lengths and hands the kernels per-row maps
-   (ops.DeviceRng.rows, the rng_row arguments of the C ABI), so a W-rank step draws exactly the masks of the 1-rank step;
+   (ops.DeviceRng.rows keyed by layout kind, selected by the call site's tag -- ops.SITE_LAYOUTS --; the rng_row arguments of the
+   C ABI), so a W-rank step draws exactly the masks of the 1-rank step; a site without a registered layout raises at world > 1;
  * the epoch collector (y, y_hat, f_fake) is all-gathered back into global bag order; logged losses are all-reduced.
 This module is compute-agnostic (it only sees flat tensors), so the gloo tests drive it on CPU.
 """
@@ -36,6 +37,32 @@ class BagParallel:
 
     def global_index(self, local_index: int) -> int:
         return local_index * self.world + self.rank
+
+    def local_step_bags(self, bp_every_batch: int) -> int:
+        """cfg['bp_every_batch'] is the GLOBAL step batch (config/cfg_nlst.yaml:71: 16 bags per optimizer step), whatever the world
+        size: every rank steps after bp_every_batch / W of its own bags."""
+        if bp_every_batch % self.world != 0:
+            raise ValueError(f"bp_every_batch={bp_every_batch} is the global step batch and must be a multiple of the world size "
+                             f"{self.world} (bag i of a step batch runs on rank i mod W)")
+        return bp_every_batch // self.world
+
+    def shard_epoch(self, items, bp_every_batch: int):
+        """This rank's bags of an epoch: the reference steps every bp_every_batch bags and never back-propagates a trailing partial
+        batch (model_handler.py:321-345), so only the first floor(len / bp) * bp bags count; of those, bag i runs on rank i mod W.
+        Every rank gets the same number of bags and of optimizer steps (a rank with one bag more would hang the others in the
+        step's collectives)."""
+        self.local_step_bags(bp_every_batch)
+        usable = len(items) // bp_every_batch * bp_every_batch
+        return [it for i, it in enumerate(items[:usable]) if self.owns(i)]
+
+    def check_equal(self, value: int, what: str, device="cpu"):
+        """Raise on every rank if `value` differs between ranks (instead of hanging in a later collective)."""
+        if not (self.enabled and self.world > 1):
+            return
+        vals = [v[0] for v in self.allgather_ints([int(value)], device)]
+        if len(set(vals)) != 1:
+            raise RuntimeError(f"bag-parallel: {what} differs between ranks ({vals}); shard the epoch with "
+                               "BagParallel.shard_epoch so that every rank runs the same number of optimizer steps")
 
     # ---- exchange
     def allreduce_(self, flat: torch.Tensor) -> torch.Tensor:
@@ -85,9 +112,11 @@ class BagParallel:
 def rng_row_maps(all_lens, W, r, cluster=False):
     """Host side of the world-size-invariant randomness. `all_lens[q][j]` = patch rows of rank q's j-th bag of the step; this
     rank's bag j is bag j*W + r of the global step batch, whose single-process slab stacks the bags in global order.
-    Returns ({row count: int64 array local row -> single-process row}, per-bag region-row offsets for the attention kernels).
-    Keys: sum N (patch rows), sum N/16 (region rows), 2 * sum N/16 (the D update's stacked fake|real region rows), n (bag rows),
-    2n (the stacked tail rows), 8n (DeepAttMISL's cluster rows)."""
+    Returns ({layout kind: int64 array local row -> single-process row}, per-bag region-row offsets for the attention kernels).
+    Kinds (the layouts a slab-level tensor of the step can have; every dropout / noise call site names the kinds it can be fed,
+    ops.SITE_LAYOUTS, so two layouts that happen to have the same row count never get confused):
+      patch [sum N], region [sum N/16], region2 [2 sum N/16] (the D update's stacked fake|real region rows), bag [n],
+      bag2 [2n] (the stacked tail rows), cluster [8n] (DeepAttMISL's cluster rows)."""
     import numpy as np
     lens = list(all_lens[r])
     n = len(lens)
@@ -99,18 +128,10 @@ def rng_row_maps(all_lens, W, r, cluster=False):
     region = np.concatenate([goff[gi[j]] // 16 + np.arange(lens[j] // 16, dtype=np.int64) for j in range(n)])
     bags = np.asarray(gi, dtype=np.int64)
     SLg = int(goff[-1]) // 16
-    maps = {}
-
-    def put(arr):
-        k = int(arr.shape[0])
-        if k in maps and not np.array_equal(maps[k], arr):
-            raise NotImplementedError("bag-parallel RNG row maps are ambiguous for this step batch (two slab-level tensors of "
-                                      f"{k} rows with different layouts): bags this small are not supported at world > 1")
-        maps[k] = arr
-
-    put(patch); put(region); put(np.concatenate([region, SLg + region])); put(bags); put(np.concatenate([bags, G + bags]))
+    maps = {"patch": patch, "region": region, "region2": np.concatenate([region, SLg + region]), "bag": bags,
+            "bag2": np.concatenate([bags, G + bags])}
     if cluster:
-        put(np.concatenate([8 * g_ + np.arange(8, dtype=np.int64) for g_ in gi]))
+        maps["cluster"] = np.concatenate([8 * g_ + np.arange(8, dtype=np.int64) for g_ in gi])
     loc16 = np.concatenate([[0], np.cumsum([v // 16 for v in lens])])[:-1]
     off16 = np.asarray([goff[gi[j]] // 16 - loc16[j] for j in range(n)], dtype=np.int64)
     return maps, off16

@@ -1,15 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- WSI bags/sec through the full AdvMIL G+D training step on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+      N > 1 under torch.distributed.run (RANK / WORLD_SIZE in the environment): this process is one rank.
+      N > 1 WITHOUT a launcher environment: bench.py starts the N ranks itself (a child `python -m torch.distributed.run
+      --nproc-per-node N bench.py ...`, spawned before this process touches the GPU), relays rank 0's JSON line and the
+      exit code. It refuses (exit 2) when the box has fewer than N GPUs, unless ADVMIL_DIST_BACKEND=gloo asks for ranks
+      that share devices (functional testing).
 
 One "step" = one optimizer step of the hot path (`_update_disc` + `gen_updates=1` x `_update_gen`,
 reference model/model_handler.py:321-345) over `--bags` bags per GPU (default bp_every_batch = 16,
 config/cfg_nlst.yaml:71). Workload = BASELINE.json configs[1]: ABMIL generator + RLIP projection
 discriminator on synthetic 8192-patch x 1024 bags, resident in HBM before the timed region
 (>= 64 distinct bags per GPU = 2.1 GB >> the 256 MB Infinity Cache). Multi-GPU: bag-parallel, every rank
-runs its own bags, one RCCL all-reduce of each network's flat gradient arena per step (weak scaling:
-global step batch = bags x N).
+runs its own bags, one RCCL all-reduce of each network's flat gradient arena per step. `value` is the WEAK-scaling figure
+(global step batch = bags x N); the line also carries `strong_scaling` (N > 1): the reference's own step batch of 16 bags
+(cfg_nlst.yaml:71) split over the ranks, 16 / N bags per rank per step.
 
 Prints ONE JSON line (rank 0). Extra objects:
   roofline     : the dominant kernel of the step. ABMIL / DeepAttMISL / PatchGCN: the contraction (kernel, shape) that owns the
@@ -20,8 +26,11 @@ Prints ONE JSON line (rank 0). Extra objects:
   pool_roofline: the attention-pool call against the HBM roof, at the step slab and at one bag.
   sizes        : (1 GPU) the same step at the other sizes north_star names -- ABMIL 1k / 32k patches, ESAT 8k / 32k patches
                  (bags/s, and for ESAT the attention-core roofline) -- plus the exact-fp32 arithmetic mode and one bag per step.
-  train_each_epoch_eager_ragged : (1 GPU) the product loop itself -- MyHandler._train_each_epoch, eager, ragged pinned host bags
-                 through the staging slab (PCIe-inclusive) -- next to the graph-replay `value`.
+  product_loop : (1 GPU) the product loop itself -- MyHandler._train_each_epoch, eager launches, ragged pinned host bags -- over
+                 two epochs of the same loader: epoch 1 through the staging slab (PCIe-inclusive), epoch 2 out of the
+                 device-resident bag cache (no PCIe); plus `graph_resident_split_in_step` (graph replay with fp32-only residency:
+                 the operand-plane split inside every step), so the gap between `value` and the product loop can be apportioned
+                 between PCIe, the per-step split and eager launch overhead.
   cpu_baseline : the oracle (pure PyTorch CPU restatement of the reference schedule, pinned against the
                  reference to <=1e-6) timed on this box's host cores over a bounded sample of the same workload.
 """
@@ -57,6 +66,7 @@ def parse():
                     help="skip the extra measurements (other sizes / backbones, exact-fp32 mode, one bag per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling leg (N > 1)")
     ap.add_argument("--cpu-bags", type=int, default=4, help="bags in the CPU-baseline sample")
     return ap.parse_args()
 
@@ -154,13 +164,14 @@ def cpu_baseline(args, torch):
     dt = time.perf_counter() - t0
     return {"value": round(nb * reps / dt, 4), "unit": "bags/s", "cores": nthreads, "kind": "port",
             "sample": f"{reps} optimizer step(s) of {nb} bags x {N} patches x 1024 fp32, {kind}+RLIP, shipped dropout rates, "
-                      f"oracle/advmil_oracle.py::train_step, torch {torch.__version__} CPU, {nthreads} threads of {os.cpu_count()} cpus"}
+                      f"oracle/advmil_oracle.py::train_step, torch {torch.__version__} CPU, {nthreads} threads of {os.cpu_count()} cpus "
+                      f"(NOTE: the CPU sample steps every {nb} bags, the GPU line every 16; both are bags/s through full G+D steps)"}
 
 
 class Case:
     """One workload on this rank: a handler, its resident bag pool and one captured HIP graph per group of `bags` bags."""
 
-    def __init__(self, torch, dev, mode, patches, bags, pool, gemm_mode, seed, eager=False, world=1):
+    def __init__(self, torch, dev, mode, patches, bags, pool, gemm_mode, seed, eager=False, world=1, resident_planes=True):
         from advmil_amd.config import default_cfg
         from advmil_amd.model import MyHandler
         self.torch, self.dev, self.mode, self.patches, self.bags, self.world = torch, dev, mode, patches, bags, world
@@ -168,6 +179,7 @@ class Case:
         if mode == "graph":            # PatchGCN dims of the reference's model_stats.py:63
             cfg.update(bcb_dims="1024-128-128", gen_dims="128-1")
         self.h = MyHandler(cfg, device=dev)
+        self.h.resident_planes = resident_planes
         self.n_pool = max(pool, bags)
         self.xs, self.ys, self.ys_host = make_pool(torch, dev, mode, self.n_pool, patches, seed=seed, group=bags)
         self.cursor = 0
@@ -295,15 +307,169 @@ def pool_roofline(torch, ops, dev, patches, bags, iters=40):
             "method": f"{iters} back-to-back calls between two HIP events, rotating slabs > 256 MB; per-kernel durations: profiles/ (rocprofv3 --kernel-trace)"}
 
 
+def self_launch(args):
+    """`bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks as a CHILD torch.distributed.run job (this
+    process has not touched the GPU: torch.cuda.device_count() does not initialise it), relay rank 0's line, exit with its code."""
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("ADVMIL_DIST_BACKEND")
+    if ndev < args.gpus and backend != "gloo":
+        print(f"bench.py: --gpus {args.gpus} but {ndev} GPU(s) visible: refusing to report a {args.gpus}-GPU number from fewer "
+              "devices (set ADVMIL_DIST_BACKEND=gloo to run ranks that share devices, for functional testing only)", file=sys.stderr)
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in proc.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    elif proc.returncode == 0:
+        print("bench.py: the rank job printed no result line", file=sys.stderr)
+        sys.exit(1)
+    sys.exit(proc.returncode)
+
+
+def product_loop(args, torch, dev, case):
+    from advmil_amd.config import default_cfg
+    from advmil_amd.graphed import GraphedStep
+    from advmil_amd.model import MyHandler
+    if case is not None and case.h is not None:
+        case.free()
+    out = {}
+    hh = MyHandler(default_cfg(bcb_mode=args.mode, bp_every_batch=args.bags, cuda_id=dev.index, gemm_mode=args.gemm_mode), device=dev)
+    gcpu = torch.Generator().manual_seed(7)
+    nsteps, base = (30 if args.patches <= 8192 else 8), args.patches
+    fr = (0.75, 1.0, 1.25, 0.5, 1.5, 1.0, 0.875, 1.125)                      # ragged: 0.5x .. 1.5x the nominal size
+    nbag = args.bags * (nsteps + 2)
+    lens = [int(base * fr[i % len(fr)]) // 16 * 16 for i in range(nbag)]
+    distinct = min(nbag, 64 if args.patches <= 8192 else 16)                   # distinct host bags (pinned): 64 x 33.5 MB = 2.1 GB
+    hostpool = [torch.randn(1, lens[i], 1024, generator=gcpu).pin_memory() for i in range(distinct)]
+    # the loader's patient index IS the cache key: bag i of the epoch is patient i mod `distinct`
+    loader = [(torch.tensor([[i % distinct]], dtype=torch.int), [hostpool[i % distinct], torch.zeros(1, 1)],
+               torch.tensor([[0.3 + 0.01 * (i % 50), float(i % 2)]])) for i in range(nbag)]
+    rows = sum(hostpool[i % distinct].shape[1] for i in range(2 * args.bags, nbag))
+    os.environ["ADVMIL_BAG_CACHE_GB"] = "0"
+    hh._train_each_epoch(loader[:2 * args.bags], "warmup")                     # allocates the pinned + device staging slabs
+    torch.cuda.synchronize()
+
+    def epoch(tag):
+        t1 = time.perf_counter()
+        hh._train_each_epoch(loader[2 * args.bags:], tag)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t1
+
+    def ent(dte, path):
+        return {"value": round(args.bags * nsteps / dte, 2), "unit": "bags/s", "ms_per_step": round(1e3 * dte / nsteps, 3), "steps": nsteps,
+                "patches_per_bag": "ragged %d..%d (mean %d)" % (min(lens), max(lens), rows // (args.bags * nsteps)), "path": path}
+
+    d0 = epoch("nocache")
+    out["eager_pcie_ragged"] = ent(d0, "MyHandler._train_each_epoch, eager launches, pinned host bags -> SlabStager (copy stream) -> step slab; "
+                                       "bag cache off: every epoch pays PCIe")
+    out["eager_pcie_ragged"]["h2d_mb_per_step"] = round(rows * 4096 / nsteps / 1e6, 1)
+    del os.environ["ADVMIL_BAG_CACHE_GB"]
+    hh._bag_caches = {}
+    d1 = epoch("train")                                                          # epoch 1: PCIe + fills the cache
+    d2 = epoch("train")                                                          # epoch 2: out of HBM
+    cache = hh._bag_caches.get("train")
+    out["epoch1_fill_cache"] = ent(d1, "same loop, device-resident bag cache on (default): first epoch = PCIe + one D2D copy + plane split per new bag")
+    out["eager_resident_ragged"] = ent(d2, "same loop, second epoch: every bag served from the HBM cache (no PCIe); step slab + operand planes "
+                                           "assembled by row gathers; eager launches")
+    out["eager_resident_ragged"]["cache"] = None if cache is None else cache.stats()
+    del hh, hostpool, loader
+    import gc
+    gc.collect(); torch.cuda.empty_cache()
+    # graph replay with fp32-only residency: the bf16x3 operand planes of the slab are re-derived inside every step
+    if args.gemm_mode == "bf16x3":
+        c3 = Case(torch, dev, args.mode, args.patches, args.bags, min(args.pool, 32 if args.patches <= 8192 else 16), args.gemm_mode, 777,
+                  resident_planes=False)
+        n3 = 40 if args.patches <= 8192 else 10
+        d3, _ = c3.timed(n3, 2, torch.cuda.synchronize)
+        out["graph_resident_split_in_step"] = {"value": round(args.bags * n3 / d3, 2), "unit": "bags/s", "ms_per_step": round(1e3 * d3 / n3, 3),
+                                               "steps": n3, "launch": c3.launch_note,
+                                               "path": "HIP-graph replay over resident fp32 bags WITHOUT resident operand planes: "
+                                                       "advmil_split_planes of the step slab runs inside every step (half the resident bytes)"}
+        c3.free()
+    return out
+
+
+def genconv_roofline(torch, ops, dev, patches, bags, iters=20):
+    """GENConv softmax aggregation (csrc/graph.hip) on the step's block-diagonal graph (bags x patches nodes, 8-NN grid, C = 128)
+    against the HBM roof. Algorithmic bytes (8N x 128 x 4 gathered + N x 128 x 4 written), per launch:
+    forward = 8 neighbour rows + own row read, out / lse / m2 written; backward = per out-edge (dout, out, x, lse) rows of the
+    target + own (x, dout) read, dx written; index arrays 4 B per edge + 4 B per node."""
+    from advmil_amd import synth
+    C, N = 128, bags * patches
+    ei1 = torch.from_numpy(synth.grid_knn_graph(patches, 8)).to(dev).long()
+    ei = torch.cat([ei1 + b * patches for b in range(bags)], dim=1)
+    csr = ops.GraphCSR(ei, N)
+    E = int(ei.shape[1])
+    t = torch.ones(1, device=dev, requires_grad=True)
+    nbuf = max(2, int(600e6 // (4 * N * C)) + 1)
+    xs = [torch.randn(N, C, device=dev, requires_grad=True) for _ in range(nbuf)]
+    k = [0]
+
+    def fwd():
+        with torch.no_grad():
+            ops.genconv_aggregate(xs[k[0] % nbuf], t, csr)
+        k[0] += 1
+
+    us_f = event_time_us(torch, fwd, iters)
+    ys = [ops.genconv_aggregate(x, t, csr) for x in xs]
+    go = torch.randn(N, C, device=dev)
+    L = ops._lib.lib()
+    saved = [(y.grad_fn.saved_tensors, y.grad_fn) for y in ys]
+
+    def bwd():
+        x, tt, out, lse, m2 = saved[k[0] % nbuf][0]
+        dx = torch.empty_like(x)
+        ops._lib.check(L.advmil_genconv_bwd(ops._p(go), ops._p(x), ops._p(out), ops._p(lse), ops._p(csr.rowptr_src), ops._p(csr.col_dst),
+                                            ops._p(tt), 1e-7, N, C, ops._p(dx), ops._stream()), "genconv_bwd")
+        k[0] += 1
+
+    us_b = event_time_us(torch, bwd, iters)
+    row = 4.0 * C
+    # compulsory HBM bytes: every row of every array once (a row gathered by several neighbouring targets is an L2 hit after its
+    # first read); the per-EDGE figure of SURVEY 8d (8N x 128 x 4 gathered) is what the load path serves, reported as `gathered`
+    bytes_f = N * row + 3 * N * row + 4.0 * (E + N)
+    bytes_b = 4 * N * row + N * row + 4.0 * (E + N)
+    gath_f, gath_b = E * row, 4.0 * E * row
+    ach = (bytes_f + bytes_b) / (us_f + us_b) / 1e3
+    return {"bound": "hbm", "kernel": "genconv_fwd128_kernel + genconv_bwd128_kernel (csrc/graph.hip)", "nodes": N, "edges": E, "channels": C,
+            "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+            "fwd_launch_us": round(us_f, 1), "fwd_gbps": round(bytes_f / us_f / 1e3, 1), "bwd_launch_us": round(us_b, 1),
+            "bwd_gbps": round(bytes_b / us_b / 1e3, 1), "algorithmic_bytes_per_launch": {"fwd": bytes_f, "bwd": bytes_b},
+            "gathered_bytes_per_launch": {"fwd": gath_f, "bwd": gath_b},
+            "gathered_gbps": {"fwd": round((gath_f + bytes_f - N * row) / us_f / 1e3, 1), "bwd": round((gath_b + bytes_b - 4 * N * row) / us_b / 1e3, 1)},
+            "note": "algorithmic = compulsory HBM bytes (each row of x / out / lse / dout once, outputs once, indices); `gathered` counts a "
+                    "neighbour row once per EDGE (SURVEY 8d's 8N x 128 x 4): those re-reads hit in L2, so it is a load-path rate, not HBM",
+            "rotating_inputs": nbuf, "method": f"{iters} back-to-back launches between two HIP events on the launch stream"}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
     import torch
     import torch.distributed as dist
     from advmil_amd import ops, parallel
 
     rank, world, local = parallel.init_from_env()
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if world != args.gpus:
+        if world > 1:
+            args.gpus = world
+        else:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher environment says WORLD_SIZE={world}")
+    ranks_seen = dist.get_world_size() if world > 1 else 1
+    backend = dist.get_backend() if world > 1 else None
     dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
 
@@ -325,6 +491,32 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     finite = case.logs_finite()
+
+    # ---- strong scaling (N > 1): the reference's own optimizer step of 16 bags (cfg_nlst.yaml:71) split over the ranks, bag i of
+    # the step batch on rank i mod W -> 16 / W bags per rank per step; same barrier / max-over-ranks timing
+    strong = None
+    GLOBAL_STEP = 16
+    if world > 1 and not args.no_strong:
+        if GLOBAL_STEP % world == 0:
+            per = GLOBAL_STEP // world
+            cs = Case(torch, dev, args.mode, args.patches, per, max(per, min(args.pool, 8 * per)), args.gemm_mode, 99 + rank, args.eager, world)
+            oks = torch.tensor([1.0 if (cs.graphs or args.eager) else 0.0], device=dev)
+            dist.all_reduce(oks, op=dist.ReduceOp.MIN)
+            if float(oks.item()) == 0.0:
+                cs.graphs = []
+            dts, _ = cs.timed(args.steps, args.warmup, barrier)
+            ts = torch.tensor([dts], dtype=torch.float64, device=dev)
+            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+            dts = float(ts.item())
+            strong = {"scaling": "strong", "value": round(GLOBAL_STEP * args.steps / dts, 3), "unit": "bags/s",
+                      "ms_per_step": round(1e3 * dts / args.steps, 3), "steps": args.steps, "global_bags_per_step": GLOBAL_STEP,
+                      "bags_per_step_per_gpu": per, "gd_steps_per_sec": round(args.steps / dts, 3),
+                      "losses_finite": bool(cs.logs_finite()), "launch": cs.launch_note,
+                      "note": "the reference's step batch (bp_every_batch = 16) split over the ranks; the same global optimizer step at every N"}
+            cs.free()
+            del cs
+        else:
+            strong = {"skipped": f"16 bags per step do not divide over {world} ranks"}
 
     # replicas must hold bit-identical weights after the timed steps (same reduced gradients, same Adam)
     in_sync = True
@@ -487,7 +679,8 @@ def main():
         case.free()
         sizes = {}
         for tag, mode_, patches_, bags_, pool_, steps_ in (("abmil_1024", "abmil", 1024, 16, 128, 60), ("abmil_32768", "abmil", 32768, 16, 16, 12),
-                                                          ("esat_8192", "patch", 8192, 16, 64, 30), ("esat_32768", "patch", 32768, 16, 16, 12)):
+                                                          ("esat_8192", "patch", 8192, 16, 64, 30), ("esat_32768", "patch", 32768, 16, 16, 12),
+                                                          ("patchgcn_4096", "graph", 4096, 16, 32, 30)):
             if mode_ == args.mode and patches_ == args.patches:
                 continue
             try:
@@ -499,43 +692,24 @@ def main():
                 del c2
                 if mode_ == "patch":
                     ent["roofline"] = attention_roofline(torch, ops, dev, patches_ // 16, bags_, iters=10)
+                if mode_ == "graph":           # configs[4]'s backbone at a size one GPU steps through quickly; its sparse gather vs HBM
+                    ent["roofline"] = genconv_roofline(torch, ops, dev, patches_, bags_)
                 sizes[tag] = ent
             except Exception as exc:
                 sizes[tag] = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
                 torch.cuda.synchronize()
 
     # ---- extra (single GPU): the PRODUCT loop -- MyHandler._train_each_epoch, eager launches, RAGGED bags arriving as pinned host
-    # tensors through the staging slab (advmil_amd/ingest.py): PCIe-inclusive, one step plan per batch, no HIP graph (ragged segments
-    # change every step). Reported next to the graph-replay number, never as `value`.
+    # tensors. Two epochs over the same loader: epoch 1 goes through the staging slab (advmil_amd/ingest.py::SlabStager, PCIe-
+    # inclusive) and fills the device-resident bag cache; epoch 2 is served from HBM (BagCache: no PCIe, the step's operand planes
+    # are a row gather). One step plan per batch, no HIP graph (ragged segments change every step). Never `value`.
     epoch_extra = None
     if world == 1 and rank == 0 and not args.no_extras and args.mode in ("abmil", "patch"):
         try:
-            from advmil_amd.config import default_cfg
-            from advmil_amd.model import MyHandler
-            if "case" in dir() and case is not None and case.h is not None:
-                case.free()
-            hh = MyHandler(default_cfg(bcb_mode=args.mode, bp_every_batch=args.bags, cuda_id=dev.index, gemm_mode=args.gemm_mode), device=dev)
-            gcpu = torch.Generator().manual_seed(7)
-            nsteps, base = 6, args.patches
-            lens = [int(base * f) // 16 * 16 for f in (0.75, 1.0, 1.25, 0.5, 1.5, 1.0, 0.875, 1.125)]     # ragged: 0.5x .. 1.5x the nominal size
-            hostpool = [torch.randn(1, n, 1024, generator=gcpu).pin_memory() for n in lens]
-            loader = [(torch.tensor([[i]], dtype=torch.int), [hostpool[i % len(hostpool)], torch.zeros(1, 1)],
-                       torch.tensor([[0.3 + 0.01 * (i % 50), float(i % 2)]])) for i in range(args.bags * (nsteps + 2))]
-            hh._train_each_epoch(loader[:2 * args.bags], "train")          # warm-up: allocates the pinned + device slabs
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            hh._train_each_epoch(loader[2 * args.bags:], "train")
-            torch.cuda.synchronize()
-            dte = time.perf_counter() - t1
-            rows = sum(lens[i % len(lens)] for i in range(args.bags * nsteps))
-            epoch_extra = {"value": round(args.bags * nsteps / dte, 2), "unit": "bags/s", "ms_per_step": round(1e3 * dte / nsteps, 3), "steps": nsteps,
-                           "patches_per_bag": "ragged %d..%d (mean %d)" % (min(lens), max(lens), rows // (args.bags * nsteps)),
-                           "h2d_mb_per_step": round(rows * 4096 / nsteps / 1e6, 1),
-                           "path": "MyHandler._train_each_epoch, eager launches, pinned host bags -> SlabStager (copy stream) -> step slab, "
-                                   "one step plan per batch; PCIe-inclusive"}
-            del hh, hostpool, loader
+            epoch_extra = product_loop(args, torch, dev, case)
         except Exception as exc:
             epoch_extra = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
+            torch.cuda.synchronize()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only; at N > 1 the other ranks would idle in the barrier
@@ -563,7 +737,7 @@ def main():
             "host_submit_ms_per_step": round(1e3 * t_submit / args.steps, 3),
             "roofline": roof, "gemm_roofline": (gemm_roof if roof is not gemm_roof else None), "pool_roofline": pool_roof,
             "cpu_baseline": cpu, "exact_f32_mfma_mode": exact_extra, "bp_every_batch_1": bp1_extra, "sizes": sizes,
-            "train_each_epoch_eager_ragged": epoch_extra,
+            "product_loop": epoch_extra, "strong_scaling": strong, "ranks_seen": ranks_seen, "dist_backend": backend,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

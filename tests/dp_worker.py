@@ -11,15 +11,23 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 LENS = (256, 128, 64, 192, 320, 96, 160, 224)       # 2 steps x 4 bags (global), ragged, multiples of 16
+# `collide`: per rank 2 bags of 32 patches per step -> 2n = 4 stacked tail rows AND sum N / 16 = 4 region rows: two different
+# layouts with the same row count (the row maps are keyed by call site, not by row count)
+LENS_COLLIDE = (32, 32, 32, 32, 32, 32, 32, 32)
 
 
-def build_loader(kind, idxs):
+def build_loader(kind, idxs, lens=LENS):
+    from types import SimpleNamespace
     from advmil_amd import synth
     from tests import helpers as H
     loader = []
     for i in idxs:
-        x = H.bag(300 + i, 512)[:, :LENS[i]].contiguous()
-        ext = H.T(synth.cluster_ids(0, 300 + i, LENS[i])) if kind == "cluster" else torch.zeros(1, 1)
+        x = H.bag(300 + i, 512)[:, :lens[i]].contiguous()
+        if kind == "graph":                  # PatchGCN: device-resident graph objects (x [N, C], edge_index [2, 8N]), as the bench feeds them
+            x = x.to("cuda:0")
+            ext = SimpleNamespace(x=x[0], edge_index=H.T(synth.grid_knn_graph(lens[i], 8), "cuda:0"))
+        else:
+            ext = H.T(synth.cluster_ids(0, 300 + i, lens[i])) if kind == "cluster" else torch.zeros(1, 1)
         loader.append((torch.tensor([[i]], dtype=torch.int), [x, ext], H.label(300 + i)))
     return loader
 
@@ -29,13 +37,20 @@ def run(kind, world, rank, dp=None):
     from advmil_amd.config import default_cfg
     from advmil_amd.model import MyHandler
     from tests import helpers as H
-    h = MyHandler(default_cfg(bcb_mode=kind, bp_every_batch=4 // world), device="cuda:0", parallel=dp)
+    lens = LENS
+    if kind.endswith("-collide"):
+        kind, lens = kind[:-len("-collide")], LENS_COLLIDE
+    cfg = default_cfg(bcb_mode=kind, bp_every_batch=4)         # the GLOBAL step batch: every rank steps after 4 / world of its bags
+    if kind == "graph":
+        cfg.update(bcb_dims="1024-128-128", gen_dims="128-1")
+    h = MyHandler(cfg, device="cuda:0", parallel=dp)
     for net, prefix in ((h.netG, f"G-{kind}:"), (h.netD, "D-prj:")):
         sd = {k: H.T(synth.param(H.PARAM_SEED, prefix + k, tuple(v.shape))) for k, v in net.state_dict().items()}
         net.load_state_dict(sd, strict=True)
     h.rng.reset(4321)
-    idxs = [i for i in range(len(LENS)) if i % world == rank]
-    cl = h._train_each_epoch(build_loader(kind, idxs), "train", "wlabel")
+    from advmil_amd.parallel import BagParallel
+    idxs = (dp or BagParallel()).shard_epoch(list(range(len(lens))), 4)     # bag i of a global step batch -> rank i mod W
+    cl = h._train_each_epoch(build_loader(kind, idxs, lens), "train", "wlabel")
     logs = h.pop_logs()
     return {"cl": cl, "logs": logs, "G": {k: v.detach().cpu() for k, v in h.netG.state_dict().items()},
             "D": {k: v.detach().cpu() for k, v in h.netD.state_dict().items()}}

@@ -113,6 +113,41 @@ def test_other_d_losses(which):
     run_case(lens=(128, 256, 64), loss_netD=which, tol=4e-4, check_weights=False)
 
 
+@pytest.mark.parametrize("which", ["hinge", "wasserstein", "bce"])
+def test_d_loss_gradients_before_adam(which):
+    """The hinge / wasserstein D losses (loss/utils.py:182-203) at the contract's tolerance WITHOUT Adam in between: the raw
+    gradients of one D backward and one G backward (the arenas the optimizer kernels read) against the oracle's autograd, every
+    parameter, 2e-5 of the tensor's gradient scale. (Post-Adam weights of these two losses are round-off noise on both sides:
+    their real and fake means nearly cancel, test_other_d_losses.)"""
+    from advmil_amd.model import MyHandler
+    lens, nb = (128, 256, 64), 3
+    h = MyHandler(default_cfg(bcb_mode="abmil", bp_every_batch=nb, loss_netD=which), device=DEV)
+    PG, PD = load_synth(h.netG, "G-abmil:"), load_synth(h.netD, "D-prj:")
+    zero_dropout(h.netG); zero_dropout(h.netD)
+    bags = [(H.bag(40 + i, 512)[:, :n].contiguous(), None, H.label(i)) for i, n in enumerate(lens)]
+    xs = [[b[0].to(DEV), torch.zeros(1, 1, device=DEV)] for b in bags]
+    ys_host = [b[2] for b in bags]
+    ys = [y.to(DEV) for y in ys_host]
+    nd = [[H.noise_tensor("gr_d", i, 192)] for i in range(nb)]
+    ng = [[H.noise_tensor("gr_g", i, 192)] for i in range(nb)]
+    plan = h._plan(xs, ys, "wlabel", None, ys_host)
+    h._disc_backward(0, xs, ys, plan, [[n[0].to(DEV)] for n in nd])
+    h._gen_backward(0, xs, ys, plan, [[n[0].to(DEV)] for n in ng])
+    torch.cuda.synchronize()
+    cfg = O.StepConfig(kind="abmil", loss_netD=which, l1_coef=0.0)           # (the L1 sub-gradient is applied inside the Adam kernel)
+    _, gD, _, _ = O.update_disc(cfg, PG, PD, bags, nd)
+    _, gG, _ = O.update_gen(cfg, PG, PD, bags, ng)
+    for net, want in ((h.netD, gD), (h.netG, gG)):
+        for k, p in net.named_parameters():
+            w = want.get(k)
+            got = torch.zeros_like(p) if p.grad is None else p.grad
+            if w is None:
+                assert float(got.abs().max()) == 0.0, k
+                continue
+            scale = max(float(w.abs().max()), 1e-3)
+            assert float((got.cpu() - w).abs().max()) <= 2e-5 * scale, (which, k, float((got.cpu() - w).abs().max()), scale)
+
+
 @pytest.mark.parametrize("over", [dict(disc_type="cat", disc_prj_path=None), dict(disc_prj_iprd="bag"), dict(disc_prj_path="y"),
                                   dict(disc_prj_iprd="bag", disc_prj_path=None)])
 def test_discriminator_variants(over):
@@ -190,15 +225,56 @@ def test_ingest_stager_makes_the_step_slab_zero_copy():
               for i in range(6)]
     seen = []
     orig = h._slab
-    h._slab = lambda xs: seen.append(orig(xs)) or seen[-1]
+    h._slab = lambda xs, plan=None: seen.append(orig(xs, plan)) or seen[-1]
     h._train_each_epoch(loader, "train")
     st = h._stager
     bases = {st.dev[0].data_ptr(), st.dev[1].data_ptr()}
     assert len(seen) == 4 and {t.data_ptr() for t in seen} == bases          # D and G phase of two steps, two buffer pairs
+    assert seen[0] is seen[1] and seen[2] is seen[3]                         # one slab per step plan, shared by the D and the G update
     assert all(tuple(t.shape) == (sum(lens), 1024) for t in seen)
     torch.cuda.synchronize()
     want = torch.cat([loader[3 + j][1][0][0] for j in range(3)], dim=0)       # second step's bags, in order
     assert torch.equal(seen[-1].cpu(), want)
+
+
+@pytest.mark.parametrize("nrows", [64, 2048])
+def test_second_epoch_is_served_from_the_device_resident_bag_cache(nrows):
+    """Epoch 1 stages the host bags over PCIe and keeps each one (with its bf16x3 operand planes when the slab is large enough
+    to use them) in HBM, keyed by the loader's patient index; epoch 2 over a SHUFFLED loader touches no host bag (the host
+    tensors are poisoned in between) and equals, bit for bit, a handler that stages every epoch (ADVMIL_BAG_CACHE_GB=0);
+    an LRU budget that holds only part of the cohort still gives the same numbers. Replaces the per-epoch `.cuda()` of
+    reference model/model_handler.py:315."""
+    from advmil_amd.model import MyHandler
+    lens = (nrows, 2 * nrows, nrows // 2 * 3)
+
+    def mk():
+        return [(torch.tensor([[i]], dtype=torch.int), [H.bag(80 + i, 3 * nrows)[:, :lens[i % 3]].contiguous(), torch.zeros(1, 1)], H.label(i))
+                for i in range(6)]
+
+    def run(cache_gb, poison):
+        h = MyHandler(default_cfg(bp_every_batch=3, bag_cache_gb=cache_gb), device=DEV)
+        load_synth(h.netG, "G-abmil:"); load_synth(h.netD, "D-prj:")
+        h.rng.reset(99)
+        loader = mk()
+        h._train_each_epoch(loader, "train")
+        order = [4, 0, 5, 2, 1, 3]                                             # epoch 2: shuffled, step batches regrouped
+        if poison:
+            torch.cuda.synchronize()
+            loader = [(it[0], [torch.full_like(it[1][0], float("nan")), it[1][1]], it[2]) for it in loader]
+        cl = h._train_each_epoch([loader[i] for i in order], "train")
+        return cl, h.pop_logs(), h.optimizerG.flat_param.clone(), h._bag_caches.get("train")
+
+    a = run(None, True)                  # default budget: everything resident, the poisoned host bags are never read
+    b = run(0, False)                    # no cache: every epoch over PCIe
+    one = (lens[0] + lens[1]) * 1024 * 8 / 1e9
+    c = run(one, False)                  # a budget of about two bags: evictions, mixed cached / staged step batches
+    assert a[3].stats()["bags"] == 6 and a[3].stats()["hits"] == 6 and b[3] is None and c[3].stats()["evictions"] > 0
+    for other in (b, c):
+        assert torch.equal(a[0]["y_hat"], other[0]["y_hat"]) and torch.equal(a[0]["f_fake"], other[0]["f_fake"])
+        assert torch.equal(a[2], other[2])
+        for la, lb in zip(a[1], other[1]):
+            for k in la:
+                assert float(la[k]) == float(lb[k]), k
 
 
 @pytest.mark.parametrize("kind", ["abmil", "patch", "cluster"])

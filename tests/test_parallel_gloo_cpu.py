@@ -105,20 +105,62 @@ def test_rng_row_maps_cover_the_single_process_slab():
         maps, off16 = rng_row_maps(all_lens, W, r, cluster=True)
         lens = all_lens[r]
         n, SN, SL = len(lens), sum(lens), sum(lens) // 16
-        assert set(maps) == {SN, SL, 2 * SL, n, 2 * n, 8 * n}
+        assert {k: len(v) for k, v in maps.items()} == {"patch": SN, "region": SL, "region2": 2 * SL, "bag": n, "bag2": 2 * n, "cluster": 8 * n}
         o = 0
         for j, L in enumerate(lens):                      # local bag j = global bag j*W + r, rows in order
             g = j * W + r
-            assert np.array_equal(maps[SN][o:o + L], goff[g] + np.arange(L))
+            assert np.array_equal(maps["patch"][o:o + L], goff[g] + np.arange(L))
             assert off16[j] == goff[g] // 16 - o // 16
             o += L
-        assert np.array_equal(maps[2 * SL][:SL], maps[SL]) and np.array_equal(maps[2 * SL][SL:], maps[SL] + goff[-1] // 16)
-        assert np.array_equal(maps[n], [j * W + r for j in range(n)])
-        assert np.array_equal(maps[2 * n][n:], maps[n] + 6)
-        assert np.array_equal(maps[8 * n].reshape(n, 8), 8 * maps[n][:, None] + np.arange(8)[None, :])
-        seen_patch.append(maps[SN]); seen_region.append(maps[SL]); seen_bag.append(maps[n])
+        assert np.array_equal(maps["region2"][:SL], maps["region"]) and np.array_equal(maps["region2"][SL:], maps["region"] + goff[-1] // 16)
+        assert np.array_equal(maps["bag"], [j * W + r for j in range(n)])
+        assert np.array_equal(maps["bag2"][n:], maps["bag"] + 6)
+        assert np.array_equal(maps["cluster"].reshape(n, 8), 8 * maps["bag"][:, None] + np.arange(8)[None, :])
+        seen_patch.append(maps["patch"]); seen_region.append(maps["region"]); seen_bag.append(maps["bag"])
     assert np.array_equal(np.sort(np.concatenate(seen_patch)), np.arange(goff[-1]))
     assert np.array_equal(np.sort(np.concatenate(seen_region)), np.arange(goff[-1] // 16))
     assert np.array_equal(np.sort(np.concatenate(seen_bag)), np.arange(6))
-    with pytest.raises(NotImplementedError):              # 2 regions per bag: [2n] stacked-tail rows and region rows collide
-        rng_row_maps([[32, 32], [32, 32]], 2, 0)
+    # 2 regions per bag: the [2n] stacked-tail rows and the region rows have the same COUNT; the maps are per layout, so both exist
+    maps, _ = rng_row_maps([[32, 32], [32, 32]], 2, 0)
+    assert len(maps["bag2"]) == len(maps["region"]) == 4 and not np.array_equal(maps["bag2"], maps["region"])
+
+
+def test_row_map_is_selected_by_call_site_not_by_row_count():
+    """ops.DeviceRng.row_map: the site's tag names the layouts it can be fed; equal row counts of two different layouts do not
+    collide, and a site without a registered layout (or fed an unexpected row count) raises at world > 1 instead of silently
+    drawing local-row masks."""
+    sys.path.insert(0, ROOT)
+    from advmil_amd import ops
+    from advmil_amd.parallel import rng_row_maps
+    maps, _ = rng_row_maps([[32, 32], [32, 32]], 2, 1)
+    rng = ops.DeviceRng("cpu")
+    assert rng.row_map(4, "dx_fc2.2") is None                                  # single process: identity
+    rng.rows = {k: torch.from_numpy(v) for k, v in maps.items()}
+    assert torch.equal(rng.row_map(4, "dx_fc2.2"), rng.rows["bag2"])           # 4 stacked tail rows
+    assert torch.equal(rng.row_map(4, "gapool_att_a"), rng.rows["region"])     # 4 region rows: same count, other layout
+    assert torch.equal(rng.row_map(8, "dx_fc1"), rng.rows["region2"])
+    assert torch.equal(rng.row_map(64, "abmil_fc"), rng.rows["patch"])
+    assert torch.equal(rng.row_map(2, "gen_mlp0.2"), rng.rows["bag"])
+    with pytest.raises(RuntimeError, match="no registered row layout"):
+        rng.row_map(4, "some_new_dropout_site")
+    with pytest.raises(RuntimeError, match="none of its layouts"):
+        rng.row_map(5, "abmil_fc")
+
+
+def test_shard_epoch_gives_every_rank_the_same_number_of_steps():
+    """BagParallel.shard_epoch: the trailing partial step batch is dropped (the reference never back-propagates it,
+    model_handler.py:321-345), bag i of a step batch goes to rank i mod W, cfg['bp_every_batch'] stays the GLOBAL step batch."""
+    sys.path.insert(0, ROOT)
+    from advmil_amd.parallel import BagParallel
+    items = list(range(37))
+    shards = []
+    for r in range(4):
+        dp = BagParallel()
+        dp.world, dp.rank = 4, r
+        assert dp.local_step_bags(16) == 4
+        shards.append(dp.shard_epoch(items, 16))
+        with pytest.raises(ValueError):
+            dp.local_step_bags(6)
+    assert all(len(s) == 8 for s in shards)                  # 37 bags -> 2 global steps of 16 -> 8 bags per rank
+    assert sorted(sum(shards, [])) == list(range(32))
+    assert shards[1][:4] == [1, 5, 9, 13] and shards[1][4:] == [17, 21, 25, 29]

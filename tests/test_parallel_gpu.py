@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("kind", ["abmil", "patch", "cluster"])
+@pytest.mark.parametrize("kind", ["abmil", "patch", "cluster", "graph", "abmil-collide", "patch-collide"])
 def test_two_rank_step_equals_single_rank_with_dropout_on(kind, tmp_path):
     from tests import dp_worker
     want = dp_worker.run(kind, 1, 0)
@@ -41,6 +41,7 @@ def test_two_rank_step_equals_single_rank_with_dropout_on(kind, tmp_path):
     # g ~ 0, so compare per-tensor update norms relatively -- a wrong mask would move these by O(1))
     from advmil_amd import synth
     from tests import helpers as H
+    kind = kind.split("-")[0]
     for tag, prefix in (("G", f"G-{kind}:"), ("D", "D-prj:")):
         for k in want[tag]:
             p0 = H.T(synth.param(H.PARAM_SEED, prefix + k, tuple(want[tag][k].shape))).double()
