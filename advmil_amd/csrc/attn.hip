@@ -7,116 +7,127 @@
 //
 // Arithmetic: "bf16x3" -- every fp32 operand element is split hi + lo (bf16 each) and a product is three
 // v_mfma_f32_32x32x16_bf16 (lo.hi + hi.lo + hi.hi) with fp32 accumulation, the same arithmetic as the contraction engine's
-// bf16x3 mode (gemm_f32.hip); softmax statistics, exponentials and the rescaling are fp32.
+// bf16x3 mode (gemm_f32.hip); softmax statistics, exponentials and the rescaling are fp32. The operands ARRIVE split: qkv (and, in
+// the backward, dO) are read as two bf16 planes (hi, lo) of the packed [L, 3*H*HD] matrix (advmil_split_planes, or the plane
+// output of the in-projection's epilogue), so no kernel here converts an operand; only the probabilities / score gradients, which
+// are produced in registers, are split in the kernels.
 //
-// Layout per workgroup (4 waves, 256 threads): wave w owns 32 rows of the stationary operand (queries for fwd / dQ, keys for dK/dV)
-// as MFMA *columns* (B operand, fragments resident in VGPRs); the streamed operand comes through LDS in tiles of 64 rows as two
-// bf16 planes (hi, lo) of [row][72 halfwords]:
-//   * 144-byte pitch: a ds_read_b128 row fragment (lane = row, 8 consecutive head dims) puts the 16 lanes of a group on 16
-//     distinct 16-byte bank slots, and the four rows of a ds_read_b64_tr_b16 block land on four distinct 32-byte bank windows;
-//   * contractions over the head dimension read row fragments (ds_read_b128);
-//   * contractions over the streamed rows (P.V, dS^T.K, P^T.dO, dS^T.Q) read the SAME planes through the LDS transpose read,
-//     and take their second operand straight from the accumulator registers of the score tile: with scores computed transposed
-//     (rows = streamed rows, column = lane's stationary row) a lane holds, for its column, 8 row values per 16-row k-step in
-//     exactly the (lane-half, slot) positions an MFMA B fragment wants once the k-slot <-> row map is chosen as
-//     slot t of half h  <->  row 16*s + 8*(t>>2) + 4*h + (t&3); the transpose reads use the same map, so no cross-lane traffic.
-//   * per-query softmax statistics are lane-local (column = query); the two lane halves exchange one max per tile.
-// head_dim 48 = 3 k-steps of 16 for Q K^T (no padding); the 48 output dims of P.V / dQ / dK / dV occupy 1.5 MFMA row tiles
-// (pad columns of the planes are zero).
+// Structure (round 3; one 512-thread workgroup = 8 waves per CU, 256 stationary rows):
+//   * wave w owns 32 rows of the stationary operand (queries for fwd / dQ, keys for dK/dV) as MFMA *columns* (B operand,
+//     fragments resident in VGPRs, loaded straight from the planes); the streamed operand comes through LDS in tiles of 64 rows;
+//   * the tiles arrive by LDS-DMA (global_load_lds_dwordx4, 1 KB per wave-instruction, 4 per wave per tile) into a ring of 4
+//     slots of [K hi | K lo | V hi | V lo] (or Q / dO), counted s_waitcnt vmcnt + raw s_barrier: two tiles are in flight while two
+//     are being read; nothing is staged through registers and nothing is converted on the way;
+//   * LDS image of a plane tile: [64 rows][128 B] (8 units of 16 B; head_dim <= 64, the units beyond it are never written), the unit
+//     stored at position q of row r being unit q ^ sw(r), sw(r) = ((r>>1)&1)<<2 | ((r>>2)&3) -- applied to each lane's SOURCE address
+//     (the DMA writes lane-linear). Row fragments (ds_read_b128: lane = row) of any 16 rows distinct mod 16 then cover all 16
+//     16-byte slots of the 256-byte bank line, and the four rows of a ds_read_b64_tr_b16 block land in four different 64-byte bank
+//     quarters: both read patterns are conflict-free on the same image;
+//   * ANTI-PHASE wave groups. The per-tile work is cut into a matrix phase M (QK^T of tile t and P.V of tile t-1: 42 MFMAs for
+//     head_dim 48, only LDS reads beside them) and a vector phase V (softmax / dropout / hi-lo split of tile t: ~300 VALU, no
+//     MFMA), separated by workgroup barriers. Waves 0-3 and waves 4-7 (one of each per SIMD) run the same sequence ONE PHASE
+//     APART: while a SIMD's first wave multiplies, its second exponentiates, so the matrix pipe and the vector ALU of every SIMD
+//     are both busy instead of alternating in lockstep (the round-2 kernel: all waves in the same phase, the phases added up);
+//   * contractions over the streamed rows (P.V, dS^T.K, P^T.dO, dS^T.Q) take their second operand straight from the accumulator
+//     registers of the score tile: scores are computed transposed (rows = streamed rows, column = lane's stationary row), so a
+//     lane holds, for its column, 8 row values per 16-row k-step in exactly the (lane-half, slot) positions an MFMA B fragment wants
+//     with the k-slot <-> row map  slot t of half h <-> row 16*s + 8*(t>>2) + 4*h + (t&3); the transpose reads use the same map;
+//   * per-query softmax statistics are lane-local (column = query); the two lane halves exchange one max per tile. Scores stay
+//     unscaled in the accumulators: p = exp2(fma(s, log2(e)/sqrt(hd), -m)) folds the scale into the exponent's FMA.
 // Workgroup -> (bag, tile, head) with head = blockIdx % nhead: for nhead = 8 every XCD (blockIdx % 8) serves one head, so the K/V
 // panel of a (bag, head) is fetched into exactly one L2.
 //
-// Dropout on the attention probabilities (train mode): keep(i, j) = 16-bit half (j & 1) of hash32(rowkey(i) + (j >> 1) * 0x9E3779B9)
-// >= floor(p * 2^16), rowkey(i) = high word of splitmix64(key(seed, stream) + (global region row of query i) * nhead + head);
-// restated on the host in advmil_amd/synth.py::attn_dropout_keep. A per-row 64-bit mix + one 32-bit finaliser per key PAIR costs
-// ~5 VALU per probability where a lane walks keys (forward, dQ) -- a splitmix64 per element would cost ~4x the MFMA time of the
-// tile -- and is layout independent, which the key-stationary backward needs (there a lane walks queries and hashes per element).
-// The drop probability is thereby quantised to 1/65536 (0.25 is exact).
+// Dropout on the attention probabilities (train mode): ONE 32-bit hash per (query, group of 4 consecutive keys), one byte per key:
+//   keep(i, j) = byte (j & 3) of mix(rowkey(i) + (j >> 2) * 0x9E3779B9) >= floor(p * 256),
+//   mix(x): x ^= x >> 15; x *= 0x7feb352d; x ^= x >> 15,   rowkey(i) = high word of splitmix64(key(seed, stream) + row_id(i) * nhead + head);
+// restated on the host in advmil_amd/synth.py::attn_dropout_keep. Where a lane walks keys (forward, dQ) that is 8 hashes per 64-key
+// tile and a byte compare per probability; where a lane walks queries (dK/dV) the four lanes of a key group compute 4 of the 16
+// row hashes each and trade them with DPP quad broadcasts. The drop probability is thereby quantised to 1/256 (0.25 is exact) and
+// the kept probabilities are scaled by 256 / (256 - floor(256 p)).
 #include "common.h"
 #include "bf16split.h"
 #include "../../include/advmil_hip.h"
 
-#define AT_PITCH 72   // halfwords per plane row
-#define AT_KT 64      // streamed rows per LDS tile
-// stationary rows per workgroup = 32 * NW (NW = 4 or 8 waves): a (bag, head)'s streamed K/V (or Q/dO) panel is re-read by every
-// such workgroup, so 8 waves halve that traffic and the staging work per stationary row; the host takes 8 when the bags are long
-#define AT_PLANE (AT_KT * AT_PITCH)
+#define AT_KT 64                       // streamed rows per LDS tile
+#define AT_NS 4                        // ring slots
+#define AT_PLANE_B 8192                // bytes of one plane tile: 64 rows x 128 B
+#define AT_SLOT_B (4 * AT_PLANE_B)     // [K hi | K lo | V hi | V lo]
+#define AT_QB 256                      // stationary rows per workgroup (8 waves x 32)
+#define AT_PPW 4                       // DMA pieces per wave and tile
+#define AT_GOLD 0x9E3779B9u
+#define GLB_AS __attribute__((address_space(1)))
 
 struct AttnArgs {
-  const float* qkv;   // [Ltot, 3*H*HD] packed in-projection output (q | k | v), row pitch ldq
+  const bf16raw* qkv_hi;  // planes of the packed in-projection output [Ltot, 3*H*HD] (q | k | v), row pitch ldq halfwords
+  const bf16raw* qkv_lo;
   int64_t ldq;
-  float* out;         // fwd: O [Ltot, H*HD]
-  float* lse;         // [Ltot, H] log2-domain log-sum-exp of the scaled scores
-  const float* dout;  // bwd: dO [Ltot, H*HD]
-  const float* dsum;  // bwd: D [Ltot, H] = sum_d dO * O
-  float* dqkv;        // bwd: [Ltot, 3*H*HD], row pitch ldq
-  const int64_t* ptr; // [nseg+1] first region row of every bag, or NULL (one bag of Ltot rows)
+  const bf16raw* do_hi;   // bwd: planes of dO [Ltot, H*HD], row pitch H*HD
+  const bf16raw* do_lo;
+  float* out;             // fwd: O [Ltot, H*HD]
+  float* lse;             // [Ltot, H] log2-domain log-sum-exp of the scaled scores
+  const float* dsum;      // bwd: D [Ltot, H] = sum_d dO * O
+  float* dqkv;            // bwd: [Ltot, 3*H*HD], row pitch ldq
+  const int64_t* ptr;     // [nseg+1] first region row of every bag, or NULL (one bag of Ltot rows)
   const int64_t* rng_rowoff;  // [nseg] added to a bag's local rows to form the dropout stream's row id, or NULL
   int64_t Ltot;
   int nseg, ntile, H;
-  float scale_log2e;  // log2(e) / sqrt(head_dim)
-  float scale;        // 1 / sqrt(head_dim)
-  uint32_t drop_thr;  // floor(p * 2^16)
-  float inv_keep;     // 1 / (1 - p)
+  float scale_log2e;      // log2(e) / sqrt(head_dim)
+  float scale;            // 1 / sqrt(head_dim)
+  uint32_t drop_thr;      // floor(p * 256)
+  float inv_keep;         // 256 / (256 - drop_thr)
   const uint64_t* seed;
   uint64_t stream_id;
 };
 
+// Dev probe (tools/probe/stamp_attn.sh builds a copy of the library with -DAT_STAMP): shader-clock stamps of waves 0 and 4 of
+// workgroup 0 at the section boundaries of the forward's tile loop; never compiled into the product library.
+#ifdef AT_STAMP
+__device__ unsigned long long g_at_stamps[2 * 1024];
+extern "C" int advmil_debug_attn_stamps(unsigned long long* dst, int n) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_at_stamps), (size_t)n * 8); }
+#define AT_ST(tag)                                                                                          \
+  do {                                                                                                      \
+    if (blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && st_i < 1024)                                     \
+      g_at_stamps[(wave >> 2) * 1024 + st_i++] = (__builtin_amdgcn_s_memtime() << 4) | (unsigned)(tag);     \
+  } while (0)
+#else
+#define AT_ST(tag) do { } while (0)
+#endif
+
+template <int N>
+__device__ __forceinline__ void at_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void at_barrier() {
+  __builtin_amdgcn_s_barrier();          // raw: __syncthreads would drain vmcnt (an LDS-DMA is a pending LDS write)
+  asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ uint32_t attn_row_key(uint64_t key, uint64_t row_id) { return (uint32_t)(splitmix64(key + row_id) >> 32); }
-// one 32-bit hash serves the key PAIR (2m, 2m+1): 16 bits each, compared with floor(p * 2^16)
-__device__ __forceinline__ uint32_t attn_hash(uint32_t rk, uint32_t jpair) {
-  uint32_t x = rk + jpair * 0x9E3779B9u;
-  x ^= x >> 16; x *= 0x7feb352du;
-  x ^= x >> 15; x *= 0x846ca68bu;
-  x ^= x >> 16;
+// the per-(query, key group) hash: 4 keys, one byte each
+__device__ __forceinline__ uint32_t attn_mix(uint32_t x) {
+  x ^= x >> 15; x *= 0x7feb352du;
+  x ^= x >> 15;
   return x;
 }
-__device__ __forceinline__ bool attn_keep(uint32_t rk, uint32_t j, uint32_t thr) {
-  return ((attn_hash(rk, j >> 1) >> ((j & 1u) * 16u)) & 0xffffu) >= thr;
-}
 
-// ---- staging: [64 rows][HD] fp32 from global -> registers -> two bf16 planes in LDS
-template <int HD, int NT>
-struct TileRegs {
-  static constexpr int NE = AT_KT * (HD / 4);          // float4 elements of a streamed tile
-  static constexpr int NP = (NE + NT - 1) / NT;
-  float4 f[NP];
-  __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int64_t row0, int64_t row_end, int tid) {
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int e = p * NT + tid;
-      const int64_t row = row0 + e / (HD / 4);
-      const int c4 = e % (HD / 4);
-      f[p] = (e < NE && row < row_end) ? *reinterpret_cast<const float4*>(base + row * ld + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-  __device__ __forceinline__ void store(bf16raw* __restrict__ planes, int tid, float mul) const {
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int e = p * NT + tid;
-      if (NE % NT != 0 && e >= NE) break;
-      const int off = (e / (HD / 4)) * AT_PITCH + (e % (HD / 4)) * 4;
-      uint2 h, l;
-      split4(make_float4(f[p].x * mul, f[p].y * mul, f[p].z * mul, f[p].w * mul), h, l);
-      *reinterpret_cast<uint2*>(planes + off) = h;
-      *reinterpret_cast<uint2*>(planes + AT_PLANE + off) = l;
-    }
-  }
-};
+// swizzle of the 16-byte units of plane-tile row r
+__device__ __forceinline__ int at_sw(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
 
-// row fragment: lane (i = lane & 31, half = lane >> 5) <- plane[row][koff .. koff + 7]
-__device__ __forceinline__ bf16x8 frag_rows(const bf16raw* __restrict__ plane, int row, int koff) {
+// row fragment (8 consecutive head dims of row `row`, unit u): lane (i = lane & 31, half) <- plane[row][8u .. 8u + 7]
+__device__ __forceinline__ bf16x8 frag_rows(const unsigned char* __restrict__ plane, int row, int u) {
   Frag8 f;
-  f.u = *reinterpret_cast<const uint4*>(plane + row * AT_PITCH + koff);
+  f.u = *reinterpret_cast<const uint4*>(plane + row * 128 + ((u ^ at_sw(row)) << 4));
   return f.v;
 }
-// transposed fragment: lane (i = lane & 31 -> column mbase + i, half) <- rows r0 + {0..3} (slots 0-3) and r0 + 8 + {0..3} (slots 4-7);
-// r0 already holds the half's offset (16*s + 4*half): the k-slot <-> row map of the header comment
-__device__ __forceinline__ bf16x8 frag_tr(const bf16raw* __restrict__ plane, int r0, int mbase, int lane) {
-  const bf16raw* p = plane + (r0 + ((lane & 15) >> 2)) * AT_PITCH + mbase + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+// transposed fragment for MFMA row block `dt` (head dims 32 dt ...): lane (i = lane & 31 -> head dim 32 dt + i, half) <- rows
+// r0 + {0..3} (k slots 0-3) and r0 + 8 + {0..3} (slots 4-7); r0 already holds the half's offset (16 s + 4 half), a multiple of 4
+__device__ __forceinline__ bf16x8 frag_tr(const unsigned char* __restrict__ plane, int r0, int dt, int lane) {
+  const int q4 = (lane & 15) >> 2, b = (lane >> 4) & 1, e = lane & 3;
+  const int u = 4 * dt + 2 * b + (e >> 1);
+  const int ra = r0 + q4, rb = ra + 8;
+  const unsigned char* pa = plane + ra * 128 + ((u ^ at_sw(ra)) << 4) + (e & 1) * 8;
+  const unsigned char* pb = plane + rb * 128 + ((u ^ at_sw(rb)) << 4) + (e & 1) * 8;
   union { bf16x4_t q[2]; bf16x8 v; } a;
-  a.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(p));
-  a.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(p + 8 * AT_PITCH));
+  a.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(pa));
+  a.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(pb));
   return a.v;
 }
 // 8 fp32 accumulator values -> hi / lo B fragments
@@ -126,19 +137,19 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& 
   for (int i = 0; i < 4; ++i) split2(v[2 * i], v[2 * i + 1], h.u[i], l.u[i]);
   hi = h.v; lo = l.v;
 }
-// the stationary operand's fragments: 8 consecutive head dims of one row at 16*ks + 8*half, scaled, split
+// the stationary operand's fragments, straight from the planes: 8 consecutive head dims of one row at 16 ks + 8 half
 template <int HD>
-__device__ __forceinline__ void load_row_frags(const float* __restrict__ row, bool ok, int half, float mul, bf16x8 (&fh)[HD / 16],
-                                               bf16x8 (&fl)[HD / 16]) {
+__device__ __forceinline__ void load_row_frags(const bf16raw* __restrict__ hi, const bf16raw* __restrict__ lo, bool ok, int half,
+                                               bf16x8 (&fh)[HD / 16], bf16x8 (&fl)[HD / 16]) {
 #pragma unroll
   for (int ks = 0; ks < HD / 16; ++ks) {
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    Frag8 a, b;
+    a.u = make_uint4(0u, 0u, 0u, 0u); b.u = a.u;
     if (ok) {
-      a = *reinterpret_cast<const float4*>(row + 16 * ks + 8 * half);
-      b = *reinterpret_cast<const float4*>(row + 16 * ks + 8 * half + 4);
+      a.u = *reinterpret_cast<const uint4*>(hi + 16 * ks + 8 * half);
+      b.u = *reinterpret_cast<const uint4*>(lo + 16 * ks + 8 * half);
     }
-    const float v[8] = {a.x * mul, a.y * mul, a.z * mul, a.w * mul, b.x * mul, b.y * mul, b.z * mul, b.w * mul};
-    split8(v, fh[ks], fl[ks]);
+    fh[ks] = a.v; fl[ks] = b.v;
   }
 }
 #define MFMA3(acc, ah, al, bh, bl)                                        \
@@ -147,24 +158,70 @@ __device__ __forceinline__ void load_row_frags(const float* __restrict__ row, bo
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);  \
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);  \
   } while (0)
-
-__device__ __forceinline__ void zero_lds(bf16raw* smem, int halfwords, int tid, int nt) {
-  for (int e = tid * 8; e < halfwords; e += nt * 8) *reinterpret_cast<uint4*>(smem + e) = make_uint4(0u, 0u, 0u, 0u);
-}
 // row of accumulator register r in a 32x32 tile: (r & 3) + 8 * (r >> 2) + 4 * half
 #define ACC_ROW(r, half) (((r) & 3) + 8 * ((r) >> 2) + 4 * (half))
+
+// The transposed fragments of the last MFMA row block read head dims up to 32 * DT - 1 >= HD: those units are never written by the
+// DMA. They are zeroed once (zero operands also cost the matrix pipe less power than whatever the LDS held before).
+template <int HD>
+__device__ __forceinline__ void zero_pad_units(unsigned char* smem, int nslots, int tid) {
+  constexpr int UN = HD / 8, UP = 4 * ((HD + 31) / 32) - UN;       // data units, pad units per row
+  if (UP == 0) return;
+  const int total = nslots * 4 * AT_KT * UP;
+  for (int e = tid; e < total; e += 512) {
+    const int pu = e % UP, r = (e / UP) % AT_KT, pl = e / (UP * AT_KT);
+    *reinterpret_cast<uint4*>(smem + pl * AT_PLANE_B + r * 128 + (((UN + pu) ^ at_sw(r)) << 4)) = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
+// One tile of the streamed operand pair -> ring slot `slot`: this wave's 4 pieces (rows 8 wave .. 8 wave + 7 of each of the four
+// planes). `col_a` / `col_b`: halfword column of the head's slice in the two source matrices; rows beyond the bag re-read its
+// last row (finite data; their scores are masked).
+struct TileDma {
+  int lrow, usrc;
+  bool on;
+  __device__ __forceinline__ void init(int wave, int lane, int UN) {
+    lrow = wave * 8 + (lane >> 3);
+    usrc = (lane & 7) ^ at_sw(lrow);
+    on = usrc < UN;
+  }
+  __device__ __forceinline__ void issue(unsigned char* smem, int wave, int slot, int64_t tile_row0, int64_t Lg, const bf16raw* a_hi,
+                                        const bf16raw* a_lo, int64_t lda, const bf16raw* b_hi, const bf16raw* b_lo, int64_t ldb) const {
+    int64_t r = tile_row0 + lrow;
+    if (r > Lg - 1) r = Lg - 1;
+    unsigned char* dst = smem + slot * AT_SLOT_B + wave * 1024;
+    if (on) {
+      const int64_t ea = r * lda + usrc * 8, eb = r * ldb + usrc * 8;
+      __builtin_amdgcn_global_load_lds((const GLB_AS void*)(a_hi + ea), (LDS_AS void*)(dst), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const GLB_AS void*)(a_lo + ea), (LDS_AS void*)(dst + AT_PLANE_B), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const GLB_AS void*)(b_hi + eb), (LDS_AS void*)(dst + 2 * AT_PLANE_B), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const GLB_AS void*)(b_lo + eb), (LDS_AS void*)(dst + 3 * AT_PLANE_B), 16, 0, 0);
+    }
+  }
+};
 
 // =====================================================================================
 // forward
 // =====================================================================================
-template <int HD, bool DROP, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnArgs a) {
-  constexpr int NT = 64 * NW, AT_QB = 32 * NW;
-  constexpr int KS = HD / 16, DT = (HD + 31) / 32;
-  __shared__ __attribute__((aligned(16))) bf16raw smem[4 * AT_PLANE];   // K hi | K lo | V hi | V lo
-  bf16raw* const sK = smem;
-  bf16raw* const sV = smem + 2 * AT_PLANE;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, half = lane >> 5;
+// Four v_exp_f32 behind each other and ONE pair of wait states for the last (common.h::hw_exp2: a transcendental's consumer directly
+// behind it can read stale lanes; the first three results are three issue slots old when the block ends)
+__device__ __forceinline__ void hw_exp2x4(float& a, float& b, float& c, float& d) {
+  asm("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\tv_exp_f32 %2, %2\n\tv_exp_f32 %3, %3\n\ts_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+
+// Forward. Measured on the way here (tools/probe/stamp_attn.sh, rocprofv3 counters): with two waves per SIMD the kernel is bound by
+// instruction ISSUE, not by either pipe -- a wave issues one instruction per ~4.3 cycles, a tile costs it ~575 instructions next to 42
+// MFMAs, and an in-order wave that is waiting for the matrix pipe (busy with its partner's MFMA) issues nothing else. Three
+// structures (lockstep phases, anti-phase wave groups, in-wave software pipeline) all landed at 490-580 us for 16 x 2048 tokens.
+// What the SIMD needs is more waves to draw instructions from: this kernel keeps its live state under 128 VGPRs -- one 32-key
+// half-tile at a time: S (16) -> P split (16) -> O (32), Q fragments (24) -- so that TWO workgroups (4 waves per SIMD) share a CU,
+// each with a double-buffered 64 KB ring; their barriers are independent, so one workgroup's softmax runs under the other's MFMAs.
+template <int HD, bool DROP>
+__global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnArgs a) {
+  constexpr int KS = HD / 16, DT = (HD + 31) / 32, UN = HD / 8;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * AT_SLOT_B];
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = a.H;
   const int h = blockIdx.x % H;
   const int rest = blockIdx.x / H;
@@ -173,20 +230,33 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnArgs a) {
   const int64_t Lg = a.ptr ? a.ptr[g + 1] - row0 : a.Ltot;
   if ((int64_t)qt * AT_QB >= Lg) return;
   const int D = H * HD;
-  const float* const Qb = a.qkv + row0 * a.ldq + h * HD;
-  const float* const Kb = Qb + D;
-  const float* const Vb = Qb + 2 * D;
-  zero_lds(smem, 4 * AT_PLANE, tid, NT);   // pad columns [HD, 72) stay zero: the transposed reads of the last head-dim tile cover [32, 64)
+  const int64_t ldq = a.ldq;
+  const bf16raw* const Kh = a.qkv_hi + row0 * ldq + D + h * HD;
+  const bf16raw* const Kl = a.qkv_lo + row0 * ldq + D + h * HD;
+  const bf16raw* const Vh = Kh + D;
+  const bf16raw* const Vl = Kl + D;
+  const int T = (int)((Lg + AT_KT - 1) / AT_KT);
+
+  TileDma dma;
+  dma.init(wave, lane, UN);
+  dma.issue(smem, wave, 0, 0, Lg, Kh, Kl, ldq, Vh, Vl, ldq);
+  if (T > 1) dma.issue(smem, wave, 1, AT_KT, Lg, Kh, Kl, ldq, Vh, Vl, ldq);
+  zero_pad_units<HD>(smem, 2, tid);
 
   const int64_t q = (int64_t)qt * AT_QB + wave * 32 + j;
   const bool qok = q < Lg;
   bf16x8 qh[KS], ql[KS];
-  load_row_frags<HD>(Qb + q * a.ldq, qok, half, a.scale_log2e, qh, ql);
-  uint32_t rk = 0;
+  {
+    const int64_t qo = (row0 + (qok ? q : 0)) * ldq + h * HD;
+    load_row_frags<HD>(a.qkv_hi + qo, a.qkv_lo + qo, qok, half, qh, ql);
+  }
+  uint32_t hbase = 0;
   if (DROP) {
     const uint64_t grow = (uint64_t)(row0 + (a.rng_rowoff ? a.rng_rowoff[g] : 0) + q);
-    rk = attn_row_key(rng_key(*a.seed, a.stream_id), grow * (uint64_t)H + (uint64_t)h);
+    hbase = attn_row_key(rng_key(*a.seed, a.stream_id), grow * (uint64_t)H + (uint64_t)h) + (uint32_t)half * AT_GOLD;
   }
+  const float c = a.scale_log2e;
+  const uint32_t thr = a.drop_thr;
 
   f32x16 o[DT];
 #pragma unroll
@@ -194,96 +264,92 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
-
-  TileRegs<HD, NT> rK, rV;
-  rK.load(Kb, a.ldq, 0, Lg, tid);
-  rV.load(Vb, a.ldq, 0, Lg, tid);
-  for (int64_t kb = 0; kb < Lg; kb += AT_KT) {
-    __syncthreads();                       // every wave is done with the previous tile (and the zero fill)
-    rK.store(sK, tid, 1.f);
-    rV.store(sV, tid, 1.f);
-    __syncthreads();
-    if (kb + AT_KT < Lg) {                 // next tile's loads fly under this tile's MFMAs
-      rK.load(Kb, a.ldq, kb + AT_KT, Lg, tid);
-      rV.load(Vb, a.ldq, kb + AT_KT, Lg, tid);
-    }
-    // ---- S^T[key, q] = K . Q'^T  (already in the log2 domain)
-    f32x16 s[2];
+#ifdef AT_STAMP
+  int st_i = 0;
+#endif
+  if (T > 1) at_wait_vmcnt<AT_PPW>(); else at_wait_vmcnt<0>();      // (the Q fragments were requested after the tiles: tile 0 has landed)
+  at_barrier();
+  for (int t = 0; t < T; ++t) {
+    AT_ST(1);
+    const unsigned char* sK = smem + (t & 1) * AT_SLOT_B;
+    const unsigned char* sV = sK + 2 * AT_PLANE_B;
+    const int64_t kb = (int64_t)t * AT_KT;
+    const bool tail = kb + AT_KT > Lg;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int u = 0; u < 2; ++u) {
+      // ---- S^T[key, q] = K . Q^T for keys kb + 32 u ...
+      f32x16 s;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 kh = frag_rows(sK, 32 * t + j, 16 * ks + 8 * half);
-        const bf16x8 kl = frag_rows(sK + AT_PLANE, 32 * t + j, 16 * ks + 8 * half);
-        MFMA3(s[t], kh, kl, qh[ks], ql[ks]);
+        const bf16x8 kh = frag_rows(sK, 32 * u + j, 2 * ks + half), kl = frag_rows(sK + AT_PLANE_B, 32 * u + j, 2 * ks + half);
+        MFMA3(s, kh, kl, qh[ks], ql[ks]);
       }
-    }
-    if (kb + AT_KT > Lg) {                 // ragged tail: keys past the bag get probability 0
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
+      if (tail) {                                // ragged tail: keys past the bag get probability 0
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (kb + 32 * t + ACC_ROW(r, half) >= Lg) s[t][r] = -INFINITY;
-    }
-    float mx = m_run;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    // rescale the running state only when some query of this wave saw a new maximum (after the first tiles it rarely moves)
-    const bool moved = __any(mx != m_run);
-    float alpha = 1.f;
-    if (moved) {
-      alpha = hw_exp2(m_run - mx);
-      m_run = mx;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-    }
-    float psum = 0.f;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = hw_exp2(s[t][r] - mx);
-        psum += p;
-        s[t][r] = p;
+          if (kb + 32 * u + ACC_ROW(r, half) >= Lg) s[r] = -INFINITY;
       }
-    if (DROP) {
+      // ---- statistics, probabilities, dropout, split
+      float mx = m_run;
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      if (__any(mx != m_run)) {                  // rescale only when some query of this wave saw a new maximum (rare after the first tiles)
+        const float alpha = hw_exp2((m_run - mx) * c);
+        m_run = mx;
+        l_run *= alpha;
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {       // 4 consecutive keys per register group = 2 hashes
-          const uint32_t jp = (uint32_t)(kb + 32 * t + 8 * rg + 4 * half) >> 1;
-          const uint32_t h0 = attn_hash(rk, jp), h1 = attn_hash(rk, jp + 1);
-          if ((h0 & 0xffffu) < a.drop_thr) s[t][4 * rg] = 0.f;
-          if ((h0 >> 16) < a.drop_thr) s[t][4 * rg + 1] = 0.f;
-          if ((h1 & 0xffffu) < a.drop_thr) s[t][4 * rg + 2] = 0.f;
-          if ((h1 >> 16) < a.drop_thr) s[t][4 * rg + 3] = 0.f;
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+      }
+      const float nmc = -mx * c;
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r += 4) {
+        float e0 = fmaf(s[r], c, nmc), e1 = fmaf(s[r + 1], c, nmc), e2 = fmaf(s[r + 2], c, nmc), e3 = fmaf(s[r + 3], c, nmc);
+        hw_exp2x4(e0, e1, e2, e3);
+        psum += (e0 + e1) + (e2 + e3);
+        s[r] = e0; s[r + 1] = e1; s[r + 2] = e2; s[r + 3] = e3;
+      }
+      l_run += psum;
+      if (DROP) {                                // register 4 rg + e <-> key kb + 32 u + 8 rg + 4 half + e: one hash per register group
+        const uint32_t hb = hbase + (uint32_t)(t * (AT_KT / 4) + 8 * u) * AT_GOLD;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const uint32_t hsh = attn_mix(hb + (uint32_t)(2 * rg) * AT_GOLD);
+          if ((hsh & 0xffu) < thr) s[4 * rg] = 0.f;
+          if (((hsh >> 8) & 0xffu) < thr) s[4 * rg + 1] = 0.f;
+          if (((hsh >> 16) & 0xffu) < thr) s[4 * rg + 2] = 0.f;
+          if ((hsh >> 24) < thr) s[4 * rg + 3] = 0.f;
         }
-    }
-    l_run = l_run * alpha + psum;
-    // ---- O^T[d, q] += V^T[d, key] . P^T[key, q]
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
+      }
+      // ---- O^T[d, q] += V^T[d, key] . P^T[key, q]
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = s[t][8 * s2 + u];
+        for (int e = 0; e < 8; ++e) v[e] = s[8 * s2 + e];
         bf16x8 ph, pl;
         split8(v, ph, pl);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-          const bf16x8 vh = frag_tr(sV, 32 * t + 16 * s2 + 4 * half, 32 * dt, lane);
-          const bf16x8 vl = frag_tr(sV + AT_PLANE, 32 * t + 16 * s2 + 4 * half, 32 * dt, lane);
+          const bf16x8 vh = frag_tr(sV, 32 * u + 16 * s2 + 4 * half, dt, lane);
+          const bf16x8 vl = frag_tr(sV + AT_PLANE_B, 32 * u + 16 * s2 + 4 * half, dt, lane);
           MFMA3(o[dt], vh, vl, ph, pl);
         }
       }
+      AT_ST(3 + u);
+    }
+    if (t + 1 < T) {
+      at_wait_vmcnt<0>();                        // this wave's pieces of tile t + 1 (issued one trip ago)
+      AT_ST(5);
+      at_barrier();                              // every wave is done with tile t's slot, every piece of tile t + 1 is visible
+      if (t + 2 < T) dma.issue(smem, wave, t & 1, (int64_t)(t + 2) * AT_KT, Lg, Kh, Kl, ldq, Vh, Vl, ldq);
+      AT_ST(2);
+    }
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (qok) {
@@ -298,21 +364,22 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnArgs a) {
           *reinterpret_cast<float4*>(orow + d) =
               make_float4(o[dt][4 * rg] * inv, o[dt][4 * rg + 1] * inv, o[dt][4 * rg + 2] * inv, o[dt][4 * rg + 3] * inv);
       }
-    if (half == 0) a.lse[(row0 + q) * H + h] = m_run + hw_log2(l_tot);
+    if (half == 0) a.lse[(row0 + q) * H + h] = m_run * c + hw_log2(l_tot);
   }
 }
 
 // =====================================================================================
 // backward, queries stationary: dQ = scale * dS K
 // =====================================================================================
-template <int HD, bool DROP, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(AttnArgs a) {
-  constexpr int NT = 64 * NW, AT_QB = 32 * NW;
-  constexpr int KS = HD / 16, DT = (HD + 31) / 32;
-  __shared__ __attribute__((aligned(16))) bf16raw smem[4 * AT_PLANE];   // K hi | K lo | V hi | V lo
-  bf16raw* const sK = smem;
-  bf16raw* const sV = smem + 2 * AT_PLANE;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, half = lane >> 5;
+// One workgroup (8 waves) per CU; the K / V tiles ride a ring of 3 slots: tile t + 2 is requested at the top of trip t (its slot's
+// tile t - 1 was released by the barrier that closed trip t - 1), tile t + 1 is awaited at the bottom of trip t, one barrier per tile.
+// A 32-key half-tile at a time through scores -> dS -> dQ: only one pair of 32x32 accumulators is live.
+template <int HD, bool DROP>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnArgs a) {
+  constexpr int KS = HD / 16, DT = (HD + 31) / 32, UN = HD / 8;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * AT_SLOT_B];
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = a.H;
   const int h = blockIdx.x % H;
   const int rest = blockIdx.x / H;
@@ -321,24 +388,37 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   const int64_t Lg = a.ptr ? a.ptr[g + 1] - row0 : a.Ltot;
   if ((int64_t)qt * AT_QB >= Lg) return;
   const int D = H * HD;
-  const float* const Qb = a.qkv + row0 * a.ldq + h * HD;
-  const float* const Kb = Qb + D;
-  const float* const Vb = Qb + 2 * D;
-  zero_lds(smem, 4 * AT_PLANE, tid, NT);
+  const int64_t ldq = a.ldq;
+  const bf16raw* const Kh = a.qkv_hi + row0 * ldq + D + h * HD;
+  const bf16raw* const Kl = a.qkv_lo + row0 * ldq + D + h * HD;
+  const bf16raw* const Vh = Kh + D;
+  const bf16raw* const Vl = Kl + D;
+  const int T = (int)((Lg + AT_KT - 1) / AT_KT);
+
+  TileDma dma;
+  dma.init(wave, lane, UN);
+  dma.issue(smem, wave, 0, 0, Lg, Kh, Kl, ldq, Vh, Vl, ldq);
+  if (T > 1) dma.issue(smem, wave, 1, AT_KT, Lg, Kh, Kl, ldq, Vh, Vl, ldq);
+  zero_pad_units<HD>(smem, 3, tid);
 
   const int64_t q = (int64_t)qt * AT_QB + wave * 32 + j;
   const bool qok = q < Lg;
   bf16x8 qh[KS], ql[KS], gh[KS], gl[KS];
-  load_row_frags<HD>(Qb + q * a.ldq, qok, half, a.scale_log2e, qh, ql);
-  load_row_frags<HD>(a.dout + (row0 + q) * D + h * HD, qok, half, 1.f, gh, gl);
+  {
+    const int64_t qo = (row0 + (qok ? q : 0)) * ldq + h * HD, go = (row0 + (qok ? q : 0)) * D + h * HD;
+    load_row_frags<HD>(a.qkv_hi + qo, a.qkv_lo + qo, qok, half, qh, ql);
+    load_row_frags<HD>(a.do_hi + go, a.do_lo + go, qok, half, gh, gl);
+  }
   const float lse_q = qok ? a.lse[(row0 + q) * H + h] : 0.f;
   const float d_q = qok ? a.dsum[(row0 + q) * H + h] : 0.f;
-  uint32_t rk = 0;
+  uint32_t hbase = 0;
   if (DROP) {
     const uint64_t grow = (uint64_t)(row0 + (a.rng_rowoff ? a.rng_rowoff[g] : 0) + q);
-    rk = attn_row_key(rng_key(*a.seed, a.stream_id), grow * (uint64_t)H + (uint64_t)h);
+    hbase = attn_row_key(rng_key(*a.seed, a.stream_id), grow * (uint64_t)H + (uint64_t)h) + (uint32_t)half * AT_GOLD;
   }
   const float ik = DROP ? a.inv_keep : 1.f;
+  const float c = a.scale_log2e;
+  const uint32_t thr = a.drop_thr;
 
   f32x16 dq[DT];
 #pragma unroll
@@ -346,72 +426,76 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
 
-  TileRegs<HD, NT> rK, rV;
-  rK.load(Kb, a.ldq, 0, Lg, tid);
-  rV.load(Vb, a.ldq, 0, Lg, tid);
-  for (int64_t kb = 0; kb < Lg; kb += AT_KT) {
-    __syncthreads();
-    rK.store(sK, tid, 1.f);
-    rV.store(sV, tid, 1.f);
-    __syncthreads();
-    if (kb + AT_KT < Lg) {
-      rK.load(Kb, a.ldq, kb + AT_KT, Lg, tid);
-      rV.load(Vb, a.ldq, kb + AT_KT, Lg, tid);
-    }
-    // one 32-key sub-tile at a time through scores -> dS -> dQ: only one pair of 32x32 accumulators is live (both sub-tiles at once
-    // put the dropout instantiation 5 registers over the file: 20 bytes of scratch)
+  at_wait_vmcnt<0>();
+  at_barrier();                                  // tiles 0 and 1 have landed
+  for (int t = 0; t < T; ++t) {
+    if (t + 2 < T) dma.issue(smem, wave, (t + 2) % 3, (int64_t)(t + 2) * AT_KT, Lg, Kh, Kl, ldq, Vh, Vl, ldq);
+    const unsigned char* sK = smem + (t % 3) * AT_SLOT_B;
+    const unsigned char* sV = sK + 2 * AT_PLANE_B;
+    const int64_t kb = (int64_t)t * AT_KT;
     const bool tail = kb + AT_KT > Lg;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int u = 0; u < 2; ++u) {
       f32x16 st, dpt;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 kh = frag_rows(sK, 32 * t + j, 16 * ks + 8 * half);
-        const bf16x8 kl = frag_rows(sK + AT_PLANE, 32 * t + j, 16 * ks + 8 * half);
-        MFMA3(st, kh, kl, qh[ks], ql[ks]);                   // S^T[key, q]
-        const bf16x8 vh = frag_rows(sV, 32 * t + j, 16 * ks + 8 * half);
-        const bf16x8 vl = frag_rows(sV + AT_PLANE, 32 * t + j, 16 * ks + 8 * half);
-        MFMA3(dpt, vh, vl, gh[ks], gl[ks]);                  // dPd^T[key, q] = V . dO^T
+        const bf16x8 kh = frag_rows(sK, 32 * u + j, 2 * ks + half), kl = frag_rows(sK + AT_PLANE_B, 32 * u + j, 2 * ks + half);
+        const bf16x8 vh = frag_rows(sV, 32 * u + j, 2 * ks + half), vl = frag_rows(sV + AT_PLANE_B, 32 * u + j, 2 * ks + half);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[ks], st, 0, 0, 0);          // S^T[key, q]   (unscaled)
+        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, gh[ks], dpt, 0, 0, 0);        // dPd^T[key, q] = V . dO^T
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[ks], st, 0, 0, 0);
+        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, gl[ks], dpt, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[ks], st, 0, 0, 0);
+        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, gh[ks], dpt, 0, 0, 0);
       }
-      if (DROP) {
+      if (DROP) {                                // register 4 rg + e <-> key kb + 32 u + 8 rg + 4 half + e: one hash per register group
+        const uint32_t hb = hbase + (uint32_t)(t * (AT_KT / 4) + 8 * u) * AT_GOLD;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-          const uint32_t jp = (uint32_t)(kb + 32 * t + 8 * rg + 4 * half) >> 1;
-          const uint32_t h0 = attn_hash(rk, jp), h1 = attn_hash(rk, jp + 1);
-          if ((h0 & 0xffffu) < a.drop_thr) dpt[4 * rg] = 0.f;
-          if ((h0 >> 16) < a.drop_thr) dpt[4 * rg + 1] = 0.f;
-          if ((h1 & 0xffffu) < a.drop_thr) dpt[4 * rg + 2] = 0.f;
-          if ((h1 >> 16) < a.drop_thr) dpt[4 * rg + 3] = 0.f;
+          const uint32_t hsh = attn_mix(hb + (uint32_t)(2 * rg) * AT_GOLD);
+          if ((hsh & 0xffu) < thr) dpt[4 * rg] = 0.f;
+          if (((hsh >> 8) & 0xffu) < thr) dpt[4 * rg + 1] = 0.f;
+          if (((hsh >> 16) & 0xffu) < thr) dpt[4 * rg + 2] = 0.f;
+          if ((hsh >> 24) < thr) dpt[4 * rg + 3] = 0.f;
         }
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t key = kb + 32 * t + ACC_ROW(r, half);
-        float p = hw_exp2(st[r] - lse_q);
-        if (tail && key >= Lg) p = 0.f;
-        st[r] = p * (dpt[r] * ik - d_q);                     // dS^T
+      for (int r = 0; r < 16; r += 4) {
+        float e0 = fmaf(st[r], c, -lse_q), e1 = fmaf(st[r + 1], c, -lse_q), e2 = fmaf(st[r + 2], c, -lse_q), e3 = fmaf(st[r + 3], c, -lse_q);
+        hw_exp2x4(e0, e1, e2, e3);
+        st[r] = e0 * fmaf(dpt[r], ik, -d_q); st[r + 1] = e1 * fmaf(dpt[r + 1], ik, -d_q);
+        st[r + 2] = e2 * fmaf(dpt[r + 2], ik, -d_q); st[r + 3] = e3 * fmaf(dpt[r + 3], ik, -d_q);     // dS^T
+      }
+      if (tail) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kb + 32 * u + ACC_ROW(r, half) >= Lg) st[r] = 0.f;
       }
       // dQ^T[d, q] += K^T[d, key] . dS^T[key, q]
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = st[8 * s2 + u];
+        for (int e = 0; e < 8; ++e) v[e] = st[8 * s2 + e];
         bf16x8 dh, dl;
         split8(v, dh, dl);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-          const bf16x8 kh = frag_tr(sK, 32 * t + 16 * s2 + 4 * half, 32 * dt, lane);
-          const bf16x8 kl = frag_tr(sK + AT_PLANE, 32 * t + 16 * s2 + 4 * half, 32 * dt, lane);
+          const bf16x8 kh = frag_tr(sK, 32 * u + 16 * s2 + 4 * half, dt, lane);
+          const bf16x8 kl = frag_tr(sK + AT_PLANE_B, 32 * u + 16 * s2 + 4 * half, dt, lane);
           MFMA3(dq[dt], kh, kl, dh, dl);
         }
       }
     }
+    if (t + 1 < T) {
+      if (t + 2 < T) at_wait_vmcnt<AT_PPW>(); else at_wait_vmcnt<0>();      // tile t + 1 (only tile t + 2's pieces may still fly)
+      at_barrier();
+    }
   }
   if (qok) {
-    float* const drow = a.dqkv + (row0 + q) * a.ldq + h * HD;
+    float* const drow = a.dqkv + (row0 + q) * ldq + h * HD;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -427,18 +511,16 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 // =====================================================================================
 // backward, keys stationary: dV = Pd^T dO, dK = scale * dS^T Q
 // =====================================================================================
-template <int HD, bool DROP, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
-  constexpr int NT = 64 * NW, AT_QB = 32 * NW;
-  constexpr int KS = HD / 16, DT = (HD + 31) / 32;
-  // Q' hi | Q' lo | dO hi | dO lo | lse[64] | D[64] | rowkey[64]
-  __shared__ __attribute__((aligned(16))) bf16raw smem[4 * AT_PLANE + 3 * AT_KT * 2];
-  bf16raw* const sQ = smem;
-  bf16raw* const sG = smem + 2 * AT_PLANE;
-  float* const sLse = reinterpret_cast<float*>(smem + 4 * AT_PLANE);
-  float* const sD = sLse + AT_KT;
-  uint32_t* const sRk = reinterpret_cast<uint32_t*>(sD + AT_KT);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, half = lane >> 5;
+// Same ring; the streamed tiles are [Q hi | Q lo | dO hi | dO lo] of 64 queries, consumed in two 32-query halves. The side data of
+// a tile's queries (lse, D, dropout row key) sit in a double-buffered LDS array: lanes 0-7 of wave w load those of query 8 w + lane
+// of tile t + 1 at the top of trip t and store them at its bottom, in front of the barrier.
+template <int HD, bool DROP>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
+  constexpr int KS = HD / 16, DT = (HD + 31) / 32, UN = HD / 8;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * AT_SLOT_B + 2 * 3 * AT_KT * 4];
+  float* const sAux = reinterpret_cast<float*>(smem + 3 * AT_SLOT_B);     // per parity: lse[64] | D[64] | rowkey[64]
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = a.H;
   const int h = blockIdx.x % H;
   const int rest = blockIdx.x / H;
@@ -447,20 +529,53 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   const int64_t Lg = a.ptr ? a.ptr[g + 1] - row0 : a.Ltot;
   if ((int64_t)kt * AT_QB >= Lg) return;
   const int D = H * HD;
-  const float* const Qb = a.qkv + row0 * a.ldq + h * HD;
-  const float* const Kb = Qb + D;
-  const float* const Vb = Qb + 2 * D;
-  const float* const Gb = a.dout + row0 * D + h * HD;
-  zero_lds(smem, 4 * AT_PLANE, tid, NT);
+  const int64_t ldq = a.ldq;
+  const bf16raw* const Qh = a.qkv_hi + row0 * ldq + h * HD;
+  const bf16raw* const Ql = a.qkv_lo + row0 * ldq + h * HD;
+  const bf16raw* const Gh = a.do_hi + row0 * D + h * HD;
+  const bf16raw* const Gl = a.do_lo + row0 * D + h * HD;
+  const int T = (int)((Lg + AT_KT - 1) / AT_KT);
+
+  const uint64_t key64 = DROP ? rng_key(*a.seed, a.stream_id) : 0;
+  const int64_t rowoff = a.rng_rowoff ? a.rng_rowoff[g] : 0;
+  float ax_l = 0.f, ax_d = 0.f;
+  auto aux_load = [&](int tile) {
+    if (lane < 8) {
+      const int64_t qq = (int64_t)tile * AT_KT + wave * 8 + lane;
+      const bool ok = qq < Lg;
+      ax_l = ok ? a.lse[(row0 + qq) * H + h] : 0.f;
+      ax_d = ok ? a.dsum[(row0 + qq) * H + h] : 0.f;
+    }
+  };
+  auto aux_store = [&](int tile) {
+    if (lane < 8) {
+      float* p = sAux + (tile & 1) * 3 * AT_KT + wave * 8 + lane;
+      p[0] = ax_l; p[AT_KT] = ax_d;
+      if (DROP) {
+        const int64_t qq = (int64_t)tile * AT_KT + wave * 8 + lane;
+        reinterpret_cast<uint32_t*>(p)[2 * AT_KT] = attn_row_key(key64, (uint64_t)(row0 + rowoff + qq) * (uint64_t)H + (uint64_t)h);
+      }
+    }
+  };
+  TileDma dma;
+  dma.init(wave, lane, UN);
+  aux_load(0);
+  dma.issue(smem, wave, 0, 0, Lg, Qh, Ql, ldq, Gh, Gl, D);
+  if (T > 1) dma.issue(smem, wave, 1, AT_KT, Lg, Qh, Ql, ldq, Gh, Gl, D);
+  zero_pad_units<HD>(smem, 3, tid);
 
   const int64_t key = (int64_t)kt * AT_QB + wave * 32 + j;
   const bool kok = key < Lg;
   bf16x8 kh[KS], kl[KS], vh[KS], vl[KS];
-  load_row_frags<HD>(Kb + key * a.ldq, kok, half, 1.f, kh, kl);
-  load_row_frags<HD>(Vb + key * a.ldq, kok, half, 1.f, vh, vl);
-  const uint64_t key64 = DROP ? rng_key(*a.seed, a.stream_id) : 0;
-  const int64_t rowoff = a.rng_rowoff ? a.rng_rowoff[g] : 0;
+  {
+    const int64_t ko = (row0 + (kok ? key : 0)) * ldq + D + h * HD;
+    load_row_frags<HD>(a.qkv_hi + ko, a.qkv_lo + ko, kok, half, kh, kl);
+    load_row_frags<HD>(a.qkv_hi + ko + D, a.qkv_lo + ko + D, kok, half, vh, vl);
+  }
   const float ik = DROP ? a.inv_keep : 1.f;
+  const float c = a.scale_log2e;
+  const uint32_t kgold = (uint32_t)(key >> 2) * AT_GOLD;        // this lane's key group
+  const int kbyte = (int)(key & 3) * 8;
 
   f32x16 dk[DT], dv[DT];
 #pragma unroll
@@ -468,83 +583,99 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
 
-  TileRegs<HD, NT> rQ, rG;
-  rQ.load(Qb, a.ldq, 0, Lg, tid);
-  rG.load(Gb, D, 0, Lg, tid);
-  for (int64_t qb = 0; qb < Lg; qb += AT_KT) {
-    __syncthreads();
-    rQ.store(sQ, tid, a.scale_log2e);
-    rG.store(sG, tid, 1.f);
-    if (tid < AT_KT) {
-      const int64_t qq = qb + tid;
-      const bool ok = qq < Lg;
-      sLse[tid] = ok ? a.lse[(row0 + qq) * H + h] : 0.f;
-      sD[tid] = ok ? a.dsum[(row0 + qq) * H + h] : 0.f;
-      if (DROP) sRk[tid] = attn_row_key(key64, (uint64_t)(row0 + rowoff + qq) * (uint64_t)H + (uint64_t)h);
-    }
-    __syncthreads();
-    if (qb + AT_KT < Lg) {
-      rQ.load(Qb, a.ldq, qb + AT_KT, Lg, tid);
-      rG.load(Gb, D, qb + AT_KT, Lg, tid);
-    }
+  at_wait_vmcnt<0>();
+  aux_store(0);
+  at_barrier();                                  // tiles 0 and 1 and tile 0's side data are in LDS
+  for (int t = 0; t < T; ++t) {
+    if (t + 1 < T) aux_load(t + 1);
+    if (t + 2 < T) dma.issue(smem, wave, (t + 2) % 3, (int64_t)(t + 2) * AT_KT, Lg, Qh, Ql, ldq, Gh, Gl, D);
+    const unsigned char* sQ = smem + (t % 3) * AT_SLOT_B;
+    const unsigned char* sG = sQ + 2 * AT_PLANE_B;
+    const float* axt = sAux + (t & 1) * 3 * AT_KT;
+    const int64_t qb = (int64_t)t * AT_KT;
+    const bool tail = qb + AT_KT > Lg;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int u = 0; u < 2; ++u) {
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 ah = frag_rows(sQ, 32 * t + j, 16 * ks + 8 * half);
-        const bf16x8 al = frag_rows(sQ + AT_PLANE, 32 * t + j, 16 * ks + 8 * half);
-        MFMA3(s, ah, al, kh[ks], kl[ks]);                    // S[q, key]
-        const bf16x8 bh = frag_rows(sG, 32 * t + j, 16 * ks + 8 * half);
-        const bf16x8 bl = frag_rows(sG + AT_PLANE, 32 * t + j, 16 * ks + 8 * half);
-        MFMA3(dp, bh, bl, vh[ks], vl[ks]);                   // dPd[q, key] = dO . V^T
+        const bf16x8 ah = frag_rows(sQ, 32 * u + j, 2 * ks + half), al = frag_rows(sQ + AT_PLANE_B, 32 * u + j, 2 * ks + half);
+        const bf16x8 bh = frag_rows(sG, 32 * u + j, 2 * ks + half), bl = frag_rows(sG + AT_PLANE_B, 32 * u + j, 2 * ks + half);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, kh[ks], s, 0, 0, 0);            // S[q, key]   (unscaled)
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, vh[ks], dp, 0, 0, 0);          // dPd[q, key] = dO . V^T
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, kl[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, vl[ks], dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, kh[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, vh[ks], dp, 0, 0, 0);
       }
-      // rows of this tile are queries: 4 consecutive ones per register group
+      const float* ax = axt + 32 * u;
+      // rows of this half are queries: 4 consecutive ones per register group
+      uint32_t hq[4];
+      if (DROP) {                                // quad lane e hashes the queries (e) + 8 rg + 4 half, rg = 0..3, for the quad's key group
+        const uint32_t* rkp = reinterpret_cast<const uint32_t*>(ax) + 2 * AT_KT;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) hq[rg] = attn_mix(rkp[8 * rg + 4 * half + (lane & 3)] + kgold);
+      }
       float pd[16];
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const int qo = 32 * t + 8 * rg + 4 * half;
-        const float4 l4 = *reinterpret_cast<const float4*>(sLse + qo);
-        const float4 d4 = *reinterpret_cast<const float4*>(sD + qo);
-        uint4 k4 = make_uint4(0u, 0u, 0u, 0u);
-        if (DROP) k4 = *reinterpret_cast<const uint4*>(sRk + qo);
-        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
-        const uint32_t kv[4] = {k4.x, k4.y, k4.z, k4.w};
+        const int qo = 8 * rg + 4 * half;
+        const float4 l4 = *reinterpret_cast<const float4*>(ax + qo);
+        const float4 d4 = *reinterpret_cast<const float4*>(ax + AT_KT + qo);
+        const float dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+        uint32_t hx[4] = {0u, 0u, 0u, 0u};
+        if (DROP) {                              // hash of query qo + e lives in quad lane e
+          hx[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)hq[rg], 0x00, 0xf, 0xf, false);
+          hx[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)hq[rg], 0x55, 0xf, 0xf, false);
+          hx[2] = (uint32_t)__builtin_amdgcn_mov_dpp((int)hq[rg], 0xaa, 0xf, 0xf, false);
+          hx[3] = (uint32_t)__builtin_amdgcn_mov_dpp((int)hq[rg], 0xff, 0xf, 0xf, false);
+        }
+        float e0 = fmaf(s[4 * rg], c, -l4.x), e1 = fmaf(s[4 * rg + 1], c, -l4.y), e2 = fmaf(s[4 * rg + 2], c, -l4.z), e3 = fmaf(s[4 * rg + 3], c, -l4.w);
+        hw_exp2x4(e0, e1, e2, e3);
+        const float pv[4] = {e0, e1, e2, e3};
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int r = 4 * rg + u;
-          const float p = hw_exp2(s[r] - lv[u]);
-          const bool keep = !DROP || attn_keep(kv[u], (uint32_t)key, a.drop_thr);
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * rg + e;
+          float p = pv[e];
+          if (tail && qb + 32 * u + qo + e >= Lg) p = 0.f;       // queries past the bag (their lse slot holds 0)
+          const bool keep = !DROP || ((hx[e] >> kbyte) & 0xffu) >= a.drop_thr;
           pd[r] = keep ? p * ik : 0.f;
-          s[r] = p * ((keep ? dp[r] * ik : 0.f) - dvv[u]);    // dS[q, key]
+          s[r] = p * ((keep ? dp[r] * ik : 0.f) - dvv[e]);        // dS[q, key]
         }
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         float v[8], w[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { v[u] = pd[8 * s2 + u]; w[u] = s[8 * s2 + u]; }
+        for (int e = 0; e < 8; ++e) { v[e] = pd[8 * s2 + e]; w[e] = s[8 * s2 + e]; }
         bf16x8 ph, pl, dh, dl;
         split8(v, ph, pl);
         split8(w, dh, dl);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-          const bf16x8 gh = frag_tr(sG, 32 * t + 16 * s2 + 4 * half, 32 * dt, lane);
-          const bf16x8 gl = frag_tr(sG + AT_PLANE, 32 * t + 16 * s2 + 4 * half, 32 * dt, lane);
-          MFMA3(dv[dt], gh, gl, ph, pl);                     // dV^T[d, key] += dO^T[d, q] . Pd[q, key]
-          const bf16x8 qh = frag_tr(sQ, 32 * t + 16 * s2 + 4 * half, 32 * dt, lane);
-          const bf16x8 ql = frag_tr(sQ + AT_PLANE, 32 * t + 16 * s2 + 4 * half, 32 * dt, lane);
-          MFMA3(dk[dt], qh, ql, dh, dl);                     // dK^T[d, key] += Q'^T[d, q] . dS[q, key]
+          const bf16x8 gh = frag_tr(sG, 32 * u + 16 * s2 + 4 * half, dt, lane);
+          const bf16x8 gl = frag_tr(sG + AT_PLANE_B, 32 * u + 16 * s2 + 4 * half, dt, lane);
+          const bf16x8 qh = frag_tr(sQ, 32 * u + 16 * s2 + 4 * half, dt, lane);
+          const bf16x8 ql = frag_tr(sQ + AT_PLANE_B, 32 * u + 16 * s2 + 4 * half, dt, lane);
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl, ph, dv[dt], 0, 0, 0);     // dV^T[d, key] += dO^T[d, q] . Pd[q, key]
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ql, dh, dk[dt], 0, 0, 0);     // dK^T[d, key] += Q^T[d, q] . dS[q, key]
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, pl, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh, dl, dk[dt], 0, 0, 0);
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, ph, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh, dh, dk[dt], 0, 0, 0);
         }
       }
     }
+    if (t + 1 < T) {
+      if (t + 2 < T) at_wait_vmcnt<AT_PPW>(); else at_wait_vmcnt<0>();      // tile t + 1 and its side data (requested before tile t + 2)
+      aux_store(t + 1);
+      at_barrier();
+    }
   }
   if (kok) {
-    // Q' carries scale * log2(e): dK = scale * dS^T Q = (dS^T Q') * ln 2
-    const float ln2 = 0.693147180559945309f;
-    float* const krow = a.dqkv + (row0 + key) * a.ldq + D + h * HD;
+    float* const krow = a.dqkv + (row0 + key) * ldq + D + h * HD;
     float* const vrow = krow + D;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -552,8 +683,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
       for (int rg = 0; rg < 4; ++rg) {
         const int d = 32 * dt + 8 * rg + 4 * half;
         if (d < HD) {
-          *reinterpret_cast<float4*>(krow + d) =
-              make_float4(dk[dt][4 * rg] * ln2, dk[dt][4 * rg + 1] * ln2, dk[dt][4 * rg + 2] * ln2, dk[dt][4 * rg + 3] * ln2);
+          *reinterpret_cast<float4*>(krow + d) = make_float4(dk[dt][4 * rg] * a.scale, dk[dt][4 * rg + 1] * a.scale,
+                                                             dk[dt][4 * rg + 2] * a.scale, dk[dt][4 * rg + 3] * a.scale);
           *reinterpret_cast<float4*>(vrow + d) = make_float4(dv[dt][4 * rg], dv[dt][4 * rg + 1], dv[dt][4 * rg + 2], dv[dt][4 * rg + 3]);
         }
       }
@@ -561,19 +692,25 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 }
 
 // D[row, h] = sum_d dO[row, h*HD + d] * O[row, h*HD + d]   (the softmax backward's row constant; holds with dropout, since
-// sum_j dP_j P_j = sum_j dPd_j Pd_j = dO . O)
+// sum_j dP_j P_j = sum_j dPd_j Pd_j = dO . O), and the bf16x3 operand planes of dO for the two gradient kernels, in one pass
 template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const float* __restrict__ dout, const float* __restrict__ out,
-                                                            int64_t n /* rows * H */, float* __restrict__ dsum) {
+                                                            int64_t n /* rows * H */, float* __restrict__ dsum,
+                                                            bf16raw* __restrict__ g_hi, bf16raw* __restrict__ g_lo) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n) return;
   const float4* a = reinterpret_cast<const float4*>(dout + idx * HD);
   const float4* b = reinterpret_cast<const float4*>(out + idx * HD);
+  uint2* gh = reinterpret_cast<uint2*>(g_hi + idx * HD);
+  uint2* gl = reinterpret_cast<uint2*>(g_lo + idx * HD);
   float s = 0.f;
 #pragma unroll
-  for (int c = 0; c < HD / 4; ++c) {
-    const float4 x = a[c], y = b[c];
+  for (int cc = 0; cc < HD / 4; ++cc) {
+    const float4 x = a[cc], y = b[cc];
     s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    uint2 hh, ll;
+    split4(x, hh, ll);
+    gh[cc] = hh; gl[cc] = ll;
   }
   dsum[idx] = s;
 }
@@ -581,87 +718,94 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const float* __restr
 // =====================================================================================
 // C ABI
 // =====================================================================================
-static int attn_args(AttnArgs& a, const float* qkv, int64_t Ltot, int nhead, int head_dim, int nseg, const int64_t* ptr,
-                     int64_t max_len, float drop_p, const uint64_t* seed, uint64_t stream_id, const int64_t* rng_rowoff, int& nw) {
-  if (!qkv || Ltot <= 0 || nhead <= 0 || nseg <= 0 || max_len <= 0 || max_len > Ltot) return ADVMIL_EINVAL;
-  if (head_dim != 48) return ADVMIL_EINVAL;                 // the ESAT layer: d_model 384 / 8 heads (model/backbone.py:30-33)
+static int attn_args(AttnArgs& a, const void* qkv_hi, const void* qkv_lo, int64_t Ltot, int nhead, int head_dim, int nseg,
+                     const int64_t* ptr, int64_t max_len, float drop_p, const uint64_t* seed, uint64_t stream_id,
+                     const int64_t* rng_rowoff) {
+  if (!qkv_hi || !qkv_lo || Ltot <= 0 || nhead <= 0 || nseg <= 0 || max_len <= 0 || max_len > Ltot) return ADVMIL_EINVAL;
+  // d_model / 8 heads of any bcb_dims the reference accepts (model/backbone.py:30-33: 384 -> 48; 128 / 256 / 512 -> 16 / 32 / 64)
+  if (head_dim != 16 && head_dim != 32 && head_dim != 48 && head_dim != 64) return ADVMIL_EINVAL;
   if (nseg > 1 && !ptr) return ADVMIL_EINVAL;
   if (drop_p < 0.f || drop_p >= 1.f) return ADVMIL_EINVAL;
-  if ((uintptr_t)qkv & 15) return ADVMIL_EINVAL;
-  // 8-wave workgroups (256 stationary rows) when the bags are long enough to still fill the chip: half the streamed-panel re-reads
-  static const int force_nw = []() { const char* e = getenv("ADVMIL_ATTN_WAVES"); return e ? atoi(e) : 0; }();
-  nw = (force_nw == 4 || force_nw == 8) ? force_nw : ((max_len >= 1024 && (max_len / 256) * nseg * nhead >= 512) ? 8 : 4);
-  const int64_t ntile = (max_len + 32 * nw - 1) / (32 * nw);
+  if (((uintptr_t)qkv_hi & 15) || ((uintptr_t)qkv_lo & 15)) return ADVMIL_EINVAL;
+  const int64_t ntile = (max_len + AT_QB - 1) / AT_QB;
   if (ntile * nseg * nhead > 0x7fffffffLL) return ADVMIL_EINVAL;
-  a.qkv = qkv; a.ldq = 3 * (int64_t)nhead * head_dim;
-  a.out = nullptr; a.lse = nullptr; a.dout = nullptr; a.dsum = nullptr; a.dqkv = nullptr;
+  a.qkv_hi = (const bf16raw*)qkv_hi; a.qkv_lo = (const bf16raw*)qkv_lo; a.ldq = 3 * (int64_t)nhead * head_dim;
+  a.do_hi = nullptr; a.do_lo = nullptr;
+  a.out = nullptr; a.lse = nullptr; a.dsum = nullptr; a.dqkv = nullptr;
   a.ptr = ptr; a.rng_rowoff = rng_rowoff; a.Ltot = Ltot; a.nseg = nseg; a.ntile = (int)ntile; a.H = nhead;
   a.scale = 1.0f / sqrtf((float)head_dim);
   a.scale_log2e = a.scale * 1.44269504088896340736f;
   const bool drop = seed && drop_p > 0.f;
   a.seed = drop ? seed : nullptr;
   a.stream_id = stream_id;
-  a.drop_thr = drop ? (uint32_t)((double)drop_p * 65536.0) : 0u;
-  a.inv_keep = drop ? 1.0f / (1.0f - drop_p) : 1.0f;
+  a.drop_thr = drop ? (uint32_t)((double)drop_p * 256.0) : 0u;
+  a.inv_keep = drop ? 256.0f / (256.0f - (float)a.drop_thr) : 1.0f;
   return ADVMIL_OK;
 }
 
-extern "C" int advmil_mha_fwd(const float* qkv, int64_t Ltot, int nhead, int head_dim, int nseg, const int64_t* ptr,
-                              int64_t max_len, float drop_p, const uint64_t* seed, uint64_t stream_id,
+#define AT_LAUNCH(KERNEL, HD_, GRID, STREAM, ARGS)                                                              \
+  do {                                                                                                          \
+    if ((ARGS).seed) hipLaunchKernelGGL((KERNEL<HD_, true>), GRID, dim3(512), 0, STREAM, ARGS);                 \
+    else hipLaunchKernelGGL((KERNEL<HD_, false>), GRID, dim3(512), 0, STREAM, ARGS);                            \
+  } while (0)
+#define AT_DISPATCH(KERNEL, GRID, STREAM, ARGS, HD_RT)            \
+  do {                                                            \
+    switch (HD_RT) {                                              \
+      case 16: AT_LAUNCH(KERNEL, 16, GRID, STREAM, ARGS); break;  \
+      case 32: AT_LAUNCH(KERNEL, 32, GRID, STREAM, ARGS); break;  \
+      case 48: AT_LAUNCH(KERNEL, 48, GRID, STREAM, ARGS); break;  \
+      default: AT_LAUNCH(KERNEL, 64, GRID, STREAM, ARGS); break;  \
+    }                                                             \
+  } while (0)
+
+extern "C" int advmil_mha_fwd(const void* qkv_hi, const void* qkv_lo, int64_t Ltot, int nhead, int head_dim, int nseg,
+                              const int64_t* ptr, int64_t max_len, float drop_p, const uint64_t* seed, uint64_t stream_id,
                               const int64_t* rng_rowoff, float* out, float* lse, advmil_stream_t stream_) {
   AttnArgs a;
-  int nw = 4;
-  const int rc = attn_args(a, qkv, Ltot, nhead, head_dim, nseg, ptr, max_len, drop_p, seed, stream_id, rng_rowoff, nw);
+  const int rc = attn_args(a, qkv_hi, qkv_lo, Ltot, nhead, head_dim, nseg, ptr, max_len, drop_p, seed, stream_id, rng_rowoff);
   if (rc) return rc;
   if (!out || !lse || ((uintptr_t)out & 15)) return ADVMIL_EINVAL;
   a.out = out; a.lse = lse;
   const dim3 grid((unsigned)(a.ntile * nseg * nhead));
-  if (nw == 8) {
-    if (a.seed) hipLaunchKernelGGL((attn_fwd_kernel<48, true, 8>), grid, dim3(512), 0, (hipStream_t)stream_, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<48, false, 8>), grid, dim3(512), 0, (hipStream_t)stream_, a);
-  } else {
-    if (a.seed) hipLaunchKernelGGL((attn_fwd_kernel<48, true, 4>), grid, dim3(256), 0, (hipStream_t)stream_, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<48, false, 4>), grid, dim3(256), 0, (hipStream_t)stream_, a);
-  }
+  AT_DISPATCH(attn_fwd_kernel, grid, (hipStream_t)stream_, a, head_dim);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }
 
-extern "C" size_t advmil_mha_bwd_workspace_bytes(int64_t Ltot, int nhead) { return (size_t)Ltot * (size_t)nhead * sizeof(float); }
+// D [Ltot, nhead] fp32, then the two planes of dO [Ltot, nhead*head_dim] bf16 (each part 16-byte aligned)
+static size_t attn_ws_dsum_bytes(int64_t Ltot, int nhead) { return ((size_t)Ltot * (size_t)nhead * sizeof(float) + 15) / 16 * 16; }
+extern "C" size_t advmil_mha_bwd_workspace_bytes(int64_t Ltot, int nhead, int head_dim) {
+  return attn_ws_dsum_bytes(Ltot, nhead) + 2 * (((size_t)Ltot * (size_t)nhead * (size_t)head_dim * 2 + 15) / 16 * 16);
+}
 
-extern "C" int advmil_mha_bwd(const float* qkv, const float* out, const float* dout, const float* lse, int64_t Ltot, int nhead,
-                              int head_dim, int nseg, const int64_t* ptr, int64_t max_len, float drop_p, const uint64_t* seed,
-                              uint64_t stream_id, const int64_t* rng_rowoff, float* dqkv, void* ws, size_t ws_bytes,
-                              advmil_stream_t stream_) {
+extern "C" int advmil_mha_bwd(const void* qkv_hi, const void* qkv_lo, const float* out, const float* dout, const float* lse,
+                              int64_t Ltot, int nhead, int head_dim, int nseg, const int64_t* ptr, int64_t max_len, float drop_p,
+                              const uint64_t* seed, uint64_t stream_id, const int64_t* rng_rowoff, float* dqkv, void* ws,
+                              size_t ws_bytes, advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   AttnArgs a;
-  int nw = 4;
-  const int rc = attn_args(a, qkv, Ltot, nhead, head_dim, nseg, ptr, max_len, drop_p, seed, stream_id, rng_rowoff, nw);
+  const int rc = attn_args(a, qkv_hi, qkv_lo, Ltot, nhead, head_dim, nseg, ptr, max_len, drop_p, seed, stream_id, rng_rowoff);
   if (rc) return rc;
   if (!out || !dout || !lse || !dqkv || !ws) return ADVMIL_EINVAL;
   if (((uintptr_t)out & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 15) || ((uintptr_t)ws & 15)) return ADVMIL_EINVAL;
-  if (ws_bytes < advmil_mha_bwd_workspace_bytes(Ltot, nhead)) return ADVMIL_EWORKSPACE;
+  if (ws_bytes < advmil_mha_bwd_workspace_bytes(Ltot, nhead, head_dim)) return ADVMIL_EWORKSPACE;
   float* dsum = (float*)ws;
+  bf16raw* g_hi = (bf16raw*)((char*)ws + attn_ws_dsum_bytes(Ltot, nhead));
+  bf16raw* g_lo = (bf16raw*)((char*)g_hi + ((size_t)Ltot * (size_t)nhead * (size_t)head_dim * 2 + 15) / 16 * 16);
   const int64_t n = Ltot * nhead;
-  hipLaunchKernelGGL((attn_bwd_prep_kernel<48>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dout, out, n, dsum);
-  ADVMIL_LAUNCH_CHECK();
-  a.lse = const_cast<float*>(lse); a.dout = dout; a.dsum = dsum; a.dqkv = dqkv;
-  const dim3 grid((unsigned)(a.ntile * nseg * nhead));
-  if (nw == 8) {
-    if (a.seed) {
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<48, true, 8>), grid, dim3(512), 0, stream, a);
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<48, true, 8>), grid, dim3(512), 0, stream, a);
-    } else {
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<48, false, 8>), grid, dim3(512), 0, stream, a);
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<48, false, 8>), grid, dim3(512), 0, stream, a);
-    }
-  } else if (a.seed) {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<48, true, 4>), grid, dim3(256), 0, stream, a);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<48, true, 4>), grid, dim3(256), 0, stream, a);
-  } else {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<48, false, 4>), grid, dim3(256), 0, stream, a);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<48, false, 4>), grid, dim3(256), 0, stream, a);
+  const dim3 pg((unsigned)((n + 255) / 256));
+  switch (head_dim) {
+    case 16: hipLaunchKernelGGL((attn_bwd_prep_kernel<16>), pg, dim3(256), 0, stream, dout, out, n, dsum, g_hi, g_lo); break;
+    case 32: hipLaunchKernelGGL((attn_bwd_prep_kernel<32>), pg, dim3(256), 0, stream, dout, out, n, dsum, g_hi, g_lo); break;
+    case 48: hipLaunchKernelGGL((attn_bwd_prep_kernel<48>), pg, dim3(256), 0, stream, dout, out, n, dsum, g_hi, g_lo); break;
+    default: hipLaunchKernelGGL((attn_bwd_prep_kernel<64>), pg, dim3(256), 0, stream, dout, out, n, dsum, g_hi, g_lo); break;
   }
+  ADVMIL_LAUNCH_CHECK();
+  a.lse = const_cast<float*>(lse); a.do_hi = g_hi; a.do_lo = g_lo; a.dsum = dsum; a.dqkv = dqkv;
+  const dim3 grid((unsigned)(a.ntile * nseg * nhead));
+  AT_DISPATCH(attn_bwd_dq_kernel, grid, stream, a, head_dim);
+  ADVMIL_LAUNCH_CHECK();
+  AT_DISPATCH(attn_bwd_dkv_kernel, grid, stream, a, head_dim);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }

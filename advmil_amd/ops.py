@@ -998,54 +998,59 @@ def gate_scores(h, Wa, ba, Wb, bb, wc, bc, p=0.0, rng=None, tag=""):
 class MhaFn(torch.autograd.Function):
     """Self-attention core of the ESAT layer (nn.MultiheadAttention inside nn.TransformerEncoderLayer, reference
     model/backbone_utils.py:113-127): packed qkv[L_total, 3d] of a slab of bags (`seg`; None = one bag) -> O[L_total, d]; attention
-    never crosses a bag. ONE fused launch (advmil_mha_fwd: QK^T, online softmax, dropout, PV on the matrix pipe; no [H, L, L]
-    tensor exists), three for the backward (advmil_mha_bwd). Ragged bags and any bag length are handled inside the kernels."""
+    never crosses a bag. The kernels read qkv as its two bf16x3 operand planes (`planes`: emitted by the in-projection's epilogue,
+    else one advmil_split_planes pass here). ONE fused launch (advmil_mha_fwd: QK^T, online softmax, dropout, PV on the matrix
+    pipe; no [H, L, L] tensor exists), three for the backward (advmil_mha_bwd). Ragged bags and any bag length are handled inside
+    the kernels."""
 
     @staticmethod
-    def forward(ctx, qkv, nhead, p, seed, sid, seg, rowoff):
+    def forward(ctx, qkv, nhead, p, seed, sid, seg, rowoff, planes=None):
         _chk(qkv, "qkv")
         qkv = qkv.contiguous()
         Lt, d3 = qkv.shape
         d = d3 // 3
         hd = d // nhead
         dev = qkv.device
+        if planes is None:
+            planes = split_planes(qkv)
         out = torch.empty(Lt, d, dtype=torch.float32, device=dev)
         lse = torch.empty(Lt, nhead, dtype=torch.float32, device=dev)
         nseg = 1 if seg is None else seg.nseg
         mlen = Lt if seg is None else seg.max_len
         ptr = None if seg is None else seg.ptr
-        _lib.check(_lib.lib().advmil_mha_fwd(_p(qkv), Lt, nhead, hd, nseg, _p(ptr), mlen, p, _p(seed if p > 0.0 else None), sid,
-                                             _p(rowoff), _p(out), _p(lse), _stream()), "mha_fwd")
-        ctx.save_for_backward(qkv, out, lse)
+        _lib.check(_lib.lib().advmil_mha_fwd(_p(planes.hi), _p(planes.lo), Lt, nhead, hd, nseg, _p(ptr), mlen, p, _p(seed if p > 0.0 else None),
+                                             sid, _p(rowoff), _p(out), _p(lse), _stream()), "mha_fwd")
+        ctx.save_for_backward(planes.hi, planes.lo, out, lse)
         ctx.cfg = (nhead, hd, p, seed, sid, seg, rowoff)
         return out
 
     @staticmethod
     def backward(ctx, dO):
-        qkv, out, lse = ctx.saved_tensors
+        qhi, qlo, out, lse = ctx.saved_tensors
         nhead, hd, p, seed, sid, seg, rowoff = ctx.cfg
-        Lt = qkv.shape[0]
+        Lt = qhi.shape[0]
         L = _lib.lib()
         dO = dO.contiguous()
-        dqkv = torch.empty_like(qkv)
+        dqkv = torch.empty(qhi.shape, dtype=torch.float32, device=qhi.device)
         nseg = 1 if seg is None else seg.nseg
         mlen = Lt if seg is None else seg.max_len
         ptr = None if seg is None else seg.ptr
-        wsb = L.advmil_mha_bwd_workspace_bytes(Lt, nhead)
-        ws = _ws(wsb, qkv.device)
-        _lib.check(L.advmil_mha_bwd(_p(qkv), _p(out), _p(dO), _p(lse), Lt, nhead, hd, nseg, _p(ptr), mlen, p,
+        wsb = L.advmil_mha_bwd_workspace_bytes(Lt, nhead, hd)
+        ws = _ws(wsb, qhi.device)
+        _lib.check(L.advmil_mha_bwd(_p(qhi), _p(qlo), _p(out), _p(dO), _p(lse), Lt, nhead, hd, nseg, _p(ptr), mlen, p,
                                     _p(seed if p > 0.0 else None), sid, _p(rowoff), _p(dqkv), _p(ws), wsb, _stream()), "mha_bwd")
-        return dqkv, None, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None
 
 
 def mha(qkv, nhead, p=0.0, rng=None, seg=None, rowoff=None):
     """qkv[L_total, 3d]; `seg` (ops.Segments) partitions the rows into bags. `rowoff`: optional int64 device tensor [nseg] added
-    to each bag's local region rows to form the dropout stream's row ids (bag-parallel world-size invariance)."""
+    to each bag's local region rows to form the dropout stream's row ids (bag-parallel world-size invariance). Operand planes
+    attached to qkv by the producing contraction (`_advmil_planes`) are used as they are."""
     sid, seed = 0, None
     if p > 0.0:
         rng = rng or default_rng(qkv.device)
         sid, seed = rng.site("mha_attn", (qkv.shape[0], nhead), p), rng.seed
-    return MhaFn.apply(qkv, nhead, float(p), seed, sid, seg, rowoff)
+    return MhaFn.apply(qkv, nhead, float(p), seed, sid, seg, rowoff, getattr(qkv, "_advmil_planes", None) if qkv.is_contiguous() else None)
 
 
 class AddDropoutLayerNormFn(torch.autograd.Function):

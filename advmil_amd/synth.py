@@ -93,22 +93,26 @@ def rng_key(seed, stream) -> np.uint64:
 
 
 def attn_dropout_keep(seed, stream, row_ids, nhead, head, n_keys, p):
-    """Host restatement of the fused attention kernels' dropout decision (csrc/attn.hip::attn_keep): query with global region row
-    id r (row_ids, array), head `head`, key j in [0, n_keys) is kept iff the 16-bit half (j & 1) of
-        hash32(rowkey + (j >> 1) * 0x9E3779B9)  is  >= floor(p * 2^16),
-    rowkey = high 32 bits of splitmix64(key(seed, stream) + r*nhead + head),
-    hash32 = x ^= x >> 16; x *= 0x7feb352d; x ^= x >> 15; x *= 0x846ca68b; x ^= x >> 16.   -> bool [len(row_ids), n_keys]."""
+    """Host restatement of the fused attention kernels' dropout decision (csrc/attn.hip): query with global region row id r
+    (row_ids, array), head `head`, key j in [0, n_keys) is kept iff byte (j & 3) of
+        mix(rowkey + (j >> 2) * 0x9E3779B9)  is  >= floor(p * 256),      mix(x): x ^= x >> 15; x *= 0x7feb352d; x ^= x >> 15,
+    rowkey = high 32 bits of splitmix64(key(seed, stream) + r*nhead + head): one 32-bit hash per query and group of 4 keys.
+    -> bool [len(row_ids), n_keys]. The kernels scale the kept probabilities by 256 / (256 - floor(256 p))."""
     key = rng_key(seed, stream)
     with np.errstate(over="ignore"):
         rid = np.asarray(row_ids, dtype=np.uint64) * np.uint64(nhead) + np.uint64(head)
         rk = (splitmix64(np.uint64(key) + rid) >> np.uint64(32)).astype(np.uint32)
         j = np.arange(n_keys, dtype=np.uint32)
-        x = rk[:, None] + (j >> np.uint32(1))[None, :] * np.uint32(0x9E3779B9)
-        x ^= x >> np.uint32(16); x *= np.uint32(0x7FEB352D)
-        x ^= x >> np.uint32(15); x *= np.uint32(0x846CA68B)
-        x ^= x >> np.uint32(16)
-        half = (x >> ((j & np.uint32(1)) * np.uint32(16))[None, :]) & np.uint32(0xFFFF)
-    return half >= np.uint32(int(float(np.float32(p)) * 65536.0))
+        x = rk[:, None] + (j >> np.uint32(2))[None, :] * np.uint32(0x9E3779B9)
+        x ^= x >> np.uint32(15); x *= np.uint32(0x7FEB352D)
+        x ^= x >> np.uint32(15)
+        byte = (x >> ((j & np.uint32(3)) * np.uint32(8))[None, :]) & np.uint32(0xFF)
+    return byte >= np.uint32(int(float(np.float32(p)) * 256.0))
+
+
+def attn_dropout_scale(p):
+    """1 / (1 - p_eff) of the attention kernels: p quantised to 1/256."""
+    return 256.0 / (256.0 - int(float(np.float32(p)) * 256.0))
 
 
 def kernel_uniform(seed, stream, n, offset=0):

@@ -274,7 +274,7 @@ def attention_roofline(torch, ops, dev, L, bags, p=0.25, iters=20):
     us_b = event_time_us(torch, bwd, iters)
     ff, fb = 4.0 * L * L * d * bags, 10.0 * L * L * d * bags
     ach = (ff + fb) / (us_f + us_b) / 1e6
-    return {"bound": "mfma", "kernel": "attn_fwd_kernel<48,drop> + attn_bwd_dq_kernel + attn_bwd_dkv_kernel (csrc/attn.hip)",
+    return {"bound": "mfma", "kernel": "split_planes + attn_fwd_kernel<48,drop> + attn_bwd_prep + attn_bwd_dq_kernel + attn_bwd_dkv_kernel (csrc/attn.hip)",
             "tokens_per_bag": L, "bags": bags, "heads": nh, "head_dim": 48, "attn_dropout": p,
             "achieved": round(ach, 2), "peak": round(PEAK_BF16X3_TFLOPS, 1), "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16X3_TFLOPS, 4),
             "peak_note": "bf16x3: 3 bf16 MFMAs per fp32-equivalent product -> roof = dense bf16 MFMA peak / 3 in algorithmic flops",

@@ -140,26 +140,31 @@ int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, c
  * model/backbone_utils.py:113-127, reached from DualTrans_HS.forward, model/backbone.py:188-196; the reference runs one
  * call per bag, model_handler.py:352, batch_size 1):  O = dropout(softmax(Q K^T / sqrt(head_dim))) V  per (bag, head).
  * Flash-style: the [L, L] scores never exist in HBM; the backward recomputes them from `lse`.
- *   qkv  [Ltot, 3*nhead*head_dim]  packed in-projection output (q | k | v); head h of q at columns h*head_dim ...
+ *   qkv_hi / qkv_lo  [Ltot, 3*nhead*head_dim] bf16: the two bf16x3 operand planes (hi = bf16(x), lo = bf16(x - hi)) of the packed
+ *        in-projection output (q | k | v; head h of q at columns h*head_dim ...), as advmil_split_planes or a contraction's
+ *        c_hi / c_lo plane output produce them; 16-byte aligned, row pitch 3*nhead*head_dim. The kernels stream them into LDS by
+ *        LDS-DMA and never see the fp32 values.
  *   out  [Ltot, nhead*head_dim];  lse [Ltot, nhead] = log2-domain log-sum-exp of the scaled scores (opaque to the caller)
  *   Rows are a slab of `nseg` bags, bag b = rows [ptr[b], ptr[b+1]) (device int64; NULL = one bag), max_len = longest bag;
- *   attention never crosses a bag. Any bag length >= 1 (ragged tails are masked). head_dim must be 48 (d_model 384 / 8 heads,
- *   the only shape load_backbone builds: model/backbone.py:30-33).
- * Dropout on the probabilities (train mode; NULL seed or p == 0 = off): keep(i, j) = 16-bit half (j & 1) of
- *   hash32(rowkey + (j >> 1)*0x9E3779B9) >= floor(p*2^16)  (p quantised to 1/65536; 0.25 is exact),
+ *   attention never crosses a bag. Any bag length >= 1 (ragged tails are masked). head_dim in {16, 32, 48, 64}: d_model / 8 heads
+ *   of the bcb_dims load_backbone accepts (model/backbone.py:30-33; 384 -> 48 in the shipped config).
+ * Dropout on the probabilities (train mode; NULL seed or p == 0 = off): one 32-bit hash per (query, 4 consecutive keys),
+ *   keep(i, j) = byte (j & 3) of mix(rowkey + (j >> 2)*0x9E3779B9) >= floor(p*256),  mix(x): x ^= x >> 15; x *= 0x7feb352d; x ^= x >> 15
+ *   (p quantised to 1/256 -- 0.25 is exact --, kept probabilities scaled by 256 / (256 - floor(256 p))),
  *   rowkey = high 32 bits of splitmix64(key(seed, stream_id) + (ptr[b] + rng_rowoff[b] + i)*nhead + h); rng_rowoff (device int64
  *   [nseg], NULL = zeros) lets a rank of a bag-parallel job address the row ids the single-process run would use.
  *   Host restatement: advmil_amd/synth.py::attn_dropout_keep.
  * Arithmetic: split-bf16 ("bf16x3": hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate) in BOTH modes of
  *   advmil_set_gemm_mode -- ~2^-17 relative per product; softmax statistics and exponentials in fp32.
- * bwd: dqkv [Ltot, 3*nhead*head_dim] (every element written); ws >= advmil_mha_bwd_workspace_bytes. Deterministic (no atomics). */
-int advmil_mha_fwd(const float* qkv, int64_t Ltot, int nhead, int head_dim, int nseg, const int64_t* ptr, int64_t max_len,
-                   float drop_p, const uint64_t* seed, uint64_t stream_id, const int64_t* rng_rowoff, float* out, float* lse,
-                   advmil_stream_t stream);
-size_t advmil_mha_bwd_workspace_bytes(int64_t Ltot, int nhead);
-int advmil_mha_bwd(const float* qkv, const float* out, const float* dout, const float* lse, int64_t Ltot, int nhead, int head_dim,
-                   int nseg, const int64_t* ptr, int64_t max_len, float drop_p, const uint64_t* seed, uint64_t stream_id,
-                   const int64_t* rng_rowoff, float* dqkv, void* ws, size_t ws_bytes, advmil_stream_t stream);
+ * bwd: out / dout fp32 [Ltot, nhead*head_dim]; dqkv [Ltot, 3*nhead*head_dim] fp32 (every element written);
+ *   ws >= advmil_mha_bwd_workspace_bytes (holds D = rowsum(dO * O) and the operand planes of dO). Deterministic (no atomics). */
+int advmil_mha_fwd(const void* qkv_hi, const void* qkv_lo, int64_t Ltot, int nhead, int head_dim, int nseg, const int64_t* ptr,
+                   int64_t max_len, float drop_p, const uint64_t* seed, uint64_t stream_id, const int64_t* rng_rowoff, float* out,
+                   float* lse, advmil_stream_t stream);
+size_t advmil_mha_bwd_workspace_bytes(int64_t Ltot, int nhead, int head_dim);
+int advmil_mha_bwd(const void* qkv_hi, const void* qkv_lo, const float* out, const float* dout, const float* lse, int64_t Ltot,
+                   int nhead, int head_dim, int nseg, const int64_t* ptr, int64_t max_len, float drop_p, const uint64_t* seed,
+                   uint64_t stream_id, const int64_t* rng_rowoff, float* dqkv, void* ws, size_t ws_bytes, advmil_stream_t stream);
 /* Post-norm residual of the same layer (norm_first = False):  y = LayerNorm(x + dropout(o)) over rows of width d <= 512.
  * fwd also writes z = x + dropout(o), mean[R], rstd[R] for the backward; dropout element index = row*d + col on `stream_id`.
  * bwd: dx = LayerNorm'(dy); dob (may be NULL) = dx * keep; dgamma / dbeta = column sums (accumulate != 0 adds into them).

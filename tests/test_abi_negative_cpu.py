@@ -84,14 +84,16 @@ def test_pooling_group_checks_shapes_and_workspace(L):
 def test_attention_group_checks_head_dim_and_segments(L):
     lib = L.lib()
     p = lambda k: ctypes.c_void_p(A16 + (k << 20))   # noqa: E731
-    ok_hd = [hd for hd in (16, 32, 48, 64) if lib.advmil_mha_fwd(None, 0, 8, hd, 1, None, 0, 0.0, None, 0, None, None, None, None) == EINVAL]
-    assert ok_hd == [16, 32, 48, 64]                                            # (null-pointer rejection for all of them)
-    assert lib.advmil_mha_fwd(p(0), 512, 8, 40, 1, None, 512, 0.0, None, 0, None, p(1), p(2), None) == EINVAL            # head_dim % 16 != 0
-    assert lib.advmil_mha_fwd(p(0), 512, 8, 48, 4, None, 128, 0.0, None, 0, None, p(1), p(2), None) == EINVAL            # 4 bags, no offsets
-    assert lib.advmil_mha_fwd(p(0), 512, 8, 48, 1, None, 1024, 0.0, None, 0, None, p(1), p(2), None) == EINVAL           # max_len > rows
-    assert lib.advmil_mha_fwd(p(0), 512, 8, 48, 1, None, 512, 1.0, p(3), 0, None, p(1), p(2), None) == EINVAL            # p >= 1
-    need = lib.advmil_mha_bwd_workspace_bytes(512, 8)
-    assert lib.advmil_mha_bwd(p(0), p(1), p(2), p(3), 512, 8, 48, 1, None, 512, 0.0, None, 0, None, p(4), p(5), need - 4, None) == EWORKSPACE
+    fwd = lambda hd=48, Lt=512, nseg=1, mlen=512, pd=0.0, seed=None, hi=p(0): lib.advmil_mha_fwd(   # noqa: E731
+        hi, p(1), Lt, 8, hd, nseg, None, mlen, pd, seed, 0, None, p(2), p(3), None)
+    assert fwd(hd=40) == EINVAL and fwd(hd=96) == EINVAL                      # head_dim in {16, 32, 48, 64}
+    assert fwd(nseg=4, mlen=128) == EINVAL                                    # 4 bags, no offsets
+    assert fwd(mlen=1024) == EINVAL                                           # max_len > rows
+    assert fwd(pd=1.0, seed=p(4)) == EINVAL                                   # p >= 1
+    assert fwd(hi=ctypes.c_void_p(A16 + 8)) == EINVAL                         # planes are read in 16-byte units
+    need = lib.advmil_mha_bwd_workspace_bytes(512, 8, 48)
+    assert need >= 512 * 8 * 4 + 2 * 512 * 384 * 2
+    assert lib.advmil_mha_bwd(p(0), p(1), p(2), p(3), p(4), 512, 8, 48, 1, None, 512, 0.0, None, 0, None, p(5), p(6), need - 16, None) == EWORKSPACE
 
 
 def test_optimizer_graph_and_evaluator_groups(L):

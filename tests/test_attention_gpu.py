@@ -42,9 +42,10 @@ def relerr(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-def ref_attention(qkv, lens, masks=None):
-    """float64: per bag and head softmax(q k^T / sqrt(48)) (* mask) v on the packed [L_total, 3*384] rows."""
+def ref_attention(qkv, lens, masks=None, HD=HD):
+    """float64: per bag and head softmax(q k^T / sqrt(head_dim)) (* mask) v on the packed [L_total, 3*8*head_dim] rows."""
     outs, r0 = [], 0
+    D = NH * HD
     for b, L in enumerate(lens):
         blk = qkv[r0:r0 + L]
         q, k, v = (t.reshape(L, NH, HD).transpose(0, 1) for t in blk.split(D, dim=1))
@@ -90,6 +91,42 @@ def test_mha_fused_fwd_bwd_vs_float64(ops, mode, lens, p):
     # per-block relative error too (q | k | v gradients have different magnitudes)
     for c in range(3):
         assert relerr(a.grad[:, c * D:(c + 1) * D], r.grad[:, c * D:(c + 1) * D]) < 5e-5, c
+
+
+@pytest.mark.parametrize("hd", [16, 32, 64])
+def test_mha_other_head_dims(ops, hd):
+    """nn.TransformerEncoderLayer(d_model = bcb_dims[1], nhead = 8) for the other backbone widths the reference's load_backbone
+    accepts (model/backbone.py:30-33): d_model 128 / 256 / 512 -> head_dim 16 / 32 / 64, ragged bags, dropout on."""
+    lens, p, d = [130, 64, 300], 0.25, NH * hd
+    Lt = sum(lens)
+    qkv = rnd(f"hd{hd}", Lt, 3 * d, scale=0.7); go = rnd(f"hdg{hd}", Lt, d)
+    seg = ops.Segments(lens, DEV)
+    rng = ops.DeviceRng(DEV, seed=78)
+    rng.record = True
+    a = qkv.clone().to(DEV).requires_grad_(True)
+    o = ops.mha(a, NH, p, rng, seg=seg)
+    (o * go.to(DEV)).sum().backward()
+    (_, sid, _, _), = [e for e in rng.log if e[0] == "mha_attn"]
+    masks = host_masks(78, sid, lens, p)
+    r = qkv.clone().double().requires_grad_(True)
+    orf = ref_attention(r, lens, masks, HD=hd)
+    (orf * go.double()).sum().backward()
+    assert relerr(o, orf) < 1e-5, relerr(o, orf)
+    for c in range(3):
+        assert relerr(a.grad[:, c * d:(c + 1) * d], r.grad[:, c * d:(c + 1) * d]) < 5e-5, c
+
+
+def test_attention_dropout_statistics():
+    """The per-(query, 4 keys) byte hash of the attention dropout: keep rate, and no visible correlation along keys / queries."""
+    m = np.stack([synth.attn_dropout_keep(5, 9, np.arange(1024), NH, h, 2048, 0.25) for h in range(2)]).astype(np.float64)
+    assert abs(m.mean() - 0.75) < 1e-3
+    def corr(a, b):
+        a = a - a.mean(); b = b - b.mean()
+        return float((a * b).mean() / np.sqrt((a * a).mean() * (b * b).mean()))
+    for lag in (1, 2, 3, 4, 8, 64):
+        assert abs(corr(m[:, :, :-lag], m[:, :, lag:])) < 3e-3, lag
+    assert abs(corr(m[:, :-1], m[:, 1:])) < 3e-3 and abs(corr(m[0], m[1])) < 3e-3
+    assert abs(synth.attn_dropout_scale(0.25) - 1 / 0.75) < 1e-12
 
 
 def test_mha_forced_rescale_and_large_scores(ops):
@@ -141,7 +178,7 @@ def test_mha_slab_equals_per_bag_and_rowoff_replays_global_rows(ops):
 def test_mha_rejects_bad_args(ops):
     from advmil_amd._lib import AdvmilHipError
     with pytest.raises(AdvmilHipError):
-        ops.mha(torch.randn(64, 3 * 256, device=DEV), 8)          # head_dim 32: not the ESAT shape
+        ops.mha(torch.randn(64, 3 * 320, device=DEV), 8)          # head_dim 40: only 16 / 32 / 48 / 64 are built
     with pytest.raises(RuntimeError):
         ops.mha(torch.randn(64, 3 * D), 8)                         # CPU tensor: no fallback
 

@@ -144,8 +144,10 @@ def test_d_loss_gradients_before_adam(which):
             if w is None:
                 assert float(got.abs().max()) == 0.0, k
                 continue
-            scale = max(float(w.abs().max()), 1e-3)
-            assert float((got.cpu() - w).abs().max()) <= 2e-5 * scale, (which, k, float((got.cpu() - w).abs().max()), scale)
+            scale = float(w.abs().max())
+            # (+ 1e-7: gradients that are exactly 0 in exact arithmetic -- the logit's additive bias under hinge / wasserstein, 1 - 1 --
+            # come out as round-off on one side and as 0 on the other)
+            assert float((got.cpu() - w).abs().max()) <= 2e-5 * scale + 1e-7, (which, k, float((got.cpu() - w).abs().max()), scale)
 
 
 @pytest.mark.parametrize("over", [dict(disc_type="cat", disc_prj_path=None), dict(disc_prj_iprd="bag"), dict(disc_prj_path="y"),
