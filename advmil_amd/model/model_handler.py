@@ -376,7 +376,10 @@ class MyHandler(object):
         if (pls and all(p is not None for p in pls) and X.shape[0] >= 4096 and ops.USE_PLANES and ops.get_gemm_mode() == "bf16x3"
                 and ops.gemm_plan_planes(X.shape[0], 128, c)):
             # bags from the device-resident cache carry their operand planes: the step's planes are a row gather, not a re-split
-            X._advmil_planes = ops.Planes(torch.cat([p.hi for p in pls], dim=0), torch.cat([p.lo for p in pls], dim=0))
+            xpl = ops.Planes.alloc(tuple(X.shape), X.device)          # (one allocation for both planes: ops.Planes.alloc)
+            torch.cat([p.hi for p in pls], dim=0, out=xpl.hi)
+            torch.cat([p.lo for p in pls], dim=0, out=xpl.lo)
+            X._advmil_planes = xpl
         else:
             self._slab_planes(X, x0 if ok else None)
         return X

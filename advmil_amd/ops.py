@@ -205,8 +205,26 @@ class Planes:
     def __init__(self, hi, lo):
         self.hi, self.lo = hi, lo
 
+    # The two planes of a tensor live in ONE allocation, lo starting 64 KB behind the end of hi. Measured on the plane-fed two-layer
+    # launch (131072 x 512 x 1024, rocprofv3 FETCH_SIZE, tools/pmc_fetch_skew.sh): two separate allocations fetch 1 145 MB per launch
+    # for 539 MB of operands -- the hi and the lo stream of the same rows evict each other from L2 before the workgroup that shares
+    # the A panel has read them --, one allocation 690-750 MB (64 KB skew: 690), a row-interleaved [hi | lo] layout 778 MB. The
+    # launch time does not move (the kernel is not HBM-bound), the traffic does.
+    SKEW = 32768             # halfwords
+
+    @staticmethod
+    def alloc(shape, device):
+        n = 1
+        for v in shape:
+            n *= int(v)
+        pad = (-n) % 8
+        buf = torch.empty(2 * n + pad + Planes.SKEW, dtype=torch.bfloat16, device=device)
+        return Planes(buf[:n].view(*shape), buf[n + pad + Planes.SKEW:n + pad + Planes.SKEW + n].view(*shape))
+
     @staticmethod
     def empty_like(x):
+        if x.is_contiguous():
+            return Planes.alloc(tuple(x.shape), x.device)
         return Planes(torch.empty_strided(x.shape, x.stride(), dtype=torch.bfloat16, device=x.device),
                       torch.empty_strided(x.shape, x.stride(), dtype=torch.bfloat16, device=x.device))
 
@@ -375,7 +393,7 @@ def gemm_two_layers(x, xpl, W1, w1pl, b1, act1, W2, w2pl, b2, act2, emit_planes1
     y2 = torch.empty(M, N2, dtype=torch.float32, device=dev)
     cpl = None
     if emit_planes1:
-        cpl = Planes(torch.empty(M, N1, dtype=torch.bfloat16, device=dev), torch.empty(M, N1, dtype=torch.bfloat16, device=dev))
+        cpl = Planes.alloc((M, N1), dev)
     e = Epilogue()
     e.bias = None if b1 is None else b1.data_ptr()
     e.bias2 = None if b2 is None else b2.data_ptr()
@@ -651,12 +669,12 @@ class LinearActFn(torch.autograd.Function):
         cpl = None
         if y0 is None:
             if emit and get_gemm_mode() == "bf16x3":
-                cpl = Planes(torch.empty(M, N, dtype=torch.bfloat16, device=x.device), torch.empty(M, N, dtype=torch.bfloat16, device=x.device))
+                cpl = Planes.alloc((M, N), x.device)
             y = gemm(x, W2, True, True, M, N, K, bias=b, act0=act, drop_p=p, seed=seed, stream_id=sid, rng_row=rr,
                      a_planes=xpl, b_planes=wpl, c_planes=cpl, splits=1 if cpl is not None else None)
         elif p > 0.0:       # memoized act(x W^T + b) of the eval forward: only this forward's dropout draw is new
             if emit and MEMO_PLANES and get_gemm_mode() == "bf16x3":
-                cpl = Planes(torch.empty(M, N, dtype=torch.bfloat16, device=x.device), torch.empty(M, N, dtype=torch.bfloat16, device=x.device))
+                cpl = Planes.alloc((M, N), x.device)
             y, _ = act_dropout_bwd(y0, y0, ACT_NONE, M, N, p, seed, sid, want_bias=False, rng_row=rr, planes=cpl)
         else:
             y = y0
@@ -685,7 +703,7 @@ class LinearActFn(torch.autograd.Function):
             xpl0 = ctx.xpl if (DW_PLANES and get_gemm_mode() == "bf16x3") else None
             only = (DG_PLANES_ONLY and need_w and not need_x and xpl0 is not None and M >= 4096 and N % 8 == 0
                     and pre_a_tile_ok(gemm_plan(N, K, M, False, False)[0], False, False, True))
-            dpl = Planes(torch.empty(M, N, dtype=torch.bfloat16, device=dy.device), torch.empty(M, N, dtype=torch.bfloat16, device=dy.device)) if only else None
+            dpl = Planes.alloc((M, N), dy.device) if only else None
             dpre, db = act_dropout_bwd(dy, y, act, M, N, p, seed, sid, want_bias=need_b, db_out=ctx.gb if need_b else None, rng_row=rr,
                                        planes=dpl, planes_only=only)
             if only:
@@ -873,14 +891,14 @@ class GatedAttnPoolFn(torch.autograd.Function):
         gpl = None
         dh_nt = bool(need_h and USE_PLANES and DH_PLANES and get_gemm_mode() == "bf16x3" and gemm_plan_planes(N, D, 2 * D))
         if dh_nt:
-            gpl = Planes(torch.empty(N, 2 * D, dtype=torch.bfloat16, device=h.device), torch.empty(N, 2 * D, dtype=torch.bfloat16, device=h.device))
+            gpl = Planes.alloc((N, 2 * D), h.device)
         # bf16x3, slab-sized: dG is consumed by exactly two contractions (dh = dG Wab, dWab = dG^T h) that would split it into hi + lo
         # anyway -> the gate backward writes the planes INSTEAD of the fp32 values (same bytes) and both take their A operand pre-split
         only = (DG_PLANES_ONLY and USE_PLANES and get_gemm_mode() == "bf16x3" and N >= 4096 and (2 * D) % 8 == 0
                 and pre_a_tile_ok(gemm_plan(2 * D, D, N, False, False)[0], False, False)
                 and (not need_h or dh_nt or pre_a_tile_ok(gemm_plan(N, D, 2 * D, True, False)[0], True, False)))
         if only and gpl is None:
-            gpl = Planes(torch.empty(N, 2 * D, dtype=torch.bfloat16, device=h.device), torch.empty(N, 2 * D, dtype=torch.bfloat16, device=h.device))
+            gpl = Planes.alloc((N, 2 * D), h.device)
         if ctx.arena is not None:
             gWab, gbab, gwc, gbc = ctx.arena
             dG, _, _, _ = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb, dwc=gwc, dbc=gbc, dbias=gbab, rng_row=rr, planes=gpl, planes_only=only)
@@ -891,8 +909,8 @@ class GatedAttnPoolFn(torch.autograd.Function):
             # dG [N,2D] . Wab [2D,D]  +  A[n] * dpooled[bag(n), d]   (pooling's direct path, rank-1 per bag)
             if dh_nt:
                 WabT = Wab.t().contiguous()                                       # [D, 2D]: k (= 2D) contiguous
-                dh = gemm(dG, WabT, True, True, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg,
-                          a_planes=gpl, b_planes=split_planes(WabT))
+                dh = gemm(None if only else dG, WabT, True, True, N, D, 2 * D, rowv=A, colv=dpooled,
+                          rowseg=None if seg is None else seg.rowseg, a_planes=gpl, b_planes=split_planes(WabT))
             elif only:
                 dh = gemm(None, Wab, True, False, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg, a_planes=gpl)
             else:
@@ -1425,7 +1443,7 @@ def gate_interleave(Wa, ba, Wb, bb, D, planes=False):
     dev = Wa.device
     Wi = torch.empty(2 * D, D, dtype=torch.float32, device=dev)
     bi = torch.empty(2 * D, dtype=torch.float32, device=dev)
-    pl = Planes(torch.empty(2 * D, D, dtype=torch.bfloat16, device=dev), torch.empty(2 * D, D, dtype=torch.bfloat16, device=dev)) if planes else None
+    pl = Planes.alloc((2 * D, D), dev) if planes else None
     _lib.check(_lib.lib().advmil_gate_interleave(_p(Wa), _p(Wb), _p(ba), _p(bb), D, _p(Wi), _p(None if pl is None else pl.hi),
                                                  _p(None if pl is None else pl.lo), _p(bi), _stream()), "gate_interleave")
     return Wi, bi, pl
