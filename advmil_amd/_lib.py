@@ -45,6 +45,7 @@ SIGNATURES = {
     "advmil_gemm_f32_plan": (c_int, [c_int64, c_int64, c_int64, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "advmil_gemm_f32_plan_layout": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "advmil_gemm_f32_plan_planes": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, ctypes.POINTER(c_int)]),
+    "advmil_gemm_f32_plan_tn_planes": (c_int, [c_int64, c_int64, c_int64, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "advmil_gemm_f32_tiled": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                                       c_int64, ctypes.POINTER(Epilogue), c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "advmil_mha_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64, c_float, c_void_p, c_uint64,

@@ -192,6 +192,16 @@ def gemm_plan_planes(M, N, K, a_kc=True, b_kc=True):
     return _PLAN_CACHE[key]
 
 
+def gemm_plan_tn_planes(M, N, K):
+    """(tile, splits) of the plane-fed TN kernel (both operands [K, .] as Planes: deep-K weight gradients), or (0, 1)."""
+    key = ("tn", M, N, K, _lib.lib().advmil_get_gemm_mode())
+    if key not in _PLAN_CACHE:
+        t, sp = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(_lib.lib().advmil_gemm_f32_plan_tn_planes(M, N, K, ctypes.byref(t), ctypes.byref(sp)), "gemm_plan_tn_planes")
+        _PLAN_CACHE[key] = (t.value, sp.value)
+    return _PLAN_CACHE[key]
+
+
 def auto_splits(M, N, K):
     return gemm_plan(M, N, K)[1]
 
@@ -311,6 +321,12 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
             elif (gate_wc is None and N % 256 == 0 and (M // 256) * (N // 256) >= 384 and rowv is None and maskref is None
                   and not accumulate and (drop_p <= 0.0 or seed is None)):
                 tile = 85                                      # plain bias + activation (+ planes): the 256x256 form (9 % over 256x192)
+    if (tile == 0 and splits is None and a_planes is not None and b_planes is not None and not a_kc and not b_kc and gate_wc is None
+            and not ((a_planes.hi.data_ptr() | a_planes.lo.data_ptr() | b_planes.hi.data_ptr() | b_planes.lo.data_ptr()) & 15)
+            and a_planes.hi.stride(0) % 8 == 0 and b_planes.hi.stride(0) % 8 == 0):
+        ttile, tsplits = gemm_plan_tn_planes(M, N, K)          # both [K, .] operands pre-split: the plane-fed TN kernel, if the shape fits
+        if ttile:
+            tile, splits = ttile, tsplits
     if gate_wc is not None:
         # fused gate score (advmil_epilogue_t.gate_wc): B / bias hold the INTERLEAVED branches; returns per-row partial scores
         # [M, column blocks] instead of C
@@ -354,7 +370,7 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
         ptile, splits = gemm_plan(M, N, K, a_kc, b_kc)
         if tile == 0:
             tile = ptile
-    if planes_only_a and not (82 <= tile <= 85) and not pre_a_tile_ok(tile if tile else gemm_plan(M, N, K, a_kc, b_kc)[0], a_kc, b_kc,
+    if planes_only_a and not (82 <= tile <= 85) and not (91 <= tile <= 93) and not pre_a_tile_ok(tile if tile else gemm_plan(M, N, K, a_kc, b_kc)[0], a_kc, b_kc,
                                                                      b_planes is not None):       # (82-85: plane-fed, reads planes only)
         raise ValueError(f"gemm(A=None): tile {tile} has no pre-split-A instantiation for this layout")
     L = _lib.lib()
@@ -370,6 +386,7 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         name = ("gemm_nt_planes_kernel<%d>" % (tile - 80)) if 82 <= tile <= 84 else "gemm_nt_planes_kernel<4,plain>" if tile == 85 else \
+            ("gemm_tn_planes_kernel<%d>" % tile) if 91 <= tile <= 93 else \
             "gemm_f32_kernel<%d,%d,%d,%d>" % (bool(a_kc), bool(b_kc), tile // 10, tile % 10)
         prof.append((name, (M, N, K, splits), 2.0 * M * N * K, e0, e1))
     return gate_out if gate_wc is not None else out
@@ -865,6 +882,7 @@ class GatedAttnPoolFn(torch.autograd.Function):
         s = gate_score(ab, wcv, bc, N, D, p, seed, sa, sb, rr)
         A, pooled = softmax_pool(s, h, N, D, seg)
         ctx.save_for_backward(h, Wab, ab, A, wcv)
+        ctx.hpl = hpl                          # h's operand planes: B operand of dWab = dG^T h (with dG as planes: the plane-fed TN kernel)
         ctx.cfg = (p, seed, sa, sb, N, D, wc.shape, seg, rr)
         # fused weight-gradient accumulation needs every parameter's arena slot, with the a|b pairs adjacent
         gs = [_arena_grad(t) for t in (Wa, ba, Wb, bb, wc, bc)]
@@ -918,9 +936,11 @@ class GatedAttnPoolFn(torch.autograd.Function):
         nones = (None,) * 8
         apl = gpl if only else None
         if ctx.arena is not None:
-            gemm(dG, h, False, False, 2 * D, D, N, out=gWab, ldc=D, accumulate=True, a_planes=apl)       # dG^T h
+            bpl = ctx.hpl if (apl is not None and gemm_plan_tn_planes(2 * D, D, N)[0]) else None
+            gemm(dG, h, False, False, 2 * D, D, N, out=gWab, ldc=D, accumulate=True, a_planes=apl, b_planes=bpl)       # dG^T h
             return (dh, None, None, None, None, None, None) + nones
-        dWab = gemm(dG, h, False, False, 2 * D, D, N, a_planes=apl)
+        bpl = ctx.hpl if (apl is not None and gemm_plan_tn_planes(2 * D, D, N)[0]) else None
+        dWab = gemm(dG, h, False, False, 2 * D, D, N, a_planes=apl, b_planes=bpl)
         return (dh, dWab[:D], dbias[:D], dWab[D:], dbias[D:], dwc.reshape(wcshape), dbc) + nones
 
 

@@ -128,6 +128,11 @@ int advmil_gemm_f32_plan_layout(int a_kc, int b_kc, int64_t M, int64_t N, int64_
  * advmil_gemm_f32_gate_blocks and may pass 84 (256 x 256, instantiated for that mode only) when N % 256 == 0. Results are
  * bit-identical to the generic kernel's. */
 int advmil_gemm_f32_plan_planes(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, int* tile);
+/* TN form (A [K, M], B [K, N], both m-contiguous) with BOTH operands as planes -- the deep-K weight gradients dW = dY^T X over a
+ * step slab (torch's addmm backward of nn.Linear / the 1x1 Conv, reference model/backbone.py:60-66, backbone_utils.py:158-168):
+ * tile code (91 / 92 / 93 = 128x256 / 256x128 / 256x256, LDS-DMA fed split-K kernel) and split count to pass to
+ * advmil_gemm_f32_tiled, or *tile = 0 when the shape does not qualify (then the ordinary plan applies). */
+int advmil_gemm_f32_plan_tn_planes(int64_t M, int64_t N, int64_t K, int* tile, int* splits);
 /* Same, with an explicit block tile: tile = 10*TM + TN selects (64*TM) x (64*TN) output tiles
  * (22 = 128x128, 23 = 128x192, 13 = 64x192, 12 = 64x128, 11 = 64x64; 43 = 256x192, 42 = 256x128, 34 = 192x256, 24 = 128x256 with 512 threads,
  * bf16x3 mode only -- in exact mode they fall back to 23 / 22); 0 = the plan's choice (what advmil_gemm_f32 uses). */

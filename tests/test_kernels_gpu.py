@@ -257,6 +257,40 @@ def test_gemm_planes_bit_identical_to_on_the_fly_split(ops, a_kc, b_kc, shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(384, 1024, 32768), (768, 384, 16384), (128, 1024, 65536), (256, 256, 8192 + 96), (512, 256, 16384)])
+def test_gemm_tn_planes_kernel_bit_identical_to_generic(ops, M, N, K):
+    """The LDS-DMA fed TN contraction over two plane-held [K, .] operands (deep-K weight gradients, tile codes 91-93) against the
+    generic kernel with the same split count: every partial sum is accumulated in the same k order, so the results are EQUAL --
+    plain, and accumulated into an existing gradient (the arena form); and within 2e-5 of a float64 product."""
+    prev = ops.get_gemm_mode()
+    ops.set_gemm_mode("bf16x3")
+    try:
+        tile, sp = ops.gemm_plan_tn_planes(M, N, K)
+        planned = tile != 0
+        if not planned:                          # too few tiles for the plan to pick the kernel: drive the 256x256 form directly
+            assert M % 256 == 0 and N % 256 == 0
+            tile, sp = 93, 4
+        assert tile in (91, 92, 93) and sp >= 1, (tile, sp)
+        g = torch.Generator(device="cuda").manual_seed(11)
+        A = torch.randn(K, M, device="cuda", generator=g)
+        B = torch.randn(K, N, device="cuda", generator=g)
+        pa, pb = ops.split_planes(A), ops.split_planes(B)
+        ref = ops.gemm(A, B, False, False, M, N, K, tile=22, splits=sp, a_planes=pa, b_planes=pb)
+        got = ops.gemm(None, B, False, False, M, N, K, a_planes=pa, b_planes=pb, tile=tile, splits=sp)     # (A as planes only)
+        assert torch.equal(got, ref)
+        base = torch.randn(M, N, device="cuda", generator=g)
+        acc_ref, acc_got = base.clone(), base.clone()
+        ops.gemm(A, B, False, False, M, N, K, out=acc_ref, ldc=N, accumulate=True, tile=22, splits=sp, a_planes=pa, b_planes=pb)
+        ops.gemm(None, B, False, False, M, N, K, out=acc_got, ldc=N, accumulate=True, a_planes=pa, b_planes=pb,
+                 **({} if planned else dict(tile=tile, splits=sp)))                    # (planned shapes: the plan picks the kernel itself)
+        assert torch.equal(acc_got, acc_ref)
+        want = (A.double().t() @ B.double())
+        assert float((got.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())        # (bf16x3: ~2^-17 per product)
+    finally:
+        ops.set_gemm_mode(prev)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tile,N,K,R", [(34, 384, 1024, 8192), (34, 192, 264, 4104), (24, 128, 1024, 8192), (24, 136, 520, 4104)])
 @pytest.mark.parametrize("p", [0.0, 0.25])
 def test_weight_gradient_from_planes_only_activation_backward(ops, tile, N, K, R, p):
