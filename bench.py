@@ -559,9 +559,9 @@ def main():
                       f"us/launch={1e3 * v['ms'] / v['n']:.1f}  TF={v['flops'] * v['n'] / v['ms'] / 1e9:.0f}", file=sys.stderr)
         (kname, shape), top = max(agg.items(), key=lambda kv: kv[1]["ms"])
         M, N, K, sp = shape
-        planes_kernel = kname.startswith("gemm_nt_planes")
-        if planes_kernel:                     # NT form, both operands arrive as bf16 planes (hi, lo): the same 4 bytes per element
-            a_kc = b_kc = True
+        planes_kernel = kname.startswith("gemm_nt_planes") or kname.startswith("gemm_tn_planes")
+        if planes_kernel:                     # both operands arrive as bf16 planes (hi, lo): the same 4 bytes per element
+            a_kc = b_kc = kname.startswith("gemm_nt_planes")      # (TN form: both [K, .])
         else:
             a_kc, b_kc = kname.split("<")[1].startswith("1"), kname.split("<")[1].split(",")[1].startswith("1")
         A = torch.randn((M, K) if a_kc else (K, M), device=dev)
@@ -570,6 +570,8 @@ def main():
         kw = dict(a_planes=ops.split_planes(A), b_planes=ops.split_planes(B)) if planes_kernel else {}
         if not planes_kernel:
             kw["tile"] = int(kname.rstrip(">").split(",")[2]) * 10 + int(kname.rstrip(">").split(",")[3])
+        elif sp > 1:
+            kw["splits"] = sp
         us = event_time_us(torch, lambda: ops.gemm(A, B, a_kc, b_kc, M, N, K, out=out, **kw), 50)
         flops = 2.0 * M * N * K
         achieved = flops / us / 1e6

@@ -13,9 +13,9 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import prof_summary  # noqa: E402
 import csv  # noqa: E402
 
-SRC = os.path.join(ROOT, "gpurun_out", "prof_r02")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+SRC = os.path.join(ROOT, "gpurun_out", "prof_" + TAG)
 DST = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
 def newest(pattern):
@@ -49,7 +49,7 @@ def stats_avg(run):
     return out
 
 
-for run in ("bench_abmil", "bench_esat32k", "pool16", "pool1", "attn2048"):
+for run in ("bench_abmil", "bench_esat32k", "bench_patchgcn", "pool16", "pool1", "attn2048"):
     f = first(f"{run}/**/*kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(DST, f"{TAG}_{run}_kernel_stats.csv"))
@@ -106,8 +106,8 @@ if va:
 
 # ---- slab contractions: HBM traffic per launch + instruction mix, generic (on-the-fly split) and plane-fed kernels
 def kname(sym):
-    if sym.startswith("gemm_nt_planes_kernel"):
-        return "gemm_nt_planes_kernel<%s>" % sym[sym.index("<") + 1:sym.index(">")]
+    if sym.startswith("gemm_nt_planes_kernel") or sym.startswith("gemm_tn_planes_kernel"):
+        return sym[:sym.index("<")] + "<%s>" % sym[sym.index("<") + 1:sym.index(">")]
     t = sym[sym.index("<") + 1:sym.index(">")].split(", ")       # A_KC, B_KC, TM, TN, SPLIT, PRE, BKT, WR, WC
     return "gemm_f32_kernel<%d,%d,%s,%s>" % (t[0] == "true", t[1] == "true", int(t[2]) * (int(t[7]) // 2), int(t[3]) * (int(t[8]) // 2))
 
@@ -122,7 +122,7 @@ for shape in ("131072x768x384", "131072x384x1024", "131072x512x1024"):
         mb, ld = counter(f"{prefix}_{shape}_sq", "SQ_VALU_MFMA_BUSY_CYCLES"), counter(f"{prefix}_{shape}_sq", "SQ_INSTS_LDS")
         st = stats_avg(f"{prefix}_{shape}_stats")
         src = fe or va or {}
-        ks = [k for k in src if k.startswith("gemm_f32_kernel") or k.startswith("gemm_nt_planes_kernel")]
+        ks = [k for k in src if k.startswith("gemm_f32_kernel") or k.startswith("gemm_nt_planes_kernel") or k.startswith("gemm_tn_planes_kernel")]
         if not ks:
             continue
         k = max(ks, key=lambda n: src[n][0])
@@ -153,5 +153,5 @@ if launches or planes_launches:
                           "separate --pmc WRITE_SIZE, --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS and "
                           "--kernel-trace --stats passes (tools/profile_round.sh gemm)",
                "units": "KB counters; FETCH_SIZE x2 (gfx950 correction)", "launches": launches, "planes_kernel_launches": planes_launches},
-              open(os.path.join(DST, f"{TAG}_pmc_gemm.json"), "w"), indent=1)
+              open(os.path.join(DST, f"{TAG}_pmc_gemm_all.json"), "w"), indent=1)
 print(sorted(os.listdir(DST)))

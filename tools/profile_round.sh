@@ -1,10 +1,10 @@
 #!/bin/bash
-# rocprofv3 evidence for the numbers bench.py prints (run on the GPU box through gpurun; outputs under gpurun_out/prof_r02/).
+# rocprofv3 evidence for the numbers bench.py prints (run on the GPU box through gpurun; outputs under gpurun_out/prof_<round>/ (ROUND=r03 by default)).
 # Kernel-trace + stats runs and PMC runs are SEPARATE invocations (the pool refuses --pmc combined with API traces).
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-O=gpurun_out/prof_r02
+O=gpurun_out/prof_${ROUND:-r03}
 mkdir -p $O
 what="${1:-all}"
 if [ "$what" = all ] || [ "$what" = bench ]; then
@@ -29,6 +29,10 @@ if [ "$what" = all ] || [ "$what" = gemm ]; then
     ADVMIL_GEMM_MODE=bf16x3 rocprofv3 --kernel-trace --stats --output-format csv -d $O/gemm_${tag}_stats -- python3 tools/pmc_gemm.py $shape 1 1 12 > $O/gemm_${tag}_stats.log 2>&1
     ADVMIL_GEMM_MODE=bf16x3 rocprofv3 --kernel-trace --stats --output-format csv -d $O/gemmpl_${tag}_stats -- python3 tools/pmc_gemm.py $shape 1 1 12 1 > $O/gemmpl_${tag}_stats.log 2>&1
   done
+fi
+if [ "$what" = all ] || [ "$what" = graph ]; then
+  # PatchGCN (configs[4]'s backbone) at a size one GPU steps through: the step's kernels incl. genconv_fwd128 / genconv_bwd128
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_patchgcn -- python3 bench.py --mode graph --patches 4096 --pool 32 --steps 20 --no-extras --no-cpu-baseline > $O/bench_patchgcn.log 2>&1
 fi
 if [ "$what" = all ] || [ "$what" = attn ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/attn2048 -- python3 tools/attn_bench.py 2048 16 0.25 10 > $O/attn2048.log 2>&1
