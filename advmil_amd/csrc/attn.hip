@@ -640,9 +640,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
           const int r = 4 * rg + e;
           float p = pv[e];
           if (tail && qb + 32 * u + qo + e >= Lg) p = 0.f;       // queries past the bag (their lse slot holds 0)
-          const bool keep = !DROP || ((hx[e] >> kbyte) & 0xffu) >= a.drop_thr;
-          pd[r] = keep ? p * ik : 0.f;
-          s[r] = p * ((keep ? dp[r] * ik : 0.f) - dvv[e]);        // dS[q, key]
+          const float kf = (!DROP || ((hx[e] >> kbyte) & 0xffu) >= a.drop_thr) ? ik : 0.f;      // keep / (1 - p)
+          pd[r] = p * kf;
+          s[r] = p * fmaf(dp[r], kf, -dvv[e]);                    // dS[q, key]
         }
       }
 #pragma unroll

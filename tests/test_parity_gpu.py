@@ -385,6 +385,36 @@ def test_slab_features_equal_per_bag_features(kind):
     close(multi, single, 1e-5)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [128, 256, 512])
+def test_esat_other_backbone_widths_vs_oracle(d):
+    """load_backbone('patch', [1024, d, d]) for the other widths the reference accepts (nn.TransformerEncoderLayer(d_model = d,
+    nhead = 8): head_dim 16 / 32 / 64, model/backbone.py:30-33, backbone_utils.py:113-127): generator forward + every parameter
+    gradient against the oracle, dropout off, two ragged bags through the slab path."""
+    from types import SimpleNamespace
+    from advmil_amd.model import Generator, load_backbone
+    bb = load_backbone("patch", [1024, d, d])
+    g = Generator(d, 1, bb, SimpleNamespace(noise=[0, 1], hops=1, noise_dist="uniform"), False, 0.6, "sigmoid").to(DEV)
+    PG = load_synth(g, f"G-patch{d}:")
+    zero_dropout(g)
+    g.train()
+    x = H.bag(31, 1024, DEV)[:, :784].contiguous()                      # 49 regions: a ragged last key tile
+    nz = [H.noise_tensor("esatw", d, d // 2, DEV)]
+    pred = g(x, None, noise=nz)
+    pred.sum().backward()
+    Pr = {k: v.clone().requires_grad_(True) for k, v in PG.items()}
+    pr = O.generator(Pr, x.cpu(), None, "patch", (0, 1), [nz[0].cpu()], None, "sigmoid")
+    pr.sum().backward()
+    close(pred, pr)
+    for k, p in g.named_parameters():
+        want = Pr[k].grad
+        if want is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        scale = float(want.abs().max()) + 1e-12
+        assert float((p.grad.cpu() - want).abs().max()) <= 1e-4 * scale + 1e-8, (k, float((p.grad.cpu() - want).abs().max()), scale)
+
+
 def test_G1_patch_32768_eval_forward_vs_reference(golden2):
     """BASELINE.json configs[3] at its size: ESAT on one 32768-patch bag (2048 region tokens through the fused attention core),
     against the reference's own forward."""
