@@ -162,7 +162,7 @@ __device__ __forceinline__ void load_row_frags(const bf16raw* __restrict__ hi, c
 #define ACC_ROW(r, half) (((r) & 3) + 8 * ((r) >> 2) + 4 * (half))
 
 // The transposed fragments of the last MFMA row block read head dims up to 32 * DT - 1 >= HD: those units are never written by the
-// DMA. They are zeroed once (zero operands also cost the matrix pipe less power than whatever the LDS held before).
+// DMA. They are zeroed once (whatever the LDS held before may be NaN patterns; their products only reach discarded rows, but zeros are safer).
 template <int HD>
 __device__ __forceinline__ void zero_pad_units(unsigned char* smem, int nslots, int tid) {
   constexpr int UN = HD / 8, UP = 4 * ((HD + 31) / 32) - UN;       // data units, pad units per row
@@ -209,11 +209,11 @@ __device__ __forceinline__ void hw_exp2x4(float& a, float& b, float& c, float& d
   asm("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\tv_exp_f32 %2, %2\n\tv_exp_f32 %3, %3\n\ts_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 
-// Forward. Measured on the way here (tools/probe/stamp_attn.sh, rocprofv3 counters): with two waves per SIMD the kernel is bound by
-// instruction ISSUE, not by either pipe -- a wave issues one instruction per ~4.3 cycles, a tile costs it ~575 instructions next to 42
-// MFMAs, and an in-order wave that is waiting for the matrix pipe (busy with its partner's MFMA) issues nothing else. Three
-// structures (lockstep phases, anti-phase wave groups, in-wave software pipeline) all landed at 490-580 us for 16 x 2048 tokens.
-// What the SIMD needs is more waves to draw instructions from: this kernel keeps its live state under 128 VGPRs -- one 32-key
+// Forward. Measured on the way here (tools/probe/overlap_probe.hip, attn_model_probe.hip, stamp_attn.sh, rocprofv3 counters): on a
+// gfx950 SIMD the time of the matrix instructions and of the vector instructions ADDS (18 ns per MFMA + ~2 ns per VALU, x 0.8 at
+// best) whatever the schedule -- lockstep phases, anti-phase wave groups and an in-wave software pipeline all landed at 490-580 us for
+// 16 x 2048 tokens, and a tile costs 42 MFMAs plus ~450 VALU. The probe's best overlap is at 4 waves per SIMD, and more waves hide
+// the LDS / MFMA latencies without any scheduling effort: this kernel keeps its live state under 128 VGPRs -- one 32-key
 // half-tile at a time: S (16) -> P split (16) -> O (32), Q fragments (24) -- so that TWO workgroups (4 waves per SIMD) share a CU,
 // each with a double-buffered 64 KB ring; their barriers are independent, so one workgroup's softmax runs under the other's MFMAs.
 template <int HD, bool DROP>

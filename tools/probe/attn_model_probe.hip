@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256 * W) void model(const float* __restrict__ in, f
   if (PRIO == 2 && (wave >> 2) == 0) __builtin_amdgcn_s_setprio(1);
   __syncthreads();
   if (STAG) for (int d = 0; d < (wave >> 2) * (1400 / W); d += 64) __builtin_amdgcn_s_sleep(1);
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz, constant
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < iters; ++it) {
     if (PRIO == 1) __builtin_amdgcn_s_setprio(2);
@@ -53,16 +54,17 @@ __global__ __launch_bounds__(256 * W) void model(const float* __restrict__ in, f
     if (BAR && (it & 1)) __builtin_amdgcn_s_barrier();
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
   float acc = 0.f;
   for (int r = 0; r < 16; ++r) acc += s[r] + o0[r] + o1[r];
   out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
-  if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+  if (threadIdx.x == 0 && blockIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = r1 - r0; }
 }
 
 template <int W, int BAR, int STAG, int PRIO, int NVX>
 void run(const float* in, float* out, unsigned long long* cyc) {
   const int iters = 4000;
-  unsigned long long h;
+  unsigned long long h, hr[2];
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   hipLaunchKernelGGL((model<W, BAR, STAG, PRIO, NVX>), dim3(256), dim3(256 * W), 0, 0, in, out, 100, cyc);      // warm-up
@@ -73,10 +75,12 @@ void run(const float* in, float* out, unsigned long long* cyc) {
   hipError_t err = hipDeviceSynchronize();
   float ms = 0.f;
   hipEventElapsedTime(&ms, e0, e1);
-  hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+  hipMemcpy(hr, cyc, 16, hipMemcpyDeviceToHost);
+  h = hr[0];
+  const double ghz = (double)hr[0] / ((double)hr[1] * 10.0);          // s_memtime ticks per ns of s_memrealtime (100 MHz)
   const double per = (double)h / iters, ns_simd = 1e6 * ms / iters / W;      // wall ns per half-tile per SIMD (W waves share it)
-  printf("W=%d bar=%d stag=%d prio=%d VALU=%3d+12 : wave0 %7.1f ticks per half-tile; wall %7.1f ns per half-tile per SIMD-wave = %.2f of the matrix-pipe time (21 MFMA x 32 cyc @ 2.4 GHz = 280 ns)%s\n",
-         W, BAR, STAG, PRIO, 16 * NVX + 16, per, ns_simd, 280.0 / ns_simd, err == hipSuccess ? "" : "  LAUNCH ERROR");
+  printf("W=%d bar=%d stag=%d prio=%d VALU=%3d+12 : wave0 %7.1f ticks per half-tile; wall %7.1f ns per half-tile per SIMD-wave = %.2f of the matrix-pipe time (21 MFMA x 32 cyc @ 2.4 GHz = 280 ns); wave 0: %.0f ns by s_memrealtime, s_memtime / s_memrealtime = %.2f ticks per ns%s\n",
+         W, BAR, STAG, PRIO, 16 * NVX + 16, per, ns_simd, 280.0 / ns_simd, (double)hr[1] * 10.0 / iters, ghz, err == hipSuccess ? "" : "  LAUNCH ERROR");
 }
 
 int main() {

@@ -77,16 +77,32 @@ __global__ __launch_bounds__(256 * W) void probe(const float* __restrict__ in, f
   if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 
+template <typename F>
+static double wall_ns(F launch, int iters) {        // kernel wall time per round (hipEvents), ns
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  launch(50);
+  hipDeviceSynchronize();
+  hipEventRecord(e0, 0);
+  launch(iters);
+  hipEventRecord(e1, 0);
+  hipDeviceSynchronize();
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  return 1e6 * ms / iters;
+}
+
 template <int KIND, int W, int SPLIT>
 void run(const float* in, float* out, unsigned long long* cyc, const char* name) {
-  const int iters = 2000;
-  unsigned long long h[3];
-  hipLaunchKernelGGL((probe<KIND, true, false, W, SPLIT>), dim3(256), dim3(256 * W), 0, 0, in, out, iters, cyc); hipMemcpy(&h[0], cyc, 8, hipMemcpyDeviceToHost);
-  hipLaunchKernelGGL((probe<KIND, false, true, W, SPLIT>), dim3(256), dim3(256 * W), 0, 0, in, out, iters, cyc); hipMemcpy(&h[1], cyc, 8, hipMemcpyDeviceToHost);
-  hipLaunchKernelGGL((probe<KIND, true, true, W, SPLIT>), dim3(256), dim3(256 * W), 0, 0, in, out, iters, cyc); hipMemcpy(&h[2], cyc, 8, hipMemcpyDeviceToHost);
-  // per round: 4 MFMAs, 32 VALU per issuing wave
-  printf("%-22s W=%d split=%d : MFMA only %6.1f  VALU only %6.1f  both %6.1f cycles per round (4 MFMA = 128 pipe cycles per MFMA-issuing wave; 32 VALU per VALU-issuing wave)\n",
-         name, W, SPLIT, (double)h[0] / iters, (double)h[1] / iters, (double)h[2] / iters);
+  const int iters = 4000;
+  // WALL time of the whole kernel per round: every SIMD carries W waves, each round = 4 MFMAs and / or 32 VALU per issuing wave.
+  // (The cycle count a single wave reads back is NOT the SIMD's: the oldest wave is served first and sees little of its partners.)
+  const double m = wall_ns([&](int n) { hipLaunchKernelGGL((probe<KIND, true, false, W, SPLIT>), dim3(256), dim3(256 * W), 0, 0, in, out, n, cyc); }, iters);
+  const double v = wall_ns([&](int n) { hipLaunchKernelGGL((probe<KIND, false, true, W, SPLIT>), dim3(256), dim3(256 * W), 0, 0, in, out, n, cyc); }, iters);
+  const double b = wall_ns([&](int n) { hipLaunchKernelGGL((probe<KIND, true, true, W, SPLIT>), dim3(256), dim3(256 * W), 0, 0, in, out, n, cyc); }, iters);
+  const int wm = SPLIT ? W / 2 : W, wv = SPLIT ? W - W / 2 : W;          // waves per SIMD that issue MFMAs / VALU
+  printf("%-20s W=%d split=%d : wall per round  MFMA only %6.1f ns (%5.1f per MFMA)  VALU only %6.1f ns (%4.2f per VALU)  both %6.1f ns  = %.2f x (MFMA + VALU), %.2f x max\n",
+         name, W, SPLIT, m, m / (4.0 * wm), v, v / (32.0 * wv), b, b / (m + v), b / (m > v ? m : v));
 }
 
 int main() {
@@ -96,6 +112,7 @@ int main() {
   for (int i = 0; i < 1024; ++i) hin[i] = 0.5f + 0.0001f * (float)((i * 2654435761u) % 1000);
   hipMemcpy(in, hin, 4096, hipMemcpyHostToDevice);
   run<0, 1, 0>(in, out, cyc, "v_fma_f32");        run<0, 2, 0>(in, out, cyc, "v_fma_f32");        run<0, 2, 1>(in, out, cyc, "v_fma_f32");       run<0, 4, 0>(in, out, cyc, "v_fma_f32");
+  run<0, 4, 1>(in, out, cyc, "v_fma_f32");
   run<1, 1, 0>(in, out, cyc, "v_exp_f32");        run<1, 2, 0>(in, out, cyc, "v_exp_f32");        run<1, 2, 1>(in, out, cyc, "v_exp_f32");
   run<2, 1, 0>(in, out, cyc, "v_cndmask_b32");    run<2, 2, 0>(in, out, cyc, "v_cndmask_b32");
   run<3, 1, 0>(in, out, cyc, "v_cvt_pk_bf16_f32"); run<3, 2, 0>(in, out, cyc, "v_cvt_pk_bf16_f32");
