@@ -20,15 +20,17 @@ class SlabStager:
         self.dev = [None, None]
         self.free_evt = [None, None]      # recorded on the compute stream when the step reading pair k is enqueued
         self.h2d_evt = [None, None]       # recorded on the copy stream when pair k's H2D copies are all enqueued
+        self.pl = [None, None]            # operand planes of the device slabs (allocated when a cached bag brings its planes)
         self.k = 1
         self.rows = 0
         self.views = []
+        self.planes_rows = 0              # rows [0, planes_rows) of the current batch have their planes in self.pl[k]
 
     def _ensure(self, k, rows):
         cap = 0 if self.dev[k] is None else self.dev[k].shape[0]
         if rows <= cap:
             return
-        new_cap = max(rows, int(cap * 1.5), 1024)
+        new_cap = (max(rows, int(cap * 1.5), 1024) + 4095) // 4096 * 4096    # (whole 8 MB of plane rows: keeps the lo plane's 64 KB skew)
         host = torch.empty(new_cap, self.channels, dtype=self.dtype).pin_memory()
         dev = torch.empty(new_cap, self.channels, dtype=self.dtype, device=self.device)
         # the block comes from the COMPUTE stream's allocator pool: kernels already enqueued there may still be using it, and the
@@ -43,12 +45,29 @@ class SlabStager:
         self.host[k], self.dev[k] = host, dev
         self.views = [self.dev[k][a:b].unsqueeze(0) for a, b in self._spans]
 
+    def _ensure_planes(self, k):
+        """Plane slab of pair k, as many rows as its fp32 slab (one allocation, hi then lo: ops.Planes.alloc)."""
+        from . import ops
+        cap = self.dev[k].shape[0]
+        old = self.pl[k]
+        if old is not None and old.hi.shape[0] >= cap:
+            return
+        pl = ops.Planes.alloc((cap, self.channels), self.device)
+        self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))     # (same allocator-pool ordering as in _ensure)
+        pl.hi.record_stream(self.copy_stream)
+        if old is not None and self.planes_rows:                                 # grown in the middle of a batch
+            with torch.cuda.stream(self.copy_stream):
+                pl.hi[:self.planes_rows].copy_(old.hi[:self.planes_rows])
+                pl.lo[:self.planes_rows].copy_(old.lo[:self.planes_rows])
+        self.pl[k] = pl
+
     def begin(self):
         """Start staging a new step batch into the other buffer pair."""
         self.k ^= 1
         if self.h2d_evt[self.k] is not None:                     # the pinned slab / kept loader tensors of this pair may still be DMA sources
             self.h2d_evt[self.k].synchronize()
         self.rows = 0
+        self.planes_rows = 0
         self.views = []
         self._spans = []
         self._keep = []
@@ -76,6 +95,39 @@ class SlabStager:
             self.views.append(self.dev[k][a:b].unsqueeze(0))
         return self.views[-1]
 
+    def add_device(self, x_dev, planes=None, ready_evt=None):
+        """Stage one bag that is ALREADY in HBM (the device-resident bag cache): device-to-device copies of its fp32 rows -- and of
+        its operand planes, when it carries them -- into the slab on the copy stream, i.e. under the compute of the step before.
+        `ready_evt`: event recorded on the compute stream behind the kernels that produced the cached tensors."""
+        x2 = x_dev.reshape(-1, x_dev.shape[-1])
+        n = x2.shape[0]
+        k = self.k
+        self._spans.append((self.rows, self.rows + n))
+        self._ensure(k, self.rows + n)
+        a, b = self.rows, self.rows + n
+        if planes is not None and self.planes_rows == a:
+            self._ensure_planes(k)
+        if ready_evt is not None:
+            self.copy_stream.wait_event(ready_evt)
+        with torch.cuda.stream(self.copy_stream):
+            self.dev[k][a:b].copy_(x2, non_blocking=True)
+            if planes is not None and self.pl[k] is not None and self.planes_rows == a:
+                self.pl[k].hi[a:b].copy_(planes.hi.reshape(n, -1), non_blocking=True)
+                self.pl[k].lo[a:b].copy_(planes.lo.reshape(n, -1), non_blocking=True)
+                self.planes_rows = b
+        self._keep.append(x_dev)
+        self.rows = b
+        if len(self.views) < len(self._spans):
+            self.views.append(self.dev[k][a:b].unsqueeze(0))
+        return self.views[-1]
+
+    def batch_planes(self):
+        """Operand planes of the whole staged batch (rows [0, rows)), when every bag brought its own; else None."""
+        if self.rows and self.planes_rows == self.rows and self.pl[self.k] is not None:
+            from . import ops
+            return ops.Planes(self.pl[self.k].hi[:self.rows], self.pl[self.k].lo[:self.rows])
+        return None
+
     def ready(self):
         """Make the compute stream wait for the staged copies; returns the per-bag device views of this batch."""
         evt = torch.cuda.Event()
@@ -96,7 +148,8 @@ class BagCache:
     model/model_handler.py:315 / dataset/PatchWSI.py:65-83): the first time a bag (keyed by the loader's patient index) comes
     through the staging slab it is copied once more, device to device, into its own HBM allocation together with its bf16x3
     operand planes (the same 4 B per element again); from the second epoch on a step batch is assembled from the cached bags by
-    one row gather each for the fp32 rows and the two planes -- no PCIe traffic, no per-step split. 288 GB hold a whole NLST-sized
+    device-to-device copies of the fp32 rows and the two planes into the staging slab, issued on the copy stream while the step
+    before computes (SlabStager.add_device) -- no PCIe traffic, no per-step split, no gather on the compute stream. 288 GB hold a whole NLST-sized
     cohort (8 B per element: ~4 000 bags of 8192 patches). LRU under a byte budget; a bag that does not fit is simply not kept."""
 
     def __init__(self, device, budget_bytes, with_planes=True):
@@ -133,6 +186,8 @@ class BagCache:
         x = x_dev.clone()
         if planes:
             x._advmil_bag_planes = ops.split_planes(x.view(-1, x.shape[-1]))
+        x._advmil_ready = torch.cuda.Event()          # the copy stream that later reads this entry waits for it
+        x._advmil_ready.record(torch.cuda.current_stream(self.device))
         self.entries[key] = (x, nbytes)
         self.bytes += nbytes
 

@@ -208,19 +208,21 @@ class MyHandler(object):
             if torch.is_tensor(x0) and not x0.is_cuda and self.bcb != "graph":
                 key = int(data_idx.reshape(-1)[0]) if cache is not None else None
                 hit = cache.get(key) if cache is not None else None
-                if hit is not None:              # resident since an earlier epoch: no H2D for the bag
-                    data_x = [hit] + [dx.to(self.device, non_blocking=True) if torch.is_tensor(dx) else dx for dx in data_x[1:]]
+                if stager is None:
+                    stager = self.__dict__.setdefault("_stager", None) or SlabStager(self.device, x0.shape[-1])
+                    self._stager = stager
+                if not staged:
+                    stager.begin()
+                    staged = True
+                staged_pos.append(len(x_col))
+                if hit is not None:              # resident since an earlier epoch: no H2D; its rows (and operand planes) are copied into
+                    #                              the step slab device to device on the copy stream, under the previous step's compute
+                    v = stager.add_device(hit, getattr(hit, "_advmil_bag_planes", None), getattr(hit, "_advmil_ready", None))
                 else:
-                    if stager is None:
-                        stager = self.__dict__.setdefault("_stager", None) or SlabStager(self.device, x0.shape[-1])
-                        self._stager = stager
-                    if not staged:
-                        stager.begin()
-                        staged = True
                     if cache is not None:
                         fresh.append((key, len(x_col)))
-                    staged_pos.append(len(x_col))
-                    data_x = [stager.add(x0)] + [dx.to(self.device, non_blocking=True) if torch.is_tensor(dx) else dx for dx in data_x[1:]]
+                    v = stager.add(x0)
+                data_x = [v] + [dx.to(self.device, non_blocking=True) if torch.is_tensor(dx) else dx for dx in data_x[1:]]
             else:
                 data_x = [dx.to(self.device, non_blocking=True) if torch.is_tensor(dx) else dx for dx in data_x]
             data_y = data_y.to(self.device, non_blocking=True)
@@ -229,6 +231,9 @@ class MyHandler(object):
                 if staged:                               # growth may have re-based the views: take the final ones
                     for j, v in zip(staged_pos, stager.ready()):
                         x_col[j][0] = v
+                    bpl = stager.batch_planes()          # every bag came from the cache with its planes: the slab's planes are ready
+                    if bpl is not None and staged_pos:
+                        x_col[staged_pos[0]][0]._advmil_stager_planes = bpl
                 mask = self._get_label_visiable_mask(name_loader, i_col)
                 ys_host = None if any(h is None for h in yh_col) else yh_col
                 nz_d = nz_g = None
@@ -372,6 +377,11 @@ class MyHandler(object):
                 ptr += r * c * 4
         X = (x0.as_strided((sum(rows), c), (c, 1), x0.storage_offset()) if ok
              else torch.cat([x[0].reshape(-1, c) for x in xs], dim=0))
+        spl = getattr(x0, "_advmil_stager_planes", None) if ok else None
+        if (spl is not None and spl.hi.shape[0] == X.shape[0] and X.shape[0] >= 4096 and ops.USE_PLANES and ops.get_gemm_mode() == "bf16x3"
+                and ops.gemm_plan_planes(X.shape[0], 128, c)):
+            X._advmil_planes = spl               # assembled by the staging slab from the cached bags' planes (copy stream)
+            return X
         pls = None if ok else [getattr(x[0], "_advmil_bag_planes", None) for x in xs]
         if (pls and all(p is not None for p in pls) and X.shape[0] >= 4096 and ops.USE_PLANES and ops.get_gemm_mode() == "bf16x3"
                 and ops.gemm_plan_planes(X.shape[0], 128, c)):

@@ -385,7 +385,7 @@ def product_loop(args, torch, dev, case):
     cache = hh._bag_caches.get("train")
     out["epoch1_fill_cache"] = ent(d1, "same loop, device-resident bag cache on (default): first epoch = PCIe + one D2D copy + plane split per new bag")
     out["eager_resident_ragged"] = ent(d2, "same loop, second epoch: every bag served from the HBM cache (no PCIe); step slab + operand planes "
-                                           "assembled by row gathers; eager launches")
+                                           "assembled by D2D copies on the copy stream under the previous step; eager launches")
     out["eager_resident_ragged"]["cache"] = None if cache is None else cache.stats()
     del hh, hostpool, loader
     import gc
