@@ -48,3 +48,45 @@ def test_two_rank_step_equals_single_rank_with_dropout_on(kind, tmp_path):
             da, db = float((got[tag][k].double() - p0).norm()), float((want[tag][k].double() - p0).norm())
             assert abs(da - db) <= 5e-3 * db + 5e-5, (tag, k, da, db)
             assert float((got[tag][k].double() - want[tag][k].double()).abs().max()) <= 2.5 * 8e-5, (tag, k)
+
+
+_RCCL_PROBE = r"""
+import os, sys, torch, torch.distributed as dist
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % sys.argv[1], rank=0, world_size=1, device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl"
+from advmil_amd.parallel import BagParallel
+dp = BagParallel()
+g = torch.arange(912384, dtype=torch.float32, device="cuda")          # a flat gradient arena the size of G's (3.65 MB)
+want = g.clone()
+dist.all_reduce(g, op=dist.ReduceOp.SUM)                               # what allreduce_ issues at world > 1
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    w = dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True)        # what allreduce_async issues (D's overlapped exchange)
+w.wait()
+torch.cuda.current_stream().wait_stream(side)
+t = torch.tensor([3, 1, 4], dtype=torch.int64, device="cuda")
+outs = [torch.empty_like(t)]
+dist.all_gather(outs, t)
+dist.broadcast(g, src=0)
+dist.barrier()
+torch.cuda.synchronize()
+assert torch.equal(g, want) and outs[0].tolist() == [3, 1, 4]
+assert dp.enabled and dp.world == 1 and dp.local_step_bags(16) == 16
+dist.destroy_process_group()
+print("rccl-ok", torch.cuda.nccl.version())
+"""
+
+
+@pytest.mark.timeout(300)
+def test_rccl_communicator_comes_up_on_this_image(tmp_path):
+    """One GPU cannot hold two RCCL ranks (duplicate-device check), so the bag-parallel tests above run over gloo. This one brings
+    up the REAL backend (`nccl` = RCCL, dmabuf IPC mode as exported by the image) as a one-rank communicator and issues the
+    collectives the product path uses -- SUM all-reduce of an arena-sized buffer (sync, and async from a side stream), all-gather,
+    broadcast, barrier -- so a broken RCCL install / environment shows up here and not first in the driver's 8-GPU run."""
+    port = str(31300 + os.getpid() % 1500)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_PROBE, port], cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "rccl-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
