@@ -37,6 +37,7 @@ SIGNATURES = {
     "advmil_gemm_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                                 c_int64, ctypes.POINTER(Epilogue), c_int, c_void_p, c_size_t, c_void_p]),
     "advmil_split_planes": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "advmil_stage_bag": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "advmil_gate_interleave": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "advmil_gate_partial_sum": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
     "advmil_gemm_f32_gate_blocks": (c_int, [c_int, c_int64]),

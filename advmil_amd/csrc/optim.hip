@@ -81,6 +81,38 @@ extern "C" int advmil_abs_sum(const float* p, int64_t n, float* out, void* ws, s
   return ADVMIL_OK;
 }
 
+// Bag ingest out of the device-resident cache (advmil_amd/ingest.py::SlabStager.add_device; replaces the per-epoch `.cuda()` of
+// reference model/model_handler.py:315): up to three device-to-device range copies in ONE launch -- a cached bag's fp32 rows and its
+// two operand planes into their places in the step slab. blockIdx.y = range; 16-byte units, four loads in flight per thread.
+struct StageSpan { uint4* dst; const uint4* src; int64_t n16; };
+__global__ __launch_bounds__(256) void stage_bag_kernel(StageSpan a, StageSpan b, StageSpan c) {
+  const StageSpan sp = blockIdx.y == 0 ? a : (blockIdx.y == 1 ? b : c);
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < sp.n16; i += 4 * stride) {
+    const uint4 v0 = sp.src[i], v1 = sp.src[i + stride], v2 = sp.src[i + 2 * stride], v3 = sp.src[i + 3 * stride];
+    sp.dst[i] = v0; sp.dst[i + stride] = v1; sp.dst[i + 2 * stride] = v2; sp.dst[i + 3 * stride] = v3;
+  }
+  for (; i < sp.n16; i += stride) sp.dst[i] = sp.src[i];
+}
+extern "C" int advmil_stage_bag(void* dst_rows, const void* src_rows, size_t rows_bytes, void* dst_hi, const void* src_hi, void* dst_lo,
+                                const void* src_lo, size_t plane_bytes, advmil_stream_t stream_) {
+  if (!dst_rows || !src_rows || rows_bytes == 0 || (rows_bytes & 15)) return ADVMIL_EINVAL;
+  const bool planes = dst_hi || src_hi || dst_lo || src_lo || plane_bytes;
+  if (planes && (!dst_hi || !src_hi || !dst_lo || !src_lo || plane_bytes == 0 || (plane_bytes & 15))) return ADVMIL_EINVAL;
+  if (((uintptr_t)dst_rows | (uintptr_t)src_rows | (uintptr_t)dst_hi | (uintptr_t)src_hi | (uintptr_t)dst_lo | (uintptr_t)src_lo) & 15)
+    return ADVMIL_EINVAL;
+  StageSpan a{(uint4*)dst_rows, (const uint4*)src_rows, (int64_t)(rows_bytes >> 4)};
+  StageSpan b{(uint4*)dst_hi, (const uint4*)src_hi, planes ? (int64_t)(plane_bytes >> 4) : 0};
+  StageSpan c{(uint4*)dst_lo, (const uint4*)src_lo, planes ? (int64_t)(plane_bytes >> 4) : 0};
+  int64_t blocks = ((int64_t)(rows_bytes >> 4) + 1023) / 1024;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(stage_bag_kernel, dim3((unsigned)blocks, planes ? 3 : 1), dim3(256), 0, (hipStream_t)stream_, a, b, c);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}
+
 // rng_row (optional, with the row width `width`): element i of the flat tensor belongs to row i / width, whose draws are indexed
 // as row rng_row[i / width] -- the row it would occupy in the single-process run (bag-parallel world-size invariance)
 __device__ __forceinline__ uint64_t rng_flat_index(int64_t i, const int64_t* rng_row, int64_t width) {

@@ -161,6 +161,18 @@ class MyHandler(object):
         pids = self.patient_id[k]
         return [pids[i] for i in idxs.reshape(-1).tolist()]
 
+    @staticmethod
+    def _set_mode(net, training):
+        """net.train(training) without the recursive Module.train walk (4 walks per optimizer step x ~30 modules through
+        Module.__setattr__: 0.25-0.5 ms of host time per step): `training` is a plain attribute of every module."""
+        mods = net.__dict__.get("_advmil_modules")
+        if mods is None or net.__dict__.get("_advmil_modules_n") != sum(1 for _ in net.children()):
+            mods = list(net.modules())
+            net.__dict__["_advmil_modules"] = mods
+            net.__dict__["_advmil_modules_n"] = sum(1 for _ in net.children())
+        for m in mods:
+            m.__dict__["training"] = training
+
     def _get_label_visiable_mask(self, k, idxs):
         if "label_visible" not in self.patient_id:
             return None
@@ -217,17 +229,32 @@ class MyHandler(object):
                 staged_pos.append(len(x_col))
                 if hit is not None:              # resident since an earlier epoch: no H2D; its rows (and operand planes) are copied into
                     #                              the step slab device to device on the copy stream, under the previous step's compute
-                    v = stager.add_device(hit, getattr(hit, "_advmil_bag_planes", None), getattr(hit, "_advmil_ready", None))
+                    ev = hit.__dict__.get("_advmil_ready")
+                    v = stager.add_device(hit, hit.__dict__.get("_advmil_bag_planes"), ev)
+                    if ev is not None:           # the copy stream is now ordered behind the kernels that made this entry, for good
+                        hit._advmil_ready = None
                 else:
                     if cache is not None:
                         fresh.append((key, len(x_col)))
                     v = stager.add(x0)
-                data_x = [v] + [dx.to(self.device, non_blocking=True) if torch.is_tensor(dx) else dx for dx in data_x[1:]]
+                # (the second loader field is the cluster ids / graph of those two backbones; ABMIL and ESAT never read it, and a pageable
+                # host tensor's `.to()` is a host-synchronous copy that would throttle the launch queue to the device's pace)
+                ext_used = self.bcb in ("cluster", "graph")
+                data_x = [v] + [dx.to(self.device, non_blocking=True) if (ext_used and torch.is_tensor(dx)) else dx for dx in data_x[1:]]
             else:
                 data_x = [dx.to(self.device, non_blocking=True) if torch.is_tensor(dx) else dx for dx in data_x]
-            data_y = data_y.to(self.device, non_blocking=True)
             i_col.append(data_idx); x_col.append(data_x); y_col.append(data_y)
             if i_batch % bp_every_batch == 0:
+                ys_host = None if any(h is None for h in yh_col) else yh_col
+                if ys_host is not None and len({tuple(h.shape) for h in ys_host}) == 1 and ys_host[0].dim() == 2:
+                    # the step's labels in ONE pinned stack and one asynchronous copy (was: one tiny H2D per bag + two concatenations)
+                    y_pin = torch.empty(sum(h.shape[0] for h in ys_host), ys_host[0].shape[1], dtype=ys_host[0].dtype, pin_memory=True)
+                    torch.cat(ys_host, dim=0, out=y_pin)
+                    y_step = y_pin.to(self.device, non_blocking=True)
+                    y_col = list(y_step.split([h.shape[0] for h in ys_host], dim=0))
+                else:
+                    y_col = [y.to(self.device, non_blocking=True) for y in y_col]
+                    y_step = torch.cat(y_col, dim=0)
                 if staged:                               # growth may have re-based the views: take the final ones
                     for j, v in zip(staged_pos, stager.ready()):
                         x_col[j][0] = v
@@ -235,12 +262,11 @@ class MyHandler(object):
                     if bpl is not None and staged_pos:
                         x_col[staged_pos[0]][0]._advmil_stager_planes = bpl
                 mask = self._get_label_visiable_mask(name_loader, i_col)
-                ys_host = None if any(h is None for h in yh_col) else yh_col
                 nz_d = nz_g = None
                 if self.noise_hook is not None:
                     nz_d = [self.noise_hook("d", int(ix.reshape(-1)[0])) for ix in i_col]
                     nz_g = [self.noise_hook("g", int(ix.reshape(-1)[0])) for ix in i_col]
-                plan = self._plan(x_col, y_col, mode, mask, ys_host)      # ONE plan per step batch, shared by the D and G updates
+                plan = self._plan(x_col, y_col, mode, mask, ys_host, y_step)   # ONE plan per step batch, shared by the D and G updates
                 # bag-parallel: D's gradient exchange is started asynchronously and completed inside the first generator update, after
                 # the generator's backbone forward (which does not depend on D) has been enqueued -> the two overlap
                 overlap = self.dp.world > 1 and num_update_gen > 0
@@ -253,7 +279,7 @@ class MyHandler(object):
                 if staged:
                     stager.release()
                     staged = False
-                ys_all.append(torch.cat(y_col, dim=0)); yhat_all.append(torch.cat(preds, dim=0).detach())
+                ys_all.append(y_step); yhat_all.append(torch.cat(preds, dim=0).detach())
                 ffake_all.append(torch.cat(fakes, dim=0))
                 i_col, x_col, y_col, yh_col = [], [], [], []
         cltor = {"y": None, "y_hat": None, "f_fake": None}
@@ -291,7 +317,7 @@ class MyHandler(object):
             self._disc_apply()
         return preds, fakes
 
-    def _plan(self, xs, ys, mode, label_visible_mask, ys_host):
+    def _plan(self, xs, ys, mode, label_visible_mask, ys_host, y_stack=None):
         """Host-side facts of a step batch (built OUTSIDE HIP-graph capture): which bags feed a real pair / the supervised loss,
         the GLOBAL denominators of the reference's means, the row segments of the step slab and -- under bag-parallel -- the maps
         from this rank's rows to the rows of the single-process slab that index every dropout / noise draw. All device arrays are
@@ -324,7 +350,7 @@ class MyHandler(object):
         seg16.twice()                                    # (built here: the D update stacks its fake and real passes)
         seg16.rng_rowoff = rowoff16
         self._plan_count = getattr(self, "_plan_count", 0) + 1
-        y = torch.cat(ys, dim=0)
+        y = torch.cat(ys, dim=0) if y_stack is None else y_stack
         return SimpleNamespace(vis=vis, is_real=is_real, n_real=n_real, n_fake=n_fake, n_vis=n_vis, y=y,
                                y_t=y[:, 0:1].contiguous(), y_e=y[:, 1:2].contiguous(),     # label columns, contiguous once per plan
                                vis_mask=None if all(vis) else masks_d[n:], real_mask=masks_d[:n], seg=seg, seg16=seg16,
@@ -448,8 +474,8 @@ class MyHandler(object):
         """Capturable (no host sync, no collective): zero D grads, forward of the step slab, ONE backward of the D loss.
         All N-row / region-row kernels run once over the B bags' rows (segmented softmax-pool per bag); the [1,d]-sized
         heads and tails run once on [B,d] stacks."""
-        self.netD.train()
-        self.netG.eval()
+        self._set_mode(self.netD, True)
+        self._set_mode(self.netG, False)
         self.rng.rows = plan.rng_rows          # (cleared again below: the process-wide rng must not carry this step's maps)
         try:
             return self._disc_backward_body(i_batch, xs, ys, plan, noise)
@@ -491,7 +517,8 @@ class MyHandler(object):
             loss, st = ops.gan_d_loss_stacked(f2, len(xs), plan.real_mask, self.which_loss, plan.n_fake, plan.n_real, root=True)
         else:
             loss, st = ops.gan_d_loss(f_fake, None, None, self.which_loss, plan.n_fake, plan.n_real, root=True)
-        torch.autograd.backward(loss, grad_tensors=self._one())      # (the root gradient is a cached 1: no fill launch per step)
+        with torch.autograd.set_multithreading_enabled(False):       # backward on THIS thread (see _gen_finish)
+            torch.autograd.backward(loss, grad_tensors=self._one())  # (the root gradient is a cached 1: no fill launch per step)
         self._st_d = (st, plan, i_batch)     # this rank's partial sums over the global denominators; reduced + logged in _disc_apply
         preds = list(pred.split(1, dim=0))
         fakes = list(f_fake.detach().split(1, dim=0))
@@ -543,8 +570,8 @@ class MyHandler(object):
 
     def _gen_forward(self, xs, plan, noise=None):
         """The part of the generator update that does not depend on D: zero G grads, backbone + head forward (graph kept)."""
-        self.netD.eval()
-        self.netG.train()
+        self._set_mode(self.netD, False)
+        self._set_mode(self.netG, True)
         self.rng.rows = plan.rng_rows
         try:
             self._gen_forward_body(xs, plan, noise)
@@ -605,7 +632,11 @@ class MyHandler(object):
         rc = self._recon
         total, st = ops.gan_g_loss(pred, f_fake, plan.y_t, plan.y_e, plan.vis_mask, rc["alpha"], rc["gamma"], rc["norm"],
                                    self.coef_ganloss, plan.n_fake, n_vis, root=True)
-        torch.autograd.backward(total, grad_tensors=self._one())
+        # The engine would hand a CUDA graph to its device thread; every node of ours is a short Python function that only enqueues
+        # launches, so the hand-over and the GIL ping-pong cost more than they buy (host issue per eager step 2.9 -> 2.5 ms,
+        # tools/probe/eager_host_profile.py). Scoped: the caller's setting comes back on exit.
+        with torch.autograd.set_multithreading_enabled(False):
+            torch.autograd.backward(total, grad_tensors=self._one())
         if join is not None:
             # the generator's forward ran on the side stream, so autograd ran its backward nodes there too; the weight gradients
             # are added into the arena by raw kernels (no AccumulateGrad node -> the engine syncs nothing back): the optimizer step

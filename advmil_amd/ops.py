@@ -23,7 +23,15 @@ FUSED_GATE_SCORE = os.environ.get("ADVMIL_FUSED_GATE", "1") != "0"
 _ACT = {None: 0, "none": 0, "relu": 1, "tanh": 2, "sigmoid": 3}
 
 
+# torch.cuda.current_stream() builds a Stream object per call (2.8 us, tools/probe/host_call_cost.py); an eager step makes ~165
+# launches, each of which asks for the stream -> the raw handle straight from the C layer (0.2 us).
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    if _raw_stream is not None and _cur_device is not None:
+        return ctypes.c_void_p(_raw_stream(_cur_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -163,17 +171,29 @@ _PLAN_CACHE = {}
 
 def set_gemm_mode(mode):
     """'exact' (fp32 MFMA) or 'bf16x3' (split-bf16 on the bf16 matrix pipe, fp32 accumulate) for the fp32 engine."""
+    global _MODE_CODE
     code = {"exact": 0, "f32": 0, 0: 0, "bf16x3": 1, "split": 1, 1: 1}[mode]
     _lib.check(_lib.lib().advmil_set_gemm_mode(code), "set_gemm_mode")
+    _MODE_CODE = code
+
+
+_MODE_CODE = None            # mirror of the library's mode (set only through set_gemm_mode / the environment at load time)
+
+
+def _mode_code():
+    global _MODE_CODE
+    if _MODE_CODE is None:
+        _MODE_CODE = int(_lib.lib().advmil_get_gemm_mode())
+    return _MODE_CODE
 
 
 def get_gemm_mode():
-    return "bf16x3" if _lib.lib().advmil_get_gemm_mode() == 1 else "exact"
+    return "bf16x3" if _mode_code() == 1 else "exact"
 
 
 def gemm_plan(M, N, K, a_kc=True, b_kc=True):
     """(tile, splits) from the library's launch plan (advmil_gemm_f32_plan_layout); depends on the arithmetic mode."""
-    key = (M, N, K, bool(a_kc), bool(b_kc), _lib.lib().advmil_get_gemm_mode())
+    key = (M, N, K, bool(a_kc), bool(b_kc), _mode_code())
     if key not in _PLAN_CACHE:
         t, sp = ctypes.c_int(0), ctypes.c_int(0)
         _lib.check(_lib.lib().advmil_gemm_f32_plan_layout(1 if a_kc else 0, 1 if b_kc else 0, M, N, K, ctypes.byref(t),
@@ -184,7 +204,7 @@ def gemm_plan(M, N, K, a_kc=True, b_kc=True):
 
 def gemm_plan_planes(M, N, K, a_kc=True, b_kc=True):
     """Tile code (82 / 83) of the plane-fed LDS-DMA kernel for an NT contraction whose operands both come as Planes, or 0."""
-    key = ("pl", M, N, K, bool(a_kc), bool(b_kc), _lib.lib().advmil_get_gemm_mode())
+    key = ("pl", M, N, K, bool(a_kc), bool(b_kc), _mode_code())
     if key not in _PLAN_CACHE:
         t = ctypes.c_int(0)
         _lib.check(_lib.lib().advmil_gemm_f32_plan_planes(1 if a_kc else 0, 1 if b_kc else 0, M, N, K, ctypes.byref(t)), "gemm_plan_planes")
@@ -194,7 +214,7 @@ def gemm_plan_planes(M, N, K, a_kc=True, b_kc=True):
 
 def gemm_plan_tn_planes(M, N, K):
     """(tile, splits) of the plane-fed TN kernel (both operands [K, .] as Planes: deep-K weight gradients), or (0, 1)."""
-    key = ("tn", M, N, K, _lib.lib().advmil_get_gemm_mode())
+    key = ("tn", M, N, K, _mode_code())
     if key not in _PLAN_CACHE:
         t, sp = ctypes.c_int(0), ctypes.c_int(0)
         _lib.check(_lib.lib().advmil_gemm_f32_plan_tn_planes(M, N, K, ctypes.byref(t), ctypes.byref(sp)), "gemm_plan_tn_planes")
@@ -341,23 +361,34 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
         ldc = out.stride(0)
     lda = A.stride(0)
     ldb = B.stride(0)
-    e = Epilogue()
-    e.bias = None if bias is None else bias.data_ptr()
+    e = Epilogue()                            # zero-initialised: only the fields that differ are written (host time per launch)
+    if bias is not None:
+        e.bias = bias.data_ptr()
     e.act0 = act0
     e.act1 = act0 if act1 is None else act1
     e.act_split = (1 << 30) if act_split is None else act_split
-    e.drop_p = float(drop_p)
-    e.seed = None if (seed is None or drop_p <= 0.0) else seed.data_ptr()
-    e.stream_id = stream_id
-    e.rowv = None if rowv is None else rowv.data_ptr()
-    e.colv = None if colv is None else colv.data_ptr()
-    e.rowseg = None if rowseg is None else rowseg.data_ptr()
-    e.maskref = None if maskref is None else maskref.data_ptr()
-    e.ldmask = 0 if maskref is None else maskref.stride(0)
+    use_seed = seed is not None and drop_p > 0.0
+    if use_seed:
+        e.drop_p = float(drop_p)
+        e.seed = seed.data_ptr()
+        e.stream_id = stream_id
+        if rng_row is not None:
+            e.rng_row = rng_row.data_ptr()
+    elif drop_p:
+        e.drop_p = float(drop_p)
+    if rowv is not None:
+        e.rowv = rowv.data_ptr()
+    if colv is not None:
+        e.colv = colv.data_ptr()
+    if rowseg is not None:
+        e.rowseg = rowseg.data_ptr()
+    if maskref is not None:
+        e.maskref = maskref.data_ptr()
+        e.ldmask = maskref.stride(0)
     e.mask_scale = float(mask_scale)
-    e.accumulate = 1 if accumulate else 0
+    if accumulate:
+        e.accumulate = 1
     e.alpha = float(alpha)
-    e.rng_row = None if (rng_row is None or e.seed is None) else rng_row.data_ptr()
     if a_planes is not None:
         e.a_hi, e.a_lo = a_planes.hi.data_ptr(), a_planes.lo.data_ptr()
     if b_planes is not None:

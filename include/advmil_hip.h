@@ -279,6 +279,11 @@ int advmil_adam_step(float* p, const float* grad, float* m, float* v, const floa
 int advmil_abs_sum(const float* p, int64_t n, float* out, void* ws, size_t ws_bytes, advmil_stream_t stream);
 size_t advmil_abs_sum_workspace_bytes(int64_t n);
 
+/* Bag ingest from the device-resident bag cache (replaces the per-bag, per-epoch `.cuda()` of model/model_handler.py:315 for a bag
+ * that has been seen before): one launch copies rows_bytes of fp32 rows and, when the four plane pointers are given, plane_bytes of
+ * each bf16 operand plane, device to device, into the step slab. All pointers and sizes multiples of 16 bytes; planes all or none. */
+int advmil_stage_bag(void* dst_rows, const void* src_rows, size_t rows_bytes, void* dst_hi, const void* src_hi, void* dst_lo,
+                     const void* src_lo, size_t plane_bytes, advmil_stream_t stream);
 /* fill out[i] = U[0,1) from the counter RNG (generator noise, utils/func.py:154-164) */
 int advmil_uniform_fill(float* out, int64_t n, const uint64_t* seed, uint64_t stream_id, const int64_t* rng_row, int64_t width,
                         advmil_stream_t stream);

@@ -26,6 +26,23 @@ t_issue = time.perf_counter() - t0
 torch.cuda.synchronize()
 t_all = time.perf_counter() - t0
 print(f"eager: host issue {1e3 * t_issue / steps:.3f} ms per step, wall {1e3 * t_all / steps:.3f} ms per step")
+# pure host cost of the same launch sequence: tiny bags, so that the device is never the limit
+small = bench.Case(torch, dev, "abmil", 4096, 16, 16, "bf16x3", 1, eager=True) if os.environ.get("PROBE_SMALL", "1") == "1" else None
+if small is not None:
+    for mt in (True, False):
+        torch.autograd.set_multithreading_enabled(mt)
+        for _ in range(5):
+            small.eager_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            small.eager_step()
+        ti = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        ta = time.perf_counter() - t0
+        print(f"4096-patch bags, autograd multithreading {mt}: host issue {1e3 * ti / steps:.3f} ms per step, wall {1e3 * ta / steps:.3f}")
+    small.free()
+torch.autograd.set_multithreading_enabled(os.environ.get("PROBE_MT", "0") == "1")      # backward on THIS thread: cProfile sees it
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(steps):
