@@ -206,6 +206,118 @@ class BagCache:
         self.entries[key] = (x, nbytes)
         self.bytes += nbytes
 
+    def set_budget(self, budget_bytes):
+        """Change the byte budget (the last handler / evaluation to ask decides); evicts down to it at once."""
+        self.budget = int(budget_bytes)
+        while self.bytes > self.budget and self.entries:
+            _, (_, b) = self.entries.popitem(last=False)
+            self.bytes -= b
+            self.evictions += 1
+
+    def clear(self):
+        self.entries.clear()
+        self.bytes = 0
+
+    def drop_scope(self, scope):
+        """Forget every bag of one scope (its dataset object is gone)."""
+        for k in [k for k in self.entries if isinstance(k, tuple) and len(k) == 2 and k[0] == scope]:
+            self.bytes -= self.entries.pop(k)[1]
+
     def stats(self):
         return {"bags": len(self.entries), "gb": round(self.bytes / 1e9, 3), "hits": self.hits, "misses": self.misses,
                 "evictions": self.evictions}
+
+
+class BagCacheView:
+    """One loader's window onto the device's shared BagCache: keys are (scope, patient index), so the training loop, the
+    per-epoch validation / test passes (MyHandler.test_model) and the k-fold loaders of `exec_semi_sl` share ONE byte budget and
+    one LRU order instead of one budget each. Counts its own hits / misses."""
+
+    def __init__(self, cache, scope):
+        self.cache, self.scope = cache, scope
+        self.hits = self.misses = 0
+        self._ev0 = cache.evictions
+
+    def get(self, key):
+        x = self.cache.get((self.scope, key))
+        if x is None:
+            self.misses += 1
+        else:
+            self.hits += 1
+        return x
+
+    def put(self, key, x_dev):
+        self.cache.put((self.scope, key), x_dev)
+
+    def stats(self):
+        mine = [b for k, (_, b) in self.cache.entries.items() if isinstance(k, tuple) and len(k) == 2 and k[0] == self.scope]
+        return {"bags": len(mine), "gb": round(sum(mine) / 1e9, 3), "hits": self.hits, "misses": self.misses,
+                "evictions": self.cache.evictions - self._ev0}
+
+
+_DEVICE_CACHES = {}
+_DEVICE_STAGERS = {}
+_SCOPE_TOKENS = {}            # id(dataset) -> (weakref, token): a dataset object's identity for as long as it lives
+_NEXT_TOKEN = [0]
+
+
+def new_scope_token():
+    _NEXT_TOKEN[0] += 1
+    return _NEXT_TOKEN[0]
+
+
+def default_budget(device):
+    return 0.45 * torch.cuda.get_device_properties(torch.device(device)).total_memory
+
+
+def device_bag_cache(device, budget_bytes=None):
+    """THE bag cache of a device (created on first use). `budget_bytes`: None keeps the current budget (default_budget at
+    creation: 45 % of the device's memory); a handler passes its configured budget, the static evaluation pass never changes it."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    c = _DEVICE_CACHES.get(key)
+    if c is None:
+        if budget_bytes is None:
+            budget_bytes = default_budget(device)
+        c = _DEVICE_CACHES[key] = BagCache(device, budget_bytes)
+    elif budget_bytes is not None and int(budget_bytes) != c.budget:
+        c.set_budget(budget_bytes)
+    return c
+
+
+def device_stager(device, channels):
+    """The evaluation passes' staging slabs (one SlabStager per device and bag width; the training loop keeps its own)."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), int(channels))
+    st = _DEVICE_STAGERS.get(key)
+    if st is None:
+        st = _DEVICE_STAGERS[key] = SlabStager(device, channels)
+    return st
+
+
+def dataset_scope(loader):
+    """Cache scope of a loader's DATASET object -- `dataset[i]` is the same bag whichever DataLoader wraps it (the training loader
+    and a train-set evaluation share their bags); None when the loader has no such object; False when its bags must not be kept:
+    the reference's WSIPatch with `ratio_mask` draws a fresh random instance mask in every `__getitem__` (dataset/PatchWSI.py:73-74).
+    Dies with the dataset: a weak reference drops its bags from every device cache."""
+    import weakref
+    ds = getattr(loader, "dataset", None)
+    if ds is None:
+        return None
+    if getattr(ds, "ratio_mask", None):
+        return False                                  # never cache: every visit is a different bag
+    ent = _SCOPE_TOKENS.get(id(ds))
+    if ent is not None and ent[0]() is ds:
+        return ("ds", ent[1])
+    tok = new_scope_token()
+
+    def gone(_ref, _id=id(ds), _tok=tok):
+        _SCOPE_TOKENS.pop(_id, None)
+        for c in _DEVICE_CACHES.values():
+            c.drop_scope(("ds", _tok))
+    try:
+        ref = weakref.ref(ds, gone)
+    except TypeError:
+        return None
+    _SCOPE_TOKENS[id(ds)] = (ref, tok)
+    return ("ds", tok)

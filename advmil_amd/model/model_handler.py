@@ -209,7 +209,7 @@ class MyHandler(object):
         i_col, x_col, y_col, yh_col = [], [], [], []
         stager = None
         staged = False
-        cache = self._bag_cache_for(name_loader)
+        cache = self._bag_cache_for(name_loader, train_loader)
         fresh = []                               # (cache key, index into x_col) of the bags of this step that came over PCIe
         staged_pos = []                          # indices into x_col of the bags of this step that sit in the staging slab
         i_batch = 0
@@ -289,16 +289,22 @@ class MyHandler(object):
                                        "f_fake": gather(torch.cat(ffake_all)).cpu()})
         return cltor
 
-    def _bag_cache_for(self, name_loader):
-        """The device-resident bag cache of a loader (advmil_amd/ingest.py::BagCache), or None. Budget: cfg['bag_cache_gb'] /
-        ADVMIL_BAG_CACHE_GB (0 = off); default 45 % of the device's memory."""
+    def _bag_cache_for(self, name_loader, loader=None):
+        """This loader's view of the device-resident bag cache (advmil_amd/ingest.py::BagCache, ONE per device, shared with the
+        evaluation passes), or None. Budget: cfg['bag_cache_gb'] / ADVMIL_BAG_CACHE_GB (0 = off); default 45 % of the device's
+        memory. Scope of the keys: the loader's dataset object when it has one (DataLoader), else (this handler, name_loader)."""
+        from ..ingest import BagCacheView, dataset_scope, default_budget, device_bag_cache, new_scope_token
         caches = self.__dict__.setdefault("_bag_caches", {})
-        if name_loader not in caches:
+        scope = dataset_scope(loader) if loader is not None else None
+        if scope is None:
+            scope = ("h", self.__dict__.setdefault("_cache_token", new_scope_token()), name_loader)
+        scopes = self.__dict__.setdefault("_bag_cache_scopes", {})
+        if name_loader not in caches or scopes.get(name_loader) != scope:
+            view = None
             gb = os.environ.get("ADVMIL_BAG_CACHE_GB", self.cfg.get("bag_cache_gb"))
-            if gb is None:
-                gb = 0.45 * torch.cuda.get_device_properties(self.device).total_memory / 1e9
-            gb = float(gb)
-            caches[name_loader] = BagCache(self.device, gb * 1e9) if gb > 0 else None
+            if scope is not False and (gb is None or float(gb) > 0):
+                view = BagCacheView(device_bag_cache(self.device, default_budget(self.device) if gb is None else float(gb) * 1e9), scope)
+            caches[name_loader], scopes[name_loader] = view, scope
         return caches[name_loader]
 
     # ------------------------------------------------------------------------------------------
@@ -389,9 +395,13 @@ class MyHandler(object):
         return X
 
     def _slab_build(self, xs):
+        return MyHandler._slab_build_static(xs, getattr(self, "resident_planes", True))
+
+    @staticmethod
+    def _slab_build_static(xs, resident_planes=True):
         x0 = xs[0][0]
         c = x0.shape[-1]
-        rows = [self._rows(x[0]) for x in xs]
+        rows = [x[0].shape[-2] for x in xs]
         ok = all(x[0].is_contiguous() for x in xs)
         if ok:
             st = x0.untyped_storage().data_ptr()
@@ -417,10 +427,14 @@ class MyHandler(object):
             torch.cat([p.lo for p in pls], dim=0, out=xpl.lo)
             X._advmil_planes = xpl
         else:
-            self._slab_planes(X, x0 if ok else None)
+            MyHandler._slab_planes_static(X, x0 if ok else None, resident_planes)
         return X
 
     def _slab_planes(self, X, anchor):
+        MyHandler._slab_planes_static(X, anchor, getattr(self, "resident_planes", True))
+
+    @staticmethod
+    def _slab_planes_static(X, anchor, resident_planes=True):
         """bf16x3 mode: the slab's operand planes (hi = bf16(x), lo = bf16(x - hi); the same 4 bytes per element as the fp32 rows).
         Every contraction that reads X (the generator's and the discriminator's embedding FCs, twice per step each) then takes the
         plane-fed LDS-DMA kernel instead of re-splitting the rows in every workgroup. A resident slab (zero-copy view starting at
@@ -429,7 +443,7 @@ class MyHandler(object):
         (anchor None) is split per step."""
         if X.shape[0] < 4096 or not ops.USE_PLANES or ops.get_gemm_mode() != "bf16x3" or not ops.gemm_plan_planes(X.shape[0], 128, X.shape[1]):
             return                            # (small slabs: the plane-fed kernel's 256-row tiles would not fill the chip)
-        if anchor is None or not getattr(self, "resident_planes", True):
+        if anchor is None or not resident_planes:
             # (resident_planes = False: fp32-only residency -- the split is part of every step, also under HIP-graph replay)
             X._advmil_planes = ops.split_planes(X)
             return
@@ -451,16 +465,20 @@ class MyHandler(object):
         """The generator's eval forward and the discriminator's forward of the D update both start with a Linear over the step
         slab X (model/backbone.py:60-66 / backbone_utils.py:158-168; model_utils.py:130-140): ops.prefill_two_layers runs the two
         as one plane-fed launch. Layer lookup is by backbone kind; anything else simply takes the ordinary path."""
-        bb = self.netG.backbone
-        if self.bcb == "abmil" and hasattr(bb, "attention_net"):
+        return MyHandler._prefill_static(self.netG, self.netD, self.bcb, X)
+
+    @staticmethod
+    def _prefill_static(netG, netD, bcb, X):
+        bb = netG.backbone
+        if bcb == "abmil" and hasattr(bb, "attention_net"):
             fc = bb.attention_net[0]
             l1 = (fc.weight, fc.bias, "relu", True)
-        elif self.bcb == "patch" and hasattr(bb, "patch_embedding_layer") and hasattr(bb.patch_embedding_layer, "conv"):
+        elif bcb == "patch" and hasattr(bb, "patch_embedding_layer") and hasattr(bb.patch_embedding_layer, "conv"):
             cv = bb.patch_embedding_layer.conv
             l1 = (cv.weight, cv.bias, "none", False)
         else:
             return False
-        emb = getattr(getattr(self.netD, "net_pair_one", None), "embedding", None)
+        emb = getattr(getattr(netD, "net_pair_one", None), "embedding", None)
         if emb is None or not hasattr(emb, "conv"):
             return False
         return ops.prefill_two_layers(X, l1, (emb.conv.weight, emb.conv.bias, "none", False))
@@ -663,37 +681,122 @@ class MyHandler(object):
 
     # ------------------------------------------------------------------------------------------
     @staticmethod
-    def test_model(modelG, modelD, backbone, loader, times_test_sample=1, checkpoints=None, test_zero_noise=False, noise=None):
-        """Eval: y_hat, f_fake, and `times_test_sample` more generator samples + their median per bag.
-        In eval mode the backbone output is identical across the samples (only the head noise differs), so the
-        bag is embedded ONCE and the head is sampled times_test_sample+1 times (reference: that many full forwards,
-        model_handler.py:624-636). `noise`: optional per-bag list of injected noise tensors (tests)."""
+    def test_model(modelG, modelD, backbone, loader, times_test_sample=1, checkpoints=None, test_zero_noise=False, noise=None,
+                   batch_bags=None):
+        """Eval: y_hat, f_fake, and `times_test_sample` more generator samples + their median per bag (reference
+        model_handler.py:598-643: one synchronous `.cuda()`, 1 + times_test_sample full generator forwards, one D forward and
+        4-6 `.cpu()` syncs PER BAG -- and `_run_training` runs it over the validation and the test set after every epoch).
+        Here: in eval mode the backbone output is identical across the samples (only the head noise differs), so a bag is embedded
+        ONCE and the head sampled times_test_sample + 1 times; and `batch_bags` bags (default 16, ADVMIL_EVAL_BATCH_BAGS) go
+        through the generator and the discriminator as ONE step slab (the training step's slab kernels), staged through the pinned
+        double-buffered slab on the copy stream and kept in the device-resident bag cache across epochs (keyed by the loader's
+        dataset object and patient index, shared budget with the training loop). The collector comes back with one D2H per key.
+        PatchGCN bags, bags whose length is not a multiple of 16 and injected-noise calls with ragged lists take the per-bag path.
+        `noise`: optional per-bag list of injected noise tensors (tests)."""
         if checkpoints is not None:
             dev = next(modelG.parameters()).device
             modelG.load_state_dict(torch.load(checkpoints[0], map_location=dev)["model"])
             modelD.load_state_dict(torch.load(checkpoints[1], map_location=dev)["model"])
         modelG.eval(); modelD.eval()
         dev = next(modelG.parameters()).device
-        res = {"idx": None, "y": None, "y_hat": None, "f_fake": None}
+        nb_max = int(batch_bags if batch_bags is not None else os.environ.get("ADVMIL_EVAL_BATCH_BAGS", "16"))
+        keys = ["idx", "y", "y_hat", "f_fake"] + (["dist_y_hat", "avg_y_hat"] if times_test_sample > 1 else [])
+        parts = {k: [] for k in keys}                 # device (or host, for idx / y) pieces in loader order; ONE .cpu() per key at the end
+
+        def one_bag(b, idx, x, y):
+            x_data, x_ext = [t.to(dev) if torch.is_tensor(t) else t for t in x]
+            if backbone == "graph":
+                H = modelG.backbone(x_ext, None)
+            elif backbone == "patch":
+                H = modelG.backbone(x_data, None)
+            else:
+                H = modelG.backbone(x_data, x_ext)
+            it = iter(noise[b]) if noise is not None else None
+            y_hat = modelG.head(H, test_zero_noise, None if it is None else [next(it)])
+            parts["idx"].append(idx.detach()); parts["y"].append(y.detach())
+            parts["y_hat"].append(y_hat); parts["f_fake"].append(modelD(x_data, y_hat))
+            if times_test_sample > 1:
+                ys = torch.stack([modelG.head(H, test_zero_noise, None if it is None else [next(it)]) for _ in range(times_test_sample)])
+                parts["dist_y_hat"].append(ys.transpose(0, 1)); parts["avg_y_hat"].append(torch.median(ys, dim=0)[0])
+
+        def slab_batch(items, stager, fresh, cache):
+            """items: [(b, idx, [x view in the staging slab, ext], y)] -> the batch through the slab kernels."""
+            for j, v in enumerate(stager.ready()):
+                items[j][2][0] = v
+            bpl = stager.batch_planes()
+            if bpl is not None:
+                items[0][2][0]._advmil_stager_planes = bpl
+            xs = [it[2] for it in items]
+            X = MyHandler._slab_build_static(xs)
+            seg = ops.Segments([x[0].shape[-2] for x in xs], dev)
+            MyHandler._prefill_static(modelG, modelD, backbone, X)       # G's and D's first layers over the slab from one launch
+            exts = [x[1].to(dev) if torch.is_tensor(x[1]) else x[1] for x in xs] if backbone == "cluster" else None
+            feats = modelG.features_multi(X, seg, exts)                    # [B, d]: the bags are embedded ONCE
+            bb = modelG.backbone
+            H = bb.post(feats) if hasattr(bb, "post") else feats
+            nz = None
+            if noise is not None:                                          # per-bag [n0, n1, ...] -> per-call [B, w] stacks
+                nz = [torch.cat([noise[it[0]][c] for it in items], dim=0) for c in range(len(noise[items[0][0]]))]
+            y_hat = modelG.head(H, test_zero_noise, None if nz is None else [nz[0]])
+            emb = modelD.embed_rows(X)
+            eb, im = modelD.bag_features_multi(emb, seg.div(16))
+            f_fake = modelD.tail(eb, im, y_hat)
+            ops.PREFILL.clear()
+            parts["idx"].extend(it[1].detach() for it in items); parts["y"].extend(it[3].detach() for it in items)
+            parts["y_hat"].append(y_hat); parts["f_fake"].append(f_fake.reshape(len(items), -1))
+            if times_test_sample > 1:
+                ys = torch.stack([modelG.head(H, test_zero_noise, None if nz is None else [nz[1 + c]]) for c in range(times_test_sample)])
+                parts["dist_y_hat"].append(ys.transpose(0, 1)); parts["avg_y_hat"].append(torch.median(ys, dim=0)[0])
+            for key, j in fresh:                                           # first sight: keep the bag (and its operand planes) in HBM
+                cache.put(key, items[j][2][0])
+            stager.release()
+
+        from ..ingest import BagCacheView, dataset_scope, device_bag_cache, device_stager
+        scope = dataset_scope(loader)
+        gb = os.environ.get("ADVMIL_BAG_CACHE_GB")
+        cache = None
+        if scope and (gb is None or float(gb) > 0) and dev.type == "cuda":
+            cache = BagCacheView(device_bag_cache(dev, None if gb is None else float(gb) * 1e9), scope)
+        items, fresh, stager = [], [], None
+        nlen = None if noise is None else {len(nb) for nb in noise}
+
+        def flush():
+            nonlocal items, fresh
+            if items:
+                slab_batch(items, stager, fresh, cache)
+            items, fresh = [], []
+
         with torch.no_grad():
             for b, (idx, x, y) in enumerate(loader):
-                x_data, x_ext = [t.to(dev) if torch.is_tensor(t) else t for t in x]
-                if backbone == "graph":
-                    H = modelG.backbone(x_ext, None)
-                elif backbone == "patch":
-                    H = modelG.backbone(x_data, None)
+                x0 = x[0]
+                slab_ok = (nb_max > 1 and backbone != "graph" and torch.is_tensor(x0) and not x0.is_cuda and x0.dim() == 3
+                           and x0.shape[0] == 1 and x0.shape[1] % 16 == 0 and x0.shape[1] > 0 and x0.dtype == torch.float32
+                           and (nlen is None or len(nlen) == 1) and hasattr(modelG, "features_multi") and hasattr(modelD, "bag_features_multi"))
+                if not slab_ok:
+                    flush()
+                    one_bag(b, idx, x, y)
+                    continue
+                if stager is None:
+                    stager = device_stager(dev, x0.shape[-1])
+                if not items:
+                    stager.begin()
+                hit = cache.get(int(idx.reshape(-1)[0])) if cache is not None else None
+                if hit is not None:
+                    ev = hit.__dict__.get("_advmil_ready")
+                    v = stager.add_device(hit, hit.__dict__.get("_advmil_bag_planes"), ev)
+                    if ev is not None:
+                        hit._advmil_ready = None
                 else:
-                    H = modelG.backbone(x_data, x_ext)
-                it = iter(noise[b]) if noise is not None else None
-                y_hat = modelG.head(H, test_zero_noise, None if it is None else [next(it)])
-                f_fake = modelD(x_data, y_hat)
-                res = agg_tensor(res, {"idx": idx.detach().cpu(), "y": y.detach().cpu(), "y_hat": y_hat.detach().cpu(),
-                                       "f_fake": f_fake.detach().cpu()})
-                if times_test_sample > 1:
-                    ys = torch.stack([modelG.head(H, test_zero_noise, None if it is None else [next(it)])
-                                      for _ in range(times_test_sample)])
-                    res = agg_tensor(res, {"dist_y_hat": ys.transpose(0, 1).detach().cpu()})
-                    res = agg_tensor(res, {"avg_y_hat": torch.median(ys, dim=0)[0].detach().cpu()})
+                    if cache is not None:
+                        fresh.append((int(idx.reshape(-1)[0]), len(items)))
+                    v = stager.add(x0)
+                items.append((b, idx, [v, x[1]], y))
+                if len(items) == nb_max:
+                    flush()
+            flush()
+        res = {k: None for k in ("idx", "y", "y_hat", "f_fake")}
+        if parts["idx"]:
+            res = {k: torch.cat([t if t.dim() > 0 else t.reshape(1) for t in parts[k]], dim=0).detach().cpu() for k in keys}
         return res
 
     # ------------------------------------------------------------------------------------------

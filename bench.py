@@ -30,7 +30,9 @@ Prints ONE JSON line (rank 0). Extra objects:
                  two epochs of the same loader: epoch 1 through the staging slab (PCIe-inclusive), epoch 2 out of the
                  device-resident bag cache (no PCIe); plus `graph_resident_split_in_step` (graph replay with fp32-only residency:
                  the operand-plane split inside every step), so the gap between `value` and the product loop can be apportioned
-                 between PCIe, the per-step split and eager launch overhead.
+                 between PCIe, the per-step split and eager launch overhead; and `eval_loop`: the per-epoch evaluation
+                 (MyHandler.test_model, reference model_handler.py:278-285 / 598-643) per bag on pageable host bags (the reference's
+                 loop shape), batched over PCIe, and batched out of the bag cache.
   cpu_baseline : the oracle (pure PyTorch CPU restatement of the reference schedule, pinned against the
                  reference to <=1e-6) timed on this box's host cores over a bounded sample of the same workload.
 """
@@ -391,7 +393,56 @@ def product_loop(args, torch, dev, case):
     out["eager_resident_ragged"] = ent(d2, "same loop, second epoch: every bag served from the HBM cache (no PCIe); step slab + operand planes "
                                            "assembled by D2D copies on the copy stream under the previous step; eager launches")
     out["eager_resident_ragged"]["cache"] = None if cache is None else cache.stats()
+
+    # ---- the per-epoch evaluation (reference `_run_training`, model_handler.py:278-285: MyHandler.test_model over the validation and
+    # the test set after EVERY epoch, times_test_sample = 1; 598-643: one synchronous `.cuda()`, full forwards and 4 `.cpu()` syncs
+    # per bag). Same ragged pinned host bags behind a DataLoader-like object (the cache scope is its `.dataset`).
+    class _DS:
+        def __init__(self, items):
+            self.items = items
+
+    class _DL:
+        def __init__(self, ds):
+            self.dataset = ds
+
+        def __iter__(self):
+            return iter(self.dataset.items)
+
+    nev = min(len(loader), 8 * args.bags)
+    ev_items = loader[:nev]
+
+    def ev(ld, n, **kw):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        r = MyHandler.test_model(hh.netG, hh.netD, args.mode, ld, times_test_sample=1, **kw)
+        torch.cuda.synchronize()
+        assert r["y_hat"].shape[0] == n and bool(torch.isfinite(r["y_hat"]).all()), (r["y_hat"].shape, n)
+        return time.perf_counter() - t1
+
+    def eent(dte, path):
+        return {"value": round(nev / dte, 2), "unit": "bags/s", "bags": nev, "ms_per_bag": round(1e3 * dte / nev, 3), "path": path}
+
+    pageable = [(it[0], [it[1][0].clone(), it[1][1]], it[2]) for it in ev_items[:2 * args.bags]]        # what a default DataLoader hands over
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    MyHandler.test_model(hh.netG, hh.netD, args.mode, pageable, times_test_sample=1, batch_bags=1)
+    torch.cuda.synchronize()
+    d_ref = (time.perf_counter() - t1) / len(pageable) * nev
+    ev(ev_items[:2 * args.bags], 2 * args.bags)                                        # (warm the evaluation's own staging slabs)
+    dl = _DL(_DS(ev_items))
+    d_b1 = ev(dl, nev)
+    d_b2 = ev(dl, nev)
+    out["eval_loop"] = {
+        "per_bag_pageable": eent(d_ref, "MyHandler.test_model(batch_bags=1) on pageable host bags: the reference's loop shape -- synchronous copy, one "
+                                        "forward of G and D per bag (backbone once per bag), results fetched per epoch; timed on %d bags" % len(pageable)),
+        "batched_first_pass": eent(d_b1, "default: %d bags per slab through the training step's slab kernels, pinned staging slab on the copy stream; "
+                                         "first pass over this dataset = PCIe + fills the device-resident bag cache" % int(os.environ.get("ADVMIL_EVAL_BATCH_BAGS", "16"))),
+        "batched_resident": eent(d_b2, "same call, second pass (the next epoch's evaluation): every bag out of the HBM cache, no PCIe"),
+    }
+    del dl, pageable, ev_items
     del hh, hostpool, loader
+    from advmil_amd import ingest as _ingest
+    _ingest.device_bag_cache(dev).clear()
     import gc
     gc.collect(); torch.cuda.empty_cache()
     # graph replay with fp32-only residency: the bf16x3 operand planes of the slab are re-derived inside every step

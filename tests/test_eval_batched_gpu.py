@@ -1,0 +1,112 @@
+"""MyHandler.test_model (reference model_handler.py:598-643, run over the validation and the test set after every
+epoch by `_run_training`, 278-285): the batched evaluation -- `batch_bags` bags through the generator and the discriminator as one
+step slab, staged on the copy stream, kept in the device-resident bag cache across epochs -- against the per-bag evaluation
+(`batch_bags=1`, the reference's loop shape). The reference itself pins the per-bag numbers: golden G2 (tests/test_parity_gpu.py)."""
+import pytest
+import torch
+
+from advmil_amd import synth
+from tests import helpers as H
+from tests.test_parity_gpu import DEV, build_disc, build_generator, load_synth
+
+pytestmark = pytest.mark.gpu
+
+
+class Dataset:
+    """What a torch DataLoader shows the handler: iteration + a `.dataset` object (the cache scope)."""
+
+    def __init__(self, items, ratio_mask=None):
+        self.items, self.ratio_mask = items, ratio_mask
+
+
+class Loader:
+    def __init__(self, dataset, order=None):
+        self.dataset, self.order = dataset, order
+
+    def __iter__(self):
+        its = self.dataset.items
+        return iter(its if self.order is None else [its[i] for i in self.order])
+
+
+def make(kind, lens, start=40):
+    items = []
+    for i, n in enumerate(lens):
+        ext = H.T(synth.cluster_ids(0, start + i, n)) if kind == "cluster" else torch.zeros(1, 1)
+        items.append((torch.tensor([[i]], dtype=torch.int), [H.bag(start + i, max(lens))[:, :n].contiguous(), ext], H.label(start + i)))
+    return items
+
+
+def nets(kind, disc=("prj", "instance", "x")):
+    g, d = build_generator(kind), build_disc(*disc)
+    load_synth(g, f"G-{kind}:"); load_synth(d, "D-prj:" if disc[0] == "prj" else "D-cat:")
+    return g, d
+
+
+def same(a, b, tol=2e-6):
+    assert set(a) == set(b)
+    for k in a:
+        assert a[k].shape == b[k].shape and a[k].dtype == b[k].dtype and a[k].device.type == "cpu", (k, a[k].shape, b[k].shape)
+        assert float((a[k].double() - b[k].double()).abs().max()) <= tol * max(1.0, float(b[k].double().abs().max())), k
+
+
+@pytest.mark.parametrize("kind,disc", [("abmil", ("prj", "instance", "x")), ("patch", ("prj", "bag", "x")), ("cluster", ("cat", "bag", None))])
+def test_batched_eval_equals_per_bag_eval(kind, disc):
+    """Ragged bags, injected head noise (so both paths see the same draws), 7 samples per bag; batches of 3 with a remainder; one
+    bag that is already a device tensor drops to the per-bag path in the middle of the epoch (order and results unchanged)."""
+    from advmil_amd.model import MyHandler
+    g, d = nets(kind, disc)
+    lens = (256, 128, 512, 64, 192, 384, 320)
+    items = make(kind, lens)
+    items[4] = (items[4][0], [items[4][1][0].to(DEV), items[4][1][1]], items[4][2])
+    noises = [[H.noise_tensor(f"ev:{kind}:{i}", k, 192, DEV) for k in range(8)] for i in range(len(lens))]
+    per_bag = MyHandler.test_model(g, d, kind, items, times_test_sample=7, noise=noises, batch_bags=1)
+    batched = MyHandler.test_model(g, d, kind, items, times_test_sample=7, noise=noises, batch_bags=3)
+    same(batched, per_bag)
+    assert batched["idx"].reshape(-1).tolist() == list(range(len(lens))) and batched["dist_y_hat"].shape == (len(lens), 7, 1)
+    one = MyHandler.test_model(g, d, kind, items, times_test_sample=1, noise=[nz[:1] for nz in noises])
+    assert set(one) == {"idx", "y", "y_hat", "f_fake"}
+    same({k: one[k] for k in ("y_hat", "f_fake")}, {k: per_bag[k] for k in ("y_hat", "f_fake")})
+
+
+def test_eval_bags_stay_in_hbm_between_epochs():
+    """Second evaluation pass over the same dataset (another loader object, another order): no host bag is read -- the host tensors
+    are poisoned in between -- and the predictions are those of the first pass, re-ordered. Slabs large enough for operand planes."""
+    from advmil_amd import ingest
+    from advmil_amd.model import MyHandler
+    g, d = nets("abmil")
+    lens = (2048, 4096, 1024, 3072, 2048)
+    ds = Dataset(make("abmil", lens))
+    noises = [[H.noise_tensor(f"ev2:{i}", 0, 192, DEV)] for i in range(len(lens))]
+    cache = ingest.device_bag_cache(DEV)
+    h0, m0 = cache.hits, cache.misses
+    a = MyHandler.test_model(g, d, "abmil", Loader(ds), noise=noises, batch_bags=2)
+    assert cache.misses - m0 == len(lens) and cache.hits == h0
+    torch.cuda.synchronize()
+    for it in ds.items:
+        it[1][0].fill_(float("nan"))
+    order = [3, 0, 4, 1, 2]
+    b = MyHandler.test_model(g, d, "abmil", Loader(ds, order), noise=[noises[i] for i in order], batch_bags=3)
+    assert cache.hits - h0 == len(lens)
+    assert b["idx"].reshape(-1).tolist() == order
+    for k in ("y_hat", "f_fake", "y"):
+        assert torch.isfinite(b[k]).all()
+        assert float((b[k] - a[k][order]).abs().max()) <= 2e-6, k
+    scope = ingest.dataset_scope(Loader(ds))
+    del ds
+    import gc
+    gc.collect()
+    assert not any(isinstance(k, tuple) and k[0] == scope for k in cache.entries)      # the bags went with their dataset
+
+
+def test_randomly_masked_dataset_is_never_cached():
+    """WSIPatch(ratio_mask=...) draws a new random instance mask per __getitem__ (dataset/PatchWSI.py:73-74): its bags are not kept."""
+    from advmil_amd import ingest
+    from advmil_amd.model import MyHandler
+    g, d = nets("abmil")
+    ds = Dataset(make("abmil", (256, 128)), ratio_mask=0.3)
+    cache = ingest.device_bag_cache(DEV)
+    n0, h0, m0 = len(cache.entries), cache.hits, cache.misses
+    assert ingest.dataset_scope(Loader(ds)) is False
+    MyHandler.test_model(g, d, "abmil", Loader(ds))
+    MyHandler.test_model(g, d, "abmil", Loader(ds))
+    assert (len(cache.entries), cache.hits, cache.misses) == (n0, h0, m0)

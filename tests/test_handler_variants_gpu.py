@@ -264,13 +264,14 @@ def test_second_epoch_is_served_from_the_device_resident_bag_cache(nrows):
             torch.cuda.synchronize()
             loader = [(it[0], [torch.full_like(it[1][0], float("nan")), it[1][1]], it[2]) for it in loader]
         cl = h._train_each_epoch([loader[i] for i in order], "train")
-        return cl, h.pop_logs(), h.optimizerG.flat_param.clone(), h._bag_caches.get("train")
+        view = h._bag_caches.get("train")      # (this loader's window onto the device's ONE shared cache: stats taken now)
+        return cl, h.pop_logs(), h.optimizerG.flat_param.clone(), None if view is None else view.stats()
 
     a = run(None, True)                  # default budget: everything resident, the poisoned host bags are never read
     b = run(0, False)                    # no cache: every epoch over PCIe
     one = (lens[0] + lens[1]) * 1024 * 8 / 1e9
     c = run(one, False)                  # a budget of about two bags: evictions, mixed cached / staged step batches
-    assert a[3].stats()["bags"] == 6 and a[3].stats()["hits"] == 6 and b[3] is None and c[3].stats()["evictions"] > 0
+    assert a[3]["bags"] == 6 and a[3]["hits"] == 6 and b[3] is None and c[3]["evictions"] > 0
     for other in (b, c):
         assert torch.equal(a[0]["y_hat"], other[0]["y_hat"]) and torch.equal(a[0]["f_fake"], other[0]["f_fake"])
         assert torch.equal(a[2], other[2])
