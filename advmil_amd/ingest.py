@@ -321,3 +321,105 @@ def dataset_scope(loader):
         return None
     _SCOPE_TOKENS[id(ds)] = (ref, tok)
     return ("ds", tok)
+
+
+def loader_cache_view(device, loader, fallback_scope=None, budget_bytes=None):
+    """This loader's BagCacheView on the device's cache, or None (CPU device, caching off, randomly masked dataset, or no scope)."""
+    import os
+    device = torch.device(device)
+    gb = os.environ.get("ADVMIL_BAG_CACHE_GB")
+    if device.type != "cuda" or (gb is not None and float(gb) <= 0):
+        return None
+    scope = dataset_scope(loader)
+    if scope is None:
+        scope = fallback_scope
+    if not scope:
+        return None
+    if gb is not None:
+        budget_bytes = float(gb) * 1e9
+    return BagCacheView(device_bag_cache(device, budget_bytes), scope)
+
+
+class StepBatch:
+    """`n` bags of a loader, in loader order. staged: their rows sit back to back in the staging slab (xs[j][0] are views of it; a zero-copy
+    step slab, with `_advmil_stager_planes` on the first view when every bag came out of the cache with its operand planes)."""
+    __slots__ = ("pos", "idx", "xs", "ys", "staged")
+
+    def __init__(self, pos, idx, xs, ys, staged):
+        self.pos, self.idx, self.xs, self.ys, self.staged = pos, idx, xs, ys, staged
+
+
+def step_batches(loader, device, nb, cache=None, stager=None, drop_last=False, stageable=None, group_unstaged=False):
+    """Walk `loader` ((idx, [x, ext], y) items, x[1, N, C] on the host) in step batches of `nb` bags whose rows are contiguous in HBM:
+    host bags through the pinned staging slab on the copy stream, bags seen before out of the device-resident cache (device-to-
+    device, on the copy stream too). Items `stageable(x)` rejects (device tensors, graphs, odd shapes) come as single-bag batches with
+    staged = False, in order (`group_unstaged`: grouped `nb` at a time as well, for a training loop whose loader hands over device
+    tensors). The consumer must have ENQUEUED its work on a batch before asking for the next one: the code behind
+    the `yield` then keeps first-seen bags in the cache and lets the staging slab be rewritten once that work has run."""
+    device = torch.device(device)
+    pos, idxs, xs, ys, fresh = [], [], [], [], []
+    loose = StepBatch([], [], [], [], False)      # unstaged items being grouped (group_unstaged)
+    own = stager
+
+    def ok(x0):
+        return (torch.is_tensor(x0) and not x0.is_cuda and x0.dim() == 3 and x0.shape[0] == 1 and x0.shape[1] > 0
+                and x0.dtype == torch.float32 and (stageable is None or stageable(x0)))
+
+    def finish():
+        for j, v in enumerate(own.ready()):
+            xs[j][0] = v
+        bpl = own.batch_planes()
+        if bpl is not None:
+            xs[0][0]._advmil_stager_planes = bpl
+        return StepBatch(list(pos), list(idxs), list(xs), list(ys), True)
+
+    def after():
+        for key, j in fresh:
+            cache.put(key, xs[j][0])
+        own.release()
+        del pos[:], idxs[:], xs[:], ys[:], fresh[:]
+
+    for b, (idx, x, y) in enumerate(loader):
+        x0 = x[0]
+        if nb <= 1 or not ok(x0):
+            if xs:
+                if drop_last and group_unstaged:  # (a step batch is `nb` bags of ONE kind; a training loop never mixes them)
+                    raise ValueError("step_batches: host and device bags alternate inside one step batch")
+                yield finish()
+                after()
+            if group_unstaged and nb > 1:
+                loose.pos.append(b); loose.idx.append(idx); loose.xs.append(list(x)); loose.ys.append(y)
+                if len(loose.xs) == nb:
+                    yield loose
+                    loose = StepBatch([], [], [], [], False)
+            else:
+                yield StepBatch([b], [idx], [list(x)], [y], False)
+            continue
+        if loose.xs:
+            raise ValueError("step_batches: host and device bags alternate inside one step batch")
+        if own is None:
+            own = device_stager(device, x0.shape[-1])
+        if not xs:
+            own.begin()
+        key = int(idx.reshape(-1)[0]) if cache is not None else None
+        hit = cache.get(key) if cache is not None else None
+        if hit is not None:
+            ev = hit.__dict__.get("_advmil_ready")
+            v = own.add_device(hit, hit.__dict__.get("_advmil_bag_planes"), ev)
+            if ev is not None:                   # the copy stream is ordered behind the kernels that made this entry, for good
+                hit._advmil_ready = None
+        else:
+            if cache is not None:
+                fresh.append((key, len(xs)))
+            v = own.add(x0)
+        pos.append(b); idxs.append(idx); xs.append([v] + list(x[1:])); ys.append(y)
+        if len(xs) == nb:
+            yield finish()
+            after()
+    if xs and not drop_last:
+        yield finish()
+        after()
+    elif xs:
+        own.release()
+    if loose.xs and not drop_last:
+        yield loose

@@ -77,29 +77,49 @@ class BaselineHandler(object):
         return out
 
     def _train_each_epoch(self, train_loader, name_loader):
-        """Reference contract (287-326): returns {'y', 'y_hat'} collected over the epoch."""
+        """Reference contract (287-326): returns {'y', 'y_hat'} collected over the epoch. Host bags go through the pinned staging
+        slab on the copy stream and stay in the device-resident bag cache across epochs (advmil_amd/ingest.py::step_batches: the
+        same ingest as MyHandler's); the trailing partial step batch is dropped as the reference drops it."""
+        from ..ingest import loader_cache_view, new_scope_token, step_batches
         bp = self.cfg["bp_every_batch"]
+        ys_all, yh_all = [], []
+        gb = self.cfg.get("bag_cache_gb")
+        view = None
+        if self.bcb != "graph" and (gb is None or float(gb) > 0):
+            view = loader_cache_view(self.device, train_loader, ("h", self.__dict__.setdefault("_cache_token", new_scope_token()), name_loader),
+                                     None if gb is None else float(gb) * 1e9)
+        seen = 0
+        for bt in step_batches(train_loader, self.device, bp, view, drop_last=True, group_unstaged=True,
+                               stageable=lambda x0: self.bcb != "graph"):
+            seen += len(bt.xs)
+            if len(bt.xs) != bp:
+                continue
+            xs = bt.xs if bt.staged else [[dx.to(self.device, non_blocking=True) if torch.is_tensor(dx) else dx for dx in x] for x in bt.xs]
+            if bt.staged and self.bcb == "cluster":
+                xs = [[x[0]] + [dx.to(self.device, non_blocking=True) if torch.is_tensor(dx) else dx for dx in x[1:]] for x in xs]
+            if all(not y.is_cuda for y in bt.ys):    # the step's labels: one pinned stack, one asynchronous copy
+                y_pin = torch.empty(sum(y.shape[0] for y in bt.ys), bt.ys[0].shape[1], dtype=bt.ys[0].dtype, pin_memory=self.device.type == "cuda")
+                torch.cat(bt.ys, dim=0, out=y_pin)
+                y = y_pin.to(self.device, non_blocking=True)
+            else:
+                y = torch.cat([t.to(self.device) for t in bt.ys], dim=0)
+            preds = self._update_network(seen, xs, y)
+            ys_all.append(y); yh_all.append(preds)
         cltor = {"y": None, "y_hat": None}
-        xs, ys = [], []
-        for i_batch, (data_idx, data_x, data_y) in enumerate(train_loader, start=1):
-            xs.append([dx.to(self.device, non_blocking=True) if torch.is_tensor(dx) else dx for dx in data_x])
-            ys.append(data_y.to(self.device, non_blocking=True))
-            if i_batch % bp == 0:
-                preds = self._update_network(i_batch, xs, ys)
-                cltor = agg_tensor(cltor, {"y": torch.cat(ys, dim=0).detach().cpu(), "y_hat": preds.detach().cpu()})
-                xs, ys = [], []
+        if ys_all:                                   # one D2H per key and epoch
+            cltor = {"y": torch.cat(ys_all, dim=0).detach().cpu(), "y_hat": torch.cat(yh_all, dim=0).detach().cpu()}
         return cltor
 
     def _update_network(self, i_batch, xs, ys):
         """One optimizer step over the collected bags (328-368): predictions [B, dim_out] of the step batch."""
+        from .model_handler import MyHandler
         self.net.train()
         self.optimizer.zero_grad()
-        c = xs[0][0].shape[-1]
-        X = torch.cat([x[0].reshape(-1, c) for x in xs], dim=0) if len(xs) > 1 else xs[0][0].reshape(-1, c)
+        X = MyHandler._slab_build_static(xs)         # zero-copy when the bags sit back to back in the staging slab; operand planes attached
         seg = ops.Segments([x[0].shape[-2] for x in xs], self.device)
         exts = [x[1] for x in xs] if self.bcb in ("cluster", "graph") else None
         preds = self.net.finish(self.net.features_multi(X, seg, exts))
-        y = torch.cat(ys, dim=0)
+        y = ys if torch.is_tensor(ys) else torch.cat(ys, dim=0)
         net_loss = self.supervised_loss(preds, y[:, 0:1], y[:, 1:2])
         net_loss.backward()
         total = net_loss.detach()
@@ -111,28 +131,46 @@ class BaselineHandler(object):
 
     # ------------------------------------------------------------------------------------------
     @staticmethod
-    def test_model(model, backbone, loader, times_test_sample=1, checkpoint=None):
+    def test_model(model, backbone, loader, times_test_sample=1, checkpoint=None, batch_bags=None):
         """443-487. The network has no noise, so in eval mode the `times_test_sample` repeated forwards of the reference are
-        identical: the bag is run once and the sample axis is filled with that prediction."""
+        identical: a bag is run once and the sample axis is filled with that prediction. `batch_bags` (default 16,
+        ADVMIL_EVAL_BATCH_BAGS) host bags are evaluated as one step slab, staged on the copy stream and kept in the device-resident
+        bag cache between epochs (as MyHandler.test_model); device tensors, graphs and batch_bags=1 take the per-bag loop."""
+        from ..ingest import loader_cache_view, step_batches
+        from .model_handler import MyHandler
         dev = next(model.parameters()).device
         if checkpoint is not None:
             model.load_state_dict(torch.load(checkpoint, map_location=dev)["model"])
         model.eval()
-        res = {"idx": None, "y": None, "y_hat": None}
+        nb = int(batch_bags if batch_bags is not None else os.environ.get("ADVMIL_EVAL_BATCH_BAGS", "16"))
+        if backbone == "graph" or not hasattr(model, "features_multi"):
+            nb = 1
+        idxs, ys, preds = [], [], []
         with torch.no_grad():
-            for idx, x, y in loader:
-                x_data, x_ext = [t.to(dev) if torch.is_tensor(t) else t for t in x]
-                if backbone == "graph":
-                    y_hat = model(x_ext, None)
-                elif backbone == "patch":
-                    y_hat = model(x_data, None)
+            for bt in step_batches(loader, dev, nb, loader_cache_view(dev, loader)):
+                if bt.staged:
+                    xs = bt.xs
+                    X = MyHandler._slab_build_static(xs)
+                    seg = ops.Segments([x[0].shape[-2] for x in xs], dev)
+                    exts = [x[1].to(dev) if torch.is_tensor(x[1]) else x[1] for x in xs] if backbone == "cluster" else None
+                    y_hat = model.finish(model.features_multi(X, seg, exts))
                 else:
-                    y_hat = model(x_data, x_ext)
-                res = agg_tensor(res, {"idx": idx.detach().cpu(), "y": y.detach().cpu(), "y_hat": y_hat.detach().cpu()})
-                if times_test_sample > 1:
-                    ys = y_hat.unsqueeze(0).expand(times_test_sample, *y_hat.shape)
-                    res = agg_tensor(res, {"dist_y_hat": ys.transpose(0, 1).detach().cpu()})
-                    res = agg_tensor(res, {"avg_y_hat": torch.median(ys, dim=0)[0].detach().cpu()})
+                    x_data, x_ext = [t.to(dev) if torch.is_tensor(t) else t for t in bt.xs[0]]
+                    if backbone == "graph":
+                        y_hat = model(x_ext, None)
+                    elif backbone == "patch":
+                        y_hat = model(x_data, None)
+                    else:
+                        y_hat = model(x_data, x_ext)
+                idxs.extend(i.detach() for i in bt.idx); ys.extend(y.detach() for y in bt.ys); preds.append(y_hat)
+        res = {"idx": None, "y": None, "y_hat": None}
+        if preds:                                    # one D2H per key
+            y_hat = torch.cat(preds, dim=0).detach().cpu()
+            res = {"idx": torch.cat(idxs, dim=0).cpu(), "y": torch.cat(ys, dim=0).cpu(), "y_hat": y_hat}
+            if times_test_sample > 1:
+                dist = y_hat.unsqueeze(0).expand(times_test_sample, *y_hat.shape).contiguous()
+                res["dist_y_hat"] = dist.transpose(0, 1).contiguous()
+                res["avg_y_hat"] = torch.median(dist, dim=0)[0]
         return res
 
     # ------------------------------------------------------------------------------------------

@@ -719,14 +719,9 @@ class MyHandler(object):
                 ys = torch.stack([modelG.head(H, test_zero_noise, None if it is None else [next(it)]) for _ in range(times_test_sample)])
                 parts["dist_y_hat"].append(ys.transpose(0, 1)); parts["avg_y_hat"].append(torch.median(ys, dim=0)[0])
 
-        def slab_batch(items, stager, fresh, cache):
-            """items: [(b, idx, [x view in the staging slab, ext], y)] -> the batch through the slab kernels."""
-            for j, v in enumerate(stager.ready()):
-                items[j][2][0] = v
-            bpl = stager.batch_planes()
-            if bpl is not None:
-                items[0][2][0]._advmil_stager_planes = bpl
-            xs = [it[2] for it in items]
+        def slab_batch(bt):
+            """One StepBatch (ingest.step_batches) through the slab kernels."""
+            xs, n = bt.xs, len(bt.xs)
             X = MyHandler._slab_build_static(xs)
             seg = ops.Segments([x[0].shape[-2] for x in xs], dev)
             MyHandler._prefill_static(modelG, modelD, backbone, X)       # G's and D's first layers over the slab from one launch
@@ -736,64 +731,28 @@ class MyHandler(object):
             H = bb.post(feats) if hasattr(bb, "post") else feats
             nz = None
             if noise is not None:                                          # per-bag [n0, n1, ...] -> per-call [B, w] stacks
-                nz = [torch.cat([noise[it[0]][c] for it in items], dim=0) for c in range(len(noise[items[0][0]]))]
+                nz = [torch.cat([noise[b][c] for b in bt.pos], dim=0) for c in range(len(noise[bt.pos[0]]))]
             y_hat = modelG.head(H, test_zero_noise, None if nz is None else [nz[0]])
             emb = modelD.embed_rows(X)
             eb, im = modelD.bag_features_multi(emb, seg.div(16))
             f_fake = modelD.tail(eb, im, y_hat)
             ops.PREFILL.clear()
-            parts["idx"].extend(it[1].detach() for it in items); parts["y"].extend(it[3].detach() for it in items)
-            parts["y_hat"].append(y_hat); parts["f_fake"].append(f_fake.reshape(len(items), -1))
+            parts["idx"].extend(i.detach() for i in bt.idx); parts["y"].extend(y.detach() for y in bt.ys)
+            parts["y_hat"].append(y_hat); parts["f_fake"].append(f_fake.reshape(n, -1))
             if times_test_sample > 1:
                 ys = torch.stack([modelG.head(H, test_zero_noise, None if nz is None else [nz[1 + c]]) for c in range(times_test_sample)])
                 parts["dist_y_hat"].append(ys.transpose(0, 1)); parts["avg_y_hat"].append(torch.median(ys, dim=0)[0])
-            for key, j in fresh:                                           # first sight: keep the bag (and its operand planes) in HBM
-                cache.put(key, items[j][2][0])
-            stager.release()
 
-        from ..ingest import BagCacheView, dataset_scope, device_bag_cache, device_stager
-        scope = dataset_scope(loader)
-        gb = os.environ.get("ADVMIL_BAG_CACHE_GB")
-        cache = None
-        if scope and (gb is None or float(gb) > 0) and dev.type == "cuda":
-            cache = BagCacheView(device_bag_cache(dev, None if gb is None else float(gb) * 1e9), scope)
-        items, fresh, stager = [], [], None
-        nlen = None if noise is None else {len(nb) for nb in noise}
-
-        def flush():
-            nonlocal items, fresh
-            if items:
-                slab_batch(items, stager, fresh, cache)
-            items, fresh = [], []
-
+        from ..ingest import loader_cache_view, step_batches
+        slab_able = (backbone != "graph" and hasattr(modelG, "features_multi") and hasattr(modelD, "bag_features_multi")
+                     and (noise is None or len({len(nb) for nb in noise}) == 1))
         with torch.no_grad():
-            for b, (idx, x, y) in enumerate(loader):
-                x0 = x[0]
-                slab_ok = (nb_max > 1 and backbone != "graph" and torch.is_tensor(x0) and not x0.is_cuda and x0.dim() == 3
-                           and x0.shape[0] == 1 and x0.shape[1] % 16 == 0 and x0.shape[1] > 0 and x0.dtype == torch.float32
-                           and (nlen is None or len(nlen) == 1) and hasattr(modelG, "features_multi") and hasattr(modelD, "bag_features_multi"))
-                if not slab_ok:
-                    flush()
-                    one_bag(b, idx, x, y)
-                    continue
-                if stager is None:
-                    stager = device_stager(dev, x0.shape[-1])
-                if not items:
-                    stager.begin()
-                hit = cache.get(int(idx.reshape(-1)[0])) if cache is not None else None
-                if hit is not None:
-                    ev = hit.__dict__.get("_advmil_ready")
-                    v = stager.add_device(hit, hit.__dict__.get("_advmil_bag_planes"), ev)
-                    if ev is not None:
-                        hit._advmil_ready = None
+            for bt in step_batches(loader, dev, nb_max if slab_able else 1, loader_cache_view(dev, loader),
+                                   stageable=lambda x0: x0.shape[1] % 16 == 0):
+                if bt.staged:
+                    slab_batch(bt)
                 else:
-                    if cache is not None:
-                        fresh.append((int(idx.reshape(-1)[0]), len(items)))
-                    v = stager.add(x0)
-                items.append((b, idx, [v, x[1]], y))
-                if len(items) == nb_max:
-                    flush()
-            flush()
+                    one_bag(bt.pos[0], bt.idx[0], bt.xs[0], bt.ys[0])
         res = {k: None for k in ("idx", "y", "y_hat", "f_fake")}
         if parts["idx"]:
             res = {k: torch.cat([t if t.dim() > 0 else t.reshape(1) for t in parts[k]], dim=0).detach().cpu() for k in keys}

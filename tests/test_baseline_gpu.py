@@ -92,3 +92,38 @@ def test_test_model_and_checkpoint_round_trip(tmp_path):
     h2.resume_model("last")
     b = BaselineHandler.test_model(h2.net, "abmil", loader)
     assert torch.equal(a["y_hat"], b["y_hat"])
+
+
+@pytest.mark.parametrize("kind", ["abmil", "cluster", "patch"])
+def test_batched_eval_and_staged_training_equal_the_per_bag_forms(kind):
+    """The shared ingest (advmil_amd/ingest.py::step_batches): host bags through the staging slab == the same bags handed over as
+    device tensors (training, two steps); evaluation in slabs of 3 == the per-bag loop (ragged bags)."""
+    from advmil_amd.model import BaselineHandler
+    lens = (256, 128, 512, 64, 192, 384, 320, 96)
+
+    def loader(device=None):
+        out = []
+        for i, n in enumerate(lens):
+            x = H.bag(500 + i, 512)[:, :n].contiguous()
+            ext = H.T(synth.cluster_ids(0, 500 + i, n)) if kind == "cluster" else torch.zeros(1, 1)
+            if device is not None:
+                x, ext = x.to(device), ext.to(device)
+            out.append((torch.tensor([[i]], dtype=torch.int), [x, ext], H.label(i)))
+        return out
+
+    def train(ld):
+        h = BaselineHandler(default_baseline_cfg(bcb_mode=kind, task="surv_reg", bp_every_batch=3), device=DEV)
+        load_synth(h.net, f"S-{kind}-ev:")
+        zero_dropout(h.net)
+        return h, h._train_each_epoch(ld, "train"), h.pop_logs()
+
+    (ha, cla, la), (hb, clb, lb) = train(loader()), train(loader(DEV))
+    assert cla["y_hat"].shape == (6, 1) and len(la) == len(lb) == 2          # 8 bags, steps of 3: the trailing two are dropped
+    assert float((cla["y_hat"] - clb["y_hat"]).abs().max()) <= 2e-6 and torch.equal(cla["y"], clb["y"])
+    for a, b in zip(la, lb):
+        assert abs(a["train_batch/net/loss_supervision"] - b["train_batch/net/loss_supervision"]) <= 2e-6
+    one = BaselineHandler.test_model(ha.net, kind, loader(), times_test_sample=2, batch_bags=1)
+    bat = BaselineHandler.test_model(ha.net, kind, loader(), times_test_sample=2, batch_bags=3)
+    assert set(one) == set(bat) == {"idx", "y", "y_hat", "dist_y_hat", "avg_y_hat"}
+    for k in one:
+        assert one[k].shape == bat[k].shape and float((one[k].double() - bat[k].double()).abs().max()) <= 2e-6, k
