@@ -7,7 +7,53 @@ memcpy'd into the pinned slab and sent to the device slab with an async H2D copy
   * while step t computes on pair k, the host already stages step t+1 into pair k^1 (PCIe overlaps compute);
   * a pair is only rewritten after the step that read it has finished (event from the compute stream).
 """
+import os
+
 import torch
+
+
+def effective_cpus():
+    """CPUs this process may really use: the affinity mask capped by the cgroup's CPU quota (a container with `cpu.max` = 16 CPUs on a
+    256-thread host runs 128 OpenMP threads at the speed of 16, erratically)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+_COPY_POOL = None
+
+
+def host_copy_rows(dst, src):
+    """dst[rows, C] (pinned staging slab) <- src[rows, C] (pageable loader tensor) by a small pool of threads running numpy copies
+    (the GIL is released inside them). torch's `copy_` hands a 33 MB copy to every OpenMP thread of the process: under a container
+    CPU quota that took 5-100 ms for 16 bags from call to call; 8 plain threads take 5-7 ms (tools/probe/host_copy_threads.py:
+    108 GB/s), which keeps a pageable loader at the PCIe rate. ADVMIL_INGEST_THREADS (default min(8, usable CPUs); 0 = torch copy_)."""
+    global _COPY_POOL
+    nt = int(os.environ.get("ADVMIL_INGEST_THREADS", min(8, effective_cpus())))
+    rows = src.shape[0]
+    if nt <= 1 or rows < 4 * nt or src.dtype != dst.dtype or not src.is_contiguous() or not dst.is_contiguous():
+        dst.copy_(src)
+        return
+    import numpy as np
+    if _COPY_POOL is None or _COPY_POOL._max_workers != nt:
+        from concurrent.futures import ThreadPoolExecutor
+        _COPY_POOL = ThreadPoolExecutor(nt, thread_name_prefix="advmil-ingest")
+    d, s_ = dst.numpy(), src.numpy()
+    step = (rows + nt - 1) // nt
+    futs = [_COPY_POOL.submit(np.copyto, d[r0:r0 + step], s_[r0:r0 + step]) for r0 in range(0, rows, step)]
+    for f in futs:
+        f.result()
 
 
 class SlabStager:
@@ -86,7 +132,7 @@ class SlabStager:
             src = x2
             self._keep.append(x_cpu)                              # keep the source alive until the copy has run
         else:
-            self.host[k][a:b].copy_(x2)                           # pageable -> pinned (one host memcpy, ~10 GB/s per thread)
+            host_copy_rows(self.host[k][a:b], x2)                 # pageable -> pinned, a few plain threads (see host_copy_rows)
             src = self.host[k][a:b]
         with torch.cuda.stream(self.copy_stream):
             self.dev[k][a:b].copy_(src, non_blocking=True)

@@ -108,7 +108,9 @@ def cpu_baseline(args, torch):
     from advmil_amd.model import Generator, load_backbone  # noqa: F401  (shapes only, built on CPU)
     from types import SimpleNamespace
     import advmil_amd.model.GANSurv as GS
-    nthreads = torch.get_num_threads()
+    from advmil_amd.ingest import effective_cpus
+    nthreads = min(torch.get_num_threads(), effective_cpus())      # (a cgroup CPU quota below the thread count only adds contention)
+    torch.set_num_threads(nthreads)
     kind, N, nb = args.mode, args.patches, args.cpu_bags
     dg = 128 if kind == "graph" else 384
     bb = load_backbone(kind, [1024, dg, dg])
@@ -380,6 +382,20 @@ def product_loop(args, torch, dev, case):
     out["eager_pcie_ragged"] = ent(d0, "MyHandler._train_each_epoch, eager launches, pinned host bags -> SlabStager (copy stream) -> step slab; "
                                        "bag cache off: every epoch pays PCIe")
     out["eager_pcie_ragged"]["h2d_mb_per_step"] = round(rows * 4096 / nsteps / 1e6, 1)
+    # the same loop fed what a default DataLoader (pin_memory=False, the reference's) hands over: pageable tensors, copied into the
+    # pinned staging slab by the ingest's own thread pool (advmil_amd/ingest.py::host_copy_rows) on their way to the DMA
+    npg = min(nsteps, 8)
+    pageable = [(it[0], [it[1][0].clone(), it[1][1]], it[2]) for it in loader[2 * args.bags:(2 + npg) * args.bags]]
+    hh._train_each_epoch(pageable[:args.bags], "warmup")
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    hh._train_each_epoch(pageable, "nocache")
+    torch.cuda.synchronize()
+    dpg = time.perf_counter() - t1
+    out["eager_pcie_pageable_ragged"] = {"value": round(args.bags * npg / dpg, 2), "unit": "bags/s", "ms_per_step": round(1e3 * dpg / npg, 3), "steps": npg,
+                                         "path": "same loop, bag cache off, PAGEABLE host bags (DataLoader without pin_memory): pageable -> pinned slab by a "
+                                                 "pool of 8 copy threads -> DMA"}
+    del pageable
     del os.environ["ADVMIL_BAG_CACHE_GB"]
     hh._bag_caches = {}
     d1 = epoch("train")                                                          # epoch 1: PCIe + fills the cache
