@@ -90,7 +90,8 @@ class BaselineHandler(object):
                                      None if gb is None else float(gb) * 1e9)
         seen = 0
         for bt in step_batches(train_loader, self.device, bp, view, drop_last=True, group_unstaged=True,
-                               stageable=lambda x0: self.bcb != "graph"):
+                               stageable=lambda x0: self.bcb != "graph",
+                               pad_multiple=int(os.environ.get("ADVMIL_SLAB_PAD", self.cfg.get("slab_pad", 256)))):
             seen += len(bt.xs)
             if len(bt.xs) != bp:
                 continue
@@ -103,22 +104,25 @@ class BaselineHandler(object):
                 y = y_pin.to(self.device, non_blocking=True)
             else:
                 y = torch.cat([t.to(self.device) for t in bt.ys], dim=0)
-            preds = self._update_network(seen, xs, y)
+            preds = self._update_network(seen, xs, y, bt.pad)
             ys_all.append(y); yh_all.append(preds)
         cltor = {"y": None, "y_hat": None}
         if ys_all:                                   # one D2H per key and epoch
             cltor = {"y": torch.cat(ys_all, dim=0).detach().cpu(), "y_hat": torch.cat(yh_all, dim=0).detach().cpu()}
         return cltor
 
-    def _update_network(self, i_batch, xs, ys):
+    def _update_network(self, i_batch, xs, ys, pad=0):
         """One optimizer step over the collected bags (328-368): predictions [B, dim_out] of the step batch."""
         from .model_handler import MyHandler
         self.net.train()
         self.optimizer.zero_grad()
-        X = MyHandler._slab_build_static(xs)         # zero-copy when the bags sit back to back in the staging slab; operand planes attached
-        seg = ops.Segments([x[0].shape[-2] for x in xs], self.device)
+        X = MyHandler._slab_build_static(xs, True, pad)   # zero-copy when the bags sit back to back in the staging slab; operand planes attached
+        lens = [x[0].shape[-2] for x in xs]
+        seg = ops.Segments(lens + [pad] if pad else lens, self.device)      # (`pad` zero rows behind the bags: a dummy bag, dropped)
         exts = [x[1] for x in xs] if self.bcb in ("cluster", "graph") else None
-        preds = self.net.finish(self.net.features_multi(X, seg, exts))
+        if exts is not None and pad:
+            exts = exts + [torch.zeros(pad, dtype=exts[0].dtype, device=self.device)]
+        preds = self.net.finish(self.net.features_multi(X, seg, exts)[:len(xs)])
         y = ys if torch.is_tensor(ys) else torch.cat(ys, dim=0)
         net_loss = self.supervised_loss(preds, y[:, 0:1], y[:, 1:2])
         net_loss.backward()
@@ -147,13 +151,16 @@ class BaselineHandler(object):
             nb = 1
         idxs, ys, preds = [], [], []
         with torch.no_grad():
-            for bt in step_batches(loader, dev, nb, loader_cache_view(dev, loader)):
+            for bt in step_batches(loader, dev, nb, loader_cache_view(dev, loader), pad_multiple=int(os.environ.get("ADVMIL_SLAB_PAD", "256"))):
                 if bt.staged:
-                    xs = bt.xs
-                    X = MyHandler._slab_build_static(xs)
-                    seg = ops.Segments([x[0].shape[-2] for x in xs], dev)
+                    xs, pad = bt.xs, bt.pad
+                    X = MyHandler._slab_build_static(xs, True, pad)
+                    lens = [x[0].shape[-2] for x in xs]
+                    seg = ops.Segments(lens + [pad] if pad else lens, dev)
                     exts = [x[1].to(dev) if torch.is_tensor(x[1]) else x[1] for x in xs] if backbone == "cluster" else None
-                    y_hat = model.finish(model.features_multi(X, seg, exts))
+                    if exts is not None and pad:
+                        exts = exts + [torch.zeros(pad, dtype=exts[0].dtype, device=dev)]
+                    y_hat = model.finish(model.features_multi(X, seg, exts)[:len(xs)])
                 else:
                     x_data, x_ext = [t.to(dev) if torch.is_tensor(t) else t for t in bt.xs[0]]
                     if backbone == "graph":

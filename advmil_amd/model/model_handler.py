@@ -77,6 +77,8 @@ class MyHandler(object):
         # results are identical. Measured on the 16 x 8192 step: 3.85 ms against 3.79 ms serial -- the slab kernels of both
         # branches each want every CU's LDS, so they time-slice and the short launches gain nothing. Off by default.
         self.overlap_gfwd = os.environ.get("ADVMIL_OVERLAP_GFWD", "0") == "1"
+        # rows of a staged step slab are padded with zero rows to a multiple of this (0 = off): see ingest.SlabStager.pad_rows
+        self.slab_pad = int(os.environ.get("ADVMIL_SLAB_PAD", cfg.get("slab_pad", 256)))
         self._side_stream = None
         self._fork_evt = self._join_evt = None
         self.cfg = cfg
@@ -255,7 +257,10 @@ class MyHandler(object):
                 else:
                     y_col = [y.to(self.device, non_blocking=True) for y in y_col]
                     y_step = torch.cat(y_col, dim=0)
+                pad = 0
                 if staged:                               # growth may have re-based the views: take the final ones
+                    if len(staged_pos) == len(x_col):
+                        pad = stager.pad_rows(self.slab_pad)     # whole 256-row tiles for the slab kernels' fast forms
                     for j, v in zip(staged_pos, stager.ready()):
                         x_col[j][0] = v
                     bpl = stager.batch_planes()          # every bag came from the cache with its planes: the slab's planes are ready
@@ -266,7 +271,7 @@ class MyHandler(object):
                 if self.noise_hook is not None:
                     nz_d = [self.noise_hook("d", int(ix.reshape(-1)[0])) for ix in i_col]
                     nz_g = [self.noise_hook("g", int(ix.reshape(-1)[0])) for ix in i_col]
-                plan = self._plan(x_col, y_col, mode, mask, ys_host, y_step)   # ONE plan per step batch, shared by the D and G updates
+                plan = self._plan(x_col, y_col, mode, mask, ys_host, y_step, pad)   # ONE plan per step batch, shared by the D and G updates
                 # bag-parallel: D's gradient exchange is started asynchronously and completed inside the first generator update, after
                 # the generator's backbone forward (which does not depend on D) has been enqueued -> the two overlap
                 overlap = self.dp.world > 1 and num_update_gen > 0
@@ -323,7 +328,7 @@ class MyHandler(object):
             self._disc_apply()
         return preds, fakes
 
-    def _plan(self, xs, ys, mode, label_visible_mask, ys_host, y_stack=None):
+    def _plan(self, xs, ys, mode, label_visible_mask, ys_host, y_stack=None, pad=0):
         """Host-side facts of a step batch (built OUTSIDE HIP-graph capture): which bags feed a real pair / the supervised loss,
         the GLOBAL denominators of the reference's means, the row segments of the step slab and -- under bag-parallel -- the maps
         from this rank's rows to the rows of the single-process slab that index every dropout / noise draw. All device arrays are
@@ -341,17 +346,24 @@ class MyHandler(object):
         counts = [sum(is_real), n, sum(vis)]
         rng_rows = rowoff16 = None
         if W > 1:
-            allv = self.dp.allgather_ints(counts + lens, dev)
+            allv = self.dp.allgather_ints(counts + [int(pad)] + lens, dev)
             n_real, n_fake, n_vis = (sum(v[k] for v in allv) for k in range(3))
-            rng_rows, rowoff16 = self._rng_row_maps([v[3:] for v in allv], lens, n, W, r)
+            rng_rows, rowoff16 = self._rng_row_maps([v[4:] for v in allv], lens, n, W, r, [v[3] for v in allv])
         else:
             n_real, n_fake, n_vis = counts
+            if pad:                                      # the real rows draw what they draw in the unpadded slab (parallel.rng_row_maps)
+                rng_rows, rowoff16 = self._rng_row_maps([lens], lens, n, 1, 0, [int(pad)])
         masks = torch.empty(2 * n, dtype=torch.float32, pin_memory=True)
         mv = masks.numpy()
         mv[:n] = [1.0 if q else 0.0 for q in is_real]
         mv[n:] = [1.0 if v else 0.0 for v in vis]
         masks_d = masks.to(dev, non_blocking=True)
-        seg = ops.Segments(lens, dev)
+        # `pad` zero rows behind the bags (SlabStager.pad_rows) are one more segment of the slab: a dummy bag whose pooled row is
+        # dropped (`_bags`) before anything bag-level sees it
+        seg = ops.Segments(lens + [pad] if pad else lens, dev)
+        sel2 = None
+        if pad:                                          # rows of the D update's stacked [fake | real] pooled features that are bags
+            sel2 = torch.tensor(list(range(n)) + list(range(n + 1, 2 * n + 1)), dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
         seg16 = seg.div(16)                              # D's region embedding needs N % 16 == 0 (backbone_utils.py:65)
         seg16.twice()                                    # (built here: the D update stacks its fake and real passes)
         seg16.rng_rowoff = rowoff16
@@ -360,15 +372,31 @@ class MyHandler(object):
         return SimpleNamespace(vis=vis, is_real=is_real, n_real=n_real, n_fake=n_fake, n_vis=n_vis, y=y,
                                y_t=y[:, 0:1].contiguous(), y_e=y[:, 1:2].contiguous(),     # label columns, contiguous once per plan
                                vis_mask=None if all(vis) else masks_d[n:], real_mask=masks_d[:n], seg=seg, seg16=seg16,
-                               rng_rows=rng_rows, token=self._plan_count, _keep=(masks, masks_d), _X=None, _X_src=None)
+                               rng_rows=rng_rows, token=self._plan_count, _keep=(masks, masks_d), _X=None, _X_src=None,
+                               pad=int(pad), nb=n, sel2=sel2)
 
-    def _rng_row_maps(self, all_lens, lens, n, W, r):
+    def _rng_row_maps(self, all_lens, lens, n, W, r, pads=None):
         """Bag-parallel: upload parallel.rng_row_maps (local row -> row in the single-process slab, one map per row LAYOUT a
         slab-level tensor of the step can have) as ONE pinned buffer / one asynchronous copy -> (ops.DeviceRng.rows keyed by layout
         kind, Segments.rng_rowoff)."""
         from ..parallel import rng_row_maps
-        maps, off16 = rng_row_maps(all_lens, W, r, cluster=self.bcb == "cluster")
+        ident = {}
+        if W == 1:
+            # single process with a pad: every layout but the stacked one is the identity on its real rows and the pad rows sit behind
+            # them (their draws are never used) -> no lookup in the kernels, no map to build; the attention offsets of the real bags
+            # are zero. Same indices as parallel.rng_row_maps(..., pads) gives for W = 1 (tests/test_parallel_gloo_cpu.py).
+            import numpy as np
+            pad = int(pads[0])
+            L, p16 = sum(lens) // 16, (pad + 15) // 16
+            ar, ap = np.arange(L, dtype=np.int64), np.arange(p16, dtype=np.int64)
+            maps = {"region2": np.concatenate([ar, 2 * L + ap, L + ar, 2 * L + p16 + 1 + ap])}
+            rows_of = {"patch": sum(lens) + pad, "region": L + p16, "bag": n, "bag2": 2 * n, "cluster": 8 * (n + 1)}
+            ident = {k: ops.IdentityRows(v) for k, v in rows_of.items() if k != "cluster" or self.bcb == "cluster"}
+            off16 = np.zeros(0, dtype=np.int64)
+        else:
+            maps, off16 = rng_row_maps(all_lens, W, r, cluster=self.bcb == "cluster", pads=pads)
         kinds = list(maps)
+        n = int(off16.shape[0])                          # (one more entry when this rank's slab carries a pad bag)
         host = torch.empty(sum(int(maps[k].shape[0]) for k in kinds) + n, dtype=torch.int64, pin_memory=True)
         hv, o, spans = host.numpy(), 0, {}
         for k in kinds:
@@ -377,7 +405,9 @@ class MyHandler(object):
         hv[o:o + n] = off16
         devbuf = host.to(self.device, non_blocking=True)
         self._rng_keep = (host, devbuf)
-        return {k: devbuf[a_:b_] for k, (a_, b_) in spans.items()}, devbuf[o:o + n]
+        out = {k: devbuf[a_:b_] for k, (a_, b_) in spans.items()}
+        out.update(ident)
+        return out, (None if W == 1 else devbuf[o:o + n])
 
     @staticmethod
     def _rows(x):
@@ -389,16 +419,23 @@ class MyHandler(object):
         plan: the D and the G update of a step read the same matrix, and the forward memo recognises it by its address)."""
         if plan is not None and getattr(plan, "_X", None) is not None and plan._X_src == [id(x[0]) for x in xs]:
             return plan._X
-        X = self._slab_build(xs)
+        X = self._slab_build(xs, 0 if plan is None else getattr(plan, "pad", 0))
         if plan is not None:
             plan._X, plan._X_src = X, [id(x[0]) for x in xs]
         return X
 
-    def _slab_build(self, xs):
-        return MyHandler._slab_build_static(xs, getattr(self, "resident_planes", True))
+    def _slab_build(self, xs, pad=0):
+        return MyHandler._slab_build_static(xs, getattr(self, "resident_planes", True), pad)
 
     @staticmethod
-    def _slab_build_static(xs, resident_planes=True):
+    def _bags(t, plan, stacked=False):
+        """Drop the dummy bag of the slab pad (`_plan`) from a pooled [B + 1, d] tensor ([2 (B + 1), d] when `stacked`)."""
+        if t is None or not getattr(plan, "pad", 0):
+            return t
+        return t.index_select(0, plan.sel2) if stacked else t[:plan.nb]
+
+    @staticmethod
+    def _slab_build_static(xs, resident_planes=True, pad=0):
         x0 = xs[0][0]
         c = x0.shape[-1]
         rows = [x[0].shape[-2] for x in xs]
@@ -411,7 +448,9 @@ class MyHandler(object):
                     ok = False
                     break
                 ptr += r * c * 4
-        X = (x0.as_strided((sum(rows), c), (c, 1), x0.storage_offset()) if ok
+        if pad and not ok:
+            raise RuntimeError("a slab pad needs the bags back to back in the staging slab")
+        X = (x0.as_strided((sum(rows) + pad, c), (c, 1), x0.storage_offset()) if ok       # (pad: zero rows the stager put behind them)
              else torch.cat([x[0].reshape(-1, c) for x in xs], dim=0))
         spl = getattr(x0, "_advmil_stager_planes", None) if ok else None
         if (spl is not None and spl.hi.shape[0] == X.shape[0] and X.shape[0] >= 4096 and ops.USE_PLANES and ops.get_gemm_mode() == "bf16x3"
@@ -486,7 +525,9 @@ class MyHandler(object):
     def _gen_features(self, X, plan, xs):
         """Generator backbone over the whole step slab -> [B, d]. `patch` mode skips coords (model_handler.py:390)."""
         exts = [x[1] for x in xs] if self.bcb in ("cluster", "graph") else None
-        return self.netG.features_multi(X, plan.seg, exts)
+        if exts is not None and getattr(plan, "pad", 0):
+            exts = exts + [torch.zeros(plan.pad, dtype=exts[0].dtype, device=exts[0].device)]     # the dummy bag's cluster ids
+        return self._bags(self.netG.features_multi(X, plan.seg, exts), plan)
 
     def _disc_backward(self, i_batch, xs, ys, plan, noise=None):
         """Capturable (no host sync, no collective): zero D grads, forward of the step slab, ONE backward of the D loss.
@@ -523,11 +564,12 @@ class MyHandler(object):
             # scores of bags without a visible event are computed and dropped (B rows of [B,d] work).
             nb = len(xs)
             eb2, im2 = self.netD.bag_features_multi(torch.cat([emb, emb], dim=0), plan.seg16.twice())
+            eb2, im2 = self._bags(eb2, plan, True), self._bags(im2, plan, True)
             f2 = self.netD.tail(eb2, im2, torch.cat([pred, plan.y_t], dim=0)).view(-1)
             f_fake = f2.detach()[:nb]                                           # (the loss takes f2 whole: no slice backward)
         else:
             eb, im = self.netD.bag_features_multi(emb, plan.seg16)
-            f_fake = self.netD.tail(eb, im, pred).view(-1)
+            f_fake = self.netD.tail(self._bags(eb, plan), self._bags(im, plan), pred).view(-1)
         # real_fake_loss with the global denominators (loss/utils.py:182-203, model_handler.py:412) as ONE launch that also yields
         # d loss / d score; the real pairs are selected by a 0/1 mask (same sum as f_real[event & visible], no index backward)
         ops.PREFILL.clear()                  # (anything the two forwards did not take is stale from here on)
@@ -630,6 +672,7 @@ class MyHandler(object):
             torch.cuda.current_stream().wait_event(join)
         with torch.no_grad():                                                  # nothing of D(x) depends on G
             eb, im = self.netD.bag_features_multi(self.netD.embed_rows(X), plan.seg16)
+            eb, im = self._bags(eb, plan), self._bags(im, plan)
         # The generator loss only needs d f / d pred. The reference lets autograd also fill netD's weight gradients here and
         # throws them away at the next optimizerD.zero_grad() (model_handler.py:409, 497); with D's parameters frozen for this
         # backward those contractions (five small dW launches + their reductions) are never issued.
@@ -721,12 +764,15 @@ class MyHandler(object):
 
         def slab_batch(bt):
             """One StepBatch (ingest.step_batches) through the slab kernels."""
-            xs, n = bt.xs, len(bt.xs)
-            X = MyHandler._slab_build_static(xs)
-            seg = ops.Segments([x[0].shape[-2] for x in xs], dev)
+            xs, n, pad = bt.xs, len(bt.xs), bt.pad
+            X = MyHandler._slab_build_static(xs, True, pad)
+            lens = [x[0].shape[-2] for x in xs]
+            seg = ops.Segments(lens + [pad] if pad else lens, dev)       # (the pad's zero rows are a dummy bag, dropped below)
             MyHandler._prefill_static(modelG, modelD, backbone, X)       # G's and D's first layers over the slab from one launch
             exts = [x[1].to(dev) if torch.is_tensor(x[1]) else x[1] for x in xs] if backbone == "cluster" else None
-            feats = modelG.features_multi(X, seg, exts)                    # [B, d]: the bags are embedded ONCE
+            if exts is not None and pad:
+                exts = exts + [torch.zeros(pad, dtype=exts[0].dtype, device=dev)]
+            feats = modelG.features_multi(X, seg, exts)[:n]                # [B, d]: the bags are embedded ONCE
             bb = modelG.backbone
             H = bb.post(feats) if hasattr(bb, "post") else feats
             nz = None
@@ -735,7 +781,7 @@ class MyHandler(object):
             y_hat = modelG.head(H, test_zero_noise, None if nz is None else [nz[0]])
             emb = modelD.embed_rows(X)
             eb, im = modelD.bag_features_multi(emb, seg.div(16))
-            f_fake = modelD.tail(eb, im, y_hat)
+            f_fake = modelD.tail(eb[:n], None if im is None else im[:n], y_hat)
             ops.PREFILL.clear()
             parts["idx"].extend(i.detach() for i in bt.idx); parts["y"].extend(y.detach() for y in bt.ys)
             parts["y_hat"].append(y_hat); parts["f_fake"].append(f_fake.reshape(n, -1))
@@ -748,7 +794,7 @@ class MyHandler(object):
                      and (noise is None or len({len(nb) for nb in noise}) == 1))
         with torch.no_grad():
             for bt in step_batches(loader, dev, nb_max if slab_able else 1, loader_cache_view(dev, loader),
-                                   stageable=lambda x0: x0.shape[1] % 16 == 0):
+                                   stageable=lambda x0: x0.shape[1] % 16 == 0, pad_multiple=int(os.environ.get("ADVMIL_SLAB_PAD", "256"))):
                 if bt.staged:
                     slab_batch(bt)
                 else:

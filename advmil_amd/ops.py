@@ -70,6 +70,15 @@ def _ws(nbytes, device):
 # ---------------------------------------------------------------------------------------
 # counter RNG state (seed in device memory so HIP graphs can replay with fresh randomness)
 # ---------------------------------------------------------------------------------------
+class IdentityRows:
+    """A row layout of the step whose rows draw at their own index (entry of DeviceRng.rows: a single process whose slab carries
+    a zero-row pad maps only the stacked layouts; the kernels then skip the per-row lookup)."""
+    __slots__ = ("shape",)
+
+    def __init__(self, n):
+        self.shape = (int(n),)
+
+
 class DeviceRng:
     def __init__(self, device, seed=0):
         self.device = torch.device(device)
@@ -117,7 +126,7 @@ class DeviceRng:
         for k in kinds:
             m = self.rows.get(k)
             if m is not None and m.shape[0] == int(n_rows):
-                return m
+                return None if isinstance(m, IdentityRows) else m
         raise RuntimeError(f"bag-parallel: site '{tag}' was given {int(n_rows)} rows, none of its layouts {kinds} has that many "
                            f"({ {k: int(v.shape[0]) for k, v in self.rows.items()} })")
 

@@ -109,14 +109,18 @@ class BagParallel:
         return flat
 
 
-def rng_row_maps(all_lens, W, r, cluster=False):
+def rng_row_maps(all_lens, W, r, cluster=False, pads=None):
     """Host side of the world-size-invariant randomness. `all_lens[q][j]` = patch rows of rank q's j-th bag of the step; this
     rank's bag j is bag j*W + r of the global step batch, whose single-process slab stacks the bags in global order.
     Returns ({layout kind: int64 array local row -> single-process row}, per-bag region-row offsets for the attention kernels).
     Kinds (the layouts a slab-level tensor of the step can have; every dropout / noise call site names the kinds it can be fed,
     ops.SITE_LAYOUTS, so two layouts that happen to have the same row count never get confused):
       patch [sum N], region [sum N/16], region2 [2 sum N/16] (the D update's stacked fake|real region rows), bag [n],
-      bag2 [2n] (the stacked tail rows), cluster [8n] (DeepAttMISL's cluster rows)."""
+      bag2 [2n] (the stacked tail rows), cluster [8n] (DeepAttMISL's cluster rows).
+    `pads[q]`: zero rows rank q appends to its slab (ingest.SlabStager.pad_rows: a dummy bag behind the real ones). Its rows draw at
+    indices BEHIND every real row of the single-process slab, so the real rows' draws do not depend on the pad either (W = 1 with a
+    pad uses these maps too: a padded step draws exactly what the unpadded step draws). The dummy bag is dropped before any
+    bag-level site, so `bag` / `bag2` stay [n] / [2n]; `cluster` and the attention offsets get one more bag."""
     import numpy as np
     lens = list(all_lens[r])
     n = len(lens)
@@ -128,12 +132,27 @@ def rng_row_maps(all_lens, W, r, cluster=False):
     region = np.concatenate([goff[gi[j]] // 16 + np.arange(lens[j] // 16, dtype=np.int64) for j in range(n)])
     bags = np.asarray(gi, dtype=np.int64)
     SLg = int(goff[-1]) // 16
-    maps = {"patch": patch, "region": region, "region2": np.concatenate([region, SLg + region]), "bag": bags,
-            "bag2": np.concatenate([bags, G + bags])}
+    pad = 0 if pads is None else int(pads[r])
+    if pad:
+        before, ptot = int(sum(pads[:r])), int(sum(pads))
+        p16 = (pad + 15) // 16
+        b16, t16 = (before + 15) // 16 + r, (ptot + 15) // 16 + W           # (disjoint per rank whatever the pads' remainders)
+        patch = np.concatenate([patch, int(goff[-1]) + before + np.arange(pad, dtype=np.int64)])
+        padA = 2 * SLg + b16 + np.arange(p16, dtype=np.int64)
+        region2 = np.concatenate([region, padA, SLg + region, padA + t16])
+        region = np.concatenate([region, padA])
+    else:
+        region2 = np.concatenate([region, SLg + region])
+    maps = {"patch": patch, "region": region, "region2": region2, "bag": bags, "bag2": np.concatenate([bags, G + bags])}
     if cluster:
-        maps["cluster"] = np.concatenate([8 * g_ + np.arange(8, dtype=np.int64) for g_ in gi])
-    loc16 = np.concatenate([[0], np.cumsum([v // 16 for v in lens])])[:-1]
-    off16 = np.asarray([goff[gi[j]] // 16 - loc16[j] for j in range(n)], dtype=np.int64)
+        cl = [8 * g_ + np.arange(8, dtype=np.int64) for g_ in gi]
+        if pad:
+            cl.append(8 * (G + r) + np.arange(8, dtype=np.int64))
+        maps["cluster"] = np.concatenate(cl)
+    seg_lens = lens + [pad] if pad else lens
+    loc16 = np.concatenate([[0], np.cumsum([v // 16 for v in seg_lens])])[:-1]
+    first16 = [goff[gi[j]] // 16 for j in range(n)] + ([2 * SLg + b16] if pad else [])
+    off16 = np.asarray([first16[j] - loc16[j] for j in range(len(seg_lens))], dtype=np.int64)
     return maps, off16
 
 

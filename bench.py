@@ -357,7 +357,9 @@ def product_loop(args, torch, dev, case):
     nsteps, base = (30 if args.patches <= 8192 else 8), args.patches
     fr = (0.75, 1.0, 1.25, 0.5, 1.5, 1.0, 0.875, 1.125)                      # ragged: 0.5x .. 1.5x the nominal size
     nbag = args.bags * (nsteps + 2)
-    lens = [int(base * fr[i % len(fr)]) // 16 * 16 for i in range(nbag)]
+    # (minus a few 16-row regions per bag: the rows of a real step batch are a multiple of 16, not of the slab kernels' 256-row tiles --
+    # the loop pads the staged slab with zero rows, ingest.SlabStager.pad_rows)
+    lens = [int(base * fr[i % len(fr)]) // 16 * 16 - 16 * ((i * 7) % 11) for i in range(nbag)]
     distinct = min(nbag, 64 if args.patches <= 8192 else 16)                   # distinct host bags (pinned): 64 x 33.5 MB = 2.1 GB
     hostpool = [torch.randn(1, lens[i], 1024, generator=gcpu).pin_memory() for i in range(distinct)]
     # the loader's patient index IS the cache key: bag i of the epoch is patient i mod `distinct`

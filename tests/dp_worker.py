@@ -14,6 +14,9 @@ LENS = (256, 128, 64, 192, 320, 96, 160, 224)       # 2 steps x 4 bags (global),
 # `collide`: per rank 2 bags of 32 patches per step -> 2n = 4 stacked tail rows AND sum N / 16 = 4 region rows: two different
 # layouts with the same row count (the row maps are keyed by call site, not by row count)
 LENS_COLLIDE = (32, 32, 32, 32, 32, 32, 32, 32)
+# `pad`: slabs large enough for the zero-row pad of the staging slab (>= 4096 rows, not a multiple of 256) -- with two ranks each
+# pads its own half of the step batch (different pads per rank and per step), the single process pads the whole batch
+LENS_PAD = (2064, 2208, 2576, 2128, 2320, 2096, 2704, 2240)
 
 
 def build_loader(kind, idxs, lens=LENS):
@@ -22,7 +25,7 @@ def build_loader(kind, idxs, lens=LENS):
     from tests import helpers as H
     loader = []
     for i in idxs:
-        x = H.bag(300 + i, 512)[:, :lens[i]].contiguous()
+        x = H.bag(300 + i, max(512, max(lens)))[:, :lens[i]].contiguous()
         if kind == "graph":                  # PatchGCN: device-resident graph objects (x [N, C], edge_index [2, 8N]), as the bench feeds them
             x = x.to("cuda:0")
             ext = SimpleNamespace(x=x[0], edge_index=H.T(synth.grid_knn_graph(lens[i], 8), "cuda:0"))
@@ -40,6 +43,8 @@ def run(kind, world, rank, dp=None):
     lens = LENS
     if kind.endswith("-collide"):
         kind, lens = kind[:-len("-collide")], LENS_COLLIDE
+    elif kind.endswith("-pad"):
+        kind, lens = kind[:-len("-pad")], LENS_PAD
     cfg = default_cfg(bcb_mode=kind, bp_every_batch=4)         # the GLOBAL step batch: every rank steps after 4 / world of its bags
     if kind == "graph":
         cfg.update(bcb_dims="1024-128-128", gen_dims="128-1")

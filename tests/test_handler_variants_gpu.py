@@ -468,3 +468,40 @@ def test_two_generator_updates_per_step():
         if kk.endswith("pool.fc2.bias"):
             continue
         assert float((v.cpu() - PD2[kk]).abs().max()) < 5e-5, kk
+
+
+@pytest.mark.parametrize("kind", ["abmil", "patch", "cluster"])
+def test_slab_pad_is_numerically_neutral(kind, monkeypatch):
+    """The rows of a real step batch are a multiple of 16, not of the slab kernels' 256-row tiles: the staging slab appends zero rows
+    (a dummy bag, SlabStager.pad_rows) so that the fast forms apply. Two optimizer steps with the pad (default) against two steps
+    without it (ADVMIL_SLAB_PAD=0): predictions, D scores, logged losses and updated weights agree to round-off -- the pad rows
+    contribute exact zeros to every gradient -- and the padded run really took whole tiles."""
+    from advmil_amd.model import MyHandler
+    lens = (2048, 1040, 1536, 912)                         # 5536 rows per step: 5536 % 256 = 160 -> 96 pad rows
+
+    def run(pad):
+        monkeypatch.setenv("ADVMIL_SLAB_PAD", str(pad))
+        h = MyHandler(default_cfg(bcb_mode=kind, bp_every_batch=4, bag_cache_gb=0), device=DEV)
+        load_synth(h.netG, f"G-{kind}:"); load_synth(h.netD, "D-prj:")
+        h.rng.reset(77)
+        seen = []
+        orig = h._slab_build
+        h._slab_build = lambda xs, p=0: seen.append(int(orig(xs, p).shape[0])) or orig(xs, p)
+        loader = []
+        for i in range(8):
+            n = lens[i % 4]
+            ext = H.T(synth.cluster_ids(0, 600 + i, n)) if kind == "cluster" else torch.zeros(1, 1)
+            loader.append((torch.tensor([[i]], dtype=torch.int), [H.bag(600 + i, 2048)[:, :n].contiguous(), ext], H.label(i)))
+        cl = h._train_each_epoch(loader, "train")
+        return cl, h.pop_logs(), h.optimizerG.flat_param.clone(), h.optimizerD.flat_param.clone(), seen
+
+    a, b = run(256), run(0)
+    assert set(a[4]) == {5632} and set(b[4]) == {5536}
+    for k in ("y_hat", "f_fake"):
+        assert float((a[0][k] - b[0][k]).abs().max()) <= 2e-6, k
+    for la, lb in zip(a[1], b[1]):
+        for k in la:
+            assert abs(float(la[k]) - float(lb[k])) <= 2e-6 * max(1.0, abs(float(lb[k]))), k
+    for i in (2, 3):                                       # Adam turns round-off in g ~ 0 into 2 lr at most; the bulk must agree
+        d = (a[i] - b[i]).abs()
+        assert float(d.max()) <= 2.5e-4 and float((d > 1e-6).float().mean()) < 0.02, (i, float(d.max()), float((d > 1e-6).float().mean()))

@@ -164,3 +164,34 @@ def test_shard_epoch_gives_every_rank_the_same_number_of_steps():
     assert all(len(s) == 8 for s in shards)                  # 37 bags -> 2 global steps of 16 -> 8 bags per rank
     assert sorted(sum(shards, [])) == list(range(32))
     assert shards[1][:4] == [1, 5, 9, 13] and shards[1][4:] == [17, 21, 25, 29]
+
+
+def test_row_maps_with_slab_pads_leave_the_real_rows_draws_unchanged():
+    """A rank may append zero rows (a dummy bag) to its slab so that the slab kernels see whole tiles (ingest.SlabStager.pad_rows):
+    the real rows keep the single-process indices they have without the pad, the pad rows get indices behind every real row,
+    disjoint between ranks and between the two copies of the stacked region layout; W = 1 with a pad is the identity on real rows."""
+    import numpy as np
+    from advmil_amd.parallel import rng_row_maps
+    all_lens = [[64, 32], [48, 96]]
+    pads = [16, 160]
+    total = sum(sum(v) for v in all_lens)
+    seen_patch, seen_r2 = [], []
+    for r in range(2):
+        base, off0 = rng_row_maps(all_lens, 2, r, cluster=True)
+        padded, off1 = rng_row_maps(all_lens, 2, r, cluster=True, pads=pads)
+        nreal, lreal = sum(all_lens[r]), sum(all_lens[r]) // 16
+        assert np.array_equal(padded["patch"][:nreal], base["patch"]) and padded["patch"].shape[0] == nreal + pads[r]
+        assert padded["patch"][nreal:].min() >= total
+        assert np.array_equal(padded["region"][:lreal], base["region"]) and padded["region"].shape[0] == lreal + pads[r] // 16
+        p16 = pads[r] // 16
+        r2 = padded["region2"]
+        assert r2.shape[0] == 2 * (lreal + p16)
+        assert np.array_equal(np.concatenate([r2[:lreal], r2[lreal + p16:2 * lreal + p16]]), base["region2"])
+        assert np.array_equal(padded["bag"], base["bag"]) and np.array_equal(padded["bag2"], base["bag2"])
+        assert np.array_equal(padded["cluster"][:16], base["cluster"]) and padded["cluster"].shape[0] == 24
+        assert np.array_equal(off1[:2], off0) and off1.shape[0] == 3
+        seen_patch.append(padded["patch"][nreal:]); seen_r2.append(np.concatenate([r2[lreal:lreal + p16], r2[2 * lreal + p16:]]))
+        assert padded["region2"][lreal:lreal + p16].min() >= 2 * (total // 16)
+    assert len(np.unique(np.concatenate(seen_patch))) == sum(pads) and len(np.unique(np.concatenate(seen_r2))) == 2 * sum(pads) // 16
+    one, _ = rng_row_maps([[64, 32]], 1, 0, pads=[160])
+    assert np.array_equal(one["patch"][:96], np.arange(96)) and np.array_equal(one["region2"][6 + 10:6 + 10 + 6], 6 + np.arange(6))

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("kind", ["abmil", "patch", "cluster", "graph", "abmil-collide", "patch-collide"])
+@pytest.mark.parametrize("kind", ["abmil", "patch", "cluster", "graph", "abmil-collide", "patch-collide", "abmil-pad", "patch-pad", "cluster-pad"])
 def test_two_rank_step_equals_single_rank_with_dropout_on(kind, tmp_path):
     from tests import dp_worker
     want = dp_worker.run(kind, 1, 0)

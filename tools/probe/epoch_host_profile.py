@@ -22,6 +22,9 @@ g = torch.Generator().manual_seed(7)
 fr = (0.75, 1.0, 1.25, 0.5, 1.5, 1.0, 0.875, 1.125)
 nbag = bags * nsteps
 lens = [int(base * fr[i % len(fr)]) // 16 * 16 for i in range(nbag)]
+if os.environ.get("PROBE_ODD"):            # real cohorts: the rows of a step batch are a multiple of 16, not of 256
+    lens = [n + (16 * int(os.environ["PROBE_ODD"]) if i % 16 == 0 else 0) for i, n in enumerate(lens)]      # (negative: rows short of whole tiles)
+print("rows of the first step batch:", sum(lens[:16]), "mod 256 =", sum(lens[:16]) % 256)
 distinct = 64
 pool = [torch.randn(1, lens[i], 1024, generator=g).pin_memory() for i in range(distinct)]
 loader = [(torch.tensor([[i % distinct]], dtype=torch.int), [pool[i % distinct], torch.zeros(1, 1)],
