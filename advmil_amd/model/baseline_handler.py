@@ -86,8 +86,12 @@ class BaselineHandler(object):
         gb = self.cfg.get("bag_cache_gb")
         view = None
         if self.bcb != "graph" and (gb is None or float(gb) > 0):
-            view = loader_cache_view(self.device, train_loader, ("h", self.__dict__.setdefault("_cache_token", new_scope_token()), name_loader),
-                                     None if gb is None else float(gb) * 1e9)
+            scope = ("h", self.__dict__.setdefault("_cache_token", new_scope_token()), name_loader)
+            view = loader_cache_view(self.device, train_loader, scope, None if gb is None else float(gb) * 1e9)
+            if view is not None and view.scope == scope and scope not in self.__dict__.setdefault("_cache_scopes", set()):
+                import weakref
+                self._cache_scopes.add(scope)
+                weakref.finalize(self, view.cache.drop_scope, scope)     # this handler's bags leave the device's cache with it
         seen = 0
         for bt in step_batches(train_loader, self.device, bp, view, drop_last=True, group_unstaged=True,
                                stageable=lambda x0: self.bcb != "graph",

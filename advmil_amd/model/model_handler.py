@@ -308,7 +308,11 @@ class MyHandler(object):
             view = None
             gb = os.environ.get("ADVMIL_BAG_CACHE_GB", self.cfg.get("bag_cache_gb"))
             if scope is not False and (gb is None or float(gb) > 0):
-                view = BagCacheView(device_bag_cache(self.device, default_budget(self.device) if gb is None else float(gb) * 1e9), scope)
+                cache = device_bag_cache(self.device, default_budget(self.device) if gb is None else float(gb) * 1e9)
+                view = BagCacheView(cache, scope)
+                if scope[0] == "h":                  # bags scoped by this handler leave the device's cache with it
+                    import weakref
+                    weakref.finalize(self, cache.drop_scope, scope)
             caches[name_loader], scopes[name_loader] = view, scope
         return caches[name_loader]
 
