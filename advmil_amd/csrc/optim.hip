@@ -95,13 +95,51 @@ __global__ __launch_bounds__(256) void stage_bag_kernel(StageSpan a, StageSpan b
   }
   for (; i < sp.n16; i += stride) sp.dst[i] = sp.src[i];
 }
+// Same copy of the fp32 rows, with the two operand planes DERIVED on the way (hi = bf16(x), lo = bf16(x - hi): the rounding of
+// advmil_split_planes and of the contraction kernels' own staging): the cache then keeps 4 bytes per element instead of 8 and a staged
+// bag moves 12 bytes per element instead of 16. One thread = 8 consecutive floats (two 16-byte loads, two fp32 stores, one 16-byte
+// store per plane).
+__global__ __launch_bounds__(256) void stage_bag_split_kernel(const float* src, float* dst, int64_t n8, uint4* __restrict__ hi,
+                                                              uint4* __restrict__ lo) {
+  const bool copy = dst != src;                        // (in place: rows that just arrived over PCIe only get their planes)
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n8; idx += (int64_t)gridDim.x * 256) {
+    const float4 a = reinterpret_cast<const float4*>(src)[2 * idx], b = reinterpret_cast<const float4*>(src)[2 * idx + 1];
+    if (copy) {
+      reinterpret_cast<float4*>(dst)[2 * idx] = a;
+      reinterpret_cast<float4*>(dst)[2 * idx + 1] = b;
+    }
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    union { __bf16 v[8]; uint4 u; } h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      h.v[j] = (__bf16)x[j];
+      l.v[j] = (__bf16)(x[j] - (float)h.v[j]);
+    }
+    hi[idx] = h.u;
+    lo[idx] = l.u;
+  }
+}
+
 extern "C" int advmil_stage_bag(void* dst_rows, const void* src_rows, size_t rows_bytes, void* dst_hi, const void* src_hi, void* dst_lo,
                                 const void* src_lo, size_t plane_bytes, advmil_stream_t stream_) {
   if (!dst_rows || !src_rows || rows_bytes == 0 || (rows_bytes & 15)) return ADVMIL_EINVAL;
   const bool planes = dst_hi || src_hi || dst_lo || src_lo || plane_bytes;
-  if (planes && (!dst_hi || !src_hi || !dst_lo || !src_lo || plane_bytes == 0 || (plane_bytes & 15))) return ADVMIL_EINVAL;
+  const bool split = planes && !src_hi && !src_lo;                 // planes wanted, none held: derive them from the rows
+  if (planes && (!dst_hi || !dst_lo || plane_bytes == 0 || (plane_bytes & 15))) return ADVMIL_EINVAL;
+  if (planes && !split && (!src_hi || !src_lo)) return ADVMIL_EINVAL;
   if (((uintptr_t)dst_rows | (uintptr_t)src_rows | (uintptr_t)dst_hi | (uintptr_t)src_hi | (uintptr_t)dst_lo | (uintptr_t)src_lo) & 15)
     return ADVMIL_EINVAL;
+  if (split) {
+    if (plane_bytes * 2 != rows_bytes || (rows_bytes & 31)) return ADVMIL_EINVAL;      // bf16 planes of fp32 rows, 8 floats per thread
+    const int64_t n8 = (int64_t)(rows_bytes >> 5);
+    int64_t blocks = (n8 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(stage_bag_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, (const float*)src_rows,
+                       (float*)dst_rows, n8, (uint4*)dst_hi, (uint4*)dst_lo);
+    ADVMIL_LAUNCH_CHECK();
+    return ADVMIL_OK;
+  }
   StageSpan a{(uint4*)dst_rows, (const uint4*)src_rows, (int64_t)(rows_bytes >> 4)};
   StageSpan b{(uint4*)dst_hi, (const uint4*)src_hi, planes ? (int64_t)(plane_bytes >> 4) : 0};
   StageSpan c{(uint4*)dst_lo, (const uint4*)src_lo, planes ? (int64_t)(plane_bytes >> 4) : 0};

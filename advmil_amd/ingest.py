@@ -72,6 +72,7 @@ class SlabStager:
         self.views = []
         self.planes_rows = 0              # rows [0, planes_rows) of the current batch have their planes in self.pl[k]
         self.pad = 0                      # zero rows behind the batch (pad_rows): the step slab is rows + pad rows long
+        self.split = False                # derive every staged bag's bf16x3 operand planes on the copy stream (set per batch by begin())
 
     def _ensure(self, k, rows):
         cap = 0 if self.dev[k] is None else self.dev[k].shape[0]
@@ -110,6 +111,8 @@ class SlabStager:
 
     def begin(self):
         """Start staging a new step batch into the other buffer pair."""
+        from . import ops
+        self.split = bool(ops.USE_PLANES and ops.get_gemm_mode() == "bf16x3" and self.device.type == "cuda")
         self.k ^= 1
         if self.h2d_evt[self.k] is not None:                     # the pinned slab / kept loader tensors of this pair may still be DMA sources
             self.h2d_evt[self.k].synchronize()
@@ -138,10 +141,22 @@ class SlabStager:
             src = self.host[k][a:b]
         with torch.cuda.stream(self.copy_stream):
             self.dev[k][a:b].copy_(src, non_blocking=True)
+        if self.split and self.planes_rows == a and self._split_ok(n):
+            # the bag's operand planes behind its H2D copy, on the copy stream: the step slab's planes are complete when it is
+            self._ensure_planes(k)
+            from . import _lib
+            C, dst, pl = self.channels, self.dev[k], self.pl[k]
+            p0 = dst.data_ptr() + a * C * 4
+            if _lib.lib().advmil_stage_bag(p0, p0, n * C * 4, pl.hi.data_ptr() + a * C * 2, None, pl.lo.data_ptr() + a * C * 2, None,
+                                           n * C * 2, self.copy_stream.cuda_stream) == 0:
+                self.planes_rows = b
         self.rows = b
         if len(self.views) < len(self._spans):
             self.views.append(self.dev[k][a:b].unsqueeze(0))
         return self.views[-1]
+
+    def _split_ok(self, n):
+        return self.dtype == torch.float32 and (n * self.channels) % 8 == 0
 
     def add_device(self, x_dev, planes=None, ready_evt=None):
         """Stage one bag that is ALREADY in HBM (the device-resident bag cache): device-to-device copies of its fp32 rows -- and of
@@ -153,7 +168,8 @@ class SlabStager:
         self._spans.append((self.rows, self.rows + n))
         self._ensure(k, self.rows + n)
         a, b = self.rows, self.rows + n
-        with_planes = planes is not None and self.planes_rows == a
+        derive = planes is None and self.split and self._split_ok(n)        # fp32-only cache entry: planes made on the way
+        with_planes = (planes is not None or derive) and self.planes_rows == a
         if with_planes:
             self._ensure_planes(k)
         if ready_evt is not None:
@@ -167,15 +183,17 @@ class SlabStager:
         pl = self.pl[k] if with_planes else None
         rc = _lib.lib().advmil_stage_bag(
             dst.data_ptr() + a * C * esz, x2.data_ptr(), n * C * esz,
-            None if pl is None else pl.hi.data_ptr() + a * C * 2, None if pl is None else planes.hi.data_ptr(),
-            None if pl is None else pl.lo.data_ptr() + a * C * 2, None if pl is None else planes.lo.data_ptr(),
+            None if pl is None else pl.hi.data_ptr() + a * C * 2, None if (pl is None or derive) else planes.hi.data_ptr(),
+            None if pl is None else pl.lo.data_ptr() + a * C * 2, None if (pl is None or derive) else planes.lo.data_ptr(),
             0 if pl is None else n * C * 2, self.copy_stream.cuda_stream)
         if rc != 0:                                   # unaligned rows (channels not a multiple of 8): the general copies
             with torch.cuda.stream(self.copy_stream):
                 dst[a:b].copy_(x2, non_blocking=True)
-                if pl is not None:
+                if pl is not None and not derive:
                     pl.hi[a:b].copy_(planes.hi.reshape(n, -1), non_blocking=True)
                     pl.lo[a:b].copy_(planes.lo.reshape(n, -1), non_blocking=True)
+                elif pl is not None:
+                    pl = None                         # (no planes for this batch: the step splits the slab)
         if pl is not None:
             self.planes_rows = b
         self._keep.append(x_dev)
@@ -229,18 +247,21 @@ class SlabStager:
 
 class BagCache:
     """Device-resident bags across epochs (replaces the per-bag, per-EPOCH `.cuda()` of reference
-    model/model_handler.py:315 / dataset/PatchWSI.py:65-83): the first time a bag (keyed by the loader's patient index) comes
-    through the staging slab it is copied once more, device to device, into its own HBM allocation together with its bf16x3
-    operand planes (the same 4 B per element again); from the second epoch on a step batch is assembled from the cached bags by
-    device-to-device copies of the fp32 rows and the two planes into the staging slab, issued on the copy stream while the step
-    before computes (SlabStager.add_device) -- no PCIe traffic, no per-step split, no gather on the compute stream. 288 GB hold a whole NLST-sized
-    cohort (8 B per element: ~4 000 bags of 8192 patches). LRU under a byte budget; a bag that does not fit is simply not kept."""
+    model/model_handler.py:315 / dataset/PatchWSI.py:65-83): the first time a bag comes through the staging slab it is copied once
+    more, device to device, into its own HBM allocation (fp32 rows: 4 B per element); from then on a step batch is assembled from
+    the cached bags by ONE launch per bag on the copy stream, while the step before computes (SlabStager.add_device ->
+    advmil_stage_bag), which writes the bag's rows into the staging slab and derives its two bf16x3 operand planes on the way -- no
+    PCIe traffic, no per-step split, no gather on the compute stream. 45 % of 288 GB hold ~3 900 bags of 8192 patches. One cache per
+    device, shared by the training loop and the evaluation passes (keys: (scope, patient index), BagCacheView). LRU under a byte
+    budget; a bag that does not fit is simply not kept."""
 
-    def __init__(self, device, budget_bytes, with_planes=True):
+    def __init__(self, device, budget_bytes, with_planes=None):
         from collections import OrderedDict
         self.device = torch.device(device)
         self.budget = int(budget_bytes)
-        self.with_planes = with_planes
+        # fp32 rows only by default: the staging launch derives the operand planes on the way into the step slab (advmil_stage_bag's
+        # split form: 12 bytes moved per element instead of 16, 4 bytes held instead of 8). ADVMIL_CACHE_PLANES=1 keeps the planes too.
+        self.with_planes = (os.environ.get("ADVMIL_CACHE_PLANES", "0") == "1") if with_planes is None else with_planes
         self.entries = OrderedDict()      # key -> (x [1, N, C] fp32 device tensor carrying `_advmil_bag_planes`, bytes)
         self.bytes = 0
         self.hits = self.misses = self.evictions = 0

@@ -281,7 +281,10 @@ size_t advmil_abs_sum_workspace_bytes(int64_t n);
 
 /* Bag ingest from the device-resident bag cache (replaces the per-bag, per-epoch `.cuda()` of model/model_handler.py:315 for a bag
  * that has been seen before): one launch copies rows_bytes of fp32 rows and, when the four plane pointers are given, plane_bytes of
- * each bf16 operand plane, device to device, into the step slab. All pointers and sizes multiples of 16 bytes; planes all or none. */
+ * each bf16 operand plane, device to device, into the step slab. All pointers and sizes multiples of 16 bytes; planes all or none.
+ * dst_hi / dst_lo given with src_hi = src_lo = NULL: the planes are DERIVED from the fp32 rows on the way (hi = bf16(x), lo = bf16(x - hi),
+ * as advmil_split_planes; plane_bytes = rows_bytes / 2) -- the cache then holds the fp32 rows only. src == dst rows is allowed in that
+ * form (split in place of rows that just arrived over PCIe). */
 int advmil_stage_bag(void* dst_rows, const void* src_rows, size_t rows_bytes, void* dst_hi, const void* src_hi, void* dst_lo,
                      const void* src_lo, size_t plane_bytes, advmil_stream_t stream);
 /* fill out[i] = U[0,1) from the counter RNG (generator noise, utils/func.py:154-164) */

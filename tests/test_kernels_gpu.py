@@ -590,3 +590,42 @@ def test_skinny_linear_fwd_bwd(ops, B, K, N, act):
     (ref * w.cpu().double()).sum().backward()
     for a, c in zip(got, (ref.detach(), xc.grad, Wc.grad, bc_.grad)):
         assert float((a.cpu().double() - c).abs().max()) < 1e-5 * (1.0 + float(c.abs().max()))
+
+
+def test_stage_bag_copies_rows_and_derives_or_copies_planes():
+    """advmil_stage_bag (ingest of a cached bag into the step slab, one launch): the copy form moves the fp32 rows and both planes; the
+    split form (no source planes) derives hi / lo on the way, bit for bit what advmil_split_planes gives; in place (src == dst) it only
+    writes the planes; misaligned / inconsistent arguments are refused."""
+    import ctypes
+    from advmil_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    x = torch.randn(1040, 1024, device=dev)
+    want = ops.split_planes(x)
+    L = _lib.lib()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    slab = torch.full((2048, 1024), float("nan"), device=dev)
+    pl = ops.Planes.alloc((2048, 1024), dev)
+    pl.hi.zero_(); pl.lo.zero_()
+    a = 512
+    nb = x.numel() * 4
+    assert L.advmil_stage_bag(slab.data_ptr() + a * 4096, x.data_ptr(), nb, pl.hi.data_ptr() + a * 2048, None, pl.lo.data_ptr() + a * 2048,
+                              None, nb // 2, st) == 0
+    assert torch.equal(slab[a:a + 1040], x) and torch.isnan(slab[:a]).all() and torch.isnan(slab[a + 1040:]).all()
+    assert torch.equal(pl.hi[a:a + 1040].view(torch.int16), want.hi.view(torch.int16))
+    assert torch.equal(pl.lo[a:a + 1040].view(torch.int16), want.lo.view(torch.int16))
+    assert int(pl.hi[:a].view(torch.int16).abs().max()) == 0 and int(pl.hi[a + 1040:].view(torch.int16).abs().max()) == 0
+    # copy form
+    slab2 = torch.zeros(1040, 1024, device=dev)
+    pl2 = ops.Planes.alloc((1040, 1024), dev)
+    assert L.advmil_stage_bag(slab2.data_ptr(), x.data_ptr(), nb, pl2.hi.data_ptr(), want.hi.data_ptr(), pl2.lo.data_ptr(),
+                              want.lo.data_ptr(), nb // 2, st) == 0
+    assert torch.equal(slab2, x) and torch.equal(pl2.hi.view(torch.int16), want.hi.view(torch.int16))
+    assert torch.equal(pl2.lo.view(torch.int16), want.lo.view(torch.int16))
+    # in place: planes only
+    pl3 = ops.Planes.alloc((1040, 1024), dev)
+    assert L.advmil_stage_bag(x.data_ptr(), x.data_ptr(), nb, pl3.hi.data_ptr(), None, pl3.lo.data_ptr(), None, nb // 2, st) == 0
+    assert torch.equal(pl3.lo.view(torch.int16), want.lo.view(torch.int16)) and torch.equal(slab2, x)
+    EINVAL = -1
+    assert L.advmil_stage_bag(slab2.data_ptr(), x.data_ptr(), nb, pl2.hi.data_ptr(), None, pl2.lo.data_ptr(), None, nb // 2 - 16, st) == EINVAL
+    assert L.advmil_stage_bag(slab2.data_ptr() + 4, x.data_ptr(), nb - 16, None, None, None, None, 0, st) == EINVAL
+    assert L.advmil_stage_bag(slab2.data_ptr(), x.data_ptr(), nb, pl2.hi.data_ptr(), want.hi.data_ptr(), pl2.lo.data_ptr(), None, nb // 2, st) == EINVAL
