@@ -284,11 +284,143 @@ __global__ __launch_bounds__(256) void pool_partial8_kernel(const float* __restr
   }
 }
 
+// ---- two-launch form of the pooling call (D % 8 == 0): no separate statistics pass.
+// Launch 1: every workgroup softmax-weights ITS rows against its own maximum (online softmax: m_j = max of the block's scores,
+// w_n = exp(s_n - m_j) kept in LDS -- one exponential per row instead of one per thread and row --, l_j = sum w_n) and leaves
+// partial_j = sum w_n h_n with (m_j, l_j). Launch 2, per segment and 16-column block: M = max m_j, c_j = exp(m_j - M), L = sum l_j c_j
+// (fixed order: deterministic, and identical in every workgroup of the segment), pooled = sum_j c_j partial_j / L, and the workgroups of
+// a segment share out its rows to write A_n = exp(s_n - M) / L. Same contract as softmax_stats + pool_partial8 + colsum_merge.
+__global__ __launch_bounds__(256) void pool_partial8_online_kernel(const float* __restrict__ s, const float* __restrict__ h, int64_t ldh,
+                                                                   int64_t N, int64_t D, const int64_t* __restrict__ seg_ptr,
+                                                                   float* __restrict__ partial, float* __restrict__ pstats, int rpb) {
+  __shared__ __attribute__((aligned(16))) float red[2048];      // rpp * D <= 256 / (D/8) * D = 2048 floats
+  __shared__ float wts[512];                                    // rows_per_block <= 512
+  __shared__ float wred[8];
+  const int cols8 = (int)(D >> 3), rpp = 256 / cols8;
+  const int c8 = threadIdx.x % cols8, rl = threadIdx.x / cols8;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int b = blockIdx.y;
+  int64_t beg, end;
+  seg_range(seg_ptr, b, N, beg, end);
+  const int64_t r0 = beg + (int64_t)blockIdx.x * rpb;
+  float* pst = pstats + ((int64_t)b * gridDim.x + blockIdx.x) * 2;
+  float* prow = partial + ((int64_t)b * gridDim.x + blockIdx.x) * D;
+  if (r0 >= end) {                                              // past the segment's end: an empty block (weight 0 in the merge)
+    if (tid < (int)(D >> 2)) *reinterpret_cast<float4*>(prow + tid * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid == 0) { pst[0] = -INFINITY; pst[1] = 0.f; }
+    return;
+  }
+  float mx = -INFINITY;
+  for (int r = tid; r < rpb; r += 256) {
+    const int64_t n = r0 + r;
+    const float v = n < end ? s[n] : -INFINITY;
+    wts[r] = v;
+    mx = fmaxf(mx, v);
+  }
+  mx = wave_max(mx);
+  if (lane == 0) wred[w] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+  float ls = 0.f;
+  for (int r = tid; r < rpb; r += 256) {
+    const float e = (r0 + r < end) ? hw_exp(wts[r] - mx) : 0.f;
+    wts[r] = e;
+    ls += e;
+  }
+  ls = wave_sum(ls);
+  if (lane == 0) wred[4 + w] = ls;
+  __syncthreads();
+  if (tid == 0) { pst[0] = mx; pst[1] = (wred[4] + wred[5]) + (wred[6] + wred[7]); }
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (rl < rpp) {
+#pragma unroll 4
+    for (int r = rl; r < rpb; r += rpp) {
+      const int64_t n = r0 + r;
+      const int64_t nn = n < end ? n : beg;                // predicated: keeps the unrolled loads independent of the bound (weight 0)
+      const float wgt = wts[r];
+      const float4 v0 = *reinterpret_cast<const float4*>(h + nn * ldh + c8 * 8);
+      const float4 v1 = *reinterpret_cast<const float4*>(h + nn * ldh + c8 * 8 + 4);
+      acc[0] += wgt * v0.x; acc[1] += wgt * v0.y; acc[2] += wgt * v0.z; acc[3] += wgt * v0.w;
+      acc[4] += wgt * v1.x; acc[5] += wgt * v1.y; acc[6] += wgt * v1.z; acc[7] += wgt * v1.w;
+    }
+    float* dst = red + (int64_t)rl * D + c8 * 8;
+    *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
+  __syncthreads();
+  if (tid < (int)(D >> 2)) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < rpp; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(red + (int64_t)q * D + tid * 4);
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    *reinterpret_cast<float4*>(prow + tid * 4) = t;
+  }
+}
+
+#define POOL_ONLINE_MAX_NBLK 2048
+__global__ __launch_bounds__(256) void pool_merge_online_kernel(const float* __restrict__ partial, const float* __restrict__ pstats, int nblk,
+                                                                int64_t D, const float* __restrict__ s, int64_t N,
+                                                                const int64_t* __restrict__ seg_ptr, float* __restrict__ pooled,
+                                                                float* __restrict__ A, float* __restrict__ stats) {
+  __shared__ float sc[POOL_ONLINE_MAX_NBLK];
+  __shared__ float red[16][17];
+  __shared__ float wred[8];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int b = blockIdx.y;
+  const float* pst = pstats + (int64_t)b * nblk * 2;
+  float mx = -INFINITY;
+  for (int j = tid; j < nblk; j += 256) mx = fmaxf(mx, pst[2 * j]);
+  mx = wave_max(mx);
+  if (lane == 0) wred[w] = mx;
+  __syncthreads();
+  const float M = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+  float ls = 0.f;
+  for (int j = tid; j < nblk; j += 256) {
+    const float mj = pst[2 * j];
+    const float c = mj == -INFINITY ? 0.f : hw_exp(mj - M);
+    sc[j] = c;
+    ls += pst[2 * j + 1] * c;
+  }
+  ls = wave_sum(ls);
+  if (lane == 0) wred[4 + w] = ls;
+  __syncthreads();
+  const float inv = hw_rcp((wred[4] + wred[5]) + (wred[6] + wred[7]));
+  if (blockIdx.x == 0 && tid == 0 && stats) { stats[2 * b] = M; stats[2 * b + 1] = inv; }
+  // pooled: this workgroup's 16 columns over the segment's partial rows (16 row-lanes, folded in order)
+  const int cl = tid & 15, rl = tid >> 4;
+  const int64_t c = (int64_t)blockIdx.x * 16 + cl;
+  const float* pp = partial + (int64_t)b * nblk * D;
+  float sv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < D) {
+    int j = rl;
+    for (; j + 48 < nblk; j += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sv[u] += pp[(int64_t)(j + 16 * u) * D + c] * sc[j + 16 * u];
+    }
+    for (; j < nblk; j += 16) sv[0] += pp[(int64_t)j * D + c] * sc[j];
+  }
+  red[rl][cl] = (sv[0] + sv[1]) + (sv[2] + sv[3]);
+  __syncthreads();
+  if (rl == 0 && c < D) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += red[r][cl];
+    pooled[(int64_t)b * D + c] = t * inv;
+  }
+  // A: the workgroups of the segment share out its rows
+  int64_t beg, end;
+  seg_range(seg_ptr, b, N, beg, end);
+  for (int64_t n = beg + (int64_t)blockIdx.x * 256 + tid; n < end; n += (int64_t)gridDim.x * 256) A[n] = hw_exp(s[n] - M) * inv;
+}
+
 static inline int64_t pool_nblk(int64_t max_len) { const int r = rows_per_block(max_len); return (max_len + r - 1) / r; }
 
 extern "C" size_t advmil_softmax_pool_workspace_bytes(int64_t max_len, int64_t D, int nseg) {
   if (nseg < 1) nseg = 1;
-  const int64_t a = 4 * (int64_t)nseg + (int64_t)nseg * pool_nblk(max_len) * D;   // fwd: stats + partials
+  const int64_t a = 4 * (int64_t)nseg + (int64_t)nseg * pool_nblk(max_len) * (D + 2);   // fwd: stats + partials (+ per-block (m, l))
   const int64_t b = 4 + (int64_t)nseg * ((max_len + 3) / 4);                       // bwd: per-workgroup partials of sum A t
   return (size_t)(a > b ? a : b) * sizeof(float);
 }
@@ -306,6 +438,16 @@ extern "C" int advmil_softmax_pool_fwd(const float* s, const float* h, int64_t l
   float* stats = (float*)ws;
   float* partial = stats + 4 * nseg;
   const int nblk = (int)pool_nblk(max_len);
+  if ((D & 7) == 0 && D >= 16 && nblk <= POOL_ONLINE_MAX_NBLK) {     // two launches: online-softmax partials, then merge + A
+    float* pstats = partial + (int64_t)nseg * nblk * D;
+    hipLaunchKernelGGL(pool_partial8_online_kernel, dim3(nblk, nseg), dim3(256), 0, stream, s, h, ldh, N, D, seg_ptr, partial, pstats,
+                       rows_per_block(max_len));
+    ADVMIL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pool_merge_online_kernel, dim3((unsigned)((D + 15) / 16), nseg), dim3(256), 0, stream, partial, pstats, nblk, D, s,
+                       N, seg_ptr, pooled, A, stats);
+    ADVMIL_LAUNCH_CHECK();
+    return ADVMIL_OK;
+  }
   hipLaunchKernelGGL(softmax_stats_kernel, dim3(nseg), dim3(1024), 0, stream, s, N, seg_ptr, stats);
   ADVMIL_LAUNCH_CHECK();
   if ((D & 7) == 0 && D >= 16)

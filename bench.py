@@ -307,7 +307,7 @@ def pool_roofline(torch, ops, dev, patches, bags, iters=40):
 
     usp = event_time_us(torch, call, iters)
     byt = 4.0 * nrows * Dh + 3 * 4.0 * nrows
-    return {"bound": "hbm", "kernel": "softmax_stats + pool_partial8 + colsum_merge (advmil_softmax_pool_fwd, 3 launches)",
+    return {"bound": "hbm", "kernel": "pool_partial8_online + pool_merge_online (advmil_softmax_pool_fwd, 2 launches: online-softmax partials, merge + A)",
             "rows": nrows, "bags": bags, "achieved": round(byt / usp / 1e3, 1), "peak": 8000.0, "unit": "GB/s",
             "frac": round(byt / usp / 1e3 / 8000.0, 4), "avg_call_us": round(usp, 2), "algorithmic_bytes_per_call": byt,
             "rotating_slabs": nbuf,
