@@ -66,12 +66,14 @@ if fe:
                       "durations: rocprofv3 --kernel-trace --stats -- python3 tools/pool_bench.py 8192 16 40 (and 8192 1 200)",
            "units": "FETCH_SIZE / WRITE_SIZE are KB; FETCH_SIZE x2 (gfx950: wide coalesced reads tallied at half their bytes)",
            "rows": rows, "D": D, "kernels": {}}
-    for k in ("pool_partial8_kernel", "pool_bwd_dot_kernel", "softmax_stats_kernel", "pool_bwd_ds_kernel", "colsum_merge_kernel"):
+    for k in ("pool_partial8_online_kernel", "pool_merge_online_kernel", "pool_partial8_kernel", "pool_bwd_dot_kernel", "softmax_stats_kernel",
+              "pool_bwd_ds_kernel", "colsum_merge_kernel"):
         if k not in fe:
             continue
         fetched = 2.0 * fe[k][1] * 1024
         written = wr.get(k, (0, 0.0))[1] * 1024
-        alg = {"pool_partial8_kernel": 4.0 * rows * D + 4.0 * rows, "pool_bwd_dot_kernel": 4.0 * rows * D + 8.0 * rows}.get(k)
+        alg = {"pool_partial8_kernel": 4.0 * rows * D + 4.0 * rows, "pool_partial8_online_kernel": 4.0 * rows * D + 4.0 * rows,
+               "pool_bwd_dot_kernel": 4.0 * rows * D + 8.0 * rows}.get(k)
         ent = {"fetch_bytes_per_launch": fetched, "write_bytes_per_launch": written, "hbm_bytes_per_launch": fetched + written,
                "algorithmic_bytes_per_launch": alg}
         if k in st16:
