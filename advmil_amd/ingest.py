@@ -1,11 +1,18 @@
-"""Bag ingest for the step slab (replaces the synchronous pageable `.cuda()` per bag at
-reference model/model_handler.py:315).
+"""Bag ingest for the step slab (replaces the synchronous pageable `.cuda()` per bag and per epoch at reference
+model/model_handler.py:315, and the same in its evaluation loop, 598-643).
 
-The loader hands over CPU tensors `x[1, N, 1024]`. `SlabStager` owns two (pinned host slab, device slab) pairs. Each bag is
-memcpy'd into the pinned slab and sent to the device slab with an async H2D copy on a dedicated copy stream, so
-  * the bags of one optimizer step land BACK TO BACK in HBM -> the step's `[sum N, 1024]` matrix is a zero-copy view;
-  * while step t computes on pair k, the host already stages step t+1 into pair k^1 (PCIe overlaps compute);
-  * a pair is only rewritten after the step that read it has finished (event from the compute stream).
+The loader hands over CPU tensors `x[1, N, 1024]`. `SlabStager` owns two (pinned host slab, device slab, device plane slab) sets.
+  * A NEW bag is copied into the pinned slab (pageable source: a small pool of copy threads, `host_copy_rows`; a pinned source is
+    DMA'd directly) and sent to the device slab with an async H2D copy on a dedicated copy stream; one launch behind it derives its
+    bf16x3 operand planes (`advmil_stage_bag`, split form).
+  * A bag SEEN BEFORE comes out of the device-resident `BagCache` (one per device, fp32 rows, LRU under a byte budget, shared by the
+    training loop and the evaluation passes through `BagCacheView`s scoped by dataset object): one launch on the copy stream writes
+    its rows into the slab and derives the planes on the way.
+  * The bags of one optimizer step land BACK TO BACK in HBM -> the step's `[sum N, 1024]` matrix and its planes are zero-copy views;
+    `pad_rows` appends zero rows up to whole 256-row tiles (a dummy bag the handlers drop after pooling).
+  * While step t computes on set k, the host already stages step t+1 into set k^1 (PCIe / D2D overlap compute); a set is only
+    rewritten after the step that read it has finished (event from the compute stream).
+`step_batches` is the generator both handlers' loops and evaluations are built on.
 """
 import os
 
@@ -66,7 +73,7 @@ class SlabStager:
         self.dev = [None, None]
         self.free_evt = [None, None]      # recorded on the compute stream when the step reading pair k is enqueued
         self.h2d_evt = [None, None]       # recorded on the copy stream when pair k's H2D copies are all enqueued
-        self.pl = [None, None]            # operand planes of the device slabs (allocated when a cached bag brings its planes)
+        self.pl = [None, None]            # bf16x3 operand planes of the device slabs (allocated with the first batch that needs them)
         self.k = 1
         self.rows = 0
         self.views = []
