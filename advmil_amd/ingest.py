@@ -260,7 +260,7 @@ class BagCache:
     advmil_stage_bag), which writes the bag's rows into the staging slab and derives its two bf16x3 operand planes on the way -- no
     PCIe traffic, no per-step split, no gather on the compute stream. 45 % of 288 GB hold ~3 900 bags of 8192 patches. One cache per
     device, shared by the training loop and the evaluation passes (keys: (scope, patient index), BagCacheView). LRU under a byte
-    budget; a bag that does not fit is simply not kept."""
+    budget (with an admission rule for cohorts larger than the budget, see `put`); a bag that does not fit is simply not kept."""
 
     def __init__(self, device, budget_bytes, with_planes=None):
         from collections import OrderedDict
@@ -269,16 +269,19 @@ class BagCache:
         # fp32 rows only by default: the staging launch derives the operand planes on the way into the step slab (advmil_stage_bag's
         # split form: 12 bytes moved per element instead of 16, 4 bytes held instead of 8). ADVMIL_CACHE_PLANES=1 keeps the planes too.
         self.with_planes = (os.environ.get("ADVMIL_CACHE_PLANES", "0") == "1") if with_planes is None else with_planes
-        self.entries = OrderedDict()      # key -> (x [1, N, C] fp32 device tensor carrying `_advmil_bag_planes`, bytes)
+        self.entries = OrderedDict()      # key -> [x [1, N, C] fp32 device tensor (+ `_advmil_bag_planes`), bytes, tick of its last use]
         self.bytes = 0
-        self.hits = self.misses = self.evictions = 0
+        self.hits = self.misses = self.evictions = self.refused = 0
+        self.tick = 0                     # counts lookups: the clock of the admission rule in `put`
 
     def get(self, key):
+        self.tick += 1
         ent = self.entries.get(key)
         if ent is None:
             self.misses += 1
             return None
         self.entries.move_to_end(key)
+        ent[2] = self.tick
         self.hits += 1
         return ent[0]
 
@@ -291,24 +294,32 @@ class BagCache:
         nbytes = x_dev.numel() * (8 if planes else 4)
         if nbytes > self.budget:
             return
+        # Admission when full. An epoch visits every bag once, in a new order: plain LRU over a cohort larger than the budget evicts
+        # exactly the bags the next epoch needs (measured: 4 GB budget, 9 GB cohort -> 2 % hits, and every miss also paid for its
+        # insertion). So a bag only displaces entries that have gone UNUSED for a long time -- 16 x the number of resident bags in
+        # lookups, i.e. bags of a dataset that is no longer iterated; otherwise the resident set stays as it is and the hit rate is
+        # the resident fraction of the cohort (same run: 43 % hits).
+        stale_after = 16 * max(len(self.entries), 64)
         while self.bytes + nbytes > self.budget and self.entries:
-            _, (_, b) = self.entries.popitem(last=False)
-            self.bytes -= b
+            k0 = next(iter(self.entries))
+            if self.tick - self.entries[k0][2] <= stale_after:
+                self.refused += 1
+                return
+            self.bytes -= self.entries.pop(k0)[1]
             self.evictions += 1
         x = x_dev.clone()
         if planes:
             x._advmil_bag_planes = ops.split_planes(x.view(-1, x.shape[-1]))
         x._advmil_ready = torch.cuda.Event()          # the copy stream that later reads this entry waits for it
         x._advmil_ready.record(torch.cuda.current_stream(self.device))
-        self.entries[key] = (x, nbytes)
+        self.entries[key] = [x, nbytes, self.tick]
         self.bytes += nbytes
 
     def set_budget(self, budget_bytes):
         """Change the byte budget (the last handler / evaluation to ask decides); evicts down to it at once."""
         self.budget = int(budget_bytes)
         while self.bytes > self.budget and self.entries:
-            _, (_, b) = self.entries.popitem(last=False)
-            self.bytes -= b
+            self.bytes -= self.entries.popitem(last=False)[1][1]
             self.evictions += 1
 
     def clear(self):
@@ -322,7 +333,7 @@ class BagCache:
 
     def stats(self):
         return {"bags": len(self.entries), "gb": round(self.bytes / 1e9, 3), "hits": self.hits, "misses": self.misses,
-                "evictions": self.evictions}
+                "evictions": self.evictions, "refused": self.refused}
 
 
 class BagCacheView:
@@ -333,7 +344,7 @@ class BagCacheView:
     def __init__(self, cache, scope):
         self.cache, self.scope = cache, scope
         self.hits = self.misses = 0
-        self._ev0 = cache.evictions
+        self._ev0, self._rf0 = cache.evictions, cache.refused
 
     def get(self, key):
         x = self.cache.get((self.scope, key))
@@ -347,9 +358,9 @@ class BagCacheView:
         self.cache.put((self.scope, key), x_dev)
 
     def stats(self):
-        mine = [b for k, (_, b) in self.cache.entries.items() if isinstance(k, tuple) and len(k) == 2 and k[0] == self.scope]
+        mine = [e[1] for k, e in self.cache.entries.items() if isinstance(k, tuple) and len(k) == 2 and k[0] == self.scope]
         return {"bags": len(mine), "gb": round(sum(mine) / 1e9, 3), "hits": self.hits, "misses": self.misses,
-                "evictions": self.cache.evictions - self._ev0}
+                "evictions": self.cache.evictions - self._ev0, "refused": self.cache.refused - self._rf0}
 
 
 _DEVICE_CACHES = {}

@@ -110,3 +110,32 @@ def test_randomly_masked_dataset_is_never_cached():
     MyHandler.test_model(g, d, "abmil", Loader(ds))
     MyHandler.test_model(g, d, "abmil", Loader(ds))
     assert (len(cache.entries), cache.hits, cache.misses) == (n0, h0, m0)
+
+
+def test_cache_admission_keeps_a_resident_set_for_cohorts_larger_than_the_budget():
+    """Epochs visit every bag once in a new order: with plain LRU a cohort larger than the budget gets no hits at all. The cache only
+    displaces entries that have gone unused for long (a dataset no longer iterated): the hit rate over a cohort three times the budget
+    is the resident third, every epoch; bags of a scope that stopped being used do give way to a new scope's."""
+    import random
+    from advmil_amd.ingest import BagCache
+    rnd = random.Random(0)
+    bag = torch.randn(1, 64, 256, device=DEV)
+    c = BagCache(DEV, 20 * bag.numel() * 4)                                  # room for 20 bags
+    cohort = list(range(60))
+    for epoch in range(4):
+        rnd.shuffle(cohort)
+        h0 = c.hits
+        for k in cohort:
+            if c.get(("a", k)) is None:
+                c.put(("a", k), bag)
+        if epoch:
+            assert c.hits - h0 == 20, (epoch, c.hits - h0)
+    assert c.evictions == 0 and c.refused == 40 * 4 and len(c.entries) == 20
+    other = list(range(100, 130))
+    for epoch in range(60):                                                  # another dataset takes over: the old bags go stale
+        rnd.shuffle(other)
+        for k in other:
+            if c.get(("b", k)) is None:
+                c.put(("b", k), bag)
+    mine = sum(1 for k in c.entries if k[0] == "b")
+    assert mine == 20 and c.evictions == 20, (mine, c.evictions)
