@@ -262,6 +262,8 @@ def test_second_epoch_is_served_from_the_device_resident_bag_cache(nrows):
                 for i in range(6)]
 
     def run(cache_gb, poison):
+        from advmil_amd import ingest
+        ingest.device_bag_cache(DEV).clear()     # (the device's cache is shared: bags of earlier tests would hold the small budget)
         h = MyHandler(default_cfg(bp_every_batch=3, bag_cache_gb=cache_gb), device=DEV)
         load_synth(h.netG, "G-abmil:"); load_synth(h.netD, "D-prj:")
         h.rng.reset(99)
