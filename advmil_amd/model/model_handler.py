@@ -242,7 +242,8 @@ class MyHandler(object):
                     v = stager.add(x0)
                 # (the second loader field is the cluster ids / graph of those two backbones; ABMIL and ESAT never read it, and a pageable
                 # host tensor's `.to()` is a host-synchronous copy that would throttle the launch queue to the device's pace)
-                ext_used = self.bcb in ("cluster", "graph")
+                # DeepAttMISL's cluster ids stay on the host until the step: `_gen_features` sends the step's ids as ONE pinned buffer
+                ext_used = self.bcb == "graph"
                 data_x = [v] + [dx.to(self.device, non_blocking=True) if (ext_used and torch.is_tensor(dx)) else dx for dx in data_x[1:]]
             else:
                 data_x = [dx.to(self.device, non_blocking=True) if torch.is_tensor(dx) else dx for dx in data_x]
@@ -530,8 +531,19 @@ class MyHandler(object):
     def _gen_features(self, X, plan, xs):
         """Generator backbone over the whole step slab -> [B, d]. `patch` mode skips coords (model_handler.py:390)."""
         exts = [x[1] for x in xs] if self.bcb in ("cluster", "graph") else None
-        if exts is not None and getattr(plan, "pad", 0):
-            exts = exts + [torch.zeros(plan.pad, dtype=exts[0].dtype, device=exts[0].device)]     # the dummy bag's cluster ids
+        pad = getattr(plan, "pad", 0)
+        if self.bcb == "cluster" and all(torch.is_tensor(e) and not e.is_cuda for e in exts):
+            # host ids (the epoch loop leaves them there): the step's ids -- and zeros for the pad's dummy bag -- as one pinned buffer,
+            # one asynchronous copy per step plan instead of one synchronous pageable copy per bag
+            ids = plan.__dict__.get("_cluster_ids")
+            if ids is None:
+                n = sum(int(e.numel()) for e in exts)
+                buf = torch.zeros(n + pad, dtype=exts[0].dtype, pin_memory=True)
+                torch.cat([e.reshape(-1) for e in exts], out=buf[:n])
+                ids = plan._cluster_ids = buf.to(self.device, non_blocking=True)
+            exts = [ids]
+        elif exts is not None and pad:
+            exts = exts + [torch.zeros(pad, dtype=exts[0].dtype, device=exts[0].device)]          # the dummy bag's cluster ids
         return self._bags(self.netG.features_multi(X, plan.seg, exts), plan)
 
     def _disc_backward(self, i_batch, xs, ys, plan, noise=None):
