@@ -139,3 +139,24 @@ def test_cache_admission_keeps_a_resident_set_for_cohorts_larger_than_the_budget
                 c.put(("b", k), bag)
     mine = sum(1 for k in c.entries if k[0] == "b")
     assert mine == 20 and c.evictions == 20, (mine, c.evictions)
+
+
+def test_degenerate_loaders():
+    """Empty loaders, an epoch shorter than one step batch (the reference then makes no optimizer step and returns an empty collector,
+    model_handler.py:321-347), a one-region bag, and an evaluation whose last slab holds a single bag."""
+    from advmil_amd.config import default_cfg
+    from advmil_amd.model import MyHandler
+    h = MyHandler(default_cfg(bcb_mode="abmil", bp_every_batch=4), device=DEV)
+    load_synth(h.netG, "G-abmil:"); load_synth(h.netD, "D-prj:")
+    assert h._train_each_epoch([], "train") == {"y": None, "y_hat": None, "f_fake": None}
+    three = make("abmil", (64, 16, 128))
+    p0 = h.optimizerG.flat_param.clone()
+    assert h._train_each_epoch(three, "train") == {"y": None, "y_hat": None, "f_fake": None} and torch.equal(p0, h.optimizerG.flat_param)
+    assert h.pop_logs() == []
+    assert MyHandler.test_model(h.netG, h.netD, "abmil", []) == {"idx": None, "y": None, "y_hat": None, "f_fake": None}
+    five = make("abmil", (64, 16, 128, 16, 4112))                            # slabs of 4 + 1 bags; the last one is padded (4112 rows)
+    a = MyHandler.test_model(h.netG, h.netD, "abmil", five, test_zero_noise=True, batch_bags=4)
+    b = MyHandler.test_model(h.netG, h.netD, "abmil", five, test_zero_noise=True, batch_bags=1)
+    same(a, b)
+    cl = h._train_each_epoch(five, "train")                                    # one step of 4 bags, the fifth is dropped
+    assert cl["y_hat"].shape == (4, 1) and len(h.pop_logs()) == 2 and bool(torch.isfinite(cl["f_fake"]).all())
