@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
+    # The suite's default arithmetic is the exact fp32 mode (tests that cover bf16x3 select it themselves, and put it back): an
+    # inherited ADVMIL_GEMM_MODE=bf16x3 would run the 2e-6 "same result on two paths" comparisons at 2^-17 per product.
+    os.environ.pop("ADVMIL_GEMM_MODE", None)
 
 
 @pytest.fixture(scope="session")
