@@ -75,3 +75,28 @@ def test_auto_splits_heuristic():
     assert auto_splits(8192, 384, 1024) == 1            # 192 tiles: enough parallelism
     assert auto_splits(384, 1024, 8192) > 1             # dW: 24 tiles, the bag length is K
     assert auto_splits(8, 384, 64) == 1
+
+
+def test_host_copy_rows_and_effective_cpus(monkeypatch):
+    """ingest.host_copy_rows: the pageable -> pinned copy of a loader tensor by a small thread pool (chunks of rows; any row count,
+    also fewer rows than threads, non-contiguous sources and a different dtype take torch's copy_) copies exactly; effective_cpus is
+    the affinity mask capped by the cgroup quota and at least 1."""
+    import os
+    from advmil_amd import ingest
+    assert 1 <= ingest.effective_cpus() <= (os.cpu_count() or 1)
+    g = torch.Generator().manual_seed(0)
+    for nt in ("8", "3", "1", "0"):
+        monkeypatch.setenv("ADVMIL_INGEST_THREADS", nt)
+        for rows in (1, 5, 33, 257, 1000):
+            src = torch.randn(rows, 96, generator=g)
+            dst = torch.full((rows, 96), float("nan"))
+            ingest.host_copy_rows(dst, src)
+            assert torch.equal(dst, src), (nt, rows)
+        src = torch.randn(64, 192, generator=g)[:, ::2]                       # non-contiguous source
+        dst = torch.empty(64, 96)
+        ingest.host_copy_rows(dst, src)
+        assert torch.equal(dst, src)
+        src = torch.randn(64, 96, generator=g).double()                        # another dtype: converted by copy_
+        dst = torch.empty(64, 96)
+        ingest.host_copy_rows(dst, src)
+        assert torch.equal(dst, src.float())
