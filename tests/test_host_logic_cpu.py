@@ -100,3 +100,32 @@ def test_host_copy_rows_and_effective_cpus(monkeypatch):
         dst = torch.empty(64, 96)
         ingest.host_copy_rows(dst, src)
         assert torch.equal(dst, src.float())
+
+
+def test_dataset_scope_follows_the_dataset_object():
+    """ingest.dataset_scope: the bag cache's scope of a loader is its DATASET object (two loaders over one dataset share it, two
+    datasets never do, even at a recycled address), None without one, False for a dataset that re-draws a random instance mask per
+    visit (WSIPatch.ratio_mask, dataset/PatchWSI.py:73-74); the token dies with the object."""
+    import gc
+    from types import SimpleNamespace
+    from advmil_amd import ingest
+
+    class DS:
+        def __init__(self, ratio_mask=None):
+            self.ratio_mask = ratio_mask
+
+    a, b = DS(), DS()
+    sa = ingest.dataset_scope(SimpleNamespace(dataset=a))
+    assert sa == ingest.dataset_scope(SimpleNamespace(dataset=a)) and sa != ingest.dataset_scope(SimpleNamespace(dataset=b))
+    assert ingest.dataset_scope([1, 2, 3]) is None and ingest.dataset_scope(SimpleNamespace(dataset=DS(0.3))) is False
+    assert ingest.dataset_scope(SimpleNamespace(dataset=DS(0.0))) not in (None, False)          # ratio_mask 0: nothing is masked
+    n0 = len(ingest._SCOPE_TOKENS)
+    ida = id(a)
+    del a
+    gc.collect()
+    assert ida not in ingest._SCOPE_TOKENS and len(ingest._SCOPE_TOKENS) < n0 + 1
+    seen = {sa}
+    for _ in range(50):                                                         # fresh objects (often at the address just freed): fresh tokens
+        s = ingest.dataset_scope(SimpleNamespace(dataset=DS()))
+        assert s not in seen
+        seen.add(s)
