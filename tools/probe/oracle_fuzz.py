@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Randomised parity of the adversarial step against the oracle (tests/test_handler_variants_gpu.py::run_case: two optimizer steps,
+logged losses, predictions, D scores and updated weights at the contract's tolerances): random backbone, bag count, ragged bag
+lengths (multiples of 16; some step batches >= 4096 rows so that the padded slab path runs), event flags, label visibility, D loss.
+usage: oracle_fuzz.py [cases] [seed]"""
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from tests.test_handler_variants_gpu import run_case  # noqa: E402
+
+ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+for case in range(ncase):
+    kind = rnd.choice(("abmil", "abmil", "patch", "cluster"))
+    nb = rnd.randint(1, 6)
+    big = rnd.random() < 0.5
+    lens = tuple(16 * rnd.randint(1, 160 if big else 40) for _ in range(nb))
+    if big and sum(lens) < 4096:
+        lens = lens[:-1] + (lens[-1] + 16 * ((4096 - sum(lens)) // 16 + rnd.randint(1, 9)),)
+    events = tuple(rnd.randint(0, 1) for _ in range(nb))
+    mode = rnd.choice(("wlabel", "wlabel", "wolabel"))
+    visible = tuple(rnd.random() < 0.6 for _ in range(nb)) if mode == "wolabel" else None
+    loss = rnd.choice(("bce", "bce", "hinge", "wasserstein"))
+    kw = {} if loss == "bce" else {"loss_netD": loss, "tol": 4e-4, "check_weights": False}
+    t0 = time.time()
+    run_case(kind=kind, lens=lens, events=events, visible=visible, mode=mode, **kw)
+    print(f"case {case}: {kind} bags {nb} rows/step {sum(lens)} (mod 256 {sum(lens) % 256}) events {events} mode {mode} "
+          f"visible {visible} loss {loss}: ok ({time.time() - t0:.1f} s)", flush=True)
+print("all ok")
