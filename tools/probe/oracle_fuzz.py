@@ -25,7 +25,11 @@ for case in range(ncase):
     mode = rnd.choice(("wlabel", "wlabel", "wolabel"))
     visible = tuple(rnd.random() < 0.6 for _ in range(nb)) if mode == "wolabel" else None
     loss = rnd.choice(("bce", "bce", "hinge", "wasserstein"))
-    kw = {} if loss == "bce" else {"loss_netD": loss, "tol": 4e-4, "check_weights": False}
+    # hinge / wasserstein: post-Adam quantities only agree to a few 1e-4 (tests/test_handler_variants_gpu.py::test_other_d_losses: Adam
+    # moves parameters whose gradient is round-off by +-lr; seed 11's case 26 -- DeepAttMISL, wasserstein -- reached 4.7e-4, and there
+    # the fp32 oracle itself is 3.8e-3 off its float64 self on one gradient, test_d_loss_gradients_before_adam). Their raw gradients
+    # are held to 2e-5 against the float64 oracle by that test.
+    kw = {} if loss == "bce" else {"loss_netD": loss, "tol": 1e-3, "check_weights": False}
     t0 = time.time()
     run_case(kind=kind, lens=lens, events=events, visible=visible, mode=mode, **kw)
     print(f"case {case}: {kind} bags {nb} rows/step {sum(lens)} (mod 256 {sum(lens) % 256}) events {events} mode {mode} "
