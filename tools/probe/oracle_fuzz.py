@@ -30,8 +30,13 @@ for case in range(ncase):
     # the fp32 oracle itself is 3.8e-3 off its float64 self on one gradient, test_d_loss_gradients_before_adam). Their raw gradients
     # are held to 2e-5 against the float64 oracle by that test.
     kw = {} if loss == "bce" else {"loss_netD": loss, "tol": 1e-3, "check_weights": False}
+    over = {}
+    if rnd.random() < 0.35:                          # the other discriminators (concat head, bag-level inner product, projection on y / none)
+        over = rnd.choice((dict(disc_type="cat", disc_prj_path=None), dict(disc_prj_iprd="bag"), dict(disc_prj_path="y"),
+                           dict(disc_prj_iprd="bag", disc_prj_path=None)))
+    kw.update(over)
     t0 = time.time()
     run_case(kind=kind, lens=lens, events=events, visible=visible, mode=mode, **kw)
     print(f"case {case}: {kind} bags {nb} rows/step {sum(lens)} (mod 256 {sum(lens) % 256}) events {events} mode {mode} "
-          f"visible {visible} loss {loss}: ok ({time.time() - t0:.1f} s)", flush=True)
+          f"visible {visible} loss {loss} disc {over or 'prj/instance/x'}: ok ({time.time() - t0:.1f} s)", flush=True)
 print("all ok")
