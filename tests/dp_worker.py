@@ -45,6 +45,8 @@ def run(kind, world, rank, dp=None):
         kind, lens = kind[:-len("-collide")], LENS_COLLIDE
     elif kind.endswith("-pad"):
         kind, lens = kind[:-len("-pad")], LENS_PAD
+    elif kind.endswith("-env"):                      # tools/probe/dp_fuzz.py: eight bag lengths from the environment
+        kind, lens = kind[:-len("-env")], tuple(int(v) for v in os.environ["DP_LENS"].split(","))
     cfg = default_cfg(bcb_mode=kind, bp_every_batch=4)         # the GLOBAL step batch: every rank steps after 4 / world of its bags
     if kind == "graph":
         cfg.update(bcb_dims="1024-128-128", gen_dims="128-1")
