@@ -1342,6 +1342,8 @@ class GenConvAggFn(torch.autograd.Function):
 
 
 def genconv_aggregate(x, t, csr, eps=1e-7):
+    if csr.E == 0:                           # a graph without edges: nothing is aggregated (the kernels take no empty edge arrays)
+        return x + 0.0 * t.sum()
     return GenConvAggFn.apply(x, t, csr, eps)
 
 
