@@ -629,3 +629,35 @@ def test_stage_bag_copies_rows_and_derives_or_copies_planes():
     assert L.advmil_stage_bag(slab2.data_ptr(), x.data_ptr(), nb, pl2.hi.data_ptr(), None, pl2.lo.data_ptr(), None, nb // 2 - 16, st) == EINVAL
     assert L.advmil_stage_bag(slab2.data_ptr() + 4, x.data_ptr(), nb - 16, None, None, None, None, 0, st) == EINVAL
     assert L.advmil_stage_bag(slab2.data_ptr(), x.data_ptr(), nb, pl2.hi.data_ptr(), want.hi.data_ptr(), pl2.lo.data_ptr(), None, nb // 2, st) == EINVAL
+
+
+def test_genconv_on_random_graph_and_without_edges():
+    """The GENConv aggregation on a graph that is not a k-NN grid (random in-degrees, a hub, an isolated node, self loops) against
+    float64 -- the kernels only see CSR arrays --, and a graph without edges: out = x, identity gradient (the kernels take no empty
+    edge arrays; tools/probe/graph_fuzz.py)."""
+    from advmil_amd import ops
+    g = torch.Generator().manual_seed(3)
+    N, C, E = 300, 128, 2400
+    src = torch.randint(0, N, (E,), generator=g); dst = torch.randint(1, N, (E,), generator=g)      # node 0 receives nothing
+    dst[:600] = 7                                                                                      # a hub
+    src[600:640] = dst[600:640]                                                                        # self loops
+    ei = torch.stack([src, dst])
+    x = torch.randn(N, C, generator=g); t = torch.tensor([1.7]); go = torch.randn(N, C, generator=g)
+    xd, td = x.clone().to(DEV).requires_grad_(True), t.clone().to(DEV).requires_grad_(True)
+    out = ops.genconv_aggregate(xd, td, ops.GraphCSR(ei.to(DEV), N))
+    (out * go.to(DEV)).sum().backward()
+    xr, tr = x.clone().double().requires_grad_(True), t.clone().double().requires_grad_(True)
+    msg = torch.relu(xr[src]) + 1e-7
+    z = msg * tr
+    zmax = torch.full((N, C), -float("inf"), dtype=torch.float64).scatter_reduce(0, dst[:, None].expand(-1, C), z.detach(), reduce="amax", include_self=True)
+    e = torch.exp(z - zmax[dst])
+    w = e / torch.zeros(N, C, dtype=torch.float64).index_add_(0, dst, e)[dst]
+    orf = torch.zeros(N, C, dtype=torch.float64).index_add_(0, dst, w * msg) + xr
+    (orf * go.double()).sum().backward()
+    assert relerr(out, orf) < 4e-6 and relerr(xd.grad, xr.grad) < 2e-5
+    assert abs(float(td.grad) - float(tr.grad)) < 2e-6 * float((go.double()[dst].abs() * w * msg * (msg + (orf - xr)[dst])).sum())
+    assert torch.equal(out[0], xd.detach()[0])                                                        # the isolated node
+    x0 = x.clone().to(DEV).requires_grad_(True)
+    o0 = ops.genconv_aggregate(x0, td.detach().clone().requires_grad_(True), ops.GraphCSR(torch.zeros(2, 0, dtype=torch.long, device=DEV), N))
+    o0.backward(go.to(DEV))
+    assert torch.equal(o0.detach(), x0.detach()) and torch.equal(x0.grad, go.to(DEV))
