@@ -2,7 +2,7 @@
 kernel family against float64 / the oracle on shapes and parameters nobody picked by hand -- contraction engine (layouts, modes,
 epilogues, tiles, planes), fused attention (ragged bags, head dims, dropout), segmented pooling (online softmax under extreme score
 spreads), GENConv on random graphs, LayerNorm-mean16 / gated pool / Adam / concordance index, the adversarial step against the oracle
-(backbones, losses, visibility, discriminators), the slab pad, and two ranks against one process."""
+(backbones, losses, visibility, discriminators), the slab pad, two ranks against one process, and the supervised baselines against the oracle."""
 import os
 import subprocess
 import sys
@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("script,args", [("gemm_fuzz.py", ("80", "101")), ("attn_fuzz.py", ("24", "102")), ("pool_fuzz.py", ("40", "103")),
                                          ("graph_fuzz.py", ("40", "104")), ("misc_fuzz.py", ("10", "105")), ("oracle_fuzz.py", ("8", "106")),
-                                         ("pad_fuzz.py", ("1", "107")), ("dp_fuzz.py", ("2", "108"))])
+                                         ("pad_fuzz.py", ("1", "107")), ("dp_fuzz.py", ("2", "108")), ("baseline_fuzz.py", ("6", "109"))])
 def test_randomised_probe(script, args):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("ADVMIL_GEMM_MODE", None)

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Randomised parity of the supervised baselines (BaselineHandler) against the oracle's baseline_step (pinned to the
+reference's BaselineHandler._update_network by golden G7): random backbone (ABMIL / DeepAttMISL with ANY bag length, ESAT with
+multiples of 16), task (regression / Cox partial likelihood / discrete-time NLL), bag count, ragged lengths (some step batches >= 4096
+rows: padded slab), two optimizer steps; predictions and logged losses at 2e-5, weights like tests/test_handler_variants_gpu.py.
+usage: baseline_fuzz.py [cases] [seed]"""
+import os
+import random
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from advmil_amd import synth  # noqa: E402
+from advmil_amd.config import default_baseline_cfg  # noqa: E402
+from advmil_amd.model import BaselineHandler  # noqa: E402
+from oracle import advmil_oracle as O  # noqa: E402
+from tests import helpers as H  # noqa: E402
+from tests.test_parity_gpu import DEV, load_synth, zero_dropout  # noqa: E402
+
+ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+for case in range(ncase):
+    kind = rnd.choice(("abmil", "cluster", "patch"))
+    task = rnd.choice(("surv_reg", "surv_cox", "surv_nll"))
+    pdh = "384-4" if task == "surv_nll" else "384-1"
+    nb = rnd.randint(1, 5)
+    unit = 16 if kind == "patch" else 1
+    big = rnd.random() < 0.4
+    lens = [unit * rnd.randint(1, (2600 if big else 700) // unit) for _ in range(nb)]
+    if big and sum(lens) < 4096:
+        lens[-1] += unit * ((4200 - sum(lens)) // unit + 1)
+    h = BaselineHandler(default_baseline_cfg(bcb_mode=kind, task=task, pdh_dims=pdh, bp_every_batch=nb, bag_cache_gb=0), device=DEV)
+    P = load_synth(h.net, f"S-fz{case}:")
+    zero_dropout(h.net)
+    bags, loader = [], []
+    for s in range(2):
+        for j, n in enumerate(lens):
+            i = s * nb + j
+            x = H.bag(900 + i, max(lens))[:, :n].contiguous()
+            y = H.label(i).clone()
+            if task == "surv_nll":
+                y[0, 0] = float(int(y[0, 0] * 4) % 4)
+            elif task == "surv_cox":
+                y[0, 0] = y[0, 0] * 100.0 + i * 0.01
+            ext = H.T(synth.cluster_ids(0, 900 + i, n)) if kind == "cluster" else None
+            bags.append((x, ext, y))
+            loader.append((torch.tensor([[i]], dtype=torch.int), [x, ext if ext is not None else torch.zeros(1, 1)], y))
+    cl = h._train_each_epoch(loader, "train")
+    logs = h.pop_logs()
+    st = {}
+    for s in range(2):
+        P, lg, preds = O.baseline_step(P, st, bags[s * nb:(s + 1) * nb], kind=kind, task=task,
+                                       out_scale="none" if task == "surv_cox" else "sigmoid")
+        want = torch.cat(preds, dim=0)
+        got = cl["y_hat"][s * nb:(s + 1) * nb]
+        ep = float((got - want).abs().max())
+        el = max(abs(logs[s]["train_batch/net/loss_supervision"] - lg["loss_supervision"]), abs(logs[s]["train_batch/net/loss_total"] - lg["loss_total"]))
+        sc = max(1.0, abs(lg["loss_total"]))
+        assert ep < 2e-5 * max(1.0, float(want.abs().max())) and el < 2e-5 * sc, (case, kind, task, lens, s, ep, el)
+    for k, v in h.net.state_dict().items():
+        diff = (v.cpu() - P[k]).abs()
+        n_off = int((diff >= 5e-5).sum())
+        assert n_off <= max(1, diff.numel() // 5000) and float(diff.max()) < 2.05 * 8e-5 * 2, (case, kind, task, k, n_off, float(diff.max()))
+    print(f"case {case}: {kind} {task} lens {lens} (rows/step {sum(lens)}): ok", flush=True)
+print("all ok")
