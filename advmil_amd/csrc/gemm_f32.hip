@@ -1348,7 +1348,7 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
     dim3 pgrid(ntile_all < ncu ? ntile_all : ncu);        // persistent: one workgroup per CU walks its share of the tiles
     switch (tile) {
       case 84: hipLaunchKernelGGL((gemm_nt_planes_kernel<4, 2, 4, 32, 1>), pgrid, dim3(512), 0, stream, g); break;   // 2 x 64 KB
-      case 85: hipLaunchKernelGGL((gemm_nt_planes_kernel<4, 2, 4, 32, 2>), pgrid, dim3(512), 0, stream, g); break;   // EXPERIMENT
+      case 85: hipLaunchKernelGGL((gemm_nt_planes_kernel<4, 2, 4, 32, 2>), pgrid, dim3(512), 0, stream, g); break;   // 256x256, plain streaming epilogue (+ two layers)
       case 83: hipLaunchKernelGGL((gemm_nt_planes_kernel<3, 2, 4, 32>), pgrid, dim3(512), 0, stream, g); break;   // 2 x 56 KB
       case 82: hipLaunchKernelGGL((gemm_nt_planes_kernel<2, 3, 4, 32>), pgrid, dim3(512), 0, stream, g); break;   // 3 x 48 KB: two chunks in flight
       default: return ADVMIL_EINVAL;
