@@ -145,6 +145,14 @@ def test_row_map_is_selected_by_call_site_not_by_row_count():
         rng.row_map(4, "some_new_dropout_site")
     with pytest.raises(RuntimeError, match="none of its layouts"):
         rng.row_map(5, "abmil_fc")
+    # a single process whose slab carries a zero-row pad maps only the stacked layout; the others are declared identities (no lookup in
+    # the kernels) but still checked for their row count
+    rng.rows = {"patch": ops.IdentityRows(80), "region": ops.IdentityRows(5), "bag": ops.IdentityRows(2), "bag2": ops.IdentityRows(4),
+                "region2": torch.arange(10)}
+    assert rng.row_map(80, "abmil_fc") is None and rng.row_map(5, "gapool_att_a") is None and rng.row_map(4, "dx_fc2.2") is None
+    assert torch.equal(rng.row_map(10, "dx_fc1"), torch.arange(10))
+    with pytest.raises(RuntimeError, match="none of its layouts"):
+        rng.row_map(64, "abmil_fc")
 
 
 def test_shard_epoch_gives_every_rank_the_same_number_of_steps():
