@@ -81,6 +81,7 @@ class SlabStager:
         self.pad = 0                      # zero rows behind the batch (pad_rows): the step slab is rows + pad rows long
         self.split = False                # derive every staged bag's bf16x3 operand planes on the copy stream (set per batch by begin())
         self.hint_rows = 0                # expected rows of a step batch (first allocation of the slabs; see _ensure)
+        self.max_bag_rows = 0             # longest bag staged so far (expect(): ragged cohorts start a batch with any length)
 
     def _ensure(self, k, rows):
         cap = 0 if self.dev[k] is None else self.dev[k].shape[0]
@@ -119,6 +120,12 @@ class SlabStager:
                 pl.lo[:self.planes_rows].copy_(old.lo[:self.planes_rows])
         self.pl[k] = pl
 
+    def expect(self, nb, first_rows):
+        """Size hint before a batch of `nb` bags whose first bag has `first_rows` rows: 1.25 x nb x the longest bag seen so far. (A
+        hint from the first bag alone re-allocated the pinned slabs whenever a batch happened to start with a longer bag.)"""
+        self.max_bag_rows = max(self.max_bag_rows, int(first_rows))
+        self.hint_rows = max(self.hint_rows, int(1.25 * nb * self.max_bag_rows))
+
     def begin(self):
         """Start staging a new step batch into the other buffer pair."""
         from . import ops
@@ -139,6 +146,7 @@ class SlabStager:
         """Stage one bag x[1, N, C] (CPU) -> device view [1, N, C] inside the slab (valid after `ready()`)."""
         x2 = x_cpu.reshape(-1, x_cpu.shape[-1])
         n = x2.shape[0]
+        self.max_bag_rows = max(self.max_bag_rows, n)
         k = self.k
         self._spans.append((self.rows, self.rows + n))
         self._ensure(k, self.rows + n)
@@ -174,6 +182,7 @@ class SlabStager:
         `ready_evt`: event recorded on the compute stream behind the kernels that produced the cached tensors."""
         x2 = x_dev.reshape(-1, x_dev.shape[-1])
         n = x2.shape[0]
+        self.max_bag_rows = max(self.max_bag_rows, n)
         k = self.k
         self._spans.append((self.rows, self.rows + n))
         self._ensure(k, self.rows + n)
@@ -512,7 +521,7 @@ def step_batches(loader, device, nb, cache=None, stager=None, drop_last=False, s
         if own is None:
             own = device_stager(device, x0.shape[-1])
         if not xs:
-            own.hint_rows = max(own.hint_rows, int(1.3 * nb * x0.shape[1]))
+            own.expect(nb, x0.shape[1])
             own.begin()
         key = int(idx.reshape(-1)[0]) if cache is not None else None
         hit = cache.get(key) if cache is not None else None

@@ -226,7 +226,7 @@ class MyHandler(object):
                     stager = self.__dict__.setdefault("_stager", None) or SlabStager(self.device, x0.shape[-1])
                     self._stager = stager
                 if not staged:
-                    stager.hint_rows = max(stager.hint_rows, int(1.3 * bp_every_batch * x0.shape[1]))
+                    stager.expect(bp_every_batch, x0.shape[1])
                     stager.begin()
                     staged = True
                 staged_pos.append(len(x_col))
