@@ -83,7 +83,8 @@ for case in range(ncase):
     # error model: |A||B| accumulates like sqrt(K) x eps x the product scale; relative to the OUTPUT's scale (act / cancellation can
     # make it small) -> scale the allowance by max|pre| / max|v|
     amp = float(pre.abs().max() / (v.abs().max() + 1e-30)) if float(v.abs().max()) > 0 else 1.0
-    tol = (3e-6 if mode == "exact" else 4e-5) * max(1.0, amp)
+    # (fp32 accumulation over K terms: the exact mode's error grows like sqrt(K) eps -- 6e-6 of the product scale at K = 32 512)
+    tol = (3e-6 * max(1.0, (K / 1024.0) ** 0.5) if mode == "exact" else 4e-5) * max(1.0, amp)
     worst[mode] = max(worst[mode], err / max(1.0, amp))
     ok = err <= tol and bool(torch.isfinite(C).all())
     if not ok or case % 20 == 0:
