@@ -715,6 +715,17 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const float* __restr
   dsum[idx] = s;
 }
 
+#ifdef AT_STAMP
+// Dev probe: what the occupancy API says about co-resident workgroups per CU for the head_dim-48 kernels
+extern "C" int advmil_debug_attn_occupancy(int which) {
+  int n = -1;
+  if (which == 0) hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<48, true>, 512, 0);
+  else if (which == 1) hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dq_kernel<48, true>, 512, 0);
+  else hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dkv_kernel<48, true>, 512, 0);
+  return n;
+}
+#endif
+
 // =====================================================================================
 // C ABI
 // =====================================================================================

@@ -193,6 +193,10 @@ class SlabStager:
             self._ensure_planes(k)
         if ready_evt is not None:
             self.copy_stream.wait_event(ready_evt)
+        x_dev.record_stream(self.copy_stream)         # a cache eviction must not hand the block back while this launch reads it
+        if planes is not None:
+            planes.hi.record_stream(self.copy_stream)
+            planes.lo.record_stream(self.copy_stream)
         # ONE launch on the copy stream for the bag's fp32 rows and both planes (advmil_stage_bag); three torch copy_ calls inside a
         # stream context cost ~45 us of host time per bag, 16 bags per step
         from . import _lib
@@ -270,7 +274,7 @@ class BagCache:
     more, device to device, into its own HBM allocation (fp32 rows: 4 B per element); from then on a step batch is assembled from
     the cached bags by ONE launch per bag on the copy stream, while the step before computes (SlabStager.add_device ->
     advmil_stage_bag), which writes the bag's rows into the staging slab and derives its two bf16x3 operand planes on the way -- no
-    PCIe traffic, no per-step split, no gather on the compute stream. 45 % of 288 GB hold ~3 900 bags of 8192 patches. One cache per
+    PCIe traffic, no per-step split, no gather on the compute stream. The default budget of 30 % of 288 GB holds ~2 500 bags of 8192 patches. One cache per
     device, shared by the training loop and the evaluation passes (keys: (scope, patient index), BagCacheView). LRU under a byte
     budget (with an admission rule for cohorts larger than the budget, see `put`); a bag that does not fit is simply not kept."""
 
@@ -281,15 +285,23 @@ class BagCache:
         # fp32 rows only by default: the staging launch derives the operand planes on the way into the step slab (advmil_stage_bag's
         # split form: 12 bytes moved per element instead of 16, 4 bytes held instead of 8). ADVMIL_CACHE_PLANES=1 keeps the planes too.
         self.with_planes = (os.environ.get("ADVMIL_CACHE_PLANES", "0") == "1") if with_planes is None else with_planes
-        self.entries = OrderedDict()      # key -> [x [1, N, C] fp32 device tensor (+ `_advmil_bag_planes`), bytes, tick of its last use]
+        self.entries = OrderedDict()      # key -> [x [1, N, C] fp32 device tensor (+ `_advmil_bag_planes`), bytes, tick of its last use, fingerprint]
         self.bytes = 0
-        self.hits = self.misses = self.evictions = self.refused = 0
+        self.hits = self.misses = self.evictions = self.refused = self.mismatches = 0
         self.tick = 0                     # counts lookups: the clock of the admission rule in `put`
 
-    def get(self, key):
+    def get(self, key, fingerprint=None):
+        """The cached bag, or None. `fingerprint` (bag_fingerprint of the loader's host tensor): an entry whose shape or sampled
+        values differ from what the loader handed over NOW is not this bag (another loader under the same scope, a dataset that
+        changes its bags between visits) -- it is dropped and the lookup is a miss."""
         self.tick += 1
         ent = self.entries.get(key)
         if ent is None:
+            self.misses += 1
+            return None
+        if fingerprint is not None and ent[3] is not None and ent[3] != fingerprint:
+            self.bytes -= self.entries.pop(key)[1]
+            self.mismatches += 1
             self.misses += 1
             return None
         self.entries.move_to_end(key)
@@ -297,7 +309,7 @@ class BagCache:
         self.hits += 1
         return ent[0]
 
-    def put(self, key, x_dev):
+    def put(self, key, x_dev, fingerprint=None):
         """Keep a private copy of the staged bag `x_dev` [1, N, C] (a view into the staging slab, valid on the current stream)."""
         from . import ops
         if key in self.entries or self.budget <= 0:
@@ -324,7 +336,7 @@ class BagCache:
             x._advmil_bag_planes = ops.split_planes(x.view(-1, x.shape[-1]))
         x._advmil_ready = torch.cuda.Event()          # the copy stream that later reads this entry waits for it
         x._advmil_ready.record(torch.cuda.current_stream(self.device))
-        self.entries[key] = [x, nbytes, self.tick]
+        self.entries[key] = [x, nbytes, self.tick, fingerprint]
         self.bytes += nbytes
 
     def set_budget(self, budget_bytes):
@@ -345,7 +357,16 @@ class BagCache:
 
     def stats(self):
         return {"bags": len(self.entries), "gb": round(self.bytes / 1e9, 3), "hits": self.hits, "misses": self.misses,
-                "evictions": self.evictions, "refused": self.refused}
+                "evictions": self.evictions, "refused": self.refused, "mismatches": self.mismatches}
+
+
+def bag_fingerprint(x0):
+    """Cheap identity of a host bag [1, N, C]: its shape and five sampled elements (a few microseconds; no pass over the bag). Kept
+    with the cache entry and compared on every hit, so a key that now names a different bag cannot serve a stale one."""
+    flat = x0.reshape(-1)
+    n = flat.numel()
+    pick = (0, n // 3, n // 2, (2 * n) // 3, n - 1) if n else ()
+    return (tuple(x0.shape), tuple(float(flat[i]) for i in pick))
 
 
 class BagCacheView:
@@ -358,16 +379,16 @@ class BagCacheView:
         self.hits = self.misses = 0
         self._ev0, self._rf0 = cache.evictions, cache.refused
 
-    def get(self, key):
-        x = self.cache.get((self.scope, key))
+    def get(self, key, fingerprint=None):
+        x = self.cache.get((self.scope, key), fingerprint)
         if x is None:
             self.misses += 1
         else:
             self.hits += 1
         return x
 
-    def put(self, key, x_dev):
-        self.cache.put((self.scope, key), x_dev)
+    def put(self, key, x_dev, fingerprint=None):
+        self.cache.put((self.scope, key), x_dev, fingerprint)
 
     def stats(self):
         mine = [e[1] for k, e in self.cache.entries.items() if isinstance(k, tuple) and len(k) == 2 and k[0] == self.scope]
@@ -386,13 +407,17 @@ def new_scope_token():
     return _NEXT_TOKEN[0]
 
 
+DEFAULT_BUDGET_FRACTION = 0.30
+
+
 def default_budget(device):
-    return 0.45 * torch.cuda.get_device_properties(torch.device(device)).total_memory
+    """30 % of the device's memory (86 GB of 288: ~2 500 bags of 8192 patches) unless cfg['bag_cache_gb'] / ADVMIL_BAG_CACHE_GB say otherwise."""
+    return DEFAULT_BUDGET_FRACTION * torch.cuda.get_device_properties(torch.device(device)).total_memory
 
 
 def device_bag_cache(device, budget_bytes=None):
     """THE bag cache of a device (created on first use). `budget_bytes`: None keeps the current budget (default_budget at
-    creation: 45 % of the device's memory); a handler passes its configured budget, the static evaluation pass never changes it."""
+    creation: 30 % of the device's memory); a handler passes its configured budget, the static evaluation pass never changes it."""
     device = torch.device(device)
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     c = _DEVICE_CACHES.get(key)
@@ -424,8 +449,8 @@ def dataset_scope(loader):
     ds = getattr(loader, "dataset", None)
     if ds is None:
         return None
-    if getattr(ds, "ratio_mask", None):
-        return False                                  # never cache: every visit is a different bag
+    if getattr(ds, "ratio_mask", None) or getattr(ds, "advmil_no_cache", False):
+        return False                                  # never cache: every visit is a different bag (or the dataset opted out)
     ent = _SCOPE_TOKENS.get(id(ds))
     if ent is not None and ent[0]() is ds:
         return ("ds", ent[1])
@@ -495,8 +520,8 @@ def step_batches(loader, device, nb, cache=None, stager=None, drop_last=False, s
         return StepBatch(list(pos), list(idxs), list(xs), list(ys), True, pad)
 
     def after():
-        for key, j in fresh:
-            cache.put(key, xs[j][0])
+        for key, j, fp in fresh:
+            cache.put(key, xs[j][0], fp)
         own.release()
         del pos[:], idxs[:], xs[:], ys[:], fresh[:]
 
@@ -524,15 +549,15 @@ def step_batches(loader, device, nb, cache=None, stager=None, drop_last=False, s
             own.expect(nb, x0.shape[1])
             own.begin()
         key = int(idx.reshape(-1)[0]) if cache is not None else None
-        hit = cache.get(key) if cache is not None else None
+        fp = bag_fingerprint(x0) if cache is not None else None
+        hit = cache.get(key, fp) if cache is not None else None
         if hit is not None:
-            ev = hit.__dict__.get("_advmil_ready")
-            v = own.add_device(hit, hit.__dict__.get("_advmil_bag_planes"), ev)
-            if ev is not None:                   # the copy stream is ordered behind the kernels that made this entry, for good
-                hit._advmil_ready = None
+            # the entry keeps its event: ANY copy stream that reads it (the handler's stager, the evaluation's) is ordered behind
+            # the kernels that made it; waiting on a completed event costs nothing
+            v = own.add_device(hit, hit.__dict__.get("_advmil_bag_planes"), hit.__dict__.get("_advmil_ready"))
         else:
             if cache is not None:
-                fresh.append((key, len(xs)))
+                fresh.append((key, len(xs), fp))
             v = own.add(x0)
         pos.append(b); idxs.append(idx); xs.append([v] + list(x[1:])); ys.append(y)
         if len(xs) == nb:

@@ -86,7 +86,9 @@ class BaselineHandler(object):
         gb = self.cfg.get("bag_cache_gb")
         view = None
         if self.bcb != "graph" and (gb is None or float(gb) > 0):
-            scope = ("h", self.__dict__.setdefault("_cache_token", new_scope_token()), name_loader)
+            # (a loader without a dataset object is cached -- under this handler's scope -- only on explicit request: bag_cache_gb set)
+            explicit = gb is not None or os.environ.get("ADVMIL_BAG_CACHE_GB") is not None
+            scope = ("h", self.__dict__.setdefault("_cache_token", new_scope_token()), name_loader) if explicit else None
             view = loader_cache_view(self.device, train_loader, scope, None if gb is None else float(gb) * 1e9)
             if view is not None and view.scope == scope and scope not in self.__dict__.setdefault("_cache_scopes", set()):
                 import weakref

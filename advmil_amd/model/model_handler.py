@@ -298,17 +298,20 @@ class MyHandler(object):
 
     def _bag_cache_for(self, name_loader, loader=None):
         """This loader's view of the device-resident bag cache (advmil_amd/ingest.py::BagCache, ONE per device, shared with the
-        evaluation passes), or None. Budget: cfg['bag_cache_gb'] / ADVMIL_BAG_CACHE_GB (0 = off); default 45 % of the device's
+        evaluation passes), or None. Budget: cfg['bag_cache_gb'] / ADVMIL_BAG_CACHE_GB (0 = off); default 30 % of the device's
         memory. Scope of the keys: the loader's dataset object when it has one (DataLoader), else (this handler, name_loader)."""
         from ..ingest import BagCacheView, dataset_scope, default_budget, device_bag_cache, new_scope_token
         caches = self.__dict__.setdefault("_bag_caches", {})
         scope = dataset_scope(loader) if loader is not None else None
+        gb = os.environ.get("ADVMIL_BAG_CACHE_GB", self.cfg.get("bag_cache_gb"))
         if scope is None:
-            scope = ("h", self.__dict__.setdefault("_cache_token", new_scope_token()), name_loader)
+            # An iterable without a dataset object (a list, a generator) has no identity of its own: its bags are kept -- under
+            # (this handler, name_loader) -- only when the caller asked for the cache explicitly (cfg['bag_cache_gb'] /
+            # ADVMIL_BAG_CACHE_GB); by default such a loader is re-read every epoch, as the reference does (model_handler.py:315).
+            scope = ("h", self.__dict__.setdefault("_cache_token", new_scope_token()), name_loader) if gb is not None else False
         scopes = self.__dict__.setdefault("_bag_cache_scopes", {})
         if name_loader not in caches or scopes.get(name_loader) != scope:
             view = None
-            gb = os.environ.get("ADVMIL_BAG_CACHE_GB", self.cfg.get("bag_cache_gb"))
             if scope is not False and (gb is None or float(gb) > 0):
                 cache = device_bag_cache(self.device, default_budget(self.device) if gb is None else float(gb) * 1e9)
                 view = BagCacheView(cache, scope)

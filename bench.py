@@ -370,9 +370,24 @@ def product_loop(args, torch, dev, case):
     hh._train_each_epoch(loader[:2 * args.bags], "warmup")                     # allocates the pinned + device staging slabs
     torch.cuda.synchronize()
 
+    # a DataLoader-like object: the bag cache's scope is the loader's `.dataset` (a bare list is re-read every epoch unless
+    # cfg['bag_cache_gb'] asks for the cache explicitly)
+    class _DS:
+        def __init__(self, items):
+            self.items = items
+
+    class _DL:
+        def __init__(self, ds):
+            self.dataset = ds
+
+        def __iter__(self):
+            return iter(self.dataset.items)
+
+    train_dl = _DL(_DS(loader[2 * args.bags:]))
+
     def epoch(tag):
         t1 = time.perf_counter()
-        hh._train_each_epoch(loader[2 * args.bags:], tag)
+        hh._train_each_epoch(train_dl, tag)
         torch.cuda.synchronize()
         return time.perf_counter() - t1
 
@@ -415,17 +430,6 @@ def product_loop(args, torch, dev, case):
     # ---- the per-epoch evaluation (reference `_run_training`, model_handler.py:278-285: MyHandler.test_model over the validation and
     # the test set after EVERY epoch, times_test_sample = 1; 598-643: one synchronous `.cuda()`, full forwards and 4 `.cpu()` syncs
     # per bag). Same ragged pinned host bags behind a DataLoader-like object (the cache scope is its `.dataset`).
-    class _DS:
-        def __init__(self, items):
-            self.items = items
-
-    class _DL:
-        def __init__(self, ds):
-            self.dataset = ds
-
-        def __iter__(self):
-            return iter(self.dataset.items)
-
     nev = min(len(loader), 8 * args.bags)
     ev_items = loader[:nev]
 

@@ -22,6 +22,8 @@ with torch.no_grad():
         ops.mha(qkv, 8, p, rng, seg=seg)
 torch.cuda.synchronize()
 h = ctypes.CDLL(_lib.LIB_PATH)
+if hasattr(h, "advmil_debug_attn_occupancy"):
+    print("occupancy API (workgroups per CU): fwd", h.advmil_debug_attn_occupancy(0), "dq", h.advmil_debug_attn_occupancy(1), "dkv", h.advmil_debug_attn_occupancy(2))
 buf = (ctypes.c_ulonglong * 2048)()
 assert h.advmil_debug_attn_stamps(buf, 2048) == 0
 for w in range(2):
