@@ -12,27 +12,31 @@
 // output of the in-projection's epilogue), so no kernel here converts an operand; only the probabilities / score gradients, which
 // are produced in registers, are split in the kernels.
 //
-// Structure (round 3; one 512-thread workgroup = 8 waves per CU, 256 stationary rows):
+// Structure as shipped (512-thread workgroups = 8 waves, 256 stationary rows per workgroup):
 //   * wave w owns 32 rows of the stationary operand (queries for fwd / dQ, keys for dK/dV) as MFMA *columns* (B operand,
 //     fragments resident in VGPRs, loaded straight from the planes); the streamed operand comes through LDS in tiles of 64 rows;
-//   * the tiles arrive by LDS-DMA (global_load_lds_dwordx4, 1 KB per wave-instruction, 4 per wave per tile) into a ring of 4
-//     slots of [K hi | K lo | V hi | V lo] (or Q / dO), counted s_waitcnt vmcnt + raw s_barrier: two tiles are in flight while two
-//     are being read; nothing is staged through registers and nothing is converted on the way;
+//   * the tiles arrive by LDS-DMA (global_load_lds_dwordx4, 1 KB per wave-instruction, 4 per wave per tile: a wave-uniform tile base
+//     in scalar registers + a 32-bit per-lane offset) into a ring of [K hi | K lo | V hi | V lo] (or Q / dO) slots -- forward: 2 slots
+//     (64 KB), <= 128 VGPRs, `__launch_bounds__(512, 4)`: two workgroups co-resident per CU (census: tools/probe/residency_census.hip);
+//     backward kernels: 3 slots (96 KB), one workgroup per CU, one barrier per tile, counted s_waitcnt vmcnt + raw s_barrier;
+//     nothing is staged through registers and nothing is converted on the way;
 //   * LDS image of a plane tile: [64 rows][128 B] (8 units of 16 B; head_dim <= 64, the units beyond it are never written), the unit
 //     stored at position q of row r being unit q ^ sw(r), sw(r) = ((r>>1)&1)<<2 | ((r>>2)&3) -- applied to each lane's SOURCE address
 //     (the DMA writes lane-linear). Row fragments (ds_read_b128: lane = row) of any 16 rows distinct mod 16 then cover all 16
 //     16-byte slots of the 256-byte bank line, and the four rows of a ds_read_b64_tr_b16 block land in four different 64-byte bank
-//     quarters: both read patterns are conflict-free on the same image;
-//   * ANTI-PHASE wave groups. The per-tile work is cut into a matrix phase M (QK^T of tile t and P.V of tile t-1: 42 MFMAs for
-//     head_dim 48, only LDS reads beside them) and a vector phase V (softmax / dropout / hi-lo split of tile t: ~300 VALU, no
-//     MFMA), separated by workgroup barriers. Waves 0-3 and waves 4-7 (one of each per SIMD) run the same sequence ONE PHASE
-//     APART: while a SIMD's first wave multiplies, its second exponentiates, so the matrix pipe and the vector ALU of every SIMD
-//     are both busy instead of alternating in lockstep (the round-2 kernel: all waves in the same phase, the phases added up);
+//     quarters: both read patterns are conflict-free on the same image. The swizzle terms of a transposed read depend on the lane
+//     only, so every read of a tile is one of four per-tile bases + an immediate (TrAddr / TrBase);
+//   * one 32-row half-tile of the streamed operand at a time goes scores -> softmax / dropout / hi-lo split -> second contraction, all
+//     waves in the same phase. Round 3 built and measured the alternatives (anti-phase wave groups, an in-wave software pipeline),
+//     round 4 a fully zipped stream (one MFMA : ~7 VALU, order-pinned; tools/probe/attic/): none is faster. On this chip the time of
+//     these kernels follows  cycles per SIMD = 32 x MFMAs + ~4.3 x other VALU  within 5 % for all of them, so what
+//     pays is removing instructions: address arithmetic folded into immediates, 32-bit tail tests behind a uniform branch, no SLP
+//     packing (v_pk_* f32 costs two passes), epilogue coordinates recomputed instead of carried (0 bytes of scratch in all 24 kernels);
 //   * contractions over the streamed rows (P.V, dS^T.K, P^T.dO, dS^T.Q) take their second operand straight from the accumulator
 //     registers of the score tile: scores are computed transposed (rows = streamed rows, column = lane's stationary row), so a
 //     lane holds, for its column, 8 row values per 16-row k-step in exactly the (lane-half, slot) positions an MFMA B fragment wants
 //     with the k-slot <-> row map  slot t of half h <-> row 16*s + 8*(t>>2) + 4*h + (t&3); the transpose reads use the same map;
-//   * per-query softmax statistics are lane-local (column = query); the two lane halves exchange one max per tile. Scores stay
+//   * per-query softmax statistics are lane-local (column = query); the two lane halves exchange one max per half-tile. Scores stay
 //     unscaled in the accumulators: p = exp2(fma(s, log2(e)/sqrt(hd), -m)) folds the scale into the exponent's FMA.
 // Workgroup -> (bag, tile, head) with head = blockIdx % nhead: for nhead = 8 every XCD (blockIdx % 8) serves one head, so the K/V
 // panel of a (bag, head) is fetched into exactly one L2.
@@ -130,6 +134,41 @@ __device__ __forceinline__ bf16x8 frag_tr(const unsigned char* __restrict__ plan
   a.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(pb));
   return a.v;
 }
+// The same transposed fragment from per-lane offsets computed ONCE: for r0 = a multiple of 16 plus 4 half, the swizzle terms of
+// the two rows r0 + q4 and r0 + q4 + 8 depend on the lane only ((ra >> 1) & 1 = (q4 >> 1) & 1, (ra >> 2) & 3 = half, (rb >> 2) & 3 =
+// (half + 2) & 3), so a read is `plane + 128 * (16-row block) + off`: the per-read v_add3 / v_subrev address arithmetic of frag_tr
+// (two VALU per ds_read_b64_tr_b16: 68 per tile in the dQ kernel, 136 in the dK/dV kernel) becomes an immediate offset.
+struct TrAddr {
+  unsigned a[2], b[2];                 // [dt]: byte offsets of the rows 4 half + q4 and 4 half + q4 + 8 inside a 16-row block
+  __device__ __forceinline__ void init(int lane) {
+    const int half = lane >> 5, q4 = (lane & 15) >> 2, bb = (lane >> 4) & 1, e = lane & 3;
+    const int ra = 4 * half + q4, rb = ra + 8;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int u = 4 * dt + 2 * bb + (e >> 1);
+      a[dt] = (unsigned)(ra * 128 + ((u ^ at_sw(ra)) << 4) + (e & 1) * 8);
+      b[dt] = (unsigned)(rb * 128 + ((u ^ at_sw(rb)) << 4) + (e & 1) * 8);
+    }
+  }
+};
+// A tile slot's four read bases (slot address + lane offsets), formed once per tile and made opaque to the optimiser, which otherwise
+// re-derives "(t % 3) * slot bytes" per read as an induction variable minus a scalar: one VALU per ds_read_b64_tr_b16. Every read
+// of the tile is then base + immediate (16-row block, plane, K / V half of the slot: all < 32 KB).
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(LDS_AS const unsigned char*)p; }
+struct TrBase {
+  unsigned a[2], b[2];
+  __device__ __forceinline__ void set(unsigned slot, const TrAddr& ta) {
+    a[0] = slot + ta.a[0]; a[1] = slot + ta.a[1]; b[0] = slot + ta.b[0]; b[1] = slot + ta.b[1];
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]));
+  }
+};
+// off: byte offset of the plane inside the slot; rows16: first row of the 16-row block (a multiple of 16)
+__device__ __forceinline__ bf16x8 frag_tr_pre(const TrBase& tb, int off, int rows16, int dt) {
+  union { bf16x4_t q[2]; bf16x8 v; } r;
+  r.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(size_t)(tb.a[dt] + (unsigned)(off + rows16 * 128)));
+  r.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(size_t)(tb.b[dt] + (unsigned)(off + rows16 * 128)));
+  return r.v;
+}
 // 8 fp32 accumulator values -> hi / lo B fragments
 __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
   union { unsigned u[4]; bf16x8 v; } h, l;
@@ -185,17 +224,24 @@ struct TileDma {
     usrc = (lane & 7) ^ at_sw(lrow);
     on = usrc < UN;
   }
+  // Source addresses = a wave-uniform tile base (scalar registers) + a 32-bit per-lane byte offset formed at the issue: no 64-bit
+  // per-lane address lives across the tile loop (under the forward's 128-VGPR bound those were the values that went to scratch).
   __device__ __forceinline__ void issue(unsigned char* smem, int wave, int slot, int64_t tile_row0, int64_t Lg, const bf16raw* a_hi,
                                         const bf16raw* a_lo, int64_t lda, const bf16raw* b_hi, const bf16raw* b_lo, int64_t ldb) const {
-    int64_t r = tile_row0 + lrow;
-    if (r > Lg - 1) r = Lg - 1;
+    const int64_t rem = Lg - 1 - tile_row0;                   // rows of the bag behind the tile's first one
+    const int lim = rem < (int64_t)(AT_KT - 1) ? (int)rem : AT_KT - 1;
+    const int rl = lrow < lim ? lrow : lim;
     unsigned char* dst = smem + slot * AT_SLOT_B + wave * 1024;
     if (on) {
-      const int64_t ea = r * lda + usrc * 8, eb = r * ldb + usrc * 8;
-      __builtin_amdgcn_global_load_lds((const GLB_AS void*)(a_hi + ea), (LDS_AS void*)(dst), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const GLB_AS void*)(a_lo + ea), (LDS_AS void*)(dst + AT_PLANE_B), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const GLB_AS void*)(b_hi + eb), (LDS_AS void*)(dst + 2 * AT_PLANE_B), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const GLB_AS void*)(b_lo + eb), (LDS_AS void*)(dst + 3 * AT_PLANE_B), 16, 0, 0);
+      const unsigned oa = (unsigned)(rl * (int)lda + usrc * 8) * 2u, ob = (unsigned)(rl * (int)ldb + usrc * 8) * 2u;
+      const char* ta_hi = reinterpret_cast<const char*>(a_hi + tile_row0 * lda);
+      const char* ta_lo = reinterpret_cast<const char*>(a_lo + tile_row0 * lda);
+      const char* tb_hi = reinterpret_cast<const char*>(b_hi + tile_row0 * ldb);
+      const char* tb_lo = reinterpret_cast<const char*>(b_lo + tile_row0 * ldb);
+      __builtin_amdgcn_global_load_lds((const GLB_AS void*)(ta_hi + oa), (LDS_AS void*)(dst), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const GLB_AS void*)(ta_lo + oa), (LDS_AS void*)(dst + AT_PLANE_B), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const GLB_AS void*)(tb_hi + ob), (LDS_AS void*)(dst + 2 * AT_PLANE_B), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const GLB_AS void*)(tb_lo + ob), (LDS_AS void*)(dst + 3 * AT_PLANE_B), 16, 0, 0);
     }
   }
 };
@@ -217,7 +263,7 @@ __device__ __forceinline__ void hw_exp2x4(float& a, float& b, float& c, float& d
 // half-tile at a time: S (16) -> P split (16) -> O (32), Q fragments (24) -- so that TWO workgroups (4 waves per SIMD) share a CU,
 // each with a double-buffered 64 KB ring; their barriers are independent, so one workgroup's softmax runs under the other's MFMAs.
 template <int HD, bool DROP>
-__global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(512, HD == 64 ? 2 : 4) void attn_fwd_kernel(AttnArgs a) {
   constexpr int KS = HD / 16, DT = (HD + 31) / 32, UN = HD / 8;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * AT_SLOT_B];
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, half = lane >> 5;
@@ -239,6 +285,9 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnArgs a) {
 
   TileDma dma;
   dma.init(wave, lane, UN);
+  TrAddr tra;
+  tra.init(lane);
+  const unsigned smem_l = lds_addr(smem);
   dma.issue(smem, wave, 0, 0, Lg, Kh, Kl, ldq, Vh, Vl, ldq);
   if (T > 1) dma.issue(smem, wave, 1, AT_KT, Lg, Kh, Kl, ldq, Vh, Vl, ldq);
   zero_pad_units<HD>(smem, 2, tid);
@@ -272,7 +321,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnArgs a) {
   for (int t = 0; t < T; ++t) {
     AT_ST(1);
     const unsigned char* sK = smem + (t & 1) * AT_SLOT_B;
-    const unsigned char* sV = sK + 2 * AT_PLANE_B;
+    TrBase trb;
+    trb.set(smem_l + (t & 1) * AT_SLOT_B, tra);
     const int64_t kb = (int64_t)t * AT_KT;
     const bool tail = kb + AT_KT > Lg;
 #pragma unroll
@@ -287,9 +337,10 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnArgs a) {
         MFMA3(s, kh, kl, qh[ks], ql[ks]);
       }
       if (tail) {                                // ragged tail: keys past the bag get probability 0
+        const int lim = (int)(Lg - kb);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (kb + 32 * u + ACC_ROW(r, half) >= Lg) s[r] = -INFINITY;
+          if (32 * u + ACC_ROW(r, half) >= lim) s[r] = -INFINITY;
       }
       // ---- statistics, probabilities, dropout, split
       float mx = m_run;
@@ -336,8 +387,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnArgs a) {
         split8(v, ph, pl);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-          const bf16x8 vh = frag_tr(sV, 32 * u + 16 * s2 + 4 * half, dt, lane);
-          const bf16x8 vl = frag_tr(sV + AT_PLANE_B, 32 * u + 16 * s2 + 4 * half, dt, lane);
+          const bf16x8 vh = frag_tr_pre(trb, 2 * AT_PLANE_B, 32 * u + 16 * s2, dt);
+          const bf16x8 vl = frag_tr_pre(trb, 3 * AT_PLANE_B, 32 * u + 16 * s2, dt);
           MFMA3(o[dt], vh, vl, ph, pl);
         }
       }
@@ -352,19 +403,25 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(AttnArgs a) {
     }
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  if (qok) {
+  // The epilogue's lane coordinates are derived AGAIN here, from a thread id the optimiser cannot connect with the prologue's: under
+  // the 128-VGPR bound it otherwise carries q / the output pointers through the tile loop in scratch memory (5 spilled registers).
+  int tid2 = threadIdx.x;
+  asm volatile("" : "+v"(tid2));
+  const int j2 = tid2 & 31, half2 = (tid2 >> 5) & 1;
+  const int64_t q2 = (int64_t)qt * AT_QB + (tid2 >> 6) * 32 + j2;
+  if (q2 < Lg) {
     const float inv = (DROP ? a.inv_keep : 1.f) * hw_rcp(l_tot);
-    float* const orow = a.out + (row0 + q) * D + h * HD;
+    float* const orow = a.out + (row0 + q2) * D + h * HD;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const int d = 32 * dt + 8 * rg + 4 * half;
+        const int d = 32 * dt + 8 * rg + 4 * half2;
         if (d < HD)
           *reinterpret_cast<float4*>(orow + d) =
               make_float4(o[dt][4 * rg] * inv, o[dt][4 * rg + 1] * inv, o[dt][4 * rg + 2] * inv, o[dt][4 * rg + 3] * inv);
       }
-    if (half == 0) a.lse[(row0 + q) * H + h] = m_run * c + hw_log2(l_tot);
+    if (half2 == 0) a.lse[(row0 + q2) * H + h] = m_run * c + hw_log2(l_tot);
   }
 }
 
@@ -397,6 +454,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 
   TileDma dma;
   dma.init(wave, lane, UN);
+  TrAddr tra;
+  tra.init(lane);
+  const unsigned smem_l = lds_addr(smem);
   dma.issue(smem, wave, 0, 0, Lg, Kh, Kl, ldq, Vh, Vl, ldq);
   if (T > 1) dma.issue(smem, wave, 1, AT_KT, Lg, Kh, Kl, ldq, Vh, Vl, ldq);
   zero_pad_units<HD>(smem, 3, tid);
@@ -432,6 +492,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     if (t + 2 < T) dma.issue(smem, wave, (t + 2) % 3, (int64_t)(t + 2) * AT_KT, Lg, Kh, Kl, ldq, Vh, Vl, ldq);
     const unsigned char* sK = smem + (t % 3) * AT_SLOT_B;
     const unsigned char* sV = sK + 2 * AT_PLANE_B;
+    TrBase trb;
+    trb.set(smem_l + (t % 3) * AT_SLOT_B, tra);
     const int64_t kb = (int64_t)t * AT_KT;
     const bool tail = kb + AT_KT > Lg;
 #pragma unroll
@@ -469,9 +531,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         st[r + 2] = e2 * fmaf(dpt[r + 2], ik, -d_q); st[r + 3] = e3 * fmaf(dpt[r + 3], ik, -d_q);     // dS^T
       }
       if (tail) {
+        const int lim = (int)(Lg - kb);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (kb + 32 * u + ACC_ROW(r, half) >= Lg) st[r] = 0.f;
+          if (32 * u + ACC_ROW(r, half) >= lim) st[r] = 0.f;
       }
       // dQ^T[d, q] += K^T[d, key] . dS^T[key, q]
 #pragma unroll
@@ -483,8 +546,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         split8(v, dh, dl);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-          const bf16x8 kh = frag_tr(sK, 32 * u + 16 * s2 + 4 * half, dt, lane);
-          const bf16x8 kl = frag_tr(sK + AT_PLANE_B, 32 * u + 16 * s2 + 4 * half, dt, lane);
+          const bf16x8 kh = frag_tr_pre(trb, 0, 32 * u + 16 * s2, dt);
+          const bf16x8 kl = frag_tr_pre(trb, AT_PLANE_B, 32 * u + 16 * s2, dt);
           MFMA3(dq[dt], kh, kl, dh, dl);
         }
       }
@@ -494,13 +557,17 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnArgs a) {
       at_barrier();
     }
   }
-  if (qok) {
-    float* const drow = a.dqkv + (row0 + q) * ldq + h * HD;
+  int tid2 = threadIdx.x;                        // (lane coordinates derived again for the epilogue: see the forward)
+  asm volatile("" : "+v"(tid2));
+  const int half2 = (tid2 >> 5) & 1;
+  const int64_t q2 = (int64_t)qt * AT_QB + (tid2 >> 6) * 32 + (tid2 & 31);
+  if (q2 < Lg) {
+    float* const drow = a.dqkv + (row0 + q2) * ldq + h * HD;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const int d = 32 * dt + 8 * rg + 4 * half;
+        const int d = 32 * dt + 8 * rg + 4 * half2;
         if (d < HD)
           *reinterpret_cast<float4*>(drow + d) = make_float4(dq[dt][4 * rg] * a.scale, dq[dt][4 * rg + 1] * a.scale,
                                                              dq[dt][4 * rg + 2] * a.scale, dq[dt][4 * rg + 3] * a.scale);
@@ -559,6 +626,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   };
   TileDma dma;
   dma.init(wave, lane, UN);
+  TrAddr tra;
+  tra.init(lane);
+  const unsigned smem_l = lds_addr(smem);
   aux_load(0);
   dma.issue(smem, wave, 0, 0, Lg, Qh, Ql, ldq, Gh, Gl, D);
   if (T > 1) dma.issue(smem, wave, 1, AT_KT, Lg, Qh, Ql, ldq, Gh, Gl, D);
@@ -591,6 +661,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     if (t + 2 < T) dma.issue(smem, wave, (t + 2) % 3, (int64_t)(t + 2) * AT_KT, Lg, Qh, Ql, ldq, Gh, Gl, D);
     const unsigned char* sQ = smem + (t % 3) * AT_SLOT_B;
     const unsigned char* sG = sQ + 2 * AT_PLANE_B;
+    TrBase trb;
+    trb.set(smem_l + (t % 3) * AT_SLOT_B, tra);
     const float* axt = sAux + (t & 1) * 3 * AT_KT;
     const int64_t qb = (int64_t)t * AT_KT;
     const bool tail = qb + AT_KT > Lg;
@@ -634,12 +706,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         }
         float e0 = fmaf(s[4 * rg], c, -l4.x), e1 = fmaf(s[4 * rg + 1], c, -l4.y), e2 = fmaf(s[4 * rg + 2], c, -l4.z), e3 = fmaf(s[4 * rg + 3], c, -l4.w);
         hw_exp2x4(e0, e1, e2, e3);
+        if (tail) {                              // queries past the bag (their lse slot holds 0): one uniform branch per group
+          const int lim = (int)(Lg - qb);
+          if (32 * u + qo + 0 >= lim) e0 = 0.f;
+          if (32 * u + qo + 1 >= lim) e1 = 0.f;
+          if (32 * u + qo + 2 >= lim) e2 = 0.f;
+          if (32 * u + qo + 3 >= lim) e3 = 0.f;
+        }
         const float pv[4] = {e0, e1, e2, e3};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * rg + e;
-          float p = pv[e];
-          if (tail && qb + 32 * u + qo + e >= Lg) p = 0.f;       // queries past the bag (their lse slot holds 0)
+          const float p = pv[e];
           const float kf = (!DROP || ((hx[e] >> kbyte) & 0xffu) >= a.drop_thr) ? ik : 0.f;      // keep / (1 - p)
           pd[r] = p * kf;
           s[r] = p * fmaf(dp[r], kf, -dvv[e]);                    // dS[q, key]
@@ -655,10 +733,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         split8(w, dh, dl);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-          const bf16x8 gh = frag_tr(sG, 32 * u + 16 * s2 + 4 * half, dt, lane);
-          const bf16x8 gl = frag_tr(sG + AT_PLANE_B, 32 * u + 16 * s2 + 4 * half, dt, lane);
-          const bf16x8 qh = frag_tr(sQ, 32 * u + 16 * s2 + 4 * half, dt, lane);
-          const bf16x8 ql = frag_tr(sQ + AT_PLANE_B, 32 * u + 16 * s2 + 4 * half, dt, lane);
+          const bf16x8 gh = frag_tr_pre(trb, 2 * AT_PLANE_B, 32 * u + 16 * s2, dt);
+          const bf16x8 gl = frag_tr_pre(trb, 3 * AT_PLANE_B, 32 * u + 16 * s2, dt);
+          const bf16x8 qh = frag_tr_pre(trb, 0, 32 * u + 16 * s2, dt);
+          const bf16x8 ql = frag_tr_pre(trb, AT_PLANE_B, 32 * u + 16 * s2, dt);
           dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl, ph, dv[dt], 0, 0, 0);     // dV^T[d, key] += dO^T[d, q] . Pd[q, key]
           dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ql, dh, dk[dt], 0, 0, 0);     // dK^T[d, key] += Q^T[d, q] . dS[q, key]
           dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, pl, dv[dt], 0, 0, 0);
@@ -674,14 +752,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
       at_barrier();
     }
   }
-  if (kok) {
-    float* const krow = a.dqkv + (row0 + key) * ldq + D + h * HD;
+  int tid2 = threadIdx.x;                        // (lane coordinates derived again for the epilogue: see the forward)
+  asm volatile("" : "+v"(tid2));
+  const int half2 = (tid2 >> 5) & 1;
+  const int64_t key2 = (int64_t)kt * AT_QB + (tid2 >> 6) * 32 + (tid2 & 31);
+  if (key2 < Lg) {
+    float* const krow = a.dqkv + (row0 + key2) * ldq + D + h * HD;
     float* const vrow = krow + D;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const int d = 32 * dt + 8 * rg + 4 * half;
+        const int d = 32 * dt + 8 * rg + 4 * half2;
         if (d < HD) {
           *reinterpret_cast<float4*>(krow + d) = make_float4(dk[dt][4 * rg] * a.scale, dk[dt][4 * rg + 1] * a.scale,
                                                              dk[dt][4 * rg + 2] * a.scale, dk[dt][4 * rg + 3] * a.scale);
@@ -693,26 +775,36 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 
 // D[row, h] = sum_d dO[row, h*HD + d] * O[row, h*HD + d]   (the softmax backward's row constant; holds with dropout, since
 // sum_j dP_j P_j = sum_j dPd_j Pd_j = dO . O), and the bf16x3 operand planes of dO for the two gradient kernels, in one pass
+// One thread per float4: loads and plane stores are contiguous across the wave (the one-thread-per-(row, head) form of round 3
+// walked 192-byte strides: 58 us for 150 MB); the HD / 4 partial dot products of a (row, head) meet in LDS.
 template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const float* __restrict__ dout, const float* __restrict__ out,
-                                                            int64_t n /* rows * H */, float* __restrict__ dsum,
-                                                            bf16raw* __restrict__ g_hi, bf16raw* __restrict__ g_lo) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= n) return;
-  const float4* a = reinterpret_cast<const float4*>(dout + idx * HD);
-  const float4* b = reinterpret_cast<const float4*>(out + idx * HD);
-  uint2* gh = reinterpret_cast<uint2*>(g_hi + idx * HD);
-  uint2* gl = reinterpret_cast<uint2*>(g_lo + idx * HD);
+__global__ __launch_bounds__(HD == 48 ? 192 : 256) void attn_bwd_prep_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                                           int64_t n /* rows * H */, float* __restrict__ dsum,
+                                                                           bf16raw* __restrict__ g_hi, bf16raw* __restrict__ g_lo) {
+  constexpr int BT = HD == 48 ? 192 : 256, G = HD / 4, NG = BT / G;
+  __shared__ float part[BT];
+  const int tid = threadIdx.x;
+  const int64_t idx4 = (int64_t)blockIdx.x * BT + tid, n4 = n * G;
   float s = 0.f;
-#pragma unroll
-  for (int cc = 0; cc < HD / 4; ++cc) {
-    const float4 x = a[cc], y = b[cc];
-    s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+  if (idx4 < n4) {
+    const float4 x = reinterpret_cast<const float4*>(dout)[idx4], y = reinterpret_cast<const float4*>(out)[idx4];
+    s = (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
     uint2 hh, ll;
     split4(x, hh, ll);
-    gh[cc] = hh; gl[cc] = ll;
+    reinterpret_cast<uint2*>(g_hi)[idx4] = hh;
+    reinterpret_cast<uint2*>(g_lo)[idx4] = ll;
   }
-  dsum[idx] = s;
+  part[tid] = s;
+  __syncthreads();
+  if (tid < NG) {
+    const int64_t gi = (int64_t)blockIdx.x * NG + tid;
+    if (gi < n) {
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < G; ++i) acc += part[tid * G + i];
+      dsum[gi] = acc;
+    }
+  }
 }
 
 #ifdef AT_STAMP
@@ -804,12 +896,14 @@ extern "C" int advmil_mha_bwd(const void* qkv_hi, const void* qkv_lo, const floa
   bf16raw* g_hi = (bf16raw*)((char*)ws + attn_ws_dsum_bytes(Ltot, nhead));
   bf16raw* g_lo = (bf16raw*)((char*)g_hi + ((size_t)Ltot * (size_t)nhead * (size_t)head_dim * 2 + 15) / 16 * 16);
   const int64_t n = Ltot * nhead;
-  const dim3 pg((unsigned)((n + 255) / 256));
+  const int pbt = head_dim == 48 ? 192 : 256;                       // threads per block; each covers pbt / (head_dim / 4) (row, head) pairs
+  const int64_t png = pbt / (head_dim / 4);
+  const dim3 pg((unsigned)((n + png - 1) / png));
   switch (head_dim) {
-    case 16: hipLaunchKernelGGL((attn_bwd_prep_kernel<16>), pg, dim3(256), 0, stream, dout, out, n, dsum, g_hi, g_lo); break;
-    case 32: hipLaunchKernelGGL((attn_bwd_prep_kernel<32>), pg, dim3(256), 0, stream, dout, out, n, dsum, g_hi, g_lo); break;
-    case 48: hipLaunchKernelGGL((attn_bwd_prep_kernel<48>), pg, dim3(256), 0, stream, dout, out, n, dsum, g_hi, g_lo); break;
-    default: hipLaunchKernelGGL((attn_bwd_prep_kernel<64>), pg, dim3(256), 0, stream, dout, out, n, dsum, g_hi, g_lo); break;
+    case 16: hipLaunchKernelGGL((attn_bwd_prep_kernel<16>), pg, dim3(pbt), 0, stream, dout, out, n, dsum, g_hi, g_lo); break;
+    case 32: hipLaunchKernelGGL((attn_bwd_prep_kernel<32>), pg, dim3(pbt), 0, stream, dout, out, n, dsum, g_hi, g_lo); break;
+    case 48: hipLaunchKernelGGL((attn_bwd_prep_kernel<48>), pg, dim3(pbt), 0, stream, dout, out, n, dsum, g_hi, g_lo); break;
+    default: hipLaunchKernelGGL((attn_bwd_prep_kernel<64>), pg, dim3(pbt), 0, stream, dout, out, n, dsum, g_hi, g_lo); break;
   }
   ADVMIL_LAUNCH_CHECK();
   a.lse = const_cast<float*>(lse); a.do_hi = g_hi; a.do_lo = g_lo; a.dsum = dsum; a.dqkv = dqkv;
