@@ -360,13 +360,16 @@ class BagCache:
                 "evictions": self.evictions, "refused": self.refused, "mismatches": self.mismatches}
 
 
+def fingerprint_positions(n):
+    """Flat element indices of a bag of n elements that bag_fingerprint samples."""
+    return (0, n // 3, n // 2, (2 * n) // 3, n - 1) if n else ()
+
+
 def bag_fingerprint(x0):
     """Cheap identity of a host bag [1, N, C]: its shape and five sampled elements (a few microseconds; no pass over the bag). Kept
     with the cache entry and compared on every hit, so a key that now names a different bag cannot serve a stale one."""
     flat = x0.reshape(-1)
-    n = flat.numel()
-    pick = (0, n // 3, n // 2, (2 * n) // 3, n - 1) if n else ()
-    return (tuple(x0.shape), tuple(float(flat[i]) for i in pick))
+    return (tuple(x0.shape), tuple(float(flat[i]) for i in fingerprint_positions(flat.numel())))
 
 
 class BagCacheView:

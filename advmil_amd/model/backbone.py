@@ -38,9 +38,7 @@ def load_backbone(mode, dims):
 def _small_fc(seq, x, rng, tag):
     """Linear -> ReLU -> Dropout on a [1, d] vector (launch-bound; stays a couple of tiny device ops)."""
     lin, drop = seq[0], seq[2]
-    if x.dim() == 2 and lin.in_features % 4 == 0 and lin.out_features % 4 == 0:      # one launch, dropout in the epilogue
-        return ops.linear_act(x, lin.weight, lin.bias, "relu", drop.p if seq.training else 0.0, rng, tag)
-    return dropout_small(F.relu(F.linear(x, lin.weight, lin.bias)), drop.p, seq.training, rng, tag)
+    return ops.linear_act_any(x, lin.weight, lin.bias, "relu", drop.p if seq.training else 0.0, rng, tag)   # one launch, dropout in the epilogue
 
 
 class ABMIL(nn.Module):
@@ -100,7 +98,7 @@ class DeepAttMISL(nn.Module):
             cid = cid + seg.rowseg.to(torch.long) * K
         h_cluster = ops.segmented_mean(h, cid, K * nb)                            # [8B, hid]
         fc, p = self.attention_net[0], (self.attention_net[2].p if self.training else 0.0)
-        hc = dropout_small(F.relu(F.linear(h_cluster, fc.weight, fc.bias)), p, self.training, rng, "misl_fc")
+        hc = ops.linear_act_any(h_cluster, fc.weight, fc.bias, "relu", p, rng, "misl_fc")
         pooled, A, _ = self.attention_net[3].pool(hc, None if seg is None else seg.uniform(K))
         self.last_attention = A.detach()
         return pooled.unsqueeze(0) if seg is None else pooled

@@ -120,9 +120,22 @@ def run_mlp_small(seq, x, rng, tag, final_act=None):
                 x = ops.skinny_linear(x, m.weight, m.bias, act)
                 j = k
                 continue
-            x = F.linear(x, m.weight, m.bias)
+            # any other width (not a multiple of 4 floats): zero-padded through the same contraction (ops.linear_act_any)
+            act, p, k = "none", 0.0, j + 1
+            if k < len(mods) and isinstance(mods[k], nn.ReLU):
+                act, k = "relu", k + 1
+                if k < len(mods) and isinstance(mods[k], nn.Dropout):
+                    p, k = (mods[k].p if seq.training else 0.0), k + 1
+            x = ops.linear_act_any(x, m.weight, m.bias, act, p, rng, f"{tag}.{k - 1}")
+            j = k
+            continue
         elif isinstance(m, nn.LayerNorm):
-            x = F.layer_norm(x, m.normalized_shape, m.weight, m.bias, m.eps)
+            # make_mlp_layer(layer_norm=True): Linear -> LayerNorm -> ReLU (-> Dropout): LayerNorm + ReLU is one row kernel each way
+            if not (j + 1 < len(mods) and isinstance(mods[j + 1], nn.ReLU) and len(m.normalized_shape) == 1 and x.dim() == 2):
+                raise NotImplementedError("advmil_amd: a LayerNorm that is not followed by ReLU has no HIP path (the reference's builders never make one)")
+            x = ops.ln_relu(x.contiguous(), m.weight, m.bias, m.eps)
+            j += 2
+            continue
         elif isinstance(m, nn.ReLU):
             x = F.relu(x)
         elif isinstance(m, nn.Sigmoid):

@@ -890,6 +890,26 @@ def linear_act(x, W, b, act="none", p=0.0, rng=None, tag="", emit_planes=False):
     return out
 
 
+def linear_act_any(x, W, b, act="none", p=0.0, rng=None, tag=""):
+    """linear_act for a [B, d]-sized layer of ANY width: the contraction engine wants every contiguous extent to be a multiple of 4
+    floats, so a layer that is not (no shipped configuration has one; odd `pdh_dims` / `hid_dims` of the reference's builders do)
+    runs on zero-padded copies of x / W / b (torch pad + slice: copies, no arithmetic) and its dropout is drawn on the unpadded
+    [B, N] result, i.e. from the same (tag, shape) site as before. There is no eager-ATen linear anywhere in the product path."""
+    K, N = W.shape[1], W.shape[0]
+    if x.dim() != 2 or not x.is_cuda:
+        raise RuntimeError("advmil_amd: linear layers run on 2-D HIP tensors only (no CPU / eager fallback)")
+    if K % 4 == 0 and N % 4 == 0:
+        return linear_act(x, W, b, act, p, rng, tag)
+    pk, pn = (-K) % 4, (-N) % 4
+    xp = torch.nn.functional.pad(x, (0, pk)) if pk else x
+    Wp = torch.nn.functional.pad(W, (0, pk, 0, pn)) if (pk or pn) else W
+    bp = None if b is None else (torch.nn.functional.pad(b, (0, pn)) if pn else b)
+    y = linear_act(xp.contiguous(), Wp.contiguous(), bp, act)[:, :N]
+    if p > 0.0:
+        y = dropout(y.contiguous(), p, rng or default_rng(x.device), tag)
+    return y
+
+
 class GatedAttnPoolFn(torch.autograd.Function):
     """(pooled[B,D], A[N]) = per-bag softmax-pool of h[N,D] scored by the gated attention net; `seg` partitions the rows
     into the B bags of a step slab (None = one bag). Attn_Net_Gated + softmax + mm (model/backbone_utils.py:11-29,

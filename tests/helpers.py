@@ -96,3 +96,16 @@ def bag(i, n, device="cpu"):
 
 def label(i, device="cpu"):
     return T(synth.label(DATA_SEED, i), device)
+
+
+def poison_host_bag(x):
+    """NaN everywhere in a host bag except the five elements the bag cache samples as the bag's identity
+    (advmil_amd.ingest.bag_fingerprint): a later epoch that still READ the host bag would produce NaNs, while the cache keeps
+    recognising it as the same bag. Returns the poisoned tensor (a new one)."""
+    import torch
+    from advmil_amd.ingest import fingerprint_positions
+    y = torch.full_like(x, float("nan"))
+    fx, fy = x.reshape(-1), y.reshape(-1)
+    for i in fingerprint_positions(fx.numel()):
+        fy[i] = fx[i]
+    return y

@@ -83,7 +83,7 @@ def test_eval_bags_stay_in_hbm_between_epochs():
     assert cache.misses - m0 == len(lens) and cache.hits == h0
     torch.cuda.synchronize()
     for it in ds.items:
-        it[1][0].fill_(float("nan"))
+        it[1][0].copy_(H.poison_host_bag(it[1][0]))
     order = [3, 0, 4, 1, 2]
     b = MyHandler.test_model(g, d, "abmil", Loader(ds, order), noise=[noises[i] for i in order], batch_bags=3)
     assert cache.hits - h0 == len(lens)
@@ -160,3 +160,32 @@ def test_degenerate_loaders():
     same(a, b)
     cl = h._train_each_epoch(five, "train")                                    # one step of 4 bags, the fifth is dropped
     assert cl["y_hat"].shape == (4, 1) and len(h.pop_logs()) == 2 and bool(torch.isfinite(cl["f_fake"]).all())
+
+
+def test_a_cache_hit_is_checked_against_the_bag_the_loader_hands_over():
+    """A key that now names a DIFFERENT bag (another loader under the same scope, a dataset that changes its bags between visits)
+    must not be served from the cache: the entry keeps the host bag's shape and five sampled elements and is dropped on a mismatch.
+    A bare list / generator (no `.dataset`) is only cached when the configuration asks for the cache explicitly."""
+    from advmil_amd.config import default_cfg
+    from advmil_amd.ingest import BagCache, bag_fingerprint
+    from advmil_amd.model import MyHandler
+    x = torch.randn(1, 64, 256)
+    c = BagCache(DEV, 1e9)
+    c.put(("s", 1), x.to(DEV), bag_fingerprint(x))
+    assert c.get(("s", 1), bag_fingerprint(x)) is not None and c.hits == 1
+    y = x.clone()
+    y[0, 0, 0] += 1.0
+    assert c.get(("s", 1), bag_fingerprint(y)) is None and c.mismatches == 1 and len(c.entries) == 0 and c.bytes == 0
+    c.put(("s", 1), x.to(DEV), bag_fingerprint(x))
+    assert c.get(("s", 1), bag_fingerprint(x[:, :32].contiguous())) is None and c.mismatches == 2
+    # list loaders: cached only on request
+    lens = (256, 128)
+    loader = [(torch.tensor([[i]], dtype=torch.int), [H.bag(500 + i, 256)[:, :n].contiguous(), torch.zeros(1, 1)], H.label(i))
+              for i, n in enumerate(lens)]
+    h = MyHandler(default_cfg(bp_every_batch=2), device=DEV)
+    h._train_each_epoch(loader, "train")
+    assert h._bag_caches["train"] is None
+    h2 = MyHandler(default_cfg(bp_every_batch=2, bag_cache_gb=1.0), device=DEV)
+    h2._train_each_epoch(loader, "train")
+    h2._train_each_epoch(loader, "train")
+    assert h2._bag_caches["train"] is not None and h2._bag_caches["train"].stats()["hits"] == 2

@@ -284,19 +284,30 @@ def test_second_epoch_is_served_from_the_device_resident_bag_cache(nrows):
         return [(torch.tensor([[i]], dtype=torch.int), [H.bag(80 + i, 3 * nrows)[:, :lens[i % 3]].contiguous(), torch.zeros(1, 1)], H.label(i))
                 for i in range(6)]
 
+    class DS:                                    # a dataset object: the cache's scope (a bare list is only cached on request)
+        def __init__(self, items):
+            self.items = items
+
+    class DL:
+        def __init__(self, ds, order):
+            self.dataset, self.order = ds, order
+
+        def __iter__(self):
+            return iter([self.dataset.items[i] for i in self.order])
+
     def run(cache_gb, poison):
         from advmil_amd import ingest
         ingest.device_bag_cache(DEV).clear()     # (the device's cache is shared: bags of earlier tests would hold the small budget)
         h = MyHandler(default_cfg(bp_every_batch=3, bag_cache_gb=cache_gb), device=DEV)
         load_synth(h.netG, "G-abmil:"); load_synth(h.netD, "D-prj:")
         h.rng.reset(99)
-        loader = mk()
-        h._train_each_epoch(loader, "train")
+        ds = DS(mk())
+        h._train_each_epoch(DL(ds, list(range(6))), "train")
         order = [4, 0, 5, 2, 1, 3]                                             # epoch 2: shuffled, step batches regrouped
         if poison:
             torch.cuda.synchronize()
-            loader = [(it[0], [torch.full_like(it[1][0], float("nan")), it[1][1]], it[2]) for it in loader]
-        cl = h._train_each_epoch([loader[i] for i in order], "train")
+            ds.items = [(it[0], [H.poison_host_bag(it[1][0]), it[1][1]], it[2]) for it in ds.items]
+        cl = h._train_each_epoch(DL(ds, order), "train")
         view = h._bag_caches.get("train")      # (this loader's window onto the device's ONE shared cache: stats taken now)
         return cl, h.pop_logs(), h.optimizerG.flat_param.clone(), None if view is None else view.stats()
 
