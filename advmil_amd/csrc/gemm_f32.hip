@@ -143,6 +143,15 @@ __device__ __forceinline__ void read_frag_presplit(const bf16raw* __restrict__ p
   h = a.v; l = b.v;
 }
 
+// the hi plane's fragment alone (single-plane operands)
+template <int BKT>
+__device__ __forceinline__ void read_frag_hi(const bf16raw* __restrict__ planes, int rbase, int ks, int i, int hi, bf16x8& h) {
+  const int row = rbase + i;
+  Frag8 a;
+  a.u = *reinterpret_cast<const uint4*>(planes + row * PITCH_PS(BKT) + ps_unit(row, ks * 2 + hi, BKT / 8) * 8);
+  h = a.v;
+}
+
 // Pre-split LDS image of an m-contiguous operand tile ([k][rows] source, e.g. both operands of dW = dY^T X): two bf16 planes
 // [k][PITCH_MC(ROWS)], hi then lo, in the SOURCE orientation (coalesced 8-byte stores), consumed with the gfx950 LDS transpose
 // read: ds_read_b64_tr_b16 hands lane c of a 16-lane group the 4 k-consecutive halfwords of column c out of a [4 k][16 m]
@@ -236,7 +245,7 @@ struct OperandStage {
           off = k * ld + m;
         }
         ph[p] = ok ? *reinterpret_cast<const uint4*>(hi + off) : make_uint4(0u, 0u, 0u, 0u);
-        pl[p] = ok ? *reinterpret_cast<const uint4*>(lo + off) : make_uint4(0u, 0u, 0u, 0u);
+        pl[p] = (ok && lo) ? *reinterpret_cast<const uint4*>(lo + off) : make_uint4(0u, 0u, 0u, 0u);      // (single-plane operand: lo == NULL)
       }
     }
   }
@@ -791,20 +800,26 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // contraction, tools/probe/stamp_gemm.sh) and lets the C stores drain under the next tile's K loop instead of at workgroup exit.
 // EPI = 1: instantiated for the fused gate score alone (its epilogue stores one partial per row and column block, no C): the
 // 256x256 form, which beside the full streaming epilogue would not fit the register file. EPI = 2: 256x256 with the PLAIN streaming form.
-template <int TN, int NBUF, int WR, int BKT, int EPI = 0>
+// ALO = 0: A is a single-plane (bf16) operand -- no A lo rows in the ring (a 256x256 chunk stages 48 KB instead of 64), two MFMAs
+// per product (a.b = ah.bh + ah.bl exactly as the three-product form with al = 0: same order, bit-identical to it).
+template <int TN, int NBUF, int WR, int BKT, int EPI = 0, int ALO = 1>
 __global__ __launch_bounds__(128 * WR, 2) void gemm_nt_planes_kernel(GemmArgs g) {
   constexpr int TM = 2, WC = 2, NW = WR * WC;
   constexpr int BM_ = 64 * WR, BN_ = 64 * TN;
-  constexpr int ROWS_ALL = 2 * (BM_ + BN_);            // plane rows per buffer: A hi, A lo, B hi, B lo
+  constexpr int AROWS = (1 + ALO) * BM_;               // plane rows of A per buffer
+  constexpr int ROWS_ALL = AROWS + 2 * BN_;            // plane rows per buffer: A hi, (A lo,) B hi, B lo
   constexpr int RPP = 512 / BKT, LPR = BKT / 8;        // rows per 1 KB piece, lanes (16-byte units) per row
   constexpr int NPIECE = ROWS_ALL / RPP, PPW = NPIECE / NW;
   static_assert(NPIECE % NW == 0, "pieces must divide evenly over the waves");
   constexpr int BUF_HW = ROWS_ALL * BKT;               // halfwords per buffer
   constexpr int PATCH_FLOATS = NW * EPI_WAVE_FLOATS(TM, TN);
-  static_assert(PATCH_FLOATS <= BUF_HW / 2, "the epilogue area must fit one ring slot");
+  // the epilogue's LDS area: the ring slot of the chunk just consumed when it fits one (every two-plane-A form), else an area of its
+  // own behind the ring (the narrower single-plane-A slots of the 256x128 / 256x192 tiles)
+  constexpr bool EPI_IN_SLOT = PATCH_FLOATS <= BUF_HW / 2;
+  static_assert(EPI_IN_SLOT || ALO == 0, "the epilogue area must fit one ring slot");
   constexpr int EST = TM * TN * 4;                     // stores per wave of the streaming epilogue (its lower bound)
   static_assert(EST + PPW <= 63, "counted waits are 6-bit");
-  __shared__ __attribute__((aligned(16))) float smem[NBUF * BUF_HW / 2];
+  __shared__ __attribute__((aligned(16))) float smem[NBUF * BUF_HW / 2 + (EPI_IN_SLOT ? 0 : PATCH_FLOATS)];
   bf16raw* const lds = reinterpret_cast<bf16raw*>(smem);
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);     // uniform: lives in an SGPR
   const int wr = wave / WC, wc = wave % WC;
@@ -840,9 +855,9 @@ __global__ __launch_bounds__(128 * WR, 2) void gemm_nt_planes_kernel(GemmArgs g)
       int r;                                                 // tile-local row of its operand
       int64_t ld, row0;
       if (prow < BM_) { r = prow; ld = g.lda; row0 = (int64_t)mt * BM_; }
-      else if (prow < 2 * BM_) { r = prow - BM_; ld = g.lda; row0 = (int64_t)mt * BM_; }
-      else if (prow < 2 * BM_ + BN_) { r = prow - 2 * BM_; ld = g.ldb; row0 = (int64_t)nt * BN_; }
-      else { r = prow - 2 * BM_ - BN_; ld = g.ldb; row0 = (int64_t)nt * BN_; }
+      else if (prow < AROWS) { r = prow - BM_; ld = g.lda; row0 = (int64_t)mt * BM_; }
+      else if (prow < AROWS + BN_) { r = prow - AROWS; ld = g.ldb; row0 = (int64_t)nt * BN_; }
+      else { r = prow - AROWS - BN_; ld = g.ldb; row0 = (int64_t)nt * BN_; }
       soff[it] = (uint32_t)(((row0 + r) * ld + ps_unit(r, lane % LPR, LPR) * 8) * 2);
     }
   };
@@ -852,8 +867,8 @@ __global__ __launch_bounds__(128 * WR, 2) void gemm_nt_planes_kernel(GemmArgs g)
 #pragma unroll
     for (int it = 0; it < PPW; ++it) {
       const int p0 = (wave + NW * it) * RPP;               // uniform
-      const char* base = reinterpret_cast<const char*>(p0 < BM_ ? g.epi.a_hi : (p0 < 2 * BM_ ? g.epi.a_lo : (p0 < 2 * BM_ + BN_ ? g.epi.b_hi : g.epi.b_lo)));
-      base += (k0 + (next ? (p0 < 2 * BM_ ? dA : dB) : 0)) * 2;
+      const char* base = reinterpret_cast<const char*>(p0 < BM_ ? g.epi.a_hi : (p0 < AROWS ? g.epi.a_lo : (p0 < AROWS + BN_ ? g.epi.b_hi : g.epi.b_lo)));
+      base += (k0 + (next ? (p0 < AROWS ? dA : dB) : 0)) * 2;
       __builtin_amdgcn_global_load_lds((const GLB_AS void*)(base + soff[it]), (LDS_AS void*)(lds + buf * BUF_HW + (wave + NW * it) * 512), 16, 0, 0);
     }
   };
@@ -903,19 +918,22 @@ __global__ __launch_bounds__(128 * WR, 2) void gemm_nt_planes_kernel(GemmArgs g)
         else if (has_next) dma(pbuf, (int64_t)(pc - C) * BKT, true);
       }
       const bf16raw* cA = lds + cur * BUF_HW;
-      const bf16raw* cB = cA + 2 * BM_ * BKT;
+      const bf16raw* cB = cA + AROWS * BKT;
 #pragma unroll
       for (int ks = 0; ks < BKT / 16; ++ks) {
         bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-        for (int a = 0; a < TM; ++a) read_frag_presplit<BM_, BKT>(cA, wr * 32 * TM + a * 32, ks, i, hi, ah[a], al[a]);
+        for (int a = 0; a < TM; ++a) {
+          if constexpr (ALO) read_frag_presplit<BM_, BKT>(cA, wr * 32 * TM + a * 32, ks, i, hi, ah[a], al[a]);
+          else read_frag_hi<BKT>(cA, wr * 32 * TM + a * 32, ks, i, hi, ah[a]);
+        }
 #pragma unroll
         for (int b = 0; b < TN; ++b) read_frag_presplit<BN_, BKT>(cB, wc * 32 * TN + b * 32, ks, i, hi, bh[b], bl[b]);
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
           for (int b = 0; b < TN; ++b) {
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+            if constexpr (ALO) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
           }
@@ -925,7 +943,8 @@ __global__ __launch_bounds__(128 * WR, 2) void gemm_nt_planes_kernel(GemmArgs g)
     // the epilogue's LDS area: the ring slot of the chunk just consumed (the other slots hold / receive the next tile's chunks; the
     // slot is refilled only behind the next tile's first barrier, which every wave reaches after it has left the epilogue)
     const int last = cur == 0 ? NBUF - 1 : cur - 1;
-    young = gemm_epilogue<TM, TN, WR, WC, true, EPI>(g, acc, smem + last * (BUF_HW / 2), wave, lane, wr, wc, m0, n0, 0, nt_i);
+    young = gemm_epilogue<TM, TN, WR, WC, true, EPI>(g, acc, EPI_IN_SLOT ? smem + last * (BUF_HW / 2) : smem + NBUF * (BUF_HW / 2), wave, lane, wr,
+                                                     wc, m0, n0, 0, nt_i);
     mt_i = mt_n; nt_i = nt_n;
     if (has_next) {
       int lane2 = (int)threadIdx.x & 63;
@@ -963,13 +982,26 @@ __device__ __forceinline__ void read_frag_tn(const unsigned char* __restrict__ t
   h = x.v; l = y.v;
 }
 
-template <int TM, int TN, int WR, int WC, int NBUF>
+// BLO = 0: B is a single-plane (bf16) operand (the slab X of the x_storage = "bf16" mode): no B lo pieces, two MFMAs per product.
+template <int BR>
+__device__ __forceinline__ void read_frag_tn_hi(const unsigned char* __restrict__ tile, int rbase, int ks, int lane, bf16x8& h) {
+  constexpr int ROWB = BR * 2;
+  const int q4 = (lane & 15) >> 2, b = (lane >> 4) & 1, e = lane & 3;
+  const int krow = ks * 16 + (lane >> 5) * 8 + q4;
+  const unsigned char* p = tile + krow * ROWB + (((rbase >> 5) ^ q4) << 6) + 32 * b + 8 * e;
+  union { bf16x4_t q[2]; bf16x8 v; } x;
+  x.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(p));
+  x.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(p + 4 * ROWB));
+  h = x.v;
+}
+
+template <int TM, int TN, int WR, int WC, int NBUF, int BLO = 1>
 __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_tn_planes_kernel(GemmArgs g) {
   constexpr int NW = WR * WC, BKT = 32;
   constexpr int BM_ = 32 * TM * WR, BN_ = 32 * TN * WC;
   static_assert(BM_ == 128 || BM_ == 256, "row pitch of the LDS image"); static_assert(BN_ == 128 || BN_ == 256, "row pitch");
   constexpr int PA = BM_ / 16, PB = BN_ / 16;                // 1 KB pieces per plane and chunk
-  constexpr int NPIECE = 2 * (PA + PB), PPW = NPIECE / NW;
+  constexpr int NPIECE = 2 * PA + (1 + BLO) * PB, PPW = NPIECE / NW;
   static_assert(NPIECE % NW == 0, "pieces must divide evenly over the waves");
   constexpr int SLOT_B = NPIECE * 1024;                      // [A hi | A lo | B hi | B lo]
   constexpr int PATCH_B = NW * EPI_WAVE_FLOATS(TM, TN) * 4;
@@ -1041,13 +1073,16 @@ __global__ __launch_bounds__(64 * WR * WC, 2) void gemm_tn_planes_kernel(GemmArg
 #pragma unroll
       for (int a = 0; a < TM; ++a) read_frag_tn<BM_>(cA, wr * 32 * TM + a * 32, ks, lane, ah[a], al[a]);
 #pragma unroll
-      for (int b = 0; b < TN; ++b) read_frag_tn<BN_>(cB, wc * 32 * TN + b * 32, ks, lane, bh[b], bl[b]);
+      for (int b = 0; b < TN; ++b) {
+        if constexpr (BLO) read_frag_tn<BN_>(cB, wc * 32 * TN + b * 32, ks, lane, bh[b], bl[b]);
+        else read_frag_tn_hi<BN_>(cB, wc * 32 * TN + b * 32, ks, lane, bh[b]);
+      }
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+          if constexpr (BLO) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
         }
     }
@@ -1141,8 +1176,10 @@ static void launch_tile(int a_kc, int b_kc, dim3 grid, hipStream_t stream, const
 
 // Which operands can be taken from caller-provided planes: both planes present, 16-byte aligned, pitch and contiguous extent
 // multiples of 8 halfwords (a 16-byte piece never straddles a row end or the K range).
+// lo == NULL with hi present: a SINGLE-plane operand -- the tensor IS bf16 (a bag stored in bf16: the x_storage = "bf16" mode), its
+// lo plane is identically zero, nothing is fetched for it and the kernels built for it issue two MFMAs per product instead of three.
 static int planes_usable(const void* hi, const void* lo, int64_t ld, int64_t contiguous_extent) {
-  return hi && lo && !((uintptr_t)hi & 15) && !((uintptr_t)lo & 15) && !(ld & 7) && !(contiguous_extent & 7);
+  return hi && !((uintptr_t)hi & 15) && !((uintptr_t)lo & 15) && !(ld & 7) && !(contiguous_extent & 7);
 }
 
 // tile = 10*TM + TN  (22: 128x128, 23: 128x192, 13: 64x192, 12: 64x128, 11: 64x64).
@@ -1346,6 +1383,17 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
     static const int ncu = []() { int dev = 0, n = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
     const int ntile_all = g.mtiles * g.ntiles;
     dim3 pgrid(ntile_all < ncu ? ntile_all : ncu);        // persistent: one workgroup per CU walks its share of the tiles
+    if (!epi->b_lo) return ADVMIL_EINVAL;                 // (a single-plane B has no instantiation here: weights are always hi + lo)
+    if (!epi->a_lo) {                                     // A = a bf16 slab (x_storage = "bf16"): two products per MFMA step
+      switch (tile) {
+        case 85: hipLaunchKernelGGL((gemm_nt_planes_kernel<4, 2, 4, 32, 2, 0>), pgrid, dim3(512), 0, stream, g); break;
+        case 83: hipLaunchKernelGGL((gemm_nt_planes_kernel<3, 2, 4, 32, 0, 0>), pgrid, dim3(512), 0, stream, g); break;
+        case 82: hipLaunchKernelGGL((gemm_nt_planes_kernel<2, 3, 4, 32, 0, 0>), pgrid, dim3(512), 0, stream, g); break;
+        default: return ADVMIL_EINVAL;
+      }
+      ADVMIL_LAUNCH_CHECK();
+      return ADVMIL_OK;
+    }
     switch (tile) {
       case 84: hipLaunchKernelGGL((gemm_nt_planes_kernel<4, 2, 4, 32, 1>), pgrid, dim3(512), 0, stream, g); break;   // 2 x 64 KB
       case 85: hipLaunchKernelGGL((gemm_nt_planes_kernel<4, 2, 4, 32, 2>), pgrid, dim3(512), 0, stream, g); break;   // 256x256, plain streaming epilogue (+ two layers)
@@ -1366,6 +1414,14 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
     g.ntiles = (int)(N / bn);
     const int gs = M >= N ? g.ntiles : g.mtiles, og = M >= N ? g.mtiles : g.ntiles;
     const dim3 tgrid((unsigned)(8 * ((splits * og + 7) / 8) * gs));
+    if (!epi->a_lo) return ADVMIL_EINVAL;                 // (only B -- the slab -- may be a single-plane operand here)
+    if (!epi->b_lo) {
+      switch (tile) {
+        case 91: hipLaunchKernelGGL((gemm_tn_planes_kernel<2, 2, 2, 4, 3, 0>), tgrid, dim3(512), 0, stream, g); break;
+        case 92: hipLaunchKernelGGL((gemm_tn_planes_kernel<2, 2, 4, 2, 3, 0>), tgrid, dim3(512), 0, stream, g); break;
+        default: hipLaunchKernelGGL((gemm_tn_planes_kernel<2, 4, 4, 2, 2, 0>), tgrid, dim3(512), 0, stream, g); break;
+      }
+    } else
     switch (tile) {
       case 91: hipLaunchKernelGGL((gemm_tn_planes_kernel<2, 2, 2, 4, 3>), tgrid, dim3(512), 0, stream, g); break;   // 3 x 48 KB
       case 92: hipLaunchKernelGGL((gemm_tn_planes_kernel<2, 2, 4, 2, 3>), tgrid, dim3(512), 0, stream, g); break;   // 3 x 48 KB
@@ -1439,19 +1495,19 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
       l.v[j] = (__bf16)(x[j] - (float)h.v[j]);
     }
     reinterpret_cast<uint4*>(hi)[idx] = h.u;
-    reinterpret_cast<uint4*>(lo)[idx] = l.u;
+    if (lo) reinterpret_cast<uint4*>(lo)[idx] = l.u;         // lo == NULL: the bf16 rounding alone (a bag entering a bf16 slab)
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
     const int64_t j = (n8 << 3) + threadIdx.x;
     const __bf16 h = (__bf16)src[j];
     const __bf16 l = (__bf16)(src[j] - (float)h);
     hi[j] = *reinterpret_cast<const bf16raw*>(&h);
-    lo[j] = *reinterpret_cast<const bf16raw*>(&l);
+    if (lo) lo[j] = *reinterpret_cast<const bf16raw*>(&l);
   }
 }
 
 extern "C" int advmil_split_planes(const float* src, int64_t n, void* hi, void* lo, advmil_stream_t stream_) {
-  if (!src || !hi || !lo || n < 0) return ADVMIL_EINVAL;
+  if (!src || !hi || n < 0) return ADVMIL_EINVAL;            // (lo may be NULL: hi = bf16(x) only)
   if (((uintptr_t)src & 15) || ((uintptr_t)hi & 15) || ((uintptr_t)lo & 15)) return ADVMIL_EINVAL;
   if (n == 0) return ADVMIL_OK;
   int64_t blocks = ((n >> 3) + 255) / 256;

@@ -64,10 +64,16 @@ def host_copy_rows(dst, src):
 
 
 class SlabStager:
-    def __init__(self, device, channels=1024, dtype=torch.float32):
+    """`store`: dtype of the device slab. torch.bfloat16 = the x_storage 'bf16' mode: bags are kept in HBM as ONE bf16 plane (the
+    step slab is its own operand plane: ops.is_bf16_slab); fp32 host bags cross PCIe as they are and are rounded once on the copy
+    stream behind their H2D copy, bf16 host bags (a loader that stores bf16 features) are DMA'd straight into the slab."""
+
+    def __init__(self, device, channels=1024, dtype=torch.float32, store=None):
         self.device = torch.device(device)
         self.channels = channels
         self.dtype = dtype
+        self.store = dtype if store is None else store
+        self.dev32 = [None, None]         # bf16 store fed by fp32 host bags: the H2D landing area of one batch (rounded into `dev`)
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self.host = [None, None]
         self.dev = [None, None]
@@ -91,7 +97,11 @@ class SlabStager:
         # growing bag by bag re-allocated and re-copied the pinned slab ten times in a first epoch (1.3 s of its 2.1 s)
         new_cap = (max(rows, cap * 2, int(self.hint_rows), 1024) + 4095) // 4096 * 4096
         host = torch.empty(new_cap, self.channels, dtype=self.dtype).pin_memory()
-        dev = torch.empty(new_cap, self.channels, dtype=self.dtype, device=self.device)
+        dev = torch.empty(new_cap, self.channels, dtype=self.store, device=self.device)
+        if self.store != self.dtype:
+            d32 = torch.empty(new_cap, self.channels, dtype=self.dtype, device=self.device)
+            d32.record_stream(self.copy_stream)
+            self.dev32[k] = d32                                  # (only written and read on the copy stream, inside one `add`)
         # the block comes from the COMPUTE stream's allocator pool: kernels already enqueued there may still be using it, and the
         # copy stream is about to write it -> order the copy stream behind them, and tell the allocator about the second user
         self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
@@ -129,7 +139,8 @@ class SlabStager:
     def begin(self):
         """Start staging a new step batch into the other buffer pair."""
         from . import ops
-        self.split = bool(ops.USE_PLANES and ops.get_gemm_mode() == "bf16x3" and self.device.type == "cuda")
+        self.split = bool(ops.USE_PLANES and ops.get_gemm_mode() == "bf16x3" and self.device.type == "cuda"
+                          and self.store == torch.float32)
         self.k ^= 1
         if self.h2d_evt[self.k] is not None:                     # the pinned slab / kept loader tensors of this pair may still be DMA sources
             self.h2d_evt[self.k].synchronize()
@@ -158,7 +169,15 @@ class SlabStager:
             host_copy_rows(self.host[k][a:b], x2)                 # pageable -> pinned, a few plain threads (see host_copy_rows)
             src = self.host[k][a:b]
         with torch.cuda.stream(self.copy_stream):
-            self.dev[k][a:b].copy_(src, non_blocking=True)
+            if self.store == self.dtype:
+                self.dev[k][a:b].copy_(src, non_blocking=True)
+            else:                                                 # fp32 over PCIe, rounded to the bf16 slab behind the copy
+                self.dev32[k][a:b].copy_(src, non_blocking=True)
+        if self.store != self.dtype:
+            from . import _lib
+            C = self.channels
+            _lib.check(_lib.lib().advmil_split_planes(self.dev32[k].data_ptr() + a * C * 4, n * C, self.dev[k].data_ptr() + a * C * 2, None,
+                                                      self.copy_stream.cuda_stream), "split_planes(bf16 slab)")
         if self.split and self.planes_rows == a and self._split_ok(n):
             # the bag's operand planes behind its H2D copy, on the copy stream: the step slab's planes are complete when it is
             self._ensure_planes(k)
@@ -187,6 +206,8 @@ class SlabStager:
         self._spans.append((self.rows, self.rows + n))
         self._ensure(k, self.rows + n)
         a, b = self.rows, self.rows + n
+        if x2.dtype != self.store:
+            raise TypeError(f"SlabStager(store={self.store}): a cached bag of dtype {x2.dtype} cannot enter this slab")
         derive = planes is None and self.split and self._split_ok(n)        # fp32-only cache entry: planes made on the way
         with_planes = (planes is not None or derive) and self.planes_rows == a
         if with_planes:
@@ -299,7 +320,7 @@ class BagCache:
         if ent is None:
             self.misses += 1
             return None
-        if fingerprint is not None and ent[3] is not None and ent[3] != fingerprint:
+        if fingerprint is not None and ent[3] is not None and ent[3] != fingerprint[:2]:
             self.bytes -= self.entries.pop(key)[1]
             self.mismatches += 1
             self.misses += 1
@@ -314,8 +335,8 @@ class BagCache:
         from . import ops
         if key in self.entries or self.budget <= 0:
             return
-        planes = self.with_planes and ops.USE_PLANES and ops.get_gemm_mode() == "bf16x3"
-        nbytes = x_dev.numel() * (8 if planes else 4)
+        planes = self.with_planes and ops.USE_PLANES and ops.get_gemm_mode() == "bf16x3" and x_dev.dtype == torch.float32
+        nbytes = x_dev.numel() * (8 if planes else x_dev.element_size())      # (a bf16 slab's bags: 2 bytes per element)
         if nbytes > self.budget:
             return
         # Admission when full. An epoch visits every bag once, in a new order: plain LRU over a cohort larger than the budget evicts
@@ -336,7 +357,7 @@ class BagCache:
             x._advmil_bag_planes = ops.split_planes(x.view(-1, x.shape[-1]))
         x._advmil_ready = torch.cuda.Event()          # the copy stream that later reads this entry waits for it
         x._advmil_ready.record(torch.cuda.current_stream(self.device))
-        self.entries[key] = [x, nbytes, self.tick, fingerprint]
+        self.entries[key] = [x, nbytes, self.tick, None if fingerprint is None else fingerprint[:2]]
         self.bytes += nbytes
 
     def set_budget(self, budget_bytes):
@@ -433,13 +454,22 @@ def device_bag_cache(device, budget_bytes=None):
     return c
 
 
-def device_stager(device, channels):
-    """The evaluation passes' staging slabs (one SlabStager per device and bag width; the training loop keeps its own)."""
+def x_store_dtype(x_storage, host_dtype=torch.float32):
+    """Device dtype of the bags for a configured x_storage ('fp32' | 'bf16' | None = ADVMIL_X_STORAGE, default fp32)."""
+    xs = x_storage or os.environ.get("ADVMIL_X_STORAGE", "fp32")
+    if xs not in ("fp32", "bf16"):
+        raise ValueError(f"x_storage must be 'fp32' or 'bf16', got {xs!r}")
+    return torch.bfloat16 if (xs == "bf16" or host_dtype == torch.bfloat16) else torch.float32
+
+
+def device_stager(device, channels, dtype=torch.float32, store=None):
+    """The evaluation passes' staging slabs (one SlabStager per device, bag width and dtypes; the training loop keeps its own)."""
     device = torch.device(device)
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), int(channels))
+    store = dtype if store is None else store
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), int(channels), dtype, store)
     st = _DEVICE_STAGERS.get(key)
     if st is None:
-        st = _DEVICE_STAGERS[key] = SlabStager(device, channels)
+        st = _DEVICE_STAGERS[key] = SlabStager(device, channels, dtype, store)
     return st
 
 
@@ -497,7 +527,8 @@ class StepBatch:
         self.pos, self.idx, self.xs, self.ys, self.staged, self.pad = pos, idx, xs, ys, staged, pad   # pad: zero rows behind the bags
 
 
-def step_batches(loader, device, nb, cache=None, stager=None, drop_last=False, stageable=None, group_unstaged=False, pad_multiple=0):
+def step_batches(loader, device, nb, cache=None, stager=None, drop_last=False, stageable=None, group_unstaged=False, pad_multiple=0,
+                 x_storage=None):
     """Walk `loader` ((idx, [x, ext], y) items, x[1, N, C] on the host) in step batches of `nb` bags whose rows are contiguous in HBM:
     host bags through the pinned staging slab on the copy stream, bags seen before out of the device-resident cache (device-to-
     device, on the copy stream too). Items `stageable(x)` rejects (device tensors, graphs, odd shapes) come as single-bag batches with
@@ -511,7 +542,7 @@ def step_batches(loader, device, nb, cache=None, stager=None, drop_last=False, s
 
     def ok(x0):
         return (torch.is_tensor(x0) and not x0.is_cuda and x0.dim() == 3 and x0.shape[0] == 1 and x0.shape[1] > 0
-                and x0.dtype == torch.float32 and (stageable is None or stageable(x0)))
+                and x0.dtype in (torch.float32, torch.bfloat16) and (stageable is None or stageable(x0)))
 
     def finish():
         pad = own.pad_rows(pad_multiple) if pad_multiple else 0       # (whole 256-row tiles: SlabStager.pad_rows)
@@ -547,13 +578,15 @@ def step_batches(loader, device, nb, cache=None, stager=None, drop_last=False, s
         if loose.xs:
             raise ValueError("step_batches: host and device bags alternate inside one step batch")
         if own is None:
-            own = device_stager(device, x0.shape[-1])
+            own = device_stager(device, x0.shape[-1], x0.dtype, x_store_dtype(x_storage, x0.dtype))
         if not xs:
             own.expect(nb, x0.shape[1])
             own.begin()
         key = int(idx.reshape(-1)[0]) if cache is not None else None
         fp = bag_fingerprint(x0) if cache is not None else None
         hit = cache.get(key, fp) if cache is not None else None
+        if hit is not None and hit.dtype != own.store:           # kept under another x_storage: not this slab's bag
+            hit = None
         if hit is not None:
             # the entry keeps its event: ANY copy stream that reads it (the handler's stager, the evaluation's) is ordered behind
             # the kernels that made it; waiting on a completed event costs nothing

@@ -26,7 +26,7 @@ import torch
 from .. import ops
 from ..loss.utils import fake_generator_loss, real_fake_loss, real_fake_terms, recon_loss, recon_terms
 from ..optim import FlatAdam, create_optimizer
-from ..ingest import BagCache, SlabStager
+from ..ingest import BagCache, SlabStager, bag_fingerprint, x_store_dtype
 from ..parallel import BagParallel
 from ..utils.func import agg_tensor, seed_everything, sparse_key, sparse_str
 from .backbone import load_backbone
@@ -79,6 +79,9 @@ class MyHandler(object):
         self.overlap_gfwd = os.environ.get("ADVMIL_OVERLAP_GFWD", "0") == "1"
         # rows of a staged step slab are padded with zero rows to a multiple of this (0 = off): see ingest.SlabStager.pad_rows
         self.slab_pad = int(os.environ.get("ADVMIL_SLAB_PAD", cfg.get("slab_pad", 256)))
+        # 'fp32' (default) | 'bf16': how bags are held in HBM (staging slab, device-resident cache). 'bf16' = ONE bf16 plane per bag
+        # (half the bytes; the contractions over the slab form each product with two MFMAs instead of three); see DESIGN.md
+        self.x_storage = os.environ.get("ADVMIL_X_STORAGE", cfg.get("x_storage", "fp32"))
         self._side_stream = None
         self._fork_evt = self._join_evt = None
         self.cfg = cfg
@@ -221,10 +224,16 @@ class MyHandler(object):
             x0 = data_x[0]
             if torch.is_tensor(x0) and not x0.is_cuda and self.bcb != "graph":
                 key = int(data_idx.reshape(-1)[0]) if cache is not None else None
-                hit = cache.get(key) if cache is not None else None
+                fp = bag_fingerprint(x0) if cache is not None else None
+                hit = cache.get(key, fp) if cache is not None else None
                 if stager is None:
-                    stager = self.__dict__.setdefault("_stager", None) or SlabStager(self.device, x0.shape[-1])
+                    stager = self.__dict__.setdefault("_stager", None)
+                    store = x_store_dtype(self.x_storage, x0.dtype)
+                    if stager is None or stager.dtype != x0.dtype or stager.store != store or stager.channels != x0.shape[-1]:
+                        stager = SlabStager(self.device, x0.shape[-1], x0.dtype, store)
                     self._stager = stager
+                if hit is not None and hit.dtype != stager.store:      # kept under another x_storage: not this slab's bag
+                    hit = None
                 if not staged:
                     stager.expect(bp_every_batch, x0.shape[1])
                     stager.begin()
@@ -232,13 +241,11 @@ class MyHandler(object):
                 staged_pos.append(len(x_col))
                 if hit is not None:              # resident since an earlier epoch: no H2D; its rows (and operand planes) are copied into
                     #                              the step slab device to device on the copy stream, under the previous step's compute
-                    ev = hit.__dict__.get("_advmil_ready")
-                    v = stager.add_device(hit, hit.__dict__.get("_advmil_bag_planes"), ev)
-                    if ev is not None:           # the copy stream is now ordered behind the kernels that made this entry, for good
-                        hit._advmil_ready = None
+                    # (the entry keeps its event: any copy stream that reads it is ordered behind the kernels that made it)
+                    v = stager.add_device(hit, hit.__dict__.get("_advmil_bag_planes"), hit.__dict__.get("_advmil_ready"))
                 else:
                     if cache is not None:
-                        fresh.append((key, len(x_col)))
+                        fresh.append((key, len(x_col), fp))
                     v = stager.add(x0)
                 # (the second loader field is the cluster ids / graph of those two backbones; ABMIL and ESAT never read it, and a pageable
                 # host tensor's `.to()` is a host-synchronous copy that would throttle the launch queue to the device's pace)
@@ -280,8 +287,8 @@ class MyHandler(object):
                 preds, fakes = self._update_disc(i_batch, x_col, y_col, mode, mask, ys_host=ys_host, noise=nz_d, plan=plan, defer_apply=overlap)
                 for _ in range(num_update_gen):
                     self._update_gen(i_batch, x_col, y_col, mode, mask, ys_host=ys_host, noise=nz_g, plan=plan)
-                for key, j in fresh:                     # first sight of these bags: keep them (and their operand planes) in HBM
-                    cache.put(key, x_col[j][0])
+                for key, j, fp in fresh:                 # first sight of these bags: keep them (and their operand planes) in HBM
+                    cache.put(key, x_col[j][0], fp)
                 fresh, staged_pos = [], []
                 if staged:
                     stager.release()
@@ -456,11 +463,13 @@ class MyHandler(object):
                 if x[0].data_ptr() != ptr or x[0].untyped_storage().data_ptr() != st:
                     ok = False
                     break
-                ptr += r * c * 4
+                ptr += r * c * x0.element_size()
         if pad and not ok:
             raise RuntimeError("a slab pad needs the bags back to back in the staging slab")
         X = (x0.as_strided((sum(rows) + pad, c), (c, 1), x0.storage_offset()) if ok       # (pad: zero rows the stager put behind them)
              else torch.cat([x[0].reshape(-1, c) for x in xs], dim=0))
+        if ops.is_bf16_slab(X):
+            return X                             # x_storage = 'bf16': the slab is its own (single) operand plane, nothing to derive
         spl = getattr(x0, "_advmil_stager_planes", None) if ok else None
         if (spl is not None and spl.hi.shape[0] == X.shape[0] and X.shape[0] >= 4096 and ops.USE_PLANES and ops.get_gemm_mode() == "bf16x3"
                 and ops.gemm_plan_planes(X.shape[0], 128, c)):

@@ -48,6 +48,22 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def is_bf16_slab(t):
+    """A bag / step slab held as ONE bf16 plane (cfg x_storage = 'bf16'): the tensor is its own operand plane, there is no fp32 image."""
+    return t is not None and t.dtype == torch.bfloat16
+
+
+def as_f32(t):
+    """fp32 image of a bf16 slab (exact), for the few launches that cannot take it as a plane; kept on the tensor object."""
+    if t.dtype != torch.bfloat16:
+        return t
+    f = t.__dict__.get("_advmil_f32")
+    if f is None or f[0] != t._version:
+        f = (t._version, t.float())
+        t._advmil_f32 = f
+    return f[1]
+
+
 _CONST_ZEROS = {}
 
 
@@ -242,7 +258,18 @@ class Planes:
     __slots__ = ("hi", "lo")
 
     def __init__(self, hi, lo):
-        self.hi, self.lo = hi, lo
+        self.hi, self.lo = hi, lo               # lo None: a SINGLE-plane operand -- the tensor is bf16 itself (x_storage = "bf16")
+
+    @property
+    def single(self):
+        return self.lo is None
+
+    def ptrs(self):
+        """OR of the planes' addresses (alignment checks)."""
+        return self.hi.data_ptr() | (0 if self.lo is None else self.lo.data_ptr())
+
+    def lo_ptr(self):
+        return 0 if self.lo is None else self.lo.data_ptr()
 
     # The two planes of a tensor live in ONE allocation, lo starting 64 KB behind the end of hi. Measured on the plane-fed two-layer
     # launch (131072 x 512 x 1024, rocprofv3 FETCH_SIZE, tools/pmc_fetch_skew.sh): two separate allocations fetch 1 145 MB per launch
@@ -268,7 +295,7 @@ class Planes:
                       torch.empty_strided(x.shape, x.stride(), dtype=torch.bfloat16, device=x.device))
 
     def view_rows(self, r0, r1):
-        return Planes(self.hi[r0:r1], self.lo[r0:r1])
+        return Planes(self.hi[r0:r1], None if self.lo is None else self.lo[r0:r1])
 
 
 # Operand planes of tensors that several contractions read (bf16x3 mode). They always travel as an ATTRIBUTE of the tensor object
@@ -293,7 +320,9 @@ MEMO_PLANES = os.environ.get("ADVMIL_MEMO_PLANES", "1") != "0"
 
 
 def planes_of(x):
-    """Planes of an activation / slab tensor, or None."""
+    """Planes of an activation / slab tensor, or None. A bf16 slab is its own (single) plane."""
+    if is_bf16_slab(x):
+        return Planes(x, None)
     return getattr(x, "_advmil_planes", None) if USE_PLANES else None
 
 
@@ -337,10 +366,21 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
             raise ValueError("gemm(A=None) needs a_planes in bf16x3 mode")
         A = a_planes.hi                       # (pointer and pitch only: never read as fp32)
     else:
-        _chk(A, "A")
-    _chk(B, "B")
-    if (tile == 0 and a_planes is not None and b_planes is not None and (splits is None or splits == 1)
-            and not ((a_planes.hi.data_ptr() | a_planes.lo.data_ptr() | b_planes.hi.data_ptr() | b_planes.lo.data_ptr()) & 15)
+        if is_bf16_slab(A):                   # a bf16 slab: it IS its hi plane; its pointer only carries the pitch
+            a_planes = a_planes or Planes(A, None)
+            planes_only_a = True
+        else:
+            _chk(A, "A")
+    b_single = False
+    if is_bf16_slab(B):
+        b_planes = b_planes or Planes(B, None)
+        b_single = True
+    else:
+        _chk(B, "B")
+    if (planes_only_a or b_single) and get_gemm_mode() != "bf16x3":
+        raise ValueError("bf16 slabs need gemm_mode 'bf16x3' (ops.as_f32 gives their fp32 image)")
+    if (tile == 0 and a_planes is not None and b_planes is not None and (splits is None or splits == 1) and not b_planes.single
+            and not ((a_planes.ptrs() | b_planes.ptrs()) & 15)
             and a_planes.hi.stride(0) % 8 == 0 and b_planes.hi.stride(0) % 8 == 0):
         ptile = gemm_plan_planes(M, N, K, a_kc, b_kc)          # both operands pre-split: the plane-fed LDS-DMA kernel, if the shape fits
         if ptile:
@@ -351,7 +391,7 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
                   and not accumulate and (drop_p <= 0.0 or seed is None)):
                 tile = 85                                      # plain bias + activation (+ planes): the 256x256 form (9 % over 256x192)
     if (tile == 0 and splits is None and a_planes is not None and b_planes is not None and not a_kc and not b_kc and gate_wc is None
-            and not ((a_planes.hi.data_ptr() | a_planes.lo.data_ptr() | b_planes.hi.data_ptr() | b_planes.lo.data_ptr()) & 15)
+            and not a_planes.single and not ((a_planes.ptrs() | b_planes.ptrs()) & 15)
             and a_planes.hi.stride(0) % 8 == 0 and b_planes.hi.stride(0) % 8 == 0):
         ttile, tsplits = gemm_plan_tn_planes(M, N, K)          # both [K, .] operands pre-split: the plane-fed TN kernel, if the shape fits
         if ttile:
@@ -399,9 +439,9 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
         e.accumulate = 1
     e.alpha = float(alpha)
     if a_planes is not None:
-        e.a_hi, e.a_lo = a_planes.hi.data_ptr(), a_planes.lo.data_ptr()
+        e.a_hi, e.a_lo = a_planes.hi.data_ptr(), a_planes.lo_ptr()
     if b_planes is not None:
-        e.b_hi, e.b_lo = b_planes.hi.data_ptr(), b_planes.lo.data_ptr()
+        e.b_hi, e.b_lo = b_planes.hi.data_ptr(), b_planes.lo_ptr()
     if c_planes is not None:
         e.c_hi, e.c_lo = c_planes.hi.data_ptr(), c_planes.lo.data_ptr()
     if gate_wc is not None:
@@ -410,6 +450,10 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
         ptile, splits = gemm_plan(M, N, K, a_kc, b_kc)
         if tile == 0:
             tile = ptile
+    if b_single and not (91 <= tile <= 93) and tile not in (22, 12, 11) and not (tile in (34, 24) and not a_kc and not b_kc):
+        tile = 22                             # a bf16 B operand has no fp32 image: land on a kernel that stages B from its plane
+    if planes_only_a and a_planes.single and not (82 <= tile <= 85) and tile not in (22, 12, 11):
+        tile = 22
     if planes_only_a and not (82 <= tile <= 85) and not (91 <= tile <= 93) and not pre_a_tile_ok(tile if tile else gemm_plan(M, N, K, a_kc, b_kc)[0], a_kc, b_kc,
                                                                      b_planes is not None):       # (82-85: plane-fed, reads planes only)
         raise ValueError(f"gemm(A=None): tile {tile} has no pre-split-A instantiation for this layout")
@@ -456,7 +500,7 @@ def gemm_two_layers(x, xpl, W1, w1pl, b1, act1, W2, w2pl, b2, act2, emit_planes1
     e.bias2 = None if b2 is None else b2.data_ptr()
     e.act0, e.act1, e.act_split = act1, act2, N1
     e.alpha = 1.0
-    e.a_hi, e.a_lo = xpl.hi.data_ptr(), xpl.lo.data_ptr()
+    e.a_hi, e.a_lo = xpl.hi.data_ptr(), xpl.lo_ptr()
     e.b_hi, e.b_lo = wcat.hi.data_ptr(), wcat.lo.data_ptr()
     if cpl is not None:
         e.c_hi, e.c_lo = cpl.hi.data_ptr(), cpl.lo.data_ptr()
@@ -718,7 +762,9 @@ class LinearActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W, b, act, p, seed, sid, y0=None, rr=None, xpl=None, wpl=None, emit=False):
-        _chk(x, "x"); _chk(W, "weight")
+        if not is_bf16_slab(x):               # (a bf16 slab is read through its plane only: linear_act made sure of that)
+            _chk(x, "x")
+        _chk(W, "weight")
         x = x.contiguous()
         W2 = W.detach().reshape(W.shape[0], -1)
         M, K = x.shape
@@ -772,6 +818,8 @@ class LinearActFn(torch.autograd.Function):
         dW = None
         if need_w:                                           # dpre^T x
             xpl = ctx.xpl if (DW_PLANES and get_gemm_mode() == "bf16x3") else None
+            if xpl is None and is_bf16_slab(x):
+                x = as_f32(x)
             if ctx.gW is not None:
                 gemm(dpre, x, False, False, N, K, M, out=ctx.gW.view(N, K), ldc=K, accumulate=True, b_planes=xpl)
             else:
@@ -876,6 +924,8 @@ def linear_act(x, W, b, act="none", p=0.0, rng=None, tag="", emit_planes=False):
         xpl, wpl = planes_of(x2), weight_planes(W)
         if wpl is not None:
             wpl = Planes(wpl.hi.reshape(W.shape[0], -1), wpl.lo.reshape(W.shape[0], -1))
+    if is_bf16_slab(x2) and get_gemm_mode() != "bf16x3":
+        x2 = as_f32(x2)                       # exact-fp32 arithmetic reads fp32 operands: the slab's (exact) fp32 image
     # emit y's planes only when the contraction that reads y (the gate branches: N' = 2N columns over K' = N) will take them
     emit = bool(emit_planes) and big and bool(gemm_plan_planes(x2.shape[0], 2 * W.shape[0], W.shape[0]))
     y = LinearActFn.apply(x2, W, b, _ACT[act], float(p), seed, sid, y0, rr, xpl, wpl, emit)

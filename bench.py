@@ -73,7 +73,7 @@ def parse():
     return ap.parse_args()
 
 
-def make_pool(torch, dev, mode, n_pool, n_patches, seed, group=16):
+def make_pool(torch, dev, mode, n_pool, n_patches, seed, group=16, x_storage="fp32"):
     """Synthetic bags x ~ N(0,1) [1,N,1024] fp32 generated on the device + labels (t~U, e = i mod 2). The pool is laid out
     as slabs of `group` bags (what a loader's staging buffer looks like), so a step batch is one contiguous [group*N, 1024]."""
     g = torch.Generator(device=dev).manual_seed(seed)
@@ -82,8 +82,10 @@ def make_pool(torch, dev, mode, n_pool, n_patches, seed, group=16):
     for i in range(n_pool):
         if i % group == 0:
             slab = torch.empty(min(group, n_pool - i), n_patches, 1024, device=dev)
+            slab.normal_(generator=g)
+            if x_storage == "bf16":               # the same numbers, held as ONE bf16 plane per bag (cfg x_storage = 'bf16')
+                slab = slab.to(torch.bfloat16)
         x = slab[i % group].unsqueeze(0)
-        x.normal_(generator=g)
         if mode == "cluster":
             ext = torch.randint(0, 8, (1, n_patches), device=dev, generator=g).float()
         elif mode == "graph":   # patches on a sqrt(N) grid, 8-NN (tools/patchgcn_graph_s2.py:66-80 layout)
@@ -178,17 +180,17 @@ def cpu_baseline(args, torch):
 class Case:
     """One workload on this rank: a handler, its resident bag pool and one captured HIP graph per group of `bags` bags."""
 
-    def __init__(self, torch, dev, mode, patches, bags, pool, gemm_mode, seed, eager=False, world=1, resident_planes=True):
+    def __init__(self, torch, dev, mode, patches, bags, pool, gemm_mode, seed, eager=False, world=1, resident_planes=True, x_storage="fp32"):
         from advmil_amd.config import default_cfg
         from advmil_amd.model import MyHandler
         self.torch, self.dev, self.mode, self.patches, self.bags, self.world = torch, dev, mode, patches, bags, world
-        cfg = default_cfg(bcb_mode=mode, bp_every_batch=bags, cuda_id=dev.index, gemm_mode=gemm_mode)
+        cfg = default_cfg(bcb_mode=mode, bp_every_batch=bags, cuda_id=dev.index, gemm_mode=gemm_mode, x_storage=x_storage)
         if mode == "graph":            # PatchGCN dims of the reference's model_stats.py:63
             cfg.update(bcb_dims="1024-128-128", gen_dims="128-1")
         self.h = MyHandler(cfg, device=dev)
         self.h.resident_planes = resident_planes
         self.n_pool = max(pool, bags)
-        self.xs, self.ys, self.ys_host = make_pool(torch, dev, mode, self.n_pool, patches, seed=seed, group=bags)
+        self.xs, self.ys, self.ys_host = make_pool(torch, dev, mode, self.n_pool, patches, seed=seed, group=bags, x_storage=x_storage)
         self.cursor = 0
         self.graphs = []
         self.launch_note = "eager"
@@ -343,6 +345,42 @@ def self_launch(args):
         print("bench.py: the rank job printed no result line", file=sys.stderr)
         sys.exit(1)
     sys.exit(proc.returncode)
+
+
+def xbf16_parity(torch, dev, args, steps=2):
+    """Largest deviation of the x_storage = 'bf16' step from the fp32-storage step over `steps` eager optimizer steps on the same bags,
+    weights, noise and dropout draws: logged losses, the collected predictions / discriminator scores, and the post-step weights."""
+    res = {}
+    runs = {}
+    for xs in ("fp32", "bf16"):
+        c = Case(torch, dev, args.mode, args.patches, args.bags, args.bags * steps, args.gemm_mode, 777, eager=True, x_storage=xs)
+        c.h.rng.reset(4242)
+        outs = []
+        for _ in range(steps):
+            i0, nb, h = c.cursor, c.bags, c.h
+            idx = [(i0 + j) % c.n_pool for j in range(nb)]
+            c.cursor = (i0 + nb) % c.n_pool
+            bx, by, bh = [c.xs[i] for i in idx], [c.ys[i] for i in idx], [c.ys_host[i] for i in idx]
+            plan = h._plan(bx, by, "wlabel", None, bh)
+            preds, fakes = h._update_disc(0, bx, by, "wlabel", None, ys_host=bh, plan=plan)
+            h._update_gen(0, bx, by, "wlabel", None, ys_host=bh, plan=plan)
+            h.rng.advance(1)
+            outs.append((torch.cat(preds).detach().double().cpu(), torch.cat(fakes).detach().double().cpu()))
+        logs = c.h.pop_logs()
+        runs[xs] = (outs, logs, c.h.optimizerG.flat_param.detach().double().cpu(), c.h.optimizerD.flat_param.detach().double().cpu())
+        c.free()
+        del c
+    (oa, la, ga, da), (ob, lb, gb, db) = runs["fp32"], runs["bf16"]
+    res["y_hat_maxabs"] = max(float((a[0] - b[0]).abs().max()) for a, b in zip(oa, ob))
+    res["f_fake_maxabs"] = max(float((a[1] - b[1]).abs().max()) for a, b in zip(oa, ob))
+    res["loss_maxabs"] = max(abs(float(x[k]) - float(y[k])) for x, y in zip(la, lb) for k in x if k != "i_batch")
+    res["weights_G_maxabs"] = float((ga - gb).abs().max())
+    res["weights_D_maxabs"] = float((da - db).abs().max())
+    res["parity_maxabs"] = max(res["y_hat_maxabs"], res["f_fake_maxabs"], res["loss_maxabs"])
+    res["steps"] = steps
+    res["note"] = ("north_star contract: 1e-4 on predictions, scores and losses. Post-Adam weights move by up to 2 lr where a gradient "
+                   "component's sign flips (Adam's first steps are lr * sign(g)): lr_G = 8e-5")
+    return res
 
 
 def product_loop(args, torch, dev, case):
@@ -779,6 +817,25 @@ def main():
                 sizes[tag] = ent
             except Exception as exc:
                 sizes[tag] = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
+                torch.cuda.synchronize()
+
+        # ---- the X-only bf16 storage mode (configs[1] says "bf16"; SURVEY 8: "bf16-storage / fp32-accumulate perf mode"): bags held as
+        # ONE bf16 plane (resident pool, cache, staging: half the bytes), weights / activations / gradients still hi + lo, so every
+        # contraction over the slab forms its products with two MFMAs instead of three. Same workload as `value`; the deviation from the
+        # fp32-storage step on the SAME bags, weights and draws is measured in this run (two eager optimizer steps each).
+        if args.gemm_mode == "bf16x3" and args.mode in ("abmil", "patch"):
+            try:
+                cb = Case(torch, dev, args.mode, args.patches, args.bags, args.pool, args.gemm_mode, 1234 + rank, x_storage="bf16")
+                db_, _ = cb.timed(args.steps, args.warmup, sync_barrier)
+                ent = {"value": round(args.bags * args.steps / db_, 2), "unit": "bags/s", "ms_per_step": round(1e3 * db_ / args.steps, 3),
+                       "steps": args.steps, "x_storage": "bf16 (one plane per bag: 2 B per element resident; two MFMAs per product on the slab "
+                       "contractions)", "losses_finite": cb.logs_finite(), "launch": cb.launch_note}
+                cb.free()
+                del cb
+                ent["parity_vs_fp32_storage"] = xbf16_parity(torch, dev, args)
+                sizes[f"{args.mode}_{args.patches}_xbf16"] = ent
+            except Exception as exc:
+                sizes[f"{args.mode}_{args.patches}_xbf16"] = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
                 torch.cuda.synchronize()
 
     # ---- extra (single GPU): the PRODUCT loop -- MyHandler._train_each_epoch, eager launches, RAGGED bags arriving as pinned host

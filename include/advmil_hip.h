@@ -67,7 +67,11 @@ typedef struct {
    * hi = bf16(x), lo = bf16(x - hi) of the SAME shape and leading dimension (advmil_split_planes; the Adam kernel emits them
    * for the weights; c_hi/c_lo below for activations). When both planes of an operand are given (16-byte aligned, leading
    * dimension and contiguous extent multiples of 8) the engine stages them straight into LDS instead of re-splitting the fp32
-   * values in every workgroup that re-reads them -- results are bit-identical to the on-the-fly split. */
+   * values in every workgroup that re-reads them -- results are bit-identical to the on-the-fly split.
+   * SINGLE-plane operand: a_hi (or b_hi) given with a_lo (b_lo) = NULL says the operand IS a bf16 matrix (a bag stored in bf16: the
+   * x_storage = "bf16" mode of the ingest; the A / B pointer then only carries the pitch and is never dereferenced). Its products
+   * are formed with two MFMAs instead of three -- built for A of the NT plane-fed forms (the embedding FCs over the slab) and B of
+   * the TN plane-fed forms (the weight gradients dY^T X); the generic tiles 22 / 12 / 11 / 34 / 24 stage a zero lo plane. */
   const void* a_hi;
   const void* a_lo;
   const void* b_hi;
@@ -104,6 +108,7 @@ int advmil_gemm_f32(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, const f
 /* Arithmetic of the fp32 engine (process-wide): 0 = exact fp32 MFMA; 1 = split-bf16 ("bf16x3"): every fp32 operand is
  * split into hi + lo bf16 in registers and a.b is formed as ah.bh + ah.bl + al.bh on the bf16 matrix pipe with fp32
  * accumulate -- dropped terms ~2^-17 |a||b| per product, 3/16 of the matrix-pipe time. Storage stays fp32 everywhere. */
+/* lo may be NULL: only hi = bf16(x) is written (the rounding a bag undergoes on its way into a bf16 slab). */
 int advmil_split_planes(const float* src, int64_t n, void* hi, void* lo, advmil_stream_t stream);
 /* Glue of the fused gate score (epilogue.gate_wc): Wi[2D, D] = rows a0, b0, a1, b1, ... of the attention branches' weights Wa, Wb [D, D]
  * (reference model/backbone_utils.py Attn_Net_Gated: attention_a / attention_b), its planes (Wi_hi / Wi_lo, both or neither) and the
