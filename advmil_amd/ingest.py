@@ -56,6 +56,8 @@ def host_copy_rows(dst, src):
     if _COPY_POOL is None or _COPY_POOL._max_workers != nt:
         from concurrent.futures import ThreadPoolExecutor
         _COPY_POOL = ThreadPoolExecutor(nt, thread_name_prefix="advmil-ingest")
+    if src.dtype == torch.bfloat16:                              # (numpy has no bfloat16: copy the same bytes as int16)
+        dst, src = dst.view(torch.int16), src.view(torch.int16)
     d, s_ = dst.numpy(), src.numpy()
     step = (rows + nt - 1) // nt
     futs = [_COPY_POOL.submit(np.copyto, d[r0:r0 + step], s_[r0:r0 + step]) for r0 in range(0, rows, step)]

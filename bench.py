@@ -465,6 +465,44 @@ def product_loop(args, torch, dev, case):
                                            "assembled by D2D copies on the copy stream under the previous step; eager launches")
     out["eager_resident_ragged"]["cache"] = None if cache is None else cache.stats()
 
+    # ---- the same loop with the bags held as ONE bf16 plane (cfg x_storage = 'bf16'): a loader that stores bf16 features hands over
+    # half the bytes (PCIe, staging slab, device cache); fp32 host bags would cross PCIe as they are and be rounded on the copy stream
+    if args.gemm_mode == "bf16x3":
+        try:
+            hb = MyHandler(default_cfg(bcb_mode=args.mode, bp_every_batch=args.bags, cuda_id=dev.index, gemm_mode=args.gemm_mode,
+                                       x_storage="bf16"), device=dev)
+            pool16 = [t.to(torch.bfloat16).pin_memory() for t in hostpool]
+            items16 = [(it[0], [pool16[int(it[0].reshape(-1)[0])], it[1][1]], it[2]) for it in loader]
+            dl16 = _DL(_DS(items16[2 * args.bags:]))
+            os.environ["ADVMIL_BAG_CACHE_GB"] = "0"
+            hb._train_each_epoch(items16[:2 * args.bags], "warmup")
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            hb._train_each_epoch(dl16, "nocache")
+            torch.cuda.synchronize()
+            e0 = time.perf_counter() - t1
+            del os.environ["ADVMIL_BAG_CACHE_GB"]
+            hb._bag_caches = {}
+            t1 = time.perf_counter()
+            hb._train_each_epoch(dl16, "train")
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            hb._train_each_epoch(dl16, "train")
+            torch.cuda.synchronize()
+            e2 = time.perf_counter() - t1
+            out["x_storage_bf16"] = {
+                "eager_pcie_ragged": dict(ent(e0, "bf16 host bags (pinned) -> bf16 staging slab: every epoch over PCIe, half the bytes"),
+                                          h2d_mb_per_step=round(rows * 2048 / nsteps / 1e6, 1)),
+                "eager_resident_ragged": dict(ent(e2, "second epoch out of the bf16 device cache (2 B per element resident)"),
+                                              cache=None if hb._bag_caches.get("train") is None else hb._bag_caches["train"].stats())}
+            del hb, pool16, items16, dl16
+            from advmil_amd import ingest as _ing
+            _ing.device_bag_cache(dev).clear()
+        except Exception as exc:
+            out["x_storage_bf16"] = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
+            os.environ.pop("ADVMIL_BAG_CACHE_GB", None)
+            torch.cuda.synchronize()
+
     # ---- the per-epoch evaluation (reference `_run_training`, model_handler.py:278-285: MyHandler.test_model over the validation and
     # the test set after EVERY epoch, times_test_sample = 1; 598-643: one synchronous `.cuda()`, full forwards and 4 `.cpu()` syncs
     # per bag). Same ragged pinned host bags behind a DataLoader-like object (the cache scope is its `.dataset`).

@@ -549,3 +549,58 @@ def test_slab_pad_is_numerically_neutral(kind, monkeypatch):
     for i in (2, 3):                                       # Adam turns round-off in g ~ 0 into 2 lr at most; the bulk must agree
         d = (a[i] - b[i]).abs()
         assert float(d.max()) <= 2.5e-4 and float((d > 1e-6).float().mean()) < 0.02, (i, float(d.max()), float((d > 1e-6).float().mean()))
+
+
+@pytest.mark.parametrize("kind", ["abmil", "patch"])
+def test_x_storage_bf16_equals_fp32_storage_on_rounded_bags(kind):
+    """cfg x_storage = 'bf16' (bags held as ONE bf16 plane: staging slab, device-resident cache; two MFMAs per product on the slab
+    contractions) is the fp32-storage step on the bf16-rounded bags, bit for bit: the products it drops are exact zeros. Checked
+    through the product loop with fp32 host bags (rounded on the copy stream behind their H2D copy), with bf16 host bags (DMA'd
+    as they are: half the PCIe bytes), and on a second epoch served from the bf16 cache."""
+    from advmil_amd import ingest, ops
+    from advmil_amd.model import MyHandler
+    prev = ops.get_gemm_mode()
+    ops.set_gemm_mode("bf16x3")
+    try:
+        lens = (2048, 1024, 3072, 2048)
+
+        class DS:
+            def __init__(self, items):
+                self.items = items
+
+        class DL:
+            def __init__(self, ds):
+                self.dataset = ds
+
+            def __iter__(self):
+                return iter(self.dataset.items)
+
+        def run(x_storage, host):
+            ingest.device_bag_cache(DEV).clear()
+            h = MyHandler(default_cfg(bcb_mode=kind, bp_every_batch=4, x_storage=x_storage), device=DEV)
+            load_synth(h.netG, f"G-{kind}:"); load_synth(h.netD, "D-prj:")
+            h.rng.reset(31)
+            items = []
+            for i, n in enumerate(lens):
+                x = H.bag(700 + i, 3072)[:, :n].contiguous()
+                xb = x.to(torch.bfloat16)
+                xh = {"fp32": x, "rounded": xb.float(), "bf16": xb}[host]
+                items.append((torch.tensor([[i]], dtype=torch.int), [xh, torch.zeros(1, 1)], H.label(i)))
+            dl = DL(DS(items))
+            out = []
+            for _ in range(2):
+                cl = h._train_each_epoch(dl, "train")
+                out.append((cl["y_hat"].clone(), cl["f_fake"].clone()))
+            view = h._bag_caches["train"]
+            return out, h.optimizerG.flat_param.clone(), None if view is None else view.stats(), h
+
+        ref, wref, _, _ = run("fp32", "rounded")
+        for host in ("fp32", "bf16"):
+            got, w, st, h = run("bf16", host)
+            assert st["bags"] == 4 and st["hits"] == 4 and st["gb"] < 4 * 3072 * 1024 * 2 / 1e9 + 1e-6       # 2 bytes per element
+            assert h._stager.store == torch.bfloat16
+            for (ya, fa), (yb, fb) in zip(ref, got):
+                assert torch.equal(ya, yb) and torch.equal(fa, fb), host
+            assert torch.equal(wref, w), host
+    finally:
+        ops.set_gemm_mode(prev)
