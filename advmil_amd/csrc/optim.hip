@@ -355,6 +355,288 @@ __global__ __launch_bounds__(256) void skinny_linear_bwd_kernel(const float* __r
   }
 }
 
+// =====================================================================================
+// Linear layers on [B, d] head / tail tensors (B = the bags of one optimizer step, <= 32 rows): hop MLP and rho of the generator,
+// the discriminator's bag-level MLPs and label embedding (reference model/GANSurv.py:30-49, 89-105; model_utils.py:116-186).
+// Round 3 ran them on the 64x64-tile MFMA contraction: 7-10 us per launch in-graph (its K walk is a serial chain of dependent MFMAs
+// on ONE accumulator block: 0.44 us per 32 k whatever the prefetch depth), and a backward was up to six launches (activation /
+// dropout backward, dW contraction + split-K reduce, dX contraction, bias column sum + merge). Here: plain fp32 FMA, one wave per 4
+// output columns with the 64 lanes splitting K (1 KB contiguous weight reads), a value-halving butterfly for the lane reduction
+// (V values cost ~V shuffles instead of 6 V), bias / activation / dropout in the same launch; backward = ONE launch for dpre, dW,
+// dbias (+ one for dX when the input needs a gradient). Same dropout draw as the contraction epilogue (rng_keep(key, row * N + col)).
+// =====================================================================================
+// sum of v[i] over the 64 lanes for V (a power of two) values per lane: stage d keeps half of the values and trades the other half
+// with lane ^ d. Afterwards lane l holds the totals of the original indices base(l) + [0, max(V / 64, 1)) with
+// base(l) = sum over the first log2(V) stages s of ((l >> (5 - s)) & 1) * (V >> (s + 1)); written to out[V] (wave-private LDS).
+template <int V>
+__device__ __forceinline__ void wave_multi_reduce(float (&v)[V], int lane, float* __restrict__ out) {
+  int base = 0;
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    const int d = 32 >> s;
+    const int len = (V >> s) > 1 ? (V >> s) : 1;       // values per lane entering the stage
+    if (len > 1) {
+      const int half = len / 2;
+      const bool up = (lane & d) != 0;
+#pragma unroll
+      for (int i = 0; i < half; ++i) {
+        const float a = v[i], b = v[i + half];
+        const float send = up ? a : b, keep = up ? b : a;
+        v[i] = keep + __shfl_xor(send, d, 64);
+      }
+      if (up) base += half;
+    } else {
+      v[0] += __shfl_xor(v[0], d, 64);
+    }
+  }
+  constexpr int R = V >= 64 ? V / 64 : 1;
+#pragma unroll
+  for (int i = 0; i < R; ++i) out[base + i] = v[i];
+}
+
+// MT = rows of the tile (>= M, power of two). grid = ceil(N / 16) blocks of 4 waves; wave w of block g owns columns 16 g + 4 w .. + 3
+template <int MT>
+__global__ __launch_bounds__(256) void small_linear_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ W,
+                                                               const float* __restrict__ bias, int M, int N, int K, int act, float p,
+                                                               const uint64_t* seed, uint64_t stream_id, const int64_t* __restrict__ rng_row,
+                                                               float* __restrict__ y) {
+  __shared__ float red[4][4 * MT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = ((int)blockIdx.x * 4 + wave) * 4;
+  if (n0 >= N) return;
+  float acc[4 * MT];
+#pragma unroll
+  for (int i = 0; i < 4 * MT; ++i) acc[i] = 0.f;
+  for (int k = 4 * lane; k < K; k += 256) {
+    float4 wv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      wv[j] = n0 + j < N ? *reinterpret_cast<const float4*>(W + (int64_t)(n0 + j) * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (m < M) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)m * ldx + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j * MT + m] += (xv.x * wv[j].x + xv.y * wv[j].y) + (xv.z * wv[j].z + xv.w * wv[j].w);
+      }
+    }
+  }
+  wave_multi_reduce<4 * MT>(acc, lane, red[wave]);
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane < 4 * MT) {
+    const int j = lane / MT, m = lane % MT, n = n0 + j;
+    if (m < M && n < N) {
+      float v = red[wave][lane] + (bias ? bias[n] : 0.f);
+      v = act_apply(act, v);
+      if (seed && p > 0.f) {
+        const int64_t grow = rng_row ? rng_row[m] : m;
+        v *= rng_keep(rng_key(*seed, stream_id), (uint64_t)(grow * N + n), p, hw_rcp(1.f - p));
+      }
+      y[(int64_t)m * N + n] = v;
+    }
+  }
+  if (4 * MT > 64 && lane + 64 < 4 * MT) {                       // (MT = 32: 128 results per wave)
+    const int t = lane + 64, j = t / MT, m = t % MT, n = n0 + j;
+    if (m < M && n < N) {
+      float v = red[wave][t] + (bias ? bias[n] : 0.f);
+      v = act_apply(act, v);
+      if (seed && p > 0.f) {
+        const int64_t grow = rng_row ? rng_row[m] : m;
+        v *= rng_keep(rng_key(*seed, stream_id), (uint64_t)(grow * N + n), p, hw_rcp(1.f - p));
+      }
+      y[(int64_t)m * N + n] = v;
+    }
+  }
+}
+
+// backward, weights side: dpre[m, n] = dy * keep * act'(y) (also written to `dpre_out` for the dX launch), dW[n, :] (+)= sum_m dpre x[m, :],
+// dbias[n] (+)= sum_m dpre. Same grid as the forward.
+template <int MT>
+__global__ __launch_bounds__(256) void small_linear_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                 const float* __restrict__ x, int64_t ldx, int M, int N, int K, int act, float p,
+                                                                 const uint64_t* seed, uint64_t stream_id, const int64_t* __restrict__ rng_row,
+                                                                 float* __restrict__ dW, int acc_w, float* __restrict__ dbias, int acc_b,
+                                                                 float* __restrict__ dpre_out) {
+  __shared__ float dps[4][4 * MT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = ((int)blockIdx.x * 4 + wave) * 4;
+  if (n0 >= N) return;
+  const bool drop = seed && p > 0.f;
+  uint64_t key = 0;
+  float inv = 1.f;
+  if (drop) { key = rng_key(*seed, stream_id); inv = hw_rcp(1.f - p); }
+#pragma unroll
+  for (int t0 = 0; t0 < 4 * MT; t0 += 64) {
+    const int t = t0 + lane;
+    if (t < 4 * MT) {
+      const int j = t / MT, m = t % MT, n = n0 + j;
+      float d = 0.f;
+      if (m < M && n < N) {
+        float f = 1.f, yy = y[(int64_t)m * N + n];
+        if (drop) {
+          const int64_t grow = rng_row ? rng_row[m] : m;
+          f = rng_keep(key, (uint64_t)(grow * N + n), p, inv);
+          yy *= 1.f - p;                       // undo the 1/(1-p) on kept elements (dropped ones get f = 0 anyway)
+        }
+        d = dy[(int64_t)m * N + n] * f * act_grad_from_out(act, yy);
+        if (dpre_out) dpre_out[(int64_t)m * N + n] = d;
+      }
+      dps[wave][t] = d;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  float dp[4 * MT];
+#pragma unroll
+  for (int i = 0; i < 4 * MT; ++i) dp[i] = dps[wave][i];
+  if (dbias && lane < 4 && n0 + lane < N) {
+    float sb = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) sb += dps[wave][lane * MT + m];
+    if (acc_b) sb += dbias[n0 + lane];
+    dbias[n0 + lane] = sb;
+  }
+  if (!dW) return;
+  for (int k = 4 * lane; k < K; k += 256) {
+    float4 g[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (m < M) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)m * ldx + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d = dp[j * MT + m];
+          g[j].x += d * xv.x; g[j].y += d * xv.y; g[j].z += d * xv.z; g[j].w += d * xv.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (n0 + j < N) {
+        float4* dst = reinterpret_cast<float4*>(dW + (int64_t)(n0 + j) * K + k);
+        if (acc_w) { const float4 o = *dst; g[j].x += o.x; g[j].y += o.y; g[j].z += o.z; g[j].w += o.w; }
+        *dst = g[j];
+      }
+    }
+  }
+}
+
+// backward, input side: dx[m, k] = sum_n dpre[m, n] W[n, k]. Block = 8 waves splitting n, lane = 4 consecutive k; rows in chunks of 8:
+// the chunk's dpre rows are staged in LDS first (a wave-uniform global load inside the n loop made every step wait a full memory
+// latency: 48 dependent steps = 14 us on a [16, 384] layer), the weight rows are fetched four at a time; the cross-wave sums go
+// through LDS (8 waves x 8 rows x 256 k floats = 64 KB). N <= SMALL_NMAX.
+#define SMALL_NMAX 1024
+__global__ __launch_bounds__(512) void small_linear_bwd_x_kernel(const float* __restrict__ dpre, const float* __restrict__ W, int M, int N,
+                                                                 int K, float* __restrict__ dx, int64_t lddx) {
+  __shared__ float4 part[8][8][64];
+  __shared__ __attribute__((aligned(16))) float dps[8][SMALL_NMAX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k = ((int)blockIdx.x * 64 + lane) * 4;
+  const bool kok = k < K;
+  const int nper = (((N + 7) / 8) + 3) & ~3;                     // columns per wave, a multiple of 4
+  const int nb = wave * nper, ne = nb + nper < N ? nb + nper : N;
+  for (int m0 = 0; m0 < M; m0 += 8) {
+    for (int e = tid; e < 8 * N; e += 512) {
+      const int i = e / N, n = e - i * N;
+      dps[i][n] = m0 + i < M ? dpre[(int64_t)(m0 + i) * N + n] : 0.f;
+    }
+    __syncthreads();
+    float4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kok) {
+      int n = nb;
+      for (; n + 4 <= ne; n += 4) {
+        float4 wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wv[u] = *reinterpret_cast<const float4*>(W + (int64_t)(n + u) * K + k);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float4 d4 = *reinterpret_cast<const float4*>(&dps[i][n]);        // (n is a multiple of 4: nb, nper are)
+          const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            acc[i].x += dv[u] * wv[u].x; acc[i].y += dv[u] * wv[u].y; acc[i].z += dv[u] * wv[u].z; acc[i].w += dv[u] * wv[u].w;
+          }
+        }
+      }
+      for (; n < ne; ++n) {
+        const float4 wv = *reinterpret_cast<const float4*>(W + (int64_t)n * K + k);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float d = dps[i][n];
+          acc[i].x += d * wv.x; acc[i].y += d * wv.y; acc[i].z += d * wv.z; acc[i].w += d * wv.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) part[wave][i][lane] = acc[i];
+    __syncthreads();
+    {
+      const int i = wave;                          // wave i sums row m0 + i over the 8 partials
+      if (m0 + i < M && kok) {
+        float4 s4 = part[0][i][lane];
+#pragma unroll
+        for (int w2 = 1; w2 < 8; ++w2) { const float4 q = part[w2][i][lane]; s4.x += q.x; s4.y += q.y; s4.z += q.z; s4.w += q.w; }
+        *reinterpret_cast<float4*>(dx + (int64_t)(m0 + i) * lddx + k) = s4;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+static int small_mt(int M) { return M <= 1 ? 1 : M <= 2 ? 2 : M <= 4 ? 4 : M <= 8 ? 8 : M <= 16 ? 16 : 32; }
+#define SMALL_DISPATCH(KERNEL, MT_, GRID, STREAM, ...)                                                            \
+  do {                                                                                                            \
+    switch (MT_) {                                                                                                \
+      case 1: hipLaunchKernelGGL((KERNEL<1>), GRID, dim3(256), 0, STREAM, __VA_ARGS__); break;                    \
+      case 2: hipLaunchKernelGGL((KERNEL<2>), GRID, dim3(256), 0, STREAM, __VA_ARGS__); break;                    \
+      case 4: hipLaunchKernelGGL((KERNEL<4>), GRID, dim3(256), 0, STREAM, __VA_ARGS__); break;                    \
+      case 8: hipLaunchKernelGGL((KERNEL<8>), GRID, dim3(256), 0, STREAM, __VA_ARGS__); break;                    \
+      case 16: hipLaunchKernelGGL((KERNEL<16>), GRID, dim3(256), 0, STREAM, __VA_ARGS__); break;                  \
+      default: hipLaunchKernelGGL((KERNEL<32>), GRID, dim3(256), 0, STREAM, __VA_ARGS__); break;                  \
+    }                                                                                                             \
+  } while (0)
+
+extern "C" int advmil_small_linear_fwd(const float* x, int64_t ldx, const float* W, const float* bias, int M, int N, int K, int act,
+                                       float drop_p, const uint64_t* seed, uint64_t stream_id, const int64_t* rng_row, float* y,
+                                       advmil_stream_t stream_) {
+  if (!x || !W || !y || M <= 0 || M > 32 || N <= 0 || K <= 0 || (K & 3) || (ldx & 3) || ldx < K) return ADVMIL_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)W) & 15) return ADVMIL_EINVAL;
+  if (!(drop_p >= 0.f && drop_p < 1.f)) return ADVMIL_EINVAL;
+  const dim3 grid((unsigned)((N + 15) / 16));
+  SMALL_DISPATCH(small_linear_fwd_kernel, small_mt(M), grid, (hipStream_t)stream_, x, ldx, W, bias, M, N, K, act, drop_p, seed, stream_id,
+                 rng_row, y);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}
+
+extern "C" size_t advmil_small_linear_bwd_workspace_bytes(int M, int N) { return (size_t)M * (size_t)N * sizeof(float); }
+
+extern "C" int advmil_small_linear_bwd(const float* dy, const float* y, const float* x, int64_t ldx, const float* W, int M, int N, int K,
+                                       int act, float drop_p, const uint64_t* seed, uint64_t stream_id, const int64_t* rng_row, float* dW,
+                                       int acc_w, float* dbias, int acc_b, float* dx, int64_t lddx, void* ws, size_t ws_bytes,
+                                       advmil_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!dy || !y || !x || !W || M <= 0 || M > 32 || N <= 0 || K <= 0 || (K & 3) || (ldx & 3) || ldx < K) return ADVMIL_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)W | (uintptr_t)dW | (uintptr_t)dx) & 15) return ADVMIL_EINVAL;
+  if (dx && ((lddx & 3) || lddx < K || !ws || ws_bytes < advmil_small_linear_bwd_workspace_bytes(M, N) || N > SMALL_NMAX)) return ADVMIL_EINVAL;
+  if (!(drop_p >= 0.f && drop_p < 1.f)) return ADVMIL_EINVAL;
+  const dim3 grid((unsigned)((N + 15) / 16));
+  SMALL_DISPATCH(small_linear_bwd_w_kernel, small_mt(M), grid, stream, dy, y, x, ldx, M, N, K, act, drop_p, seed, stream_id, rng_row, dW,
+                 acc_w, dbias, acc_b, dx ? (float*)ws : (float*)nullptr);
+  ADVMIL_LAUNCH_CHECK();
+  if (dx) {
+    hipLaunchKernelGGL(small_linear_bwd_x_kernel, dim3((unsigned)((K + 255) / 256)), dim3(512), 0, stream, (const float*)ws, W, M, N, K, dx,
+                       lddx);
+    ADVMIL_LAUNCH_CHECK();
+  }
+  return ADVMIL_OK;
+}
+
 extern "C" int advmil_skinny_linear_fwd(const float* x, const float* W, const float* bias, int B, int K, int N, int act, float* y,
                                         advmil_stream_t stream_) {
   if (!x || !W || !y || B <= 0 || K <= 0 || N <= 0 || (int64_t)B * N > (1 << 20) || (K != 1 && N != 1)) return ADVMIL_EINVAL;

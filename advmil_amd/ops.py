@@ -317,6 +317,11 @@ DG_PLANES_ONLY = os.environ.get("ADVMIL_DG_PLANES_ONLY", "1") != "0"
 # weight gradients dY^T X of the layers applied to the slab: X's planes (already resident for the forward) feed the B operand
 DW_PLANES = os.environ.get("ADVMIL_DW_PLANES", "1") != "0"
 MEMO_PLANES = os.environ.get("ADVMIL_MEMO_PLANES", "1") != "0"
+# [B <= 32, d] linear layers on the fp32-FMA kernels (csrc/optim.hip small_linear_*) instead of the 64x64-tile MFMA contraction
+SMALL_LINEAR = os.environ.get("ADVMIL_SMALL_LINEAR", "1") != "0"
+# ... for up to this many rows. In-graph, forward + backward of a [B, 384] -> 384 layer (tools/probe/small_linear_time.py): B = 1-2:
+# 19-20 us against 32 us; B = 16: 39 against 39 us; B = 32: 35 against 27 us (per row the FMA kernels do 64 x the work per lane)
+SMALL_LINEAR_ROWS = int(os.environ.get("ADVMIL_SMALL_LINEAR_ROWS", "8"))
 
 
 def planes_of(x):
@@ -770,7 +775,17 @@ class LinearActFn(torch.autograd.Function):
         M, K = x.shape
         N = W2.shape[0]
         cpl = None
-        if y0 is None:
+        ctx.small = False
+        if (SMALL_LINEAR and y0 is None and M <= min(32, SMALL_LINEAR_ROWS) and K % 4 == 0 and N <= 1024 and xpl is None and not emit and x.dtype == torch.float32
+                and (b is None or b.dtype == torch.float32)):
+            # a [B, d] head / tail layer: one fp32-FMA launch (csrc/optim.hip small_linear_*), its backward one or two
+            y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+            use = seed is not None and p > 0.0
+            _lib.check(_lib.lib().advmil_small_linear_fwd(_p(x), x.stride(0), _p(W2), _p(b), M, N, K, act, float(p) if use else 0.0,
+                                                          _p(seed if use else None), sid, _p(rr if use else None), _p(y), _stream()),
+                       f"small_linear_fwd[{M}x{N}x{K}]")
+            ctx.small = True
+        elif y0 is None:
             if emit and get_gemm_mode() == "bf16x3":
                 cpl = Planes.alloc((M, N), x.device)
             y = gemm(x, W2, True, True, M, N, K, bias=b, act0=act, drop_p=p, seed=seed, stream_id=sid, rng_row=rr,
@@ -796,6 +811,21 @@ class LinearActFn(torch.autograd.Function):
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_b = has_b and ctx.needs_input_grad[2]
         db = None
+        if ctx.small:
+            L = _lib.lib()
+            dev = x.device
+            acc_w, acc_b = need_w and ctx.gW is not None, need_b and ctx.gb is not None
+            dW = (ctx.gW.view(N, K) if acc_w else torch.empty(N, K, dtype=torch.float32, device=dev)) if need_w else None
+            db = (ctx.gb if acc_b else torch.empty(N, dtype=torch.float32, device=dev)) if need_b else None
+            dx = torch.empty(M, K, dtype=torch.float32, device=dev) if need_x else None
+            wsb = L.advmil_small_linear_bwd_workspace_bytes(M, N) if need_x else 0
+            ws = _ws(wsb, dev) if wsb else None
+            use = seed is not None and p > 0.0
+            _lib.check(L.advmil_small_linear_bwd(_p(dy), _p(y), _p(x), x.stride(0), _p(W2), M, N, K, act, float(p) if use else 0.0,
+                                                 _p(seed if use else None), sid, _p(rr if use else None), _p(dW), 1 if acc_w else 0, _p(db),
+                                                 1 if acc_b else 0, _p(dx), K, _p(ws), wsb, _stream()), f"small_linear_bwd[{M}x{N}x{K}]")
+            return (dx, None if (dW is None or acc_w) else dW.reshape(wshape), None if (db is None or acc_b) else db,
+                    None, None, None, None, None, None, None, None, None)
         if act == ACT_NONE and p <= 0.0:
             dpre = dy
             if need_b:

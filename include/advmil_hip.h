@@ -316,6 +316,18 @@ int advmil_skinny_linear_fwd(const float* x, const float* W, const float* bias, 
                              advmil_stream_t stream);
 int advmil_skinny_linear_bwd(const float* x, const float* W, const float* y, const float* dy, int B, int K, int N, int act, float* dx,
                              float* dW, float* dbias, int accumulate, advmil_stream_t stream);
+/* Linear (+ bias, activation, dropout) on [B, d] head / tail tensors, B <= 32 rows -- the generator's rho / hop MLP, the discriminator's
+ * bag-level MLPs and label embedding (reference model/GANSurv.py:30-49, 89-105; model_utils.py:116-186): y = dropout(act(x W^T + bias)),
+ * x[M, K] (pitch ldx), W[N, K]; fp32 FMA; K and ldx multiples of 4, x / W 16-byte aligned. Dropout draw = the contraction epilogue's
+ * (element m * N + n of stream `stream_id`, row m replaced by rng_row[m] when given).
+ * bwd: dpre = dy * keep * act'(y); dW[N, K] / dbias[N] (each may be NULL; acc_* != 0 adds into them); dx[M, K] (pitch lddx; NULL = not
+ * needed; needs the workspace). One launch, two with dx. */
+int advmil_small_linear_fwd(const float* x, int64_t ldx, const float* W, const float* bias, int M, int N, int K, int act, float drop_p,
+                            const uint64_t* seed, uint64_t stream_id, const int64_t* rng_row, float* y, advmil_stream_t stream);
+size_t advmil_small_linear_bwd_workspace_bytes(int M, int N);
+int advmil_small_linear_bwd(const float* dy, const float* y, const float* x, int64_t ldx, const float* W, int M, int N, int K, int act,
+                            float drop_p, const uint64_t* seed, uint64_t stream_id, const int64_t* rng_row, float* dW, int acc_w,
+                            float* dbias, int acc_b, float* dx, int64_t lddx, void* ws, size_t ws_bytes, advmil_stream_t stream);
 /* Projection head of the discriminator (reference model/GANSurv.py:78-105, PrjDiscriminator.forward): out[b] = <u[b], t[b]> + <src[b], w> + bias[0]
  * for [B, d] head tensors -- u = the (region-mean) x embedding, t = the label embedding, src = the prj_layer's input (NULL: no projection
  * layer). bwd: du / dt / dsrc [B, d], dw [d], dbias [1] (each may be NULL; accumulate != 0 adds into dw / dbias). */

@@ -661,3 +661,47 @@ def test_genconv_on_random_graph_and_without_edges():
     o0 = ops.genconv_aggregate(x0, td.detach().clone().requires_grad_(True), ops.GraphCSR(torch.zeros(2, 0, dtype=torch.long, device=DEV), N))
     o0.backward(go.to(DEV))
     assert torch.equal(o0.detach(), x0.detach()) and torch.equal(x0.grad, go.to(DEV))
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 384, 384), (2, 192, 768), (16, 384, 768), (32, 128, 64), (16, 64, 128), (5, 30, 36), (3, 7, 8), (17, 260, 1028)])
+@pytest.mark.parametrize("act", ["none", "relu"])
+def test_small_linear_kernels_vs_float64_and_vs_the_contraction_path(M, N, K, act):
+    """[B <= 32, d] linear layers (csrc/optim.hip small_linear_*: the generator's rho / hop MLP, the discriminator's bag-level MLPs,
+    reference model/GANSurv.py:30-49, 89-105): forward and every gradient against float64; with dropout, against the contraction
+    engine's epilogue on the same call site (same counter-RNG draw: the masks must coincide element for element)."""
+    from advmil_amd import ops
+    g = torch.Generator().manual_seed(M * 1000 + N + K)
+    x = torch.randn(M, K, generator=g).to(DEV).requires_grad_(True)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV).requires_grad_(True)
+    b = torch.randn(N, generator=g).to(DEV).requires_grad_(True)
+    go = torch.randn(M, N, generator=g).to(DEV)
+    assert ops.SMALL_LINEAR
+    rows0, ops.SMALL_LINEAR_ROWS = ops.SMALL_LINEAR_ROWS, 32        # (the model path takes these kernels up to SMALL_LINEAR_ROWS rows only)
+    y = ops.linear_act(x, W, b, act)
+    y.backward(go)
+    xd, Wd, bd = (t.detach().double().requires_grad_(True) for t in (x, W, b))
+    pre = xd @ Wd.t() + bd
+    yr = torch.relu(pre) if act == "relu" else pre
+    yr.backward(go.double())
+    for got, ref in ((y, yr), (x.grad, xd.grad), (W.grad, Wd.grad), (b.grad, bd.grad)):
+        assert float((got.detach().double() - ref.detach()).abs().max()) <= 3e-6 * max(1.0, float(ref.detach().abs().max())), (M, N, K)
+    # dropout: the same site drawn by both paths
+    outs = []
+    for small in (True, False):
+        ops.SMALL_LINEAR = small
+        try:
+            rng = ops.DeviceRng(DEV, seed=77)
+            xs, Ws, bs = (t.detach().clone().requires_grad_(True) for t in (x, W, b))
+            if not small and (K % 4 or N % 4):
+                continue
+            yd = ops.linear_act(xs, Ws, bs, act, 0.25, rng, "site")
+            yd.backward(go)
+            outs.append((yd.detach(), xs.grad, Ws.grad, bs.grad))
+        finally:
+            ops.SMALL_LINEAR = True
+    ops.SMALL_LINEAR_ROWS = rows0
+    if len(outs) == 2:
+        assert float((outs[0][0] == 0).float().mean()) > 0.1                       # something was dropped
+        assert bool(((outs[0][0] == 0) == (outs[1][0] == 0)).all()) or act == "relu"      # (relu zeros coincide too, up to round-off at 0)
+        for a, c in zip(outs[0], outs[1]):
+            assert float((a - c).abs().max()) <= 2e-5 * max(1.0, float(c.abs().max()))

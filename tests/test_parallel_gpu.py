@@ -46,7 +46,9 @@ def test_two_rank_step_equals_single_rank_with_dropout_on(kind, tmp_path):
         for k in want[tag]:
             p0 = H.T(synth.param(H.PARAM_SEED, prefix + k, tuple(want[tag][k].shape))).double()
             da, db = float((got[tag][k].double() - p0).norm()), float((want[tag][k].double() - p0).norm())
-            assert abs(da - db) <= 5e-3 * db + 5e-5, (tag, k, da, db)
+            # (floor: a parameter whose true gradient is zero -- the pooling scorer's output bias under the softmax -- holds round-off
+            # only, which Adam turns into steps of up to lr = 8e-5 per element and optimizer step in either run)
+            assert abs(da - db) <= 5e-3 * db + max(5e-5, 2 * 8e-5 * want[tag][k].numel() ** 0.5 if db < 2e-4 else 0.0), (tag, k, da, db)
             assert float((got[tag][k].double() - want[tag][k].double()).abs().max()) <= 2.5 * 8e-5, (tag, k)
 
 
