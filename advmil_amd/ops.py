@@ -519,7 +519,7 @@ def gemm_two_layers(x, xpl, W1, w1pl, b1, act1, W2, w2pl, b2, act2, emit_planes1
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        prof.append(("gemm_nt_planes_kernel<4,two layers>", (M, N1 + N2, K, 1), 2.0 * M * (N1 + N2) * K, e0, e1))
+        prof.append((f"gemm_nt_planes_kernel<4,two layers,{N1}>", (M, N1 + N2, K, 1), 2.0 * M * (N1 + N2) * K, e0, e1))
     return y1, y2, cpl
 
 
@@ -1220,12 +1220,23 @@ class MhaFn(torch.autograd.Function):
         return dqkv, None, None, None, None, None, None, None
 
 
+_MHA_P_WARNED = set()
+
+
 def mha(qkv, nhead, p=0.0, rng=None, seg=None, rowoff=None):
     """qkv[L_total, 3d]; `seg` (ops.Segments) partitions the rows into bags. `rowoff`: optional int64 device tensor [nseg] added
     to each bag's local region rows to form the dropout stream's row ids (bag-parallel world-size invariance). Operand planes
     attached to qkv by the producing contraction (`_advmil_planes`) are used as they are."""
     sid, seed = 0, None
     if p > 0.0:
+        # the kernels compare one hash byte per key against floor(256 p): p is quantised to 1/256 (0.25, the shipped rate, is exact)
+        q = int(p * 256.0)
+        if q == 0:
+            raise ValueError(f"attention dropout p = {p} is below the kernels' resolution of 1/256 (it would silently be no dropout)")
+        if abs(q / 256.0 - p) > 1e-9 and p not in _MHA_P_WARNED:
+            _MHA_P_WARNED.add(p)
+            import warnings
+            warnings.warn(f"attention dropout p = {p} runs at {q}/256 = {q / 256.0:.6f} (byte-hash resolution of csrc/attn.hip)")
         rng = rng or default_rng(qkv.device)
         sid, seed = rng.site("mha_attn", (qkv.shape[0], nhead), p), rng.seed
     return MhaFn.apply(qkv, nhead, float(p), seed, sid, seg, rowoff, getattr(qkv, "_advmil_planes", None) if qkv.is_contiguous() else None)

@@ -316,15 +316,38 @@ def pool_roofline(torch, ops, dev, patches, bags, iters=40):
             "method": f"{iters} back-to-back calls between two HIP events, rotating slabs > 256 MB; per-kernel durations: profiles/ (rocprofv3 --kernel-trace)"}
 
 
+def visible_gpu_count():
+    """GPUs this process could use, counted WITHOUT touching HIP (on ROCm builds without amdsmi torch.cuda.device_count() calls
+    hipGetDeviceCount, which initialises the runtime in the launcher process): the *_VISIBLE_DEVICES lists when set, else the KFD
+    topology (nodes with SIMDs). The rank processes validate the count again when they set their device."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(",") if t.strip() != ""])
+    n = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for d in os.listdir(base):
+            try:
+                props = dict(ln.split() for ln in open(os.path.join(base, d, "properties")) if len(ln.split()) == 2)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        pass
+    return n
+
+
 def self_launch(args):
     """`bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks as a CHILD torch.distributed.run job (this
-    process has not touched the GPU: torch.cuda.device_count() does not initialise it), relay rank 0's line, exit with its code."""
+    process never touches the GPU: the devices are counted from the environment / the KFD topology, visible_gpu_count), relay rank
+    0's line, exit with its code."""
     import socket
     import subprocess
-    import torch
-    ndev = torch.cuda.device_count()
+    ndev = visible_gpu_count()
     backend = os.environ.get("ADVMIL_DIST_BACKEND")
-    if ndev < args.gpus and backend != "gloo":
+    if 0 < ndev < args.gpus and backend != "gloo":            # (0 = could not tell: the ranks check when they set their device)
         print(f"bench.py: --gpus {args.gpus} but {ndev} GPU(s) visible: refusing to report a {args.gpus}-GPU number from fewer "
               "devices (set ADVMIL_DIST_BACKEND=gloo to run ranks that share devices, for functional testing only)", file=sys.stderr)
         sys.exit(2)
@@ -728,16 +751,25 @@ def main():
             kw["tile"] = int(kname.rstrip(">").split(",")[2]) * 10 + int(kname.rstrip(">").split(",")[3])
         elif sp > 1:
             kw["splits"] = sp
-        us = event_time_us(torch, lambda: ops.gemm(A, B, a_kc, b_kc, M, N, K, out=out, **kw), 50)
+        replay_form = "ops.gemm: the same kernel, tile and operand form as the step's launch"
+        if "two layers" in kname:             # the two-layer first-layer launch is replayed AS ITSELF (both outputs, relu | none split, h's planes)
+            n1 = int(kname.rstrip(">").split(",")[2])
+            W1, W2 = B[:n1].contiguous(), B[n1:].contiguous()
+            p1, p2, apl = ops.split_planes(W1), ops.split_planes(W2), kw["a_planes"]
+            b1, b2 = torch.randn(n1, device=dev), torch.randn(N - n1, device=dev)
+            us = event_time_us(torch, lambda: ops.gemm_two_layers(A, apl, W1, p1, b1, 1, W2, p2, b2, 0, True), 50)
+            replay_form = f"ops.gemm_two_layers: relu({n1} columns, planes emitted) | none({N - n1} columns), one launch"
+        else:
+            us = event_time_us(torch, lambda: ops.gemm(A, B, a_kc, b_kc, M, N, K, out=out, **kw), 50)
         flops = 2.0 * M * N * K
         achieved = flops / us / 1e6
         traffic, traffic_src = None, None
         try:      # PMC passes are separate runs (profiles/README.md); only a measurement of THIS kernel + shape + mode counts
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_gemm.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_gemm.json" if os.path.exists(os.path.join(ROOT, "profiles", "r04_pmc_gemm.json")) else "r03_pmc_gemm.json")))
             ent = pmc.get("planes_kernel_launches" if planes_kernel else "launches", {}).get(f"{M}x{N}x{K}")
             same = ent and (ent.get("kernel", "").startswith(kname.split(",")[0].rstrip(">")) if planes_kernel else ent.get("kernel") == kname)
             if same and ent.get("gemm_mode") == args.gemm_mode and ent.get("hbm_bytes_per_launch"):
-                traffic, traffic_src = ent["hbm_bytes_per_launch"], "profiles/r03_pmc_gemm.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel + shape)"
+                traffic, traffic_src = ent["hbm_bytes_per_launch"], "profiles/r0x_pmc_gemm.json, latest round (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel + shape)"
         except Exception:
             pass
         total_gemm_ms = sum(v["ms"] for v in agg.values()) / nprof
@@ -751,7 +783,7 @@ def main():
                      "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": round(us, 2), "flops_per_launch": flops,
                      "algorithmic_bytes_per_launch": 4.0 * (M * K + N * K + M * N),
                      "launches_per_step": top["n"] // nprof, "share_of_gemm_time_eager": round(top["ms"] / nprof / total_gemm_ms, 3),
-                     "method": "50 back-to-back launches between two HIP events on the launch stream",
+                     "method": "50 back-to-back launches between two HIP events on the launch stream", "replayed_as": replay_form,
                      "eager_event_bracketed_us": {f"{k[0]} {list(k[1][:3])}": round(1e3 * v["ms"] / v["n"], 1)
                                                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]}}
         del A, B, out
@@ -783,8 +815,10 @@ def main():
         def sync_barrier():
             torch.cuda.synchronize()
 
-        def bp1(n1=200):
-            g1 = [GraphedStep(h, [case.xs[i]], [case.ys[i]], [case.ys_host[i]], warmup=1) for i in range(min(8, case.n_pool))]
+        def bp1(n1=200, per=1):
+            npool = min(8 * per, case.n_pool // per * per)
+            g1 = [GraphedStep(h, [case.xs[i + j] for j in range(per)], [case.ys[i + j] for j in range(per)],
+                              [case.ys_host[i + j] for j in range(per)], warmup=1) for i in range(0, npool, per)]
             for k in range(8):
                 g1[k % len(g1)].replay()
             torch.cuda.synchronize()
@@ -793,12 +827,17 @@ def main():
                 g1[k % len(g1)].replay()
             torch.cuda.synchronize()
             d1 = time.perf_counter() - t1
-            return {"value": round(n1 / d1, 2), "unit": "G+D steps/s (1 bag of %d patches per step)" % args.patches,
-                    "ms_per_step": round(1e3 * d1 / n1, 3), "steps": n1}
+            return {"value": round(n1 / d1, 2), "unit": "G+D steps/s (%d bag%s of %d patches per step)" % (per, "" if per == 1 else "s", args.patches),
+                    "ms_per_step": round(1e3 * d1 / n1, 3), "steps": n1, "bags_per_step": per}
 
         try:
             if args.bags > 1:
                 bp1_extra = {args.gemm_mode: bp1()}
+                # the per-rank step of the reference's 16-bag optimizer step split over 8 GPUs (cfg_nlst.yaml:71): 2 bags per
+                # rank. Measured on ONE GPU, without the two gradient all-reduces -- the launch-latency-bound regime that the 8-GPU
+                # strong-scaling leg runs in (DESIGN.md section 6 projects from it; no multi-GPU hardware was available to the build)
+                if args.bags >= 2 and case.n_pool >= 2:
+                    bp1_extra["strong_split_rank_step"] = bp1(per=2)
         except Exception as exc:
             bp1_extra = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
         if args.gemm_mode == "bf16x3":

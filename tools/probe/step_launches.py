@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Device launches of ONE eager optimizer step (ABMIL, 16 x 8192), by kernel: count and device time (torch.profiler, CUDA activity)."""
+"""Device launches of ONE eager optimizer step, by kernel: count and device time (torch.profiler, CUDA activity).
+usage: step_launches.py [mode=abmil] [patches=8192] [bags=16]"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -7,7 +8,8 @@ import bench  # noqa: E402
 dev = torch.device("cuda", 0)
 kind = sys.argv[1] if len(sys.argv) > 1 else "abmil"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
-case = bench.Case(torch, dev, kind, n, 16, 16, "bf16x3", seed=1, eager=True)
+bags = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+case = bench.Case(torch, dev, kind, n, bags, max(16, bags), "bf16x3", seed=1, eager=True)
 for _ in range(3):
     case.eager_step()
 torch.cuda.synchronize()
