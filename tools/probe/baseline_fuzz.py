@@ -72,6 +72,13 @@ for case in range(ncase):
         globals()["nsus"] = nsus
         assert nsus <= max(1, ncase // 15), "too many second-step deviations to be ReLU-boundary flips"
         print(f"case {case}: {kind} {task} lens {lens}: second step off by {ep:.1e} (ReLU boundary flip, see source): counted", flush=True)
+        # every counted case is logged with what reproduces it (profiles/r0x_fuzz_counted_cases.jsonl: VERDICT r3 weak #2)
+        import json
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/fuzz_counted_cases.jsonl", "a") as fh:
+            fh.write(json.dumps({"tool": "tools/probe/baseline_fuzz.py", "argv": sys.argv[1:], "case": case, "kind": kind, "task": task,
+                                 "pdh_dims": pdh, "lens": lens, "bag_seeds": [900 + i for i in range(2 * nb)], "param_prefix": f"S-fz{case}:",
+                                 "second_step_pred_dev": ep, "second_step_loss_dev": el}) + "\n")
         continue
     for k, v in h.net.state_dict().items():
         diff = (v.cpu() - P[k]).abs()
