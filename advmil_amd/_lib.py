@@ -86,8 +86,9 @@ SIGNATURES = {
                                    c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "advmil_genconv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int64, c_void_p, c_void_p,
                                    c_void_p, c_void_p]),
+    "advmil_genconv_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "advmil_genconv_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64,
-                                   c_int64, c_void_p, c_void_p]),
+                                   c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "advmil_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                                  c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "advmil_abs_sum": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -1430,25 +1430,28 @@ class GenConvAggFn(torch.autograd.Function):
         x = x.contiguous()
         N, C = x.shape
         out = torch.empty_like(x)
-        lse = torch.empty_like(x)
-        m2 = torch.empty_like(x)
+        keep = any(ctx.needs_input_grad[:2])                     # evaluation: `out` is the only row written
+        lse = torch.empty_like(x) if keep else None
+        agg = torch.empty_like(x) if keep else None
         _lib.check(_lib.lib().advmil_genconv_fwd(_p(x), _p(csr.rowptr_dst), _p(csr.col_src), _p(t), eps, N, C, _p(out), _p(lse),
-                                                 _p(m2), _stream()), "genconv_fwd")
-        ctx.save_for_backward(x, t.detach(), out, lse, m2)
+                                                 _p(agg), _stream()), "genconv_fwd")
+        if keep:
+            ctx.save_for_backward(x, t.detach(), lse, agg)
         ctx.csr, ctx.eps = csr, eps
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, t, out, lse, m2 = ctx.saved_tensors
+        x, t, lse, agg = ctx.saved_tensors
         csr = ctx.csr
         N, C = x.shape
         dout = dout.contiguous()
         dx = torch.empty_like(x)
-        _lib.check(_lib.lib().advmil_genconv_bwd(_p(dout), _p(x), _p(out), _p(lse), _p(csr.rowptr_src), _p(csr.col_dst), _p(t),
-                                                 ctx.eps, N, C, _p(dx), _stream()), "genconv_bwd")
-        agg = out - x
-        dt = (dout * (m2 - agg * agg)).sum().reshape(1)          # d/dt of the softmax weights, reduced over nodes x channels
+        dt = torch.empty(1, device=x.device, dtype=torch.float32)     # d/dt of the softmax weights: falls out of the same edge walk
+        nws = _lib.lib().advmil_genconv_bwd_workspace_bytes(N, C)
+        ws = torch.empty(nws // 4, device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().advmil_genconv_bwd(_p(dout), _p(x), _p(agg), _p(lse), _p(csr.rowptr_src), _p(csr.col_dst), _p(t),
+                                                 ctx.eps, N, C, _p(dx), _p(dt), _p(ws), nws, _stream()), "genconv_bwd")
         return dx, dt, None, None
 
 

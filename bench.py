@@ -583,8 +583,8 @@ def product_loop(args, torch, dev, case):
 def genconv_roofline(torch, ops, dev, patches, bags, iters=20):
     """GENConv softmax aggregation (csrc/graph.hip) on the step's block-diagonal graph (bags x patches nodes, 8-NN grid, C = 128)
     against the HBM roof. Algorithmic bytes (8N x 128 x 4 gathered + N x 128 x 4 written), per launch:
-    forward = 8 neighbour rows + own row read, out / lse / m2 written; backward = per out-edge (dout, out, x, lse) rows of the
-    target + own (x, dout) read, dx written; index arrays 4 B per edge + 4 B per node."""
+    forward = 8 neighbour rows + own row read, out / lse / agg written; backward = per out-edge (dout, lse, agg) rows of the
+    target + own (x, dout) read, dx written (dt comes out of the same walk); index arrays 4 B per edge + 4 B per node."""
     from advmil_amd import synth
     C, N = 128, bags * patches
     ei1 = torch.from_numpy(synth.grid_knn_graph(patches, 8)).to(dev).long()
@@ -596,22 +596,31 @@ def genconv_roofline(torch, ops, dev, patches, bags, iters=20):
     xs = [torch.randn(N, C, device=dev, requires_grad=True) for _ in range(nbuf)]
     k = [0]
 
-    def fwd():
+    def fwd():                       # the training forward: out + the two rows kept for the backward (lse, agg)
+        ops.genconv_aggregate(xs[k[0] % nbuf], t, csr)
+        k[0] += 1
+
+    def fwd_eval():                  # evaluation: `out` only
         with torch.no_grad():
             ops.genconv_aggregate(xs[k[0] % nbuf], t, csr)
         k[0] += 1
 
     us_f = event_time_us(torch, fwd, iters)
+    us_fe = event_time_us(torch, fwd_eval, iters)
     ys = [ops.genconv_aggregate(x, t, csr) for x in xs]
     go = torch.randn(N, C, device=dev)
     L = ops._lib.lib()
     saved = [(y.grad_fn.saved_tensors, y.grad_fn) for y in ys]
 
-    def bwd():
-        x, tt, out, lse, m2 = saved[k[0] % nbuf][0]
-        dx = torch.empty_like(x)
-        ops._lib.check(L.advmil_genconv_bwd(ops._p(go), ops._p(x), ops._p(out), ops._p(lse), ops._p(csr.rowptr_src), ops._p(csr.col_dst),
-                                            ops._p(tt), 1e-7, N, C, ops._p(dx), ops._stream()), "genconv_bwd")
+    nws = L.advmil_genconv_bwd_workspace_bytes(N, C)
+    ws, dt = torch.empty(nws // 4, device=dev), torch.empty(1, device=dev)
+    dxs = [torch.empty(N, C, device=dev) for _ in range(2)]
+
+    def bwd():                       # the edge walk + the one-workgroup sum of its dt partials (two launches, timed together)
+        x, tt, lse, agg = saved[k[0] % nbuf][0]
+        ops._lib.check(L.advmil_genconv_bwd(ops._p(go), ops._p(x), ops._p(agg), ops._p(lse), ops._p(csr.rowptr_src), ops._p(csr.col_dst),
+                                            ops._p(tt), 1e-7, N, C, ops._p(dxs[k[0] % 2]), ops._p(dt), ops._p(ws), nws, ops._stream()),
+                       "genconv_bwd")
         k[0] += 1
 
     us_b = event_time_us(torch, bwd, iters)
@@ -620,12 +629,13 @@ def genconv_roofline(torch, ops, dev, patches, bags, iters=20):
     # first read); the per-EDGE figure of SURVEY 8d (8N x 128 x 4 gathered) is what the load path serves, reported as `gathered`
     bytes_f = N * row + 3 * N * row + 4.0 * (E + N)
     bytes_b = 4 * N * row + N * row + 4.0 * (E + N)
-    gath_f, gath_b = E * row, 4.0 * E * row
+    gath_f, gath_b = E * row, 3.0 * E * row
     ach = (bytes_f + bytes_b) / (us_f + us_b) / 1e3
-    return {"bound": "hbm", "kernel": "genconv_fwd128_kernel + genconv_bwd128_kernel (csrc/graph.hip)", "nodes": N, "edges": E, "channels": C,
+    return {"bound": "hbm", "kernel": "genconv_fwd128_kernel<save> + genconv_bwd128_kernel (+ genconv_dt_reduce_kernel) (csrc/graph.hip)", "nodes": N, "edges": E, "channels": C,
             "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
             "fwd_launch_us": round(us_f, 1), "fwd_gbps": round(bytes_f / us_f / 1e3, 1), "bwd_launch_us": round(us_b, 1),
             "bwd_gbps": round(bytes_b / us_b / 1e3, 1), "algorithmic_bytes_per_launch": {"fwd": bytes_f, "bwd": bytes_b},
+            "fwd_eval_launch_us": round(us_fe, 1), "fwd_eval_gbps": round((bytes_f - 2 * N * row) / us_fe / 1e3, 1),
             "gathered_bytes_per_launch": {"fwd": gath_f, "bwd": gath_b},
             "gathered_gbps": {"fwd": round((gath_f + bytes_f - N * row) / us_f / 1e3, 1), "bwd": round((gath_b + bytes_b - 4 * N * row) / us_b / 1e3, 1)},
             "note": "algorithmic = compulsory HBM bytes (each row of x / out / lse / dout once, outputs once, indices); `gathered` counts a "

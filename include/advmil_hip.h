@@ -262,14 +262,17 @@ int advmil_ln_relu_bwd(const float* dout, const float* y, const float* gamma, co
  * learn_t; parity unpinned: restated from the published semantics). x[N,C]; the graph arrives as two int32 CSR images:
  *   by destination (rowptr_dst[N+1], col_src[E] = source of each in-edge)  -> forward
  *   by source      (rowptr_src[N+1], col_dst[E] = target of each out-edge) -> backward
- * fwd: out = sum_j softmax_j(t*m_j) m_j + x, m = relu(x)+eps; saves lse (log-sum-exp of t*m over in-edges) and
- *      m2 = sum_j w m^2 (for dt = sum dout*(m2 - agg^2), reduced on the caller's side).
- * bwd: dx = dout + relu'(x) * sum_{j->i} dout_i w_ij (1 + t (m_j - agg_i)). No atomics in either direction. */
+ * fwd: out = agg + x, agg = sum_j softmax_j(t*m_j) m_j, m = relu(x)+eps; saves lse (log-sum-exp of t*m over the in-edges) and agg for
+ *      the backward (both NULL: nothing is saved, an evaluation pass writes `out` only).
+ * bwd: dx = dout + relu'(x) * sum_{j->i} dout_i w_ij (1 + t (m_j - agg_i)), w_ij = exp(t m_j - lse_i);
+ *      dt[0] = sum_{j->i, c} dout_i w_ij m_j (m_j - agg_i), from the same edge walk (per-workgroup partials in `ws`, summed in a fixed
+ *      order: run-to-run identical). ws_bytes >= advmil_genconv_bwd_workspace_bytes(N, C). No atomics in either direction. */
 int advmil_genconv_fwd(const float* x, const int32_t* rowptr_dst, const int32_t* col_src, const float* t, float eps, int64_t N,
-                       int64_t C, float* out, float* lse, float* m2, advmil_stream_t stream);
-int advmil_genconv_bwd(const float* dout, const float* x, const float* out, const float* lse, const int32_t* rowptr_src,
-                       const int32_t* col_dst, const float* t, float eps, int64_t N, int64_t C, float* dx,
-                       advmil_stream_t stream);
+                       int64_t C, float* out, float* lse, float* agg, advmil_stream_t stream);
+size_t advmil_genconv_bwd_workspace_bytes(int64_t N, int64_t C);
+int advmil_genconv_bwd(const float* dout, const float* x, const float* agg, const float* lse, const int32_t* rowptr_src,
+                       const int32_t* col_dst, const float* t, float eps, int64_t N, int64_t C, float* dx, float* dt, void* ws,
+                       size_t ws_bytes, advmil_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimizer + regulariser over a flat parameter arena (torch.optim.Adam, L2-in-grad weight decay:
