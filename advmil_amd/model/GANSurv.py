@@ -102,7 +102,7 @@ class Discriminator(_PairNet):
         rng = _rng_of(self, t)
         hid_x = run_mlp_small(self.net_pair_one.fc2, emb_bag, rng, "dx_fc2")
         hid_t = run_mlp_small(self.net_pair_two, t, rng, "dy")
-        return nn.functional.linear(torch.cat([hid_x, hid_t], dim=1), self.fc.weight, self.fc.bias)
+        return ops.linear_act_any(torch.cat([hid_x, hid_t], dim=1).contiguous(), self.fc.weight, self.fc.bias)   # [B, 1]: padded to the 4-float granularity
 
     def from_embedding(self, emb_ins, t):
         return self.tail(*self.bag_features(emb_ins), t)
@@ -156,7 +156,7 @@ class PrjDiscriminator(_PairNet):
         if self.prj_layer is not None:
             src = hid_x if self.prj_path == "x" else hid_t
             out = out + (ops.skinny_linear(src, self.prj_layer.weight, self.prj_layer.bias) if src.shape[0] <= 256
-                         else nn.functional.linear(src, self.prj_layer.weight, self.prj_layer.bias))
+                         else ops.linear_act_any(src.contiguous(), self.prj_layer.weight, self.prj_layer.bias))
         return out
 
     def from_embedding(self, emb_ins, t):

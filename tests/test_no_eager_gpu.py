@@ -57,6 +57,12 @@ def test_layer_norm_heads_and_odd_widths_stay_on_the_hip_path(no_aten):
     assert no_aten == []
 
 
+def test_the_concat_discriminator_head_stays_on_the_hip_path(no_aten):
+    # disc_type = cat (reference model/GANSurv.py:57-75): fc over [hid_x, hid_t] has ONE output column
+    one_epoch("abmil", disc_type="cat")
+    assert no_aten == []
+
+
 def test_padded_linear_matches_float64():
     from advmil_amd import ops
     g = torch.Generator().manual_seed(5)
