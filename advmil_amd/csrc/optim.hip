@@ -200,6 +200,23 @@ extern "C" int advmil_seed_advance(uint64_t* seed, uint64_t inc, advmil_stream_t
   return ADVMIL_OK;
 }
 
+// Device wall-clock stamp (wall_clock64: the constant-rate counter, advmil_clock_rate_khz ticks per ms): a one-thread launch the
+// measurement side (bench.py) puts before and after a kernel INSIDE the captured step graph, so a launch is timed where it runs in the
+// step -- between its real neighbours, at the clock the step's power draw allows -- not in a back-to-back replay.
+__global__ void stamp_clock_kernel(int64_t* dst) { *dst = (int64_t)wall_clock64(); }
+extern "C" int advmil_stamp_clock(int64_t* dst, advmil_stream_t stream_) {
+  if (!dst) return ADVMIL_EINVAL;
+  hipLaunchKernelGGL(stamp_clock_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, dst);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}
+extern "C" int64_t advmil_clock_rate_khz(void) {
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return 0;
+  return (int64_t)khz;
+}
+
 // =====================================================================================
 // The two scalar losses of the step over <= bp_every_batch values, value AND analytic gradient in one launch each
 // (the reference composes ~25 elementwise/reduce ops per loss and autograd as many again: loss/utils.py:21-41, 182-208).

@@ -18,6 +18,46 @@ FUSED_WGRAD = True
 # bench.py sets this to a list to bracket every GEMM launch with HIP events on the launch stream:
 # entries are (kernel name, (M, N, K, splits), flops, start_event, stop_event)
 KERNEL_PROFILE = None
+STAMPS = None            # bench.py: a Stamps object -> device wall-clock stamps around the contraction / attention launches (also inside a graph capture)
+
+
+class Stamps:
+    """Measurement aid: `mark` launches advmil_stamp_clock (a one-thread kernel writing the device's constant-rate wall clock) into the
+    next slot of a device buffer, in stream order; begin / end marks bracket a launch where it sits in the step -- inside the captured
+    graph the stamps are graph nodes, re-written on every replay. `durations_us()` pairs them up after a synchronize."""
+
+    def __init__(self, device, cap=2048):
+        self.buf = torch.zeros(cap, dtype=torch.int64, device=device)
+        self.tags = []
+        self.khz = int(_lib.lib().advmil_clock_rate_khz()) or 100000
+
+    def mark(self, tag):
+        i = len(self.tags)
+        if i >= self.buf.numel():
+            return
+        _lib.check(_lib.lib().advmil_stamp_clock(ctypes.c_void_p(self.buf.data_ptr() + 8 * i), _stream()), "stamp_clock")
+        self.tags.append(tag)
+
+    def durations_us(self, start=0):
+        """[(name, shape, flops, us)] of every bracketed launch from mark `start` on, from the buffer's current contents (synchronize first)."""
+        t = self.buf[:len(self.tags)].cpu().tolist()
+        out, open_ = [], {}
+        for i, (ph, name, shape, flops) in enumerate(self.tags):
+            if i < start:
+                continue
+            if ph == "b":
+                open_[(name, shape)] = i
+            else:
+                j = open_.pop((name, shape), None)
+                if j is not None:
+                    out.append((name, shape, flops, (t[i] - t[j]) * 1e3 / self.khz))
+        return out
+
+
+def _stamp(ph, name, shape, flops):
+    st = STAMPS
+    if st is not None:
+        st.mark((ph, name, shape, flops))
 # no-grad gated-attention passes skip the [N,2D] activations (ADVMIL_FUSED_GATE=0 keeps the two-launch path, for A/B timing)
 FUSED_GATE_SCORE = os.environ.get("ADVMIL_FUSED_GATE", "1") != "0"
 _ACT = {None: 0, "none": 0, "relu": 1, "tanh": 2, "sigmoid": 3}
@@ -466,17 +506,23 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
     wsb = L.advmil_gemm_f32_workspace_bytes(M, N, splits)
     ws = _ws(wsb, A.device) if wsb else None
     prof = KERNEL_PROFILE
-    if prof is not None:
-        e0 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-    _lib.check(L.advmil_gemm_f32_tiled(1 if a_kc else 0, 1 if b_kc else 0, M, N, K, _p(A), lda, _p(B), ldb, _p(out), ldc,
-                                       ctypes.byref(e), splits, tile, _p(ws), wsb, _stream()), f"gemm_f32[{M}x{N}x{K}]")
-    if prof is not None:
-        e1 = torch.cuda.Event(enable_timing=True)
-        e1.record()
+    name = None
+    if prof is not None or STAMPS is not None:
         name = ("gemm_nt_planes_kernel<%d>" % (tile - 80)) if 82 <= tile <= 84 else "gemm_nt_planes_kernel<4,plain>" if tile == 85 else \
             ("gemm_tn_planes_kernel<%d>" % tile) if 91 <= tile <= 93 else \
             "gemm_f32_kernel<%d,%d,%d,%d>" % (bool(a_kc), bool(b_kc), tile // 10, tile % 10)
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    if STAMPS is not None and M * N * K >= (1 << 30):
+        _stamp("b", name, (M, N, K, splits), 2.0 * M * N * K)
+    _lib.check(L.advmil_gemm_f32_tiled(1 if a_kc else 0, 1 if b_kc else 0, M, N, K, _p(A), lda, _p(B), ldb, _p(out), ldc,
+                                       ctypes.byref(e), splits, tile, _p(ws), wsb, _stream()), f"gemm_f32[{M}x{N}x{K}]")
+    if STAMPS is not None and M * N * K >= (1 << 30):
+        _stamp("e", name, (M, N, K, splits), 2.0 * M * N * K)
+    if prof is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
         prof.append((name, (M, N, K, splits), 2.0 * M * N * K, e0, e1))
     return gate_out if gate_wc is not None else out
 
@@ -514,8 +560,10 @@ def gemm_two_layers(x, xpl, W1, w1pl, b1, act1, W2, w2pl, b2, act2, emit_planes1
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
+    _stamp("b", f"gemm_nt_planes_kernel<4,two layers,{N1}>", (M, N1 + N2, K, 1), 2.0 * M * (N1 + N2) * K)
     _lib.check(_lib.lib().advmil_gemm_f32_tiled(1, 1, M, N1 + N2, K, _p(x), x.stride(0), _p(W1), K, _p(y1), N1, ctypes.byref(e), 1, 85,
                                                 None, 0, _stream()), f"gemm_two_layers[{M}x({N1}+{N2})x{K}]")
+    _stamp("e", f"gemm_nt_planes_kernel<4,two layers,{N1}>", (M, N1 + N2, K, 1), 2.0 * M * (N1 + N2) * K)
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
@@ -1189,15 +1237,18 @@ class MhaFn(torch.autograd.Function):
         d = d3 // 3
         hd = d // nhead
         dev = qkv.device
+        nseg = 1 if seg is None else seg.nseg
+        mlen = Lt if seg is None else seg.max_len
+        ptr = None if seg is None else seg.ptr
+        shape_ = (Lt, nhead, hd, nseg)
+        _stamp("b", "mha_fwd", shape_, 0.0)
         if planes is None:
             planes = split_planes(qkv)
         out = torch.empty(Lt, d, dtype=torch.float32, device=dev)
         lse = torch.empty(Lt, nhead, dtype=torch.float32, device=dev)
-        nseg = 1 if seg is None else seg.nseg
-        mlen = Lt if seg is None else seg.max_len
-        ptr = None if seg is None else seg.ptr
         _lib.check(_lib.lib().advmil_mha_fwd(_p(planes.hi), _p(planes.lo), Lt, nhead, hd, nseg, _p(ptr), mlen, p, _p(seed if p > 0.0 else None),
                                              sid, _p(rowoff), _p(out), _p(lse), _stream()), "mha_fwd")
+        _stamp("e", "mha_fwd", shape_, 0.0)
         ctx.save_for_backward(planes.hi, planes.lo, out, lse)
         ctx.cfg = (nhead, hd, p, seed, sid, seg, rowoff)
         return out
@@ -1215,8 +1266,10 @@ class MhaFn(torch.autograd.Function):
         ptr = None if seg is None else seg.ptr
         wsb = L.advmil_mha_bwd_workspace_bytes(Lt, nhead, hd)
         ws = _ws(wsb, qhi.device)
+        _stamp("b", "mha_bwd", (Lt, nhead, hd, nseg), 0.0)
         _lib.check(L.advmil_mha_bwd(_p(qhi), _p(qlo), _p(out), _p(dO), _p(lse), Lt, nhead, hd, nseg, _p(ptr), mlen, p,
                                     _p(seed if p > 0.0 else None), sid, _p(rowoff), _p(dqkv), _p(ws), wsb, _stream()), "mha_bwd")
+        _stamp("e", "mha_bwd", (Lt, nhead, hd, nseg), 0.0)
         return dqkv, None, None, None, None, None, None, None
 
 

@@ -249,6 +249,36 @@ class Case:
         self.torch.cuda.empty_cache()
 
 
+def in_step_launch_us(torch, ops, case, replays=8):
+    """Durations of the step's large launches WHERE THEY RUN IN THE STEP: one more bag group is captured with device wall-clock stamps
+    (ops.Stamps: one-thread kernels, graph nodes) before and after every slab-sized contraction / attention call, the graph is replayed
+    `replays` times and the stamps are read after each replay. -> {(name, shape): {"us": mean, "n": launches per step, "flops": per launch}}.
+    A stamp pair adds the two inter-kernel gaps (a few us) to the launch it brackets: the figure is an upper bound of the kernel's time."""
+    from advmil_amd.graphed import GraphedStep
+    h = case.h
+    st = ops.Stamps(case.dev)
+    ov, h.overlap_gfwd = h.overlap_gfwd, False          # one stream: a bracketed launch must not share the chip with another branch
+    idx = list(range(case.bags))
+    ops.STAMPS = st
+    try:
+        g = GraphedStep(h, [case.xs[i] for i in idx], [case.ys[i] for i in idx], [case.ys_host[i] for i in idx], warmup=1)
+    finally:
+        ops.STAMPS = None
+    per = len(st.tags) // 2                              # marks of one step (the warm-up step made the first half)
+    acc = {}
+    for k in range(replays + 2):
+        g.replay()
+        torch.cuda.synchronize()
+        if k >= 2:
+            for name, shape, flops, us in st.durations_us(start=len(st.tags) - per):
+                a = acc.setdefault((name, shape), {"flops": flops, "us": []})
+                a["us"].append(us)
+    h.overlap_gfwd = ov
+    h.history.clear()
+    del g
+    return {k: {"flops": v["flops"], "us": sum(v["us"]) / len(v["us"]), "n": len(v["us"]) // replays} for k, v in acc.items()}
+
+
 def event_time_us(torch, fn, iters, warm=3):
     """Average duration of fn() over `iters` back-to-back calls between two HIP events on the launch stream (queue kept full)."""
     for _ in range(warm):
@@ -263,7 +293,7 @@ def event_time_us(torch, fn, iters, warm=3):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
-def attention_roofline(torch, ops, dev, L, bags, p=0.25, iters=20):
+def attention_roofline(torch, ops, dev, L, bags, p=0.25, iters=20, in_step=None):
     """The fused ESAT attention core on the step's region slab (bags x L tokens, 8 heads x 48): forward and backward launches
     timed back to back. Algorithmic flops: forward 4 L^2 d per bag (QK^T, PV), backward 10 L^2 d (five contractions), d = 384.
     Roof: dense bf16 MFMA / 3 (three bf16 MFMAs per fp32-equivalent product)."""
@@ -282,8 +312,20 @@ def attention_roofline(torch, ops, dev, L, bags, p=0.25, iters=20):
 
     us_b = event_time_us(torch, bwd, iters)
     ff, fb = 4.0 * L * L * d * bags, 10.0 * L * L * d * bags
+    b2b = {"fwd_launch_us": round(us_f, 1), "bwd_launches_us": round(us_b, 1), "achieved": round((ff + fb) / (us_f + us_b) / 1e6, 2),
+           "frac": round((ff + fb) / (us_f + us_b) / 1e6 / PEAK_BF16X3_TFLOPS, 4), "launches": iters,
+           "note": "the same launches repeated with nothing in between: the chip clocks down under the sustained matrix-pipe power draw, a regime the step never reaches"}
+    method = f"{iters} back-to-back launches between two HIP events on the launch stream"
+    if in_step:      # the step's own attention calls, stamped inside a captured step (in_step_launch_us): forward = mean of the eval (no dropout) and the training (dropout) pass
+        f_ = [v for k, v in in_step.items() if k[0] == "mha_fwd" and k[1][0] == bags * L]
+        b_ = [v for k, v in in_step.items() if k[0] == "mha_bwd" and k[1][0] == bags * L]
+        if f_ and b_:
+            us_f, us_b = f_[0]["us"], b_[0]["us"]
+            method = ("device wall-clock stamps (one-thread kernels = graph nodes) around the step's own ops.mha forward (eval + training pass, mean) and "
+                      "backward INSIDE a captured step, 8 replays: timed between their real neighbours, at the clock the step runs at")
     ach = (ff + fb) / (us_f + us_b) / 1e6
     return {"bound": "mfma", "kernel": "split_planes + attn_fwd_kernel<48,drop> + attn_bwd_prep + attn_bwd_dq_kernel + attn_bwd_dkv_kernel (csrc/attn.hip)",
+            "back_to_back": b2b,
             "tokens_per_bag": L, "bags": bags, "heads": nh, "head_dim": 48, "attn_dropout": p,
             "achieved": round(ach, 2), "peak": round(PEAK_BF16X3_TFLOPS, 1), "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16X3_TFLOPS, 4),
             "peak_note": "bf16x3: 3 bf16 MFMAs per fp32-equivalent product -> roof = dense bf16 MFMA peak / 3 in algorithmic flops",
@@ -291,7 +333,7 @@ def attention_roofline(torch, ops, dev, L, bags, p=0.25, iters=20):
             "bwd_launches_us": round(us_b, 1), "bwd_tflops": round(fb / us_b / 1e6, 1),
             "flops_per_launch": {"fwd": ff, "bwd": fb},
             "algorithmic_bytes_per_launch": {"fwd": 4.0 * bags * L * (4 * d + nh), "bwd": 4.0 * bags * L * (9 * d + 2 * nh)},
-            "method": f"{iters} back-to-back launches between two HIP events on the launch stream"}
+            "method": method}
 
 
 def pool_roofline(torch, ops, dev, patches, bags, iters=40):
@@ -722,6 +764,7 @@ def main():
     # (2) that exact launch is then timed back-to-back (queue kept full, so no host gaps pollute the per-launch time)
     #     between two HIP events on the same stream. achieved = algorithmic FLOPs per launch / that duration.
     gemm_roof = None
+    ist_all = None
     nprof = max(1, min(2, args.steps))
     # The instrumented pass drives full optimizer steps, which contain the two gradient all-reduces: EVERY rank has to run it
     # (rank 0 alone deadlocks the job at world > 1 -- observed: a 2-rank default-flag run hung until its 900 s timeout).
@@ -767,11 +810,24 @@ def main():
             W1, W2 = B[:n1].contiguous(), B[n1:].contiguous()
             p1, p2, apl = ops.split_planes(W1), ops.split_planes(W2), kw["a_planes"]
             b1, b2 = torch.randn(n1, device=dev), torch.randn(N - n1, device=dev)
-            us = event_time_us(torch, lambda: ops.gemm_two_layers(A, apl, W1, p1, b1, 1, W2, p2, b2, 0, True), 50)
+            us = event_time_us(torch, lambda: ops.gemm_two_layers(A, apl, W1, p1, b1, 1, W2, p2, b2, 0, True), 16)
             replay_form = f"ops.gemm_two_layers: relu({n1} columns, planes emitted) | none({N - n1} columns), one launch"
         else:
-            us = event_time_us(torch, lambda: ops.gemm(A, B, a_kc, b_kc, M, N, K, out=out, **kw), 50)
+            us = event_time_us(torch, lambda: ops.gemm(A, B, a_kc, b_kc, M, N, K, out=out, **kw), 16)
         flops = 2.0 * M * N * K
+        us_b2b = us
+        in_step = None
+        if case.graphs:                       # the launch where it runs: stamped inside one more captured step (see in_step_launch_us)
+            try:
+                ist = ist_all = in_step_launch_us(torch, ops, case)
+                hit = ist.get((kname, shape))
+                if hit:
+                    in_step = {"avg_launch_us": round(hit["us"], 2), "launches_per_step": hit["n"],
+                               "others_us": {f"{k[0]} {list(k[1][:3])}": round(v["us"], 1)
+                                             for k, v in sorted(ist.items(), key=lambda kv: -kv[1]["us"] * kv[1]["n"])[:8]}}
+                    us = hit["us"]
+            except Exception as exc:
+                in_step = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
         achieved = flops / us / 1e6
         traffic, traffic_src = None, None
         try:      # PMC passes are separate runs (profiles/README.md); only a measurement of THIS kernel + shape + mode counts
@@ -793,7 +849,15 @@ def main():
                      "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": round(us, 2), "flops_per_launch": flops,
                      "algorithmic_bytes_per_launch": 4.0 * (M * K + N * K + M * N),
                      "launches_per_step": top["n"] // nprof, "share_of_gemm_time_eager": round(top["ms"] / nprof / total_gemm_ms, 3),
-                     "method": "50 back-to-back launches between two HIP events on the launch stream", "replayed_as": replay_form,
+                     "method": ("device wall-clock stamps (one-thread kernels = graph nodes) before and after the launch INSIDE a captured step, "
+                                "8 replays: the launch timed between its real neighbours, at the clock the step runs at (includes the two "
+                                "inter-kernel gaps)" if in_step and "avg_launch_us" in in_step else
+                                "16 back-to-back launches between two HIP events on the launch stream"),
+                     "in_step": in_step,
+                     "back_to_back": {"avg_launch_us": round(us_b2b, 2), "frac": round(flops / us_b2b / 1e6 / peak, 4), "launches": 16,
+                                      "note": "the same launch repeated with nothing in between: the chip clocks down under the sustained matrix-pipe "
+                                              "power draw (DESIGN.md section 4), a regime the step never reaches"},
+                     "replayed_as": replay_form,
                      "eager_event_bracketed_us": {f"{k[0]} {list(k[1][:3])}": round(1e3 * v["ms"] / v["n"], 1)
                                                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]}}
         del A, B, out
@@ -801,7 +865,7 @@ def main():
     roof = gemm_roof
     if rank == 0 and not args.no_roofline and args.mode == "patch":
         try:
-            roof = attention_roofline(torch, ops, dev, args.patches // 16, args.bags)
+            roof = attention_roofline(torch, ops, dev, args.patches // 16, args.bags, in_step=ist_all)
         except Exception as exc:
             roof = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
 
@@ -895,10 +959,16 @@ def main():
                 d2, _ = c2.timed(steps_, 2, sync_barrier)
                 ent = {"value": round(bags_ * steps_ / d2, 2), "unit": "bags/s", "ms_per_step": round(1e3 * d2 / steps_, 3), "steps": steps_,
                        "bags_per_step": bags_, "distinct_resident_bags": c2.n_pool, "losses_finite": c2.logs_finite(), "launch": c2.launch_note}
+                ist2 = None
+                if mode_ == "patch" and c2.graphs:
+                    try:
+                        ist2 = in_step_launch_us(torch, ops, c2)
+                    except Exception:
+                        ist2 = None
                 c2.free()
                 del c2
                 if mode_ == "patch":
-                    ent["roofline"] = attention_roofline(torch, ops, dev, patches_ // 16, bags_, iters=10)
+                    ent["roofline"] = attention_roofline(torch, ops, dev, patches_ // 16, bags_, iters=10, in_step=ist2)
                 if mode_ == "graph":           # configs[4]'s backbone at a size one GPU steps through quickly; its sparse gather vs HBM
                     ent["roofline"] = genconv_roofline(torch, ops, dev, patches_, bags_)
                 sizes[tag] = ent

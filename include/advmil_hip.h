@@ -306,6 +306,10 @@ int advmil_uniform_fill(float* out, int64_t n, const uint64_t* seed, uint64_t st
 int advmil_dropout_apply(const float* x, float* y, int64_t n, float p, const uint64_t* seed, uint64_t stream_id,
                          const int64_t* rng_row, int64_t width, advmil_stream_t stream);
 int advmil_seed_advance(uint64_t* seed, uint64_t inc, advmil_stream_t stream);
+/* Measurement aid (bench.py): dst[0] = the device's constant-rate wall clock, written by a one-thread launch in stream order, so two of
+ * them bracket a kernel inside a captured step graph; advmil_clock_rate_khz() = ticks per millisecond (0: unknown). Not used by the step. */
+int advmil_stamp_clock(int64_t* dst, advmil_stream_t stream);
+int64_t advmil_clock_rate_khz(void);
 /* The step's two scalar losses over <= bp_every_batch values, value and analytic gradient in one launch each.
  * D loss (loss/utils.py:182-203 real_fake_loss with the reference's means taken over the GLOBAL counts, model_handler.py:412):
  *   which 0 = bce as shipped, 1 = hinge, 2 = wasserstein; real_mask selects the real pairs (event bags with a visible label);
