@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import prof_summary  # noqa: E402
 import csv  # noqa: E402
 
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 SRC = os.path.join(ROOT, "gpurun_out", "prof_" + TAG)
 DST = os.path.join(ROOT, "profiles")
 
@@ -49,7 +49,7 @@ def stats_avg(run):
     return out
 
 
-for run in ("bench_abmil", "bench_esat32k", "bench_patchgcn", "pool16", "pool1", "attn2048"):
+for run in ("bench_abmil", "bench_esat32k", "bench_patchgcn", "pool16", "pool1", "attn2048", "genconv"):
     f = first(f"{run}/**/*kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(DST, f"{TAG}_{run}_kernel_stats.csv"))
