@@ -817,7 +817,8 @@ def main():
         flops = 2.0 * M * N * K
         us_b2b = us
         in_step = None
-        if case.graphs:                       # the launch where it runs: stamped inside one more captured step (see in_step_launch_us)
+        if case.graphs and world == 1:        # the launch where it runs: stamped inside one more captured step (see in_step_launch_us);
+            # single process only -- a captured step holds the gradient all-reduces, which rank 0 alone must never enter
             try:
                 ist = ist_all = in_step_launch_us(torch, ops, case)
                 hit = ist.get((kname, shape))

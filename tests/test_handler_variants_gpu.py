@@ -65,7 +65,7 @@ def run_case(kind="abmil", lens=(256, 512, 128, 64), events=None, visible=None, 
             # (< 0.01 %), none further than the two-step sign-flip bound; everything else must agree to 5e-5.
             diff = (v.cpu() - P[k]).abs()
             n_off = int((diff >= 5e-5).sum())
-            assert n_off <= max(1, diff.numel() // 10000), (k, n_off, diff.numel(), float(diff.max()))
+            assert n_off <= max(1, diff.numel() // 10000), (k, n_off, diff.numel(), float(diff.max()), (diff >= 5e-5).nonzero()[:12].tolist())
             assert float(diff.max()) < 2.05 * 8e-5 * steps, (k, float(diff.max()))
     return h
 
@@ -127,8 +127,18 @@ def test_other_d_losses(which):
     # the configuration on which the randomised parity run (tools/probe/oracle_fuzz.py 30 11, case 26) left the 4e-4 band of the
     # post-Adam comparison: DeepAttMISL, one event bag, one invisible label, 4 208 rows (padded slab), wasserstein
     ("wasserstein", "cluster", (128, 896, 3184), (0, 0, 1), (False, True, True)),
-    ("hinge", "patch", (1312, 2064, 976), (1, 0, 1), (True, False, True))])
+    ("hinge", "patch", (1312, 2064, 976), (1, 0, 1), (True, False, True)),
+    # round 4, tools/probe/oracle_fuzz.py 40 11 case 25 and 40 23 case 4 (exact fp32 arithmetic, bce): 42 / 75 entries of a first-layer
+    # weight (0.03 % / 0.02 %, the post-Adam check of run_case allows 0.01 %) ended one or two sign flips (<= 2 lr per step) away from
+    # the oracle after two optimizer steps; the raw gradients of the same configurations agree to 2e-5 of the tensor's scale (here),
+    # so the excess is Adam's round-off amplification (step 1 moves the exact-zero-gradient biases by +-lr on both sides, step 2's
+    # gradients see it at the 1e-4 level), not a kernel deviation. Logged by the fuzzer with its seeds (profiles/r04_fuzz_counted_cases.jsonl).
+    ("bce", "abmil", (4144,), (1,), (False,)), ("bce", "cluster", (592, 3536), (1, 0), None)])
 def test_d_loss_gradients_before_adam(which, kind, lens, events, visible):
+    gradients_before_adam(which, kind, lens, events, visible)
+
+
+def gradients_before_adam(which, kind, lens, events, visible, **cfg_over):
     """The hinge / wasserstein D losses (loss/utils.py:182-203) at the contract's tolerance WITHOUT Adam in between: the raw
     gradients of one D backward and one G backward (the arenas the optimizer kernels read) against the oracle's autograd, every
     parameter, 2e-5 of the tensor's gradient scale. (Post-Adam weights of these two losses are round-off noise on both sides:
@@ -138,8 +148,9 @@ def test_d_loss_gradients_before_adam(which, kind, lens, events, visible):
     from advmil_amd.model import MyHandler
     nb = len(lens)
     mode = "wlabel" if visible is None else "wolabel"
-    h = MyHandler(default_cfg(bcb_mode=kind, bp_every_batch=nb, loss_netD=which), device=DEV)
-    PG, PD = load_synth(h.netG, f"G-{kind}:"), load_synth(h.netD, "D-prj:")
+    h = MyHandler(default_cfg(bcb_mode=kind, bp_every_batch=nb, loss_netD=which, **cfg_over), device=DEV)
+    dt_ = cfg_over.get("disc_type", "prj")
+    PG, PD = load_synth(h.netG, f"G-{kind}:"), load_synth(h.netD, "D-prj:" if dt_ == "prj" else "D-cat:")
     zero_dropout(h.netG); zero_dropout(h.netD)
     bags = []
     for i, n in enumerate(lens):
@@ -157,7 +168,8 @@ def test_d_loss_gradients_before_adam(which, kind, lens, events, visible):
     h._disc_backward(0, xs, ys, plan, [[n[0].to(DEV)] for n in nd])
     h._gen_backward(0, xs, ys, plan, [[n[0].to(DEV)] for n in ng])
     torch.cuda.synchronize()
-    cfg = O.StepConfig(kind=kind, loss_netD=which, l1_coef=0.0)              # (the L1 sub-gradient is applied inside the Adam kernel)
+    cfg = O.StepConfig(kind=kind, loss_netD=which, l1_coef=0.0, disc_type=dt_, inner_product=cfg_over.get("disc_prj_iprd", "instance"),
+                       prj_path=cfg_over.get("disc_prj_path", "x"))          # (the L1 sub-gradient is applied inside the Adam kernel)
     vis = None if visible is None else list(visible)
     # The oracle in FLOAT64 is the reference here. In fp32 -- the reference's own CPU arithmetic -- the oracle itself is 3.8e-3 (of the
     # tensor's scale) away from float64 on DeepAttMISL's first-layer weight gradient in the `cluster` case below (per-cluster means of
