@@ -1233,7 +1233,8 @@ extern "C" int advmil_gemm_f32_plan_planes(int a_kc, int b_kc, int64_t M, int64_
   int tnp = (N % 192 == 0) ? 3 : 2;
   if (force && (force[0] == '2' || force[0] == '3') && N % (64 * (force[0] - '0')) == 0) tnp = force[0] - '0';
   if (K < 64 || (uint64_t)M * (uint64_t)K * 2 >= (1ull << 32) || (uint64_t)N * (uint64_t)K * 2 >= (1ull << 32)) return ADVMIL_OK;
-  if ((M / 256) * (N / (64 * tnp)) < 384) return ADVMIL_OK;      // one 8-wave workgroup per CU: fewer than ~1.5 waves of them lose to the small tiles
+  static const int min_tiles = []() { const char* e = getenv("ADVMIL_NT_PLANES_MIN_TILES"); return e ? atoi(e) : 384; }();
+  if ((M / 256) * (N / (64 * tnp)) < min_tiles) return ADVMIL_OK;      // one 8-wave workgroup per CU: fewer than ~1.5 waves of them lose to the small tiles
   *tile = 80 + tnp;
   return ADVMIL_OK;
 }

@@ -953,7 +953,8 @@ __global__ __launch_bounds__(256, (QT <= 6 ? 4 : 2)) void ln_relu_mean16_bwd_ker
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  int64_t N, int64_t d, float* __restrict__ dy,
-                                                                 float* __restrict__ partial, int pool16) {
+                                                                 float* __restrict__ partial, int pool16,
+                                                                 bf16raw* __restrict__ o_hi, bf16raw* __restrict__ o_lo) {
   __shared__ float red[4 * 1536];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   constexpr int Q = QT;      // 64-column groups per row (d <= 64 * QT)
@@ -1026,7 +1027,13 @@ __global__ __launch_bounds__(256, (QT <= 6 ? 4 : 2)) void ln_relu_mean16_bwd_ker
         // (dz * gamma recomputed instead of carried through the two reductions: six registers that decide 3 vs 4 waves per SIMD)
         const float dxh = ((xh[q] * gm[q] + bt[q]) > 0.f ? de[q] : 0.f) * gm[q];
         const float v = rs * (dxh - c1 - xh[q] * c2);
-        dy[n * d + j] = v;
+        if (dy) dy[n * d + j] = v;                        // (NULL: planes only)
+        if (o_hi) {                                       // bf16x3 operand planes of dy for the weight-gradient contraction that reads it
+          unsigned hh, ll;
+          split2(v, 0.f, hh, ll);
+          o_hi[n * d + j] = (bf16raw)(hh & 0xffffu);
+          o_lo[n * d + j] = (bf16raw)(ll & 0xffffu);
+        }
         ady[q] += v;            // column sums of dy = the bias gradient of the layer that produced y (no second pass over dy)
       }
     }
@@ -1055,16 +1062,17 @@ extern "C" size_t advmil_ln_relu_mean16_bwd_workspace_bytes(int64_t N, int64_t d
 
 extern "C" int advmil_ln_relu_mean16_bwd(const float* demb, const float* y, const float* gamma, const float* beta,
                                          const float* mean, const float* rstd, int64_t N, int64_t d, float* dy,
-                                         float* dgamma, float* dbeta, int accumulate, float* dycol, void* ws, size_t ws_bytes,
-                                         advmil_stream_t stream_) {
+                                         float* dgamma, float* dbeta, int accumulate, float* dycol, void* dy_hi, void* dy_lo,
+                                         void* ws, size_t ws_bytes, advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!demb || !y || !gamma || !beta || !mean || !rstd || !dy || !dgamma || !dbeta || !ws || N <= 0 || (N & 15) || d <= 0 ||
-      d > 512)
+  if (!demb || !y || !gamma || !beta || !mean || !rstd || (!dy && !dy_hi) || !dgamma || !dbeta || !ws || N <= 0 || (N & 15) || d <= 0 ||
+      d > 512 || ((dy_hi != nullptr) != (dy_lo != nullptr)))
     return ADVMIL_EINVAL;
   if (ws_bytes < advmil_ln_relu_mean16_bwd_workspace_bytes(N, d)) return ADVMIL_EWORKSPACE;
   const int L = ln_bwd_blocks(N / 16);
   float* partial = (float*)ws;
-  LN_DISPATCH(d, ln_relu_mean16_bwd_kernel, dim3(L), stream, demb, y, gamma, beta, mean, rstd, N, d, dy, partial, 1);
+  LN_DISPATCH(d, ln_relu_mean16_bwd_kernel, dim3(L), stream, demb, y, gamma, beta, mean, rstd, N, d, dy, partial, 1, (bf16raw*)dy_hi,
+              (bf16raw*)dy_lo);
   ADVMIL_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial, L, 3 * d, d, dgamma, accumulate);
   hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial + d, L, 3 * d, d, dbeta, accumulate);
@@ -1087,7 +1095,8 @@ extern "C" int advmil_ln_relu_bwd(const float* dout, const float* y, const float
   if (ws_bytes < advmil_ln_relu_bwd_workspace_bytes(N, d)) return ADVMIL_EWORKSPACE;
   const int L = ln_bwd_blocks((N + 15) / 16);
   float* partial = (float*)ws;
-  LN_DISPATCH(d, ln_relu_mean16_bwd_kernel, dim3(L), stream, dout, y, gamma, beta, mean, rstd, N, d, dy, partial, 0);
+  LN_DISPATCH(d, ln_relu_mean16_bwd_kernel, dim3(L), stream, dout, y, gamma, beta, mean, rstd, N, d, dy, partial, 0, (bf16raw*)nullptr,
+              (bf16raw*)nullptr);
   ADVMIL_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial, L, 3 * d, d, dgamma, accumulate);
   hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial + d, L, 3 * d, d, dbeta, accumulate);

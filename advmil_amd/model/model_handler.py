@@ -602,6 +602,7 @@ class MyHandler(object):
         # real_fake_loss with the global denominators (loss/utils.py:182-203, model_handler.py:412) as ONE launch that also yields
         # d loss / d score; the real pairs are selected by a 0/1 mask (same sum as f_real[event & visible], no index backward)
         ops.PREFILL.clear()                  # (anything the two forwards did not take is stale from here on)
+        ops.DY_PLANES.clear()
         if f2 is not None:                   # rows [0, nb) fake, [nb, 2 nb) real scores of ALL bags; the mask picks the real pairs
             loss, st = ops.gan_d_loss_stacked(f2, len(xs), plan.real_mask, self.which_loss, plan.n_fake, plan.n_real, root=True)
         else:
@@ -812,6 +813,7 @@ class MyHandler(object):
             eb, im = modelD.bag_features_multi(emb, seg.div(16))
             f_fake = modelD.tail(eb[:n], None if im is None else im[:n], y_hat)
             ops.PREFILL.clear()
+            ops.DY_PLANES.clear()
             parts["idx"].extend(i.detach() for i in bt.idx); parts["y"].extend(y.detach() for y in bt.ys)
             parts["y_hat"].append(y_hat); parts["f_fake"].append(f_fake.reshape(n, -1))
             if times_test_sample > 1:

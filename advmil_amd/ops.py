@@ -527,10 +527,13 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
     return gate_out if gate_wc is not None else out
 
 
+TWO_LAYERS_MIN_TILES = int(os.environ.get("ADVMIL_TWO_LAYERS_MIN_TILES", "256"))
+
+
 def gemm_two_layers_ok(M, N1, N2, K):
     """Can act(x W1^T + b1) and act(x W2^T + b2) over the same rows run as ONE plane-fed launch (tile 85: persistent 256x256)?"""
     return (get_gemm_mode() == "bf16x3" and USE_PLANES and M >= 4096 and M % 256 == 0 and K % 32 == 0 and K >= 64 and N1 % 32 == 0
-            and (N1 + N2) % 256 == 0 and (M // 256) * ((N1 + N2) // 256) >= 256 and M * K * 2 < (1 << 32))
+            and (N1 + N2) % 256 == 0 and (M // 256) * ((N1 + N2) // 256) >= TWO_LAYERS_MIN_TILES and M * K * 2 < (1 << 32))
 
 
 def gemm_two_layers(x, xpl, W1, w1pl, b1, act1, W2, w2pl, b2, act2, emit_planes1=False):
@@ -718,8 +721,9 @@ def ln_relu_mean16_fwd(y, gamma, beta, N, d, eps=1e-5):
     return emb, mean, rstd
 
 
-def ln_relu_mean16_bwd(demb, y, gamma, beta, mean, rstd, N, d, dg_out=None, db_out=None, ycol_out=None):
-    """ycol_out: optional [d] accumulator that receives += column sums of dy (the bias gradient of the FC that produced y)."""
+def ln_relu_mean16_bwd(demb, y, gamma, beta, mean, rstd, N, d, dg_out=None, db_out=None, ycol_out=None, planes=None):
+    """ycol_out: optional [d] accumulator that receives += column sums of dy (the bias gradient of the FC that produced y).
+    planes: Planes that receive dy's bf16x3 operand planes INSTEAD of the fp32 values (the returned dy is then an unwritten token)."""
     L = _lib.lib()
     dev = y.device
     dy = torch.empty(N, d, dtype=torch.float32, device=dev)
@@ -728,8 +732,9 @@ def ln_relu_mean16_bwd(demb, y, gamma, beta, mean, rstd, N, d, dg_out=None, db_o
     db = db_out if acc else torch.empty(d, dtype=torch.float32, device=dev)
     wsb = L.advmil_ln_relu_mean16_bwd_workspace_bytes(N, d)
     ws = _ws(wsb, dev)
-    _lib.check(L.advmil_ln_relu_mean16_bwd(_p(demb), _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), N, d, _p(dy), _p(dg),
-                                           _p(db), 1 if acc else 0, _p(ycol_out), _p(ws), wsb, _stream()), "ln_relu_mean16_bwd")
+    _lib.check(L.advmil_ln_relu_mean16_bwd(_p(demb), _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), N, d, _p(None if planes is not None else dy),
+                                           _p(dg), _p(db), 1 if acc else 0, _p(ycol_out), _p(None if planes is None else planes.hi),
+                                           _p(None if planes is None else planes.lo), _p(ws), wsb, _stream()), "ln_relu_mean16_bwd")
     return dy, dg, db
 
 
@@ -812,6 +817,7 @@ def dropout(x, p, rng, tag=""):
 class LinearActFn(torch.autograd.Function):
     """y = dropout(act(x W^T + b)); x[M,K], W[N,K]. Dropout index = m*N + n on stream `sid`."""
     last_planes = None       # planes of the y just produced (side channel to linear_act: Function outputs are re-wrapped)
+    last_wants_dy_planes = False
 
     @staticmethod
     def forward(ctx, x, W, b, act, p, seed, sid, y0=None, rr=None, xpl=None, wpl=None, emit=False):
@@ -849,6 +855,13 @@ class LinearActFn(torch.autograd.Function):
         ctx.cfg = (act, p, seed, sid, M, N, K, W.shape, b is not None, rr)
         ctx.gW, ctx.gb = _arena_grad(W), _arena_grad(b)
         ctx.xpl = xpl if xpl is not None else (planes_of(x) if M >= 4096 else None)     # the weight gradient's big operand, pre-split
+        # a plain slab layer (no activation, no dropout, constant bias, no input gradient) whose weight gradient takes both operands
+        # pre-split: the backward of the LayerNorm behind it may hand dy over as operand planes only (ops.ln_relu_mean16 / DY_PLANES)
+        ctx.wants_dy_planes = bool(
+            not ctx.small and act == ACT_NONE and p <= 0.0 and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]
+            and not (b is not None and ctx.needs_input_grad[2]) and DG_PLANES_ONLY and DW_PLANES and get_gemm_mode() == "bf16x3"
+            and ctx.xpl is not None and M >= 4096 and N % 8 == 0 and pre_a_tile_ok(gemm_plan(N, K, M, False, False)[0], False, False, True))
+        LinearActFn.last_wants_dy_planes = ctx.wants_dy_planes
         return y
 
     @staticmethod
@@ -875,6 +888,18 @@ class LinearActFn(torch.autograd.Function):
             return (dx, None if (dW is None or acc_w) else dW.reshape(wshape), None if (db is None or acc_b) else db,
                     None, None, None, None, None, None, None, None, None)
         if act == ACT_NONE and p <= 0.0:
+            ent = DY_PLANES.pop(dy.data_ptr(), None) if ctx.wants_dy_planes else None
+            if ent is not None and ent[1] == (M, N) and need_w:
+                # dy arrived as operand planes only (written by the LayerNorm backward): dW = dy^T X with both operands pre-split
+                dpl, xpl0 = ent[0], ctx.xpl
+                if ctx.gW is not None:
+                    gemm(None, x, False, False, N, K, M, out=ctx.gW.view(N, K), ldc=K, accumulate=True, a_planes=dpl, b_planes=xpl0)
+                    return None, None, None, None, None, None, None, None, None, None, None, None
+                dW = gemm(None, x, False, False, N, K, M, a_planes=dpl, b_planes=xpl0).reshape(wshape)
+                return None, dW, None, None, None, None, None, None, None, None, None, None
+            if ctx.wants_dy_planes and any(v[1] == (M, N) for v in DY_PLANES.values()):
+                raise RuntimeError("advmil_amd: a gradient written as operand planes only did not reach the layer that asked for it "
+                                   "(autograd re-wrapped the token tensor?)")
             dpre = dy
             if need_b:
                 db = colsum(dy, M, N, out=ctx.gb)
@@ -1015,6 +1040,9 @@ def linear_act(x, W, b, act="none", p=0.0, rng=None, tag="", emit_planes=False):
     out = y if len(lead) == 1 else y.reshape(*lead, y.shape[-1])
     if cpl is not None:
         out._advmil_planes = cpl
+    if LinearActFn.last_wants_dy_planes:
+        out._advmil_wants_dy_planes = True         # the LayerNorm backward behind this layer may hand dy over as operand planes only
+    LinearActFn.last_wants_dy_planes = False
     return out
 
 
@@ -1154,7 +1182,7 @@ class LNReLUMean16Fn(torch.autograd.Function):
     (model/backbone_utils.py:161-167)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, eps, ycol=None):
+    def forward(ctx, y, gamma, beta, eps, ycol=None, dy_planes=False):
         _chk(y, "y")
         y = y.contiguous()
         N, d = y.shape
@@ -1163,23 +1191,39 @@ class LNReLUMean16Fn(torch.autograd.Function):
         gg, gb = _arena_grad(gamma), _arena_grad(beta)
         ctx.arena = (gg, gb) if (gg is not None and gb is not None) else None
         ctx.ycol = ycol
+        ctx.dy_planes = bool(dy_planes)
         return emb
 
     @staticmethod
     def backward(ctx, demb):
         y, gamma, beta, mean, rstd = ctx.saved_tensors
         N, d = y.shape
+        # the FC that produced y takes dy as the A operand of its weight gradient dy^T X and nothing else reads dy (its bias gradient is
+        # `ycol`): dy is then written as operand planes ONLY and handed over through DY_PLANES, keyed by the token tensor's address
+        pl = Planes.alloc((N, d), y.device) if ctx.dy_planes else None
         if ctx.arena is not None:
-            dy, _, _ = ln_relu_mean16_bwd(demb.contiguous(), y, gamma, beta, mean, rstd, N, d, ctx.arena[0], ctx.arena[1], ctx.ycol)
-            return dy, None, None, None, None
-        dy, dg, db = ln_relu_mean16_bwd(demb.contiguous(), y, gamma, beta, mean, rstd, N, d, ycol_out=ctx.ycol)
-        return dy, dg, db, None, None
+            dy, dg, db = ln_relu_mean16_bwd(demb.contiguous(), y, gamma, beta, mean, rstd, N, d, ctx.arena[0], ctx.arena[1], ctx.ycol, planes=pl)
+            dg = db = None
+        else:
+            dy, dg, db = ln_relu_mean16_bwd(demb.contiguous(), y, gamma, beta, mean, rstd, N, d, ycol_out=ctx.ycol, planes=pl)
+        if pl is not None:
+            DY_PLANES[dy.data_ptr()] = (pl, (N, d))
+        return dy, dg, db, None, None, None
+
+
+# operand planes of a gradient that was written as planes only: {address of the (unwritten) fp32 token: (Planes, shape)}. The consumer
+# (LinearActFn.backward of the FC that produced the normalised tensor) pops its entry; a token nobody claims is a bug and raises there.
+DY_PLANES = {}
+LN_DY_PLANES = os.environ.get("ADVMIL_LN_DY_PLANES", "1") != "0"
 
 
 def ln_relu_mean16(y, gamma, beta, eps=1e-5, ycol_grad=None):
     """`ycol_grad`: optional [d] gradient accumulator (an arena slot) that receives += column sums of dy in the backward -- the bias
-    gradient of the FC that produced y, for callers that hand that FC a detached bias."""
-    return LNReLUMean16Fn.apply(y, gamma, beta, eps, ycol_grad)
+    gradient of the FC that produced y, for callers that hand that FC a detached bias. When that FC marked its output
+    (`_advmil_wants_dy_planes`, set by linear_act: slab-sized layer, no input gradient, no bias of its own, planes of X resident), dy is
+    produced as operand planes only."""
+    want = bool(LN_DY_PLANES and ycol_grad is not None and getattr(y, "_advmil_wants_dy_planes", False) and y.is_contiguous())
+    return LNReLUMean16Fn.apply(y, gamma, beta, eps, ycol_grad, want)
 
 
 class GateScoreFn(torch.autograd.Function):

@@ -241,13 +241,15 @@ int advmil_colsum(const float* x, int64_t M, int64_t N, float* out, int accumula
  * y[N,d] (the 1x1-conv / FC output) -> LayerNorm(d, eps) -> ReLU -> mean over each consecutive 16
  * rows -> emb[N/16,d]. Saves mean/rstd per row for the backward. N % 16 == 0 (backbone_utils.py:65).
  * bwd: demb[N/16,d] -> dy[N,d], dgamma[d], dbeta[d]; dycol (optional, [d]) += column sums of dy -- the bias gradient of the FC
- * that produced y, which otherwise costs a second pass over dy. */
+ * that produced y, which otherwise costs a second pass over dy. dy_hi / dy_lo (both or neither): the bf16x3 operand planes of dy for
+ * the weight-gradient contraction dy^T X that consumes it (advmil_epilogue_t.a_hi / a_lo); with them dy may be NULL (planes only). */
 int advmil_ln_relu_mean16_fwd(const float* y, const float* gamma, const float* beta, float eps, int64_t N, int64_t d,
                               float* emb, float* mean, float* rstd, advmil_stream_t stream);
 size_t advmil_ln_relu_mean16_bwd_workspace_bytes(int64_t N, int64_t d);
 int advmil_ln_relu_mean16_bwd(const float* demb, const float* y, const float* gamma, const float* beta,
                               const float* mean, const float* rstd, int64_t N, int64_t d, float* dy, float* dgamma,
-                              float* dbeta, int accumulate, float* dycol, void* ws, size_t ws_bytes, advmil_stream_t stream);
+                              float* dbeta, int accumulate, float* dycol, void* dy_hi, void* dy_lo, void* ws, size_t ws_bytes,
+                              advmil_stream_t stream);
 
 /* Plain row-wise LayerNorm(d) -> ReLU (the norm='layer' MLP inside GENConv; N arbitrary). Same kernels as above. */
 int advmil_ln_relu_fwd(const float* y, const float* gamma, const float* beta, float eps, int64_t N, int64_t d, float* out,

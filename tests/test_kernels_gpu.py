@@ -321,6 +321,64 @@ def test_weight_gradient_from_planes_only_activation_backward(ops, tile, N, K, R
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("d,N,C", [(128, 8192, 1024), (384, 4096 + 256, 1024)])
+def test_layernorm_backward_hands_dy_over_as_operand_planes(ops, d, N, C):
+    """Region embedding FC -> LayerNorm -> ReLU -> mean16 (AVGPoolPatchEmbedding, reference model/backbone_utils.py:158-168): in bf16x3 mode
+    the LayerNorm backward writes dy as hi / lo operand planes ONLY and the FC's weight gradient dy^T X takes both operands pre-split
+    (ops.DY_PLANES). (1) the kernel's planes equal the split of its own fp32 dy bit for bit, gamma / beta / column-sum gradients unchanged;
+    (2) the layer's weight gradient with the hand-over equals the one without it (same contraction kernel, same products: equal),
+    and the token entry is consumed."""
+    prev = ops.get_gemm_mode()
+    ops.set_gemm_mode("bf16x3")
+    try:
+        g = torch.Generator(device="cuda").manual_seed(23)
+        y = torch.randn(N, d, device="cuda", generator=g)
+        gamma = 1.0 + 0.1 * torch.randn(d, device="cuda", generator=g)
+        beta = 0.1 * torch.randn(d, device="cuda", generator=g)
+        demb = torch.randn(N // 16, d, device="cuda", generator=g)
+        emb, mean, rstd = ops.ln_relu_mean16_fwd(y, gamma, beta, N, d, 1e-5)
+        yc0, yc1 = torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
+        dy, dg0, db0 = ops.ln_relu_mean16_bwd(demb, y, gamma, beta, mean, rstd, N, d, ycol_out=yc0)
+        pl = ops.Planes.alloc((N, d), y.device)
+        _, dg1, db1 = ops.ln_relu_mean16_bwd(demb, y, gamma, beta, mean, rstd, N, d, ycol_out=yc1, planes=pl)
+        want = ops.split_planes(dy)
+        assert torch.equal(pl.hi, want.hi) and torch.equal(pl.lo, want.lo)
+        assert torch.equal(dg0, dg1) and torch.equal(db0, db1) and torch.equal(yc0, yc1)
+        # the layer: X is a resident slab (its planes registered), the FC has a constant bias, its weight the only gradient
+        X = torch.randn(N, C, device="cuda", generator=g)
+        X._advmil_planes = ops.split_planes(X)
+        W = (torch.randn(d, C, device="cuda", generator=g) / C ** 0.5).requires_grad_(True)
+        b = torch.zeros(d, device="cuda")
+        gam, bet = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        grads, took, real = [], [], ops.ln_relu_mean16_bwd
+
+        def spy(*a, **k):
+            took.append(k.get("planes") is not None)
+            return real(*a, **k)
+        ops.ln_relu_mean16_bwd = spy
+        for on in (False, True):
+            ops.LN_DY_PLANES = on
+            ops.DY_PLANES.clear()
+            W.grad = None
+            ycol = torch.zeros(d, device="cuda")
+            out = ops.ln_relu_mean16(ops.linear_act(X, W, b, "none"), gam, bet, 1e-5, ycol_grad=ycol)
+            (out * demb).sum().backward()
+            assert not ops.DY_PLANES                                   # handed over and consumed (or never made)
+            grads.append((W.grad.clone(), ycol))
+        ops.ln_relu_mean16_bwd = real
+        assert took == [False, True]                                   # the second pass really went through the planes-only form
+        assert torch.isfinite(grads[1][0]).all()
+        assert torch.equal(grads[0][1], grads[1][1])
+        scale = float(grads[0][0].abs().max())
+        assert float((grads[0][0] - grads[1][0]).abs().max()) <= 2e-6 * scale        # (equal when both take the same tile; else fp32 order)
+    finally:
+        ops.LN_DY_PLANES = True
+        if "real" in locals():
+            ops.ln_relu_mean16_bwd = real
+        ops.set_gemm_mode(prev)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, False), (False, True)])
 @pytest.mark.parametrize("tile", [43, 42, 34, 24])
 def test_gemm_bf16x3_eight_wave_tiles(ops, a_kc, b_kc, tile):
