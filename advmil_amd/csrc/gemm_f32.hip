@@ -1233,8 +1233,10 @@ extern "C" int advmil_gemm_f32_plan_planes(int a_kc, int b_kc, int64_t M, int64_
   int tnp = (N % 192 == 0) ? 3 : 2;
   if (force && (force[0] == '2' || force[0] == '3') && N % (64 * (force[0] - '0')) == 0) tnp = force[0] - '0';
   if (K < 64 || (uint64_t)M * (uint64_t)K * 2 >= (1ull << 32) || (uint64_t)N * (uint64_t)K * 2 >= (1ull << 32)) return ADVMIL_OK;
-  static const int min_tiles = []() { const char* e = getenv("ADVMIL_NT_PLANES_MIN_TILES"); return e ? atoi(e) : 384; }();
-  if ((M / 256) * (N / (64 * tnp)) < min_tiles) return ADVMIL_OK;      // one 8-wave workgroup per CU: fewer than ~1.5 waves of them lose to the small tiles
+  static const int min_tiles = []() { const char* e = getenv("ADVMIL_NT_PLANES_MIN_TILES"); return e ? atoi(e) : 256; }();
+  // one 8-wave workgroup per CU: less than one full wave of tiles loses to the small tiles. (384 -- 1.5 waves -- until round 4; 256
+  // measured +0.9 % on the PatchGCN step, whose 65536 x 128 layers are exactly one wave, and neutral at 1-5 ABMIL bags and ESAT 8k)
+  if ((M / 256) * (N / (64 * tnp)) < min_tiles) return ADVMIL_OK;
   *tile = 80 + tnp;
   return ADVMIL_OK;
 }
