@@ -763,3 +763,42 @@ def test_small_linear_kernels_vs_float64_and_vs_the_contraction_path(M, N, K, ac
         assert bool(((outs[0][0] == 0) == (outs[1][0] == 0)).all()) or act == "relu"      # (relu zeros coincide too, up to round-off at 0)
         for a, c in zip(outs[0], outs[1]):
             assert float((a - c).abs().max()) <= 2e-5 * max(1.0, float(c.abs().max()))
+
+
+@pytest.mark.gpu
+def test_clock_stamps_bracket_a_launch_inside_a_captured_graph(ops):
+    """bench.py's in-step timing (ops.Stamps / advmil_stamp_clock): one-thread kernels that write the device wall clock are ordinary graph
+    nodes; a pair around a contraction inside a captured graph reads back a duration in the range HIP events give for the same launch
+    back to back, on every replay."""
+    M, N, K = 8192, 384, 1024
+    g = torch.Generator(device="cuda").manual_seed(3)
+    A = torch.randn(M, K, device="cuda", generator=g)
+    B = torch.randn(N, K, device="cuda", generator=g)
+    out = torch.empty(M, N, device="cuda")
+    for _ in range(3):
+        ops.gemm(A, B, True, True, M, N, K, out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        ops.gemm(A, B, True, True, M, N, K, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ref_us = e0.elapsed_time(e1) * 100.0
+    st = ops.Stamps(A.device, cap=16)
+    assert st.khz > 0
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            st.mark(("b", "gemm", (M, N, K, 1), 2.0 * M * N * K))
+            ops.gemm(A, B, True, True, M, N, K, out=out)
+            st.mark(("e", "gemm", (M, N, K, 1), 2.0 * M * N * K))
+    seen = []
+    for _ in range(4):
+        graph.replay()
+        torch.cuda.synchronize()
+        (name, shape, flops, us), = st.durations_us()
+        assert name == "gemm" and shape == (M, N, K, 1)
+        seen.append(us)
+    assert all(0.5 * ref_us < u < 3.0 * ref_us + 20.0 for u in seen), (seen, ref_us)
