@@ -445,10 +445,12 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
               make_float4(res[q][0], res[q][1], res[q][2], res[q][3]);
         continue;
       }
+      if (out) {         // (NULL: the caller wants the operand planes of the result only -- advmil_gemm_f32_tiled with C == NULL and c_hi set)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int64_t off = (rbase + a * 32 + q * 8 + rq) * ldo + col;
-        *reinterpret_cast<float4*>(out + off) = make_float4(res[q][0], res[q][1], res[q][2], res[q][3]);
+        for (int q = 0; q < 4; ++q) {
+          const int64_t off = (rbase + a * 32 + q * 8 + rq) * ldo + col;
+          *reinterpret_cast<float4*>(out + off) = make_float4(res[q][0], res[q][1], res[q][2], res[q][3]);
+        }
       }
       if (e.c_hi) {      // planes of the final values (off % 4 == 0 here: two 8-byte stores per float4)
 #pragma unroll
@@ -587,7 +589,9 @@ __device__ __forceinline__ int gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[TM
                 v[t] = x;
               }
           }
-          if (nvalid == 4 && vec_ok) {
+          if (!out) {
+            // planes only (direct launches with c_hi: checked by the host side)
+          } else if (nvalid == 4 && vec_ok) {
             *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
           } else {
 #pragma unroll
@@ -1322,7 +1326,10 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
                                      const float* B, int64_t ldb, float* C, int64_t ldc, const advmil_epilogue_t* epi,
                                      int splits, int tile, void* ws, size_t ws_bytes, advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!A || !B || !epi || (!C && !epi->gate_wc) || M <= 0 || N <= 0 || K <= 0) return ADVMIL_EINVAL;
+  if (!A || !B || !epi || (!C && !epi->gate_wc && !epi->c_hi) || M <= 0 || N <= 0 || K <= 0) return ADVMIL_EINVAL;
+  // C == NULL with c_hi / c_lo set: the operand planes of the result ONLY (a result that is consumed as a bf16x3 operand and nowhere else:
+  // the ESAT in-projection feeding the attention kernels); one pass, nothing to accumulate into
+  if (!C && !epi->gate_wc && (epi->accumulate || splits != 1 || epi->c2)) return ADVMIL_EINVAL;
   if ((lda & 3) || (ldb & 3)) return ADVMIL_EINVAL;
   if (lda < (a_kc ? K : M) || ldb < (b_kc ? K : N)) return ADVMIL_EINVAL;          // a row pitch shorter than the row it strides
   if (C && ldc < (epi->c2 ? (int64_t)epi->n_split : N)) return ADVMIL_EINVAL;      // (two-layer form: C holds the first n_split columns)

@@ -31,7 +31,8 @@ class HipTransformerEncoderLayer(nn.Module):
         rng = getattr(self, "rng", None) or ops.default_rng(x2.device)
         tr = self.training
         sa = self.self_attn
-        qkv = ops.linear_act(x2, sa.in_proj_weight, sa.in_proj_bias, "none")           # [L_total, 3d]
+        # [L_total, 3d]; consumed by the attention kernels alone, which read operand planes: the in-projection writes planes ONLY (bf16x3 mode)
+        qkv = ops.linear_act(x2, sa.in_proj_weight, sa.in_proj_bias, "none", emit_planes="only")
         # attention core: one fused launch for all (ragged) bags of the slab; `rng_rowoff` (set by the handler under
         # bag-parallel) addresses the dropout row ids of the single-process run
         o = ops.mha(qkv, self.nhead, sa.dropout if tr else 0.0, rng, seg=seg, rowoff=getattr(seg, "rng_rowoff", None))

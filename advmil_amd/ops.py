@@ -401,7 +401,7 @@ def pre_a_tile_ok(tile, a_kc, b_kc, b_planes=False):
 
 def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=None, act_split=None, drop_p=0.0,
          seed=None, stream_id=0, rowv=None, colv=None, rowseg=None, maskref=None, mask_scale=1.0, accumulate=False,
-         alpha=1.0, splits=None, tile=0, a_planes=None, b_planes=None, c_planes=None, gate_wc=None, rng_row=None):
+         alpha=1.0, splits=None, tile=0, a_planes=None, b_planes=None, c_planes=None, c_planes_only=False, gate_wc=None, rng_row=None):
     """C[M,N] = epilogue(alpha * op(A) op(B)); see include/advmil_hip.h::advmil_gemm_f32. a_planes / b_planes: optional
     Planes of A / B; c_planes: Planes to receive the split of the final C (pitch ldc)."""
     planes_only_a = A is None
@@ -448,6 +448,10 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
         npart = _lib.lib().advmil_gemm_f32_gate_blocks(tile, N)
         gate_out = torch.empty(M, npart, dtype=torch.float32, device=A.device)
         splits, out, ldc = 1, None, N
+    elif c_planes_only:                       # the result is consumed as a bf16x3 operand only: its planes are written, no fp32 C at all
+        if c_planes is None or out is not None or accumulate:
+            raise ValueError("gemm(c_planes_only=True) needs c_planes, no `out`, no accumulate")
+        splits, ldc = 1, N
     elif out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=A.device)
         ldc = N
@@ -527,6 +531,8 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
     return gate_out if gate_wc is not None else out
 
 
+# the ESAT in-projection writes q | k | v as operand planes only (no fp32 qkv, no split pass in front of the attention kernels)
+ATTN_QKV_PLANES = os.environ.get("ADVMIL_ATTN_QKV_PLANES", "1") != "0"
 TWO_LAYERS_MIN_TILES = int(os.environ.get("ADVMIL_TWO_LAYERS_MIN_TILES", "256"))
 
 
@@ -842,8 +848,15 @@ class LinearActFn(torch.autograd.Function):
         elif y0 is None:
             if emit and get_gemm_mode() == "bf16x3":
                 cpl = Planes.alloc((M, N), x.device)
-            y = gemm(x, W2, True, True, M, N, K, bias=b, act0=act, drop_p=p, seed=seed, stream_id=sid, rng_row=rr,
-                     a_planes=xpl, b_planes=wpl, c_planes=cpl, splits=1 if cpl is not None else None)
+            if emit == "only" and cpl is not None:
+                # the consumer reads y as operand planes and nothing else does (the attention kernels behind the ESAT in-projection): the
+                # epilogue writes the planes INSTEAD of the fp32 values; y is an unwritten token that carries shape and autograd identity
+                gemm(x, W2, True, True, M, N, K, bias=b, act0=act, drop_p=p, seed=seed, stream_id=sid, rng_row=rr,
+                     a_planes=xpl, b_planes=wpl, c_planes=cpl, c_planes_only=True)
+                y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+            else:
+                y = gemm(x, W2, True, True, M, N, K, bias=b, act0=act, drop_p=p, seed=seed, stream_id=sid, rng_row=rr,
+                         a_planes=xpl, b_planes=wpl, c_planes=cpl, splits=1 if cpl is not None else None)
         elif p > 0.0:       # memoized act(x W^T + b) of the eval forward: only this forward's dropout draw is new
             if emit and MEMO_PLANES and get_gemm_mode() == "bf16x3":
                 cpl = Planes.alloc((M, N), x.device)
@@ -1031,6 +1044,8 @@ def linear_act(x, W, b, act="none", p=0.0, rng=None, tag="", emit_planes=False):
         x2 = as_f32(x2)                       # exact-fp32 arithmetic reads fp32 operands: the slab's (exact) fp32 image
     # emit y's planes only when the contraction that reads y (the gate branches: N' = 2N columns over K' = N) will take them
     emit = bool(emit_planes) and big and bool(gemm_plan_planes(x2.shape[0], 2 * W.shape[0], W.shape[0]))
+    if emit_planes == "only":                 # planes INSTEAD of fp32 values (the caller guarantees a planes-only consumer): any slab-sized layer
+        emit = "only" if (big and act == "none" and p <= 0.0 and y0 is None and W.shape[0] % 8 == 0 and ATTN_QKV_PLANES) else False
     y = LinearActFn.apply(x2, W, b, _ACT[act], float(p), seed, sid, y0, rr, xpl, wpl, emit)
     cpl, LinearActFn.last_planes = LinearActFn.last_planes, None
     if pre_planes is not None:
@@ -1040,6 +1055,8 @@ def linear_act(x, W, b, act="none", p=0.0, rng=None, tag="", emit_planes=False):
     out = y if len(lead) == 1 else y.reshape(*lead, y.shape[-1])
     if cpl is not None:
         out._advmil_planes = cpl
+        if emit == "only":
+            out._advmil_planes_only = True    # the fp32 values of `out` were never written
     if LinearActFn.last_wants_dy_planes:
         out._advmil_wants_dy_planes = True         # the LayerNorm backward behind this layer may hand dy over as operand planes only
     LinearActFn.last_wants_dy_planes = False
@@ -1336,7 +1353,10 @@ def mha(qkv, nhead, p=0.0, rng=None, seg=None, rowoff=None):
             warnings.warn(f"attention dropout p = {p} runs at {q}/256 = {q / 256.0:.6f} (byte-hash resolution of csrc/attn.hip)")
         rng = rng or default_rng(qkv.device)
         sid, seed = rng.site("mha_attn", (qkv.shape[0], nhead), p), rng.seed
-    return MhaFn.apply(qkv, nhead, float(p), seed, sid, seg, rowoff, getattr(qkv, "_advmil_planes", None) if qkv.is_contiguous() else None)
+    planes = getattr(qkv, "_advmil_planes", None) if qkv.is_contiguous() else None
+    if getattr(qkv, "_advmil_planes_only", False) and planes is None:
+        raise RuntimeError("advmil_amd: qkv was produced as operand planes only and lost them on the way to ops.mha")
+    return MhaFn.apply(qkv, nhead, float(p), seed, sid, seg, rowoff, planes)
 
 
 class AddDropoutLayerNormFn(torch.autograd.Function):

@@ -76,7 +76,8 @@ typedef struct {
   const void* a_lo;
   const void* b_hi;
   const void* b_lo;
-  void* c_hi; /* also write the planes of the final C values (pitch ldc) for the next contraction */
+  void* c_hi; /* also write the planes of the final C values (pitch ldc) for the next contraction; with C == NULL in advmil_gemm_f32_tiled
+               * (one pass, no accumulate, no second layer) the planes are written INSTEAD of C: a result consumed as an operand only */
   void* c_lo;
   /* Fused gate score (Attn_Net_Gated without its [rows, 2D] activations, model/backbone_utils.py:24-28; used by the no-grad
    * generator pass of the discriminator update, model_handler.py:398-400): B's rows are the two branches INTERLEAVED (row 2j = Wa_j,

@@ -204,3 +204,47 @@ def test_add_dropout_layer_norm_vs_float64(ops, R, d, p):
     assert relerr(y, yr) < 2e-6
     for got, want in ((xa.grad, xr.grad), (oa.grad, orr.grad), (ga.grad, gr.grad), (ba.grad, br.grad)):
         assert relerr(got, want) < 1e-5, relerr(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("training", [False, True])
+def test_in_projection_writes_qkv_as_operand_planes_only(ops, training):
+    """The ESAT layer's in-projection feeds the attention kernels and nothing else, and they read q | k | v as bf16x3 operand planes: in
+    bf16x3 mode the contraction's epilogue writes the planes INSTEAD of the fp32 values (advmil_gemm_f32_tiled with C == NULL) and the
+    split pass in front of the attention launch is gone. The planes are the split of the very values the fp32 form would have stored, so
+    the layer's output and every gradient are EQUAL with the switch on and off (shipped dropout on in the training case: same draws)."""
+    from advmil_amd.model.esat import HipTransformerEncoderLayer
+    prev = ops.get_gemm_mode()
+    ops.set_gemm_mode("bf16x3")
+    try:
+        torch.manual_seed(5)
+        layer = HipTransformerEncoderLayer(384, 8, 384, 0.25).cuda()
+        layer.train(training)
+        g = torch.Generator(device="cuda").manual_seed(9)
+        lens = [2048, 1536, 512, 1040]                    # 5136 rows: slab-sized (>= 4096), ragged
+        x = torch.randn(sum(lens), 384, device="cuda", generator=g)
+        go = torch.randn(sum(lens), 384, device="cuda", generator=g)
+        seg = ops.Segments(lens, x.device)
+        outs = []
+        for on in (False, True):
+            ops.ATTN_QKV_PLANES = on
+            layer.rng = ops.DeviceRng(x.device, seed=77)
+            for p_ in layer.parameters():
+                p_.grad = None
+            xi = x.clone().requires_grad_(True)
+            seen = []
+            real = ops.split_planes
+            ops.split_planes = lambda t, *a, **k: (seen.append(tuple(t.shape)), real(t, *a, **k))[1]
+            try:
+                y = layer.forward_rows(xi, seg)
+                (y * go).sum().backward()
+            finally:
+                ops.split_planes = real
+            assert ((sum(lens), 1152) in seen) == (not on)          # the split pass of qkv runs only with the switch off
+            outs.append((y.detach().clone(), xi.grad.clone(), [p_.grad.clone() for p_ in layer.parameters()]))
+        (y0, gx0, gp0), (y1, gx1, gp1) = outs
+        assert torch.isfinite(y1).all() and torch.equal(y0, y1) and torch.equal(gx0, gx1)
+        assert all(torch.equal(a, b) for a, b in zip(gp0, gp1))
+    finally:
+        ops.ATTN_QKV_PLANES = True
+        ops.set_gemm_mode(prev)
