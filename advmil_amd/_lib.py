@@ -96,6 +96,7 @@ SIGNATURES = {
     "advmil_uniform_fill": (c_int, [c_void_p, c_int64, c_void_p, c_uint64, c_void_p, c_int64, c_void_p]),
     "advmil_dropout_apply": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_uint64, c_void_p, c_int64, c_void_p]),
     "advmil_seed_advance": (c_int, [c_void_p, c_uint64, c_void_p]),
+    "advmil_seg_scale_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "advmil_stamp_clock": (c_int, [c_void_p, c_void_p]),
     "advmil_clock_rate_khz": (c_int64, []),
     "advmil_small_linear_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_uint64,

@@ -557,6 +557,29 @@ extern "C" int advmil_softmax_pool_bwd(const float* dpooled, const float* dA, co
   return ADVMIL_OK;
 }
 
+// backward of the per-segment row mean / of any pooled = sum_n A[n] h[n] with constant A:  dh[n, :] = A[n] * dpooled[seg(n), :]
+// (the region-level inner product of the projection discriminator, GANSurv.py:96-98: mean_r fc_ins_r; was index_select + mul)
+__global__ __launch_bounds__(256) void seg_scale_rows_kernel(const float* __restrict__ dpooled, const float* __restrict__ A,
+                                                             const int32_t* __restrict__ rowseg, int64_t N, int64_t D,
+                                                             float* __restrict__ dh) {
+  const int64_t q4 = D >> 2, total = N * q4;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t n = e / q4, c = (e % q4) * 4;
+    const float a = A[n];
+    const float4 v = *reinterpret_cast<const float4*>(dpooled + (int64_t)(rowseg ? rowseg[n] : 0) * D + c);
+    *reinterpret_cast<float4*>(dh + n * D + c) = make_float4(a * v.x, a * v.y, a * v.z, a * v.w);
+  }
+}
+extern "C" int advmil_seg_scale_rows(const float* dpooled, const float* A, const int32_t* rowseg, int64_t N, int64_t D, float* dh,
+                                     advmil_stream_t stream_) {
+  if (!dpooled || !A || !dh || N <= 0 || D <= 0 || (D & 3) || (((uintptr_t)dpooled | (uintptr_t)dh) & 15)) return ADVMIL_EINVAL;
+  int64_t blocks = (N * (D >> 2) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(seg_scale_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, dpooled, A, rowseg, N, D, dh);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}
+
 // =====================================================================================
 // Glue of the fused gate score (the contraction that reduces sum_j wc_j tanh(a_j) sigmoid(b_j) in its epilogue):
 //   gate_interleave: rows a0, b0, a1, b1, ... of the two branch weights as one [2D, D] matrix (fp32 + its bf16x3 planes) and the

@@ -1449,8 +1449,12 @@ class SegRowMeanFn(torch.autograd.Function):
     def backward(ctx, dout):
         (A,) = ctx.saved_tensors
         seg = ctx.seg
-        idx = seg.rowseg_long
-        return dout.contiguous().index_select(0, idx) * A.unsqueeze(1), None
+        dout = dout.contiguous()
+        N, D = A.shape[0], dout.shape[1]
+        dh = torch.empty(N, D, dtype=torch.float32, device=A.device)
+        _lib.check(_lib.lib().advmil_seg_scale_rows(_p(dout), _p(A), _p(None if seg is None else seg.rowseg), N, D, _p(dh), _stream()),
+                   "seg_scale_rows")
+        return dh, None
 
 
 def segmented_mean_rows(h, seg):

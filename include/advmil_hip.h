@@ -219,6 +219,10 @@ int advmil_softmax_pool_fwd(const float* s, const float* h, int64_t ldh, int64_t
 int advmil_softmax_pool_bwd(const float* dpooled, const float* dA, const float* A, const float* h, int64_t ldh,
                             int64_t N, int64_t D, int nseg, const int64_t* seg_ptr, int64_t max_len, float* ds, void* ws,
                             size_t ws_bytes, advmil_stream_t stream);
+/* dh[n, :] = A[n] * dpooled[rowseg[n], :] -- the backward of a pooling with constant weights (the per-bag mean of the region features in
+ * the projection discriminator's region-level inner product, GANSurv.py:96-98). rowseg: int32 bag index per row, NULL = one bag. */
+int advmil_seg_scale_rows(const float* dpooled, const float* A, const int32_t* rowseg, int64_t N, int64_t D, float* dh,
+                          advmil_stream_t stream);
 size_t advmil_gate_bwd_workspace_bytes(int64_t N, int64_t D);
 int advmil_gate_bwd(const float* ab, const float* ds, const float* wc, float drop_p, const uint64_t* seed,
                     uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D, float* dG, float* dwc, float* dbc,

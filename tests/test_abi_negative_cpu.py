@@ -105,6 +105,7 @@ def test_optimizer_graph_and_evaluator_groups(L):
     assert lib.advmil_gan_d_loss(p(0), 4, None, None, 0, 9, 0.25, 0.0, p(1), p(2), None, None) == EINVAL                 # unknown loss kind
     assert lib.advmil_skinny_linear_fwd(p(0), p(1), None, 4, 64, 128, 0, p(2), None) == EINVAL                           # neither width is 1
     assert lib.advmil_stamp_clock(None, None) == EINVAL
+    assert lib.advmil_seg_scale_rows(p(0), p(1), None, 64, 126, p(2), None) == EINVAL                                    # D not a multiple of 4
     assert lib.advmil_genconv_bwd(p(0), p(1), p(2), p(3), p(4), p(5), p(6), 1e-7, 100, 128, p(7), p(8), p(9), 0, None) == EINVAL      # workspace too small
     assert lib.advmil_genconv_fwd(p(0), p(1), p(2), p(3), 1e-7, 100, 128, p(4), p(5), None, None) == EINVAL                  # lse without agg
     assert lib.advmil_ln_relu_mean16_bwd(p(0), p(1), p(2), p(3), p(4), p(5), 64, 128, None, p(6), p(7), 0, None, None, None, p(8), 1 << 20, None) == EINVAL   # neither dy nor its planes

@@ -802,3 +802,23 @@ def test_clock_stamps_bracket_a_launch_inside_a_captured_graph(ops):
         assert name == "gemm" and shape == (M, N, K, 1)
         seen.append(us)
     assert all(0.5 * ref_us < u < 3.0 * ref_us + 20.0 for u in seen), (seen, ref_us)
+
+
+@pytest.mark.gpu
+def test_segmented_row_mean_backward_is_one_launch_and_exact(ops):
+    """ops.segmented_mean_rows (the per-bag mean of the region features, projection discriminator RLIP): forward against torch, backward
+    dh[n] = dpooled[seg(n)] / len(seg) through advmil_seg_scale_rows -- equal to the index_select * weight form it replaces."""
+    lens = [512, 16, 1040, 256]
+    seg = ops.Segments(lens, torch.device("cuda", 0))
+    g = torch.Generator(device="cuda").manual_seed(2)
+    h = torch.randn(sum(lens), 128, device="cuda", generator=g, requires_grad=True)
+    go = torch.randn(len(lens), 128, device="cuda", generator=g)
+    out = ops.segmented_mean_rows(h, seg)
+    out.backward(go)
+    want, wantg, r0 = [], torch.empty_like(h), 0
+    for i, n in enumerate(lens):
+        want.append(h.detach()[r0:r0 + n].double().mean(0))
+        wantg[r0:r0 + n] = go[i] * (1.0 / n)
+        r0 += n
+    assert float((out.detach().double() - torch.stack(want)).abs().max()) < 2e-6
+    assert float((h.grad - wantg).abs().max()) <= 1e-7 * float(wantg.abs().max()) + 1e-12
