@@ -30,6 +30,23 @@ class Epilogue(ctypes.Structure):
                 ("rng_row", c_void_p), ("c2", c_void_p), ("ldc2", c_int64), ("n_split", c_int64), ("bias2", c_void_p)]
 
 
+class DenseLayer(ctypes.Structure):
+    """advmil_dense_layer_t"""
+    _fields_ = [("W", c_void_p), ("bias", c_void_p), ("dW", c_void_p), ("dbias", c_void_p), ("y", c_void_p), ("K", c_int), ("N", c_int),
+                ("act", c_int), ("drop_p", c_float), ("stream_id", c_uint64)]
+
+
+TAIL_MAXL = 3
+
+
+class DTail(ctypes.Structure):
+    """advmil_dtail_t"""
+    _fields_ = [("B", c_int), ("nx", c_int), ("ny", c_int), ("prj_src", c_int), ("xin", c_void_p), ("tin", c_void_p),
+                ("x", DenseLayer * TAIL_MAXL), ("y", DenseLayer * TAIL_MAXL), ("u", c_void_p), ("w_prj", c_void_p), ("b_prj", c_void_p),
+                ("dw_prj", c_void_p), ("db_prj", c_void_p), ("seed", c_void_p), ("rng_row", c_void_p), ("out", c_void_p),
+                ("dout", c_void_p), ("dxin", c_void_p), ("dtin", c_void_p), ("du", c_void_p)]
+
+
 # name -> (restype, argtypes); must list every symbol include/advmil_hip.h declares
 SIGNATURES = {
     "advmil_version": (c_int, []),
@@ -65,6 +82,9 @@ SIGNATURES = {
     "advmil_softmax_pool_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "advmil_softmax_pool_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p,
                                         c_void_p, c_void_p, c_size_t, c_void_p]),
+    "advmil_softmax_pool_mean_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
+    "advmil_softmax_pool_mean_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p,
+                                             c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "advmil_softmax_pool_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p,
                                         c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "advmil_gate_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64]),
@@ -113,6 +133,20 @@ SIGNATURES = {
     "advmil_gan_d_loss": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "advmil_gan_g_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_int, c_float, c_float,
                                   c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "advmil_dx_chain_fwd": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_uint64, c_uint64, c_uint64, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p]),
+    "advmil_dx_chain_bwd_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "advmil_dx_chain_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "advmil_dx_chain_bwd": (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_float, c_float, c_void_p, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_size_t, c_void_p]),
+    "advmil_dtail_fwd": (c_int, [ctypes.POINTER(DTail), c_void_p]),
+    "advmil_dtail_bwd": (c_int, [ctypes.POINTER(DTail), c_void_p]),
+    "advmil_defer_sums": (c_int, [c_void_p, c_int]),
+    "advmil_flush_sums": (c_int, [c_void_p]),
+    "advmil_pending_sums": (c_int, [c_void_p]),
     "advmil_cindex_counts": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p]),
 }
 

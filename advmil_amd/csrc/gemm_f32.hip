@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include "common.h"
 #include "bf16split.h"
+#include "sumq.h"
 #include "../../include/advmil_hip.h"
 
 #define BK 32          // k per chunk of the exact-fp32 variant (and the granularity of split-K chunking)
@@ -1136,6 +1137,23 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g) {
   }
 }
 
+// The reduce of a split-K launch. A weight gradient accumulated into the optimizer's arena has the trivial epilogue (C += sum of the
+// partial tiles, C dense): that sum goes through the merge queue (sumq.hip), i.e. while the stream is in deferral it shares ONE launch
+// with the backward's other partial sums.
+static int launch_splitk_reduce(const GemmArgs& g, hipStream_t stream) {
+  const advmil_epilogue_t& e = g.epi;
+  const bool plain = e.accumulate && e.alpha == 1.0f && !e.bias && !e.rowv && !e.maskref && e.act0 == 0 && e.act1 == 0 &&
+                     !(e.seed && e.drop_p > 0.0f) && !e.c_hi && !e.gate_wc && g.ldc == g.N && (g.N & 3) == 0 &&
+                     (((uintptr_t)g.C) & 15) == 0 && g.splits <= 64;
+  if (plain) return advmil_sumq(stream, g.ws, g.splits, g.M * g.N, g.M * g.N, g.C, 1);
+  const int64_t total = g.M * (g.N / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, g);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}
+
 extern "C" size_t advmil_gemm_f32_workspace_bytes(int64_t M, int64_t N, int splits) {
   return splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
@@ -1439,11 +1457,8 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
     }
     ADVMIL_LAUNCH_CHECK();
     if (splits > 1) {
-      const int64_t total = M * (N / 4);
-      int blocks = (int)((total + 255) / 256);
-      if (blocks > 2048) blocks = 2048;
-      hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, g);
-      ADVMIL_LAUNCH_CHECK();
+      const int rc = launch_splitk_reduce(g, stream);
+      if (rc) return rc;
     }
     return ADVMIL_OK;
   }
@@ -1476,11 +1491,8 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
   }
   ADVMIL_LAUNCH_CHECK();
   if (splits > 1) {
-    const int64_t total = M * (N / 4);
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, g);
-    ADVMIL_LAUNCH_CHECK();
+    const int rc = launch_splitk_reduce(g, stream);
+    if (rc) return rc;
   }
   return ADVMIL_OK;
 }

@@ -5,6 +5,7 @@
 // partials in a caller workspace, then a merge launch) -- no float atomics.
 #include "common.h"
 #include "bf16split.h"
+#include "sumq.h"
 #include "../../include/advmil_hip.h"
 
 #define ROWS_PER_BLOCK 32
@@ -290,9 +291,13 @@ __global__ __launch_bounds__(256) void pool_partial8_kernel(const float* __restr
 // partial_j = sum w_n h_n with (m_j, l_j). Launch 2, per segment and 16-column block: M = max m_j, c_j = exp(m_j - M), L = sum l_j c_j
 // (fixed order: deterministic, and identical in every workgroup of the segment), pooled = sum_j c_j partial_j / L, and the workgroups of
 // a segment share out its rows to write A_n = exp(s_n - M) / L. Same contract as softmax_stats + pool_partial8 + colsum_merge.
+// MEAN: a second partial row per workgroup, the UNWEIGHTED sum of its rows (the per-bag mean of h from the same pass over h: the
+// projection discriminator's region-level inner product, GANSurv.py:96-98, needs mean_r(fc_ins) beside the pooled fc_ins)
+template <bool MEAN>
 __global__ __launch_bounds__(256) void pool_partial8_online_kernel(const float* __restrict__ s, const float* __restrict__ h, int64_t ldh,
                                                                    int64_t N, int64_t D, const int64_t* __restrict__ seg_ptr,
-                                                                   float* __restrict__ partial, float* __restrict__ pstats, int rpb) {
+                                                                   float* __restrict__ partial, float* __restrict__ pstats, int rpb,
+                                                                   float* __restrict__ mpartial) {
   __shared__ __attribute__((aligned(16))) float red[2048];      // rpp * D <= 256 / (D/8) * D = 2048 floats
   __shared__ float wts[512];                                    // rows_per_block <= 512
   __shared__ float wred[8];
@@ -305,8 +310,12 @@ __global__ __launch_bounds__(256) void pool_partial8_online_kernel(const float* 
   const int64_t r0 = beg + (int64_t)blockIdx.x * rpb;
   float* pst = pstats + ((int64_t)b * gridDim.x + blockIdx.x) * 2;
   float* prow = partial + ((int64_t)b * gridDim.x + blockIdx.x) * D;
+  float* mrow = MEAN ? mpartial + ((int64_t)b * gridDim.x + blockIdx.x) * D : nullptr;
   if (r0 >= end) {                                              // past the segment's end: an empty block (weight 0 in the merge)
-    if (tid < (int)(D >> 2)) *reinterpret_cast<float4*>(prow + tid * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < (int)(D >> 2)) {
+      *reinterpret_cast<float4*>(prow + tid * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (MEAN) *reinterpret_cast<float4*>(mrow + tid * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (tid == 0) { pst[0] = -INFINITY; pst[1] = 0.f; }
     return;
   }
@@ -331,9 +340,9 @@ __global__ __launch_bounds__(256) void pool_partial8_online_kernel(const float* 
   if (lane == 0) wred[4 + w] = ls;
   __syncthreads();
   if (tid == 0) { pst[0] = mx; pst[1] = (wred[4] + wred[5]) + (wred[6] + wred[7]); }
-  float acc[8];
+  float acc[8], macc[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int j = 0; j < 8; ++j) { acc[j] = 0.f; macc[j] = 0.f; }
   if (rl < rpp) {
 #pragma unroll 4
     for (int r = rl; r < rpb; r += rpp) {
@@ -344,6 +353,11 @@ __global__ __launch_bounds__(256) void pool_partial8_online_kernel(const float* 
       const float4 v1 = *reinterpret_cast<const float4*>(h + nn * ldh + c8 * 8 + 4);
       acc[0] += wgt * v0.x; acc[1] += wgt * v0.y; acc[2] += wgt * v0.z; acc[3] += wgt * v0.w;
       acc[4] += wgt * v1.x; acc[5] += wgt * v1.y; acc[6] += wgt * v1.z; acc[7] += wgt * v1.w;
+      if (MEAN) {
+        const float one = n < end ? 1.f : 0.f;
+        macc[0] += one * v0.x; macc[1] += one * v0.y; macc[2] += one * v0.z; macc[3] += one * v0.w;
+        macc[4] += one * v1.x; macc[5] += one * v1.y; macc[6] += one * v1.z; macc[7] += one * v1.w;
+      }
     }
     float* dst = red + (int64_t)rl * D + c8 * 8;
     *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -358,13 +372,31 @@ __global__ __launch_bounds__(256) void pool_partial8_online_kernel(const float* 
     }
     *reinterpret_cast<float4*>(prow + tid * 4) = t;
   }
+  if (MEAN) {
+    __syncthreads();
+    if (rl < rpp) {
+      float* dst = red + (int64_t)rl * D + c8 * 8;
+      *reinterpret_cast<float4*>(dst) = make_float4(macc[0], macc[1], macc[2], macc[3]);
+      *reinterpret_cast<float4*>(dst + 4) = make_float4(macc[4], macc[5], macc[6], macc[7]);
+    }
+    __syncthreads();
+    if (tid < (int)(D >> 2)) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int q = 0; q < rpp; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(red + (int64_t)q * D + tid * 4);
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+      }
+      *reinterpret_cast<float4*>(mrow + tid * 4) = t;
+    }
+  }
 }
 
 #define POOL_ONLINE_MAX_NBLK 2048
 __global__ __launch_bounds__(256) void pool_merge_online_kernel(const float* __restrict__ partial, const float* __restrict__ pstats, int nblk,
                                                                 int64_t D, const float* __restrict__ s, int64_t N,
                                                                 const int64_t* __restrict__ seg_ptr, float* __restrict__ pooled,
-                                                                float* __restrict__ A, float* __restrict__ stats) {
+                                                                float* __restrict__ A, float* __restrict__ stats,
+                                                                const float* __restrict__ mpartial = nullptr, float* __restrict__ mean = nullptr) {
   __shared__ float sc[POOL_ONLINE_MAX_NBLK];
   __shared__ float red[16][17];
   __shared__ float wred[8];
@@ -410,9 +442,30 @@ __global__ __launch_bounds__(256) void pool_merge_online_kernel(const float* __r
     for (int r = 0; r < 16; ++r) t += red[r][cl];
     pooled[(int64_t)b * D + c] = t * inv;
   }
-  // A: the workgroups of the segment share out its rows
   int64_t beg, end;
   seg_range(seg_ptr, b, N, beg, end);
+  if (mean) {        // the unweighted partial rows: mean = their sum / the segment's length (same column map, same fixed order)
+    __syncthreads();
+    const float* mp = mpartial + (int64_t)b * nblk * D;
+    float mv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < D) {
+      int j = rl;
+      for (; j + 48 < nblk; j += 64) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mv[u] += mp[(int64_t)(j + 16 * u) * D + c];
+      }
+      for (; j < nblk; j += 16) mv[0] += mp[(int64_t)j * D + c];
+    }
+    red[rl][cl] = (mv[0] + mv[1]) + (mv[2] + mv[3]);
+    __syncthreads();
+    if (rl == 0 && c < D) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += red[r][cl];
+      mean[(int64_t)b * D + c] = end > beg ? t / (float)(end - beg) : 0.f;
+    }
+  }
+  // A: the workgroups of the segment share out its rows
   for (int64_t n = beg + (int64_t)blockIdx.x * 256 + tid; n < end; n += (int64_t)gridDim.x * 256) A[n] = hw_exp(s[n] - M) * inv;
 }
 
@@ -425,29 +478,65 @@ extern "C" size_t advmil_softmax_pool_workspace_bytes(int64_t max_len, int64_t D
   return (size_t)(a > b ? a : b) * sizeof(float);
 }
 
+static int softmax_pool_fwd_impl(const float* s, const float* h, int64_t ldh, int64_t N, int64_t D, int nseg, const int64_t* seg_ptr,
+                                 int64_t max_len, float* A, float* pooled, float* mean, void* ws, size_t ws_bytes, hipStream_t stream);
+
 extern "C" int advmil_softmax_pool_fwd(const float* s, const float* h, int64_t ldh, int64_t N, int64_t D, int nseg,
                                        const int64_t* seg_ptr, int64_t max_len, float* A, float* pooled, void* ws,
                                        size_t ws_bytes, advmil_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+  return softmax_pool_fwd_impl(s, h, ldh, N, D, nseg, seg_ptr, max_len, A, pooled, nullptr, ws, ws_bytes, (hipStream_t)stream_);
+}
+
+// the unweighted partial rows sit behind the plain call's workspace, on a 16-byte boundary (they are stored as float4)
+static inline size_t pool_mean_offset_bytes(int64_t max_len, int64_t D, int nseg) {
+  return (advmil_softmax_pool_workspace_bytes(max_len, D, nseg) + 15) / 16 * 16;
+}
+
+extern "C" size_t advmil_softmax_pool_mean_workspace_bytes(int64_t max_len, int64_t D, int nseg) {
+  if (nseg < 1) nseg = 1;
+  return pool_mean_offset_bytes(max_len, D, nseg) + (size_t)((int64_t)nseg * pool_nblk(max_len) * D) * sizeof(float);
+}
+
+extern "C" int advmil_softmax_pool_mean_fwd(const float* s, const float* h, int64_t ldh, int64_t N, int64_t D, int nseg,
+                                            const int64_t* seg_ptr, int64_t max_len, float* A, float* pooled, float* mean, void* ws,
+                                            size_t ws_bytes, advmil_stream_t stream_) {
+  if (!mean) return ADVMIL_EINVAL;
+  return softmax_pool_fwd_impl(s, h, ldh, N, D, nseg, seg_ptr, max_len, A, pooled, mean, ws, ws_bytes, (hipStream_t)stream_);
+}
+
+static int softmax_pool_fwd_impl(const float* s, const float* h, int64_t ldh, int64_t N, int64_t D, int nseg, const int64_t* seg_ptr,
+                                 int64_t max_len, float* A, float* pooled, float* mean, void* ws, size_t ws_bytes, hipStream_t stream) {
   if (!s || !h || !A || !pooled || !ws || N <= 0 || D <= 0 || (D & 3) || D > 1024 || (ldh & 3)) return ADVMIL_EINVAL;
   if (ldh < D || ((uintptr_t)h & 15)) return ADVMIL_EINVAL;        // rows are read as 16-byte vectors
   if (!seg_ptr && nseg > 1) return ADVMIL_EINVAL;                   // several bags need their row offsets
   if (!seg_ptr) { nseg = 1; max_len = N; }
   if (nseg < 1 || max_len <= 0 || max_len > N) return ADVMIL_EINVAL;
-  if (ws_bytes < advmil_softmax_pool_workspace_bytes(max_len, D, nseg)) return ADVMIL_EWORKSPACE;
+  if (ws_bytes < (mean ? advmil_softmax_pool_mean_workspace_bytes(max_len, D, nseg) : advmil_softmax_pool_workspace_bytes(max_len, D, nseg)))
+    return ADVMIL_EWORKSPACE;
   float* stats = (float*)ws;
   float* partial = stats + 4 * nseg;
   const int nblk = (int)pool_nblk(max_len);
   if ((D & 7) == 0 && D >= 16 && nblk <= POOL_ONLINE_MAX_NBLK) {     // two launches: online-softmax partials, then merge + A
     float* pstats = partial + (int64_t)nseg * nblk * D;
-    hipLaunchKernelGGL(pool_partial8_online_kernel, dim3(nblk, nseg), dim3(256), 0, stream, s, h, ldh, N, D, seg_ptr, partial, pstats,
-                       rows_per_block(max_len));
+    if (mean) {
+      float* mpartial = (float*)ws + pool_mean_offset_bytes(max_len, D, nseg) / sizeof(float);
+      hipLaunchKernelGGL(pool_partial8_online_kernel<true>, dim3(nblk, nseg), dim3(256), 0, stream, s, h, ldh, N, D, seg_ptr, partial, pstats,
+                         rows_per_block(max_len), mpartial);
+      ADVMIL_LAUNCH_CHECK();
+      hipLaunchKernelGGL(pool_merge_online_kernel, dim3((unsigned)((D + 15) / 16), nseg), dim3(256), 0, stream, partial, pstats, nblk, D, s,
+                         N, seg_ptr, pooled, A, stats, (const float*)mpartial, mean);
+      ADVMIL_LAUNCH_CHECK();
+      return ADVMIL_OK;
+    }
+    hipLaunchKernelGGL(pool_partial8_online_kernel<false>, dim3(nblk, nseg), dim3(256), 0, stream, s, h, ldh, N, D, seg_ptr, partial, pstats,
+                       rows_per_block(max_len), (float*)nullptr);
     ADVMIL_LAUNCH_CHECK();
     hipLaunchKernelGGL(pool_merge_online_kernel, dim3((unsigned)((D + 15) / 16), nseg), dim3(256), 0, stream, partial, pstats, nblk, D, s,
-                       N, seg_ptr, pooled, A, stats);
+                       N, seg_ptr, pooled, A, stats, (const float*)nullptr, (float*)nullptr);
     ADVMIL_LAUNCH_CHECK();
     return ADVMIL_OK;
   }
+  if (mean) return ADVMIL_EINVAL;          // (the mean rides in the two-launch form only: D % 8 == 0)
   hipLaunchKernelGGL(softmax_stats_kernel, dim3(nseg), dim3(1024), 0, stream, s, N, seg_ptr, stats);
   ADVMIL_LAUNCH_CHECK();
   if ((D & 7) == 0 && D >= 16)
@@ -740,9 +829,7 @@ extern "C" int advmil_gate_bwd(const float* ab, const float* ds, const float* wc
                      dG, partial, rpb, rng_row, (bf16raw*)dG_hi, (bf16raw*)dG_lo);
   ADVMIL_LAUNCH_CHECK();
   // dwc | dbias(a) | dbias(b) | dbc are adjacent in the partial rows: one merge launch over the 3D+1 columns, three destinations
-  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(3 * D + 1), dim3(256), 0, stream, partial, nblk, stride, 3 * D + 1, dwc, accumulate,
-                     (int64_t)0, (int64_t)0, dbias, D, dbc, 3 * D);
-  ADVMIL_LAUNCH_CHECK();
+  { const int rc = advmil_sumq(stream, partial, nblk, stride, 3 * D + 1, dwc, accumulate, dbias, D, dbc, 3 * D); if (rc) return rc; }
   return ADVMIL_OK;
 }
 
@@ -826,8 +913,8 @@ extern "C" int advmil_act_dropout_bwd(const float* dy, const float* y, int act, 
   }
   ADVMIL_LAUNCH_CHECK();
   if (dbias && !direct) {
-    hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(N), dim3(256), 0, stream, partial, nblk, N, N, dbias, accumulate);
-    ADVMIL_LAUNCH_CHECK();
+    const int rc = advmil_sumq(stream, partial, nblk, N, N, dbias, accumulate);
+    if (rc) return rc;
   }
   return ADVMIL_OK;
 }
@@ -867,8 +954,8 @@ extern "C" int advmil_colsum(const float* x, int64_t M, int64_t N, float* out, i
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, x, M, N, c0, W, direct ? out : (float*)ws, rpb,
                        direct ? (accumulate ? 2 : 1) : 0);
   }
-  if (!direct) hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(N), dim3(256), 0, stream, (const float*)ws, nblk, N, N, out, accumulate);
   ADVMIL_LAUNCH_CHECK();
+  if (!direct) { const int rc = advmil_sumq(stream, (const float*)ws, nblk, N, N, out, accumulate); if (rc) return rc; }
   return ADVMIL_OK;
 }
 
@@ -1097,12 +1184,16 @@ extern "C" int advmil_ln_relu_mean16_bwd(const float* demb, const float* y, cons
   LN_DISPATCH(d, ln_relu_mean16_bwd_kernel, dim3(L), stream, demb, y, gamma, beta, mean, rstd, N, d, dy, partial, 1, (bf16raw*)dy_hi,
               (bf16raw*)dy_lo);
   ADVMIL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial, L, 3 * d, d, dgamma, accumulate);
-  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial + d, L, 3 * d, d, dbeta, accumulate);
-  if (dycol)      // += column sums of dy (the bias gradient of the FC that produced y), straight into the caller's accumulator
-    hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial + 2 * d, L, 3 * d, d, dycol, 1);
-  ADVMIL_LAUNCH_CHECK();
-  return ADVMIL_OK;
+  // dgamma | dbeta | column sums of dy are adjacent in the partial rows: ONE merge entry with three destinations when all three accumulate
+  // (dycol -- the bias gradient of the FC that produced y -- always does: it is the caller's accumulator)
+  int rc;
+  if (dycol && accumulate) {
+    rc = advmil_sumq(stream, partial, L, 3 * d, 3 * d, dgamma, 1, dbeta, d, dycol, 2 * d);
+  } else {
+    rc = advmil_sumq(stream, partial, L, 3 * d, 2 * d, dgamma, accumulate, dbeta, d);
+    if (!rc && dycol) rc = advmil_sumq(stream, partial + 2 * d, L, 3 * d, d, dycol, 1);
+  }
+  return rc;
 }
 
 extern "C" size_t advmil_ln_relu_bwd_workspace_bytes(int64_t N, int64_t d) {
@@ -1121,10 +1212,7 @@ extern "C" int advmil_ln_relu_bwd(const float* dout, const float* y, const float
   LN_DISPATCH(d, ln_relu_mean16_bwd_kernel, dim3(L), stream, dout, y, gamma, beta, mean, rstd, N, d, dy, partial, 0, (bf16raw*)nullptr,
               (bf16raw*)nullptr);
   ADVMIL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial, L, 3 * d, d, dgamma, accumulate);
-  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial + d, L, 3 * d, d, dbeta, accumulate);
-  ADVMIL_LAUNCH_CHECK();
-  return ADVMIL_OK;
+  return advmil_sumq(stream, partial, L, 3 * d, 2 * d, dgamma, accumulate, dbeta, d);
 }
 
 // =====================================================================================
@@ -1276,8 +1364,5 @@ extern "C" int advmil_add_dropout_ln_bwd(const float* dy, const float* z, const 
   hipLaunchKernelGGL(add_dropout_ln_bwd_kernel, dim3(nb), dim3(256), 0, stream, dy, z, gamma, mean, rstd, R, d, drop_p, seed,
                      stream_id, dx, dob, partial, rng_row);
   ADVMIL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial, nb, 2 * d, d, dgamma, accumulate);
-  hipLaunchKernelGGL(colsum_merge_kernel, MERGE_GRID(d), dim3(256), 0, stream, partial + d, nb, 2 * d, d, dbeta, accumulate);
-  ADVMIL_LAUNCH_CHECK();
-  return ADVMIL_OK;
+  return advmil_sumq(stream, partial, nb, 2 * d, 2 * d, dgamma, accumulate, dbeta, d);
 }

@@ -133,15 +133,18 @@ class PrjDiscriminator(_PairNet):
 
     def bag_features_multi(self, emb, seg16):
         """Slab form of `bag_features`: emb[L_total, C'] + region segments -> (emb_bag[B,C'], mean_r fc_ins[B,C'] | None)."""
-        emb_bag, fc_ins = self.net_pair_one.pool_features_rows(emb, seg16)
         if self.inner_product != "instance":
-            return emb_bag, None
-        return emb_bag, ops.segmented_mean_rows(fc_ins, seg16)
+            return self.net_pair_one.pool_features_rows(emb, seg16)[0], None
+        emb_bag, _, mean = self.net_pair_one.pool_features_rows(emb, seg16, want_mean=True)
+        return emb_bag, mean
 
     def tail(self, emb_bag, ins_mean, t):
         """[B,C'] stacks + t[B,1] -> f[B,1]: fc2, net_pair_two, the (region-level) inner product and the projection,
         once per step batch instead of once per bag."""
         rng = _rng_of(self, t)
+        spec = self._tail_spec(emb_bag, ins_mean, t, rng)
+        if spec is not None:                 # the whole tail as ONE launch each way (csrc/tail.hip)
+            return ops.dtail(emb_bag, ins_mean if self.inner_product == "instance" else None, t, spec)
         hid_x = run_mlp_small(self.net_pair_one.fc2, emb_bag, rng, "dx_fc2")
         hid_t = run_mlp_small(self.net_pair_two, t, rng, "dy")
         if hid_x.shape[0] <= 256 and hid_x.is_cuda and hid_x.dtype == torch.float32:      # [B, d] head: one launch each way
@@ -158,6 +161,58 @@ class PrjDiscriminator(_PairNet):
             out = out + (ops.skinny_linear(src, self.prj_layer.weight, self.prj_layer.bias) if src.shape[0] <= 256
                          else ops.linear_act_any(src.contiguous(), self.prj_layer.weight, self.prj_layer.bias))
         return out
+
+    def _tail_spec(self, emb_bag, ins_mean, t, rng):
+        """ops.TailSpec of this tail when it can run as the fused launch (plain Linear -> ReLU -> Dropout chains, <= 32 rows), else None.
+        The dropout call sites are drawn in the order and under the tags of the layer-by-layer path (dx_fc2.*, dy.*)."""
+        if not (ops.DTAIL and emb_bag.is_cuda and emb_bag.dim() == 2 and emb_bag.shape[0] <= 32 and emb_bag.dtype == torch.float32
+                and t.dim() == 2 and t.dtype == torch.float32):
+            return None
+        if self.inner_product == "instance" and ins_mean is None:
+            return None
+        chains = []
+        for seq, tag, tr in ((self.net_pair_one.fc2, "dx_fc2", self.net_pair_one.fc2.training), (self.net_pair_two, "dy", self.net_pair_two.training)):
+            flat = []                        # (module, tag of a Dropout) with nested Sequentials opened, tags as run_mlp_small forms them
+            def walk(s, tg):
+                for j, m in enumerate(s):
+                    if isinstance(m, nn.Sequential):
+                        walk(m, f"{tg}.{j}")
+                    else:
+                        flat.append((m, f"{tg}.{j}"))
+            walk(seq, tag)
+            layers, j = [], 0
+            while j < len(flat):
+                m = flat[j][0]
+                if not isinstance(m, nn.Linear):
+                    return None
+                act, p, ptag, k = 0, 0.0, None, j + 1
+                if k < len(flat) and isinstance(flat[k][0], nn.ReLU):
+                    act, k = 1, k + 1
+                if k < len(flat) and isinstance(flat[k][0], nn.Dropout):
+                    p, ptag, k = (flat[k][0].p if tr else 0.0), flat[k][1], k + 1
+                layers.append((m, act, float(p), ptag))
+                j = k
+            chains.append(layers)
+        B = emb_bag.shape[0]
+        if chains[0][0][0].in_features != emb_bag.shape[1] or chains[1][0][0].in_features != t.shape[1]:
+            return None
+        prj_src = 0 if self.prj_layer is None else (1 if self.prj_path == "x" else 2)
+        prj_w = None if self.prj_layer is None else self.prj_layer.weight
+        prj_b = None if self.prj_layer is None else self.prj_layer.bias
+        probe = ops.TailSpec(*[[(m.weight, m.bias, act, p, 0) for (m, act, p, _) in layers] for layers in chains], prj_w, prj_b, prj_src, None, None)
+        if not ops.dtail_ok(B, probe):       # (decided BEFORE any call site is drawn: the layer-by-layer path draws its own)
+            return None
+        spec_l, seed, rr = [], None, None
+        for layers in chains:
+            out = []
+            for (m, act, p, ptag) in layers:
+                sid = 0
+                if p > 0.0:
+                    sid, seed = rng.site(ptag, (B, m.out_features), p), rng.seed
+                    rr = rng.row_map(B, ptag)
+                out.append((m.weight, m.bias, act, p, sid))
+            spec_l.append(out)
+        return ops.TailSpec(spec_l[0], spec_l[1], prj_w, prj_b, prj_src, seed, rr)
 
     def from_embedding(self, emb_ins, t):
         return self.tail(*self.bag_features(emb_ins), t)

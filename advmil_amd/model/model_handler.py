@@ -607,7 +607,8 @@ class MyHandler(object):
             loss, st = ops.gan_d_loss_stacked(f2, len(xs), plan.real_mask, self.which_loss, plan.n_fake, plan.n_real, root=True)
         else:
             loss, st = ops.gan_d_loss(f_fake, None, None, self.which_loss, plan.n_fake, plan.n_real, root=True)
-        with torch.autograd.set_multithreading_enabled(False):       # backward on THIS thread (see _gen_finish)
+        # (deferred_sums: the backward's ~7 merge launches of parameter-gradient partials become one, issued on exit)
+        with torch.autograd.set_multithreading_enabled(False), ops.deferred_sums():       # backward on THIS thread (see _gen_finish)
             torch.autograd.backward(loss, grad_tensors=self._one())  # (the root gradient is a cached 1: no fill launch per step)
         self._st_d = (st, plan, i_batch)     # this rank's partial sums over the global denominators; reduced + logged in _disc_apply
         preds = list(pred.split(1, dim=0))
@@ -726,7 +727,7 @@ class MyHandler(object):
         # The engine would hand a CUDA graph to its device thread; every node of ours is a short Python function that only enqueues
         # launches, so the hand-over and the GIL ping-pong cost more than they buy (host issue per eager step 2.9 -> 2.5 ms,
         # tools/probe/eager_host_profile.py). Scoped: the caller's setting comes back on exit.
-        with torch.autograd.set_multithreading_enabled(False):
+        with torch.autograd.set_multithreading_enabled(False), ops.deferred_sums():
             torch.autograd.backward(total, grad_tensors=self._one())
         if join is not None:
             # the generator's forward ran on the side stream, so autograd ran its backward nodes there too; the weight gradients

@@ -165,13 +165,30 @@ class EmbedXLayer(nn.Module):
         """The dropout-free, t-independent part: x -> emb_ins[1, L, C'] (shared by the real and fake pairs)."""
         return self.embedding(x)
 
-    def pool_features_rows(self, e, seg16=None):
-        """Region-level part over rows e[L_total, C'] (one bag or a slab): -> (emb_bag[B,C'] pooled before fc2, fc_ins[L_total,C'])."""
+    def pool_features_rows(self, e, seg16=None, want_mean=False):
+        """Region-level part over rows e[L_total, C'] (one bag or a slab): -> (emb_bag[B,C'] pooled before fc2, fc_ins[L_total,C']);
+        want_mean: a third result, the per-bag mean of fc_ins [B, C'] (the RLIP inner product's operand). fc1 and the pooling's scorer
+        run as ONE launch each way when the widths and the arithmetic mode allow it (ops.dx_region_pool, csrc/region.hip)."""
         rng = _rng_of(self, e)
         tr = self.training
-        h = ops.linear_act(e, self.fc1[0].weight, self.fc1[0].bias, "relu", self.fc1[2].p if tr else 0.0, rng, "dx_fc1")
-        fc_ins = ops.linear_act(h, self.fc1[3].weight, self.fc1[3].bias, "none")
-        return self.pool.pool_rows(fc_ins, seg16), fc_ins
+        f0, f3, pl = self.fc1[0], self.fc1[3], self.pool
+        p1 = self.fc1[2].p if tr else 0.0
+        if e.dim() == 2 and ops.dx_chain_ok(e, f0.weight, f0.bias, f3.weight, f3.bias, pl.fc1[0].weight, pl.fc1[0].bias, pl.score[0].weight,
+                                            pl.score[0].bias, pl.fc2.weight, pl.fc2.bias):
+            pooled, mean, A, fc_ins = ops.dx_region_pool(e, f0.weight, f0.bias, f3.weight, f3.bias, pl.fc1[0].weight, pl.fc1[0].bias,
+                                                         pl.score[0].weight, pl.score[0].bias, pl.fc2.weight, pl.fc2.bias, p1,
+                                                         pl.drop_p if pl.training else 0.0, rng, seg16, want_mean)
+            pl.last_attention = A.detach()
+            if seg16 is None:
+                pooled = pooled.reshape(1, -1)
+                mean = None if mean is None else mean.reshape(1, -1)
+            return (pooled, fc_ins, mean) if want_mean else (pooled, fc_ins)
+        h = ops.linear_act(e, f0.weight, f0.bias, "relu", p1, rng, "dx_fc1")
+        fc_ins = ops.linear_act(h, f3.weight, f3.bias, "none")
+        pooled = self.pool.pool_rows(fc_ins, seg16)
+        if want_mean:
+            return pooled, fc_ins, (ops.segmented_mean_rows(fc_ins, seg16) if seg16 is not None else fc_ins.mean(dim=0, keepdim=True))
+        return pooled, fc_ins
 
     def pool_features(self, emb_ins):
         """emb_ins[1,L,C'] -> (emb_bag[1,C'], fc_ins[1,L,C'])."""

@@ -120,7 +120,36 @@ def _const_zeros(n, device):
 
 
 def _ws(nbytes, device):
-    return torch.empty(max(int(nbytes), 16) // 4 + 4, dtype=torch.float32, device=device)
+    t = torch.empty(max(int(nbytes), 16) // 4 + 4, dtype=torch.float32, device=device)
+    if _DEFER_KEEP is not None:
+        _DEFER_KEEP.append(t)          # a queued merge reads this workspace at the flush: keep the block out of the allocator until then
+    return t
+
+
+# Deferred merges of parameter-gradient partials (include/advmil_hip.h::advmil_defer_sums, csrc/sumq.hip): inside the context every
+# accumulating merge launch of the backward kernels (bias / gate / LayerNorm column sums, split-K reduces of the weight gradients) is
+# queued and the exit issues them as ONE launch. The handler wraps each of its two backward calls: 14 merge launches per step -> 2.
+DEFER_SUMS = os.environ.get("ADVMIL_DEFER_SUMS", "1") != "0"
+_DEFER_KEEP = None
+
+
+class deferred_sums:
+    def __enter__(self):
+        global _DEFER_KEEP
+        self.on = DEFER_SUMS and _DEFER_KEEP is None
+        if self.on:
+            self.stream = _stream()
+            _lib.check(_lib.lib().advmil_defer_sums(self.stream, 1), "defer_sums")
+            _DEFER_KEEP = []
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFER_KEEP
+        if self.on:
+            keep, _DEFER_KEEP = _DEFER_KEEP, None
+            _lib.check(_lib.lib().advmil_defer_sums(self.stream, 0), "flush_sums")
+            del keep                     # (same stream as the flush: the allocator's stream order keeps the blocks intact until it has run)
+        return False
 
 
 # ---------------------------------------------------------------------------------------
@@ -653,6 +682,21 @@ def softmax_pool(s, h, N, D, seg=None):
     _lib.check(L.advmil_softmax_pool_fwd(_p(s), _p(h), h.stride(0), N, D, nseg, _p(None if seg is None else seg.ptr), mlen, _p(A),
                                          _p(pooled), _p(ws), wsb, _stream()), "softmax_pool_fwd")
     return A, pooled
+
+
+def softmax_pool_mean(s, h, N, D, seg=None):
+    """(A, pooled, mean): softmax_pool plus the per-bag unweighted mean of h's rows from the same pass (D % 8 == 0)."""
+    L = _lib.lib()
+    nseg = 1 if seg is None else seg.nseg
+    mlen = N if seg is None else seg.max_len
+    A = torch.empty(N, dtype=torch.float32, device=h.device)
+    pooled = torch.empty(nseg, D, dtype=torch.float32, device=h.device)
+    mean = torch.empty(nseg, D, dtype=torch.float32, device=h.device)
+    wsb = L.advmil_softmax_pool_mean_workspace_bytes(mlen, D, nseg)
+    ws = _ws(wsb, h.device)
+    _lib.check(L.advmil_softmax_pool_mean_fwd(_p(s), _p(h), h.stride(0), N, D, nseg, _p(None if seg is None else seg.ptr), mlen, _p(A),
+                                              _p(pooled), _p(mean), _p(ws), wsb, _stream()), "softmax_pool_mean_fwd")
+    return A, pooled, mean
 
 
 def softmax_pool_bwd(dpooled, dA, A, h, N, D, seg=None):
@@ -1799,3 +1843,253 @@ class PrjHeadFn(torch.autograd.Function):
 
 def prj_head(u, t, src=None, W=None, b=None):
     return PrjHeadFn.apply(u, t, src, W, b)
+
+
+# ---------------------------------------------------------------------------------------
+# the discriminator's bag-level tail as one launch each way (advmil_dtail_fwd / advmil_dtail_bwd, csrc/tail.hip)
+# ---------------------------------------------------------------------------------------
+DTAIL = os.environ.get("ADVMIL_DTAIL", "0") != "0"
+
+
+class TailSpec:
+    """Host description of one tail call: the two chains' layers [(W, bias, act code, p, stream id)], the projection layer, the dropout
+    seed / row map. Parameters are passed to DTailFn.apply again, flattened, so that autograd sees them."""
+    __slots__ = ("x", "y", "prj_w", "prj_b", "prj_src", "seed", "rr")
+
+    def __init__(self, x, y, prj_w, prj_b, prj_src, seed, rr):
+        self.x, self.y, self.prj_w, self.prj_b, self.prj_src, self.seed, self.rr = x, y, prj_w, prj_b, prj_src, seed, rr
+
+    def params(self):
+        out = []
+        for (W, b, _, _, _) in self.x + self.y:
+            out += [W, b]
+        return out + [self.prj_w, self.prj_b]
+
+
+def dtail_ok(B, spec):
+    """Can this tail run as the fused launch? B <= 32 rows, widths <= 256, every trainable parameter with an arena slot (the kernel ADDS
+    its weight gradients in place)."""
+    if not DTAIL or B > 32 or not (1 <= len(spec.x) <= _lib.TAIL_MAXL) or not (1 <= len(spec.y) <= _lib.TAIL_MAXL):
+        return False
+    for (W, b, _, _, _) in spec.x + spec.y:
+        if W.dim() != 2 or max(W.shape) > 256 or W.dtype != torch.float32 or not W.is_cuda or not W.is_contiguous():
+            return False
+    if spec.x[-1][0].shape[0] != spec.y[-1][0].shape[0]:
+        return False
+    for p in spec.params():
+        if p is not None and p.requires_grad and _arena_grad(p) is None:
+            return False
+    return True
+
+
+def _fill_tail(dt, B, spec, ys_x, ys_y, xin, tin, u, grads):
+    dt.B, dt.nx, dt.ny, dt.prj_src = B, len(spec.x), len(spec.y), spec.prj_src
+    dt.xin, dt.tin = xin.data_ptr(), tin.data_ptr()
+    dt.u = None if u is None else u.data_ptr()
+    for arr, layers, ys in ((dt.x, spec.x, ys_x), (dt.y, spec.y, ys_y)):
+        for i, ((W, b, act, p, sid), yb) in enumerate(zip(layers, ys)):
+            L = arr[i]
+            L.W, L.bias = W.data_ptr(), (None if b is None else b.data_ptr())
+            L.y, L.K, L.N, L.act, L.drop_p, L.stream_id = yb.data_ptr(), W.shape[1], W.shape[0], act, float(p), sid
+            gW = _arena_grad(W) if grads else None
+            gb = _arena_grad(b) if (grads and b is not None) else None
+            L.dW, L.dbias = (None if gW is None else gW.data_ptr()), (None if gb is None else gb.data_ptr())
+    if spec.prj_src:
+        dt.w_prj = spec.prj_w.data_ptr()
+        dt.b_prj = None if spec.prj_b is None else spec.prj_b.data_ptr()
+        gw = _arena_grad(spec.prj_w) if grads else None
+        gb = _arena_grad(spec.prj_b) if (grads and spec.prj_b is not None) else None
+        dt.dw_prj, dt.db_prj = (None if gw is None else gw.data_ptr()), (None if gb is None else gb.data_ptr())
+    dt.seed = None if spec.seed is None else spec.seed.data_ptr()
+    dt.rng_row = None if spec.rr is None else spec.rr.data_ptr()
+
+
+class DTailFn(torch.autograd.Function):
+    """f[B, 1] = <u, hid_t> + prj(hid_x | hid_t), hid_x = x-chain(eb), hid_t = y-chain(t), u = im (region-level inner product) or hid_x."""
+
+    @staticmethod
+    def forward(ctx, eb, im, t, spec, *params):
+        eb, t = eb.contiguous(), t.contiguous()
+        im_ = None if im is None else im.contiguous()
+        B, dev = eb.shape[0], eb.device
+        ys_x = [torch.empty(B, W.shape[0], dtype=torch.float32, device=dev) for (W, _, _, _, _) in spec.x]
+        ys_y = [torch.empty(B, W.shape[0], dtype=torch.float32, device=dev) for (W, _, _, _, _) in spec.y]
+        out = torch.empty(B, 1, dtype=torch.float32, device=dev)
+        dt = _lib.DTail()
+        _fill_tail(dt, B, spec, ys_x, ys_y, eb, t, im_, False)
+        dt.out = out.data_ptr()
+        _lib.check(_lib.lib().advmil_dtail_fwd(ctypes.byref(dt), _stream()), "dtail_fwd")
+        ctx.spec, ctx.B = spec, B
+        ctx.nx = len(ys_x)
+        ctx.has_im = im_ is not None
+        ctx.save_for_backward(eb, t, *( [im_] if im_ is not None else []), *ys_x, *ys_y)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        sv = ctx.saved_tensors
+        eb, t = sv[0], sv[1]
+        o = 2
+        im_ = None
+        if ctx.has_im:
+            im_, o = sv[2], 3
+        ys_x, ys_y = list(sv[o:o + ctx.nx]), list(sv[o + ctx.nx:])
+        spec, B, dev = ctx.spec, ctx.B, eb.device
+        dout = dout.contiguous()
+        need_eb, need_im, need_t = ctx.needs_input_grad[0], (im_ is not None and ctx.needs_input_grad[1]), ctx.needs_input_grad[2]
+        deb = torch.empty_like(eb) if need_eb else None
+        dim_ = torch.empty_like(im_) if need_im else None
+        dt_ = torch.empty_like(t) if need_t else None
+        dt = _lib.DTail()
+        _fill_tail(dt, B, spec, ys_x, ys_y, eb, t, im_, True)
+        dt.dout = dout.data_ptr()
+        dt.dxin = None if deb is None else deb.data_ptr()
+        dt.du = None if dim_ is None else dim_.data_ptr()
+        dt.dtin = None if dt_ is None else dt_.data_ptr()
+        _lib.check(_lib.lib().advmil_dtail_bwd(ctypes.byref(dt), _stream()), "dtail_bwd")
+        return (deb, dim_, dt_, None) + (None,) * len(spec.params())
+
+
+def dtail(eb, im, t, spec):
+    return DTailFn.apply(eb, im, t, spec, *spec.params())
+
+
+# ---------------------------------------------------------------------------------------
+# the discriminator's region-level network as one launch each way (advmil_dx_chain_fwd / _bwd, csrc/region.hip)
+# ---------------------------------------------------------------------------------------
+DX_CHAIN = os.environ.get("ADVMIL_DX_CHAIN", "1") != "0"
+
+
+def _stacked_planes(Wa, Wb, D):
+    """Planes of [Wa; Wb] ([2D, D]) as one strided view when the two weights lie side by side in the arena, else None."""
+    pa_, pb_ = weight_planes(Wa), weight_planes(Wb)
+    if pa_ is None or pb_ is None or not (_adjacent(pa_.hi, pb_.hi, 2) and _adjacent(pa_.lo, pb_.lo, 2)):
+        return None
+    return Planes(pa_.hi.as_strided((2 * D, D), (D, 1), pa_.hi.storage_offset()), pa_.lo.as_strided((2 * D, D), (D, 1), pa_.lo.storage_offset()))
+
+
+def dx_chain_ok(e, W1, b1, W2, b2, Wa, ba, Wb, bb, wc, bc):
+    """Can fc1 + the GAPool scorer over the region rows e [R, 128] run as the fused launches? bf16x3 arithmetic, the shipped widths
+    (128 -> 64 -> 128, scorer 128 x 128), every weight with resident operand planes, gate branches side by side in the arena, and every
+    trainable parameter with an arena slot (the backward ADDS into them)."""
+    if not (DX_CHAIN and USE_PLANES and get_gemm_mode() == "bf16x3" and e.is_cuda and e.dim() == 2 and e.dtype == torch.float32
+            and e.shape[1] == 128 and e.shape[0] >= 1):
+        return False
+    if tuple(W1.shape) != (64, 128) or tuple(W2.shape) != (128, 64) or tuple(Wa.shape) != (128, 128) or tuple(Wb.shape) != (128, 128):
+        return False
+    if any(t is None for t in (b1, b2, ba, bb, bc)) or wc.numel() != 128:
+        return False
+    if weight_planes(W1) is None or weight_planes(W2) is None or _stacked_planes(Wa, Wb, 128) is None or not _adjacent(ba, bb):
+        return False
+    ps = (W1, b1, W2, b2, Wa, ba, Wb, bb, wc, bc)
+    if any(p.requires_grad and _arena_grad(p) is None for p in ps):
+        return False
+    gs = [_arena_grad(p) for p in (Wa, Wb, ba, bb)]
+    if all(g is not None for g in gs) and not (_adjacent(gs[0], gs[1]) and _adjacent(gs[2], gs[3])):
+        return False
+    return True
+
+
+class DxRegionPoolFn(torch.autograd.Function):
+    """(pooled [B, 128], mean [B, 128] | None, A [R], fc [R, 128]) of the region rows e [R, 128]: fc = fc1(e), pooled = GAPool(fc) per bag,
+    mean = per-bag mean of fc (EmbedXLayer / GAPool, reference model/model_utils.py:202-210, model/backbone_utils.py:47-56)."""
+
+    @staticmethod
+    def forward(ctx, e, W1, b1, W2, b2, Wa, ba, Wb, bb, wc, bc, p1, pg, seed, sids, rr, seg, want_mean, nograd):
+        _chk(e, "e")
+        e = e.contiguous()
+        R, D = e.shape
+        dev = e.device
+        L = _lib.lib()
+        w1pl, w2pl, wabpl = weight_planes(W1), weight_planes(W2), _stacked_planes(Wa, Wb, D)
+        bab, _ = _stack2(ba, bb, D, 0)
+        wcv = wc.detach().reshape(-1)
+        keep = not nograd
+        h1 = torch.empty(R, 64, dtype=torch.float32, device=dev) if keep else None
+        ab = torch.empty(R, 2 * D, dtype=torch.float32, device=dev) if keep else None
+        fc = torch.empty(R, D, dtype=torch.float32, device=dev)
+        s = torch.empty(R, dtype=torch.float32, device=dev)
+        use = seed is not None and (p1 > 0.0 or pg > 0.0)
+        _lib.check(L.advmil_dx_chain_fwd(_p(e), R, D, _p(w1pl.hi), _p(w1pl.lo), _p(b1.detach()), _p(w2pl.hi), _p(w2pl.lo), _p(b2.detach()),
+                                         _p(wabpl.hi), _p(wabpl.lo), _p(bab), _p(wcv), _p(bc.detach()), float(p1), float(pg),
+                                         _p(seed if use else None), sids[0], sids[1], sids[2], _p(rr if use else None), _p(h1), _p(fc), _p(ab),
+                                         _p(s), _stream()), "dx_chain_fwd")
+        mean = None
+        if want_mean:
+            A, pooled, mean = softmax_pool_mean(s, fc, R, D, seg)      # the per-bag mean of fc from the pooling's own pass over it
+        else:
+            A, pooled = softmax_pool(s, fc, R, D, seg)
+        if keep:
+            ctx.save_for_backward(e, h1, fc, ab, A, wcv, W1.detach(), W2.detach(), _stack2(Wa, Wb, D, D)[0])
+            ctx.cfg = (p1, pg, seed if use else None, sids, rr if use else None, seg, R, D)
+            gs = [_arena_grad(t) for t in (W1, b1, W2, b2, Wa, ba, Wb, bb, wc, bc)]
+            ctx.g = gs
+        ctx.mark_non_differentiable(A)
+        ctx.set_materialize_grads(False)
+        return pooled, mean, A, fc
+
+    @staticmethod
+    def backward(ctx, dpooled, dmean, _dA, dfc_ext):
+        e, h1, fc, ab, A, wcv, W1, W2, Wab = ctx.saved_tensors
+        p1, pg, seed, sids, rr, seg, R, D = ctx.cfg
+        gW1, gb1, gW2, gb2, gWa, gba, gWb, gbb, gwc, gbc = ctx.g
+        dev = e.device
+        L = _lib.lib()
+        nseg = 1 if seg is None else seg.nseg
+        dpooled = (torch.zeros(nseg, D, dtype=torch.float32, device=dev) if dpooled is None else dpooled.contiguous().reshape(nseg, D))
+        ds = softmax_pool_bwd(dpooled, None, A, fc, R, D, seg)
+        # the weights transposed, as operand planes (three tiny matrices: one launch)
+        w1t, w2t, wabt = Planes.alloc((D, 64), dev), Planes.alloc((64, D), dev), Planes.alloc((D, 2 * D), dev)
+        _lib.check(L.advmil_dx_chain_prep(_p(W1), _p(W2), _p(Wab), D, _p(w1t.hi), _p(w1t.lo), _p(w2t.hi), _p(w2t.lo), _p(wabt.hi), _p(wabt.lo),
+                                          _stream()), "dx_chain_prep")
+        need_e = ctx.needs_input_grad[0]
+        dG = torch.empty(R, 2 * D, dtype=torch.float32, device=dev)
+        dfc = torch.empty(R, D, dtype=torch.float32, device=dev)
+        dpre = torch.empty(R, 64, dtype=torch.float32, device=dev)
+        de = torch.empty(R, D, dtype=torch.float32, device=dev) if need_e else None
+        frozen = gW1 is None          # (dx_chain_ok: every trainable parameter has its slot; none has one when D is frozen)
+        if frozen:
+            scratch = torch.zeros(3 * D + 8 + D + 64, dtype=torch.float32, device=dev)
+            dwc, dbab, dbc, db2, db1 = scratch[:D], scratch[D:3 * D], scratch[3 * D:3 * D + 1], scratch[3 * D + 8:4 * D + 8], scratch[4 * D + 8:]
+        else:
+            dwc, dbc, db2, db1 = gwc.view(-1), gbc, gb2, gb1
+            dbab = gba.as_strided((2 * D,), (1,), gba.storage_offset())
+        wsb = L.advmil_dx_chain_bwd_workspace_bytes(R, D)
+        ws = _ws(wsb, dev)
+        dm = None if dmean is None else dmean.contiguous()
+        ext = None if dfc_ext is None else dfc_ext.contiguous()
+        _lib.check(L.advmil_dx_chain_bwd(R, D, _p(ds), _p(A), _p(dpooled), _p(dm), _p(None if seg is None else seg.rowseg),
+                                         _p(None if seg is None else seg.ptr), _p(ext), _p(h1), _p(ab), _p(wcv), float(p1), float(pg), _p(seed),
+                                         sids[1], sids[2], _p(rr), _p(wabt.hi), _p(wabt.lo), _p(w2t.hi), _p(w2t.lo), _p(w1t.hi), _p(w1t.lo),
+                                         _p(dG), _p(dfc), _p(dpre), _p(de), _p(dwc), _p(dbab), _p(dbc), _p(db2), _p(db1), _p(ws), wsb, _stream()),
+                   "dx_chain_bwd")
+        if not frozen:
+            gWab = gWa.as_strided((2 * D, D), (D, 1), gWa.storage_offset())
+            gemm(dG, fc, False, False, 2 * D, D, R, out=gWab, ldc=D, accumulate=True)             # dWab += dG^T fc
+            gemm(dfc, h1, False, False, D, 64, R, out=gW2.view(D, 64), ldc=64, accumulate=True)   # dW2  += dfc^T h1
+            gemm(dpre, e, False, False, 64, D, R, out=gW1.view(64, D), ldc=D, accumulate=True)    # dW1  += dpre^T e
+        return (de,) + (None,) * 18
+
+
+def dx_region_pool(e, W1, b1, W2, b2, Wa, ba, Wb, bb, wc, bc, p1=0.0, pg=0.0, rng=None, seg=None, want_mean=False):
+    """Fused fc1 + GAPool (+ per-bag mean of fc) over the region rows; the dropout call sites are drawn in the order and under the tags of
+    the layer-by-layer path (dx_fc1, gapool_att_a, gapool_att_b)."""
+    R = e.shape[0]
+    sids, seed, rr = (0, 0, 0), None, None
+    if p1 > 0.0 or pg > 0.0:
+        rng = rng or default_rng(e.device)
+        s1 = sa = sb = 0
+        if p1 > 0.0:
+            s1 = rng.site("dx_fc1", (R, 64), p1)
+            rr = rng.row_map(R, "dx_fc1")
+        if pg > 0.0:
+            sa = rng.site("gapool_att_a", (R, 128), pg)
+            sb = rng.site("gapool_att_b", (R, 128), pg)
+            rg = rng.row_map(R, "gapool_att_a")
+            if p1 > 0.0 and (rg is not rr) and not (rg is not None and rr is not None and rg.data_ptr() == rr.data_ptr()):
+                raise RuntimeError("bag-parallel: the region layers of one pass must share their row map")
+            rr = rg
+        sids, seed = (s1, sa, sb), rng.seed
+    ps = (W1, b1, W2, b2, Wa, ba, Wb, bb, wc, bc)
+    nograd = not torch.is_grad_enabled() or not (e.requires_grad or any(t.requires_grad for t in ps))
+    return DxRegionPoolFn.apply(e, W1, b1, W2, b2, Wa, ba, Wb, bb, wc, bc, float(p1), float(pg), seed, sids, rr, seg, bool(want_mean), nograd)

@@ -216,6 +216,11 @@ size_t advmil_softmax_pool_workspace_bytes(int64_t max_len, int64_t D, int nseg)
 int advmil_softmax_pool_fwd(const float* s, const float* h, int64_t ldh, int64_t N, int64_t D, int nseg,
                             const int64_t* seg_ptr, int64_t max_len, float* A, float* pooled, void* ws, size_t ws_bytes,
                             advmil_stream_t stream);
+/* Same, plus mean[nseg, D] = the per-bag UNWEIGHTED mean of h's rows from the same pass over h (the projection discriminator's region-level
+ * inner product needs mean_r(fc_ins) beside the pooled fc_ins, GANSurv.py:96-98). D % 8 == 0. */
+size_t advmil_softmax_pool_mean_workspace_bytes(int64_t max_len, int64_t D, int nseg);
+int advmil_softmax_pool_mean_fwd(const float* s, const float* h, int64_t ldh, int64_t N, int64_t D, int nseg, const int64_t* seg_ptr,
+                                 int64_t max_len, float* A, float* pooled, float* mean, void* ws, size_t ws_bytes, advmil_stream_t stream);
 int advmil_softmax_pool_bwd(const float* dpooled, const float* dA, const float* A, const float* h, int64_t ldh,
                             int64_t N, int64_t D, int nseg, const int64_t* seg_ptr, int64_t max_len, float* ds, void* ws,
                             size_t ws_bytes, advmil_stream_t stream);
@@ -240,6 +245,18 @@ int advmil_act_dropout_bwd(const float* dy, const float* y, int act, float drop_
 /* out[n] (+)= sum_m x[m,n] */
 int advmil_colsum(const float* x, int64_t M, int64_t N, float* out, int accumulate, void* ws, size_t ws_bytes,
                   advmil_stream_t stream);
+
+/* Deferred merges of parameter-gradient partials. Every backward entry point above that ADDS a parameter gradient into its destination
+ * (`accumulate` != 0: the destinations are slots of the optimizer's flat gradient arena, model_handler.py:405-409 / 486-497 sum the
+ * per-bag gradients the same way through autograd's accumulation) first leaves per-workgroup partial rows -- or split-K partial tiles:
+ * advmil_gemm_f32 with splits > 1, alpha = 1 and no other epilogue term -- in the caller's workspace and then folds them with a second,
+ * launch-bound kernel. advmil_defer_sums(stream, 1) puts `stream` into deferral: those folds are queued instead (up to 16; a fold into a
+ * slot that already has one queued flushes first) and advmil_flush_sums(stream) / advmil_defer_sums(stream, 0) issue them as ONE launch.
+ * Contract: every workspace handed to such a call stays alive and untouched until the flush, and nothing reads the destinations before
+ * it. Non-accumulating folds are never deferred. advmil_pending_sums: queued folds (-1: the stream is not in deferral). */
+int advmil_defer_sums(advmil_stream_t stream, int on);
+int advmil_flush_sums(advmil_stream_t stream);
+int advmil_pending_sums(advmil_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Region embedding tail of AVGPoolPatchEmbedding (model/backbone_utils.py:158-168):
@@ -349,6 +366,75 @@ int advmil_prj_head_fwd(const float* u, const float* t, const float* src, const 
                         advmil_stream_t stream);
 int advmil_prj_head_bwd(const float* dout, const float* u, const float* t, const float* src, const float* w, int B, int d, float* du,
                         float* dt, float* dsrc, float* dw, float* dbias, int accumulate, advmil_stream_t stream);
+/* The discriminator's bag-level tail as ONE launch each way (reference model/GANSurv.py:89-105 PrjDiscriminator.forward after the region
+ * level: hid_x = net_pair_one.fc2(emb_bag), hid_t = net_pair_two(t), out = <u, hid_t> + prj_layer(hid_x | hid_t), u = hid_x ('bag') or the
+ * region-mean embedding ('instance', RLIP); model_utils.py:157-186 builds the two chains). B <= 32 rows (the bags of an optimizer step, or
+ * 2 x 16 for the stacked fake | real pass), every width <= 256: one workgroup walks both chains with the activations in LDS -- the six
+ * forward and up to twelve backward launches of 5-10 us each that these [B, d] layers cost as separate kernels become two.
+ *   layer: y = dropout(act(x W^T + bias)), W [N, K] row-major; dropout element index row * N + col on `stream_id` (row through rng_row when
+ *          given: advmil_epilogue_t.rng_row); `y` [B, N] is written by the forward and read by the backward.
+ *   backward: dW / dbias (NULL = not wanted) are ADDED into (optimizer arena slots); dxin / dtin / du NULL = not wanted.
+ * The two chains must end at the same width d; u [B, d] or NULL (= the x chain's output); prj_src 0 none, 1 = x chain output, 2 = y chain output. */
+#define ADVMIL_TAIL_MAXL 3
+typedef struct {
+  const float* W;
+  const float* bias;
+  float* dW;
+  float* dbias;
+  float* y;
+  int K, N, act;
+  float drop_p;
+  uint64_t stream_id;
+} advmil_dense_layer_t;
+typedef struct {
+  int B, nx, ny, prj_src;
+  const float* xin;
+  const float* tin;
+  advmil_dense_layer_t x[ADVMIL_TAIL_MAXL];
+  advmil_dense_layer_t y[ADVMIL_TAIL_MAXL];
+  const float* u;
+  const float* w_prj;
+  const float* b_prj;
+  float* dw_prj;
+  float* db_prj;
+  const uint64_t* seed;
+  const int64_t* rng_row;
+  float* out;        /* forward: [B] */
+  const float* dout; /* backward: [B] */
+  float* dxin;
+  float* dtin;
+  float* du;
+} advmil_dtail_t;
+int advmil_dtail_fwd(const advmil_dtail_t* a, advmil_stream_t stream);
+int advmil_dtail_bwd(const advmil_dtail_t* a, advmil_stream_t stream);
+/* The discriminator's region-level network as one launch each way (reference model/model_utils.py:188-210 EmbedXLayer: fc1 = Linear(d, d/2)
+ * -> ReLU -> Dropout -> Linear(d/2, d); model/backbone_utils.py:31-56 GAPool's scorer tanh(Linear(d, d)) * sigmoid(Linear(d, d)) -> Linear(d, 1))
+ * over the R region rows of a step slab, d = 128 (the shipped disc_netx_out_dim; other widths keep the layer-by-layer path):
+ *   h1 = dropout_p1(relu(e W1^T + b1)) [R, 64];  fc = h1 W2^T + b2 [R, 128];  ab = tanh | sigmoid (fc Wab^T + bab) [R, 256] (pre-dropout);
+ *   s[r] = sum_j drop_pg(a_j) drop_pg(b_j) wc_j + bc.
+ * bf16x3 arithmetic (split-bf16 products on the bf16 matrix pipe, fp32 accumulate, the contraction engine's order). Weights arrive as their
+ * operand planes (hi = bf16(w), lo = bf16(w - hi), row-major [out, in]; Wab = the tanh branch's rows, then the sigmoid branch's).
+ * Dropout draws: stream sid1 at element r * 64 + c for h1, streams sida / sidb at r * 128 + j for the two gate branches (row r through
+ * rng_row when given) -- the draws of the separate launches. h1 / ab may be NULL (a pass nobody differentiates).
+ * bwd: from ds[R] (gradient wrt the scores), A[R] and dpooled[nseg, 128] (the pooling's direct path A[r] dpooled[bag(r)]), dmean[nseg, 128] or
+ * NULL (gradient wrt the per-bag mean of fc: + dmean[bag(r)] / len(bag(r))), dfc_add[R, 128] or NULL (any other gradient wrt fc):
+ *   dG [R, 256], dfc [R, 128], dpre [R, 64] (= d h1 masked by the ReLU / dropout of h1), de [R, 128] (NULL: not wanted) are written;
+ *   dwc[128], dbab[256], dbc[1], db2[128], db1[64] are ADDED into (arena slots; the merge of the per-workgroup partial rows is deferrable:
+ *   advmil_defer_sums). The three weight gradients dWab = dG^T fc, dW2 = dfc^T h1, dW1 = dpre^T e stay contractions of the engine.
+ *   WabT / W2T / W1T: operand planes of the TRANSPOSED weights ([128, 256], [64, 128], [128, 64]), made by advmil_dx_chain_prep. */
+int advmil_dx_chain_fwd(const float* e, int64_t R, int d, const void* W1_hi, const void* W1_lo, const float* b1, const void* W2_hi,
+                        const void* W2_lo, const float* b2, const void* Wab_hi, const void* Wab_lo, const float* bab, const float* wc,
+                        const float* bc, float p1, float pg, const uint64_t* seed, uint64_t sid1, uint64_t sida, uint64_t sidb,
+                        const int64_t* rng_row, float* h1, float* fc, float* ab, float* s, advmil_stream_t stream);
+size_t advmil_dx_chain_bwd_workspace_bytes(int64_t R, int d);
+int advmil_dx_chain_prep(const float* W1, const float* W2, const float* Wab, int d, void* W1T_hi, void* W1T_lo, void* W2T_hi, void* W2T_lo,
+                         void* WabT_hi, void* WabT_lo, advmil_stream_t stream);
+int advmil_dx_chain_bwd(int64_t R, int d, const float* ds, const float* A, const float* dpooled, const float* dmean, const int32_t* rowseg,
+                        const int64_t* seg_ptr, const float* dfc_add, const float* h1, const float* ab, const float* wc, float p1, float pg,
+                        const uint64_t* seed, uint64_t sida, uint64_t sidb, const int64_t* rng_row, const void* WabT_hi, const void* WabT_lo,
+                        const void* W2T_hi, const void* W2T_lo, const void* W1T_hi, const void* W1T_lo, float* dG, float* dfc, float* dpre,
+                        float* de, float* dwc, float* dbab, float* dbc, float* db2, float* db1, void* ws, size_t ws_bytes,
+                        advmil_stream_t stream);
 int advmil_gan_d_loss(const float* fake, int nf, const float* real, const float* real_mask, int nr, int which, float inv_nf,
                       float inv_nr, float* out3, float* g_fake, float* g_real, advmil_stream_t stream);
 int advmil_gan_g_loss(const float* pred, const float* t, const float* e, const float* vis_mask, const float* fake, int n, float alpha,
