@@ -27,7 +27,7 @@ class Epilogue(ctypes.Structure):
                 ("maskref", c_void_p), ("ldmask", c_int), ("mask_scale", c_float), ("accumulate", c_int),
                 ("alpha", c_float), ("a_hi", c_void_p), ("a_lo", c_void_p), ("b_hi", c_void_p), ("b_lo", c_void_p),
                 ("c_hi", c_void_p), ("c_lo", c_void_p), ("gate_wc", c_void_p), ("gate_out", c_void_p), ("gate_np", c_int),
-                ("rng_row", c_void_p), ("c2", c_void_p), ("ldc2", c_int64), ("n_split", c_int64), ("bias2", c_void_p)]
+                ("rng_row", c_void_p), ("c2", c_void_p), ("ldc2", c_int64), ("n_split", c_int64), ("bias2", c_void_p), ("colsum", c_void_p)]
 
 
 class DenseLayer(ctypes.Structure):
@@ -58,6 +58,8 @@ SIGNATURES = {
     "advmil_gate_interleave": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "advmil_gate_partial_sum": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
     "advmil_gemm_f32_gate_blocks": (c_int, [c_int, c_int64]),
+    "advmil_gemm_f32_colsum_rows": (c_int64, [c_int, c_int64, c_int64]),
+    "advmil_merge_partials": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_void_p]),
     "advmil_set_gemm_mode": (c_int, [c_int]),
     "advmil_get_gemm_mode": (c_int, []),
     "advmil_gemm_f32_plan": (c_int, [c_int64, c_int64, c_int64, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),

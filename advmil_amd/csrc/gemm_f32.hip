@@ -305,6 +305,10 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
   const bool drop = !PLAIN && e.seed && e.drop_p > 0.0f;
   const bool mapped = drop && e.rng_row;
   const int kind = PLAIN ? 0 : (e.rowv ? 1 : (e.maskref ? 2 : (e.accumulate ? 3 : 0)));     // which per-element operand is fetched one sub-tile ahead
+  // rank-1 term AND mask in one launch (dh = dG Wab + A dpooled, masked by the first layer's stored output: that layer's activation /
+  // dropout backward rides in this epilogue instead of a row pass of its own): a second prefetched per-element operand
+  const bool rmask = !PLAIN && kind == 1 && e.maskref != nullptr;
+  const bool csum = !PLAIN && e.colsum != nullptr;      // per-wave column sums of the final values (the bias gradient of that layer)
   const float* const xbase = kind == 1 ? e.colv : (kind == 2 ? e.maskref : out);
   const int64_t xld = kind == 1 ? N : (kind == 2 ? (int64_t)e.ldmask : ldo);
   const int64_t rbase = m0 + wr * 32 * TM, cbase = n0 + wc * 32 * TN;
@@ -338,9 +342,14 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
       if (u * 64 + lane < 32 * TM) { srow_i[u * 64 + lane] = iv[u]; srow_f[u * 64 + lane] = fv[u]; }
     WAVE_LDS_SYNC();
   }
-  float4 ext[4];
+  float4 ext[4], ext2[4];
+  float cs[TN][4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) ext[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int q = 0; q < 4; ++q) { ext[q] = make_float4(0.f, 0.f, 0.f, 0.f); ext2[q] = make_float4(1.f, 1.f, 1.f, 1.f); }
+#pragma unroll
+  for (int b = 0; b < TN; ++b)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) cs[b][t] = 0.f;
 #define ADVMIL_EPI_PREFETCH(a_, b_)                                                                             \
   do {                                                                                                          \
     if (kind != 0) {                                                                                            \
@@ -348,6 +357,7 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
         const int rr_ = (a_) * 32 + q * 8 + rq;                                                                 \
         const int64_t xrow_ = kind == 1 ? (int64_t)srow_i[rr_] : rbase + rr_;                                   \
         ext[q] = *reinterpret_cast<const float4*>(xbase + xrow_ * xld + cbase + (b_) * 32 + c4);                \
+        if (rmask) ext2[q] = *reinterpret_cast<const float4*>(e.maskref + (rbase + rr_) * (int64_t)e.ldmask + cbase + (b_) * 32 + c4); \
       }                                                                                                         \
     }                                                                                                           \
   } while (0)
@@ -395,7 +405,7 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
 #pragma unroll
             for (int t = 0; t < 4; ++t) res[q][t] = act_apply(ACT_SIGMOID, res[q][t] * al + bb[t]);
         }
-      } else if (!drop && kind == 1 && act == ACT_NONE) {
+      } else if (!drop && kind == 1 && act == ACT_NONE && !rmask) {
         // rank-1 term per bag (dh = dG Wab + A[n] dpooled[bag(n)]), no activation
         const float al = e.alpha;
 #pragma unroll
@@ -435,6 +445,17 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
           if (kind == 3) x += xe[t];
           res[q][t] = x;
         }
+        if (rmask) {
+          const float me[4] = {ext2[q].x, ext2[q].y, ext2[q].z, ext2[q].w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) res[q][t] *= (me[t] > 0.0f ? e.mask_scale : 0.0f);
+        }
+      }
+      if (csum) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) cs[b][t] += res[q][t];
       }
       // next sub-tile's per-element operand: behind this sub-tile's math (the registers are free again), ahead of its stores
       if (b + 1 < TN) ADVMIL_EPI_PREFETCH(a, b + 1);
@@ -470,6 +491,20 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
     }
   }
 #undef ADVMIL_EPI_PREFETCH
+  if (csum) {
+    // the wave's 32 TM rows: the 8 row-lanes (lane >> 3) hold pieces of every column; one partial row per (m tile, wave row)
+    const int64_t prow = (m0 / (32 * TM * WR)) * WR + wr;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float v = cs[b][t];
+        v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+        cs[b][t] = v;
+      }
+      if (rq == 0) *reinterpret_cast<float4*>(e.colsum + prow * N + cbase + b * 32 + c4) = make_float4(cs[b][0], cs[b][1], cs[b][2], cs[b][3]);
+    }
+  }
 }
 
 // RAWBAR: the caller has LDS-DMA in flight (persistent plane-fed kernel): the opening barrier must not drain vmcnt.
@@ -504,7 +539,7 @@ __device__ __forceinline__ int gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[TM
   // no-grad generator pass then never writes (and gate_score never re-reads) the [rows, 2D] activations.
   const bool gate_mode = direct && e.gate_wc != nullptr;
   if constexpr (TM * TN >= 4 && EPI != 1) {   // the slab-sized tiles (the 64x64 ... 64x192 tiles serve launch-bound shapes: generic path only)
-    const int nmode = (e.rowv ? 1 : 0) + (e.maskref ? 1 : 0) + (e.accumulate ? 1 : 0);
+    const int nmode = (e.rowv && e.maskref && !e.accumulate) ? 1 : (e.rowv ? 1 : 0) + (e.maskref ? 1 : 0) + (e.accumulate ? 1 : 0);
     const bool stream = direct && !gate_mode && vec_ok && (g.N % (32 * TN * WC)) == 0 && (g.M % (32 * TM * WR)) == 0 && (e.act_split & 31) == 0 &&
                         nmode <= 1 && !(e.rowv && e.seed && e.rng_row) && (!e.bias || ((uintptr_t)e.bias & 15) == 0) && (!e.rowv || ((uintptr_t)e.colv & 15) == 0) &&
                         (!e.maskref || ((e.ldmask & 3) == 0 && ((uintptr_t)e.maskref & 15) == 0)) &&
@@ -1340,6 +1375,31 @@ extern "C" int advmil_gemm_f32_gate_blocks(int tile, int64_t N) {
   return (int)((N + 64 * tn - 1) / (64 * tn)) * tile_wc(tile);
 }
 
+// accumulator blocks per wave and wave grid of a generic tile code: (TM, TN, WR, WC); false for codes without a kernel
+static bool tile_geom(int tile, int& tm, int& tn, int& wr, int& wc) {
+  switch (tile) {
+    case 43: tm = 2; tn = 3; wr = 4; wc = 2; return true;
+    case 42: tm = 2; tn = 2; wr = 4; wc = 2; return true;
+    case 34: tm = 3; tn = 2; wr = 2; wc = 4; return true;
+    case 24: tm = 2; tn = 2; wr = 2; wc = 4; return true;
+    case 23: case 22: case 13: case 12: case 11: tm = tile / 10; tn = tile % 10; wr = 2; wc = 2; return true;
+    default: return false;
+  }
+}
+
+extern "C" int64_t advmil_gemm_f32_colsum_rows(int tile, int64_t M, int64_t N) {
+  int tm, tn, wr, wc;
+  if (g_gemm_mode != 1 || !tile_geom(tile, tm, tn, wr, wc) || tm * tn < 4) return 0;
+  const int64_t bm = 32 * tm * wr, bn = 32 * tn * wc;
+  return ((M % bm) || (N % bn)) ? 0 : (M / bm) * wr;
+}
+
+extern "C" int advmil_merge_partials(const float* partial, int nblk, int64_t stride, int64_t ncols, float* out, int accumulate,
+                                     advmil_stream_t stream) {
+  if (!partial || !out || nblk <= 0 || ncols <= 0 || stride < ncols) return ADVMIL_EINVAL;
+  return advmil_sumq((hipStream_t)stream, partial, nblk, stride, ncols, out, accumulate);
+}
+
 extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                                      const float* B, int64_t ldb, float* C, int64_t ldc, const advmil_epilogue_t* epi,
                                      int splits, int tile, void* ws, size_t ws_bytes, advmil_stream_t stream_) {
@@ -1386,6 +1446,13 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
     if (planes_usable(epi->b_hi, epi->b_lo, ldb, b_kc ? K : N)) pre |= 2;
   }
   if ((epi->c_hi != nullptr) != (epi->c_lo != nullptr)) return ADVMIL_EINVAL;
+  if (epi->colsum) {      // per-wave column sums come out of the streaming epilogue only: whole tiles of a slab-sized tile, one pass
+    int tm_, tn_, wr_, wc_;
+    if (g_gemm_mode != 1 || splits != 1 || !tile_geom(tile, tm_, tn_, wr_, wc_) || tm_ * tn_ < 4 || epi->gate_wc || epi->accumulate ||
+        (epi->seed && epi->drop_p > 0.0f))
+      return ADVMIL_EINVAL;
+    if ((M % (32 * tm_ * wr_)) || (N % (32 * tn_ * wc_)) || (((uintptr_t)epi->colsum) & 15) || (epi->act_split & 31)) return ADVMIL_EINVAL;
+  }
   if (epi->gate_wc) {       // fused gate score: no split-K, no dropout, whole float4 column groups, one partial per 32*TN*... block
     if (splits != 1 || !epi->gate_out || (N & 3) || epi->drop_p > 0.0f) return ADVMIL_EINVAL;
     if (epi->gate_np != advmil_gemm_f32_gate_blocks(tile, N)) return ADVMIL_EINVAL;

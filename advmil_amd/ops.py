@@ -381,6 +381,8 @@ USE_PLANES = os.environ.get("ADVMIL_PLANES", "1") != "0"
 # memo-replayed (dropped) h were neutral while the training-pass gate contraction took the 256x192 tile with the old epilogue; with
 # the persistent 256x256 tile and the plain streaming epilogue they pay (+0.4-0.8 %, two same-box A/B runs) -> on.
 DH_PLANES = os.environ.get("ADVMIL_DH_PLANES", "0") != "0"
+# the first layer's activation / dropout backward in the epilogue of the pool's dh contraction (rank-1 term + mask + bias column sums)
+ACT_BWD_IN_DH = os.environ.get("ADVMIL_ACT_BWD_IN_DH", "1") != "0"
 # dG of the gate backward as planes ONLY (no fp32 copy): its two consumers take the A operand pre-split (-30 us each, no extra bytes)
 DG_PLANES_ONLY = os.environ.get("ADVMIL_DG_PLANES_ONLY", "1") != "0"
 # weight gradients dY^T X of the layers applied to the slab: X's planes (already resident for the forward) feed the B operand
@@ -430,7 +432,8 @@ def pre_a_tile_ok(tile, a_kc, b_kc, b_planes=False):
 
 def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=None, act_split=None, drop_p=0.0,
          seed=None, stream_id=0, rowv=None, colv=None, rowseg=None, maskref=None, mask_scale=1.0, accumulate=False,
-         alpha=1.0, splits=None, tile=0, a_planes=None, b_planes=None, c_planes=None, c_planes_only=False, gate_wc=None, rng_row=None):
+         alpha=1.0, splits=None, tile=0, a_planes=None, b_planes=None, c_planes=None, c_planes_only=False, gate_wc=None, rng_row=None,
+         colsum=None):
     """C[M,N] = epilogue(alpha * op(A) op(B)); see include/advmil_hip.h::advmil_gemm_f32. a_planes / b_planes: optional
     Planes of A / B; c_planes: Planes to receive the split of the final C (pitch ldc)."""
     planes_only_a = A is None
@@ -524,6 +527,8 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
         e.c_hi, e.c_lo = c_planes.hi.data_ptr(), c_planes.lo.data_ptr()
     if gate_wc is not None:
         e.gate_wc, e.gate_out, e.gate_np = gate_wc.data_ptr(), gate_out.data_ptr(), npart
+    if colsum is not None:
+        e.colsum = colsum.data_ptr()
     if splits is None:
         ptile, splits = gemm_plan(M, N, K, a_kc, b_kc)
         if tile == 0:
@@ -868,6 +873,7 @@ class LinearActFn(torch.autograd.Function):
     """y = dropout(act(x W^T + b)); x[M,K], W[N,K]. Dropout index = m*N + n on stream `sid`."""
     last_planes = None       # planes of the y just produced (side channel to linear_act: Function outputs are re-wrapped)
     last_wants_dy_planes = False
+    last_act_fusable = None
 
     @staticmethod
     def forward(ctx, x, W, b, act, p, seed, sid, y0=None, rr=None, xpl=None, wpl=None, emit=False):
@@ -919,6 +925,15 @@ class LinearActFn(torch.autograd.Function):
             and not (b is not None and ctx.needs_input_grad[2]) and DG_PLANES_ONLY and DW_PLANES and get_gemm_mode() == "bf16x3"
             and ctx.xpl is not None and M >= 4096 and N % 8 == 0 and pre_a_tile_ok(gemm_plan(N, K, M, False, False)[0], False, False, True))
         LinearActFn.last_wants_dy_planes = ctx.wants_dy_planes
+        # a ReLU (+ dropout) slab layer without an input gradient whose dpre feeds the plane-fed weight gradient alone: the consumer of y
+        # (the gated-attention pool) may run this layer's activation / dropout backward in the epilogue of its own dh contraction
+        # (ops.ACT_BWD_FUSED) and hand dpre over as operand planes with the bias gradient already merged
+        ctx.act_fusable = bool(
+            ACT_BWD_IN_DH and not ctx.small and act == ACT_RELU and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]
+            and DG_PLANES_ONLY and DW_PLANES and get_gemm_mode() == "bf16x3" and ctx.xpl is not None and M >= 4096 and N % 8 == 0
+            and (not (b is not None and ctx.needs_input_grad[2]) or ctx.gb is not None)
+            and pre_a_tile_ok(gemm_plan(N, K, M, False, False)[0], False, False, True))
+        LinearActFn.last_act_fusable = (float(p), ctx.gb if (b is not None and ctx.needs_input_grad[2]) else None) if ctx.act_fusable else None
         return y
 
     @staticmethod
@@ -961,6 +976,16 @@ class LinearActFn(torch.autograd.Function):
             if need_b:
                 db = colsum(dy, M, N, out=ctx.gb)
         else:
+            ent = DY_PLANES.pop(dy.data_ptr(), None) if ctx.act_fusable else None
+            if ent is not None and ent[1] == (M, N) and len(ent) > 2 and ent[2] == "dpre":
+                # the consumer of y already applied this layer's activation / dropout backward in its dh contraction's epilogue: `dy` is a
+                # token, dpre arrives as operand planes, the bias gradient is merged: only the weight gradient is left
+                dpl, xpl0 = ent[0], ctx.xpl
+                if ctx.gW is not None:
+                    gemm(None, x, False, False, N, K, M, out=ctx.gW.view(N, K), ldc=K, accumulate=True, a_planes=dpl, b_planes=xpl0)
+                    return None, None, None, None, None, None, None, None, None, None, None, None
+                dW = gemm(None, x, False, False, N, K, M, a_planes=dpl, b_planes=xpl0).reshape(wshape)
+                return None, dW, None, None, None, None, None, None, None, None, None, None
             # slab layer whose input needs no gradient (the first layer): dpre is consumed by the weight-gradient contraction alone,
             # which splits it into hi + lo anyway -> written as planes only, and the contraction takes both operands pre-split
             xpl0 = ctx.xpl if (DW_PLANES and get_gemm_mode() == "bf16x3") else None
@@ -1104,6 +1129,9 @@ def linear_act(x, W, b, act="none", p=0.0, rng=None, tag="", emit_planes=False):
     if LinearActFn.last_wants_dy_planes:
         out._advmil_wants_dy_planes = True         # the LayerNorm backward behind this layer may hand dy over as operand planes only
     LinearActFn.last_wants_dy_planes = False
+    if LinearActFn.last_act_fusable is not None and out.requires_grad:
+        out._advmil_act_fusable = LinearActFn.last_act_fusable      # (dropout rate, bias-gradient slot | None): see GatedAttnPoolFn.backward
+    LinearActFn.last_act_fusable = None
     return out
 
 
@@ -1133,10 +1161,11 @@ class GatedAttnPoolFn(torch.autograd.Function):
     model/backbone.py:81-85) and GAPool (model/backbone_utils.py:47-56): the pooled tensor is the scored tensor in every use."""
 
     @staticmethod
-    def forward(ctx, h, Wa, ba, Wb, bb, wc, bc, p, seed, sa, sb, seg, nograd=False, rr=None, hpl=None):
+    def forward(ctx, h, Wa, ba, Wb, bb, wc, bc, p, seed, sa, sb, seg, nograd=False, rr=None, hpl=None, act_fuse=None):
         _chk(h, "h")
         h = h.contiguous()
         N, D = h.shape
+        ctx.act_fuse = act_fuse
         wcv = wc.detach().reshape(-1)
         if FUSED_GATE_SCORE and p <= 0.0 and N >= 4096 and nograd:
             # no-grad pass (the generator's eval forward of the discriminator update, test_model): nothing needs the [N, 2D] gate
@@ -1200,7 +1229,26 @@ class GatedAttnPoolFn(torch.autograd.Function):
         else:
             dG, dwc, dbc, dbias = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb, rng_row=rr, planes=gpl, planes_only=only)
         dh = None
-        if need_h:
+        fuse = ctx.act_fuse if (need_h and only and not dh_nt and ctx.act_fuse is not None) else None
+        if fuse is not None:
+            tile = gemm_plan(N, D, 2 * D, True, False)[0]
+            nrow = int(_lib.lib().advmil_gemm_f32_colsum_rows(tile, N, D)) if pre_a_tile_ok(tile, True, False) else 0
+            if nrow <= 0:
+                fuse = None
+        if fuse is not None:
+            # dpre = (dG Wab + A dpooled) * (h > 0 ? 1 / (1 - p) : 0) -- h is the first layer's stored (post-dropout) output, so the mask IS
+            # its ReLU and dropout backward -- written as operand planes only, its column sums (that layer's bias gradient) as per-wave
+            # partial rows merged into the arena slot: the row pass act_dropout_bwd over dh and h (0.11 ms at the 16-bag slab) is gone
+            p1, gb1 = fuse
+            dpl = Planes.alloc((N, D), h.device)
+            cws = _ws(nrow * D * 4, h.device) if gb1 is not None else None
+            gemm(None, Wab, True, False, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg, a_planes=gpl,
+                 maskref=h, mask_scale=1.0 / (1.0 - p1) if p1 > 0.0 else 1.0, c_planes=dpl, c_planes_only=True, colsum=cws, tile=tile)
+            if gb1 is not None:
+                _lib.check(_lib.lib().advmil_merge_partials(_p(cws), nrow, D, D, _p(gb1), 1, _stream()), "merge_partials")
+            dh = torch.empty(N, D, dtype=torch.float32, device=h.device)      # token: never written, never read
+            DY_PLANES[dh.data_ptr()] = (dpl, (N, D), "dpre")
+        elif need_h:
             # dG [N,2D] . Wab [2D,D]  +  A[n] * dpooled[bag(n), d]   (pooling's direct path, rank-1 per bag)
             if dh_nt:
                 WabT = Wab.t().contiguous()                                       # [D, 2D]: k (= 2D) contiguous
@@ -1210,7 +1258,7 @@ class GatedAttnPoolFn(torch.autograd.Function):
                 dh = gemm(None, Wab, True, False, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg, a_planes=gpl)
             else:
                 dh = gemm(dG, Wab, True, False, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg)
-        nones = (None,) * 8
+        nones = (None,) * 9
         apl = gpl if only else None
         if ctx.arena is not None:
             bpl = ctx.hpl if (apl is not None and gemm_plan_tn_planes(2 * D, D, N)[0]) else None
@@ -1234,7 +1282,8 @@ def gated_attn_pool(h, Wa, ba, Wb, bb, wc, bc, p=0.0, rng=None, tag="", seg=None
     nograd = not torch.is_grad_enabled() or not any(t.requires_grad for t in (h, Wa, ba, Wb, bb, wc, bc))
     hpl = planes_of(h) if (h.shape[0] >= 4096 and h.is_contiguous() and get_gemm_mode() == "bf16x3"
                            and gemm_plan_planes(h.shape[0], 2 * h.shape[1], h.shape[1])) else None
-    pooled, A, s = GatedAttnPoolFn.apply(h, Wa, ba, Wb, bb, wc, bc, float(p), seed, sa, sb, seg, nograd, rr, hpl)
+    pooled, A, s = GatedAttnPoolFn.apply(h, Wa, ba, Wb, bb, wc, bc, float(p), seed, sa, sb, seg, nograd, rr, hpl,
+                                         getattr(h, "_advmil_act_fusable", None))
     return (pooled[0] if seg is None else pooled), A, s
 
 

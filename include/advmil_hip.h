@@ -100,6 +100,11 @@ typedef struct {
   int64_t ldc2;
   int64_t n_split;
   const float* bias2;
+  /* Column sums of the FINAL values, one partial row per (row tile, wave row) of the launch: colsum[p * N + n], p < advmil_gemm_f32_colsum_rows
+   * (slab-sized bf16x3 tiles, whole tiles, splits = 1, no accumulate / dropout). With rowv + maskref in the same launch (rank-1 term, then
+   * the mask) this is the fused backward of the first layer behind the gated-attention pool: dpre = (dG Wab + A dpooled) * (y > 0 ?
+   * mask_scale : 0) and its bias gradient, instead of a separate pass over dh and y (model/backbone.py:79-86 autograd of ReLU + Dropout). */
+  float* colsum;
 } advmil_epilogue_t;
 
 size_t advmil_gemm_f32_workspace_bytes(int64_t M, int64_t N, int splits);
@@ -119,6 +124,10 @@ int advmil_gate_interleave(const float* Wa, const float* Wb, const float* ba, co
 int advmil_gate_partial_sum(const float* partial, int np, const float* bc, int64_t N, float* s, advmil_stream_t stream);
 /* column blocks a launch with this tile writes per row in gate-score mode (see advmil_epilogue_t.gate_wc) */
 int advmil_gemm_f32_gate_blocks(int tile, int64_t N);
+/* partial rows a launch with this tile writes into epilogue.colsum for an M x N result (0: no column-sum form for this tile / these extents) */
+int64_t advmil_gemm_f32_colsum_rows(int tile, int64_t M, int64_t N);
+/* out[c] (+)= sum_{b < nblk} partial[b * stride + c], c < ncols: the merge of per-workgroup partial rows (deferrable: advmil_defer_sums) */
+int advmil_merge_partials(const float* partial, int nblk, int64_t stride, int64_t ncols, float* out, int accumulate, advmil_stream_t stream);
 int advmil_set_gemm_mode(int mode);
 int advmil_get_gemm_mode(void);
 /* The library's launch plan for a shape: block tile (see below) and K split count. Host callers size the workspace

@@ -18,3 +18,4 @@ leg() {  # name, bench args
 leg 16 --steps 60
 leg 2 --steps 200 --bags 2
 leg 1 --steps 200 --bags 1
+if [ -n "$ESAT" ]; then leg esat32k --mode patch --patches 32768 --pool 16 --steps 12; fi
