@@ -1,0 +1,416 @@
+// Bag-level tail of the projection discriminator, the shipped widths (d = 128, hidden 64; reference config/cfg_nlst.yaml:40-52:
+// disc_netx_out_dim 128, disc_nety_hid_dims 64-128, label width 1) as a LATENCY-shaped single-workgroup kernel pair. tail.hip walks the
+// five layers one after the other and pays a global round trip (weights) per layer: 25-35 us per launch whatever B, no faster than the
+// launches it replaces (tools/probe/tail_time.py). Here
+//   * every global read of the pass -- inputs, saved activations, and each wave's weight FRAGMENTS for all its products -- is issued at
+//     the top of the kernel, before the first barrier: one memory round trip per launch instead of one per layer;
+//   * the two chains advance together: stage 1 = fc2[0] and the label layer 1, stage 2 = fc2[3] and the label layer 2 (forward); last
+//     layers, then first layers (backward): two dependent stages instead of four / five;
+//   * all 16 waves work in every stage: a product's inner dimension is split over waves (one 32 x 32 output block and 16-32 inner
+//     indices per wave: 8-16 v_mfma_f32_32x32x2_f32), the per-wave partial blocks meet in LDS and every output element is summed by one
+//     thread in a fixed order (deterministic).
+// Exact fp32 products (the 32x32x2 fp32 MFMA), dropout draws = the contraction epilogue's. Rows >= B of the 32-row block are zero.
+#include <cstdlib>
+#include "common.h"
+#include "../../include/advmil_hip.h"
+
+#define T3_D 128
+#define T3_H 64
+#define T3_NT 1024
+#define T3_PD (T3_D + 4)       // LDS row pitch of a [32][128] image
+#define T3_PH (T3_H + 4)       // ... of a [32][64] image
+
+struct Tail3Args {
+  advmil_dtail_t a;
+};
+
+// row b of a 32 x 32 MFMA accumulator block <-> (register r, lane half hi): b = (r & 3) + 8 (r >> 2) + 4 hi
+__device__ __forceinline__ int t3_r_of(int b) { return (b & 3) + 4 * (b >> 3); }
+__device__ __forceinline__ int t3_hi_of(int b) { return (b >> 2) & 1; }
+
+__device__ __forceinline__ float t3_keep(bool drop, uint64_t key, const int64_t* rng_row, int b, int B, int N, int n, float p, float inv) {
+  if (!drop) return 1.f;
+  return rng_keep(key, (uint64_t)(((rng_row && b < B) ? rng_row[b] : (int64_t)b) * N + n), p, inv);
+}
+
+__global__ __launch_bounds__(T3_NT) void dtail3_fwd_kernel(Tail3Args g) {
+  __shared__ __attribute__((aligned(16))) float sX[32 * T3_PD];        // emb_bag
+  __shared__ __attribute__((aligned(16))) float sH1[32 * T3_PH];       // fc2[0] output
+  __shared__ __attribute__((aligned(16))) float sT1[32 * T3_PH];       // label layer 1 output
+  __shared__ __attribute__((aligned(16))) float sHX[32 * T3_PD];       // fc2[3] output
+  __shared__ __attribute__((aligned(16))) float sHT[32 * T3_PD];       // label layer 2 output
+  __shared__ __attribute__((aligned(16))) float sPart[16][1024];       // per-wave partial blocks, C layout [r][lane]
+  __shared__ float sT[32];
+  const advmil_dtail_t& a = g.a;
+  const int B = a.B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, hi = lane >> 5;
+  const advmil_dense_layer_t &X0 = a.x[0], &X1 = a.x[1], &Y0 = a.y[0], &Y1 = a.y[1];
+  // ---- every global read of the launch, up front
+  // stage 1 fragments: fc2[0] (N = 64: 2 column blocks x 8 inner parts of 16)
+  const int cb1 = wave >> 3, pt1 = wave & 7;
+  float4 w1[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) w1[t] = *reinterpret_cast<const float4*>(X0.W + (int64_t)(cb1 * 32 + i) * T3_D + pt1 * 16 + t * 8 + hi * 4);
+  // stage 2 fragments: blocks 0-3 = fc2[3], 4-7 = label layer 2 (N = 128: 4 column blocks each) x 2 inner parts of 32
+  const int blk2 = wave >> 1, pt2 = wave & 1;
+  const advmil_dense_layer_t& L2 = blk2 < 4 ? X1 : Y1;
+  const int cb2 = blk2 & 3;
+  float4 w2[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) w2[t] = *reinterpret_cast<const float4*>(L2.W + (int64_t)(cb2 * 32 + i) * T3_H + pt2 * 32 + t * 8 + hi * 4);
+  // inputs
+  for (int o = tid; o < 32 * (T3_D / 4); o += T3_NT) {
+    const int b = o / (T3_D / 4), c = o % (T3_D / 4);
+    *reinterpret_cast<float4*>(sX + b * T3_PD + c * 4) =
+        b < B ? *reinterpret_cast<const float4*>(a.xin + (int64_t)b * T3_D + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (tid < 32) sT[tid] = tid < B ? a.tin[tid] : 0.f;
+  // label layer 1 (in width 1): element (b, n) = tid / 64 + 16 s, tid % 64
+  const int n1 = tid & 63;
+  const float wy = Y0.W[n1], by = Y0.bias ? Y0.bias[n1] : 0.f;
+  const bool dY0 = a.seed && Y0.drop_p > 0.f, dX0 = a.seed && X0.drop_p > 0.f, dY1 = a.seed && Y1.drop_p > 0.f, dX1 = a.seed && X1.drop_p > 0.f;
+  uint64_t kY0 = 0, kX0 = 0, kY1 = 0, kX1 = 0;
+  if (a.seed) {
+    const uint64_t sd = *a.seed;
+    kY0 = rng_key(sd, Y0.stream_id); kX0 = rng_key(sd, X0.stream_id); kY1 = rng_key(sd, Y1.stream_id); kX1 = rng_key(sd, X1.stream_id);
+  }
+  const float iY0 = dY0 ? hw_rcp(1.f - Y0.drop_p) : 1.f, iX0 = dX0 ? hw_rcp(1.f - X0.drop_p) : 1.f;
+  const float iY1 = dY1 ? hw_rcp(1.f - Y1.drop_p) : 1.f, iX1 = dX1 ? hw_rcp(1.f - X1.drop_p) : 1.f;
+  // head operands of this wave's rows (u = region-mean embedding; NULL: the x chain's output)
+  float uu[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, wp[2] = {0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int b = wave + 16 * s;
+    if (a.u && b < B) { uu[s][0] = a.u[(int64_t)b * T3_D + lane]; uu[s][1] = a.u[(int64_t)b * T3_D + 64 + lane]; }
+  }
+  if (a.prj_src) { wp[0] = a.w_prj[lane]; wp[1] = a.w_prj[64 + lane]; }
+  const float bx0 = X0.bias ? X0.bias[tid & 63] : 0.f;                 // stage-1 reduce: column tid % 64
+  const int n2 = tid & 127;                                            // stage-2 reduce: column tid % 128
+  const float bx1 = X1.bias ? X1.bias[n2] : 0.f, by1 = Y1.bias ? Y1.bias[n2] : 0.f;
+  __syncthreads();
+  // ---- stage 1: fc2[0] partial products; the label layer 1 elementwise
+  {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* xr = sX + i * T3_PD + pt1 * 16 + hi * 4;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float4 x4 = *reinterpret_cast<const float4*>(xr + t * 8);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x4.x, w1[t].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x4.y, w1[t].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x4.z, w1[t].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x4.w, w1[t].w, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sPart[wave][r * 64 + lane] = acc[r];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int b = (tid >> 6) + 16 * s;
+      float v = act_apply(Y0.act, sT[b] * wy + by) * t3_keep(dY0, kY0, a.rng_row, b, B, T3_H, n1, Y0.drop_p, iY0);
+      if (b >= B) v = 0.f;
+      sT1[b * T3_PH + n1] = v;
+      if (b < B) Y0.y[(int64_t)b * T3_H + n1] = v;
+    }
+  }
+  __syncthreads();
+  // ---- stage 1 reduce: h1[b][n] = dropout(act(sum over the 8 parts + bias)), 2 elements per thread
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int b = (tid >> 6) + 16 * s, n = tid & 63;
+    const int cb = n >> 5, idx = t3_r_of(b) * 64 + (n & 31) + 32 * t3_hi_of(b);
+    float v = 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) v += sPart[cb * 8 + p][idx];
+    v = act_apply(X0.act, v + bx0) * t3_keep(dX0, kX0, a.rng_row, b, B, T3_H, n, X0.drop_p, iX0);
+    if (b >= B) v = 0.f;
+    sH1[b * T3_PH + n] = v;
+    if (b < B) X0.y[(int64_t)b * T3_H + n] = v;
+  }
+  __syncthreads();
+  // ---- stage 2: fc2[3] (A = h1) and the label layer 2 (A = t1), inner 64 in 2 parts
+  {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* xr = (blk2 < 4 ? sH1 : sT1) + i * T3_PH + pt2 * 32 + hi * 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float4 x4 = *reinterpret_cast<const float4*>(xr + t * 8);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x4.x, w2[t].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x4.y, w2[t].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x4.z, w2[t].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x4.w, w2[t].w, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sPart[wave][r * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  // ---- stage 2 reduce: hx / ht [b][n], 4 rows per thread and layer
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int b = (tid >> 7) + 8 * s;
+    const int cb = n2 >> 5, idx = t3_r_of(b) * 64 + (n2 & 31) + 32 * t3_hi_of(b);
+    float vx = sPart[cb * 2][idx] + sPart[cb * 2 + 1][idx];
+    float vt = sPart[(4 + cb) * 2][idx] + sPart[(4 + cb) * 2 + 1][idx];
+    vx = act_apply(X1.act, vx + bx1) * t3_keep(dX1, kX1, a.rng_row, b, B, T3_D, n2, X1.drop_p, iX1);
+    vt = act_apply(Y1.act, vt + by1) * t3_keep(dY1, kY1, a.rng_row, b, B, T3_D, n2, Y1.drop_p, iY1);
+    if (b >= B) { vx = 0.f; vt = 0.f; }
+    sHX[b * T3_PD + n2] = vx;
+    sHT[b * T3_PD + n2] = vt;
+    if (b < B) { X1.y[(int64_t)b * T3_D + n2] = vx; Y1.y[(int64_t)b * T3_D + n2] = vt; }
+  }
+  __syncthreads();
+  // ---- head: out[b] = <u, ht> + <src, w> + bias, one wave per row
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int b = wave + 16 * s;
+    if (b >= B) break;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int j = lane + 64 * c;
+      const float hxv = sHX[b * T3_PD + j], htv = sHT[b * T3_PD + j];
+      acc += (a.u ? uu[s][c] : hxv) * htv;
+      if (a.prj_src == 1) acc += hxv * wp[c];
+      else if (a.prj_src == 2) acc += htv * wp[c];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) a.out[b] = acc + ((a.prj_src && a.b_prj) ? a.b_prj[0] : 0.f);
+  }
+}
+
+// one 32 x 32 block of dW[n][k] += sum_b dpre[b][n] in[b][k] (16 MFMA steps over the 32 rows), added into the arena
+__device__ __forceinline__ void t3_dw_block(const float* __restrict__ dp, int pn, const float* __restrict__ in, int pk, int n0, int k0, int K,
+                                            float* __restrict__ dW, int lane) {
+  const int i = lane & 31, hi = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float* ap = dp + hi * pn + n0 + i;
+  const float* bp = in + hi * pk + k0 + i;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s * pn], bp[2 * s * pk], acc, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+    dW[(int64_t)n * K + k0 + i] += acc[r];
+  }
+}
+
+__global__ __launch_bounds__(T3_NT) void dtail3_bwd_kernel(Tail3Args g) {
+  __shared__ __attribute__((aligned(16))) float sX[32 * T3_PD];        // emb_bag (input of fc2[0])
+  __shared__ __attribute__((aligned(16))) float sH1[32 * T3_PH];       // fc2[0] output (input of fc2[3])
+  __shared__ __attribute__((aligned(16))) float sT1[32 * T3_PH];       // label layer 1 output (input of layer 2)
+  __shared__ __attribute__((aligned(16))) float sDX[32 * T3_PD];       // d hx = dpre of fc2[3]
+  __shared__ __attribute__((aligned(16))) float sDT[32 * T3_PD];       // d ht -> dpre of the label layer 2
+  __shared__ __attribute__((aligned(16))) float sD1[32 * T3_PH];       // dpre of fc2[0]
+  __shared__ __attribute__((aligned(16))) float sE1[32 * T3_PH];       // dpre of the label layer 1
+  __shared__ __attribute__((aligned(16))) float sPart[16][1024];
+  __shared__ float sT[32], sG[32];
+  const advmil_dtail_t& a = g.a;
+  const int B = a.B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, hi = lane >> 5;
+  const advmil_dense_layer_t &X0 = a.x[0], &X1 = a.x[1], &Y0 = a.y[0], &Y1 = a.y[1];
+  const bool wantX = a.dxin != nullptr || X0.dW || X0.dbias || X1.dW || X1.dbias;      // anything of the x chain wanted at all
+  // ---- every global read of the launch, up front
+  // phase A input gradients: d h1 = dpx2 W_fc2[3] (blocks 0-1), d t1 = dpy2 W_y2 (blocks 2-3): 32 output columns x 4 inner parts of 32
+  const int blkA = wave >> 2, ptA = wave & 3;
+  const advmil_dense_layer_t& LA = blkA < 2 ? X1 : Y1;
+  const int kbA = blkA & 1;
+  float wa[4][4];
+  const bool doA = blkA >= 2 || wantX;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wa[t][u] = doA ? LA.W[(int64_t)(ptA * 32 + t * 8 + hi * 4 + u) * T3_H + kbA * 32 + i] : 0.f;
+  // phase B input gradient: d emb_bag = dpx1 W_fc2[0]: 4 output column blocks x 4 inner parts of 16
+  const int kbB = wave >> 2, ptB = wave & 3;
+  float wb[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wb[t][u] = a.dxin ? X0.W[(int64_t)(ptB * 16 + t * 8 + hi * 4 + u) * T3_D + kbB * 32 + i] : 0.f;
+  for (int o = tid; o < 32 * (T3_D / 4); o += T3_NT) {
+    const int b = o / (T3_D / 4), c = o % (T3_D / 4);
+    *reinterpret_cast<float4*>(sX + b * T3_PD + c * 4) =
+        (b < B && wantX) ? *reinterpret_cast<const float4*>(a.xin + (int64_t)b * T3_D + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int o = tid; o < 32 * (T3_H / 4); o += T3_NT) {
+    const int b = o / (T3_H / 4), c = o % (T3_H / 4);
+    *reinterpret_cast<float4*>(sH1 + b * T3_PH + c * 4) =
+        b < B ? *reinterpret_cast<const float4*>(X0.y + (int64_t)b * T3_H + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(sT1 + b * T3_PH + c * 4) =
+        b < B ? *reinterpret_cast<const float4*>(Y0.y + (int64_t)b * T3_H + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (tid < 32) { sT[tid] = tid < B ? a.tin[tid] : 0.f; sG[tid] = tid < B ? a.dout[tid] : 0.f; }
+  const int n2 = tid & 127;
+  float hxv[4], htv[4], uv[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int b = (tid >> 7) + 8 * s;
+    const int64_t go = (int64_t)b * T3_D + n2;
+    hxv[s] = b < B ? X1.y[go] : 0.f;
+    htv[s] = b < B ? Y1.y[go] : 0.f;
+    uv[s] = (a.u && b < B) ? a.u[go] : 0.f;
+  }
+  const float wpj = a.prj_src ? a.w_prj[n2] : 0.f;
+  const float wy = Y0.W[tid & 63];
+  const bool dY0 = a.seed && Y0.drop_p > 0.f, dX0 = a.seed && X0.drop_p > 0.f, dY1 = a.seed && Y1.drop_p > 0.f, dX1 = a.seed && X1.drop_p > 0.f;
+  uint64_t kY0 = 0, kX0 = 0, kY1 = 0, kX1 = 0;
+  if (a.seed) {
+    const uint64_t sd = *a.seed;
+    kY0 = rng_key(sd, Y0.stream_id); kX0 = rng_key(sd, X0.stream_id); kY1 = rng_key(sd, Y1.stream_id); kX1 = rng_key(sd, X1.stream_id);
+  }
+  const float iY0 = dY0 ? hw_rcp(1.f - Y0.drop_p) : 1.f, iX0 = dX0 ? hw_rcp(1.f - X0.drop_p) : 1.f;
+  const float iY1 = dY1 ? hw_rcp(1.f - Y1.drop_p) : 1.f, iX1 = dX1 ? hw_rcp(1.f - X1.drop_p) : 1.f;
+  __syncthreads();
+  // ---- head + the last layers' activation backward: dpx2 [b][n] (fc2[3]), dpy2 [b][n] (label layer 2); d u out; prj gradients
+  {
+    float swp = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int b = (tid >> 7) + 8 * s;
+      const float gb = sG[b];
+      const float uu = a.u ? uv[s] : hxv[s];
+      float dt_ = gb * uu, dx_ = a.u ? 0.f : gb * htv[s];
+      if (a.prj_src == 1) { dx_ += gb * wpj; swp += gb * hxv[s]; }
+      else if (a.prj_src == 2) { dt_ += gb * wpj; swp += gb * htv[s]; }
+      if (a.u && a.du && b < B) a.du[(int64_t)b * T3_D + n2] = gb * htv[s];
+      // dpre = d out * keep * act'(out undone of the dropout scale)
+      const float fx = t3_keep(dX1, kX1, a.rng_row, b, B, T3_D, n2, X1.drop_p, iX1), ft = t3_keep(dY1, kY1, a.rng_row, b, B, T3_D, n2, Y1.drop_p, iY1);
+      dx_ = dx_ * fx * act_grad_from_out(X1.act, hxv[s] * (dX1 ? 1.f - X1.drop_p : 1.f));
+      dt_ = dt_ * ft * act_grad_from_out(Y1.act, htv[s] * (dY1 ? 1.f - Y1.drop_p : 1.f));
+      if (b >= B) { dx_ = 0.f; dt_ = 0.f; }
+      sDX[b * T3_PD + n2] = dx_;
+      sDT[b * T3_PD + n2] = dt_;
+    }
+    // d w_prj[j] = sum_b g[b] src[b][j]: the 8 row groups (tid >> 7) of column n2 meet in sPart
+    if (a.prj_src && a.dw_prj) sPart[tid >> 7][n2] = swp;
+  }
+  __syncthreads();
+  if (a.prj_src && a.dw_prj && tid < T3_D) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s += sPart[r][tid];
+    a.dw_prj[tid] += s;
+  }
+  if (a.prj_src && a.db_prj && tid == 0) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += sG[b];
+    a.db_prj[0] += s;
+  }
+  // bias gradients of the last layers
+  if (tid < T3_D) {
+    if (X1.dbias) { float s = 0.f; for (int b = 0; b < B; ++b) s += sDX[b * T3_PD + tid]; X1.dbias[tid] += s; }
+  } else if (tid < 2 * T3_D) {
+    const int n = tid - T3_D;
+    if (Y1.dbias) { float s = 0.f; for (int b = 0; b < B; ++b) s += sDT[b * T3_PD + n]; Y1.dbias[n] += s; }
+  }
+  __syncthreads();          // (sPart is reused below)
+  // ---- phase A: weight gradients of the last layers (16 blocks of 32 x 32), then the input gradients' partial products
+  {
+    const int nb = (wave & 7) >> 1, kb = wave & 1;             // waves 0-7: fc2[3] [128][64], waves 8-15: label layer 2 [128][64]
+    if (wave < 8) { if (X1.dW) t3_dw_block(sDX, T3_PD, sH1, T3_PH, nb * 32, kb * 32, T3_H, X1.dW, lane); }
+    else { if (Y1.dW) t3_dw_block(sDT, T3_PD, sT1, T3_PH, nb * 32, kb * 32, T3_H, Y1.dW, lane); }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (doA) {
+      const float* ap = (blkA < 2 ? sDX : sDT) + i * T3_PD + ptA * 32 + hi * 4;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float4 a4 = *reinterpret_cast<const float4*>(ap + t * 8);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, wa[t][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, wa[t][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, wa[t][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, wa[t][3], acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sPart[wave][r * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  // ---- reduce: d h1 / d t1 [b][k] (k < 64), then the first layers' activation backward -> dpx1, dpy1
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int b = (tid >> 6) + 16 * s, k = tid & 63;
+    const int kb = k >> 5, idx = t3_r_of(b) * 64 + (k & 31) + 32 * t3_hi_of(b);
+    float dh = 0.f, dt1 = 0.f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { dh += sPart[kb * 4 + p][idx]; dt1 += sPart[(2 + kb) * 4 + p][idx]; }
+    const float h1 = sH1[b * T3_PH + k], t1 = sT1[b * T3_PH + k];
+    const float fx = t3_keep(dX0, kX0, a.rng_row, b, B, T3_H, k, X0.drop_p, iX0), ft = t3_keep(dY0, kY0, a.rng_row, b, B, T3_H, k, Y0.drop_p, iY0);
+    float d1 = dh * fx * act_grad_from_out(X0.act, h1 * (dX0 ? 1.f - X0.drop_p : 1.f));
+    float e1 = dt1 * ft * act_grad_from_out(Y0.act, t1 * (dY0 ? 1.f - Y0.drop_p : 1.f));
+    if (b >= B) { d1 = 0.f; e1 = 0.f; }
+    sD1[b * T3_PH + k] = d1;
+    sE1[b * T3_PH + k] = e1;
+  }
+  __syncthreads();
+  // ---- phase B: first layers. Bias / width-1 weight gradients by threads, fc2[0]'s weight gradient and d emb_bag by waves
+  if (tid < T3_H) {
+    if (X0.dbias) { float s = 0.f; for (int b = 0; b < B; ++b) s += sD1[b * T3_PH + tid]; X0.dbias[tid] += s; }
+  } else if (tid < 2 * T3_H) {
+    const int n = tid - T3_H;
+    float sb = 0.f, sw = 0.f;
+    for (int b = 0; b < B; ++b) { const float e = sE1[b * T3_PH + n]; sb += e; sw += e * sT[b]; }
+    if (Y0.dbias) Y0.dbias[n] += sb;
+    if (Y0.dW) Y0.dW[n] += sw;                 // label layer 1: W [64][1]
+  }
+  if (a.dtin) {                                // d t[b] = sum_n dpy1[b][n] W_y1[n]: one wave per row
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int b = wave + 16 * s;
+      if (b < B) {
+        const float v = wave_sum(sE1[b * T3_PH + lane] * wy);
+        if (lane == 0) a.dtin[b] = v;
+      }
+    }
+  }
+  if (wave < 8 && X0.dW) t3_dw_block(sD1, T3_PH, sX, T3_PD, (wave >> 2) * 32, (wave & 3) * 32, T3_D, X0.dW, lane);      // [64][128]: 2 x 4 blocks
+  if (!a.dxin) return;
+  {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* ap = sD1 + i * T3_PH + ptB * 16 + hi * 4;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float4 a4 = *reinterpret_cast<const float4*>(ap + t * 8);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, wb[t][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, wb[t][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, wb[t][2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, wb[t][3], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sPart[wave][r * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int b = (tid >> 7) + 8 * s;
+    if (b >= B) continue;
+    const int kb = n2 >> 5, idx = t3_r_of(b) * 64 + (n2 & 31) + 32 * t3_hi_of(b);
+    a.dxin[(int64_t)b * T3_D + n2] = (sPart[kb * 4][idx] + sPart[kb * 4 + 1][idx]) + (sPart[kb * 4 + 2][idx] + sPart[kb * 4 + 3][idx]);
+  }
+}
+
+// Does this call have the shape the latency-shaped pair is built for?
+static bool tail3_fits(const advmil_dtail_t* a) {
+  if (a->nx != 2 || a->ny != 2) return false;
+  const advmil_dense_layer_t &X0 = a->x[0], &X1 = a->x[1], &Y0 = a->y[0], &Y1 = a->y[1];
+  return X0.K == T3_D && X0.N == T3_H && X1.K == T3_H && X1.N == T3_D && Y0.K == 1 && Y0.N == T3_H && Y1.K == T3_H && Y1.N == T3_D &&
+         !((((uintptr_t)a->xin) | ((uintptr_t)X0.W) | ((uintptr_t)X1.W) | ((uintptr_t)Y1.W) | ((uintptr_t)X0.y) | ((uintptr_t)Y0.y)) & 15);
+}
+
+int advmil_dtail3_try(const advmil_dtail_t* a, bool bwd, hipStream_t stream) {
+  static const bool off = []() { const char* e = getenv("ADVMIL_DTAIL3"); return e && e[0] == '0'; }();
+  if (off || !tail3_fits(a)) return 1;       // not taken
+  Tail3Args g;
+  g.a = *a;
+  if (bwd) hipLaunchKernelGGL(dtail3_bwd_kernel, dim3(1), dim3(T3_NT), 0, stream, g);
+  else hipLaunchKernelGGL(dtail3_fwd_kernel, dim3(1), dim3(T3_NT), 0, stream, g);
+  hipError_t e_ = hipGetLastError();
+  return e_ == hipSuccess ? 0 : -(int)e_ - 1000;
+}

@@ -1897,7 +1897,7 @@ def prj_head(u, t, src=None, W=None, b=None):
 # ---------------------------------------------------------------------------------------
 # the discriminator's bag-level tail as one launch each way (advmil_dtail_fwd / advmil_dtail_bwd, csrc/tail.hip)
 # ---------------------------------------------------------------------------------------
-DTAIL = os.environ.get("ADVMIL_DTAIL", "0") != "0"
+DTAIL = os.environ.get("ADVMIL_DTAIL", "1") != "0"
 
 
 class TailSpec:
@@ -1931,23 +1931,28 @@ def dtail_ok(B, spec):
     return True
 
 
-def _fill_tail(dt, B, spec, ys_x, ys_y, xin, tin, u, grads):
+def _fill_tail(dt, B, spec, ys_x, ys_y, xin, tin, u, slots):
+    """slots: None (forward), or the gradient-arena slot of every parameter in spec.params() order (None = not wanted), as they
+    stood when the FORWARD ran -- a discriminator frozen for the generator update (requires_grad off around the forward) stays frozen
+    in the backward even though the flags are back on by then."""
     dt.B, dt.nx, dt.ny, dt.prj_src = B, len(spec.x), len(spec.y), spec.prj_src
     dt.xin, dt.tin = xin.data_ptr(), tin.data_ptr()
     dt.u = None if u is None else u.data_ptr()
+    k = 0
     for arr, layers, ys in ((dt.x, spec.x, ys_x), (dt.y, spec.y, ys_y)):
         for i, ((W, b, act, p, sid), yb) in enumerate(zip(layers, ys)):
             L = arr[i]
             L.W, L.bias = W.data_ptr(), (None if b is None else b.data_ptr())
             L.y, L.K, L.N, L.act, L.drop_p, L.stream_id = yb.data_ptr(), W.shape[1], W.shape[0], act, float(p), sid
-            gW = _arena_grad(W) if grads else None
-            gb = _arena_grad(b) if (grads and b is not None) else None
+            gW = slots[k] if slots is not None else None
+            gb = slots[k + 1] if slots is not None else None
+            k += 2
             L.dW, L.dbias = (None if gW is None else gW.data_ptr()), (None if gb is None else gb.data_ptr())
     if spec.prj_src:
         dt.w_prj = spec.prj_w.data_ptr()
         dt.b_prj = None if spec.prj_b is None else spec.prj_b.data_ptr()
-        gw = _arena_grad(spec.prj_w) if grads else None
-        gb = _arena_grad(spec.prj_b) if (grads and spec.prj_b is not None) else None
+        gw = slots[k] if slots is not None else None
+        gb = slots[k + 1] if slots is not None else None
         dt.dw_prj, dt.db_prj = (None if gw is None else gw.data_ptr()), (None if gb is None else gb.data_ptr())
     dt.seed = None if spec.seed is None else spec.seed.data_ptr()
     dt.rng_row = None if spec.rr is None else spec.rr.data_ptr()
@@ -1965,8 +1970,9 @@ class DTailFn(torch.autograd.Function):
         ys_y = [torch.empty(B, W.shape[0], dtype=torch.float32, device=dev) for (W, _, _, _, _) in spec.y]
         out = torch.empty(B, 1, dtype=torch.float32, device=dev)
         dt = _lib.DTail()
-        _fill_tail(dt, B, spec, ys_x, ys_y, eb, t, im_, False)
+        _fill_tail(dt, B, spec, ys_x, ys_y, eb, t, im_, None)
         dt.out = out.data_ptr()
+        ctx.slots = [(_arena_grad(p) if (p is not None and ctx.needs_input_grad[4 + j]) else None) for j, p in enumerate(spec.params())]
         _lib.check(_lib.lib().advmil_dtail_fwd(ctypes.byref(dt), _stream()), "dtail_fwd")
         ctx.spec, ctx.B = spec, B
         ctx.nx = len(ys_x)
@@ -1990,7 +1996,7 @@ class DTailFn(torch.autograd.Function):
         dim_ = torch.empty_like(im_) if need_im else None
         dt_ = torch.empty_like(t) if need_t else None
         dt = _lib.DTail()
-        _fill_tail(dt, B, spec, ys_x, ys_y, eb, t, im_, True)
+        _fill_tail(dt, B, spec, ys_x, ys_y, eb, t, im_, ctx.slots)
         dt.dout = dout.data_ptr()
         dt.dxin = None if deb is None else deb.data_ptr()
         dt.du = None if dim_ is None else dim_.data_ptr()

@@ -13,7 +13,7 @@ from tests.test_parity_gpu import DEV, build_disc, load_synth
 pytestmark = pytest.mark.gpu
 
 
-def _run(iprd, prj, B, fused, p_y=0.3, frozen=False, seed=11):
+def _run(iprd, prj, B, fused, p_y=0.3, frozen=False, seed=11, thaw=False):
     old = ops.DTAIL
     ops.DTAIL = fused
     try:
@@ -36,6 +36,9 @@ def _run(iprd, prj, B, fused, p_y=0.3, frozen=False, seed=11):
             for p in d.parameters():
                 p.requires_grad_(False)
         f = d.tail(eb, im if iprd == "instance" else None, t)
+        if frozen and thaw:                  # the handler's generator update: the flags are back on before backward() runs (model_handler.py:409)
+            for p in d.parameters():
+                p.requires_grad_(True)
         w = torch.linspace(0.5, 1.5, B, device=DEV).reshape(B, 1)
         (f * w).sum().backward()
         torch.cuda.synchronize()
@@ -119,9 +122,11 @@ def test_fused_tail_equals_the_layer_by_layer_path(iprd, prj):
             _close(a["grads"][k], b["grads"][k], 5e-6, k)
 
 
-def test_fused_tail_with_frozen_discriminator_returns_only_the_label_gradient():
-    """The generator update: D's parameters are frozen, nothing of D(x) is differentiated; only d f / d pred leaves the tail."""
-    a, b = _run("instance", "x", 16, True, frozen=True), _run("instance", "x", 16, False, frozen=True)
+@pytest.mark.parametrize("thaw", [False, True])
+def test_fused_tail_with_frozen_discriminator_returns_only_the_label_gradient(thaw):
+    """The generator update: D's parameters are frozen around the FORWARD, nothing of D(x) is differentiated; only d f / d pred leaves the
+    tail -- also when requires_grad is back on by the time the backward runs."""
+    a, b = _run("instance", "x", 16, True, frozen=True, thaw=thaw), _run("instance", "x", 16, False, frozen=True, thaw=thaw)
     _close(a["f"], b["f"], 2e-6, "f")
     _close(a["dt"], b["dt"], 5e-6, "dt")
     assert a["deb"] is None and all(g is None or float(g.abs().max()) == 0.0 for g in a["grads"].values())
