@@ -27,7 +27,7 @@ class Epilogue(ctypes.Structure):
                 ("maskref", c_void_p), ("ldmask", c_int), ("mask_scale", c_float), ("accumulate", c_int),
                 ("alpha", c_float), ("a_hi", c_void_p), ("a_lo", c_void_p), ("b_hi", c_void_p), ("b_lo", c_void_p),
                 ("c_hi", c_void_p), ("c_lo", c_void_p), ("gate_wc", c_void_p), ("gate_out", c_void_p), ("gate_np", c_int),
-                ("rng_row", c_void_p), ("c2", c_void_p), ("ldc2", c_int64), ("n_split", c_int64), ("bias2", c_void_p), ("colsum", c_void_p)]
+                ("rng_row", c_void_p), ("c2", c_void_p), ("ldc2", c_int64), ("n_split", c_int64), ("bias2", c_void_p), ("colsum", c_void_p), ("maskbits", c_void_p), ("ldbits", c_int64)]
 
 
 class DenseLayer(ctypes.Structure):
@@ -95,7 +95,7 @@ SIGNATURES = {
                                 c_void_p]),
     "advmil_colsum_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "advmil_act_dropout_bwd": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_uint64, c_int64, c_int64, c_void_p,
-                                       c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                       c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "advmil_colsum": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "advmil_ln_relu_mean16_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int64, c_void_p, c_void_p,
                                           c_void_p, c_void_p]),

@@ -279,7 +279,7 @@ struct OperandStage {
 // accumulator tile goes through a per-wave LDS patch ([32][36] floats, carved from the operand buffers) so that the math below runs
 // once per float4 in a compact loop and the global stores are 16 B per lane along the row.
 // Per-wave LDS area of the epilogue: the [32][36] accumulator patch + the streaming form's column / row side data.
-#define EPI_WAVE_FLOATS(TM, TN) (32 * PITCH_KC + 32 * ((TN) + 2 * (TM)))
+#define EPI_WAVE_FLOATS(TM, TN) (32 * PITCH_KC + 32 * ((TN) + 2 * (TM)) + 32 * (TM) * (TN))      // patch | bias, row data | mask words
 
 // Streaming form of the epilogue for launches that cover M and N with whole tiles (M % tile height == 0, N % tile width == 0, one
 // activation per 32 columns, 16-byte aligned operands, at most one of the rank-1 / mask / accumulate modes).
@@ -309,6 +309,7 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
   // dropout backward rides in this epilogue instead of a row pass of its own): a second prefetched per-element operand
   const bool rmask = !PLAIN && kind == 1 && e.maskref != nullptr;
   const bool csum = !PLAIN && e.colsum != nullptr;      // per-wave column sums of the final values (the bias gradient of that layer)
+  const bool bmask = !PLAIN && e.maskbits != nullptr;   // the mask as bits: the wave's words are parked in LDS, no load in the store loop
   const float* const xbase = kind == 1 ? e.colv : (kind == 2 ? e.maskref : out);
   const int64_t xld = kind == 1 ? N : (kind == 2 ? (int64_t)e.ldmask : ldo);
   const int64_t rbase = m0 + wr * 32 * TM, cbase = n0 + wc * 32 * TN;
@@ -317,6 +318,18 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
   float* const sbias = patch + 32 * PITCH_KC;
   int* const srow_i = reinterpret_cast<int*>(sbias + 32 * TN);
   float* const srow_f = sbias + 32 * TN + 32 * TM;
+  uint32_t* const smask = reinterpret_cast<uint32_t*>(sbias + 32 * TN + 64 * TM);      // [32 TM rows][TN words]
+  if (bmask) {
+    uint32_t mv[(32 * TM * TN + 63) / 64];
+#pragma unroll
+    for (int u = 0; u < (32 * TM * TN + 63) / 64; ++u) {
+      const int idx = u * 64 + lane;
+      mv[u] = idx < 32 * TM * TN ? e.maskbits[(rbase + idx / TN) * e.ldbits + (cbase >> 5) + idx % TN] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < (32 * TM * TN + 63) / 64; ++u)
+      if (u * 64 + lane < 32 * TM * TN) smask[u * 64 + lane] = mv[u];
+  }
   {
     float bv[(32 * TN + 63) / 64];
     int iv[(32 * TM + 63) / 64];
@@ -380,7 +393,7 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
       WAVE_LDS_SYNC();   // the reads have landed: the next sub-tile may overwrite the patch
       const int act = cbase + b * 32 < e.act_split ? e.act0 : e.act1;
       const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-      if (!drop && kind == 0) {
+      if (!drop && kind == 0 && !bmask) {
         // plain bias + activation (the forward layers): the launch-uniform tests are taken once per sub-tile, not once per element
         // (16 elements x 5 scalar branches per sub-tile made this path 1.6x slower than its stores alone, tools/probe/store_probe.hip)
         const float al = e.alpha;
@@ -405,7 +418,7 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
 #pragma unroll
             for (int t = 0; t < 4; ++t) res[q][t] = act_apply(ACT_SIGMOID, res[q][t] * al + bb[t]);
         }
-      } else if (!drop && kind == 1 && act == ACT_NONE && !rmask) {
+      } else if (!drop && kind == 1 && act == ACT_NONE && !rmask && !bmask) {
         // rank-1 term per bag (dh = dG Wab + A[n] dpooled[bag(n)]), no activation
         const float al = e.alpha;
 #pragma unroll
@@ -415,7 +428,18 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
 #pragma unroll
           for (int t = 0; t < 4; ++t) res[q][t] = res[q][t] * al + bb[t] + r1 * xe[t];
         }
-      } else if (drop && kind == 0 && (act == ACT_RELU || act == ACT_NONE)) {
+      } else if (!drop && kind == 1 && act == ACT_NONE && !rmask && bmask) {
+        // ... and the bit mask behind it (the first layer's ReLU / dropout backward): same loop, one LDS word per row
+        const float al = e.alpha, ms = e.mask_scale;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float r1 = srow_f[a * 32 + q * 8 + rq];
+          const uint32_t mw = smask[(a * 32 + q * 8 + rq) * TN + b] >> c4;
+          const float xe[4] = {ext[q].x, ext[q].y, ext[q].z, ext[q].w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) res[q][t] = ((mw >> t) & 1u) ? (res[q][t] * al + bb[t] + r1 * xe[t]) * ms : 0.0f;
+        }
+      } else if (drop && kind == 0 && !bmask && (act == ACT_RELU || act == ACT_NONE)) {
         // (ReLU +) dropout from the counter RNG (train-mode forward layers)
         const float al = e.alpha;
         const bool relu = act == ACT_RELU;
@@ -449,6 +473,11 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
           const float me[4] = {ext2[q].x, ext2[q].y, ext2[q].z, ext2[q].w};
 #pragma unroll
           for (int t = 0; t < 4; ++t) res[q][t] *= (me[t] > 0.0f ? e.mask_scale : 0.0f);
+        }
+        if (bmask) {
+          const uint32_t mw = smask[(a * 32 + q * 8 + rq) * TN + b] >> c4;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) res[q][t] *= ((mw >> t) & 1u) ? e.mask_scale : 0.0f;
         }
       }
       if (csum) {
@@ -1446,6 +1475,16 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
     if (planes_usable(epi->b_hi, epi->b_lo, ldb, b_kc ? K : N)) pre |= 2;
   }
   if ((epi->c_hi != nullptr) != (epi->c_lo != nullptr)) return ADVMIL_EINVAL;
+  if (epi->maskbits) {    // the bit mask is read by the streaming epilogue only
+    int tm_, tn_, wr_, wc_;
+    if (g_gemm_mode != 1 || splits != 1 || !tile_geom(tile, tm_, tn_, wr_, wc_) || tm_ * tn_ < 4 || epi->gate_wc || epi->maskref || epi->accumulate ||
+        (M % (32 * tm_ * wr_)) || (N % (32 * tn_ * wc_)) || (epi->act_split & 31) || epi->ldbits < N / 32 || (epi->seed && epi->drop_p > 0.0f && epi->rowv && epi->rng_row))
+      return ADVMIL_EINVAL;
+    // (everything else the streaming form asks for: a launch that fell back to the generic epilogue would silently ignore the bits)
+    if ((C && ((((uintptr_t)C) & 15) || (ldc & 3))) || (((uintptr_t)epi->bias) & 15) || (epi->rowv && (((uintptr_t)epi->colv) & 15)) ||
+        (epi->c_hi && ((((uintptr_t)epi->c_hi) | ((uintptr_t)epi->c_lo)) & 7)) || epi->c2)
+      return ADVMIL_EINVAL;
+  }
   if (epi->colsum) {      // per-wave column sums come out of the streaming epilogue only: whole tiles of a slab-sized tile, one pass
     int tm_, tn_, wr_, wc_;
     if (g_gemm_mode != 1 || splits != 1 || !tile_geom(tile, tm_, tn_, wr_, wc_) || tm_ * tn_ < 4 || epi->gate_wc || epi->accumulate ||

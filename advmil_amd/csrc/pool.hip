@@ -842,7 +842,8 @@ __global__ __launch_bounds__(256) void act_dropout_bwd_kernel(const float* __res
                                                               int64_t M, int64_t N, int64_t c0, int64_t W,
                                                               float* __restrict__ dpre, float* __restrict__ partial,
                                                               int64_t pstride, int rpb, const int64_t* __restrict__ rng_row,
-                                                              bf16raw* __restrict__ o_hi, bf16raw* __restrict__ o_lo, int direct) {
+                                                              bf16raw* __restrict__ o_hi, bf16raw* __restrict__ o_lo, int direct,
+                                                              uint32_t* __restrict__ bits) {
   __shared__ __attribute__((aligned(16))) float red[1024];
   const RowColMap m = make_map(W);
   const bool drop = seed && p > 0.f;
@@ -877,6 +878,14 @@ __global__ __launch_bounds__(256) void act_dropout_bwd_kernel(const float* __res
         *reinterpret_cast<uint2*>(o_hi + off) = hh;
         *reinterpret_cast<uint2*>(o_lo + off) = ll;
       }
+      if (bits) {
+        // (o > 0) as one bit per element, 32 columns per word: the 8 lanes of a word (host: W % 32 == 0, whole row groups per wave)
+        // fold their nibbles with three exchanges. Consumed by the contraction epilogue's bit mask (advmil_epilogue_t.maskbits).
+        uint32_t w = ((o[0] > 0.f) ? 1u : 0u) | ((o[1] > 0.f) ? 2u : 0u) | ((o[2] > 0.f) ? 4u : 0u) | ((o[3] > 0.f) ? 8u : 0u);
+        w <<= 4 * (m.c4 & 7);
+        w |= __shfl_xor(w, 1, 64); w |= __shfl_xor(w, 2, 64); w |= __shfl_xor(w, 4, 64);
+        if ((m.c4 & 7) == 0) bits[row * (N >> 5) + ((c0 + m.c4 * 4) >> 5)] = w;
+      }
       sum.x += o[0]; sum.y += o[1]; sum.z += o[2]; sum.w += o[3];
     }
   }
@@ -898,10 +907,12 @@ extern "C" size_t advmil_colsum_workspace_bytes(int64_t M, int64_t N) {
 
 extern "C" int advmil_act_dropout_bwd(const float* dy, const float* y, int act, float drop_p, const uint64_t* seed,
                                       uint64_t stream_id, int64_t M, int64_t N, float* dpre, float* dbias, int accumulate,
-                                      const int64_t* rng_row, void* out_hi, void* out_lo, void* ws, size_t ws_bytes,
+                                      const int64_t* rng_row, void* out_hi, void* out_lo, void* bits, void* ws, size_t ws_bytes,
                                       advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!dy || !y || (!dpre && !out_hi) || M <= 0 || N <= 0 || (N & 3) || ((out_hi != nullptr) != (out_lo != nullptr))) return ADVMIL_EINVAL;
+  // bit output: the 8 lanes of a word sit in one wave and one row when a row is a multiple of 32 columns (8 lanes, aligned to 8)
+  if (bits && (N & 31)) return ADVMIL_EINVAL;
   if (dbias && (!ws || ws_bytes < advmil_colsum_workspace_bytes(M, N))) return ADVMIL_EWORKSPACE;
   const int rpb = rows_per_block(M);
   const int nblk = (int)((M + rpb - 1) / rpb);
@@ -910,7 +921,8 @@ extern "C" int advmil_act_dropout_bwd(const float* dy, const float* y, int act, 
   for (int64_t c0 = 0; c0 < N; c0 += 1024) {
     const int64_t W = (N - c0 < 1024) ? (N - c0) : 1024;
     hipLaunchKernelGGL(act_dropout_bwd_kernel, dim3(nblk), dim3(256), 0, stream, dy, y, act, drop_p, seed, stream_id, M, N,
-                       c0, W, dpre, partial, N, rpb, rng_row, (bf16raw*)out_hi, (bf16raw*)out_lo, direct ? (accumulate ? 2 : 1) : 0);
+                       c0, W, dpre, partial, N, rpb, rng_row, (bf16raw*)out_hi, (bf16raw*)out_lo, direct ? (accumulate ? 2 : 1) : 0,
+                       (uint32_t*)bits);
   }
   ADVMIL_LAUNCH_CHECK();
   if (dbias && !direct) {

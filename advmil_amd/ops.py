@@ -433,7 +433,7 @@ def pre_a_tile_ok(tile, a_kc, b_kc, b_planes=False):
 def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=None, act_split=None, drop_p=0.0,
          seed=None, stream_id=0, rowv=None, colv=None, rowseg=None, maskref=None, mask_scale=1.0, accumulate=False,
          alpha=1.0, splits=None, tile=0, a_planes=None, b_planes=None, c_planes=None, c_planes_only=False, gate_wc=None, rng_row=None,
-         colsum=None):
+         colsum=None, maskbits=None):
     """C[M,N] = epilogue(alpha * op(A) op(B)); see include/advmil_hip.h::advmil_gemm_f32. a_planes / b_planes: optional
     Planes of A / B; c_planes: Planes to receive the split of the final C (pitch ldc)."""
     planes_only_a = A is None
@@ -529,6 +529,9 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
         e.gate_wc, e.gate_out, e.gate_np = gate_wc.data_ptr(), gate_out.data_ptr(), npart
     if colsum is not None:
         e.colsum = colsum.data_ptr()
+    if maskbits is not None:
+        e.maskbits, e.ldbits = maskbits.data_ptr(), maskbits.stride(0)
+        e.mask_scale = float(mask_scale)
     if splits is None:
         ptile, splits = gemm_plan(M, N, K, a_kc, b_kc)
         if tile == 0:
@@ -740,7 +743,7 @@ def gate_bwd(ab, ds, wc, N, D, p=0.0, seed=None, stream_a=0, stream_b=0, dwc=Non
 
 
 def act_dropout_bwd(dy, y, act, M, N, p=0.0, seed=None, stream_id=0, want_bias=True, db_out=None, rng_row=None, planes=None,
-                    planes_only=False):
+                    planes_only=False, bits=None):
     L = _lib.lib()
     dpre = None if (planes_only and planes is not None) else torch.empty(M, N, dtype=torch.float32, device=dy.device)
     acc = db_out is not None
@@ -751,7 +754,7 @@ def act_dropout_bwd(dy, y, act, M, N, p=0.0, seed=None, stream_id=0, want_bias=T
     sd = seed if p > 0.0 else None
     _lib.check(L.advmil_act_dropout_bwd(_p(dy), _p(y), act, p, _p(sd), stream_id, M, N, _p(dpre), _p(db), 1 if acc else 0,
                                         _p(rng_row if sd is not None else None), _p(None if planes is None else planes.hi),
-                                        _p(None if planes is None else planes.lo), _p(ws), wsb, _stream()), "act_dropout_bwd")
+                                        _p(None if planes is None else planes.lo), _p(bits), _p(ws), wsb, _stream()), "act_dropout_bwd")
     return dpre, db
 
 
@@ -874,6 +877,7 @@ class LinearActFn(torch.autograd.Function):
     last_planes = None       # planes of the y just produced (side channel to linear_act: Function outputs are re-wrapped)
     last_wants_dy_planes = False
     last_act_fusable = None
+    last_maskbits = None
 
     @staticmethod
     def forward(ctx, x, W, b, act, p, seed, sid, y0=None, rr=None, xpl=None, wpl=None, emit=False):
@@ -910,7 +914,12 @@ class LinearActFn(torch.autograd.Function):
         elif p > 0.0:       # memoized act(x W^T + b) of the eval forward: only this forward's dropout draw is new
             if emit and MEMO_PLANES and get_gemm_mode() == "bf16x3":
                 cpl = Planes.alloc((M, N), x.device)
-            y, _ = act_dropout_bwd(y0, y0, ACT_NONE, M, N, p, seed, sid, want_bias=False, rng_row=rr, planes=cpl)
+            # (+ the ReLU-and-kept mask as one bit per element: the backward of this layer then never reads y back -- ACT_BWD_IN_DH)
+            mbits = (torch.empty(M, N // 32, dtype=torch.int32, device=x.device)
+                     if (ACT_BWD_IN_DH and act == ACT_RELU and N % 32 == 0 and M >= 4096 and get_gemm_mode() == "bf16x3"
+                         and (xpl is not None or planes_of(x) is not None) and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]) else None)
+            y, _ = act_dropout_bwd(y0, y0, ACT_NONE, M, N, p, seed, sid, want_bias=False, rng_row=rr, planes=cpl, bits=mbits)
+            LinearActFn.last_maskbits = mbits
         else:
             y = y0
         LinearActFn.last_planes = cpl
@@ -1130,8 +1139,10 @@ def linear_act(x, W, b, act="none", p=0.0, rng=None, tag="", emit_planes=False):
         out._advmil_wants_dy_planes = True         # the LayerNorm backward behind this layer may hand dy over as operand planes only
     LinearActFn.last_wants_dy_planes = False
     if LinearActFn.last_act_fusable is not None and out.requires_grad:
-        out._advmil_act_fusable = LinearActFn.last_act_fusable      # (dropout rate, bias-gradient slot | None): see GatedAttnPoolFn.backward
+        # (dropout rate, bias-gradient slot | None, bit mask | None): see GatedAttnPoolFn.backward
+        out._advmil_act_fusable = LinearActFn.last_act_fusable + (LinearActFn.last_maskbits,)
     LinearActFn.last_act_fusable = None
+    LinearActFn.last_maskbits = None
     return out
 
 
@@ -1239,11 +1250,13 @@ class GatedAttnPoolFn(torch.autograd.Function):
             # dpre = (dG Wab + A dpooled) * (h > 0 ? 1 / (1 - p) : 0) -- h is the first layer's stored (post-dropout) output, so the mask IS
             # its ReLU and dropout backward -- written as operand planes only, its column sums (that layer's bias gradient) as per-wave
             # partial rows merged into the arena slot: the row pass act_dropout_bwd over dh and h (0.11 ms at the 16-bag slab) is gone
-            p1, gb1 = fuse
+            p1, gb1, mbits = fuse
             dpl = Planes.alloc((N, D), h.device)
             cws = _ws(nrow * D * 4, h.device) if gb1 is not None else None
+            # the mask: the layer's bit mask when its forward left one (1/32 of the bytes, parked in LDS by the epilogue), else h itself
             gemm(None, Wab, True, False, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg, a_planes=gpl,
-                 maskref=h, mask_scale=1.0 / (1.0 - p1) if p1 > 0.0 else 1.0, c_planes=dpl, c_planes_only=True, colsum=cws, tile=tile)
+                 maskref=h if mbits is None else None, maskbits=mbits, mask_scale=1.0 / (1.0 - p1) if p1 > 0.0 else 1.0, c_planes=dpl,
+                 c_planes_only=True, colsum=cws, tile=tile)
             if gb1 is not None:
                 _lib.check(_lib.lib().advmil_merge_partials(_p(cws), nrow, D, D, _p(gb1), 1, _stream()), "merge_partials")
             dh = torch.empty(N, D, dtype=torch.float32, device=h.device)      # token: never written, never read

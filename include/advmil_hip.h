@@ -105,6 +105,11 @@ typedef struct {
    * the mask) this is the fused backward of the first layer behind the gated-attention pool: dpre = (dG Wab + A dpooled) * (y > 0 ?
    * mask_scale : 0) and its bias gradient, instead of a separate pass over dh and y (model/backbone.py:79-86 autograd of ReLU + Dropout). */
   float* colsum;
+  /* The mask as one bit per element instead of maskref: maskbits[m * ldbits + n / 32] bit n % 32 set = keep (x mask_scale), clear = 0
+   * (advmil_act_dropout_bwd's `bits` output). Whole-tile launches of the slab-sized bf16x3 tiles only; may be combined with rowv. The
+   * epilogue parks a wave's words in LDS before its first store: no per-element mask load inside the store loop. */
+  const uint32_t* maskbits;
+  int64_t ldbits;
 } advmil_epilogue_t;
 
 size_t advmil_gemm_f32_workspace_bytes(int64_t M, int64_t N, int splits);
@@ -248,9 +253,13 @@ int advmil_gate_bwd(const float* ab, const float* ds, const float* wc, float dro
  * dbias[n] = sum_m dpre[m,n] (NULL to skip). y is the stored post-dropout output.
  * replaces: autograd of ReLU/Tanh/Sigmoid/Dropout modules (model/backbone.py:70-75 etc.). */
 size_t advmil_colsum_workspace_bytes(int64_t M, int64_t N);
+/* bits (optional, N % 32 == 0): uint32 [M, N / 32], bit c % 32 of word (m, c / 32) = (dpre[m, c] > 0) -- with act NONE and dy = y = the
+ * memoized pre-dropout activations this call IS the train-mode dropout of a ReLU layer, and the bits are that layer's ReLU-and-kept mask
+ * for the backward (advmil_epilogue_t.maskbits): 1/32 of the bytes of reading the stored output back. */
 int advmil_act_dropout_bwd(const float* dy, const float* y, int act, float drop_p, const uint64_t* seed,
                            uint64_t stream_id, int64_t M, int64_t N, float* dpre, float* dbias, int accumulate,
-                           const int64_t* rng_row, void* out_hi, void* out_lo, void* ws, size_t ws_bytes, advmil_stream_t stream);
+                           const int64_t* rng_row, void* out_hi, void* out_lo, void* bits, void* ws, size_t ws_bytes,
+                           advmil_stream_t stream);
 /* out[n] (+)= sum_m x[m,n] */
 int advmil_colsum(const float* x, int64_t M, int64_t N, float* out, int accumulate, void* ws, size_t ws_bytes,
                   advmil_stream_t stream);

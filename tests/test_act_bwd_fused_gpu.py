@@ -56,3 +56,18 @@ def test_first_layer_backward_in_the_dh_epilogue_equals_the_row_pass(nb, n):
         scale = float(b.abs().max()) + 1e-12
         assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-7, (k, float((a - b).abs().max()), scale)
     assert float(ga.abs().max()) > 0
+
+
+@pytest.mark.parametrize("M,N", [(4096, 384), (517, 128), (33, 1056)])
+def test_dropout_pass_leaves_the_keep_mask_as_one_bit_per_element(M, N):
+    g = torch.Generator().manual_seed(2)
+    y0 = torch.relu(torch.randn(M, N, generator=g)).to(DEV)
+    rng = ops.DeviceRng(DEV, seed=9)
+    bits = torch.zeros(M, N // 32, dtype=torch.int32, device=DEV)
+    y, _ = ops.act_dropout_bwd(y0, y0, ops.ACT_NONE, M, N, 0.25, rng.seed, 3, want_bias=False, bits=bits)
+    torch.cuda.synchronize()
+    b = bits.cpu().numpy().view("uint32")
+    import numpy as np
+    un = ((b[:, :, None] >> np.arange(32, dtype=np.uint32)[None, None, :]) & 1).reshape(M, N).astype(bool)
+    assert (un == (y.cpu().numpy() > 0)).all()
+    assert 0.3 < un.mean() < 0.45            # relu of a normal (1/2) x kept (3/4)
