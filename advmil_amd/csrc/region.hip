@@ -41,29 +41,26 @@ __device__ __forceinline__ int rc_off(int row, int unit) {
 }
 
 // acc[a][b] += A[rows of block rb0 + a] . B[cols n0[b] ..]^T over K: A = LDS plane images (hi, lo) [64][K], B = global planes [n][K]
+// The weight fragments of the WHOLE product are requested before the first MFMA (K / 16 x NCB x 2 planes x 4 registers: 32-128 VGPRs; one
+// workgroup per CU leaves a wave the full register file): with one k-step of prefetch every step waited a full L2 round trip behind
+// 6-12 MFMAs -- 24 us per launch whatever the row count.
 template <int K, int NRB, int NCB>
 __device__ __forceinline__ void rc_mma(const bf16raw* __restrict__ Ah, const bf16raw* __restrict__ Al, int rb0,
                                        const bf16raw* __restrict__ Bh, const bf16raw* __restrict__ Bl, const int (&n0)[NCB],
                                        f32x16 (&acc)[NRB][NCB], int lane) {
   const int i = lane & 31, hi = lane >> 5;
-  Frag8 bh[2][NCB], bl[2][NCB];
+  Frag8 bh[K / 16][NCB], bl[K / 16][NCB];
 #pragma unroll
-  for (int b = 0; b < NCB; ++b) {
-    const int64_t o = (int64_t)(n0[b] + i) * K + hi * 8;
-    bh[0][b].u = *reinterpret_cast<const uint4*>(Bh + o);
-    bl[0][b].u = *reinterpret_cast<const uint4*>(Bl + o);
-  }
+  for (int ks = 0; ks < K / 16; ++ks)
+#pragma unroll
+    for (int b = 0; b < NCB; ++b) {
+      const int64_t o = (int64_t)(n0[b] + i) * K + ks * 16 + hi * 8;
+      bh[ks][b].u = *reinterpret_cast<const uint4*>(Bh + o);
+      bl[ks][b].u = *reinterpret_cast<const uint4*>(Bl + o);
+    }
+  __builtin_amdgcn_sched_barrier(0);       // (keeps the scheduler from sinking the loads back to their first use)
 #pragma unroll
   for (int ks = 0; ks < K / 16; ++ks) {
-    const int cur = ks & 1, nxt = cur ^ 1;
-    if (ks + 1 < K / 16) {
-#pragma unroll
-      for (int b = 0; b < NCB; ++b) {
-        const int64_t o = (int64_t)(n0[b] + i) * K + (ks + 1) * 16 + hi * 8;
-        bh[nxt][b].u = *reinterpret_cast<const uint4*>(Bh + o);
-        bl[nxt][b].u = *reinterpret_cast<const uint4*>(Bl + o);
-      }
-    }
     Frag8 ah[NRB], al[NRB];
 #pragma unroll
     for (int a = 0; a < NRB; ++a) {
@@ -75,9 +72,9 @@ __device__ __forceinline__ void rc_mma(const bf16raw* __restrict__ Ah, const bf1
     for (int a = 0; a < NRB; ++a)
 #pragma unroll
       for (int b = 0; b < NCB; ++b) {
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a].v, bh[cur][b].v, acc[a][b], 0, 0, 0);
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a].v, bl[cur][b].v, acc[a][b], 0, 0, 0);
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a].v, bh[cur][b].v, acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a].v, bh[ks][b].v, acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a].v, bl[ks][b].v, acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a].v, bh[ks][b].v, acc[a][b], 0, 0, 0);
       }
   }
 }

@@ -9,17 +9,35 @@ the kernels read the step seed from device memory and the graph itself bumps it.
 Single process: ONE graph (optionally with the generator's training forward as a parallel branch: MyHandler.overlap_gfwd, measured
 slower, off by default).
 
-Under bag-parallel (world > 1) the collectives stay OUTSIDE the graphs (four segments: D backward | G backbone forward | D Adam + G
-loss/backward | G Adam), so capture never depends on RCCL's graph support; D's all-reduce is started asynchronously before the
-G-forward segment and waited for after it, so the exchange runs under that segment's kernels.
+Under bag-parallel (world > 1) the collectives stay OUTSIDE the graphs by default (four segments: D backward | G backbone forward |
+D Adam + G loss/backward | G Adam), so capture never depends on RCCL's graph support; D's all-reduce is started asynchronously before
+the G-forward segment and waited for after it, so the exchange runs under that segment's kernels. `replay` stamps the two waits with
+events (`exposed_allreduce_ms`): the time the compute stream stood still for an exchange.
+
+ADVMIL_GRAPH_COLLECTIVES=1 (backend nccl = RCCL only): the two all-reduces are captured INSIDE the step graph -- a rank's step is then
+one graph launch (on the launch-bound per-rank step of the strong split: three graph launches and two host-issued collectives less).
+Every rank must take the same path, so the choice is agreed on with an all-reduce BEFORE any capture, a failed capture on any rank
+sends all ranks back to the segments, and bench.py runs its multi-rank legs under a stall watchdog. Exercised on this image with a
+one-rank RCCL communicator only (tests/test_parallel_gpu.py); the default stays the segment path until a node has run it.
 """
+import os
+
 import torch
 
 
 class GraphedStep:
-    def __init__(self, handler, xs, ys, ys_host, mode="wlabel", label_visible_mask=None, warmup=2, force_segments=False):
+    def __init__(self, handler, xs, ys, ys_host, mode="wlabel", label_visible_mask=None, warmup=2, force_segments=False,
+                 capture_collectives=None):
         self.force_segments = force_segments
         self.h = handler
+        self.wait_events = []                # (start, stop) event pairs around the two exchange waits of the last segmented replay
+        self.captured_collectives = False
+        if capture_collectives is None:
+            capture_collectives = os.environ.get("ADVMIL_GRAPH_COLLECTIVES", "0") == "1"
+        dp = handler.dp
+        want = bool(capture_collectives and dp.enabled and (dp.world > 1 or getattr(dp, "force", False)) and not force_segments
+                    and torch.distributed.get_backend(dp.group) == "nccl")
+        self._want_captured = self._agree(want)
         if handler.dp.world > 1 or force_segments:
             handler.overlap_gfwd = False     # the segments are separate graphs: a fork event cannot cross from one capture into another
         self.xs, self.ys = xs, ys
@@ -28,6 +46,24 @@ class GraphedStep:
         self.segments = []
         self.logs = None
         self._capture(warmup)
+
+    def _agree(self, flag):
+        """True only if EVERY rank says so (one tiny MIN all-reduce, outside any capture)."""
+        dp = self.h.dp
+        if not (dp.enabled and dp.world > 1):
+            return bool(flag)
+        t = torch.tensor([1.0 if flag else 0.0], device=self.h.device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN, group=dp.group)
+        return bool(float(t.item()) > 0.5)
+
+    def _whole(self):
+        """The step with its exchanges in stream order (what a single captured graph holds)."""
+        self._seg_disc()
+        self.h._reduce_d()
+        self._seg_gfwd()
+        self._seg_mid()
+        self.h._reduce_g()
+        self._seg_end()
 
     def _lrs(self):
         return (self.h.optimizerG.param_groups[0]["lr"], self.h.optimizerD.param_groups[0]["lr"])
@@ -72,16 +108,33 @@ class GraphedStep:
         torch.cuda.synchronize()
         del h.history[:]                     # the warm-up steps' own logs are dry runs
         pool = torch.cuda.graph_pool_handle()
-        if h.dp.world > 1 or self.force_segments:
-            parts = (self._seg_disc, self._seg_gfwd, self._seg_mid, self._seg_end)
-        else:
-            parts = (lambda: (self._seg_disc(), self._seg_gfwd(), self._seg_mid(), self._seg_end()),)
-        for fn in parts:
-            g = torch.cuda.CUDAGraph()
-            # thread_local: RCCL's watchdog thread may query events while this thread captures
-            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
-                fn()
-            self.segments.append(g)
+        if self._want_captured:
+            # the exchanges inside the graph: capture on every rank, then agree that it worked everywhere -- else all fall back together
+            ok = True
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                    self._whole()
+            except Exception:
+                ok = False
+                torch.cuda.synchronize()
+            if self._agree(ok):
+                self.segments.append(g)
+                self.captured_collectives = True
+            else:
+                self._want_captured = False
+                del h.history[:]
+        if not self.segments:
+            if h.dp.world > 1 or self.force_segments or (h.dp.enabled and getattr(h.dp, "force", False)):
+                parts = (self._seg_disc, self._seg_gfwd, self._seg_mid, self._seg_end)
+            else:
+                parts = (lambda: (self._seg_disc(), self._seg_gfwd(), self._seg_mid(), self._seg_end()),)
+            for fn in parts:
+                g = torch.cuda.CUDAGraph()
+                # thread_local: RCCL's watchdog thread may query events while this thread captures
+                with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                    fn()
+                self.segments.append(g)
         self.logs = list(h.history)                          # device scalars rewritten by every replay
         h.history[:] = saved
         self._st_d, self._st_g = h._st_d, h._st_g            # the statistics tensors this graph writes (reduced between segments)
@@ -98,8 +151,26 @@ class GraphedStep:
         self.h._st_d, self.h._st_g = self._st_d, self._st_g      # this graph's statistics tensors (another group may have run since)
         pend = self.h.dp.allreduce_async(self.h.optimizerD.flat_grad, self._st_d[0])     # D's exchange ...
         segs[1].replay()                                                                 # ... under the generator's backbone forward
+        stamp = self.stamp_waits
+        if stamp:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
         for w in pend:
             w.wait()
+        if stamp:
+            ev[1].record()
         segs[2].replay()
+        if stamp:
+            ev[2].record()
         self.h._reduce_g()
+        if stamp:
+            ev[3].record()
+            self.wait_events = [(ev[0], ev[1]), (ev[2], ev[3])]
         segs[3].replay()
+
+    stamp_waits = False
+
+    def exposed_allreduce_ms(self):
+        """(D wait, G wait) of the last stamped segmented replay: how long the compute stream stood still for each exchange (after a
+        synchronize). D's is what the overlap with the generator's forward did not hide; G's exchange has nothing to hide under."""
+        return tuple(a.elapsed_time(b) for a, b in self.wait_events)

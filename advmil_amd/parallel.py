@@ -22,11 +22,14 @@ import torch.distributed as dist
 
 
 class BagParallel:
-    def __init__(self, group=None):
+    def __init__(self, group=None, force=False):
         self.enabled = dist.is_available() and dist.is_initialized()
         self.group = group
         self.rank = dist.get_rank(group) if self.enabled else 0
         self.world = dist.get_world_size(group) if self.enabled else 1
+        # force: issue the step's collectives also on a ONE-rank communicator (a test aid: this image has one GPU per box, so the
+        # captured-collective path of graphed.GraphedStep can only be exercised through a one-rank RCCL group)
+        self.force = bool(force) and self.enabled
 
     # ---- partition: bag i of the global step batch -> rank i mod W ("one WSI per GPU")
     def owns(self, global_index: int) -> bool:
@@ -67,14 +70,14 @@ class BagParallel:
     # ---- exchange
     def allreduce_(self, flat: torch.Tensor) -> torch.Tensor:
         """In-place SUM of a flat gradient arena across ranks (one bucket per network)."""
-        if self.enabled and self.world > 1:
+        if self.enabled and (self.world > 1 or self.force):
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         return flat
 
     def allreduce_async(self, *tensors):
         """Start SUM all-reduces and return their work handles: with RCCL they run on the communicator's own stream, `wait()`
         then only makes the current compute stream wait (no host block), so kernels enqueued in between overlap the exchange."""
-        if not (self.enabled and self.world > 1):
+        if not (self.enabled and (self.world > 1 or self.force)):
             return []
         return [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for t in tensors]
 

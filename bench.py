@@ -41,6 +41,7 @@ import json
 import os
 import sys
 import time
+from types import SimpleNamespace
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -202,7 +203,9 @@ class Case:
                     self.graphs.append(GraphedStep(self.h, [self.xs[i] for i in idx], [self.ys[i] for i in idx],
                                                    [self.ys_host[i] for i in idx], warmup=1))
                 self.launch_note = (f"hipGraph replay ({len(self.graphs)} captured bag groups"
-                                    + (", 4 segments: the 2 all-reduces stay outside capture, D's overlaps the G-forward segment)" if world > 1 else ")"))
+                                    + ((", ONE graph per step: the 2 all-reduces captured inside (ADVMIL_GRAPH_COLLECTIVES=1))"
+                                        if self.graphs[0].captured_collectives else
+                                        ", 4 segments: the 2 all-reduces stay outside capture, D's overlaps the G-forward segment)") if world > 1 else ")"))
             except Exception as exc:          # never lose the run to a capture problem: the eager schedule is the same step
                 self.graphs = []
                 torch.cuda.synchronize()
@@ -229,10 +232,14 @@ class Case:
     def timed(self, steps, warmup, barrier):
         for _ in range(warmup):
             self.step()
+        beat("warm-up enqueued")
         barrier()
+        beat("timed region")
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for k in range(steps):
             self.step()
+            if (k & 15) == 15:
+                beat(f"timed step {k + 1} of {steps} enqueued")
         t_submit = time.perf_counter() - t0     # host time to enqueue all K steps (== dt when the host is the bottleneck)
         barrier()
         return time.perf_counter() - t0, t_submit
@@ -381,6 +388,40 @@ def visible_gpu_count():
     return n
 
 
+class Watchdog:
+    """Multi-rank runs only: a rank that makes no progress for `limit` seconds (a collective or a captured-graph mismatch between ranks
+    hangs, it does not raise) prints where it stood and leaves with exit code 3 -- a fresh exit, never a re-exec; the launcher then
+    tears the other ranks down. `beat(what)` is called at every phase boundary and every few steps of a timed loop."""
+
+    def __init__(self, rank, limit=60.0):
+        import threading
+        self.rank, self.limit, self.last, self.what, self.on = rank, float(limit), time.time(), "start", True
+        self.th = threading.Thread(target=self._run, daemon=True)
+        self.th.start()
+
+    def beat(self, what):
+        self.last, self.what = time.time(), what
+
+    def stop(self):
+        self.on = False
+
+    def _run(self):
+        while self.on:
+            time.sleep(1.0)
+            if self.on and time.time() - self.last > self.limit:
+                print(f"bench.py watchdog: rank {self.rank} made no progress for {self.limit:.0f} s (last: {self.what}); exiting 3",
+                      file=sys.stderr, flush=True)
+                os._exit(3)
+
+
+WATCHDOG = None
+
+
+def beat(what):
+    if WATCHDOG is not None:
+        WATCHDOG.beat(what)
+
+
 def self_launch(args):
     """`bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks as a CHILD torch.distributed.run job (this
     process never touches the GPU: the devices are counted from the environment / the KFD topology, visible_gpu_count), relay rank
@@ -399,7 +440,19 @@ def self_launch(args):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    # (own process group + an overall limit: a rank job that outlives its watchdogs is killed as a group, by the PIDs this process started)
+    limit = float(os.environ.get("ADVMIL_BENCH_TIMEOUT", "1500"))
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        stdout, _ = child.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        import signal
+        os.killpg(child.pid, signal.SIGKILL)
+        stdout, _ = child.communicate()
+        print(f"bench.py: the {args.gpus}-rank job exceeded {limit:.0f} s and was killed", file=sys.stderr)
+        sys.stdout.write(stdout or "")
+        sys.exit(3)
+    proc = SimpleNamespace(stdout=stdout or "", returncode=child.returncode)
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
     for ln in proc.stdout.splitlines():
         if ln not in lines:
@@ -701,6 +754,9 @@ def main():
             raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher environment says WORLD_SIZE={world}")
     ranks_seen = dist.get_world_size() if world > 1 else 1
     backend = dist.get_backend() if world > 1 else None
+    global WATCHDOG
+    if world > 1:
+        WATCHDOG = Watchdog(rank, float(os.environ.get("ADVMIL_BENCH_STALL_S", "60")))
     dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
 
@@ -708,8 +764,38 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        beat("barrier passed")
+
+    def per_rank(x):
+        """every rank's value of a scalar, in rank order (N > 1)"""
+        t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        return [round(float(o.item()), 4) for o in outs]
+
+    def exposed_allreduce(c, replays=6):
+        """(D wait ms, G wait ms) per step of the segmented replay, mean over `replays` stamped replays, max over ranks: how long a rank's
+        compute stream stood still for the two gradient exchanges (D's is started before the generator's forward and waited for behind it)."""
+        if not c.graphs or len(c.graphs[0].segments) == 1:
+            return None
+        acc = [0.0, 0.0]
+        for k in range(replays):
+            g = c.graphs[k % len(c.graphs)]
+            g.stamp_waits = True
+            g.replay()
+            torch.cuda.synchronize()
+            d_ms, g_ms = g.exposed_allreduce_ms()
+            g.stamp_waits = False
+            acc[0] += d_ms / replays; acc[1] += g_ms / replays
+        t = torch.tensor(acc, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return {"d_wait_ms": round(float(t[0]), 4), "g_wait_ms": round(float(t[1]), 4), "replays": replays,
+                "note": "event-stamped waits of the 4-segment replay, max over ranks"}
 
     case = Case(torch, dev, args.mode, args.patches, args.bags, args.pool, args.gemm_mode, 1234 + rank, args.eager, world)
+    beat("graphs captured")
+    if world > 1 and os.environ.get("ADVMIL_BENCH_TEST_STALL") == str(rank):      # self-test of the watchdog: this rank stops making progress
+        time.sleep(1e6)
     ok = torch.tensor([1.0 if (case.graphs or args.eager) else 0.0], device=dev)
     if world > 1:                          # all ranks must take the same path
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -717,10 +803,15 @@ def main():
         case.graphs = []
     h = case.h
     dt, t_submit = case.timed(args.steps, args.warmup, barrier)
+    multi = None
     if world > 1:
+        multi = {"per_rank_ms_per_step": [round(1e3 * v / args.steps, 4) for v in per_rank(dt)],
+                 "collectives_in_graph": bool(case.graphs and case.graphs[0].captured_collectives)}
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        multi["exposed_allreduce"] = exposed_allreduce(case)
+        beat("weak leg done")
     finite = case.logs_finite()
 
     # ---- strong scaling (N > 1): the reference's own optimizer step of 16 bags (cfg_nlst.yaml:71) split over the ranks, bag i of
@@ -736,10 +827,15 @@ def main():
             if float(oks.item()) == 0.0:
                 cs.graphs = []
             dts, _ = cs.timed(args.steps, args.warmup, barrier)
+            strong_ranks = [round(1e3 * v / args.steps, 4) for v in per_rank(dts)]
             ts = torch.tensor([dts], dtype=torch.float64, device=dev)
             dist.all_reduce(ts, op=dist.ReduceOp.MAX)
             dts = float(ts.item())
+            strong_wait = exposed_allreduce(cs)
+            beat("strong leg done")
             strong = {"scaling": "strong", "value": round(GLOBAL_STEP * args.steps / dts, 3), "unit": "bags/s",
+                      "per_rank_ms_per_step": strong_ranks, "exposed_allreduce": strong_wait,
+                      "collectives_in_graph": bool(cs.graphs and cs.graphs[0].captured_collectives),
                       "ms_per_step": round(1e3 * dts / args.steps, 3), "steps": args.steps, "global_bags_per_step": GLOBAL_STEP,
                       "bags_per_step_per_gpu": per, "gd_steps_per_sec": round(args.steps / dts, 3),
                       "losses_finite": bool(cs.logs_finite()), "launch": cs.launch_note,
@@ -1035,10 +1131,14 @@ def main():
             "roofline": roof, "gemm_roofline": (gemm_roof if roof is not gemm_roof else None), "pool_roofline": pool_roof,
             "cpu_baseline": cpu, "exact_f32_mfma_mode": exact_extra, "bp_every_batch_1": bp1_extra, "sizes": sizes,
             "product_loop": epoch_extra, "strong_scaling": strong, "ranks_seen": ranks_seen, "dist_backend": backend,
+            "multi_gpu": multi,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
+        beat("result printed")
         dist.barrier()
+        if WATCHDOG is not None:
+            WATCHDOG.stop()
         dist.destroy_process_group()
 
 

@@ -35,7 +35,7 @@ def build_loader(kind, idxs, lens=LENS):
     return loader
 
 
-def run(kind, world, rank, dp=None):
+def run(kind, world, rank, dp=None, device="cuda:0"):
     from advmil_amd import synth
     from advmil_amd.config import default_cfg
     from advmil_amd.model import MyHandler
@@ -50,7 +50,7 @@ def run(kind, world, rank, dp=None):
     cfg = default_cfg(bcb_mode=kind, bp_every_batch=4)         # the GLOBAL step batch: every rank steps after 4 / world of its bags
     if kind == "graph":
         cfg.update(bcb_dims="1024-128-128", gen_dims="128-1")
-    h = MyHandler(cfg, device="cuda:0", parallel=dp)
+    h = MyHandler(cfg, device=device, parallel=dp)
     for net, prefix in ((h.netG, f"G-{kind}:"), (h.netD, "D-prj:")):
         sd = {k: H.T(synth.param(H.PARAM_SEED, prefix + k, tuple(v.shape))) for k, v in net.state_dict().items()}
         net.load_state_dict(sd, strict=True)
@@ -65,11 +65,13 @@ def run(kind, world, rank, dp=None):
 
 def main():
     rank, world, port, out, kind = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+    per_rank = os.environ.get("ADVMIL_DP_DEVICE_PER_RANK") == "1"       # one GPU per rank + RCCL (a multi-GPU node), else ranks share cuda:0 over gloo
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank) if per_rank else "0",
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     from advmil_amd import parallel
-    parallel.init_from_env(backend="gloo")           # two ranks on ONE GPU: RCCL refuses that, the exchange layer is backend agnostic
-    res = run(kind, world, rank, parallel.BagParallel())
+    # two ranks on ONE GPU: RCCL refuses that, the exchange layer is backend agnostic
+    parallel.init_from_env(backend=os.environ.get("ADVMIL_DIST_BACKEND", "gloo") if per_rank else "gloo")
+    res = run(kind, world, rank, parallel.BagParallel(), device=f"cuda:{rank}" if per_rank else "cuda:0")
     if rank == 0:
         torch.save(res, out)
     torch.distributed.barrier()

@@ -92,3 +92,69 @@ def test_rccl_communicator_comes_up_on_this_image(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", _RCCL_PROBE, port], cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0 and "rccl-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+_CAPTURE_PROBE = r"""
+import os, sys, torch, torch.distributed as dist
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % sys.argv[1], rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from advmil_amd.config import default_cfg
+from advmil_amd.graphed import GraphedStep
+from advmil_amd.model import MyHandler
+from advmil_amd.parallel import BagParallel
+from tests import helpers as H
+DEV = "cuda:0"
+res = {}
+for captured in (True, False):
+    h = MyHandler(default_cfg(bcb_mode="abmil", bp_every_batch=2, gemm_mode="bf16x3"), device=DEV, parallel=BagParallel(force=True))
+    xs = [[H.bag(i, 512, DEV), torch.zeros(1, 1, device=DEV)] for i in range(2)]
+    ys_host = [H.label(i) for i in range(2)]
+    ys = [y.to(DEV) for y in ys_host]
+    h.rng.reset(3)
+    g = GraphedStep(h, xs, ys, ys_host, warmup=1, capture_collectives=captured)
+    assert g.captured_collectives == captured, (captured, g.captured_collectives)
+    assert len(g.segments) == (1 if captured else 4)
+    g.stamp_waits = True
+    g.replay(); g.replay()
+    torch.cuda.synchronize()
+    if not captured:
+        d_ms, g_ms = g.exposed_allreduce_ms()
+        assert d_ms >= 0.0 and g_ms >= 0.0
+    res[captured] = (h.optimizerG.flat_param.clone(), h.optimizerD.flat_param.clone())
+for a, b in zip(res[True], res[False]):
+    assert torch.equal(a, b)
+dist.destroy_process_group()
+print("capture-ok")
+"""
+
+
+@pytest.mark.timeout(300)
+def test_step_graph_with_the_gradient_exchanges_captured_inside(tmp_path):
+    """ADVMIL_GRAPH_COLLECTIVES: the two all-reduces as nodes of ONE step graph (RCCL under stream capture) against the four-segment
+    replay with host-issued collectives -- bit-equal weights after 1 + 2 steps. One-rank RCCL communicator (one GPU per box), the
+    collectives forced on (BagParallel(force=True)); also exercises the exposed-wait stamps of the segment path."""
+    port = str(32300 + os.getpid() % 1500)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _CAPTURE_PROBE, port], cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "capture-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_rccl_step_when_two_devices_are_visible(tmp_path):
+    """The real exchange: two RCCL ranks on two GPUs against the single-process run (skips cleanly on a one-GPU box, which is every box
+    the build had; the driver's multi-GPU node runs it)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    from tests import dp_worker
+    want = dp_worker.run("abmil", 1, 0)
+    out = str(tmp_path / "r0.pt")
+    port = str(33300 + os.getpid() % 1500)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ADVMIL_DIST_BACKEND="nccl", ADVMIL_DP_DEVICE_PER_RANK="1")
+    procs = [subprocess.Popen([sys.executable, "-m", "tests.dp_worker", str(r), "2", port, out, "abmil"], cwd=ROOT, env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=500) == 0
+    got = torch.load(out, weights_only=False)
+    for k in ("y", "y_hat", "f_fake"):
+        a, b = got["cl"][k].double().reshape(-1), want["cl"][k].double().reshape(-1)
+        assert a.shape == b.shape and float((a - b).abs().max()) < 2e-6, (k, float((a - b).abs().max()))

@@ -7,3 +7,11 @@ set -e
 export ADVMIL_DIST_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 \
     bench.py --gpus 2 --steps 4 --warmup 1 --patches 2048 --pool 8 --bags 4
+# the stall watchdog: rank 1 stops before the first collective of the timed legs -> every rank must leave with a non-zero code within seconds
+set +e
+t0=$(date +%s)
+ADVMIL_BENCH_TEST_STALL=1 ADVMIL_BENCH_STALL_S=5 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29613 \
+    bench.py --gpus 2 --steps 4 --warmup 1 --patches 2048 --pool 8 --bags 4 --no-extras --no-roofline --no-cpu-baseline > /dev/null 2> /tmp/stall.err
+rc=$?
+echo "watchdog self-test: exit code $rc after $(( $(date +%s) - t0 )) s: $(grep -m1 'watchdog' /tmp/stall.err)"
+[ $rc -ne 0 ]
