@@ -46,6 +46,9 @@ class BaselineHandler(object):
                            out_scale=out_scale)
         self.net.apply(init_weights if self.task in ("surv_reg", "surv_nll") else general_init_weight)       # 87-90
         self.net = self.net.to(self.device)
+        # 'fp32' (default) | 'bf16': how bags are held in HBM (MyHandler.x_storage); the static test_model reads it off the network
+        self.x_storage = os.environ.get("ADVMIL_X_STORAGE", cfg.get("x_storage", "fp32"))
+        self.net._advmil_x_storage = self.x_storage
         for m in self.net.modules():
             m.rng = self.rng
         if cfg.get("gemm_mode") is not None:
@@ -97,7 +100,8 @@ class BaselineHandler(object):
         seen = 0
         for bt in step_batches(train_loader, self.device, bp, view, drop_last=True, group_unstaged=True,
                                stageable=lambda x0: self.bcb != "graph",
-                               pad_multiple=int(os.environ.get("ADVMIL_SLAB_PAD", self.cfg.get("slab_pad", 256)))):
+                               pad_multiple=int(os.environ.get("ADVMIL_SLAB_PAD", self.cfg.get("slab_pad", 256))),
+                               x_storage=self.x_storage):
             seen += len(bt.xs)
             if len(bt.xs) != bp:
                 continue
@@ -142,7 +146,7 @@ class BaselineHandler(object):
 
     # ------------------------------------------------------------------------------------------
     @staticmethod
-    def test_model(model, backbone, loader, times_test_sample=1, checkpoint=None, batch_bags=None):
+    def test_model(model, backbone, loader, times_test_sample=1, checkpoint=None, batch_bags=None, x_storage=None):
         """443-487. The network has no noise, so in eval mode the `times_test_sample` repeated forwards of the reference are
         identical: a bag is run once and the sample axis is filled with that prediction. `batch_bags` (default 16,
         ADVMIL_EVAL_BATCH_BAGS) host bags are evaluated as one step slab, staged on the copy stream and kept in the device-resident
@@ -158,7 +162,8 @@ class BaselineHandler(object):
             nb = 1
         idxs, ys, preds = [], [], []
         with torch.no_grad():
-            for bt in step_batches(loader, dev, nb, loader_cache_view(dev, loader), pad_multiple=int(os.environ.get("ADVMIL_SLAB_PAD", "256"))):
+            for bt in step_batches(loader, dev, nb, loader_cache_view(dev, loader), pad_multiple=int(os.environ.get("ADVMIL_SLAB_PAD", "256")),
+                                   x_storage=x_storage if x_storage is not None else getattr(model, "_advmil_x_storage", None)):
                 if bt.staged:
                     xs, pad = bt.xs, bt.pad
                     X = MyHandler._slab_build_static(xs, True, pad)

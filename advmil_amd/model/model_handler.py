@@ -112,6 +112,9 @@ class MyHandler(object):
         self.netD = self.netD.to(self.device)
         for m in list(self.netG.modules()) + list(self.netD.modules()):
             m.rng = self.rng
+        # the STATIC test_model (reference signature: no handler argument) reads the bags' storage mode off the generator it is given, so
+        # a cfg-only x_storage = 'bf16' is validated / tested on the same rounded bags it trains on, out of the same device cache entries
+        self.netG._advmil_x_storage = self.x_storage
         # arithmetic of the fp32 contraction engine (process-wide switch in the library): "exact" = fp32 MFMA,
         # "bf16x3" = split-bf16 on the bf16 matrix pipe with fp32 accumulate (near-fp32: ~2^-17 per product). None = leave as is.
         if cfg.get("gemm_mode") is not None:
@@ -608,8 +611,11 @@ class MyHandler(object):
         else:
             loss, st = ops.gan_d_loss(f_fake, None, None, self.which_loss, plan.n_fake, plan.n_real, root=True)
         # (deferred_sums: the backward's ~7 merge launches of parameter-gradient partials become one, issued on exit)
-        with torch.autograd.set_multithreading_enabled(False), ops.deferred_sums():       # backward on THIS thread (see _gen_finish)
-            torch.autograd.backward(loss, grad_tensors=self._one())  # (the root gradient is a cached 1: no fill launch per step)
+        try:
+            with torch.autograd.set_multithreading_enabled(False), ops.deferred_sums():       # backward on THIS thread (see _gen_finish)
+                torch.autograd.backward(loss, grad_tensors=self._one())  # (the root gradient is a cached 1: no fill launch per step)
+        finally:
+            ops.DY_PLANES.clear()            # (a backward that raised may have left a plane hand-over behind: never let it meet a reused address)
         self._st_d = (st, plan, i_batch)     # this rank's partial sums over the global denominators; reduced + logged in _disc_apply
         preds = list(pred.split(1, dim=0))
         fakes = list(f_fake.detach().split(1, dim=0))
@@ -727,8 +733,11 @@ class MyHandler(object):
         # The engine would hand a CUDA graph to its device thread; every node of ours is a short Python function that only enqueues
         # launches, so the hand-over and the GIL ping-pong cost more than they buy (host issue per eager step 2.9 -> 2.5 ms,
         # tools/probe/eager_host_profile.py). Scoped: the caller's setting comes back on exit.
-        with torch.autograd.set_multithreading_enabled(False), ops.deferred_sums():
-            torch.autograd.backward(total, grad_tensors=self._one())
+        try:
+            with torch.autograd.set_multithreading_enabled(False), ops.deferred_sums():
+                torch.autograd.backward(total, grad_tensors=self._one())
+        finally:
+            ops.DY_PLANES.clear()
         if join is not None:
             # the generator's forward ran on the side stream, so autograd ran its backward nodes there too; the weight gradients
             # are added into the arena by raw kernels (no AccumulateGrad node -> the engine syncs nothing back): the optimizer step
@@ -756,7 +765,7 @@ class MyHandler(object):
     # ------------------------------------------------------------------------------------------
     @staticmethod
     def test_model(modelG, modelD, backbone, loader, times_test_sample=1, checkpoints=None, test_zero_noise=False, noise=None,
-                   batch_bags=None):
+                   batch_bags=None, x_storage=None):
         """Eval: y_hat, f_fake, and `times_test_sample` more generator samples + their median per bag (reference
         model_handler.py:598-643: one synchronous `.cuda()`, 1 + times_test_sample full generator forwards, one D forward and
         4-6 `.cpu()` syncs PER BAG -- and `_run_training` runs it over the validation and the test set after every epoch).
@@ -824,9 +833,12 @@ class MyHandler(object):
         from ..ingest import loader_cache_view, step_batches
         slab_able = (backbone != "graph" and hasattr(modelG, "features_multi") and hasattr(modelD, "bag_features_multi")
                      and (noise is None or len({len(nb) for nb in noise}) == 1))
+        if x_storage is None:                # (the handler that built modelG stamped its storage mode on it; else ADVMIL_X_STORAGE / fp32)
+            x_storage = getattr(modelG, "_advmil_x_storage", None)
         with torch.no_grad():
             for bt in step_batches(loader, dev, nb_max if slab_able else 1, loader_cache_view(dev, loader),
-                                   stageable=lambda x0: x0.shape[1] % 16 == 0, pad_multiple=int(os.environ.get("ADVMIL_SLAB_PAD", "256"))):
+                                   stageable=lambda x0: x0.shape[1] % 16 == 0, pad_multiple=int(os.environ.get("ADVMIL_SLAB_PAD", "256")),
+                                   x_storage=x_storage):
                 if bt.staged:
                     slab_batch(bt)
                 else:

@@ -895,7 +895,7 @@ class LinearActFn(torch.autograd.Function):
             # a [B, d] head / tail layer: one fp32-FMA launch (csrc/optim.hip small_linear_*), its backward one or two
             y = torch.empty(M, N, dtype=torch.float32, device=x.device)
             use = seed is not None and p > 0.0
-            _lib.check(_lib.lib().advmil_small_linear_fwd(_p(x), x.stride(0), _p(W2), _p(b), M, N, K, act, float(p) if use else 0.0,
+            _lib.check(_lib.lib().advmil_small_linear_fwd(_p(x), K, _p(W2), _p(b), M, N, K, act, float(p) if use else 0.0,   # (x is contiguous: pitch K)
                                                           _p(seed if use else None), sid, _p(rr if use else None), _p(y), _stream()),
                        f"small_linear_fwd[{M}x{N}x{K}]")
             ctx.small = True
@@ -963,7 +963,7 @@ class LinearActFn(torch.autograd.Function):
             wsb = L.advmil_small_linear_bwd_workspace_bytes(M, N) if need_x else 0
             ws = _ws(wsb, dev) if wsb else None
             use = seed is not None and p > 0.0
-            _lib.check(L.advmil_small_linear_bwd(_p(dy), _p(y), _p(x), x.stride(0), _p(W2), M, N, K, act, float(p) if use else 0.0,
+            _lib.check(L.advmil_small_linear_bwd(_p(dy), _p(y), _p(x), K, _p(W2), M, N, K, act, float(p) if use else 0.0,
                                                  _p(seed if use else None), sid, _p(rr if use else None), _p(dW), 1 if acc_w else 0, _p(db),
                                                  1 if acc_b else 0, _p(dx), K, _p(ws), wsb, _stream()), f"small_linear_bwd[{M}x{N}x{K}]")
             return (dx, None if (dW is None or acc_w) else dW.reshape(wshape), None if (db is None or acc_b) else db,
@@ -1652,12 +1652,13 @@ class GenConvAggFn(torch.autograd.Function):
     """out = softmax-aggregated messages + x (GENConv before its MLP); t is the learnable temperature [1]."""
 
     @staticmethod
-    def forward(ctx, x, t, csr, eps):
+    def forward(ctx, x, t, csr, eps, keep_rows=True):
         _chk(x, "x")
         x = x.contiguous()
         N, C = x.shape
         out = torch.empty_like(x)
-        keep = any(ctx.needs_input_grad[:2])                     # evaluation: `out` is the only row written
+        # (needs_input_grad reflects requires_grad whatever the grad mode: t is a Parameter, so a no-grad pass must be asked about itself)
+        keep = keep_rows and any(ctx.needs_input_grad[:2])       # evaluation / no-grad passes: `out` is the only row written
         lse = torch.empty_like(x) if keep else None
         agg = torch.empty_like(x) if keep else None
         _lib.check(_lib.lib().advmil_genconv_fwd(_p(x), _p(csr.rowptr_dst), _p(csr.col_src), _p(t), eps, N, C, _p(out), _p(lse),
@@ -1679,13 +1680,13 @@ class GenConvAggFn(torch.autograd.Function):
         ws = torch.empty(nws // 4, device=x.device, dtype=torch.float32)
         _lib.check(_lib.lib().advmil_genconv_bwd(_p(dout), _p(x), _p(agg), _p(lse), _p(csr.rowptr_src), _p(csr.col_dst), _p(t),
                                                  ctx.eps, N, C, _p(dx), _p(dt), _p(ws), nws, _stream()), "genconv_bwd")
-        return dx, dt, None, None
+        return dx, dt, None, None, None
 
 
 def genconv_aggregate(x, t, csr, eps=1e-7):
     if csr.E == 0:                           # a graph without edges: nothing is aggregated (the kernels take no empty edge arrays)
         return x + 0.0 * t.sum()
-    return GenConvAggFn.apply(x, t, csr, eps)
+    return GenConvAggFn.apply(x, t, csr, eps, torch.is_grad_enabled())
 
 
 # ---------------------------------------------------------------------------------------
