@@ -74,7 +74,7 @@ SIGNATURES = {
     "advmil_mha_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64,
                                c_float, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "advmil_add_dropout_ln_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int64, c_float, c_void_p,
-                                          c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                          c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "advmil_add_dropout_ln_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "advmil_add_dropout_ln_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p,
                                           c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
@@ -98,7 +98,7 @@ SIGNATURES = {
                                        c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "advmil_colsum": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "advmil_ln_relu_mean16_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int64, c_void_p, c_void_p,
-                                          c_void_p, c_void_p]),
+                                          c_void_p, c_void_p, c_void_p, c_void_p]),
     "advmil_ln_relu_mean16_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "advmil_ln_relu_mean16_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                           c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -1071,7 +1071,8 @@ __device__ __forceinline__ float half_sum(float v) {      // over the 32 lanes o
 template <int NV>
 __global__ __launch_bounds__(256) void ln_relu_mean16_fwd4_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta, float eps, int64_t N, float* __restrict__ emb,
-                                                                  float* __restrict__ mean, float* __restrict__ rstd) {
+                                                                  float* __restrict__ mean, float* __restrict__ rstd,
+                                                                  bf16raw* __restrict__ e_hi, bf16raw* __restrict__ e_lo) {
   constexpr int d = 128 * NV;
   __shared__ __attribute__((aligned(16))) float red[8][d];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l = lane & 31, h = lane >> 5;
@@ -1123,7 +1124,14 @@ __global__ __launch_bounds__(256) void ln_relu_mean16_fwd4_kernel(const float* _
       const float4 v = *reinterpret_cast<const float4*>(&red[r][4 * j]);
       t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
     }
-    *reinterpret_cast<float4*>(emb + g * d + 4 * j) = make_float4(t.x * (1.f / 16.f), t.y * (1.f / 16.f), t.z * (1.f / 16.f), t.w * (1.f / 16.f));
+    const float4 ev = make_float4(t.x * (1.f / 16.f), t.y * (1.f / 16.f), t.z * (1.f / 16.f), t.w * (1.f / 16.f));
+    *reinterpret_cast<float4*>(emb + g * d + 4 * j) = ev;
+    if (e_hi) {                              // operand planes of the region embedding for the plane-fed in-projection behind it (ESAT)
+      uint2 hh, ll;
+      split4(ev, hh, ll);
+      *reinterpret_cast<uint2*>(e_hi + g * d + 4 * j) = hh;
+      *reinterpret_cast<uint2*>(e_lo + g * d + 4 * j) = ll;
+    }
   }
 }
 
@@ -1243,13 +1251,17 @@ __global__ __launch_bounds__(256, (NV <= 2 ? 4 : 2)) void ln_relu_mean16_bwd4_ke
 static const bool g_ln4 = []() { const char* e = getenv("ADVMIL_LN4"); return !(e && e[0] == '0'); }();
 
 extern "C" int advmil_ln_relu_mean16_fwd(const float* y, const float* gamma, const float* beta, float eps, int64_t N,
-                                         int64_t d, float* emb, float* mean, float* rstd, advmil_stream_t stream) {
+                                         int64_t d, float* emb, float* mean, float* rstd, void* emb_hi, void* emb_lo, advmil_stream_t stream) {
   if (!y || !gamma || !beta || !emb || !mean || !rstd || N <= 0 || (N & 15) || d <= 0 || d > 512) return ADVMIL_EINVAL;
-  if (g_ln4 && (d & 127) == 0 && !((((uintptr_t)y) | ((uintptr_t)gamma) | ((uintptr_t)beta) | ((uintptr_t)emb)) & 15)) {
-    LN4_DISPATCH(d, ln_relu_mean16_fwd4_kernel, dim3((unsigned)(N / 16)), (hipStream_t)stream, y, gamma, beta, eps, N, emb, mean, rstd);
+  if ((emb_hi != nullptr) != (emb_lo != nullptr)) return ADVMIL_EINVAL;
+  if (g_ln4 && (d & 127) == 0 && !((((uintptr_t)y) | ((uintptr_t)gamma) | ((uintptr_t)beta) | ((uintptr_t)emb)) & 15) &&
+      !((((uintptr_t)emb_hi) | ((uintptr_t)emb_lo)) & 7)) {
+    LN4_DISPATCH(d, ln_relu_mean16_fwd4_kernel, dim3((unsigned)(N / 16)), (hipStream_t)stream, y, gamma, beta, eps, N, emb, mean, rstd,
+                 (bf16raw*)emb_hi, (bf16raw*)emb_lo);
     ADVMIL_LAUNCH_CHECK();
     return ADVMIL_OK;
   }
+  if (emb_hi) return ADVMIL_EINVAL;          // (the plane output rides in the 16-byte form only: d % 128 == 0)
   LN_DISPATCH(d, ln_relu_mean16_fwd_kernel, dim3((unsigned)(N / 16)), (hipStream_t)stream, y, gamma, beta, eps, N, d, emb, mean, rstd, 1);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
@@ -1436,7 +1448,8 @@ __global__ __launch_bounds__(256) void add_dropout_ln_fwd_kernel(const float* __
                                                                  float eps, int64_t R, int64_t d, float p, const uint64_t* seed,
                                                                  uint64_t stream_id, float* __restrict__ z, float* __restrict__ y,
                                                                  float* __restrict__ mean, float* __restrict__ rstd,
-                                                                 const int64_t* __restrict__ rng_row) {
+                                                                 const int64_t* __restrict__ rng_row, bf16raw* __restrict__ y_hi,
+                                                                 bf16raw* __restrict__ y_lo) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int Q = (int)((d + 63) / 64);
   const bool drop = seed && p > 0.f;
@@ -1476,7 +1489,16 @@ __global__ __launch_bounds__(256) void add_dropout_ln_fwd_kernel(const float* __
 #pragma unroll
     for (int q = 0; q < LN_MAXQ; ++q) {
       const int64_t j = lane + 64 * q;
-      if (q < Q && j < d) y[n * d + j] = (v[q] - mu) * rs * gamma[j] + beta[j];
+      if (q < Q && j < d) {
+        const float yv = (v[q] - mu) * rs * gamma[j] + beta[j];
+        y[n * d + j] = yv;
+        if (y_hi) {                          // operand planes of y for the plane-fed contraction that reads it next (FFN / gate branches)
+          unsigned hh, ll;
+          split2(yv, 0.f, hh, ll);
+          y_hi[n * d + j] = (bf16raw)(hh & 0xffffu);
+          y_lo[n * d + j] = (bf16raw)(ll & 0xffffu);
+        }
+      }
     }
   }
 }
@@ -1547,12 +1569,12 @@ __global__ __launch_bounds__(256) void add_dropout_ln_bwd_kernel(const float* __
 
 extern "C" int advmil_add_dropout_ln_fwd(const float* x, const float* o, const float* gamma, const float* beta, float eps,
                                          int64_t R, int64_t d, float drop_p, const uint64_t* seed, uint64_t stream_id,
-                                         const int64_t* rng_row, float* z, float* y, float* mean, float* rstd,
+                                         const int64_t* rng_row, float* z, float* y, float* mean, float* rstd, void* y_hi, void* y_lo,
                                          advmil_stream_t stream) {
   if (!x || !o || !gamma || !beta || !z || !y || !mean || !rstd || R <= 0 || d <= 0 || d > 512) return ADVMIL_EINVAL;
-  if (drop_p < 0.f || drop_p >= 1.f) return ADVMIL_EINVAL;
+  if (drop_p < 0.f || drop_p >= 1.f || ((y_hi != nullptr) != (y_lo != nullptr))) return ADVMIL_EINVAL;
   hipLaunchKernelGGL(add_dropout_ln_fwd_kernel, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, (hipStream_t)stream, x, o, gamma,
-                     beta, eps, R, d, drop_p, seed, stream_id, z, y, mean, rstd, rng_row);
+                     beta, eps, R, d, drop_p, seed, stream_id, z, y, mean, rstd, rng_row, (bf16raw*)y_hi, (bf16raw*)y_lo);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }

@@ -39,7 +39,9 @@ class HipTransformerEncoderLayer(nn.Module):
         o = ops.linear_act(o, sa.out_proj.weight, sa.out_proj.bias, "none")
         x2 = ops.add_dropout_layer_norm(x2, o, self.norm1.weight, self.norm1.bias, self.norm1.eps,
                                         self.dropout1.p if tr else 0.0, rng, "esat_drop1")
-        f = ops.linear_act(x2, self.linear1.weight, self.linear1.bias, "relu", self.dropout.p if tr else 0.0, rng, "esat_ffn")
+        # (every [L, d] activation of the layer reaches its contraction with operand planes: the region embedding and the two LayerNorm
+        # outputs leave their kernels with them, the FFN's hidden rows get them from this epilogue, the attention output from one split pass)
+        f = ops.linear_act(x2, self.linear1.weight, self.linear1.bias, "relu", self.dropout.p if tr else 0.0, rng, "esat_ffn", emit_planes=True)
         f = ops.linear_act(f, self.linear2.weight, self.linear2.bias, "none")
         return ops.add_dropout_layer_norm(x2, f, self.norm2.weight, self.norm2.bias, self.norm2.eps,
                                           self.dropout2.p if tr else 0.0, rng, "esat_drop2")

@@ -769,12 +769,23 @@ def colsum(x, M, N, out=None):
     return out
 
 
-def ln_relu_mean16_fwd(y, gamma, beta, N, d, eps=1e-5):
+# activations that a plane-fed contraction reads next leave their producer WITH operand planes (region embedding -> ESAT in-projection,
+# the two post-norm LayerNorm outputs -> FFN / gate branches, the attention output through one split pass -> out-projection)
+ROW_PLANES = os.environ.get("ADVMIL_ROW_PLANES", "0") != "0"      # measured: ESAT 32k 9.33-9.36 ms off, 9.41-9.44 ms on (one 256-row tile per CU: the plane-fed kernel has nothing to overlap) -> opt-in
+
+
+def _wants_row_planes(rows, d):
+    """Would an NT contraction over [rows, d] activations take the plane-fed kernel (any of the widths 384 / 768 / 1152 the layer uses)?"""
+    return bool(ROW_PLANES and USE_PLANES and get_gemm_mode() == "bf16x3" and rows >= 4096 and d % 128 == 0 and gemm_plan_planes(rows, d, d))
+
+
+def ln_relu_mean16_fwd(y, gamma, beta, N, d, eps=1e-5, planes=None):
     dev = y.device
     emb = torch.empty(N // 16, d, dtype=torch.float32, device=dev)
     mean = torch.empty(N, dtype=torch.float32, device=dev)
     rstd = torch.empty(N, dtype=torch.float32, device=dev)
     _lib.check(_lib.lib().advmil_ln_relu_mean16_fwd(_p(y), _p(gamma), _p(beta), eps, N, d, _p(emb), _p(mean), _p(rstd),
+                                                    _p(None if planes is None else planes.hi), _p(None if planes is None else planes.lo),
                                                     _stream()), "ln_relu_mean16_fwd")
     return emb, mean, rstd
 
@@ -1309,7 +1320,9 @@ class LNReLUMean16Fn(torch.autograd.Function):
         _chk(y, "y")
         y = y.contiguous()
         N, d = y.shape
-        emb, mean, rstd = ln_relu_mean16_fwd(y, gamma, beta, N, d, eps)
+        epl = Planes.alloc((N // 16, d), y.device) if _wants_row_planes(N // 16, d) else None
+        emb, mean, rstd = ln_relu_mean16_fwd(y, gamma, beta, N, d, eps, planes=epl)
+        LNReLUMean16Fn.last_planes = epl
         ctx.save_for_backward(y, gamma.detach(), beta.detach(), mean, rstd)
         gg, gb = _arena_grad(gamma), _arena_grad(beta)
         ctx.arena = (gg, gb) if (gg is not None and gb is not None) else None
@@ -1346,7 +1359,11 @@ def ln_relu_mean16(y, gamma, beta, eps=1e-5, ycol_grad=None):
     (`_advmil_wants_dy_planes`, set by linear_act: slab-sized layer, no input gradient, no bias of its own, planes of X resident), dy is
     produced as operand planes only."""
     want = bool(LN_DY_PLANES and ycol_grad is not None and getattr(y, "_advmil_wants_dy_planes", False) and y.is_contiguous())
-    return LNReLUMean16Fn.apply(y, gamma, beta, eps, ycol_grad, want)
+    emb = LNReLUMean16Fn.apply(y, gamma, beta, eps, ycol_grad, want)
+    epl, LNReLUMean16Fn.last_planes = getattr(LNReLUMean16Fn, "last_planes", None), None
+    if epl is not None:
+        emb._advmil_planes = epl
+    return emb
 
 
 class GateScoreFn(torch.autograd.Function):
@@ -1462,7 +1479,11 @@ def mha(qkv, nhead, p=0.0, rng=None, seg=None, rowoff=None):
     planes = getattr(qkv, "_advmil_planes", None) if qkv.is_contiguous() else None
     if getattr(qkv, "_advmil_planes_only", False) and planes is None:
         raise RuntimeError("advmil_amd: qkv was produced as operand planes only and lost them on the way to ops.mha")
-    return MhaFn.apply(qkv, nhead, float(p), seed, sid, seg, rowoff, planes)
+    out = MhaFn.apply(qkv, nhead, float(p), seed, sid, seg, rowoff, planes)
+    if _wants_row_planes(out.shape[0], out.shape[1]):
+        # (the forward kernel sits at its 128-register bound: its epilogue takes no plane stores; one split pass over [L, d] instead)
+        out._advmil_planes = split_planes(out.detach())
+    return out
 
 
 class AddDropoutLayerNormFn(torch.autograd.Function):
@@ -1480,8 +1501,11 @@ class AddDropoutLayerNormFn(torch.autograd.Function):
         mean = torch.empty(R, dtype=torch.float32, device=dev)
         rstd = torch.empty(R, dtype=torch.float32, device=dev)
         g_, b_ = gamma.detach(), beta.detach()
+        ypl = Planes.alloc((R, d), dev) if _wants_row_planes(R, d) else None
+        AddDropoutLayerNormFn.last_planes = ypl
         _lib.check(_lib.lib().advmil_add_dropout_ln_fwd(_p(x), _p(o), _p(g_), _p(b_), eps, R, d, p, _p(seed if p > 0.0 else None), sid,
-                                                        _p(rr if p > 0.0 else None), _p(z), _p(y), _p(mean), _p(rstd), _stream()),
+                                                        _p(rr if p > 0.0 else None), _p(z), _p(y), _p(mean), _p(rstd),
+                                                        _p(None if ypl is None else ypl.hi), _p(None if ypl is None else ypl.lo), _stream()),
                    "add_dropout_ln_fwd")
         ctx.save_for_backward(z, g_, mean, rstd)
         ctx.cfg = (p, seed, sid, rr)
@@ -1516,7 +1540,11 @@ def add_dropout_layer_norm(x, o, gamma, beta, eps=1e-5, p=0.0, rng=None, tag="")
     if p > 0.0:
         rng = rng or default_rng(x.device)
         sid, seed, rr = rng.site(tag, tuple(o.shape), p), rng.seed, rng.row_map(o.shape[0], tag)
-    return AddDropoutLayerNormFn.apply(x, o, gamma, beta, float(eps), float(p), seed, sid, rr)
+    y = AddDropoutLayerNormFn.apply(x, o, gamma, beta, float(eps), float(p), seed, sid, rr)
+    ypl, AddDropoutLayerNormFn.last_planes = getattr(AddDropoutLayerNormFn, "last_planes", None), None
+    if ypl is not None:
+        y._advmil_planes = ypl
+    return y
 
 
 class SegMeanFn(torch.autograd.Function):

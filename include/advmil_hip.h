@@ -194,9 +194,10 @@ int advmil_mha_bwd(const void* qkv_hi, const void* qkv_lo, const float* out, con
  * fwd also writes z = x + dropout(o), mean[R], rstd[R] for the backward; dropout element index = row*d + col on `stream_id`.
  * bwd: dx = LayerNorm'(dy); dob (may be NULL) = dx * keep; dgamma / dbeta = column sums (accumulate != 0 adds into them).
  * ws >= advmil_add_dropout_ln_bwd_workspace_bytes. */
+/* y_hi / y_lo (both or neither): also the bf16x3 operand planes of y, for the plane-fed contraction that reads it next. */
 int advmil_add_dropout_ln_fwd(const float* x, const float* o, const float* gamma, const float* beta, float eps, int64_t R,
                               int64_t d, float drop_p, const uint64_t* seed, uint64_t stream_id, const int64_t* rng_row, float* z,
-                              float* y, float* mean, float* rstd, advmil_stream_t stream);
+                              float* y, float* mean, float* rstd, void* y_hi, void* y_lo, advmil_stream_t stream);
 size_t advmil_add_dropout_ln_bwd_workspace_bytes(int64_t R, int64_t d);
 int advmil_add_dropout_ln_bwd(const float* dy, const float* z, const float* gamma, const float* mean, const float* rstd, int64_t R,
                               int64_t d, float drop_p, const uint64_t* seed, uint64_t stream_id, const int64_t* rng_row, float* dx,
@@ -283,8 +284,9 @@ int advmil_pending_sums(advmil_stream_t stream);
  * bwd: demb[N/16,d] -> dy[N,d], dgamma[d], dbeta[d]; dycol (optional, [d]) += column sums of dy -- the bias gradient of the FC
  * that produced y, which otherwise costs a second pass over dy. dy_hi / dy_lo (both or neither): the bf16x3 operand planes of dy for
  * the weight-gradient contraction dy^T X that consumes it (advmil_epilogue_t.a_hi / a_lo); with them dy may be NULL (planes only). */
+/* emb_hi / emb_lo (both or neither; d % 128 == 0): also the bf16x3 operand planes of emb (the ESAT in-projection reads it plane-fed). */
 int advmil_ln_relu_mean16_fwd(const float* y, const float* gamma, const float* beta, float eps, int64_t N, int64_t d,
-                              float* emb, float* mean, float* rstd, advmil_stream_t stream);
+                              float* emb, float* mean, float* rstd, void* emb_hi, void* emb_lo, advmil_stream_t stream);
 size_t advmil_ln_relu_mean16_bwd_workspace_bytes(int64_t N, int64_t d);
 int advmil_ln_relu_mean16_bwd(const float* demb, const float* y, const float* gamma, const float* beta,
                               const float* mean, const float* rstd, int64_t N, int64_t d, float* dy, float* dgamma,

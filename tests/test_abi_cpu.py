@@ -63,6 +63,27 @@ def test_epilogue_struct_layout_matches_c(built, tmp_path):
     assert out[1:] == [getattr(built.Epilogue, f).offset for f in fields]
 
 
+def test_tail_struct_layouts_match_c(built, tmp_path):
+    """advmil_dense_layer_t / advmil_dtail_t (the fused bag-level tail's argument block) against their ctypes mirrors."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    body = ""
+    for cname, cls in (("advmil_dense_layer_t", built.DenseLayer), ("advmil_dtail_t", built.DTail)):
+        body += f'printf("%zu\\n", sizeof({cname}));'
+        body += "".join(f'printf("%zu\\n", offsetof({cname}, {f}));' for f, _ in cls._fields_)
+    src = tmp_path / "layout2.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "advmil_hip.h"\n' f"int main(void){{{body}return 0;}}\n")
+    exe = tmp_path / "layout2"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    want = []
+    for cls in (built.DenseLayer, built.DTail):
+        want += [ctypes.sizeof(cls)] + [getattr(cls, f).offset for f, _ in cls._fields_]
+    assert out == want
+
+
 def test_product_path_has_no_cpu_fallback(built):
     from advmil_amd import ops
     from advmil_amd.model import load_backbone

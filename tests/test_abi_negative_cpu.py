@@ -8,7 +8,9 @@ import pytest
 
 EINVAL, EWORKSPACE = -1, -2
 HOST_ONLY = {"advmil_version", "advmil_set_gemm_mode", "advmil_get_gemm_mode", "advmil_gemm_f32_plan", "advmil_gemm_f32_plan_layout",
-             "advmil_gemm_f32_plan_planes", "advmil_gemm_f32_gate_blocks"}
+             "advmil_gemm_f32_plan_planes", "advmil_gemm_f32_gate_blocks",
+             # merge-queue bookkeeping on a stream handle (NULL = the default stream is a valid one): nothing to validate, nothing launched
+             "advmil_defer_sums", "advmil_flush_sums", "advmil_pending_sums"}
 A16 = 0x7F0000001000          # a fake, 16-byte aligned "device address": never dereferenced when validation does its job
 
 
@@ -78,7 +80,7 @@ def test_pooling_group_checks_shapes_and_workspace(L):
     assert lib.advmil_softmax_pool_fwd(p(0), p(1), D, N, D, 4, None, N, p(2), p(3), p(4), need, None) == EINVAL          # 4 bags, no offsets
     assert lib.advmil_softmax_pool_fwd(p(0), ctypes.c_void_p(A16 + 8), D, N, D, 1, None, N, p(2), p(3), p(4), need, None) == EINVAL
     assert lib.advmil_gate_score_fwd(p(0), p(1), p(2), 1.5, p(3), 1, 2, N, D, p(4), None, None) == EINVAL                # p >= 1
-    assert lib.advmil_ln_relu_mean16_fwd(p(0), p(1), p(2), 1e-5, 8200, 128, p(3), p(4), p(5), None) == EINVAL            # N % 16 != 0
+    assert lib.advmil_ln_relu_mean16_fwd(p(0), p(1), p(2), 1e-5, 8200, 128, p(3), p(4), p(5), None, None, None) == EINVAL   # N % 16 != 0
 
 
 def test_attention_group_checks_head_dim_and_segments(L):
