@@ -98,10 +98,10 @@ SIGNATURES = {
                                        c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "advmil_colsum": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "advmil_ln_relu_mean16_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int64, c_void_p, c_void_p,
-                                          c_void_p, c_void_p, c_void_p, c_void_p]),
+                                          c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "advmil_ln_relu_mean16_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "advmil_ln_relu_mean16_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
-                                          c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                          c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "advmil_ln_relu_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "advmil_ln_relu_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "advmil_ln_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
@@ -112,7 +112,8 @@ SIGNATURES = {
     "advmil_genconv_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64,
                                    c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "advmil_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
-                                 c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                 c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "advmil_step_seed_tick": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p]),
     "advmil_abs_sum": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "advmil_abs_sum_workspace_bytes": (c_size_t, [c_int64]),
     "advmil_uniform_fill": (c_int, [c_void_p, c_int64, c_void_p, c_uint64, c_void_p, c_int64, c_void_p]),

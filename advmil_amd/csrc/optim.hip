@@ -36,17 +36,29 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 __global__ void step_inc_kernel(int32_t* step) { *step += 1; }
+// the step counter's increment and the RNG seed's advance of an optimizer step's end as ONE one-thread launch
+__global__ void step_seed_tick_kernel(int32_t* step, uint64_t* seed, uint64_t inc) {
+  if (step) *step += 1;
+  if (seed) *seed += inc;
+}
 
 extern "C" int advmil_adam_step(float* p, const float* grad, float* m, float* v, const float* wd, int64_t n, float lr,
                                 float beta1, float beta2, float eps, float grad_scale, float l1_coef, int32_t* step,
-                                void* p_hi, void* p_lo, advmil_stream_t stream_) {
+                                void* p_hi, void* p_lo, int tick, advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!p || !grad || !m || !v || !step || n <= 0 || ((p_hi != nullptr) != (p_lo != nullptr))) return ADVMIL_EINVAL;
   int blocks = (int)((n + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, p, grad, m, v, wd, n, lr, beta1, beta2, eps, grad_scale,
                      l1_coef, step, (unsigned short*)p_hi, (unsigned short*)p_lo);
-  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, stream, step);
+  if (tick) hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, stream, step);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}
+
+extern "C" int advmil_step_seed_tick(int32_t* step, uint64_t* seed, uint64_t inc, advmil_stream_t stream_) {
+  if (!step && !seed) return ADVMIL_EINVAL;
+  hipLaunchKernelGGL(step_seed_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, step, seed, inc);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }

@@ -1072,7 +1072,7 @@ template <int NV>
 __global__ __launch_bounds__(256) void ln_relu_mean16_fwd4_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta, float eps, int64_t N, float* __restrict__ emb,
                                                                   float* __restrict__ mean, float* __restrict__ rstd,
-                                                                  bf16raw* __restrict__ e_hi, bf16raw* __restrict__ e_lo) {
+                                                                  bf16raw* __restrict__ e_hi, bf16raw* __restrict__ e_lo, int dup) {
   constexpr int d = 128 * NV;
   __shared__ __attribute__((aligned(16))) float red[8][d];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l = lane & 31, h = lane >> 5;
@@ -1126,6 +1126,7 @@ __global__ __launch_bounds__(256) void ln_relu_mean16_fwd4_kernel(const float* _
     }
     const float4 ev = make_float4(t.x * (1.f / 16.f), t.y * (1.f / 16.f), t.z * (1.f / 16.f), t.w * (1.f / 16.f));
     *reinterpret_cast<float4*>(emb + g * d + 4 * j) = ev;
+    if (dup == 2) *reinterpret_cast<float4*>(emb + ((int64_t)gridDim.x + g) * d + 4 * j) = ev;      // [emb; emb]: the stacked fake | real pass
     if (e_hi) {                              // operand planes of the region embedding for the plane-fed in-projection behind it (ESAT)
       uint2 hh, ll;
       split4(ev, hh, ll);
@@ -1140,7 +1141,7 @@ __global__ __launch_bounds__(256, (NV <= 2 ? 4 : 2)) void ln_relu_mean16_bwd4_ke
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                   const float* __restrict__ mean, const float* __restrict__ rstd, int64_t N,
                                                                   float* __restrict__ dy, float* __restrict__ partial,
-                                                                  bf16raw* __restrict__ o_hi, bf16raw* __restrict__ o_lo) {
+                                                                  bf16raw* __restrict__ o_hi, bf16raw* __restrict__ o_lo, int dup) {
   constexpr int d = 128 * NV;
   __shared__ __attribute__((aligned(16))) float red[8][3 * d];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l = lane & 31, h = lane >> 5;
@@ -1158,7 +1159,11 @@ __global__ __launch_bounds__(256, (NV <= 2 ? 4 : 2)) void ln_relu_mean16_bwd4_ke
     float mua[2], rsa[2];
 #pragma unroll
     for (int c = 0; c < NV; ++c) {
-      const float4 v = *reinterpret_cast<const float4*>(demb + g * d + c * 128 + 4 * l);
+      float4 v = *reinterpret_cast<const float4*>(demb + g * d + c * 128 + 4 * l);
+      if (dup == 2) {        // the embedding fed two stacked passes: its gradient is the sum of the two halves of demb [2 nreg, d]
+        const float4 v2 = *reinterpret_cast<const float4*>(demb + (nreg + g) * d + c * 128 + 4 * l);
+        v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
+      }
       de[c] = make_float4(v.x * (1.f / 16.f), v.y * (1.f / 16.f), v.z * (1.f / 16.f), v.w * (1.f / 16.f));
     }
 #pragma unroll
@@ -1251,17 +1256,18 @@ __global__ __launch_bounds__(256, (NV <= 2 ? 4 : 2)) void ln_relu_mean16_bwd4_ke
 static const bool g_ln4 = []() { const char* e = getenv("ADVMIL_LN4"); return !(e && e[0] == '0'); }();
 
 extern "C" int advmil_ln_relu_mean16_fwd(const float* y, const float* gamma, const float* beta, float eps, int64_t N,
-                                         int64_t d, float* emb, float* mean, float* rstd, void* emb_hi, void* emb_lo, advmil_stream_t stream) {
+                                         int64_t d, float* emb, float* mean, float* rstd, void* emb_hi, void* emb_lo, int dup,
+                                         advmil_stream_t stream) {
   if (!y || !gamma || !beta || !emb || !mean || !rstd || N <= 0 || (N & 15) || d <= 0 || d > 512) return ADVMIL_EINVAL;
-  if ((emb_hi != nullptr) != (emb_lo != nullptr)) return ADVMIL_EINVAL;
+  if ((emb_hi != nullptr) != (emb_lo != nullptr) || (dup != 1 && dup != 2)) return ADVMIL_EINVAL;
   if (g_ln4 && (d & 127) == 0 && !((((uintptr_t)y) | ((uintptr_t)gamma) | ((uintptr_t)beta) | ((uintptr_t)emb)) & 15) &&
       !((((uintptr_t)emb_hi) | ((uintptr_t)emb_lo)) & 7)) {
     LN4_DISPATCH(d, ln_relu_mean16_fwd4_kernel, dim3((unsigned)(N / 16)), (hipStream_t)stream, y, gamma, beta, eps, N, emb, mean, rstd,
-                 (bf16raw*)emb_hi, (bf16raw*)emb_lo);
+                 (bf16raw*)emb_hi, (bf16raw*)emb_lo, dup);
     ADVMIL_LAUNCH_CHECK();
     return ADVMIL_OK;
   }
-  if (emb_hi) return ADVMIL_EINVAL;          // (the plane output rides in the 16-byte form only: d % 128 == 0)
+  if (emb_hi || dup != 1) return ADVMIL_EINVAL;      // (plane output and duplication ride in the 16-byte form only: d % 128 == 0)
   LN_DISPATCH(d, ln_relu_mean16_fwd_kernel, dim3((unsigned)(N / 16)), (hipStream_t)stream, y, gamma, beta, eps, N, d, emb, mean, rstd, 1);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
@@ -1389,7 +1395,7 @@ extern "C" size_t advmil_ln_relu_mean16_bwd_workspace_bytes(int64_t N, int64_t d
 
 extern "C" int advmil_ln_relu_mean16_bwd(const float* demb, const float* y, const float* gamma, const float* beta,
                                          const float* mean, const float* rstd, int64_t N, int64_t d, float* dy,
-                                         float* dgamma, float* dbeta, int accumulate, float* dycol, void* dy_hi, void* dy_lo,
+                                         float* dgamma, float* dbeta, int accumulate, float* dycol, void* dy_hi, void* dy_lo, int dup,
                                          void* ws, size_t ws_bytes, advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!demb || !y || !gamma || !beta || !mean || !rstd || (!dy && !dy_hi) || !dgamma || !dbeta || !ws || N <= 0 || (N & 15) || d <= 0 ||
@@ -1400,7 +1406,9 @@ extern "C" int advmil_ln_relu_mean16_bwd(const float* demb, const float* y, cons
   float* partial = (float*)ws;
   if (g_ln4 && (d & 127) == 0 && !((((uintptr_t)y) | ((uintptr_t)gamma) | ((uintptr_t)beta) | ((uintptr_t)demb) | ((uintptr_t)dy) | ((uintptr_t)partial)) & 15) &&
       !((((uintptr_t)dy_hi) | ((uintptr_t)dy_lo)) & 7)) {
-    LN4_DISPATCH(d, ln_relu_mean16_bwd4_kernel, dim3(L), stream, demb, y, gamma, beta, mean, rstd, N, dy, partial, (bf16raw*)dy_hi, (bf16raw*)dy_lo);
+    LN4_DISPATCH(d, ln_relu_mean16_bwd4_kernel, dim3(L), stream, demb, y, gamma, beta, mean, rstd, N, dy, partial, (bf16raw*)dy_hi, (bf16raw*)dy_lo, dup);
+  } else if (dup != 1) {
+    return ADVMIL_EINVAL;
   } else
   LN_DISPATCH(d, ln_relu_mean16_bwd_kernel, dim3(L), stream, demb, y, gamma, beta, mean, rstd, N, d, dy, partial, 1, (bf16raw*)dy_hi,
               (bf16raw*)dy_lo);

@@ -23,6 +23,15 @@
 #define RC_ROWS 64
 #define RC_PITCH 36      // fp32 patch row pitch (32 + 4)
 
+// Workgroup barrier for LDS data only: __syncthreads() also drains vmcnt, i.e. waits for the ACKs of every global store issued so far
+// (the saved activations of the layer just finished: 1-2 us each time); everything these kernels exchange between waves is in LDS.
+#define LDS_BARRIER()                                   \
+  do {                                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
+    __builtin_amdgcn_s_barrier();                       \
+    asm volatile("" ::: "memory");                      \
+  } while (0)
+
 #define RC_WAVE_SYNC()                                     \
   do {                                                     \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
@@ -41,24 +50,32 @@ __device__ __forceinline__ int rc_off(int row, int unit) {
 }
 
 // acc[a][b] += A[rows of block rb0 + a] . B[cols n0[b] ..]^T over K: A = LDS plane images (hi, lo) [64][K], B = global planes [n][K]
-// The weight fragments of the WHOLE product are requested before the first MFMA (K / 16 x NCB x 2 planes x 4 registers: 32-128 VGPRs; one
-// workgroup per CU leaves a wave the full register file): with one k-step of prefetch every step waited a full L2 round trip behind
-// 6-12 MFMAs -- 24 us per launch whatever the row count.
+// The weight fragments of a WHOLE product are requested up front (K / 16 x NCB x 2 planes x 4 registers: 32-128 VGPRs; one workgroup per
+// CU leaves a wave the full register file) -- and, in the kernels below, one product AHEAD: the next layer's fragments are in flight
+// while the current layer's epilogue runs, the first layers' (and every bias / scorer vector) from the top of the kernel. Per launch
+// that leaves ~3 dependent global round trips instead of ~8 (a 64-row tile is latency, not work: 23-27 us per launch whatever the rows).
+template <int K, int NCB>
+struct RcFrags {
+  Frag8 h[K / 16][NCB], l[K / 16][NCB];
+  __device__ __forceinline__ void load(const bf16raw* __restrict__ Bh, const bf16raw* __restrict__ Bl, const int (&n0)[NCB], int lane) {
+    const int i = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < K / 16; ++ks)
+#pragma unroll
+      for (int b = 0; b < NCB; ++b) {
+        const int64_t o = (int64_t)(n0[b] + i) * K + ks * 16 + hi * 8;
+        h[ks][b].u = *reinterpret_cast<const uint4*>(Bh + o);
+        l[ks][b].u = *reinterpret_cast<const uint4*>(Bl + o);
+      }
+    __builtin_amdgcn_sched_barrier(0);       // (keeps the scheduler from sinking the loads back to their first use)
+  }
+};
+
+// acc[a][b] += A[rows of block rb0 + a] . B[cols of fragment set b]^T over K: A = LDS plane images (hi, lo) [64][K], B = fragments in registers
 template <int K, int NRB, int NCB>
-__device__ __forceinline__ void rc_mma(const bf16raw* __restrict__ Ah, const bf16raw* __restrict__ Al, int rb0,
-                                       const bf16raw* __restrict__ Bh, const bf16raw* __restrict__ Bl, const int (&n0)[NCB],
+__device__ __forceinline__ void rc_mma(const bf16raw* __restrict__ Ah, const bf16raw* __restrict__ Al, int rb0, const RcFrags<K, NCB>& f,
                                        f32x16 (&acc)[NRB][NCB], int lane) {
   const int i = lane & 31, hi = lane >> 5;
-  Frag8 bh[K / 16][NCB], bl[K / 16][NCB];
-#pragma unroll
-  for (int ks = 0; ks < K / 16; ++ks)
-#pragma unroll
-    for (int b = 0; b < NCB; ++b) {
-      const int64_t o = (int64_t)(n0[b] + i) * K + ks * 16 + hi * 8;
-      bh[ks][b].u = *reinterpret_cast<const uint4*>(Bh + o);
-      bl[ks][b].u = *reinterpret_cast<const uint4*>(Bl + o);
-    }
-  __builtin_amdgcn_sched_barrier(0);       // (keeps the scheduler from sinking the loads back to their first use)
 #pragma unroll
   for (int ks = 0; ks < K / 16; ++ks) {
     Frag8 ah[NRB], al[NRB];
@@ -72,9 +89,9 @@ __device__ __forceinline__ void rc_mma(const bf16raw* __restrict__ Ah, const bf1
     for (int a = 0; a < NRB; ++a)
 #pragma unroll
       for (int b = 0; b < NCB; ++b) {
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a].v, bh[ks][b].v, acc[a][b], 0, 0, 0);
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a].v, bl[ks][b].v, acc[a][b], 0, 0, 0);
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a].v, bh[ks][b].v, acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a].v, f.h[ks][b].v, acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a].v, f.l[ks][b].v, acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a].v, f.h[ks][b].v, acc[a][b], 0, 0, 0);
       }
   }
 }
@@ -120,13 +137,26 @@ __global__ __launch_bounds__(256) void dx_chain_fwd_kernel(RcFwdArgs g) {
   const int64_t r0 = (int64_t)blockIdx.x * RC_ROWS;
   bf16raw* const Xh = sX; bf16raw* const Xl = sX + RC_ROWS * RC_D;
   bf16raw* const Hh = sH; bf16raw* const Hl = sH + RC_ROWS * RC_H;
-  for (int idx = tid; idx < RC_ROWS * (RC_D / 4); idx += 256) {
-    const int row = idx / (RC_D / 4), c4 = idx % (RC_D / 4);
-    const float4 v = (r0 + row < g.R) ? *reinterpret_cast<const float4*>(g.e + (r0 + row) * RC_D + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    rc_put_planes<RC_D>(Xh, Xl, row, c4 * 4, v);
-  }
-  __syncthreads();
+  // every parameter read of the launch that does not depend on the rows, up front: the first two layers' weight fragments, the biases
+  // and the scorer's output weights of this lane's columns
   const int c4 = (lane & 7) * 4, rq = lane >> 3;
+  const int n1[1] = {(wave & 1) * 32}, n2[1] = {wave * 32}, ng[2] = {wave * 32, RC_D + wave * 32};
+  RcFrags<RC_D, 1> f1;
+  RcFrags<RC_H, 1> f2;
+  f1.load(g.W1h, g.W1l, n1, lane);
+  f2.load(g.W2h, g.W2l, n2, lane);
+  const float4 b1v = *reinterpret_cast<const float4*>(g.b1 + n1[0] + c4);
+  const float4 b2v = *reinterpret_cast<const float4*>(g.b2 + n2[0] + c4);
+  const float4 bav = *reinterpret_cast<const float4*>(g.bab + wave * 32 + c4);
+  const float4 bbv = *reinterpret_cast<const float4*>(g.bab + RC_D + wave * 32 + c4);
+  const float4 wv = *reinterpret_cast<const float4*>(g.wc + wave * 32 + c4);
+  const float bcv = g.bc ? g.bc[0] : 0.f;
+  for (int idx = tid; idx < RC_ROWS * (RC_D / 4); idx += 256) {
+    const int row = idx / (RC_D / 4), c4e = idx % (RC_D / 4);
+    const float4 v = (r0 + row < g.R) ? *reinterpret_cast<const float4*>(g.e + (r0 + row) * RC_D + c4e * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    rc_put_planes<RC_D>(Xh, Xl, row, c4e * 4, v);
+  }
+  LDS_BARRIER();
   const bool d1 = g.seed && g.p1 > 0.f, dg = g.seed && g.pg > 0.f;
   uint64_t k1 = 0, ka = 0, kb = 0;
   float inv1 = 1.f, invg = 1.f;
@@ -142,13 +172,12 @@ __global__ __launch_bounds__(256) void dx_chain_fwd_kernel(RcFwdArgs g) {
     f32x16 acc[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
-    const int n0[1] = {(wave & 1) * 32};
     const int rb = wave >> 1;
-    rc_mma<RC_D, 1, 1>(Xh, Xl, rb, g.W1h, g.W1l, n0, acc, lane);
+    rc_mma<RC_D, 1, 1>(Xh, Xl, rb, f1, acc, lane);
     rc_to_patch(acc[0][0], pa, lane);
     RC_WAVE_SYNC();
-    const int col = n0[0] + c4;
-    const float4 bv = *reinterpret_cast<const float4*>(g.b1 + col);
+    const int col = n1[0] + c4;
+    const float4 bv = b1v;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int row = rb * 32 + q * 8 + rq;
@@ -166,7 +195,9 @@ __global__ __launch_bounds__(256) void dx_chain_fwd_kernel(RcFwdArgs g) {
       rc_put_planes<RC_H>(Hh, Hl, row, col, v);
     }
   }
-  __syncthreads();          // h1's planes complete; every wave is done reading e's planes
+  RcFrags<RC_D, 2> fg;          // the scorer's fragments: in flight under layer 2
+  fg.load(g.Wabh, g.Wabl, ng, lane);
+  LDS_BARRIER();          // h1's planes complete; every wave is done reading e's planes
   // ---- layer 2: wave -> columns 32 wave .., both row blocks
   {
     f32x16 acc[2][1];
@@ -174,10 +205,9 @@ __global__ __launch_bounds__(256) void dx_chain_fwd_kernel(RcFwdArgs g) {
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][0][r] = 0.f;
-    const int n0[1] = {wave * 32};
-    rc_mma<RC_H, 2, 1>(Hh, Hl, 0, g.W2h, g.W2l, n0, acc, lane);
-    const int col = n0[0] + c4;
-    const float4 bv = *reinterpret_cast<const float4*>(g.b2 + col);
+    rc_mma<RC_H, 2, 1>(Hh, Hl, 0, f2, acc, lane);
+    const int col = n2[0] + c4;
+    const float4 bv = b2v;
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       rc_to_patch(acc[a][0], pa, lane);
@@ -195,7 +225,7 @@ __global__ __launch_bounds__(256) void dx_chain_fwd_kernel(RcFwdArgs g) {
       RC_WAVE_SYNC();
     }
   }
-  __syncthreads();          // fc's planes complete
+  LDS_BARRIER();          // fc's planes complete
   // ---- gates: wave -> tanh columns 32 wave .. and sigmoid columns 128 + 32 wave .., both row blocks
   {
     f32x16 acc[2][2];
@@ -205,12 +235,8 @@ __global__ __launch_bounds__(256) void dx_chain_fwd_kernel(RcFwdArgs g) {
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    const int n0[2] = {wave * 32, RC_D + wave * 32};
-    rc_mma<RC_D, 2, 2>(Xh, Xl, 0, g.Wabh, g.Wabl, n0, acc, lane);
+    rc_mma<RC_D, 2, 2>(Xh, Xl, 0, fg, acc, lane);
     const int col = wave * 32 + c4;            // j of the lane's four gate units
-    const float4 bav = *reinterpret_cast<const float4*>(g.bab + col);
-    const float4 bbv = *reinterpret_cast<const float4*>(g.bab + RC_D + col);
-    const float4 wv = *reinterpret_cast<const float4*>(g.wc + col);
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       rc_to_patch(acc[a][0], pa, lane);
@@ -246,8 +272,8 @@ __global__ __launch_bounds__(256) void dx_chain_fwd_kernel(RcFwdArgs g) {
       RC_WAVE_SYNC();
     }
   }
-  __syncthreads();
-  if (tid < RC_ROWS && r0 + tid < g.R) g.s[r0 + tid] = ((sS[0][tid] + sS[1][tid]) + (sS[2][tid] + sS[3][tid])) + (g.bc ? g.bc[0] : 0.f);
+  LDS_BARRIER();
+  if (tid < RC_ROWS && r0 + tid < g.R) g.s[r0 + tid] = ((sS[0][tid] + sS[1][tid]) + (sS[2][tid] + sS[3][tid])) + bcv;
 }
 
 // ======================================================================================================================================
@@ -293,6 +319,10 @@ __global__ __launch_bounds__(256) void dx_chain_bwd_kernel(RcBwdArgs g) {
   uint64_t ka = 0, kb = 0;
   float invg = 1.f;
   if (dg) { const uint64_t sd = *g.seed; ka = rng_key(sd, g.sida); kb = rng_key(sd, g.sidb); invg = hw_rcp(1.f - g.pg); }
+  // the first product's weight fragments (WabT, 128 registers) fly under the gate backward
+  const int nA[1] = {wave * 32}, nB[1] = {(wave & 1) * 32};
+  RcFrags<2 * RC_D, 1> fA;
+  fA.load(g.WabTh, g.WabTl, nA, lane);
   // ---- gate backward: thread -> 4 gate units j = 4 (tid & 31) .., rows (tid >> 5) + 8 it
   {
     const int j = (tid & 31) * 4, rg = tid >> 5;
@@ -333,7 +363,7 @@ __global__ __launch_bounds__(256) void dx_chain_bwd_kernel(RcBwdArgs g) {
     *reinterpret_cast<float4*>(&sR[rg][2 * RC_D + j]) = make_float4(sb[0], sb[1], sb[2], sb[3]);
     if ((tid & 31) == 0) sDs[rg] = sds;
   }
-  __syncthreads();          // dG's planes and the column-sum staging complete
+  LDS_BARRIER();          // dG's planes and the column-sum staging complete
   for (int c = tid; c < 3 * RC_D; c += 256) {
     float t = 0.f;
 #pragma unroll
@@ -355,9 +385,8 @@ __global__ __launch_bounds__(256) void dx_chain_bwd_kernel(RcBwdArgs g) {
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][0][r] = 0.f;
-    const int n0[1] = {wave * 32};
-    rc_mma<2 * RC_D, 2, 1>(Gh, Gl, 0, g.WabTh, g.WabTl, n0, acc, lane);
-    const int col = n0[0] + c4;
+    rc_mma<2 * RC_D, 2, 1>(Gh, Gl, 0, fA, acc, lane);
+    const int col = nA[0] + c4;
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
@@ -398,18 +427,22 @@ __global__ __launch_bounds__(256) void dx_chain_bwd_kernel(RcBwdArgs g) {
     }
     if (rq == 0) *reinterpret_cast<float4*>(prow + 3 * RC_D + 4 + col) = make_float4(cs[0], cs[1], cs[2], cs[3]);      // db2
   }
-  __syncthreads();          // dfc's planes complete
+  // the two remaining products' fragments (W2T 64 + W1T 32 registers): requested before the barrier, consumed behind it
+  RcFrags<RC_D, 1> fB;
+  RcFrags<RC_H, 1> fC;
+  fB.load(g.W2Th, g.W2Tl, nB, lane);
+  if (g.de) fC.load(g.W1Th, g.W1Tl, nA, lane);
+  LDS_BARRIER();          // dfc's planes complete
   // ---- dpre = (dfc W2T^T) masked by h1: wave -> block (rb = wave >> 1, columns 32 (wave & 1) ..)
   {
     f32x16 acc[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
-    const int n0[1] = {(wave & 1) * 32};
     const int rb = wave >> 1;
-    rc_mma<RC_D, 1, 1>(Fh, Fl, rb, g.W2Th, g.W2Tl, n0, acc, lane);
+    rc_mma<RC_D, 1, 1>(Fh, Fl, rb, fB, acc, lane);
     rc_to_patch(acc[0][0], pa, lane);
     RC_WAVE_SYNC();
-    const int col = n0[0] + c4;
+    const int col = nB[0] + c4;
     const float inv1 = g.p1 > 0.f ? hw_rcp(1.f - g.p1) : 1.f;
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -434,7 +467,7 @@ __global__ __launch_bounds__(256) void dx_chain_bwd_kernel(RcBwdArgs g) {
     }
     if (rq == 0) *reinterpret_cast<float4*>(&sB1[rb][col]) = make_float4(cs[0], cs[1], cs[2], cs[3]);
   }
-  __syncthreads();          // dpre's planes and the two row blocks' db1 pieces complete
+  LDS_BARRIER();          // dpre's planes and the two row blocks' db1 pieces complete
   if (tid < RC_H) prow[3 * RC_D + 4 + RC_D + tid] = sB1[0][tid] + sB1[1][tid];
   if (g.de) {
     // ---- de = dpre W1T^T: wave -> columns 32 wave .., both row blocks
@@ -443,9 +476,8 @@ __global__ __launch_bounds__(256) void dx_chain_bwd_kernel(RcBwdArgs g) {
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][0][r] = 0.f;
-    const int n0[1] = {wave * 32};
-    rc_mma<RC_H, 2, 1>(Dh, Dl, 0, g.W1Th, g.W1Tl, n0, acc, lane);
-    const int col = n0[0] + c4;
+    rc_mma<RC_H, 2, 1>(Dh, Dl, 0, fC, acc, lane);
+    const int col = nA[0] + c4;
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       rc_to_patch(acc[a][0], pa, lane);

@@ -20,6 +20,15 @@
 #define T3_PD (T3_D + 4)       // LDS row pitch of a [32][128] image
 #define T3_PH (T3_H + 4)       // ... of a [32][64] image
 
+// Workgroup barrier for LDS data only: __syncthreads() also drains vmcnt, i.e. waits for the ACKs of every global store issued so far
+// (the saved activations of the layer just finished: 1-2 us each time); everything these kernels exchange between waves is in LDS.
+#define LDS_BARRIER()                                   \
+  do {                                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
+    __builtin_amdgcn_s_barrier();                       \
+    asm volatile("" ::: "memory");                      \
+  } while (0)
+
 struct Tail3Args {
   advmil_dtail_t a;
 };
@@ -87,7 +96,7 @@ __global__ __launch_bounds__(T3_NT) void dtail3_fwd_kernel(Tail3Args g) {
   const float bx0 = X0.bias ? X0.bias[tid & 63] : 0.f;                 // stage-1 reduce: column tid % 64
   const int n2 = tid & 127;                                            // stage-2 reduce: column tid % 128
   const float bx1 = X1.bias ? X1.bias[n2] : 0.f, by1 = Y1.bias ? Y1.bias[n2] : 0.f;
-  __syncthreads();
+  LDS_BARRIER();
   // ---- stage 1: fc2[0] partial products; the label layer 1 elementwise
   {
     f32x16 acc;
@@ -113,7 +122,7 @@ __global__ __launch_bounds__(T3_NT) void dtail3_fwd_kernel(Tail3Args g) {
       if (b < B) Y0.y[(int64_t)b * T3_H + n1] = v;
     }
   }
-  __syncthreads();
+  LDS_BARRIER();
   // ---- stage 1 reduce: h1[b][n] = dropout(act(sum over the 8 parts + bias)), 2 elements per thread
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(T3_NT) void dtail3_fwd_kernel(Tail3Args g) {
     sH1[b * T3_PH + n] = v;
     if (b < B) X0.y[(int64_t)b * T3_H + n] = v;
   }
-  __syncthreads();
+  LDS_BARRIER();
   // ---- stage 2: fc2[3] (A = h1) and the label layer 2 (A = t1), inner 64 in 2 parts
   {
     f32x16 acc;
@@ -145,7 +154,7 @@ __global__ __launch_bounds__(T3_NT) void dtail3_fwd_kernel(Tail3Args g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) sPart[wave][r * 64 + lane] = acc[r];
   }
-  __syncthreads();
+  LDS_BARRIER();
   // ---- stage 2 reduce: hx / ht [b][n], 4 rows per thread and layer
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(T3_NT) void dtail3_fwd_kernel(Tail3Args g) {
     sHT[b * T3_PD + n2] = vt;
     if (b < B) { X1.y[(int64_t)b * T3_D + n2] = vx; Y1.y[(int64_t)b * T3_D + n2] = vt; }
   }
-  __syncthreads();
+  LDS_BARRIER();
   // ---- head: out[b] = <u, ht> + <src, w> + bias, one wave per row
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -264,7 +273,7 @@ __global__ __launch_bounds__(T3_NT) void dtail3_bwd_kernel(Tail3Args g) {
   }
   const float iY0 = dY0 ? hw_rcp(1.f - Y0.drop_p) : 1.f, iX0 = dX0 ? hw_rcp(1.f - X0.drop_p) : 1.f;
   const float iY1 = dY1 ? hw_rcp(1.f - Y1.drop_p) : 1.f, iX1 = dX1 ? hw_rcp(1.f - X1.drop_p) : 1.f;
-  __syncthreads();
+  LDS_BARRIER();
   // ---- head + the last layers' activation backward: dpx2 [b][n] (fc2[3]), dpy2 [b][n] (label layer 2); d u out; prj gradients
   {
     float swp = 0.f;
@@ -288,7 +297,7 @@ __global__ __launch_bounds__(T3_NT) void dtail3_bwd_kernel(Tail3Args g) {
     // d w_prj[j] = sum_b g[b] src[b][j]: the 8 row groups (tid >> 7) of column n2 meet in sPart
     if (a.prj_src && a.dw_prj) sPart[tid >> 7][n2] = swp;
   }
-  __syncthreads();
+  LDS_BARRIER();
   if (a.prj_src && a.dw_prj && tid < T3_D) {
     float s = 0.f;
 #pragma unroll
@@ -307,7 +316,7 @@ __global__ __launch_bounds__(T3_NT) void dtail3_bwd_kernel(Tail3Args g) {
     const int n = tid - T3_D;
     if (Y1.dbias) { float s = 0.f; for (int b = 0; b < B; ++b) s += sDT[b * T3_PD + n]; Y1.dbias[n] += s; }
   }
-  __syncthreads();          // (sPart is reused below)
+  LDS_BARRIER();          // (sPart is reused below)
   // ---- phase A: weight gradients of the last layers (16 blocks of 32 x 32), then the input gradients' partial products
   {
     const int nb = (wave & 7) >> 1, kb = wave & 1;             // waves 0-7: fc2[3] [128][64], waves 8-15: label layer 2 [128][64]
@@ -330,7 +339,7 @@ __global__ __launch_bounds__(T3_NT) void dtail3_bwd_kernel(Tail3Args g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) sPart[wave][r * 64 + lane] = acc[r];
   }
-  __syncthreads();
+  LDS_BARRIER();
   // ---- reduce: d h1 / d t1 [b][k] (k < 64), then the first layers' activation backward -> dpx1, dpy1
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -347,7 +356,7 @@ __global__ __launch_bounds__(T3_NT) void dtail3_bwd_kernel(Tail3Args g) {
     sD1[b * T3_PH + k] = d1;
     sE1[b * T3_PH + k] = e1;
   }
-  __syncthreads();
+  LDS_BARRIER();
   // ---- phase B: first layers. Bias / width-1 weight gradients by threads, fc2[0]'s weight gradient and d emb_bag by waves
   if (tid < T3_H) {
     if (X0.dbias) { float s = 0.f; for (int b = 0; b < B; ++b) s += sD1[b * T3_PH + tid]; X0.dbias[tid] += s; }
@@ -386,7 +395,7 @@ __global__ __launch_bounds__(T3_NT) void dtail3_bwd_kernel(Tail3Args g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) sPart[wave][r * 64 + lane] = acc[r];
   }
-  __syncthreads();
+  LDS_BARRIER();
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int b = (tid >> 7) + 8 * s;

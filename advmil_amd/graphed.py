@@ -24,6 +24,8 @@ import os
 
 import torch
 
+from . import ops
+
 
 class GraphedStep:
     def __init__(self, handler, xs, ys, ys_host, mode="wlabel", label_visible_mask=None, warmup=2, force_segments=False,
@@ -82,8 +84,8 @@ class GraphedStep:
 
     def _seg_end(self):
         self.h._log_g()
-        self.h.optimizerG.step()
-        self.h.rng.advance(1)
+        self.h.optimizerG.step(tick=False)
+        ops.step_seed_tick(self.h.optimizerG.step_t, self.h.rng.seed, 1)      # G's step counter and the RNG seed: one launch
 
     def _eager(self):
         self._seg_disc()

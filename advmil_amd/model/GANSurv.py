@@ -73,9 +73,9 @@ class _PairNet(nn.Module):
     def embed_x(self, x):
         return self.net_pair_one.embed(x)
 
-    def embed_rows(self, X):
-        """Slab form: X[N_total, C] -> region embeddings [N_total/16, C']."""
-        return self.net_pair_one.embedding.embed_rows(X)
+    def embed_rows(self, X, dup=1):
+        """Slab form: X[N_total, C] -> region embeddings [N_total/16, C'] (dup = 2: stacked twice)."""
+        return self.net_pair_one.embedding.embed_rows(X, dup) if dup != 1 else self.net_pair_one.embedding.embed_rows(X)
 
     def forward(self, x, t):
         return self.from_embedding(self.embed_x(x), t)

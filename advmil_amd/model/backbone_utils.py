@@ -96,19 +96,23 @@ class AVGPoolPatchEmbedding(nn.Module):
         self.norm = nn.LayerNorm(out_dim)
         self.act = nn.ReLU(inplace=True)
 
-    def embed_rows(self, x2):
+    def embed_rows(self, x2, dup=1):
         """x2[N_total, C] -> [N_total/16, out_dim]; rows may be a slab of bags (each bag a multiple of 16 rows, so the
-        16-row regions never straddle two bags)."""
+        16-row regions never straddle two bags). dup = 2: the embedding twice, stacked ([emb; emb], the discriminator update's fake |
+        real batch) straight from the kernel -- its backward sums the two halves of the gradient on load."""
         assert x2.shape[0] % (self.scale * self.scale) == 0
+        if dup != 1 and not ops.ln_relu_mean16_dup_ok(self.norm.normalized_shape[0]):
+            e = self.embed_rows(x2)
+            return torch.cat([e] * dup, dim=0)
         b = self.conv.bias
         gb = ops._arena_grad(b) if (b is not None and b.requires_grad and torch.is_grad_enabled()) else None
         if gb is not None:
             # the FC's bias gradient is the column sum of dy, which the LayerNorm backward produces while it writes dy: the FC
             # itself sees a constant bias and never re-reads dy (805 MB at the 32768-patch slab) for it
             y = ops.linear_act(x2, self.conv.weight, b.detach(), "none")
-            return ops.ln_relu_mean16(y, self.norm.weight, self.norm.bias, self.norm.eps, ycol_grad=gb.view(-1))
+            return ops.ln_relu_mean16(y, self.norm.weight, self.norm.bias, self.norm.eps, ycol_grad=gb.view(-1), dup=dup)
         y = ops.linear_act(x2, self.conv.weight, b, "none")
-        return ops.ln_relu_mean16(y, self.norm.weight, self.norm.bias, self.norm.eps)
+        return ops.ln_relu_mean16(y, self.norm.weight, self.norm.bias, self.norm.eps, dup=dup)
 
     def forward(self, x):
         if x.dim() != 3 or x.shape[0] != 1:

@@ -587,15 +587,16 @@ class MyHandler(object):
         if self.overlap_gfwd and self.dp.world == 1:      # everything _gen_forward reads exists from here on
             self._fork_evt = torch.cuda.Event()
             self._fork_evt.record()
-        emb = self.netD.embed_rows(X)                                          # shared by the real and the fake pairs
         f_real = f2 = None
+        # the region embedding is shared by the real and the fake pairs; with real pairs in the step it leaves its kernel stacked twice
+        emb = self.netD.embed_rows(X, 2) if plan.n_real > 0 else self.netD.embed_rows(X)
         if plan.n_real > 0:                  # GLOBAL count: every rank of a bag-parallel step takes the same branch / draws
             # The fake pairs (all bags) and the real pairs go through the region-level network and the tail as ONE stacked batch:
             # rows [0, L) are the fake pass, rows [L, 2L) the real pass (its own dropout draw, as a separate forward has, because
             # the draw is indexed by row). Every kernel of the tail -- ~120 launches per pass -- runs once instead of twice; real
             # scores of bags without a visible event are computed and dropped (B rows of [B,d] work).
             nb = len(xs)
-            eb2, im2 = self.netD.bag_features_multi(torch.cat([emb, emb], dim=0), plan.seg16.twice())
+            eb2, im2 = self.netD.bag_features_multi(emb, plan.seg16.twice())
             eb2, im2 = self._bags(eb2, plan, True), self._bags(im2, plan, True)
             f2 = self.netD.tail(eb2, im2, torch.cat([pred, plan.y_t], dim=0)).view(-1)
             f_fake = f2.detach()[:nb]                                           # (the loss takes f2 whole: no slice backward)

@@ -779,18 +779,18 @@ def _wants_row_planes(rows, d):
     return bool(ROW_PLANES and USE_PLANES and get_gemm_mode() == "bf16x3" and rows >= 4096 and d % 128 == 0 and gemm_plan_planes(rows, d, d))
 
 
-def ln_relu_mean16_fwd(y, gamma, beta, N, d, eps=1e-5, planes=None):
+def ln_relu_mean16_fwd(y, gamma, beta, N, d, eps=1e-5, planes=None, dup=1):
     dev = y.device
-    emb = torch.empty(N // 16, d, dtype=torch.float32, device=dev)
+    emb = torch.empty(dup * (N // 16), d, dtype=torch.float32, device=dev)
     mean = torch.empty(N, dtype=torch.float32, device=dev)
     rstd = torch.empty(N, dtype=torch.float32, device=dev)
     _lib.check(_lib.lib().advmil_ln_relu_mean16_fwd(_p(y), _p(gamma), _p(beta), eps, N, d, _p(emb), _p(mean), _p(rstd),
                                                     _p(None if planes is None else planes.hi), _p(None if planes is None else planes.lo),
-                                                    _stream()), "ln_relu_mean16_fwd")
+                                                    int(dup), _stream()), "ln_relu_mean16_fwd")
     return emb, mean, rstd
 
 
-def ln_relu_mean16_bwd(demb, y, gamma, beta, mean, rstd, N, d, dg_out=None, db_out=None, ycol_out=None, planes=None):
+def ln_relu_mean16_bwd(demb, y, gamma, beta, mean, rstd, N, d, dg_out=None, db_out=None, ycol_out=None, planes=None, dup=1):
     """ycol_out: optional [d] accumulator that receives += column sums of dy (the bias gradient of the FC that produced y).
     planes: Planes that receive dy's bf16x3 operand planes INSTEAD of the fp32 values (the returned dy is then an unwritten token)."""
     L = _lib.lib()
@@ -803,17 +803,22 @@ def ln_relu_mean16_bwd(demb, y, gamma, beta, mean, rstd, N, d, dg_out=None, db_o
     ws = _ws(wsb, dev)
     _lib.check(L.advmil_ln_relu_mean16_bwd(_p(demb), _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), N, d, _p(None if planes is not None else dy),
                                            _p(dg), _p(db), 1 if acc else 0, _p(ycol_out), _p(None if planes is None else planes.hi),
-                                           _p(None if planes is None else planes.lo), _p(ws), wsb, _stream()), "ln_relu_mean16_bwd")
+                                           _p(None if planes is None else planes.lo), int(dup), _p(ws), wsb, _stream()), "ln_relu_mean16_bwd")
     return dy, dg, db
 
 
-def adam_step(p, grad, m, v, wd, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, l1_coef=0.0, planes=None):
+def adam_step(p, grad, m, v, wd, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, l1_coef=0.0, planes=None, tick=True):
     """In place over flat fp32 arenas; `step` is an int32 device tensor bumped by the kernel. `planes`: Planes arenas that receive
     the bf16x3 operand planes of the updated weights."""
     _lib.check(_lib.lib().advmil_adam_step(_p(p), _p(grad), _p(m), _p(v), _p(wd), p.numel(), lr, beta1, beta2, eps,
                                            grad_scale, l1_coef, _p(step), _p(None if planes is None else planes.hi),
-                                           _p(None if planes is None else planes.lo), _stream()),
+                                           _p(None if planes is None else planes.lo), 1 if tick else 0, _stream()),
                "adam_step")
+
+
+def step_seed_tick(step, seed, inc=1):
+    """step[0] += 1 and seed[0] += inc in one launch (either may be None)."""
+    _lib.check(_lib.lib().advmil_step_seed_tick(_p(step), _p(seed), int(inc), _stream()), "step_seed_tick")
 
 
 def abs_sum(p):
@@ -1316,12 +1321,13 @@ class LNReLUMean16Fn(torch.autograd.Function):
     (model/backbone_utils.py:161-167)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, eps, ycol=None, dy_planes=False):
+    def forward(ctx, y, gamma, beta, eps, ycol=None, dy_planes=False, dup=1):
         _chk(y, "y")
         y = y.contiguous()
         N, d = y.shape
-        epl = Planes.alloc((N // 16, d), y.device) if _wants_row_planes(N // 16, d) else None
-        emb, mean, rstd = ln_relu_mean16_fwd(y, gamma, beta, N, d, eps, planes=epl)
+        ctx.dup = dup
+        epl = Planes.alloc((N // 16, d), y.device) if (dup == 1 and _wants_row_planes(N // 16, d)) else None
+        emb, mean, rstd = ln_relu_mean16_fwd(y, gamma, beta, N, d, eps, planes=epl, dup=dup)
         LNReLUMean16Fn.last_planes = epl
         ctx.save_for_backward(y, gamma.detach(), beta.detach(), mean, rstd)
         gg, gb = _arena_grad(gamma), _arena_grad(beta)
@@ -1338,13 +1344,14 @@ class LNReLUMean16Fn(torch.autograd.Function):
         # `ycol`): dy is then written as operand planes ONLY and handed over through DY_PLANES, keyed by the token tensor's address
         pl = Planes.alloc((N, d), y.device) if ctx.dy_planes else None
         if ctx.arena is not None:
-            dy, dg, db = ln_relu_mean16_bwd(demb.contiguous(), y, gamma, beta, mean, rstd, N, d, ctx.arena[0], ctx.arena[1], ctx.ycol, planes=pl)
+            dy, dg, db = ln_relu_mean16_bwd(demb.contiguous(), y, gamma, beta, mean, rstd, N, d, ctx.arena[0], ctx.arena[1], ctx.ycol, planes=pl,
+                                            dup=ctx.dup)
             dg = db = None
         else:
-            dy, dg, db = ln_relu_mean16_bwd(demb.contiguous(), y, gamma, beta, mean, rstd, N, d, ycol_out=ctx.ycol, planes=pl)
+            dy, dg, db = ln_relu_mean16_bwd(demb.contiguous(), y, gamma, beta, mean, rstd, N, d, ycol_out=ctx.ycol, planes=pl, dup=ctx.dup)
         if pl is not None:
             DY_PLANES[dy.data_ptr()] = (pl, (N, d))
-        return dy, dg, db, None, None, None
+        return dy, dg, db, None, None, None, None
 
 
 # operand planes of a gradient that was written as planes only: {address of the (unwritten) fp32 token: (Planes, shape)}. The consumer
@@ -1353,13 +1360,18 @@ DY_PLANES = {}
 LN_DY_PLANES = os.environ.get("ADVMIL_LN_DY_PLANES", "1") != "0"
 
 
-def ln_relu_mean16(y, gamma, beta, eps=1e-5, ycol_grad=None):
+def ln_relu_mean16_dup_ok(d):
+    """Can the region embedding leave its kernel duplicated ([emb; emb], dup = 2)? The 16-byte kernels only."""
+    return d % 128 == 0 and os.environ.get("ADVMIL_LN4", "1") != "0" and os.environ.get("ADVMIL_LN_DUP", "1") != "0"
+
+
+def ln_relu_mean16(y, gamma, beta, eps=1e-5, ycol_grad=None, dup=1):
     """`ycol_grad`: optional [d] gradient accumulator (an arena slot) that receives += column sums of dy in the backward -- the bias
     gradient of the FC that produced y, for callers that hand that FC a detached bias. When that FC marked its output
     (`_advmil_wants_dy_planes`, set by linear_act: slab-sized layer, no input gradient, no bias of its own, planes of X resident), dy is
     produced as operand planes only."""
     want = bool(LN_DY_PLANES and ycol_grad is not None and getattr(y, "_advmil_wants_dy_planes", False) and y.is_contiguous())
-    emb = LNReLUMean16Fn.apply(y, gamma, beta, eps, ycol_grad, want)
+    emb = LNReLUMean16Fn.apply(y, gamma, beta, eps, ycol_grad, want, int(dup))
     epl, LNReLUMean16Fn.last_planes = getattr(LNReLUMean16Fn, "last_planes", None), None
     if epl is not None:
         emb._advmil_planes = epl

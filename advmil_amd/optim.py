@@ -95,12 +95,14 @@ class FlatAdam(torch.optim.Optimizer):
                 p._arena_grad = p.grad
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0):
+    def step(self, closure=None, grad_scale=1.0, tick=True):
+        """tick = False: the device step counter is left to the caller (ops.step_seed_tick(self.step_t, seed): the captured step folds it
+        into the RNG seed's advance)."""
         g0 = self.param_groups[0]
         b1, b2 = g0["betas"]
         self.n_updates = getattr(self, "n_updates", 0) + 1      # host-side version of the parameters (forward memo key)
         ops.adam_step(self.flat_param, self.flat_grad, self.flat_m, self.flat_v, self.flat_wd if self._has_wd else None,
-                      self.step_t, g0["lr"], b1, b2, g0["eps"], grad_scale, self.l1_coef, planes=self.planes)
+                      self.step_t, g0["lr"], b1, b2, g0["eps"], grad_scale, self.l1_coef, planes=self.planes, tick=tick)
 
     def state_dict(self):
         n = float(self.step_t.item())

@@ -285,12 +285,15 @@ int advmil_pending_sums(advmil_stream_t stream);
  * that produced y, which otherwise costs a second pass over dy. dy_hi / dy_lo (both or neither): the bf16x3 operand planes of dy for
  * the weight-gradient contraction dy^T X that consumes it (advmil_epilogue_t.a_hi / a_lo); with them dy may be NULL (planes only). */
 /* emb_hi / emb_lo (both or neither; d % 128 == 0): also the bf16x3 operand planes of emb (the ESAT in-projection reads it plane-fed). */
+/* dup = 2 (d % 128 == 0): emb has 2 N / 16 rows, the embedding written twice ([emb; emb]: the discriminator update feeds the fake and the
+ * real pass of the region level as one stacked batch, model_handler.py:373-401); the backward then takes demb [2 N / 16, d] and sums its
+ * halves on load -- neither a concatenation nor an add launch. dup = 1: the plain call. */
 int advmil_ln_relu_mean16_fwd(const float* y, const float* gamma, const float* beta, float eps, int64_t N, int64_t d,
-                              float* emb, float* mean, float* rstd, void* emb_hi, void* emb_lo, advmil_stream_t stream);
+                              float* emb, float* mean, float* rstd, void* emb_hi, void* emb_lo, int dup, advmil_stream_t stream);
 size_t advmil_ln_relu_mean16_bwd_workspace_bytes(int64_t N, int64_t d);
 int advmil_ln_relu_mean16_bwd(const float* demb, const float* y, const float* gamma, const float* beta,
                               const float* mean, const float* rstd, int64_t N, int64_t d, float* dy, float* dgamma,
-                              float* dbeta, int accumulate, float* dycol, void* dy_hi, void* dy_lo, void* ws, size_t ws_bytes,
+                              float* dbeta, int accumulate, float* dycol, void* dy_hi, void* dy_lo, int dup, void* ws, size_t ws_bytes,
                               advmil_stream_t stream);
 
 /* Plain row-wise LayerNorm(d) -> ReLU (the norm='layer' MLP inside GENConv; N arbitrary). Same kernels as above. */
@@ -325,9 +328,13 @@ int advmil_genconv_bwd(const float* dout, const float* x, const float* agg, cons
  * `step` is a device int32 incremented by the kernel (graph-replay safe). wd may be NULL. p_hi / p_lo (both or neither): bf16 arenas of
  * n elements that receive the bf16x3 operand planes of the UPDATED weights, so the contractions never re-split a weight.
  * abs_sum: out[0] = sum |p| (for the logged Loss_G_total). */
+/* tick != 0: the kernel's own second launch increments `step`; tick = 0: the caller increments it (advmil_step_seed_tick folds that into the
+ * RNG seed's advance at the end of an optimizer step: one one-thread launch instead of two). */
 int advmil_adam_step(float* p, const float* grad, float* m, float* v, const float* wd, int64_t n, float lr,
                      float beta1, float beta2, float eps, float grad_scale, float l1_coef, int32_t* step, void* p_hi, void* p_lo,
-                     advmil_stream_t stream);
+                     int tick, advmil_stream_t stream);
+/* step[0] += 1 (NULL: skipped) and seed[0] += inc (NULL: skipped) in one launch */
+int advmil_step_seed_tick(int32_t* step, uint64_t* seed, uint64_t inc, advmil_stream_t stream);
 int advmil_abs_sum(const float* p, int64_t n, float* out, void* ws, size_t ws_bytes, advmil_stream_t stream);
 size_t advmil_abs_sum_workspace_bytes(int64_t n);
 

@@ -80,7 +80,7 @@ def test_pooling_group_checks_shapes_and_workspace(L):
     assert lib.advmil_softmax_pool_fwd(p(0), p(1), D, N, D, 4, None, N, p(2), p(3), p(4), need, None) == EINVAL          # 4 bags, no offsets
     assert lib.advmil_softmax_pool_fwd(p(0), ctypes.c_void_p(A16 + 8), D, N, D, 1, None, N, p(2), p(3), p(4), need, None) == EINVAL
     assert lib.advmil_gate_score_fwd(p(0), p(1), p(2), 1.5, p(3), 1, 2, N, D, p(4), None, None) == EINVAL                # p >= 1
-    assert lib.advmil_ln_relu_mean16_fwd(p(0), p(1), p(2), 1e-5, 8200, 128, p(3), p(4), p(5), None, None, None) == EINVAL   # N % 16 != 0
+    assert lib.advmil_ln_relu_mean16_fwd(p(0), p(1), p(2), 1e-5, 8200, 128, p(3), p(4), p(5), None, None, 1, None) == EINVAL   # N % 16 != 0
 
 
 def test_attention_group_checks_head_dim_and_segments(L):
@@ -110,5 +110,5 @@ def test_optimizer_graph_and_evaluator_groups(L):
     assert lib.advmil_seg_scale_rows(p(0), p(1), None, 64, 126, p(2), None) == EINVAL                                    # D not a multiple of 4
     assert lib.advmil_genconv_bwd(p(0), p(1), p(2), p(3), p(4), p(5), p(6), 1e-7, 100, 128, p(7), p(8), p(9), 0, None) == EINVAL      # workspace too small
     assert lib.advmil_genconv_fwd(p(0), p(1), p(2), p(3), 1e-7, 100, 128, p(4), p(5), None, None) == EINVAL                  # lse without agg
-    assert lib.advmil_ln_relu_mean16_bwd(p(0), p(1), p(2), p(3), p(4), p(5), 64, 128, None, p(6), p(7), 0, None, None, None, p(8), 1 << 20, None) == EINVAL   # neither dy nor its planes
-    assert lib.advmil_ln_relu_mean16_bwd(p(0), p(1), p(2), p(3), p(4), p(5), 64, 128, None, p(6), p(7), 0, None, p(9), None, p(8), 1 << 20, None) == EINVAL   # one plane only
+    assert lib.advmil_ln_relu_mean16_bwd(p(0), p(1), p(2), p(3), p(4), p(5), 64, 128, None, p(6), p(7), 0, None, None, None, 1, p(8), 1 << 20, None) == EINVAL   # neither dy nor its planes
+    assert lib.advmil_ln_relu_mean16_bwd(p(0), p(1), p(2), p(3), p(4), p(5), 64, 128, None, p(6), p(7), 0, None, p(9), None, 1, p(8), 1 << 20, None) == EINVAL   # one plane only

@@ -125,3 +125,31 @@ def test_pooling_with_the_mean_from_the_same_pass():
     for i, n in enumerate(lens):
         _close(m1[i], h[o:o + n].double().mean(dim=0), 1e-5, f"mean {i}")
         o += n
+
+
+def test_region_embedding_duplicated_by_its_kernel_equals_the_concatenation():
+    """embed_rows(X, dup = 2) = [emb; emb] straight from the LayerNorm kernel, its backward summing the halves of the gradient on load,
+    against torch.cat([emb, emb]) + autograd's add."""
+    res = {}
+    for dup_on in (True, False):
+        import os
+        os.environ["ADVMIL_LN_DUP"] = "1" if dup_on else "0"
+        try:
+            d = build_disc("prj", "instance", "x").train()
+            load_synth(d, "D-prj:")
+            opt = FlatAdam(d, lr=1e-4)
+            opt.zero_grad()
+            g = torch.Generator().manual_seed(4)
+            X = torch.randn(4096 + 512, 1024, generator=g).to(DEV)
+            e2 = d.embed_rows(X, 2)
+            L = X.shape[0] // 16
+            assert e2.shape == (2 * L, 128) and torch.equal(e2[:L], e2[L:])
+            w = torch.randn(2 * L, 128, generator=g).to(DEV)
+            (e2 * w).sum().backward()
+            torch.cuda.synchronize()
+            res[dup_on] = (e2.detach().clone(), {k: p.grad.clone() for k, p in d.named_parameters() if "embedding" in k})
+        finally:
+            os.environ.pop("ADVMIL_LN_DUP", None)
+    assert torch.equal(res[True][0], res[False][0])
+    for k in res[True][1]:
+        _close(res[True][1][k], res[False][1][k], 2e-5, k)
