@@ -101,7 +101,7 @@ def test_attention_group_checks_head_dim_and_segments(L):
 def test_optimizer_graph_and_evaluator_groups(L):
     lib = L.lib()
     p = lambda k: ctypes.c_void_p(A16 + (k << 20))   # noqa: E731
-    assert lib.advmil_adam_step(p(0), p(1), p(2), p(3), p(4), -5, 1e-3, 0.9, 0.999, 1e-8, 1.0, 0.0, p(5), None, None, None) == EINVAL
+    assert lib.advmil_adam_step(p(0), p(1), p(2), p(3), p(4), -5, 1e-3, 0.9, 0.999, 1e-8, 1.0, 0.0, p(5), None, None, 1, None) == EINVAL
     assert lib.advmil_genconv_fwd(p(0), p(1), p(2), p(3), 1e-7, 100, 0, p(4), p(5), p(6), None) == EINVAL
     assert lib.advmil_cindex_counts(p(0), p(1), p(2), -1, 1e-8, p(3), None) == EINVAL
     assert lib.advmil_gan_d_loss(p(0), 4, None, None, 0, 9, 0.25, 0.0, p(1), p(2), None, None) == EINVAL                 # unknown loss kind
