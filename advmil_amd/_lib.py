@@ -47,6 +47,17 @@ class DTail(ctypes.Structure):
                 ("dout", c_void_p), ("dxin", c_void_p), ("dtin", c_void_p), ("du", c_void_p)]
 
 
+class GHead(ctypes.Structure):
+    """advmil_ghead_t"""
+    _fields_ = [("B", ctypes.c_int32), ("d0", ctypes.c_int32), ("d1", ctypes.c_int32), ("d2", ctypes.c_int32), ("noise_mode", ctypes.c_int32),
+                ("out_act", ctypes.c_int32), ("x", c_void_p), ("ldx", c_int64), ("Wr", c_void_p), ("br", c_void_p), ("W0", c_void_p),
+                ("b0", c_void_p), ("W1", c_void_p), ("b1", c_void_p), ("p1", c_float), ("p2", c_float), ("seed", c_void_p),
+                ("sid1", c_uint64), ("sid2", c_uint64), ("sid_noise", c_uint64), ("rng_row", c_void_p), ("noise", c_void_p),
+                ("hs", c_void_p), ("h2", c_void_p), ("pred", c_void_p), ("dpred", c_void_p), ("dx", c_void_p), ("lddx", c_int64),
+                ("dWr", c_void_p), ("dbr", c_void_p), ("dW0", c_void_p), ("db0", c_void_p), ("dW1", c_void_p), ("db1", c_void_p),
+                ("ws", c_void_p), ("ws_bytes", c_size_t)]
+
+
 # name -> (restype, argtypes); must list every symbol include/advmil_hip.h declares
 SIGNATURES = {
     "advmil_version": (c_int, []),
@@ -113,7 +124,7 @@ SIGNATURES = {
                                    c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "advmil_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                                  c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
-    "advmil_step_seed_tick": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p]),
+    "advmil_step_seed_tick": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p]),
     "advmil_abs_sum": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "advmil_abs_sum_workspace_bytes": (c_size_t, [c_int64]),
     "advmil_uniform_fill": (c_int, [c_void_p, c_int64, c_void_p, c_uint64, c_void_p, c_int64, c_void_p]),
@@ -147,6 +158,9 @@ SIGNATURES = {
                                     c_void_p, c_size_t, c_void_p]),
     "advmil_dtail_fwd": (c_int, [ctypes.POINTER(DTail), c_void_p]),
     "advmil_dtail_bwd": (c_int, [ctypes.POINTER(DTail), c_void_p]),
+    "advmil_ghead_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "advmil_ghead_fwd": (c_int, [ctypes.POINTER(GHead), c_void_p]),
+    "advmil_ghead_bwd": (c_int, [ctypes.POINTER(GHead), c_void_p]),
     "advmil_defer_sums": (c_int, [c_void_p, c_int]),
     "advmil_flush_sums": (c_int, [c_void_p]),
     "advmil_pending_sums": (c_int, [c_void_p]),

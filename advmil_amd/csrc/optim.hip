@@ -37,8 +37,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }
 __global__ void step_inc_kernel(int32_t* step) { *step += 1; }
 // the step counter's increment and the RNG seed's advance of an optimizer step's end as ONE one-thread launch
-__global__ void step_seed_tick_kernel(int32_t* step, uint64_t* seed, uint64_t inc) {
+__global__ void step_seed_tick_kernel(int32_t* step, int32_t* step2, uint64_t* seed, uint64_t inc) {
   if (step) *step += 1;
+  if (step2) *step2 += 1;
   if (seed) *seed += inc;
 }
 
@@ -56,9 +57,9 @@ extern "C" int advmil_adam_step(float* p, const float* grad, float* m, float* v,
   return ADVMIL_OK;
 }
 
-extern "C" int advmil_step_seed_tick(int32_t* step, uint64_t* seed, uint64_t inc, advmil_stream_t stream_) {
-  if (!step && !seed) return ADVMIL_EINVAL;
-  hipLaunchKernelGGL(step_seed_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, step, seed, inc);
+extern "C" int advmil_step_seed_tick(int32_t* step, int32_t* step2, uint64_t* seed, uint64_t inc, advmil_stream_t stream_) {
+  if ((!step && !step2 && !seed) || (step && step == step2)) return ADVMIL_EINVAL;
+  hipLaunchKernelGGL(step_seed_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, step, step2, seed, inc);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }

@@ -79,13 +79,13 @@ class GraphedStep:
 
     def _seg_mid(self):
         self.h._log_d()                      # after the exchange: the logged statistics are the reduced ones
-        self.h.optimizerD.step()
+        self.h.optimizerD.step(tick=False)   # (its counter is ticked with G's and the RNG seed at the end of the step: _seg_end)
         self.h._gen_finish(0, self.xs, self.ys, self.plan)
 
     def _seg_end(self):
         self.h._log_g()
         self.h.optimizerG.step(tick=False)
-        ops.step_seed_tick(self.h.optimizerG.step_t, self.h.rng.seed, 1)      # G's step counter and the RNG seed: one launch
+        ops.step_seed_tick(self.h.optimizerG.step_t, self.h.rng.seed, 1, step2=self.h.optimizerD.step_t)   # both step counters and the RNG seed: one launch
 
     def _eager(self):
         self._seg_disc()

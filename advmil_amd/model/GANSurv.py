@@ -54,8 +54,65 @@ class Generator(nn.Module):
         """Slab form of `features`: X[N_total, C] holding the B bags of a step back to back -> [B, d]."""
         return self.backbone.features_multi(X, seg, exts)
 
+    def _head_spec(self, feats, zero_noise, noise):
+        """ops.GHeadSpec when `finish` can run as the fused launches (csrc/ghead.hip): the shipped head -- an optional backbone `rho`
+        (Linear -> ReLU -> Dropout), MLPs[0] = Linear -> ReLU -> Dropout, uniform / zero / injected noise or none, a width-1 output layer,
+        out_scale sigmoid or none -- on <= 32 bags. Decided BEFORE any call site is drawn (the layer-by-layer path draws its own); the
+        sites are then drawn in that path's order and under its tags (abmil_rho, gen_mlp0.2, noise)."""
+        if not (ops.GHEAD and feats.is_cuda and feats.dim() == 2 and feats.dtype == torch.float32 and feats.shape[0] <= 32):
+            return None
+        if len(self.MLPs) != 2 or list(self.noise) not in ([0, 1], [0, 0]) or self.out_scale == "exp":
+            return None
+        bb = self.backbone
+        rho = None
+        if hasattr(bb, "post"):
+            rho = getattr(bb, "rho", None)
+            if not (isinstance(rho, nn.Sequential) and len(rho) == 3 and isinstance(rho[0], nn.Linear) and isinstance(rho[1], nn.ReLU)
+                    and isinstance(rho[2], nn.Dropout)):
+                return None
+        m0, m1 = self.MLPs[0], self.MLPs[1]
+        if not (isinstance(m0, nn.Sequential) and len(m0) == 3 and isinstance(m0[0], nn.Linear) and isinstance(m0[1], nn.ReLU)
+                and isinstance(m0[2], nn.Dropout) and isinstance(m1, nn.Sequential) and len(m1) == 1 and isinstance(m1[0], nn.Linear)
+                and m1[0].out_features == 1):
+            return None
+        B, d2 = feats.shape[0], m0[0].out_features
+        has_noise = self.noise[1] == 1
+        if not has_noise:
+            mode, nz = 0, None
+        elif zero_noise:
+            mode, nz = 1, None
+        elif noise is not None:
+            if len(noise) != 1:
+                return None
+            nz = noise[0].to(feats.device, torch.float32).contiguous()
+            if tuple(nz.shape) != (B, d2):
+                return None
+            mode = 2
+        elif self.noise_dist == "uniform":
+            mode, nz = 3, None
+        else:
+            return None
+        p1 = (rho[2].p if rho.training else 0.0) if rho is not None else 0.0
+        p2 = m0[2].p if m0.training else 0.0
+        probe = ops.GHeadSpec(Wr=None if rho is None else rho[0].weight, br=None if rho is None else rho[0].bias, p1=p1, W0=m0[0].weight,
+                              b0=m0[0].bias, p2=p2, W1=m1[0].weight, b1=m1[0].bias, noise_mode=mode, noise=nz,
+                              out_act=1 if self.out_scale == "sigmoid" else 0)
+        if not ops.ghead_ok(feats, probe):
+            return None
+        rng = _rng_of(self, feats)
+        if p1 > 0.0:
+            probe.sid1, probe.seed, probe.rr = rng.site("abmil_rho", (B, rho[0].out_features), p1), rng.seed, rng.row_map(B, "abmil_rho")
+        if p2 > 0.0:
+            probe.sid2, probe.seed, probe.rr = rng.site("gen_mlp0.2", (B, d2), p2), rng.seed, rng.row_map(B, "gen_mlp0.2")
+        if mode == 3:
+            probe.sid_noise, probe.seed, probe.rr = rng.site("noise", (B * d2,), None), rng.seed, rng.row_map(B, "noise")
+        return probe
+
     def finish(self, feats, zero_noise=False, noise=None):
         """feats[B, d] (stacked `features`) -> predictions [B, dim_out]."""
+        spec = self._head_spec(feats, zero_noise, noise)
+        if spec is not None:                 # rho + head as two launches each way
+            return ops.ghead(feats, spec)
         bb = self.backbone
         H = bb.post(feats) if hasattr(bb, "post") else feats
         return self.head(H, zero_noise, noise)

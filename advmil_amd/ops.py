@@ -816,9 +816,9 @@ def adam_step(p, grad, m, v, wd, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, gra
                "adam_step")
 
 
-def step_seed_tick(step, seed, inc=1):
-    """step[0] += 1 and seed[0] += inc in one launch (either may be None)."""
-    _lib.check(_lib.lib().advmil_step_seed_tick(_p(step), _p(seed), int(inc), _stream()), "step_seed_tick")
+def step_seed_tick(step, seed, inc=1, step2=None):
+    """step[0] += 1, step2[0] += 1 and seed[0] += inc in one launch (any may be None)."""
+    _lib.check(_lib.lib().advmil_step_seed_tick(_p(step), _p(step2), _p(seed), int(inc), _stream()), "step_seed_tick")
 
 
 def abs_sum(p):
@@ -2061,6 +2061,123 @@ class DTailFn(torch.autograd.Function):
 
 def dtail(eb, im, t, spec):
     return DTailFn.apply(eb, im, t, spec, *spec.params())
+
+
+# ---------------------------------------------------------------------------------------
+# the generator's bag-level head as two launches each way (advmil_ghead_fwd / _bwd, csrc/ghead.hip)
+# ---------------------------------------------------------------------------------------
+GHEAD = os.environ.get("ADVMIL_GHEAD", "1") != "0"
+
+
+class GHeadSpec:
+    """Host description of one head call: rho (Wr, br, p1, sid1) or None, MLPs[0] (W0, b0, p2, sid2), the output layer (W1, b1), the noise
+    input (mode 0 none / 1 zeros / 2 the caller's tensor / 3 drawn in the kernel at site sid_noise), out_act (0 / 1 = sigmoid), the dropout
+    seed and the bag-level row map."""
+    __slots__ = ("Wr", "br", "p1", "sid1", "W0", "b0", "p2", "sid2", "W1", "b1", "noise_mode", "noise", "sid_noise", "out_act", "seed", "rr")
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw.get(k))
+
+    def params(self):
+        return [self.Wr, self.br, self.W0, self.b0, self.W1, self.b1]
+
+
+def ghead_ok(x, spec):
+    """Can this head run as the fused launches? <= 32 bags, widths within the kernel's limits, every trainable parameter with an arena slot
+    (the backward ADDS its gradients in place)."""
+    if not GHEAD or not x.is_cuda or x.dim() != 2 or x.dtype != torch.float32 or not (1 <= x.shape[0] <= 32):
+        return False
+    d0 = x.shape[1]
+    W0, W1, Wr = spec.W0, spec.W1, spec.Wr
+    if W0 is None or W1 is None or W0.dim() != 2 or W1.dim() != 2 or W1.shape[0] != 1:
+        return False
+    d2 = W0.shape[0]
+    d1 = 0 if Wr is None else Wr.shape[0]
+    if Wr is not None and (Wr.dim() != 2 or Wr.shape[1] != d0 or W0.shape[1] != d1):
+        return False
+    if Wr is None and W0.shape[1] != d0:
+        return False
+    if d0 > 512 or d0 % 4 or d2 > 256 or d2 % 4 or (d1 if d1 else d2) % 16 or d1 > 1024:
+        return False
+    if W1.shape[1] != (d2 if spec.noise_mode == 0 else 2 * d2):
+        return False
+    for p in spec.params():
+        if p is None:
+            continue
+        if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() or (p.data_ptr() & 15 and p.dim() == 2 and p.shape[0] > 1):
+            return False
+        if p.requires_grad and torch.is_grad_enabled() and _arena_grad(p) is None:
+            return False
+    return True
+
+
+def _fill_ghead(gh, x, spec, hs, h2, pred, ws, wsb):
+    gh.B, gh.d0, gh.d2 = x.shape[0], x.shape[1], spec.W0.shape[0]
+    gh.d1 = 0 if spec.Wr is None else spec.Wr.shape[0]
+    gh.noise_mode, gh.out_act = spec.noise_mode, spec.out_act
+    gh.x, gh.ldx = x.data_ptr(), x.stride(0)
+    gh.Wr, gh.br = _p(spec.Wr), _p(spec.br)
+    gh.W0, gh.b0, gh.W1, gh.b1 = _p(spec.W0), _p(spec.b0), _p(spec.W1), _p(spec.b1)
+    gh.p1, gh.p2 = float(spec.p1 or 0.0), float(spec.p2 or 0.0)
+    gh.seed = _p(spec.seed)
+    gh.sid1, gh.sid2, gh.sid_noise = int(spec.sid1 or 0), int(spec.sid2 or 0), int(spec.sid_noise or 0)
+    gh.rng_row = _p(spec.rr)
+    gh.noise = _p(spec.noise)
+    gh.hs, gh.h2, gh.pred = _p(hs), _p(h2), _p(pred)
+    gh.ws, gh.ws_bytes = _p(ws), wsb
+
+
+class GHeadFn(torch.autograd.Function):
+    """pred [B, 1] = out_scale(MLPs[1](cat(MLPs[0](rho(x)), noise))) (Generator.finish behind the backbone's pooling)."""
+
+    @staticmethod
+    def forward(ctx, x, spec, *params):
+        if x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() & 15:
+            x = x.contiguous()
+        B, dev = x.shape[0], x.device
+        d2 = spec.W0.shape[0]
+        d1 = 0 if spec.Wr is None else spec.Wr.shape[0]
+        hs = torch.empty(B, d1 if d1 else d2, dtype=torch.float32, device=dev)
+        h2 = torch.empty(B, d2, dtype=torch.float32, device=dev) if d1 else None
+        pred = torch.empty(B, 1, dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        wsb = L.advmil_ghead_workspace_bytes(B, x.shape[1], d1, d2)
+        ws = _ws(wsb, dev)
+        gh = _lib.GHead()
+        _fill_ghead(gh, x, spec, hs, h2, pred, ws, wsb)
+        # (gradient slots as they stand NOW: parameters frozen around this forward stay frozen in the backward)
+        ctx.slots = [(_arena_grad(p) if (p is not None and ctx.needs_input_grad[2 + j]) else None) for j, p in enumerate(spec.params())]
+        _lib.check(L.advmil_ghead_fwd(ctypes.byref(gh), _stream()), "ghead_fwd")
+        ctx.spec = spec
+        ctx.has_h2 = h2 is not None
+        ctx.save_for_backward(x, hs, pred, *([h2] if h2 is not None else []))
+        return pred
+
+    @staticmethod
+    def backward(ctx, dpred):
+        sv = ctx.saved_tensors
+        x, hs, pred = sv[0], sv[1], sv[2]
+        h2 = sv[3] if ctx.has_h2 else None
+        spec, dev = ctx.spec, x.device
+        dpred = dpred.contiguous()
+        dx = torch.empty(x.shape[0], x.shape[1], dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        L = _lib.lib()
+        d1 = 0 if spec.Wr is None else spec.Wr.shape[0]
+        wsb = L.advmil_ghead_workspace_bytes(x.shape[0], x.shape[1], d1, spec.W0.shape[0])
+        ws = _ws(wsb, dev)
+        gh = _lib.GHead()
+        _fill_ghead(gh, x, spec, hs, h2, pred, ws, wsb)
+        gh.dpred = dpred.data_ptr()
+        gh.dx, gh.lddx = _p(dx), (x.shape[1] if dx is not None else 0)
+        sl = ctx.slots
+        gh.dWr, gh.dbr, gh.dW0, gh.db0, gh.dW1, gh.db1 = (_p(g) for g in sl)
+        _lib.check(L.advmil_ghead_bwd(ctypes.byref(gh), _stream()), "ghead_bwd")
+        return (dx, None) + (None,) * len(sl)
+
+
+def ghead(x, spec):
+    return GHeadFn.apply(x, spec, *spec.params())
 
 
 # ---------------------------------------------------------------------------------------

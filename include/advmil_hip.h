@@ -333,8 +333,8 @@ int advmil_genconv_bwd(const float* dout, const float* x, const float* agg, cons
 int advmil_adam_step(float* p, const float* grad, float* m, float* v, const float* wd, int64_t n, float lr,
                      float beta1, float beta2, float eps, float grad_scale, float l1_coef, int32_t* step, void* p_hi, void* p_lo,
                      int tick, advmil_stream_t stream);
-/* step[0] += 1 (NULL: skipped) and seed[0] += inc (NULL: skipped) in one launch */
-int advmil_step_seed_tick(int32_t* step, uint64_t* seed, uint64_t inc, advmil_stream_t stream);
+/* step[0] += 1, step2[0] += 1 (the two networks' counters; NULL: skipped) and seed[0] += inc (NULL: skipped) in one launch */
+int advmil_step_seed_tick(int32_t* step, int32_t* step2, uint64_t* seed, uint64_t inc, advmil_stream_t stream);
 int advmil_abs_sum(const float* p, int64_t n, float* out, void* ws, size_t ws_bytes, advmil_stream_t stream);
 size_t advmil_abs_sum_workspace_bytes(int64_t n);
 
@@ -434,6 +434,50 @@ typedef struct {
 } advmil_dtail_t;
 int advmil_dtail_fwd(const advmil_dtail_t* a, advmil_stream_t stream);
 int advmil_dtail_bwd(const advmil_dtail_t* a, advmil_stream_t stream);
+/* The generator's bag-level head as two launches each way (csrc/ghead.hip; reference model/GANSurv.py:13-46 `Generator.forward` behind the
+ * backbone's pooling: ABMIL's `rho` = Linear(d0, d1) -> ReLU -> Dropout(p1) (model/backbone.py:66-70; d1 = 0: the backbone has none),
+ * MLPs[0] = Linear(d1 | d0, d2) -> ReLU -> Dropout(p2), the noise [B, d2] concatenated, MLPs[1] = Linear(2 d2 | d2, 1), out_scale
+ * (model/model_utils.py:124-140 make_noise_mlp_layer, hops = 1, noise = [0, 1]). fp32 FMA, fixed summation order.
+ *   noise_mode 0: no noise input (W1 is [1, d2]); 1: zeros (W1 is [1, 2 d2], the noise half contributes nothing); 2: the caller's `noise`
+ *   [B, d2]; 3: drawn in the kernel, U[0, 1) at site sid_noise, element rng_row(b) * d2 + n -- the draws of advmil_uniform_fill.
+ *   out_act 0: identity, 1: sigmoid. Dropout: stream sid1 at element rng_row(b) * d1 + c (rho), sid2 at rng_row(b) * d2 + n (MLPs[0]).
+ * fwd writes hs [B, d1 | d2] (the first hidden layer, post-dropout), h2 [B, d2] (d1 > 0 only), pred [B]; bwd reads them back with dpred [B],
+ * writes dx [B, d0] (NULL: not wanted) and ADDS the weight / bias gradients in place (arena slots; NULL: not wanted).
+ * B <= 32, d0 <= 512, d0 % 4 == 0, (d1 > 0 ? d1 : d2) % 16 == 0, d2 <= 256, d2 % 4 == 0; ws: advmil_ghead_workspace_bytes. */
+typedef struct {
+  int32_t B, d0, d1, d2;
+  int32_t noise_mode, out_act;
+  const float* x;
+  int64_t ldx;
+  const float* Wr; /* [d1, d0] */
+  const float* br;
+  const float* W0; /* [d2, d1 | d0] */
+  const float* b0;
+  const float* W1; /* [1, d2 | 2 d2] */
+  const float* b1;
+  float p1, p2;
+  const uint64_t* seed;
+  uint64_t sid1, sid2, sid_noise;
+  const int64_t* rng_row;
+  const float* noise;
+  float* hs;
+  float* h2;
+  float* pred;
+  const float* dpred;
+  float* dx;
+  int64_t lddx;
+  float* dWr;
+  float* dbr;
+  float* dW0;
+  float* db0;
+  float* dW1;
+  float* db1;
+  float* ws;
+  size_t ws_bytes;
+} advmil_ghead_t;
+size_t advmil_ghead_workspace_bytes(int B, int d0, int d1, int d2);
+int advmil_ghead_fwd(const advmil_ghead_t* a, advmil_stream_t stream);
+int advmil_ghead_bwd(const advmil_ghead_t* a, advmil_stream_t stream);
 /* The discriminator's region-level network as one launch each way (reference model/model_utils.py:188-210 EmbedXLayer: fc1 = Linear(d, d/2)
  * -> ReLU -> Dropout -> Linear(d/2, d); model/backbone_utils.py:31-56 GAPool's scorer tanh(Linear(d, d)) * sigmoid(Linear(d, d)) -> Linear(d, 1))
  * over the R region rows of a step slab, d = 128 (the shipped disc_netx_out_dim; other widths keep the layer-by-layer path):
