@@ -47,6 +47,12 @@ class DTail(ctypes.Structure):
                 ("dout", c_void_p), ("dxin", c_void_p), ("dtin", c_void_p), ("du", c_void_p)]
 
 
+class GemmTnCall(ctypes.Structure):
+    """advmil_gemm_tn_call_t"""
+    _fields_ = [("M", c_int64), ("N", c_int64), ("K", c_int64), ("A", c_void_p), ("lda", c_int64), ("B", c_void_p), ("ldb", c_int64),
+                ("C", c_void_p), ("ldc", c_int64), ("accumulate", ctypes.c_int32)]
+
+
 class GHead(ctypes.Structure):
     """advmil_ghead_t"""
     _fields_ = [("B", ctypes.c_int32), ("d0", ctypes.c_int32), ("d1", ctypes.c_int32), ("d2", ctypes.c_int32), ("noise_mode", ctypes.c_int32),
@@ -158,6 +164,8 @@ SIGNATURES = {
                                     c_void_p, c_size_t, c_void_p]),
     "advmil_dtail_fwd": (c_int, [ctypes.POINTER(DTail), c_void_p]),
     "advmil_dtail_bwd": (c_int, [ctypes.POINTER(DTail), c_void_p]),
+    "advmil_gemm_tn_group_workspace_bytes": (c_size_t, [ctypes.POINTER(GemmTnCall), c_int]),
+    "advmil_gemm_tn_group": (c_int, [ctypes.POINTER(GemmTnCall), c_int, c_void_p, c_size_t, c_void_p]),
     "advmil_ghead_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "advmil_ghead_fwd": (c_int, [ctypes.POINTER(GHead), c_void_p]),
     "advmil_ghead_bwd": (c_int, [ctypes.POINTER(GHead), c_void_p]),

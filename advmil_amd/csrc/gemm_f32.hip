@@ -683,8 +683,21 @@ __device__ __forceinline__ int gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[TM
 
 // WR x WC waves per workgroup (2x2 = the 256-thread tiles; 4x2 = the 512-thread 256x192 / 256x128 tiles of the bf16x3 variant, whose
 // time is set by how many operand bytes a CU pulls through its L1 per flop: ~11 B/clk/CU whatever the inner loop looks like).
+// LDS floats of one workgroup of gemm_f32_body (operand buffers; the epilogue's per-wave areas reuse them)
+template <bool A_KC, bool B_KC, int TM, int TN, bool SPLIT, int BKT, int WR, int WC>
+__host__ __device__ constexpr int gemm_smem_floats() {
+  constexpr int BM_ = 32 * TM * WR, BN_ = 32 * TN * WC, PITCH = BKT + 4;
+  constexpr int TILEF_A = !SPLIT ? BM_ * PITCH : (A_KC ? BM_ * PITCH_PS(BKT) : BKT * PITCH_MC(BM_));
+  constexpr int TILEF_B = !SPLIT ? BN_ * PITCH : (B_KC ? BN_ * PITCH_PS(BKT) : BKT * PITCH_MC(BN_));
+  constexpr int NBUF = SPLIT ? 2 : 1;
+  constexpr int PATCH_FLOATS = WR * WC * EPI_WAVE_FLOATS(TM, TN);
+  return NBUF * (TILEF_A + TILEF_B) > PATCH_FLOATS ? NBUF * (TILEF_A + TILEF_B) : PATCH_FLOATS;
+}
+
+// The workgroup's work: tile `bid` (XCD-aware order), split `z`. A device function so that the grouped launch below (several small
+// contractions in ONE launch) runs the same code as the plain kernel.
 template <bool A_KC, bool B_KC, int TM, int TN, bool SPLIT, int PRE, int BKT, int WR, int WC>
-__global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 || TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, const int bid, const int z, float* const smem) {
   constexpr int NT = 64 * WR * WC;
   constexpr int BM_ = 32 * TM * WR, BN_ = 32 * TN * WC;
   // BKT = k per chunk, 32 everywhere. Measured alternatives: 64 for the bf16x3 variant (no gain, +60 VGPRs); 64/128 for 64x64
@@ -698,8 +711,7 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 || TM * TN > 4 ? 1 : 2))
   // The exact variant stays single-buffered: there the doubled LDS footprint costs co-resident workgroups and measured slower.
   constexpr int NBUF = SPLIT ? 2 : 1;
   constexpr int BUF_FLOATS = TILEF_A + TILEF_B;
-  constexpr int PATCH_FLOATS = WR * WC * EPI_WAVE_FLOATS(TM, TN);   // the epilogue's per-wave areas reuse the operand buffers
-  __shared__ __attribute__((aligned(16))) float smem[NBUF * BUF_FLOATS > PATCH_FLOATS ? NBUF * BUF_FLOATS : PATCH_FLOATS];
+  static_assert(gemm_smem_floats<A_KC, B_KC, TM, TN, SPLIT, BKT, WR, WC>() >= NBUF * BUF_FLOATS, "LDS size helper out of step");
   float* const sA = smem;
   float* const sB = smem + TILEF_A;
 
@@ -712,7 +724,6 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 || TM * TN > 4 ? 1 : 2))
   // operand panel are given ids 8 apart: same XCD, dispatched back to back -> the panel is fetched from HBM once and
   // re-read from that L2. "inner" is the shorter tile axis: n-tiles of one A row-panel for the forward GEMMs
   // (ntiles = 2..4), m-tiles of one B panel for the dW = dY^T X contractions (mtiles = 3..6).
-  const int bid = blockIdx.x;
   int mt_i, nt_i;
   {
     const bool inner_n = g.ntiles <= g.mtiles;
@@ -732,7 +743,6 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 || TM * TN > 4 ? 1 : 2))
     nt_i = inner_n ? i_ : o;
   }
   const int64_t m0 = (int64_t)mt_i * BM_, n0 = (int64_t)nt_i * BN_;
-  const int z = blockIdx.y;
   const int64_t kbeg = (int64_t)z * g.k_chunk;
   const int64_t kend = (kbeg + g.k_chunk < g.K) ? kbeg + g.k_chunk : g.K;
 
@@ -836,6 +846,37 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 || TM * TN > 4 ? 1 : 2))
   }
 
   gemm_epilogue<TM, TN, WR, WC>(g, acc, smem, wave, lane, wr, wc, m0, n0, z, nt_i);
+}
+
+template <bool A_KC, bool B_KC, int TM, int TN, bool SPLIT, int PRE, int BKT, int WR, int WC>
+__global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 || TM * TN > 4 ? 1 : 2)) void gemm_f32_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<A_KC, B_KC, TM, TN, SPLIT, BKT, WR, WC>()];
+  gemm_f32_body<A_KC, B_KC, TM, TN, SPLIT, PRE, BKT, WR, WC>(g, (int)blockIdx.x, (int)blockIdx.y, smem);
+}
+
+// Up to GEMM_GROUP_MAX independent TN contractions of the 64x64 tile in ONE launch (gridDim.z = member): the weight gradients behind a
+// fused small network are each a handful of tiles over a deep K -- 2-8 tiles x splits, 9-40 us apiece as separate launches because
+// none fills the chip and each pays its own launch + K-walk latency; side by side they overlap.
+#define GEMM_GROUP_MAX 4
+struct GemmGroup {
+  GemmArgs a[GEMM_GROUP_MAX];
+};
+template <bool SPLIT>
+__global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(GemmGroup gg) {
+  __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<false, false, 1, 1, SPLIT, 32, 2, 2>()];
+  const int m = (int)blockIdx.z, bid = (int)blockIdx.x, z = (int)blockIdx.y;
+  // (a static member index per branch: the argument block stays in the kernel-argument segment, read through scalar loads)
+#define GROUP_MEMBER(i)                                                                      \
+  if (m == i) {                                                                              \
+    if (bid < gg.a[i].mtiles * gg.a[i].ntiles && z < gg.a[i].splits)                         \
+      gemm_f32_body<false, false, 1, 1, SPLIT, 0, 32, 2, 2>(gg.a[i], bid, z, smem);         \
+    return;                                                                                  \
+  }
+  GROUP_MEMBER(0)
+  GROUP_MEMBER(1)
+  GROUP_MEMBER(2)
+  GROUP_MEMBER(3)
+#undef GROUP_MEMBER
 }
 
 // =====================================================================================
@@ -1607,6 +1648,69 @@ extern "C" int advmil_gemm_f32(int a_kc, int b_kc, int64_t M, int64_t N, int64_t
                                const float* B, int64_t ldb, float* C, int64_t ldc, const advmil_epilogue_t* epi,
                                int splits, void* ws, size_t ws_bytes, advmil_stream_t stream) {
   return advmil_gemm_f32_tiled(a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, epi, splits, 0, ws, ws_bytes, stream);
+}
+
+// ---- several small deep-K TN contractions C_i (+)= A_i^T B_i as ONE launch (gemm_tn_group_kernel): 64x64 tiles, split-K per member,
+// partial tiles merged by the common reduce (deferrable: advmil_defer_sums). Same kernel body and k order as the plain launch of the
+// 64x64 tile with the same split count -> bit-identical to it.
+static int group_member_splits(int64_t M, int64_t N, int64_t K) {
+  const int64_t w = ((M + 63) / 64) * ((N + 63) / 64);
+  int64_t sp = K / 256;                      // >= 256 of K per workgroup (tools/probe/chain_wgrad_sweep.py: flat from K/512 to K/128)
+  if (sp > 64) sp = 64;
+  if (sp * w > 1024) sp = 1024 / w;
+  return sp < 1 ? 1 : (int)sp;
+}
+static size_t group_member_ws(const advmil_gemm_tn_call_t& c) {
+  const int sp = group_member_splits(c.M, c.N, c.K);
+  const int64_t kchunks = (c.K + BK - 1) / BK;
+  const int64_t kc = ((kchunks + sp - 1) / sp) * BK;
+  const int splits = (int)((c.K + kc - 1) / kc);
+  return (advmil_gemm_f32_workspace_bytes(c.M, c.N, splits) + 255) & ~(size_t)255;
+}
+extern "C" size_t advmil_gemm_tn_group_workspace_bytes(const advmil_gemm_tn_call_t* calls, int n) {
+  if (!calls || n < 1 || n > GEMM_GROUP_MAX) return 0;
+  size_t t = 0;
+  for (int i = 0; i < n; ++i) t += group_member_ws(calls[i]);
+  return t;
+}
+extern "C" int advmil_gemm_tn_group(const advmil_gemm_tn_call_t* calls, int n, void* ws, size_t ws_bytes, advmil_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!calls || n < 1 || n > GEMM_GROUP_MAX) return ADVMIL_EINVAL;
+  if (ws_bytes < advmil_gemm_tn_group_workspace_bytes(calls, n)) return ADVMIL_EWORKSPACE;
+  if (ws_bytes && (!ws || ((uintptr_t)ws & 15))) return ADVMIL_EINVAL;
+  GemmGroup gg{};                              // (zero epilogue blocks: no bias / activation / dropout / planes)
+  unsigned gx = 1, gy = 1;
+  size_t off = 0;
+  for (int i = 0; i < n; ++i) {
+    const advmil_gemm_tn_call_t& c = calls[i];
+    if (!c.A || !c.B || !c.C || c.M <= 0 || c.N <= 0 || c.K <= 0 || (c.M & 3) || (c.N & 3) || (c.lda & 3) || (c.ldb & 3) || c.lda < c.M || c.ldb < c.N ||
+        c.ldc < c.N || (((uintptr_t)c.A | (uintptr_t)c.B) & 15))
+      return ADVMIL_EINVAL;
+    GemmArgs& g = gg.a[i];
+    g.M = c.M; g.N = c.N; g.K = c.K; g.A = c.A; g.lda = c.lda; g.B = c.B; g.ldb = c.ldb; g.C = c.C; g.ldc = c.ldc;
+    const int sp = group_member_splits(c.M, c.N, c.K);
+    const int64_t kchunks = (c.K + BK - 1) / BK;
+    g.k_chunk = ((kchunks + sp - 1) / sp) * BK;
+    g.splits = (int)((c.K + g.k_chunk - 1) / g.k_chunk);
+    g.ws = g.splits > 1 ? (float*)((char*)ws + off) : nullptr;
+    off += group_member_ws(c);
+    g.mtiles = (int)((c.M + 63) / 64);
+    g.ntiles = (int)((c.N + 63) / 64);
+    g.epi.alpha = 1.0f;
+    g.epi.act_split = 1 << 30;
+    g.epi.accumulate = c.accumulate ? 1 : 0;
+    if ((unsigned)(g.mtiles * g.ntiles) > gx) gx = (unsigned)(g.mtiles * g.ntiles);
+    if ((unsigned)g.splits > gy) gy = (unsigned)g.splits;
+  }
+  if (g_gemm_mode == 1) hipLaunchKernelGGL((gemm_tn_group_kernel<true>), dim3(gx, gy, n), dim3(256), 0, stream, gg);
+  else hipLaunchKernelGGL((gemm_tn_group_kernel<false>), dim3(gx, gy, n), dim3(256), 0, stream, gg);
+  ADVMIL_LAUNCH_CHECK();
+  for (int i = 0; i < n; ++i)
+    if (gg.a[i].splits > 1) {
+      const int rc = launch_splitk_reduce(gg.a[i], stream);
+      if (rc) return rc;
+    }
+  return ADVMIL_OK;
 }
 
 // ---- fp32 matrix -> bf16 planes (hi = bf16(x), lo = bf16(x - hi)); the same rounding the staging path applies on the fly

@@ -316,6 +316,26 @@ def gemm_plan_tn_planes(M, N, K):
     return _PLAN_CACHE[key]
 
 
+TN_GROUP = os.environ.get("ADVMIL_TN_GROUP", "1") != "0"
+
+
+def gemm_tn_group(calls):
+    """calls: [(A [K, M], B [K, N], out [M, N] view (row pitch = stride(0)), accumulate)], at most 4: out (+)= A^T B for all of them in ONE
+    launch (advmil_gemm_tn_group: 64x64 tiles, split-K per member). Small deep-K weight gradients that would each leave most of the chip
+    idle."""
+    n = len(calls)
+    arr = (_lib.GemmTnCall * n)()
+    for c, (A, B, out, acc) in zip(arr, calls):
+        K, M = A.shape
+        c.M, c.N, c.K = M, B.shape[1], K
+        c.A, c.lda, c.B, c.ldb = A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0)
+        c.C, c.ldc, c.accumulate = out.data_ptr(), out.stride(0), 1 if acc else 0
+    L = _lib.lib()
+    wsb = L.advmil_gemm_tn_group_workspace_bytes(arr, n)
+    ws = _ws(wsb, calls[0][0].device) if wsb else None
+    _lib.check(L.advmil_gemm_tn_group(arr, n, _p(ws), wsb, _stream()), "gemm_tn_group")
+
+
 def auto_splits(M, N, K):
     return gemm_plan(M, N, K)[1]
 
@@ -2291,9 +2311,12 @@ class DxRegionPoolFn(torch.autograd.Function):
                    "dx_chain_bwd")
         if not frozen:
             gWab = gWa.as_strided((2 * D, D), (D, 1), gWa.storage_offset())
-            gemm(dG, fc, False, False, 2 * D, D, R, out=gWab, ldc=D, accumulate=True)             # dWab += dG^T fc
-            gemm(dfc, h1, False, False, D, 64, R, out=gW2.view(D, 64), ldc=64, accumulate=True)   # dW2  += dfc^T h1
-            gemm(dpre, e, False, False, 64, D, R, out=gW1.view(64, D), ldc=D, accumulate=True)    # dW1  += dpre^T e
+            if TN_GROUP:                                                                          # the three in one launch
+                gemm_tn_group([(dG, fc, gWab, True), (dfc, h1, gW2.view(D, 64), True), (dpre, e, gW1.view(64, D), True)])
+            else:
+                gemm(dG, fc, False, False, 2 * D, D, R, out=gWab, ldc=D, accumulate=True)             # dWab += dG^T fc
+                gemm(dfc, h1, False, False, D, 64, R, out=gW2.view(D, 64), ldc=64, accumulate=True)   # dW2  += dfc^T h1
+                gemm(dpre, e, False, False, 64, D, R, out=gW1.view(64, D), ldc=D, accumulate=True)    # dW1  += dpre^T e
         return (de,) + (None,) * 18
 
 

@@ -434,6 +434,23 @@ typedef struct {
 } advmil_dtail_t;
 int advmil_dtail_fwd(const advmil_dtail_t* a, advmil_stream_t stream);
 int advmil_dtail_bwd(const advmil_dtail_t* a, advmil_stream_t stream);
+/* Several small deep-K weight-gradient contractions C_i (+)= A_i^T B_i (A_i [K, M], B_i [K, N] row-major: the TN form of advmil_gemm_f32) as
+ * ONE launch: the three weight gradients behind the fused region network are 2-8 tiles x splits each -- side by side they overlap instead of
+ * paying a launch + K-walk latency apiece. 64x64 tiles, split-K per member (>= 256 of K per workgroup), the engine's arithmetic mode and k
+ * order: bit-identical to advmil_gemm_f32_tiled(tile 11) with the same split count. n <= 4; M, N, lda, ldb multiples of 4; the merges of the
+ * partial tiles are deferrable (advmil_defer_sums) when accumulate != 0 and ldc == N. */
+typedef struct {
+  int64_t M, N, K;
+  const float* A;
+  int64_t lda;
+  const float* B;
+  int64_t ldb;
+  float* C;
+  int64_t ldc;
+  int32_t accumulate;
+} advmil_gemm_tn_call_t;
+size_t advmil_gemm_tn_group_workspace_bytes(const advmil_gemm_tn_call_t* calls, int n);
+int advmil_gemm_tn_group(const advmil_gemm_tn_call_t* calls, int n, void* ws, size_t ws_bytes, advmil_stream_t stream);
 /* The generator's bag-level head as two launches each way (csrc/ghead.hip; reference model/GANSurv.py:13-46 `Generator.forward` behind the
  * backbone's pooling: ABMIL's `rho` = Linear(d0, d1) -> ReLU -> Dropout(p1) (model/backbone.py:66-70; d1 = 0: the backbone has none),
  * MLPs[0] = Linear(d1 | d0, d2) -> ReLU -> Dropout(p2), the noise [B, d2] concatenated, MLPs[1] = Linear(2 d2 | d2, 1), out_scale

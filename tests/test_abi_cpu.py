@@ -70,7 +70,7 @@ def test_tail_struct_layouts_match_c(built, tmp_path):
     if shutil.which("gcc") is None:
         pytest.skip("gcc not available")
     body = ""
-    for cname, cls in (("advmil_dense_layer_t", built.DenseLayer), ("advmil_dtail_t", built.DTail), ("advmil_ghead_t", built.GHead)):
+    for cname, cls in (("advmil_dense_layer_t", built.DenseLayer), ("advmil_dtail_t", built.DTail), ("advmil_ghead_t", built.GHead), ("advmil_gemm_tn_call_t", built.GemmTnCall)):
         body += f'printf("%zu\\n", sizeof({cname}));'
         body += "".join(f'printf("%zu\\n", offsetof({cname}, {f}));' for f, _ in cls._fields_)
     src = tmp_path / "layout2.c"
@@ -79,7 +79,7 @@ def test_tail_struct_layouts_match_c(built, tmp_path):
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     out = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     want = []
-    for cls in (built.DenseLayer, built.DTail, built.GHead):
+    for cls in (built.DenseLayer, built.DTail, built.GHead, built.GemmTnCall):
         want += [ctypes.sizeof(cls)] + [getattr(cls, f).offset for f, _ in cls._fields_]
     assert out == want
 
