@@ -501,8 +501,10 @@ class MyHandler(object):
         the first bag's tensor `anchor`: the loader's staging buffer / the bench's pool) is split ONCE: the planes are kept on the
         anchor tensor object and reused until its storage is written again (version counter); a slab assembled by a copy
         (anchor None) is split per step."""
-        if X.shape[0] < 4096 or not ops.USE_PLANES or ops.get_gemm_mode() != "bf16x3" or not ops.gemm_plan_planes(X.shape[0], 128, X.shape[1]):
-            return                            # (small slabs: the plane-fed kernel's 256-row tiles would not fill the chip)
+        if X.shape[0] < 4096 or not ops.USE_PLANES or ops.get_gemm_mode() != "bf16x3":
+            return
+        if not ops.SLAB_PLANES_ANY and not ops.gemm_plan_planes(X.shape[0], 128, X.shape[1]):
+            return                            # (until round 5: only slabs the plane-fed NT kernel's 256-row tiles fill the chip with)
         if anchor is None or not resident_planes:
             # (resident_planes = False: fp32-only residency -- the split is part of every step, also under HIP-graph replay)
             X._advmil_planes = ops.split_planes(X)

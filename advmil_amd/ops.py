@@ -408,6 +408,10 @@ DG_PLANES_ONLY = os.environ.get("ADVMIL_DG_PLANES_ONLY", "1") != "0"
 # weight gradients dY^T X of the layers applied to the slab: X's planes (already resident for the forward) feed the B operand
 DW_PLANES = os.environ.get("ADVMIL_DW_PLANES", "1") != "0"
 MEMO_PLANES = os.environ.get("ADVMIL_MEMO_PLANES", "1") != "0"
+# operand planes for EVERY step slab of >= 4096 rows, not only for those that fill the chip with the plane-fed NT kernel's 256-row tiles: the
+# deep-K weight gradients (plane-fed TN kernel from K = 8192), the planes-only dpre / dG hand-overs and the dh epilogue fusion then also
+# apply to the 1-4 bag steps of a strong split
+SLAB_PLANES_ANY = os.environ.get("ADVMIL_SLAB_PLANES_ANY", "1") != "0"
 # [B <= 32, d] linear layers on the fp32-FMA kernels (csrc/optim.hip small_linear_*) instead of the 64x64-tile MFMA contraction
 SMALL_LINEAR = os.environ.get("ADVMIL_SMALL_LINEAR", "1") != "0"
 # ... for up to this many rows. In-graph, forward + backward of a [B, 384] -> 384 layer (tools/probe/small_linear_time.py): B = 1-2:
