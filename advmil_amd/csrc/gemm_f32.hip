@@ -1332,7 +1332,10 @@ extern "C" int advmil_gemm_f32_plan_layout(int a_kc, int b_kc, int64_t M, int64_
   if (!tile || !splits || M <= 0 || N <= 0 || K <= 0) return ADVMIL_EINVAL;
   if (g_gemm_mode == 1 && N % 192 == 0) {
     if (M >= 16384) {
-      *tile = (a_kc && b_kc) ? 23 : 43;
+      // NN / TN forms: the 8-wave 256x192 tile needs a full wave of workgroups; the 16384-row slab of a 2-bag step (128 of them) runs
+      // faster on 128x128 tiles (dh 16384 x 384 x 768: 53 -> 48 us, tools/probe/bag2_shapes.py)
+      const bool few = (M / 256) * (N / 192) < 256 && N % 128 == 0 && M % 128 == 0;
+      *tile = (a_kc && b_kc) ? 23 : (few ? 22 : 43);
       *splits = 1;
       return ADVMIL_OK;
     }
@@ -1358,12 +1361,16 @@ extern "C" int advmil_gemm_f32_plan_planes(int a_kc, int b_kc, int64_t M, int64_
   // widest tile that divides N: most flops per staged byte. (A 256x256 form measured equal to 256x192 on every slab shape and, as a
   // persistent kernel, no longer fits the register file beside the streaming epilogue: not built.)
   int tnp = (N % 192 == 0) ? 3 : 2;
+  // ... unless that leaves CUs without a tile while the 128-wide one does not (the 16384-row slab of a 2-bag step, N = 384: 128 tiles of
+  // 256x192 against 192 of 256x128: 60.7 -> 48.4 us, tools/probe/bag2_shapes.py)
+  if (tnp == 3 && N % 128 == 0 && (M / 256) * (N / 192) < 256 && (M / 256) * (N / 128) >= 192) tnp = 2;
   if (force && (force[0] == '2' || force[0] == '3') && N % (64 * (force[0] - '0')) == 0) tnp = force[0] - '0';
   if (K < 64 || (uint64_t)M * (uint64_t)K * 2 >= (1ull << 32) || (uint64_t)N * (uint64_t)K * 2 >= (1ull << 32)) return ADVMIL_OK;
   static const int min_tiles = []() { const char* e = getenv("ADVMIL_NT_PLANES_MIN_TILES"); return e ? atoi(e) : 256; }();
   // one 8-wave workgroup per CU: less than one full wave of tiles loses to the small tiles. (384 -- 1.5 waves -- until round 4; 256
   // measured +0.9 % on the PatchGCN step, whose 65536 x 128 layers are exactly one wave, and neutral at 1-5 ABMIL bags and ESAT 8k)
-  if ((M / 256) * (N / (64 * tnp)) < min_tiles) return ADVMIL_OK;
+  const int64_t nt_ = (M / 256) * (N / (64 * tnp));
+  if (nt_ < min_tiles && !(tnp == 2 && N % 192 == 0 && nt_ >= 192)) return ADVMIL_OK;
   *tile = 80 + tnp;
   return ADVMIL_OK;
 }
@@ -1385,7 +1392,10 @@ extern "C" int advmil_gemm_f32_plan_tn_planes(int64_t M, int64_t N, int64_t K, i
   const int64_t gs = M >= N ? nt : mt, og = M >= N ? mt : nt;
   if (gs > 32) return ADVMIL_OK;
   int64_t sp = (8 * (32 / gs)) / og;                    // groups per XCD x 8 XCDs, over the groups of one split
-  if (sp > K / 1024) sp = K / 1024;
+  // >= 512 of K per split (1024 until round 5: at the 16384 rows of a 2-bag step that left 64-192 workgroups for 256 CUs; dW_D 128 x 1024:
+  // 57 -> 35 us, dW1 384 x 1024: 58 -> 53 us, dWab 768 x 384: 53 -> 46 us, tools/probe/bag2_shapes.py)
+  static const int64_t mink = []() { const char* e = getenv("ADVMIL_TN_PLANES_MINK"); return (int64_t)(e ? atoi(e) : 512); }();
+  if (sp > K / mink) sp = K / mink;
   if (sp < 1) return ADVMIL_OK;
   if (sp * mt * nt < 128) return ADVMIL_OK;             // fewer than half a wave of workgroups: the generic plan spreads better
   *tile = t; *splits = (int)sp;
