@@ -1550,12 +1550,14 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
   // NT form with both operands as planes: the LDS-DMA kernel (tile codes 82 / 83 = 256 x 128 / 192, 8 waves). The plan
   // (advmil_gemm_f32_plan_planes, or tile 0 here) picks it whenever the shape qualifies; ADVMIL_NT_PLANES=0 turns it off.
   if (tile == 0 && pre == 3 && splits == 1) { int t = 0; advmil_gemm_f32_plan_planes(a_kc, b_kc, M, N, K, &t); if (t) tile = t; }
-  if (tile >= 82 && tile <= 85) {
-    const int tnp = tile == 85 ? 4 : tile % 10, bm = 256, bkt = 32;
+  if (tile >= 82 && tile <= 86) {
+    // 86: 256x128 with the PLAIN streaming epilogue (like 85): the two-layer launch of a slab too short to fill the chip with 256x256 tiles
+    const int tnp = tile == 85 ? 4 : tile == 86 ? 2 : tile % 10, bm = 256, bkt = 32;
+    const bool plain = tile == 85 || tile == 86;
     if (tile == 84 && !epi->gate_wc) return ADVMIL_EINVAL;        // 256x256: the fused gate score only
-    if (tile == 85 && (epi->gate_wc || epi->rowv || epi->maskref || epi->accumulate || (epi->seed && epi->drop_p > 0.0f))) return ADVMIL_EINVAL;
-    if (epi->c2) {      // two layers in one launch: the plain 256x256 form only, split on a 32-column boundary inside N
-      if (tile != 85 || epi->n_split <= 0 || epi->n_split >= N || (epi->n_split & 31) || (epi->ldc2 & 3) || ((uintptr_t)epi->c2 & 15) ||
+    if (plain && (epi->gate_wc || epi->rowv || epi->maskref || epi->accumulate || (epi->seed && epi->drop_p > 0.0f))) return ADVMIL_EINVAL;
+    if (epi->c2) {      // two layers in one launch: the plain forms only, split on a 32-column boundary inside N
+      if (!plain || epi->n_split <= 0 || epi->n_split >= N || (epi->n_split & 31) || (epi->ldc2 & 3) || ((uintptr_t)epi->c2 & 15) ||
           epi->act_split != epi->n_split)
         return ADVMIL_EINVAL;
     }
@@ -1572,6 +1574,7 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
     if (!epi->a_lo) {                                     // A = a bf16 slab (x_storage = "bf16"): two products per MFMA step
       switch (tile) {
         case 85: hipLaunchKernelGGL((gemm_nt_planes_kernel<4, 2, 4, 32, 2, 0>), pgrid, dim3(512), 0, stream, g); break;
+        case 86: hipLaunchKernelGGL((gemm_nt_planes_kernel<2, 3, 4, 32, 2, 0>), pgrid, dim3(512), 0, stream, g); break;
         case 83: hipLaunchKernelGGL((gemm_nt_planes_kernel<3, 2, 4, 32, 0, 0>), pgrid, dim3(512), 0, stream, g); break;
         case 82: hipLaunchKernelGGL((gemm_nt_planes_kernel<2, 3, 4, 32, 0, 0>), pgrid, dim3(512), 0, stream, g); break;
         default: return ADVMIL_EINVAL;
@@ -1582,6 +1585,7 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
     switch (tile) {
       case 84: hipLaunchKernelGGL((gemm_nt_planes_kernel<4, 2, 4, 32, 1>), pgrid, dim3(512), 0, stream, g); break;   // 2 x 64 KB
       case 85: hipLaunchKernelGGL((gemm_nt_planes_kernel<4, 2, 4, 32, 2>), pgrid, dim3(512), 0, stream, g); break;   // 256x256, plain streaming epilogue (+ two layers)
+      case 86: hipLaunchKernelGGL((gemm_nt_planes_kernel<2, 3, 4, 32, 2>), pgrid, dim3(512), 0, stream, g); break;   // 256x128, plain streaming epilogue (+ two layers)
       case 83: hipLaunchKernelGGL((gemm_nt_planes_kernel<3, 2, 4, 32>), pgrid, dim3(512), 0, stream, g); break;   // 2 x 56 KB
       case 82: hipLaunchKernelGGL((gemm_nt_planes_kernel<2, 3, 4, 32>), pgrid, dim3(512), 0, stream, g); break;   // 3 x 48 KB: two chunks in flight
       default: return ADVMIL_EINVAL;

@@ -232,19 +232,38 @@ __global__ __launch_bounds__(GH_NT) void ghead_bwd_slices_kernel(GHeadArgs g) {
   }
   LDS_BARRIER();
   // ---- second layer's weight gradient, this slice's columns: dW0[n][c0 + c] += sum_b g2[b][n] hs[b][c]
+  // (the destinations' old values are requested FIRST, all of them, and added at the end: read-add-write element by element is one
+  // memory round trip per element -- the compiler cannot reorder the loads across the stores to the same array)
   if (two && a.dW0) {
-    for (int n = bq; n < d2; n += 16) {
-      float acc = 0.f;
-      for (int b = 0; b < B; ++b) acc += sG2[b * P2 + n] * sHs[b * GH_CW + c];
-      a.dW0[(int64_t)n * ds + c0 + c] += acc;
+    float old[16], acc[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int n = bq + 16 * it;
+      old[it] = n < d2 ? a.dW0[(int64_t)n * ds + c0 + c] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int n = bq + 16 * it;
+      float t = 0.f;
+      if (n < d2)
+        for (int b = 0; b < B; ++b) t += sG2[b * P2 + n] * sHs[b * GH_CW + c];
+      acc[it] = t;
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int n = bq + 16 * it;
+      if (n < d2) a.dW0[(int64_t)n * ds + c0 + c] = old[it] + acc[it];
     }
   }
   // ---- slice layer's weight gradient rows: dWs[c0 + c][k] += sum_b gs[b][c] X[b][k]; bias
   if (dWs) {
     for (int k4 = tid; k4 < q0; k4 += GH_NT) {
-      float4 acc[GH_CW];
+      float4 acc[GH_CW], old[GH_CW];
 #pragma unroll
-      for (int cc = 0; cc < GH_CW; ++cc) acc[cc] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int cc = 0; cc < GH_CW; ++cc) {
+        acc[cc] = make_float4(0.f, 0.f, 0.f, 0.f);
+        old[cc] = *reinterpret_cast<const float4*>(dWs + (int64_t)(c0 + cc) * d0 + 4 * k4);
+      }
       for (int b = 0; b < B; ++b) {
         const float4 x = *reinterpret_cast<const float4*>(sX + b * PX + 4 * k4);
 #pragma unroll
@@ -260,10 +279,9 @@ __global__ __launch_bounds__(GH_NT) void ghead_bwd_slices_kernel(GHeadArgs g) {
       }
 #pragma unroll
       for (int cc = 0; cc < GH_CW; ++cc) {
-        float4* p = reinterpret_cast<float4*>(dWs + (int64_t)(c0 + cc) * d0 + 4 * k4);
-        float4 o = *p;
+        float4 o = old[cc];
         o.x += acc[cc].x; o.y += acc[cc].y; o.z += acc[cc].z; o.w += acc[cc].w;
-        *p = o;
+        *reinterpret_cast<float4*>(dWs + (int64_t)(c0 + cc) * d0 + 4 * k4) = o;
       }
     }
   }

@@ -562,9 +562,9 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
             tile = ptile
     if b_single and not (91 <= tile <= 93) and tile not in (22, 12, 11) and not (tile in (34, 24) and not a_kc and not b_kc):
         tile = 22                             # a bf16 B operand has no fp32 image: land on a kernel that stages B from its plane
-    if planes_only_a and a_planes.single and not (82 <= tile <= 85) and tile not in (22, 12, 11):
+    if planes_only_a and a_planes.single and not (82 <= tile <= 86) and tile not in (22, 12, 11):
         tile = 22
-    if planes_only_a and not (82 <= tile <= 85) and not (91 <= tile <= 93) and not pre_a_tile_ok(tile if tile else gemm_plan(M, N, K, a_kc, b_kc)[0], a_kc, b_kc,
+    if planes_only_a and not (82 <= tile <= 86) and not (91 <= tile <= 93) and not pre_a_tile_ok(tile if tile else gemm_plan(M, N, K, a_kc, b_kc)[0], a_kc, b_kc,
                                                                      b_planes is not None):       # (82-85: plane-fed, reads planes only)
         raise ValueError(f"gemm(A=None): tile {tile} has no pre-split-A instantiation for this layout")
     L = _lib.lib()
@@ -573,7 +573,7 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
     prof = KERNEL_PROFILE
     name = None
     if prof is not None or STAMPS is not None:
-        name = ("gemm_nt_planes_kernel<%d>" % (tile - 80)) if 82 <= tile <= 84 else "gemm_nt_planes_kernel<4,plain>" if tile == 85 else \
+        name = ("gemm_nt_planes_kernel<%d>" % (tile - 80)) if 82 <= tile <= 84 else "gemm_nt_planes_kernel<4,plain>" if tile == 85 else "gemm_nt_planes_kernel<2,plain>" if tile == 86 else \
             ("gemm_tn_planes_kernel<%d>" % tile) if 91 <= tile <= 93 else \
             "gemm_f32_kernel<%d,%d,%d,%d>" % (bool(a_kc), bool(b_kc), tile // 10, tile % 10)
     if prof is not None:
@@ -595,12 +595,25 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
 # the ESAT in-projection writes q | k | v as operand planes only (no fp32 qkv, no split pass in front of the attention kernels)
 ATTN_QKV_PLANES = os.environ.get("ADVMIL_ATTN_QKV_PLANES", "1") != "0"
 TWO_LAYERS_MIN_TILES = int(os.environ.get("ADVMIL_TWO_LAYERS_MIN_TILES", "256"))
+TWO_LAYERS_NARROW = os.environ.get("ADVMIL_TWO_LAYERS_NARROW", "1") != "0"
+
+
+def gemm_two_layers_tile(M, N1, N2, K):
+    """Tile code of the ONE plane-fed launch that runs act(x W1^T + b1) and act(x W2^T + b2) over the same rows -- 85: persistent 256x256
+    tiles; 86: 256x128 tiles, for a slab too short to give every CU a 256x256 tile (the 16384 rows of a 2-bag step: 128 against 256 tiles)
+    -- or 0 when the shapes do not qualify."""
+    if not (get_gemm_mode() == "bf16x3" and USE_PLANES and M >= 4096 and M % 256 == 0 and K % 32 == 0 and K >= 64 and N1 % 32 == 0
+            and M * K * 2 < (1 << 32)):
+        return 0
+    if (N1 + N2) % 256 == 0 and (M // 256) * ((N1 + N2) // 256) >= TWO_LAYERS_MIN_TILES:
+        return 85
+    if TWO_LAYERS_NARROW and (N1 + N2) % 128 == 0 and N1 % 128 == 0 and (M // 256) * ((N1 + N2) // 128) >= TWO_LAYERS_MIN_TILES:
+        return 86
+    return 0
 
 
 def gemm_two_layers_ok(M, N1, N2, K):
-    """Can act(x W1^T + b1) and act(x W2^T + b2) over the same rows run as ONE plane-fed launch (tile 85: persistent 256x256)?"""
-    return (get_gemm_mode() == "bf16x3" and USE_PLANES and M >= 4096 and M % 256 == 0 and K % 32 == 0 and K >= 64 and N1 % 32 == 0
-            and (N1 + N2) % 256 == 0 and (M // 256) * ((N1 + N2) // 256) >= TWO_LAYERS_MIN_TILES and M * K * 2 < (1 << 32))
+    return gemm_two_layers_tile(M, N1, N2, K) != 0
 
 
 def gemm_two_layers(x, xpl, W1, w1pl, b1, act1, W2, w2pl, b2, act2, emit_planes1=False):
@@ -631,8 +644,8 @@ def gemm_two_layers(x, xpl, W1, w1pl, b1, act1, W2, w2pl, b2, act2, emit_planes1
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
     _stamp("b", f"gemm_nt_planes_kernel<4,two layers,{N1}>", (M, N1 + N2, K, 1), 2.0 * M * (N1 + N2) * K)
-    _lib.check(_lib.lib().advmil_gemm_f32_tiled(1, 1, M, N1 + N2, K, _p(x), x.stride(0), _p(W1), K, _p(y1), N1, ctypes.byref(e), 1, 85,
-                                                None, 0, _stream()), f"gemm_two_layers[{M}x({N1}+{N2})x{K}]")
+    _lib.check(_lib.lib().advmil_gemm_f32_tiled(1, 1, M, N1 + N2, K, _p(x), x.stride(0), _p(W1), K, _p(y1), N1, ctypes.byref(e), 1,
+                                                gemm_two_layers_tile(M, N1, N2, K), None, 0, _stream()), f"gemm_two_layers[{M}x({N1}+{N2})x{K}]")
     _stamp("e", f"gemm_nt_planes_kernel<4,two layers,{N1}>", (M, N1 + N2, K, 1), 2.0 * M * (N1 + N2) * K)
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)

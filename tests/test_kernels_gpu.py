@@ -469,16 +469,17 @@ def test_gemm_streaming_epilogue_modes(ops, mode, tile):
 
 
 @pytest.mark.gpu
-def test_gemm_two_layers_in_one_launch(ops):
-    """advmil_epilogue_t's two-layer form (tile 85): act1(x W1^T + b1) and act2(x W2^T + b2) from one plane-fed launch over stacked
-    weight planes, two outputs, planes of the first. Bit-identical to the two separate plane-fed launches, and within the bf16x3
-    tolerance of float64 on the host; bad arguments are refused."""
+@pytest.mark.parametrize("M,want_tile", [(65536, 85), (16384, 86)])
+def test_gemm_two_layers_in_one_launch(ops, M, want_tile):
+    """advmil_epilogue_t's two-layer form (tile 85: 256x256; tile 86: 256x128, the slab of a 2-bag step): act1(x W1^T + b1) and
+    act2(x W2^T + b2) from one plane-fed launch over stacked weight planes, two outputs, planes of the first. Bit-identical to the two
+    separate plane-fed launches, and within the bf16x3 tolerance of float64 on the host; bad arguments are refused."""
     from advmil_amd._lib import AdvmilHipError
     prev = ops.get_gemm_mode()
     ops.set_gemm_mode("bf16x3")
     try:
-        M, K, N1, N2 = 65536, 256, 384, 128
-        assert ops.gemm_two_layers_ok(M, N1, N2, K)
+        K, N1, N2 = 256, 384, 128
+        assert ops.gemm_two_layers_tile(M, N1, N2, K) == want_tile
         g = torch.Generator(device="cuda").manual_seed(2)
         x = torch.randn(M, K, device="cuda", generator=g)
         W1 = 0.1 * torch.randn(N1, K, device="cuda", generator=g); W2 = 0.1 * torch.randn(N2, K, device="cuda", generator=g)
