@@ -129,7 +129,8 @@ SIGNATURES = {
     "advmil_genconv_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64,
                                    c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "advmil_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
-                                 c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+                                 c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "advmil_adam_blocks": (c_int, [c_int64]),
     "advmil_step_seed_tick": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p]),
     "advmil_abs_sum": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "advmil_abs_sum_workspace_bytes": (c_size_t, [c_int64]),

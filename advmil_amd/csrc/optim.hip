@@ -5,11 +5,16 @@
 extern "C" int advmil_version(void) { return 100; }
 
 // torch.optim.Adam (L2-in-grad) with the L1 sub-gradient of loss_reg_l1 folded in.
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ m,
+// abs_partial (optional): abs_partial[block] = sum |w| over the block's elements BEFORE the update -- the value of the L1 term the step
+// logs (loss/utils.py:6-14) without a pass of its own over the arena. clear != 0: the gradient is zeroed behind its last read, so the next
+// step needs no fill launch (graph replay only: p.grad reads zero afterwards).
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ grad, float* __restrict__ m,
                                                    float* __restrict__ v, const float* __restrict__ wd, int64_t n, float lr,
                                                    float b1, float b2, float eps, float gscale, float l1,
                                                    const int32_t* __restrict__ step, unsigned short* __restrict__ p_hi,
-                                                   unsigned short* __restrict__ p_lo) {
+                                                   unsigned short* __restrict__ p_lo, float* __restrict__ abs_partial, int clear) {
+  __shared__ float red[4];
+  float asum = 0.f;
   const int t = *step + 1;   // the launcher bumps *step after this kernel (a last-workgroup-bumps-it form was measured: the
                              // 2048 arrivals on one counter cost 15 us, the second launch 4)
   const float bc1 = 1.f - hw_exp2((float)t * hw_log2(b1));      // 1 - b1^t
@@ -19,6 +24,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float w = p[i];
     float g = grad[i] * gscale;
+    if (clear) grad[i] = 0.f;
+    asum += fabsf(w);
     if (l1 != 0.f) g += l1 * (w > 0.f ? 1.f : (w < 0.f ? -1.f : 0.f));
     if (wd) g += wd[i] * w;
     const float mi = b1 * m[i] + (1.f - b1) * g;
@@ -34,6 +41,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
       p_lo[i] = *reinterpret_cast<const unsigned short*>(&l);
     }
   }
+  if (abs_partial) {
+    asum = wave_sum(asum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = asum;
+    __syncthreads();
+    if (threadIdx.x == 0) abs_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
 }
 __global__ void step_inc_kernel(int32_t* step) { *step += 1; }
 // the step counter's increment and the RNG seed's advance of an optimizer step's end as ONE one-thread launch
@@ -43,15 +56,19 @@ __global__ void step_seed_tick_kernel(int32_t* step, int32_t* step2, uint64_t* s
   if (seed) *seed += inc;
 }
 
-extern "C" int advmil_adam_step(float* p, const float* grad, float* m, float* v, const float* wd, int64_t n, float lr,
+extern "C" int advmil_adam_blocks(int64_t n) {
+  if (n <= 0) return 0;
+  const int64_t b = (n + 255) / 256;
+  return (int)(b > 2048 ? 2048 : b);
+}
+extern "C" int advmil_adam_step(float* p, float* grad, float* m, float* v, const float* wd, int64_t n, float lr,
                                 float beta1, float beta2, float eps, float grad_scale, float l1_coef, int32_t* step,
-                                void* p_hi, void* p_lo, int tick, advmil_stream_t stream_) {
+                                void* p_hi, void* p_lo, int tick, float* abs_partial, int clear_grad, advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!p || !grad || !m || !v || !step || n <= 0 || ((p_hi != nullptr) != (p_lo != nullptr))) return ADVMIL_EINVAL;
-  int blocks = (int)((n + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
+  const int blocks = advmil_adam_blocks(n);
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, p, grad, m, v, wd, n, lr, beta1, beta2, eps, grad_scale,
-                     l1_coef, step, (unsigned short*)p_hi, (unsigned short*)p_lo);
+                     l1_coef, step, (unsigned short*)p_hi, (unsigned short*)p_lo, abs_partial, clear_grad);
   if (tick) hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, stream, step);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;

@@ -27,6 +27,10 @@ import torch
 from . import ops
 
 
+# the two gradient-arena fills of a step folded into the Adam launches (ADVMIL_CLEAR_IN_ADAM=0: separate fill launches, for A/B timing)
+CLEAR_IN_ADAM = os.environ.get("ADVMIL_CLEAR_IN_ADAM", "1") != "0"
+
+
 class GraphedStep:
     def __init__(self, handler, xs, ys, ys_host, mode="wlabel", label_visible_mask=None, warmup=2, force_segments=False,
                  capture_collectives=None):
@@ -79,12 +83,13 @@ class GraphedStep:
 
     def _seg_mid(self):
         self.h._log_d()                      # after the exchange: the logged statistics are the reduced ones
-        self.h.optimizerD.step(tick=False)   # (its counter is ticked with G's and the RNG seed at the end of the step: _seg_end)
+        # (its counter is ticked with G's and the RNG seed at the end of the step: _seg_end; the gradient arena is cleared behind the read)
+        self.h.optimizerD.step(tick=False, clear_grad=CLEAR_IN_ADAM)
         self.h._gen_finish(0, self.xs, self.ys, self.plan)
 
     def _seg_end(self):
         self.h._log_g()
-        self.h.optimizerG.step(tick=False)
+        self.h.optimizerG.step(tick=False, abs_partial=self.h._abs_partial, clear_grad=CLEAR_IN_ADAM)
         ops.step_seed_tick(self.h.optimizerG.step_t, self.h.rng.seed, 1, step2=self.h.optimizerD.step_t)   # both step counters and the RNG seed: one launch
 
     def _eager(self):
@@ -146,8 +151,17 @@ class GraphedStep:
             self.segments, self.lrs = [], self._lrs()
             self._capture(0)
         segs = self.segments
+        if CLEAR_IN_ADAM:
+            # the captured step holds no fill launches: it starts from arenas its own Adam launches left clean. Anything else that stepped
+            # in between (an eager step, which keeps its gradients readable) leaves them dirty: clear them here, outside the graph
+            for opt in (self.h.optimizerD, self.h.optimizerG):
+                if not getattr(opt, "_grad_clean", False):
+                    opt.flat_grad.zero_()
+                opt._grad_clean = False      # (the replay's backward launches dirty it; its Adam cleans it again: set below)
         if len(segs) == 1:
             segs[0].replay()
+            if CLEAR_IN_ADAM:
+                self.h.optimizerD._grad_clean = self.h.optimizerG._grad_clean = True
             return
         segs[0].replay()
         self.h._st_d, self.h._st_g = self._st_d, self._st_g      # this graph's statistics tensors (another group may have run since)
@@ -169,6 +183,8 @@ class GraphedStep:
             ev[3].record()
             self.wait_events = [(ev[0], ev[1]), (ev[2], ev[3])]
         segs[3].replay()
+        if CLEAR_IN_ADAM:
+            self.h.optimizerD._grad_clean = self.h.optimizerG._grad_clean = True
 
     stamp_waits = False
 

@@ -108,11 +108,12 @@ class Generator(nn.Module):
             probe.sid_noise, probe.seed, probe.rr = rng.site("noise", (B * d2,), None), rng.seed, rng.row_map(B, "noise")
         return probe
 
-    def finish(self, feats, zero_noise=False, noise=None):
-        """feats[B, d] (stacked `features`) -> predictions [B, dim_out]."""
+    def finish(self, feats, zero_noise=False, noise=None, pred_out=None):
+        """feats[B, d] (stacked `features`) -> predictions [B, dim_out]. pred_out: an fp32 [B, 1] buffer the predictions are written into
+        when the fused head runs without a graph (the D update's stacked label column); the caller checks data_ptr()."""
         spec = self._head_spec(feats, zero_noise, noise)
         if spec is not None:                 # rho + head as two launches each way
-            return ops.ghead(feats, spec)
+            return ops.ghead(feats, spec, pred_out if not torch.is_grad_enabled() else None)
         bb = self.backbone
         H = bb.post(feats) if hasattr(bb, "post") else feats
         return self.head(H, zero_noise, noise)

@@ -388,7 +388,10 @@ class MyHandler(object):
         seg16.rng_rowoff = rowoff16
         self._plan_count = getattr(self, "_plan_count", 0) + 1
         y = torch.cat(ys, dim=0) if y_stack is None else y_stack
-        return SimpleNamespace(vis=vis, is_real=is_real, n_real=n_real, n_fake=n_fake, n_vis=n_vis, y=y,
+        # the D update's stacked label column [fake predictions | real labels]: the lower half is constant per plan, the upper half is
+        # written by the generator's head itself (no concatenation launch per step)
+        t2 = torch.cat([torch.zeros(n, 1, dtype=torch.float32, device=dev), y[:, 0:1].float()], dim=0) if n_real > 0 else None
+        return SimpleNamespace(vis=vis, is_real=is_real, n_real=n_real, n_fake=n_fake, n_vis=n_vis, y=y, t2=t2,
                                y_t=y[:, 0:1].contiguous(), y_e=y[:, 1:2].contiguous(),     # label columns, contiguous once per plan
                                vis_mask=None if all(vis) else masks_d[n:], real_mask=masks_d[:n], seg=seg, seg16=seg16,
                                rng_rows=rng_rows, token=self._plan_count, _keep=(masks, masks_d), _X=None, _X_src=None,
@@ -583,7 +586,8 @@ class MyHandler(object):
         ops.MEMO.begin("record", ("G", id(self.netG), getattr(self.optimizerG, "n_updates", 0), plan.token), X)
         try:
             with torch.no_grad():                                              # the reference builds, then detaches (400)
-                pred = self.netG.finish(self._gen_features(X, plan, xs), noise=self._stack_noise(noise))     # [B,1]
+                pred = self.netG.finish(self._gen_features(X, plan, xs), noise=self._stack_noise(noise),
+                                        pred_out=None if plan.t2 is None else plan.t2[:len(xs)])               # [B,1]
         finally:
             ops.MEMO.end()
         if self.overlap_gfwd and self.dp.world == 1:      # everything _gen_forward reads exists from here on
@@ -600,7 +604,9 @@ class MyHandler(object):
             nb = len(xs)
             eb2, im2 = self.netD.bag_features_multi(emb, plan.seg16.twice())
             eb2, im2 = self._bags(eb2, plan, True), self._bags(im2, plan, True)
-            f2 = self.netD.tail(eb2, im2, torch.cat([pred, plan.y_t], dim=0)).view(-1)
+            # (pred IS the upper half of plan.t2 when the head wrote it there)
+            t2 = plan.t2 if (plan.t2 is not None and pred.data_ptr() == plan.t2.data_ptr()) else torch.cat([pred, plan.y_t], dim=0)
+            f2 = self.netD.tail(eb2, im2, t2).view(-1)
             f_fake = f2.detach()[:nb]                                           # (the loss takes f2 whole: no slice backward)
         else:
             eb, im = self.netD.bag_features_multi(emb, plan.seg16)
@@ -620,6 +626,8 @@ class MyHandler(object):
         finally:
             ops.DY_PLANES.clear()            # (a backward that raised may have left a plane hand-over behind: never let it meet a reused address)
         self._st_d = (st, plan, i_batch)     # this rank's partial sums over the global denominators; reduced + logged in _disc_apply
+        if plan.t2 is not None and pred.data_ptr() == plan.t2.data_ptr() and not torch.cuda.is_current_stream_capturing():
+            pred = pred.clone()              # the plan's buffer is rewritten by its next step; the collector keeps these
         preds = list(pred.split(1, dim=0))
         fakes = list(f_fake.detach().split(1, dim=0))
         return preds, fakes
@@ -755,15 +763,18 @@ class MyHandler(object):
     def _log_g(self):
         st, i_batch = self._st_g
         c1 = self.coef_l1 if self.coef_l1 > 1e-8 else 0.0      # added once, after the reduce: the L1 term is not a per-bag sum
-        tens = (st, ops.abs_sum(self.optimizerG.flat_param)) if c1 else (st,)
+        # sum |W| of the L1 term's logged value: per-workgroup shares written by the Adam launch that follows (the parameters as they
+        # stand before the update), summed on the host when the log is read -- no pass of its own over the arena
+        self._abs_partial = torch.empty(ops.adam_blocks(self.optimizerG.flat_param.numel()), dtype=torch.float32, device=self.device) if c1 else None
+        tens = (st, self._abs_partial) if c1 else (st,)
         self.log(LazyLog(tens, lambda v, a=None: {"train_batch/netG/Loss_G_fake": v[2], "train_batch/netG/Loss_G_time": v[1],
-                                                  "train_batch/netG/Loss_G_total": v[0] + (c1 * a[0] if a is not None else 0.0),
+                                                  "train_batch/netG/Loss_G_total": v[0] + (c1 * a.sum(dtype=a.dtype) if a is not None else 0.0),
                                                   "train_batch/netG/D_fake_avg": -v[2], "i_batch": i_batch}))
 
     def _gen_apply(self):
         self._reduce_g()
         self._log_g()
-        self.optimizerG.step()                                                 # L1 sub-gradient folded in
+        self.optimizerG.step(abs_partial=self._abs_partial)                    # L1 sub-gradient folded in
 
     # ------------------------------------------------------------------------------------------
     @staticmethod

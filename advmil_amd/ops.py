@@ -844,12 +844,22 @@ def ln_relu_mean16_bwd(demb, y, gamma, beta, mean, rstd, N, d, dg_out=None, db_o
     return dy, dg, db
 
 
-def adam_step(p, grad, m, v, wd, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, l1_coef=0.0, planes=None, tick=True):
+def adam_blocks(n):
+    """Workgroups of the Adam launch over n elements = entries of its `abs_partial` output."""
+    return int(_lib.lib().advmil_adam_blocks(int(n)))
+
+
+def adam_step(p, grad, m, v, wd, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, l1_coef=0.0, planes=None, tick=True,
+              abs_partial=None, clear_grad=False):
     """In place over flat fp32 arenas; `step` is an int32 device tensor bumped by the kernel. `planes`: Planes arenas that receive
-    the bf16x3 operand planes of the updated weights."""
+    the bf16x3 operand planes of the updated weights. abs_partial [adam_blocks(n)]: per-workgroup shares of sum |p| before the update;
+    clear_grad: zero the gradient arena behind its last read."""
+    if abs_partial is not None and (abs_partial.numel() < adam_blocks(p.numel()) or abs_partial.dtype != torch.float32):
+        raise ValueError("adam_step: abs_partial needs adam_blocks(n) fp32 entries")
     _lib.check(_lib.lib().advmil_adam_step(_p(p), _p(grad), _p(m), _p(v), _p(wd), p.numel(), lr, beta1, beta2, eps,
                                            grad_scale, l1_coef, _p(step), _p(None if planes is None else planes.hi),
-                                           _p(None if planes is None else planes.lo), 1 if tick else 0, _stream()),
+                                           _p(None if planes is None else planes.lo), 1 if tick else 0, _p(abs_partial),
+                                           1 if clear_grad else 0, _stream()),
                "adam_step")
 
 
@@ -2169,7 +2179,7 @@ class GHeadFn(torch.autograd.Function):
     """pred [B, 1] = out_scale(MLPs[1](cat(MLPs[0](rho(x)), noise))) (Generator.finish behind the backbone's pooling)."""
 
     @staticmethod
-    def forward(ctx, x, spec, *params):
+    def forward(ctx, x, spec, pred_out, *params):
         if x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() & 15:
             x = x.contiguous()
         B, dev = x.shape[0], x.device
@@ -2177,14 +2187,16 @@ class GHeadFn(torch.autograd.Function):
         d1 = 0 if spec.Wr is None else spec.Wr.shape[0]
         hs = torch.empty(B, d1 if d1 else d2, dtype=torch.float32, device=dev)
         h2 = torch.empty(B, d2, dtype=torch.float32, device=dev) if d1 else None
-        pred = torch.empty(B, 1, dtype=torch.float32, device=dev)
+        if pred_out is not None and (tuple(pred_out.shape) != (B, 1) or pred_out.dtype != torch.float32 or not pred_out.is_contiguous()):
+            pred_out = None
+        pred = pred_out if pred_out is not None else torch.empty(B, 1, dtype=torch.float32, device=dev)
         L = _lib.lib()
         wsb = L.advmil_ghead_workspace_bytes(B, x.shape[1], d1, d2)
         ws = _ws(wsb, dev)
         gh = _lib.GHead()
         _fill_ghead(gh, x, spec, hs, h2, pred, ws, wsb)
         # (gradient slots as they stand NOW: parameters frozen around this forward stay frozen in the backward)
-        ctx.slots = [(_arena_grad(p) if (p is not None and ctx.needs_input_grad[2 + j]) else None) for j, p in enumerate(spec.params())]
+        ctx.slots = [(_arena_grad(p) if (p is not None and ctx.needs_input_grad[3 + j]) else None) for j, p in enumerate(spec.params())]
         _lib.check(L.advmil_ghead_fwd(ctypes.byref(gh), _stream()), "ghead_fwd")
         ctx.spec = spec
         ctx.has_h2 = h2 is not None
@@ -2210,11 +2222,12 @@ class GHeadFn(torch.autograd.Function):
         sl = ctx.slots
         gh.dWr, gh.dbr, gh.dW0, gh.db0, gh.dW1, gh.db1 = (_p(g) for g in sl)
         _lib.check(L.advmil_ghead_bwd(ctypes.byref(gh), _stream()), "ghead_bwd")
-        return (dx, None) + (None,) * len(sl)
+        return (dx, None, None) + (None,) * len(sl)
 
 
-def ghead(x, spec):
-    return GHeadFn.apply(x, spec, *spec.params())
+def ghead(x, spec, pred_out=None):
+    """pred_out (no-grad calls only): write the predictions into this [B, 1] buffer instead of a fresh tensor."""
+    return GHeadFn.apply(x, spec, pred_out, *spec.params())
 
 
 # ---------------------------------------------------------------------------------------

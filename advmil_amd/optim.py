@@ -88,21 +88,28 @@ class FlatAdam(torch.optim.Optimizer):
             p._advmil_planes = (self, p._version, ops.Planes(self.planes.hi[o:o + k].view(p.shape), self.planes.lo[o:o + k].view(p.shape)))
 
     def zero_grad(self, set_to_none: bool = False):
-        self.flat_grad.zero_()
+        if getattr(self, "_grad_clean", False):
+            self._grad_clean = False         # the last step cleared the arena behind its read (step(clear_grad=True)): nothing to fill
+        else:
+            self.flat_grad.zero_()
         for p, o, k in self._views:          # re-attach if someone replaced .grad
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
                 p.grad = self.flat_grad[o:o + k].view(p.shape)
                 p._arena_grad = p.grad
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0, tick=True):
+    def step(self, closure=None, grad_scale=1.0, tick=True, abs_partial=None, clear_grad=False):
         """tick = False: the device step counter is left to the caller (ops.step_seed_tick(self.step_t, seed): the captured step folds it
-        into the RNG seed's advance)."""
+        into the RNG seed's advance). abs_partial: receives the per-workgroup shares of sum |p| BEFORE the update (the logged L1 term).
+        clear_grad: the kernel zeroes the gradient arena behind its read and the next zero_grad() launches nothing -- p.grad then reads
+        zero after step(), so only the captured step (nobody looks at gradients between replays) asks for it."""
         g0 = self.param_groups[0]
         b1, b2 = g0["betas"]
         self.n_updates = getattr(self, "n_updates", 0) + 1      # host-side version of the parameters (forward memo key)
         ops.adam_step(self.flat_param, self.flat_grad, self.flat_m, self.flat_v, self.flat_wd if self._has_wd else None,
-                      self.step_t, g0["lr"], b1, b2, g0["eps"], grad_scale, self.l1_coef, planes=self.planes, tick=tick)
+                      self.step_t, g0["lr"], b1, b2, g0["eps"], grad_scale, self.l1_coef, planes=self.planes, tick=tick,
+                      abs_partial=abs_partial, clear_grad=clear_grad)
+        self._grad_clean = bool(clear_grad)
 
     def state_dict(self):
         n = float(self.step_t.item())

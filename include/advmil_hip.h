@@ -330,9 +330,13 @@ int advmil_genconv_bwd(const float* dout, const float* x, const float* agg, cons
  * abs_sum: out[0] = sum |p| (for the logged Loss_G_total). */
 /* tick != 0: the kernel's own second launch increments `step`; tick = 0: the caller increments it (advmil_step_seed_tick folds that into the
  * RNG seed's advance at the end of an optimizer step: one one-thread launch instead of two). */
-int advmil_adam_step(float* p, const float* grad, float* m, float* v, const float* wd, int64_t n, float lr,
+/* abs_partial (NULL: skipped): advmil_adam_blocks(n) floats, abs_partial[i] = the i-th workgroup's share of sum |p| BEFORE the update (the logged
+ * value of the L1 term, summed on the host when the log is read). clear_grad != 0: grad is zeroed behind its last read (the next step then
+ * needs no fill launch; p.grad reads zero afterwards -- the captured step uses it, the eager handler does not). */
+int advmil_adam_blocks(int64_t n);
+int advmil_adam_step(float* p, float* grad, float* m, float* v, const float* wd, int64_t n, float lr,
                      float beta1, float beta2, float eps, float grad_scale, float l1_coef, int32_t* step, void* p_hi, void* p_lo,
-                     int tick, advmil_stream_t stream);
+                     int tick, float* abs_partial, int clear_grad, advmil_stream_t stream);
 /* step[0] += 1, step2[0] += 1 (the two networks' counters; NULL: skipped) and seed[0] += inc (NULL: skipped) in one launch */
 int advmil_step_seed_tick(int32_t* step, int32_t* step2, uint64_t* seed, uint64_t inc, advmil_stream_t stream);
 int advmil_abs_sum(const float* p, int64_t n, float* out, void* ws, size_t ws_bytes, advmil_stream_t stream);

@@ -7,7 +7,7 @@ import ctypes
 import pytest
 
 EINVAL, EWORKSPACE = -1, -2
-HOST_ONLY = {"advmil_version", "advmil_set_gemm_mode", "advmil_get_gemm_mode", "advmil_gemm_f32_plan", "advmil_gemm_f32_plan_layout",
+HOST_ONLY = {"advmil_version", "advmil_adam_blocks", "advmil_set_gemm_mode", "advmil_get_gemm_mode", "advmil_gemm_f32_plan", "advmil_gemm_f32_plan_layout",
              "advmil_gemm_f32_plan_planes", "advmil_gemm_f32_gate_blocks",
              # merge-queue bookkeeping on a stream handle (NULL = the default stream is a valid one): nothing to validate, nothing launched
              "advmil_defer_sums", "advmil_flush_sums", "advmil_pending_sums"}
@@ -80,7 +80,7 @@ def test_pooling_group_checks_shapes_and_workspace(L):
     assert lib.advmil_softmax_pool_fwd(p(0), p(1), D, N, D, 4, None, N, p(2), p(3), p(4), need, None) == EINVAL          # 4 bags, no offsets
     assert lib.advmil_softmax_pool_fwd(p(0), ctypes.c_void_p(A16 + 8), D, N, D, 1, None, N, p(2), p(3), p(4), need, None) == EINVAL
     assert lib.advmil_gate_score_fwd(p(0), p(1), p(2), 1.5, p(3), 1, 2, N, D, p(4), None, None) == EINVAL                # p >= 1
-    assert lib.advmil_ln_relu_mean16_fwd(p(0), p(1), p(2), 1e-5, 8200, 128, p(3), p(4), p(5), None, None, 1, None) == EINVAL   # N % 16 != 0
+    assert lib.advmil_ln_relu_mean16_fwd(p(0), p(1), p(2), 1e-5, 8200, 128, p(3), p(4), p(5), None, None, 1, None, 0, None) == EINVAL   # N % 16 != 0
 
 
 def test_attention_group_checks_head_dim_and_segments(L):
@@ -101,7 +101,7 @@ def test_attention_group_checks_head_dim_and_segments(L):
 def test_optimizer_graph_and_evaluator_groups(L):
     lib = L.lib()
     p = lambda k: ctypes.c_void_p(A16 + (k << 20))   # noqa: E731
-    assert lib.advmil_adam_step(p(0), p(1), p(2), p(3), p(4), -5, 1e-3, 0.9, 0.999, 1e-8, 1.0, 0.0, p(5), None, None, 1, None) == EINVAL
+    assert lib.advmil_adam_step(p(0), p(1), p(2), p(3), p(4), -5, 1e-3, 0.9, 0.999, 1e-8, 1.0, 0.0, p(5), None, None, 1, None, 0, None) == EINVAL
     assert lib.advmil_genconv_fwd(p(0), p(1), p(2), p(3), 1e-7, 100, 0, p(4), p(5), p(6), None) == EINVAL
     assert lib.advmil_cindex_counts(p(0), p(1), p(2), -1, 1e-8, p(3), None) == EINVAL
     assert lib.advmil_gan_d_loss(p(0), 4, None, None, 0, 9, 0.25, 0.0, p(1), p(2), None, None) == EINVAL                 # unknown loss kind
