@@ -162,8 +162,13 @@ extern "C" int advmil_stage_bag(void* dst_rows, const void* src_rows, size_t row
   if (split) {
     if (plane_bytes * 2 != rows_bytes || (rows_bytes & 31)) return ADVMIL_EINVAL;      // bf16 planes of fp32 rows, 8 floats per thread
     const int64_t n8 = (int64_t)(rows_bytes >> 5);
+    // ADVMIL_STAGE_BLOCKS: workgroups of a staging launch. The launch runs on the copy stream UNDER the step's kernels, whose persistent
+    // contractions hold one workgroup per CU and are bound by that CU's load path: a grid that floods every CU (4096 blocks until round 5)
+    // slows all of them, 192 blocks leave most CUs alone at a time (resident product loop 3.17 -> 3.12 ms per step; 64: 3.34, 128: 3.16,
+    // 256: 3.24; tools/probe/exp_staging.sh)
+    static const int64_t cap = []() { const char* e = getenv("ADVMIL_STAGE_BLOCKS"); return (int64_t)(e ? atoi(e) : 192); }();
     int64_t blocks = (n8 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(stage_bag_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, (const float*)src_rows,
                        (float*)dst_rows, n8, (uint4*)dst_hi, (uint4*)dst_lo);
@@ -173,8 +178,9 @@ extern "C" int advmil_stage_bag(void* dst_rows, const void* src_rows, size_t row
   StageSpan a{(uint4*)dst_rows, (const uint4*)src_rows, (int64_t)(rows_bytes >> 4)};
   StageSpan b{(uint4*)dst_hi, (const uint4*)src_hi, planes ? (int64_t)(plane_bytes >> 4) : 0};
   StageSpan c{(uint4*)dst_lo, (const uint4*)src_lo, planes ? (int64_t)(plane_bytes >> 4) : 0};
+  static const int64_t cap3 = []() { const char* e = getenv("ADVMIL_STAGE_BLOCKS"); return (int64_t)(e ? atoi(e) : 192); }();
   int64_t blocks = ((int64_t)(rows_bytes >> 4) + 1023) / 1024;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > cap3) blocks = cap3;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(stage_bag_kernel, dim3((unsigned)blocks, planes ? 3 : 1), dim3(256), 0, (hipStream_t)stream_, a, b, c);
   ADVMIL_LAUNCH_CHECK();

@@ -76,7 +76,10 @@ class SlabStager:
         self.dtype = dtype
         self.store = dtype if store is None else store
         self.dev32 = [None, None]         # bf16 store fed by fp32 host bags: the H2D landing area of one batch (rounded into `dev`)
-        self.copy_stream = torch.cuda.Stream(device=self.device)
+        # ADVMIL_COPY_PRIORITY: stream priority of the copy stream (torch: lower number = higher priority; unset = default). Its launches run
+        # under the step's kernels: with a lower priority they take CU slots only where the compute stream leaves them
+        _pr = os.environ.get("ADVMIL_COPY_PRIORITY")
+        self.copy_stream = torch.cuda.Stream(device=self.device) if _pr is None else torch.cuda.Stream(device=self.device, priority=int(_pr))
         self.host = [None, None]
         self.dev = [None, None]
         self.free_evt = [None, None]      # recorded on the compute stream when the step reading pair k is enqueued
@@ -227,8 +230,11 @@ class SlabStager:
         dst = self.dev[k]
         esz = dst.element_size()
         pl = self.pl[k] if with_planes else None
-        rc = _lib.lib().advmil_stage_bag(
-            dst.data_ptr() + a * C * esz, x2.data_ptr(), n * C * esz,
+        if os.environ.get("ADVMIL_STAGE_ABLATE") == "skip":      # (timing experiment: no staging launch at all -- the slab holds garbage)
+            rc = 0
+        else:
+          rc = _lib.lib().advmil_stage_bag(
+            (x2.data_ptr() if (derive and os.environ.get("ADVMIL_STAGE_ABLATE") == "planes") else dst.data_ptr() + a * C * esz), x2.data_ptr(), n * C * esz,
             None if pl is None else pl.hi.data_ptr() + a * C * 2, None if (pl is None or derive) else planes.hi.data_ptr(),
             None if pl is None else pl.lo.data_ptr() + a * C * 2, None if (pl is None or derive) else planes.lo.data_ptr(),
             0 if pl is None else n * C * 2, self.copy_stream.cuda_stream)
