@@ -65,6 +65,10 @@ def host_copy_rows(dst, src):
         f.result()
 
 
+# cached bags enter the step slab as operand planes only (no copy of their fp32 rows) when the step computes in bf16x3
+PLANES_ONLY_STAGE = os.environ.get("ADVMIL_STAGE_PLANES_ONLY", "1") != "0"
+
+
 class SlabStager:
     """`store`: dtype of the device slab. torch.bfloat16 = the x_storage 'bf16' mode: bags are kept in HBM as ONE bf16 plane (the
     step slab is its own operand plane: ops.is_bf16_slab); fp32 host bags cross PCIe as they are and are rounded once on the copy
@@ -155,6 +159,8 @@ class SlabStager:
         self.views = []
         self._spans = []
         self._keep = []
+        self._stale = []                      # (a, b, cached rows): spans whose fp32 rows were NOT copied (planes-only staging)
+        self.stale = False
         if self.free_evt[self.k] is not None:                    # do not overwrite bags a running step still reads
             self.copy_stream.wait_event(self.free_evt[self.k])
 
@@ -230,14 +236,22 @@ class SlabStager:
         dst = self.dev[k]
         esz = dst.element_size()
         pl = self.pl[k] if with_planes else None
+        # Planes-only staging (bf16x3 arithmetic): every contraction that reads the step slab reads its operand PLANES, so a cached bag's
+        # fp32 rows need not be copied at all -- the launch derives the planes straight from the cache entry (dst == src: no row copy) and
+        # moves 8 instead of 12 bytes per element under the running step. The slab's fp32 rows of such spans are STALE: the batch is
+        # flagged (`stale`, -> `_advmil_fp32_stale` on the step slab, ops.gemm then takes planes only); a batch that ends up without
+        # complete planes or below the handler's plane threshold gets its rows after all (`_backfill`, from `ready`).
+        only = bool(derive and pl is not None and PLANES_ONLY_STAGE)
         if os.environ.get("ADVMIL_STAGE_ABLATE") == "skip":      # (timing experiment: no staging launch at all -- the slab holds garbage)
             rc = 0
         else:
           rc = _lib.lib().advmil_stage_bag(
-            (x2.data_ptr() if (derive and os.environ.get("ADVMIL_STAGE_ABLATE") == "planes") else dst.data_ptr() + a * C * esz), x2.data_ptr(), n * C * esz,
+            (x2.data_ptr() if only else dst.data_ptr() + a * C * esz), x2.data_ptr(), n * C * esz,
             None if pl is None else pl.hi.data_ptr() + a * C * 2, None if (pl is None or derive) else planes.hi.data_ptr(),
             None if pl is None else pl.lo.data_ptr() + a * C * 2, None if (pl is None or derive) else planes.lo.data_ptr(),
             0 if pl is None else n * C * 2, self.copy_stream.cuda_stream)
+        if rc == 0 and only:
+            self._stale.append((a, b, x2))
         if rc != 0:                                   # unaligned rows (channels not a multiple of 8): the general copies
             with torch.cuda.stream(self.copy_stream):
                 dst[a:b].copy_(x2, non_blocking=True)
@@ -282,8 +296,19 @@ class SlabStager:
             return ops.Planes(self.pl[self.k].hi[:n], self.pl[self.k].lo[:n])
         return None
 
-    def ready(self):
-        """Make the compute stream wait for the staged copies; returns the per-bag device views of this batch."""
+    def _backfill(self):
+        """The fp32 rows of the spans staged as planes only, after all (this batch will be read as fp32 rows)."""
+        with torch.cuda.stream(self.copy_stream):
+            for a, b, x2 in self._stale:
+                self.dev[self.k][a:b].copy_(x2, non_blocking=True)
+        self._stale = []
+
+    def ready(self, need_rows=False):
+        """Make the compute stream wait for the staged copies; returns the per-bag device views of this batch. need_rows: the caller will
+        read the fp32 rows (a step batch that is not one zero-copy slab): spans staged as planes only get their rows now."""
+        if self._stale and (need_rows or self.batch_planes() is None or self.rows + self.pad < 4096):
+            self._backfill()                  # (the handler attaches the batch's planes to slabs of >= 4096 rows only)
+        self.stale = bool(self._stale)
         evt = torch.cuda.Event()
         evt.record(self.copy_stream)
         self.h2d_evt[self.k] = evt
@@ -559,6 +584,8 @@ def step_batches(loader, device, nb, cache=None, stager=None, drop_last=False, s
         bpl = own.batch_planes()
         if bpl is not None:
             xs[0][0]._advmil_stager_planes = bpl
+            if own.stale:
+                xs[0][0]._advmil_fp32_stale = True       # cached bags were staged as operand planes only: the slab's fp32 rows are not valid
         return StepBatch(list(pos), list(idxs), list(xs), list(ys), True, pad)
 
     def after():

@@ -273,11 +273,14 @@ class MyHandler(object):
                 if staged:                               # growth may have re-based the views: take the final ones
                     if len(staged_pos) == len(x_col):
                         pad = stager.pad_rows(self.slab_pad)     # whole 256-row tiles for the slab kernels' fast forms
-                    for j, v in zip(staged_pos, stager.ready()):
+                    # (a batch that mixes staged and device bags is concatenated, i.e. read as fp32 rows)
+                    for j, v in zip(staged_pos, stager.ready(need_rows=len(staged_pos) != len(x_col))):
                         x_col[j][0] = v
                     bpl = stager.batch_planes()          # every bag came from the cache with its planes: the slab's planes are ready
                     if bpl is not None and staged_pos:
                         x_col[staged_pos[0]][0]._advmil_stager_planes = bpl
+                        if stager.stale:                 # cached bags staged as operand planes only: the slab's fp32 rows are not valid
+                            x_col[staged_pos[0]][0]._advmil_fp32_stale = True
                 mask = self._get_label_visiable_mask(name_loader, i_col)
                 nz_d = nz_g = None
                 if self.noise_hook is not None:
@@ -477,10 +480,19 @@ class MyHandler(object):
         if ops.is_bf16_slab(X):
             return X                             # x_storage = 'bf16': the slab is its own (single) operand plane, nothing to derive
         spl = getattr(x0, "_advmil_stager_planes", None) if ok else None
+        stale = bool(getattr(x0, "_advmil_fp32_stale", False))
         if (spl is not None and spl.hi.shape[0] == X.shape[0] and X.shape[0] >= 4096 and ops.USE_PLANES and ops.get_gemm_mode() == "bf16x3"
-                and ops.gemm_plan_planes(X.shape[0], 128, c)):
+                and (ops.SLAB_PLANES_ANY or ops.gemm_plan_planes(X.shape[0], 128, c))):
             X._advmil_planes = spl               # assembled by the staging slab from the cached bags' planes (copy stream)
+            if stale:
+                # cached bags were staged as planes only (ingest.SlabStager.add_device): nothing may read this slab's fp32 rows
+                X._advmil_planes = ops.Planes(spl.hi, spl.lo)
+                X._advmil_planes.fp32_stale = True
+                X._advmil_fp32_stale = True
             return X
+        if stale:
+            raise RuntimeError("advmil_amd: a step slab staged as operand planes only cannot be read as fp32 rows (planes missing / not "
+                               "back to back / arithmetic mode changed between staging and the step)")
         pls = None if ok else [getattr(x[0], "_advmil_bag_planes", None) for x in xs]
         if (pls and all(p is not None for p in pls) and X.shape[0] >= 4096 and ops.USE_PLANES and ops.get_gemm_mode() == "bf16x3"
                 and ops.gemm_plan_planes(X.shape[0], 128, c)):

@@ -344,10 +344,13 @@ class Planes:
     """bf16x3 operand image of an fp32 matrix: hi = bf16(x), lo = bf16(x - hi), same shape/strides as x
     (include/advmil_hip.h::advmil_epilogue_t.a_hi..c_lo). A contraction given the planes of an operand skips the per-workgroup
     re-split of that operand; results are bit-identical."""
-    __slots__ = ("hi", "lo")
+    __slots__ = ("hi", "lo", "fp32_stale")
 
     def __init__(self, hi, lo):
         self.hi, self.lo = hi, lo               # lo None: a SINGLE-plane operand -- the tensor is bf16 itself (x_storage = "bf16")
+        # True: the fp32 tensor these planes belong to was never written (a step slab whose cached bags were staged as planes only,
+        # ingest.SlabStager): a contraction given them must read the planes and nothing else
+        self.fp32_stale = False
 
     @property
     def single(self):
@@ -472,13 +475,16 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
             planes_only_a = True
         else:
             _chk(A, "A")
+            if a_planes is not None and a_planes.fp32_stale:
+                planes_only_a = True          # (A's fp32 rows were never written: pointer and pitch only)
     b_single = False
     if is_bf16_slab(B):
         b_planes = b_planes or Planes(B, None)
         b_single = True
     else:
         _chk(B, "B")
-    if (planes_only_a or b_single) and get_gemm_mode() != "bf16x3":
+    b_only = b_single or (b_planes is not None and b_planes.fp32_stale)       # B must be read from its plane(s)
+    if (planes_only_a or b_only) and get_gemm_mode() != "bf16x3":
         raise ValueError("bf16 slabs need gemm_mode 'bf16x3' (ops.as_f32 gives their fp32 image)")
     if (tile == 0 and a_planes is not None and b_planes is not None and (splits is None or splits == 1) and not b_planes.single
             and not ((a_planes.ptrs() | b_planes.ptrs()) & 15)
@@ -560,10 +566,13 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
         ptile, splits = gemm_plan(M, N, K, a_kc, b_kc)
         if tile == 0:
             tile = ptile
-    if b_single and not (91 <= tile <= 93) and tile not in (22, 12, 11) and not (tile in (34, 24) and not a_kc and not b_kc):
-        tile = 22                             # a bf16 B operand has no fp32 image: land on a kernel that stages B from its plane
+    if b_only and not (91 <= tile <= 93) and tile not in (22, 12, 11) and not (tile in (34, 24) and not a_kc and not b_kc):
+        tile = 22                             # a bf16 / planes-only B operand has no fp32 image: land on a kernel that stages B from its plane(s)
     if planes_only_a and a_planes.single and not (82 <= tile <= 86) and tile not in (22, 12, 11):
-        tile = 22
+        tile = 22                             # (single-plane A: only these forms are built for it)
+    if planes_only_a and a_planes.fp32_stale and not (82 <= tile <= 86) and not (91 <= tile <= 93) and tile not in (22, 12, 11) \
+            and not pre_a_tile_ok(tile, a_kc, b_kc, b_planes is not None):
+        tile = 22                             # (a slab staged as planes only: land on a form that stages A from its planes)
     if planes_only_a and not (82 <= tile <= 86) and not (91 <= tile <= 93) and not pre_a_tile_ok(tile if tile else gemm_plan(M, N, K, a_kc, b_kc)[0], a_kc, b_kc,
                                                                      b_planes is not None):       # (82-85: plane-fed, reads planes only)
         raise ValueError(f"gemm(A=None): tile {tile} has no pre-split-A instantiation for this layout")
@@ -1060,7 +1069,7 @@ class LinearActFn(torch.autograd.Function):
                 return None, dW, None, None, None, None, None, None, None, None, None, None
             # slab layer whose input needs no gradient (the first layer): dpre is consumed by the weight-gradient contraction alone,
             # which splits it into hi + lo anyway -> written as planes only, and the contraction takes both operands pre-split
-            xpl0 = ctx.xpl if (DW_PLANES and get_gemm_mode() == "bf16x3") else None
+            xpl0 = ctx.xpl if ((DW_PLANES or (ctx.xpl is not None and ctx.xpl.fp32_stale)) and get_gemm_mode() == "bf16x3") else None
             only = (DG_PLANES_ONLY and need_w and not need_x and xpl0 is not None and M >= 4096 and N % 8 == 0
                     and pre_a_tile_ok(gemm_plan(N, K, M, False, False)[0], False, False, True))
             dpl = Planes.alloc((M, N), dy.device) if only else None
@@ -1074,7 +1083,7 @@ class LinearActFn(torch.autograd.Function):
                 return None, dW, (None if ctx.gb is not None else db), None, None, None, None, None, None, None, None, None
         dW = None
         if need_w:                                           # dpre^T x
-            xpl = ctx.xpl if (DW_PLANES and get_gemm_mode() == "bf16x3") else None
+            xpl = ctx.xpl if ((DW_PLANES or (ctx.xpl is not None and ctx.xpl.fp32_stale)) and get_gemm_mode() == "bf16x3") else None
             if xpl is None and is_bf16_slab(x):
                 x = as_f32(x)
             if ctx.gW is not None:
@@ -1177,7 +1186,10 @@ def linear_act(x, W, b, act="none", p=0.0, rng=None, tag="", emit_planes=False):
     if y0 is not None and p <= 0.0 and emit_planes:
         emit_planes = False                   # the memoized tensor is returned as is: its planes (if any) are already attached
     big = x2.shape[0] >= 4096 and get_gemm_mode() == "bf16x3"
-    if y0 is None and big and gemm_plan_planes(x2.shape[0], W.shape[0], x2.shape[1]):
+    stale = bool(getattr(x2, "_advmil_fp32_stale", False))      # a slab staged as operand planes only: its fp32 rows were never written
+    if stale and (planes_of(x2) is None or get_gemm_mode() != "bf16x3"):
+        raise RuntimeError("advmil_amd: a step slab staged as operand planes only reached a layer without its planes")
+    if (y0 is None and big and gemm_plan_planes(x2.shape[0], W.shape[0], x2.shape[1])) or stale:
         xpl, wpl = planes_of(x2), weight_planes(W)
         if wpl is not None:
             wpl = Planes(wpl.hi.reshape(W.shape[0], -1), wpl.lo.reshape(W.shape[0], -1))

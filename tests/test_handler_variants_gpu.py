@@ -636,3 +636,69 @@ def test_x_storage_bf16_equals_fp32_storage_on_rounded_bags(kind):
             assert torch.equal(wref, w), host
     finally:
         ops.set_gemm_mode(prev)
+
+
+def test_cached_bags_enter_the_step_slab_as_operand_planes_only():
+    """bf16x3: a bag served from the device-resident cache is staged WITHOUT its fp32 rows (ingest.SlabStager.add_device: the launch derives
+    the operand planes straight from the cache entry), the step slab is flagged and every contraction reads planes only. Same numbers,
+    bit for bit, as with the rows copied (ADVMIL_STAGE_PLANES_ONLY=0) -- with the slab's stale fp32 rows poisoned in between, so that any
+    kernel still reading them would show."""
+    from advmil_amd import ingest
+    from advmil_amd.model import MyHandler
+    lens = (2048, 4096, 3056)            # (a step batch of 9200 rows: 16 zero rows of slab pad behind the bags)
+
+    def mk():
+        return [(torch.tensor([[i]], dtype=torch.int), [H.bag(60 + i, 4096)[:, :lens[i % 3]].contiguous(), torch.zeros(1, 1)], H.label(i))
+                for i in range(6)]
+
+    class DS:
+        def __init__(self, items):
+            self.items = items
+
+    class DL:
+        def __init__(self, ds, order):
+            self.dataset, self.order = ds, order
+
+        def __iter__(self):
+            return iter([self.dataset.items[i] for i in self.order])
+
+    def run(planes_only):
+        from advmil_amd import ops
+        old = ingest.PLANES_ONLY_STAGE
+        prev_mode = ops.get_gemm_mode()
+        ingest.PLANES_ONLY_STAGE = planes_only
+        seen = []
+        orig = MyHandler._slab_build_static
+
+        def spy(xs, resident_planes=True, pad=0):
+            X = orig(xs, resident_planes, pad)
+            st = bool(getattr(X, "_advmil_fp32_stale", False))
+            seen.append(st)
+            if st:
+                X.fill_(float("nan"))         # nothing may read these rows (the planes are what the step computes on)
+            return X
+        MyHandler._slab_build_static = staticmethod(spy)
+        try:
+            ingest.device_bag_cache(DEV).clear()
+            h = MyHandler(default_cfg(bp_every_batch=3, gemm_mode="bf16x3"), device=DEV)
+            load_synth(h.netG, "G-abmil:"); load_synth(h.netD, "D-prj:")
+            h.rng.reset(5)
+            ds = DS(mk())
+            h._train_each_epoch(DL(ds, list(range(6))), "train")
+            n1 = len(seen)
+            cl = h._train_each_epoch(DL(ds, [4, 0, 5, 2, 1, 3]), "train")
+            torch.cuda.synchronize()
+            return cl, h.pop_logs(), h.optimizerG.flat_param.clone(), h.optimizerD.flat_param.clone(), seen[:n1], seen[n1:]
+        finally:
+            MyHandler._slab_build_static = staticmethod(orig)
+            ingest.PLANES_ONLY_STAGE = old
+            ops.set_gemm_mode(prev_mode)
+
+    a, b = run(True), run(False)
+    assert not any(a[4]) and all(a[5]) and len(a[5]) > 0          # epoch 1 stages host bags (rows valid), epoch 2 planes only
+    assert not any(b[4]) and not any(b[5])
+    assert torch.equal(a[0]["y_hat"], b[0]["y_hat"]) and torch.equal(a[0]["f_fake"], b[0]["f_fake"])
+    assert torch.isfinite(a[2]).all() and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    for la, lb in zip(a[1], b[1]):
+        for k in la:
+            assert float(la[k]) == float(lb[k]), k

@@ -4,13 +4,14 @@
 # at W = 16 / 8), ESAT 32k, PatchGCN 4096. usage (GPU box): tools/step_profiles.sh [outdir]
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-O=${1:-gpurun_out/steps_r04}
+O=${1:-gpurun_out/steps_r05}
 mkdir -p $O
 run() {  # tag, bench args...
   tag=$1; shift
   timeout 400 rocprofv3 --kernel-trace --output-format csv -d $O/$tag -- python3 bench.py --no-extras --no-roofline --no-cpu-baseline "$@" > $O/$tag.log 2>&1
   f=$(ls -t $O/$tag/*/*_kernel_trace.csv 2>/dev/null | head -1)
-  [ -n "$f" ] && python3 tools/step_profile.py $f 10 70 > $O/step_profile_$tag.txt && head -1 $O/step_profile_$tag.txt
+  [ -n "$f" ] && python3 tools/step_profile.py $f 10 70 > $O/step_profile_$tag.txt && python3 tools/step_timeline.py $f > $O/timeline_$tag.txt && head -1 $O/step_profile_$tag.txt
+  rm -rf $O/$tag
 }
 run abmil --steps 30
 run bp1 --steps 60 --bags 1
