@@ -48,9 +48,16 @@ def get_hop_dims(d, hops):
     return dims
 
 
+LN_RELU_MAX_WIDTH = 512     # advmil_ln_relu_fwd / _bwd (csrc/pool.hip): one row per wave, the row held in registers
+
+
 def make_mlp_layer(dim_in, dim_out, layer_norm=True, dropout=0.25):
     layers = [nn.Linear(dim_in, dim_out), nn.ReLU(inplace=True), nn.Dropout(dropout)]
     if layer_norm:
+        if dim_out > LN_RELU_MAX_WIDTH:
+            # (fail where the model is BUILT, naming the width, not with an EINVAL from the first step)
+            raise ValueError(f"advmil_amd: a LayerNorm MLP layer of width {dim_out} has no HIP path (the LayerNorm -> ReLU row kernel takes "
+                             f"<= {LN_RELU_MAX_WIDTH} columns): lower the hid_dims / pdh_dims entry that asks for it, or set norm: false")
         layers.insert(1, nn.LayerNorm(dim_out))
     return nn.Sequential(*layers)
 

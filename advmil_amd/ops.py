@@ -631,7 +631,20 @@ def gemm_two_layers(x, xpl, W1, w1pl, b1, act1, W2, w2pl, b2, act2, emit_planes1
     The two weight matrices' planes are stacked for the launch (two ~1 MB copies)."""
     M, K = x.shape
     N1, N2 = W1.shape[0], W2.shape[0]
-    wcat = Planes(torch.cat((w1pl.hi.reshape(N1, K), w2pl.hi.reshape(N2, K)), dim=0), torch.cat((w1pl.lo.reshape(N1, K), w2pl.lo.reshape(N2, K)), dim=0))
+
+    def pair(pl, N):
+        """[2, N, K] view over a weight's hi and lo plane when both live in one allocation (the optimizer's plane arena), else None."""
+        hi, lo = pl.hi.reshape(N, K), pl.lo.reshape(N, K)
+        d = (lo.data_ptr() - hi.data_ptr()) // 2
+        if hi.untyped_storage().data_ptr() != lo.untyped_storage().data_ptr() or d <= 0 or not hi.is_contiguous() or not lo.is_contiguous():
+            return None
+        return hi.as_strided((2, N, K), (d, K, 1), hi.storage_offset())
+    v1, v2 = pair(w1pl, N1), pair(w2pl, N2)
+    if v1 is not None and v2 is not None:     # ONE stacking launch for both planes of both layers
+        stk = torch.cat((v1, v2), dim=1)
+        wcat = Planes(stk[0], stk[1])
+    else:
+        wcat = Planes(torch.cat((w1pl.hi.reshape(N1, K), w2pl.hi.reshape(N2, K)), dim=0), torch.cat((w1pl.lo.reshape(N1, K), w2pl.lo.reshape(N2, K)), dim=0))
     dev = x.device
     y1 = torch.empty(M, N1, dtype=torch.float32, device=dev)
     y2 = torch.empty(M, N2, dtype=torch.float32, device=dev)

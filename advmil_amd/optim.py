@@ -61,7 +61,10 @@ class FlatAdam(torch.optim.Optimizer):
 
         # bf16x3 operand planes of the weights (hi = bf16(w), lo = bf16(w - hi)), same layout as the arena: written by the Adam
         # kernel with every update, so no contraction ever re-splits a weight (ops.weight_planes)
-        self.planes = ops.Planes(torch.zeros(total, dtype=torch.bfloat16, device=dev), torch.zeros(total, dtype=torch.bfloat16, device=dev))
+        # (both planes in ONE allocation, lo behind hi: a weight's two planes are then one strided view -- ops.gemm_two_layers stacks the
+        # planes of two layers with one launch)
+        self.planes = ops.Planes.alloc((total,), dev)
+        self.planes.hi.zero_(); self.planes.lo.zero_()
         self._views = []
         with torch.no_grad():
             for (n, p), o in zip(ordered, offs):

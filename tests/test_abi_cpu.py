@@ -107,3 +107,13 @@ def test_product_never_imports_the_oracle():
         for f in files:
             if f.endswith(".py"):
                 assert not pat.search(open(os.path.join(d, f)).read()), os.path.join(d, f)
+
+
+def test_layer_widths_without_a_hip_path_fail_at_model_construction():
+    """A LayerNorm MLP layer wider than the row kernel takes is refused where the model is built, naming the width (it used to surface as an
+    EINVAL from the first training step)."""
+    from advmil_amd.model.model_utils import LN_RELU_MAX_WIDTH, make_mlp_layer
+    make_mlp_layer(64, LN_RELU_MAX_WIDTH, layer_norm=True)
+    with pytest.raises(ValueError, match="no HIP path"):
+        make_mlp_layer(64, LN_RELU_MAX_WIDTH + 64, layer_norm=True)
+    make_mlp_layer(64, LN_RELU_MAX_WIDTH + 64, layer_norm=False)
