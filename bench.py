@@ -928,11 +928,12 @@ def main():
         achieved = flops / us / 1e6
         traffic, traffic_src = None, None
         try:      # PMC passes are separate runs (profiles/README.md); only a measurement of THIS kernel + shape + mode counts
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_gemm.json" if os.path.exists(os.path.join(ROOT, "profiles", "r04_pmc_gemm.json")) else "r03_pmc_gemm.json")))
+            pmc_name = next(n for n in ("r05_pmc_gemm.json", "r04_pmc_gemm.json", "r03_pmc_gemm.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
             ent = pmc.get("planes_kernel_launches" if planes_kernel else "launches", {}).get(f"{M}x{N}x{K}")
             same = ent and (ent.get("kernel", "").startswith(kname.split(",")[0].rstrip(">")) if planes_kernel else ent.get("kernel") == kname)
             if same and ent.get("gemm_mode") == args.gemm_mode and ent.get("hbm_bytes_per_launch"):
-                traffic, traffic_src = ent["hbm_bytes_per_launch"], "profiles/r0x_pmc_gemm.json, latest round (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel + shape)"
+                traffic, traffic_src = ent["hbm_bytes_per_launch"], f"profiles/{pmc_name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel + shape)"
         except Exception:
             pass
         total_gemm_ms = sum(v["ms"] for v in agg.values()) / nprof

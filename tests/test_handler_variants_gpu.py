@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 
 def run_case(kind="abmil", lens=(256, 512, 128, 64), events=None, visible=None, mode="wlabel", steps=2, tol=2e-5,
-             check_weights=True, **cfg_over):
+             check_weights=True, bag_seed0=40, **cfg_over):
     from advmil_amd.model import MyHandler
     nb = len(lens)
     h = MyHandler(default_cfg(bcb_mode=kind, bp_every_batch=nb, **cfg_over), device=DEV)
@@ -29,11 +29,11 @@ def run_case(kind="abmil", lens=(256, 512, 128, 64), events=None, visible=None, 
     for s in range(steps):
         for j, n in enumerate(lens):
             i = s * nb + j
-            x = H.bag(40 + i, max(512, max(lens)))[:, :n].contiguous()
+            x = H.bag(bag_seed0 + i, max(512, max(lens)))[:, :n].contiguous()
             y = H.label(i)
             if events is not None:
                 y[0, 1] = float(events[j])
-            ext = H.T(synth.cluster_ids(0, 40 + i, n)) if kind == "cluster" else None      # DeepAttMISL: a cluster id per patch
+            ext = H.T(synth.cluster_ids(0, bag_seed0 + i, n)) if kind == "cluster" else None      # DeepAttMISL: a cluster id per patch
             bags_all.append((x, ext, y))
             loader.append((torch.tensor([[i]], dtype=torch.int), [x, ext if ext is not None else torch.zeros(1, 1)], y))
     nd = [[H.noise_tensor("var_d", i, 192)] for i in range(steps * nb)]
@@ -138,7 +138,7 @@ def test_d_loss_gradients_before_adam(which, kind, lens, events, visible):
     gradients_before_adam(which, kind, lens, events, visible)
 
 
-def gradients_before_adam(which, kind, lens, events, visible, **cfg_over):
+def gradients_before_adam(which, kind, lens, events, visible, bag_seed0=40, **cfg_over):
     """The hinge / wasserstein D losses (loss/utils.py:182-203) at the contract's tolerance WITHOUT Adam in between: the raw
     gradients of one D backward and one G backward (the arenas the optimizer kernels read) against the oracle's autograd, every
     parameter, 2e-5 of the tensor's gradient scale. (Post-Adam weights of these two losses are round-off noise on both sides:
@@ -157,8 +157,8 @@ def gradients_before_adam(which, kind, lens, events, visible, **cfg_over):
         y = H.label(i)
         if events is not None:
             y[0, 1] = float(events[i])
-        ext = H.T(synth.cluster_ids(0, 40 + i, n)) if kind == "cluster" else None
-        bags.append((H.bag(40 + i, max(512, max(lens)))[:, :n].contiguous(), ext, y))
+        ext = H.T(synth.cluster_ids(0, bag_seed0 + i, n)) if kind == "cluster" else None
+        bags.append((H.bag(bag_seed0 + i, max(512, max(lens)))[:, :n].contiguous(), ext, y))
     xs = [[b[0].to(DEV), b[1].to(DEV) if b[1] is not None else torch.zeros(1, 1, device=DEV)] for b in bags]
     ys_host = [b[2] for b in bags]
     ys = [y.to(DEV) for y in ys_host]

@@ -49,7 +49,14 @@ def test_two_rank_step_equals_single_rank_with_dropout_on(kind, tmp_path):
             # (floor: a parameter whose true gradient is zero -- the pooling scorer's output bias under the softmax -- holds round-off
             # only, which Adam turns into steps of up to lr = 8e-5 per element and optimizer step in either run)
             assert abs(da - db) <= 5e-3 * db + max(5e-5, 2 * 8e-5 * want[tag][k].numel() ** 0.5 if db < 2e-4 else 0.0), (tag, k, da, db)
-            assert float((got[tag][k].double() - want[tag][k].double()).abs().max()) <= 2.5 * 8e-5, (tag, k)
+            # entry by entry: the two runs sum their gradients in different orders (different slabs per rank), so an entry whose gradient is at
+            # round-off level -- or that sits behind a ReLU whose pre-activation is -- takes Adam's +-lr step with either sign in either
+            # run: at most 0.01 % of a tensor's entries beyond one flip (2.5 lr), none beyond the two-step sign-flip bound (the rule of the
+            # oracle comparison, tests/test_handler_variants_gpu.py::run_case; until round 5 EVERY entry had to stay within 2.5 lr, which
+            # tools/probe/dp_fuzz.py's seed 105 showed to be too tight, on the round-4 build as well: profiles/r05_fuzz_found_cases.txt)
+            dw_ = (got[tag][k].double() - want[tag][k].double()).abs()
+            assert int((dw_ > 2.5 * 8e-5).sum()) <= max(1, dw_.numel() // 10000), (tag, k, int((dw_ > 2.5 * 8e-5).sum()))
+            assert float(dw_.max()) <= 2.05 * 8e-5 * 2, (tag, k, float(dw_.max()))
 
 
 _RCCL_PROBE = r"""

@@ -60,6 +60,27 @@ for kind in ("abmil", "patch", "cluster"):
             if nsteps == 1:
                 # which parameters hold the deviating entries
                 hh = a["h"]
+                # float64 pre-activations of the generator's first layer over the first step's rows: entries within fp32 round-off of the
+                # ReLU boundary take either branch depending on the summation order (the pad changes the tiles); the forward does not move
+                # (relu(+-1e-8) = 0 to fp32), the backward's mask does, and with it that unit's whole weight-gradient row
+                first = [(n, p) for n, p in hh.netG.named_parameters() if p.dim() >= 2 and p.shape[1] == 1024][0]      # the layer applied to the slab
+                W0 = first[1].detach()
+                w0g = a["w0"][0]
+                o0 = int((W0.data_ptr() - hh.optimizerG.flat_param.data_ptr()) // 4)
+                Wi = w0g[o0:o0 + W0.numel()].view(W0.shape[0], -1).double()
+                bname = first[0].replace("weight", "bias")
+                bpar = dict(hh.netG.named_parameters())[bname]
+                ob = int((bpar.data_ptr() - hh.optimizerG.flat_param.data_ptr()) // 4)
+                bi = w0g[ob:ob + bpar.numel()].double()
+                rows = torch.cat([H.bag(600 + i, max(lens))[0, :n] for i, n in enumerate(lens[:bp])], dim=0).to(DEV).double()
+                z = rows @ Wi.t() + bi
+                near = (z.abs() < 2e-6).nonzero()
+                print(f"      float64 pre-activations of {first[0]} over the step's {rows.shape[0]} rows: {near.shape[0]} entries within 2e-6 of 0:",
+                      [(int(r), int(c), float(z[r, c])) for r, c in near[:8].tolist()])
+                dW = (a["gG"][o0:o0 + W0.numel()] - b["gG"][o0:o0 + W0.numel()]).view(W0.shape[0], -1).abs().max(dim=1).values
+                top = torch.topk(dW, 4)
+                print("      output units with the largest difference of their weight-gradient row between the two runs:",
+                      [(int(i), f"{float(v):.2e}") for v, i in zip(top.values, top.indices)], f"(median over units {float(dW.median()):.1e})")
                 d = (a["wG"] - b["wG"]).abs()
                 off = 0
                 for name, p in hh.netG.named_parameters():
@@ -69,3 +90,16 @@ for kind in ("abmil", "patch", "cluster"):
                     if frac > 0.001:
                         gsl = b["gG"][o:o + k]
                         print(f"      {name} {tuple(p.shape)}: {frac:.4f} of its entries moved; |grad| median {float(gsl.abs().median()):.2e}, max {float(gsl.abs().max()):.2e}")
+
+        # the same bag geometry (lengths, bag and cluster-id seeds, labels) through the ORACLE comparison of the parity suite
+        # (tests/test_handler_variants_gpu.py::run_case: two optimizer steps, dropout off, injected noise; losses, predictions, scores and
+        # updated weights at the contract's tolerances), with the slab pad and without it
+        from tests.test_handler_variants_gpu import run_case
+        for pad in (256, 0):
+            for part, ll in (("first step's bags", lens[:bp]), ("second step's bags", lens[bp:])):
+                os.environ["ADVMIL_SLAB_PAD"] = str(pad)
+                try:
+                    run_case(kind=kind, lens=tuple(ll), bag_seed0=600)
+                    print(f"   oracle comparison, slab pad {pad}, {part} {ll}: ok", flush=True)
+                except AssertionError as exc:
+                    print(f"   oracle comparison, slab pad {pad}, {part} {ll}: FAIL {str(exc.args[0])[:300]}", flush=True)
