@@ -194,8 +194,15 @@ __device__ __forceinline__ void t3_dw_block(const float* __restrict__ dp, int pn
                                             float* __restrict__ dW, int lane) {
   const int i = lane & 31, hi = lane >> 5;
   f32x16 acc;
+  // the arena's old values are requested FIRST, all sixteen, and added at the end: `dW[..] += acc[r]` register by register is a load -> add ->
+  // store chain per register (the compiler cannot move the later loads across the earlier stores to the same array): sixteen memory round
+  // trips in a kernel whose whole budget is a handful
+  float old[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int r = 0; r < 16; ++r) {
+    acc[r] = 0.f;
+    old[r] = dW[(int64_t)(n0 + (r & 3) + 8 * (r >> 2) + 4 * hi) * K + k0 + i];
+  }
   const float* ap = dp + hi * pn + n0 + i;
   const float* bp = in + hi * pk + k0 + i;
 #pragma unroll
@@ -203,7 +210,7 @@ __device__ __forceinline__ void t3_dw_block(const float* __restrict__ dp, int pn
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-    dW[(int64_t)n * K + k0 + i] += acc[r];
+    dW[(int64_t)n * K + k0 + i] = old[r] + acc[r];
   }
 }
 

@@ -415,6 +415,7 @@ MEMO_PLANES = os.environ.get("ADVMIL_MEMO_PLANES", "1") != "0"
 # deep-K weight gradients (plane-fed TN kernel from K = 8192), the planes-only dpre / dG hand-overs and the dh epilogue fusion then also
 # apply to the 1-4 bag steps of a strong split
 SLAB_PLANES_ANY = os.environ.get("ADVMIL_SLAB_PLANES_ANY", "1") != "0"
+GENERIC_PLANES = os.environ.get("ADVMIL_GENERIC_PLANES", "1") != "0"
 # [B <= 32, d] linear layers on the fp32-FMA kernels (csrc/optim.hip small_linear_*) instead of the 64x64-tile MFMA contraction
 SMALL_LINEAR = os.environ.get("ADVMIL_SMALL_LINEAR", "1") != "0"
 # ... for up to this many rows. In-graph, forward + backward of a [B, 384] -> 384 layer (tools/probe/small_linear_time.py): B = 1-2:
@@ -1202,7 +1203,9 @@ def linear_act(x, W, b, act="none", p=0.0, rng=None, tag="", emit_planes=False):
     stale = bool(getattr(x2, "_advmil_fp32_stale", False))      # a slab staged as operand planes only: its fp32 rows were never written
     if stale and (planes_of(x2) is None or get_gemm_mode() != "bf16x3"):
         raise RuntimeError("advmil_amd: a step slab staged as operand planes only reached a layer without its planes")
-    if (y0 is None and big and gemm_plan_planes(x2.shape[0], W.shape[0], x2.shape[1])) or stale:
+    # (GENERIC_PLANES: a slab layer whose launch stays on the generic kernel still takes pre-split operands when both exist -- the
+    # 64x64 .. 128x128 tiles are built for them: no conversion work in the staging path)
+    if (y0 is None and big and (gemm_plan_planes(x2.shape[0], W.shape[0], x2.shape[1]) or (GENERIC_PLANES and planes_of(x2) is not None))) or stale:
         xpl, wpl = planes_of(x2), weight_planes(W)
         if wpl is not None:
             wpl = Planes(wpl.hi.reshape(W.shape[0], -1), wpl.lo.reshape(W.shape[0], -1))
