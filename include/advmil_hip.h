@@ -325,7 +325,7 @@ int advmil_genconv_bwd(const float* dout, const float* x, const float* agg, cons
  * Optimizer + regulariser over a flat parameter arena (torch.optim.Adam, L2-in-grad weight decay:
  * optim/optim_factory.py:25-37,76-77; model/model_handler.py:104-107; L1: loss/utils.py:6-14).
  *   g = grad*grad_scale + l1_coef*sign(p) + wd[i]*p ; Adam(m, v) ; p -= lr/(1-b1^t) * m/(sqrt(v)/sqrt(1-b2^t)+eps)
- * `step` is a device int32 incremented by the kernel (graph-replay safe). wd may be NULL. p_hi / p_lo (both or neither): bf16 arenas of
+ * `step` is a device int32 incremented by the kernel (graph-replay safe). wd may be NULL. The arenas are 16-byte aligned (planes: 8). p_hi / p_lo (both or neither): bf16 arenas of
  * n elements that receive the bf16x3 operand planes of the UPDATED weights, so the contractions never re-split a weight.
  * abs_sum: out[0] = sum |p| (for the logged Loss_G_total). */
 /* tick != 0: the kernel's own second launch increments `step`; tick = 0: the caller increments it (advmil_step_seed_tick folds that into the
