@@ -396,11 +396,17 @@ class Watchdog:
     def __init__(self, rank, limit=60.0):
         import threading
         self.rank, self.limit, self.last, self.what, self.on = rank, float(limit), time.time(), "start", True
+        # until the graphs are captured a rank is in SETUP: first kernel loads, the resident pool's fill, RCCL's communicator coming up at the
+        # first collective of the warm-up steps (tens of seconds on a fresh 8-GPU node) -- a longer leash there, or a healthy run gets shot
+        self.setup_limit = max(self.limit, float(os.environ.get("ADVMIL_BENCH_SETUP_S", "300")))
+        self.setup = True
         self.th = threading.Thread(target=self._run, daemon=True)
         self.th.start()
 
     def beat(self, what):
         self.last, self.what = time.time(), what
+        if what == "graphs captured":
+            self.setup = False
 
     def stop(self):
         self.on = False
@@ -408,8 +414,9 @@ class Watchdog:
     def _run(self):
         while self.on:
             time.sleep(1.0)
-            if self.on and time.time() - self.last > self.limit:
-                print(f"bench.py watchdog: rank {self.rank} made no progress for {self.limit:.0f} s (last: {self.what}); exiting 3",
+            lim = self.setup_limit if self.setup else self.limit
+            if self.on and time.time() - self.last > lim:
+                print(f"bench.py watchdog: rank {self.rank} made no progress for {lim:.0f} s (last: {self.what}); exiting 3",
                       file=sys.stderr, flush=True)
                 os._exit(3)
 
