@@ -39,7 +39,8 @@ class GraphedStep:
         self.wait_events = []                # (start, stop) event pairs around the two exchange waits of the last segmented replay
         self.captured_collectives = False
         if capture_collectives is None:
-            capture_collectives = os.environ.get("ADVMIL_GRAPH_COLLECTIVES", "0") == "1"
+            # default ON: taken only when the backend is nccl (= RCCL) and every rank agrees (below); ADVMIL_GRAPH_COLLECTIVES=0 keeps the segments
+            capture_collectives = os.environ.get("ADVMIL_GRAPH_COLLECTIVES", "1") != "0"
         dp = handler.dp
         want = bool(capture_collectives and dp.enabled and (dp.world > 1 or getattr(dp, "force", False)) and not force_segments
                     and torch.distributed.get_backend(dp.group) == "nccl")
@@ -115,6 +116,19 @@ class GraphedStep:
         torch.cuda.synchronize()
         del h.history[:]                     # the warm-up steps' own logs are dry runs
         pool = torch.cuda.graph_pool_handle()
+        for opt in (h.optimizerD, h.optimizerG):             # a captured zero_grad() launches no fill: replay() hands the graph clean arenas
+            opt.capture_assumes_clean = CLEAR_IN_ADAM
+        try:
+            self._capture_graphs(pool)
+        finally:
+            for opt in (h.optimizerD, h.optimizerG):
+                opt.capture_assumes_clean = False
+        self.logs = list(h.history)                          # device scalars rewritten by every replay
+        h.history[:] = saved
+        self._st_d, self._st_g = h._st_d, h._st_g            # the statistics tensors this graph writes (reduced between segments)
+
+    def _capture_graphs(self, pool):
+        h = self.h
         if self._want_captured:
             # the exchanges inside the graph: capture on every rank, then agree that it worked everywhere -- else all fall back together
             ok = True
@@ -142,9 +156,6 @@ class GraphedStep:
                 with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                     fn()
                 self.segments.append(g)
-        self.logs = list(h.history)                          # device scalars rewritten by every replay
-        h.history[:] = saved
-        self._st_d, self._st_g = h._st_d, h._st_g            # the statistics tensors this graph writes (reduced between segments)
 
     def replay(self):
         if self._lrs() != self.lrs:                          # lr is a launch constant: re-capture after a scheduler step
@@ -152,16 +163,17 @@ class GraphedStep:
             self._capture(0)
         segs = self.segments
         if CLEAR_IN_ADAM:
-            # the captured step holds no fill launches: it starts from arenas its own Adam launches left clean. Anything else that stepped
-            # in between (an eager step, which keeps its gradients readable) leaves them dirty: clear them here, outside the graph
+            # the captured step holds no fill launches: it starts from arenas its own Adam launches left clean. Anything else that wrote
+            # them in between -- an eager step (which keeps its gradients readable), a kernel handed an arena slot by ops._arena_grad, a
+            # torch-side write to some p.grad (version counter) -- leaves them dirty: clear them here, outside the graph
             for opt in (self.h.optimizerD, self.h.optimizerG):
-                if not getattr(opt, "_grad_clean", False):
+                if not opt.grad_is_clean():
                     opt.flat_grad.zero_()
-                opt._grad_clean = False      # (the replay's backward launches dirty it; its Adam cleans it again: set below)
+                opt.mark_grad_dirty()        # (the replay's backward launches dirty it; its Adam cleans it again: marked below)
         if len(segs) == 1:
             segs[0].replay()
             if CLEAR_IN_ADAM:
-                self.h.optimizerD._grad_clean = self.h.optimizerG._grad_clean = True
+                self.h.optimizerD.mark_grad_clean(); self.h.optimizerG.mark_grad_clean()
             return
         segs[0].replay()
         self.h._st_d, self.h._st_g = self._st_d, self._st_g      # this graph's statistics tensors (another group may have run since)
@@ -184,7 +196,7 @@ class GraphedStep:
             self.wait_events = [(ev[0], ev[1]), (ev[2], ev[3])]
         segs[3].replay()
         if CLEAR_IN_ADAM:
-            self.h.optimizerD._grad_clean = self.h.optimizerG._grad_clean = True
+            self.h.optimizerD.mark_grad_clean(); self.h.optimizerG.mark_grad_clean()
 
     stamp_waits = False
 

@@ -306,8 +306,10 @@ class SlabStager:
     def ready(self, need_rows=False):
         """Make the compute stream wait for the staged copies; returns the per-bag device views of this batch. need_rows: the caller will
         read the fp32 rows (a step batch that is not one zero-copy slab): spans staged as planes only get their rows now."""
-        if self._stale and (need_rows or self.batch_planes() is None or self.rows + self.pad < 4096):
-            self._backfill()                  # (the handler attaches the batch's planes to slabs of >= 4096 rows only)
+        if self._stale:
+            from . import ops                 # (the handler attaches the batch's planes under exactly this rule: one predicate for both)
+            if need_rows or self.batch_planes() is None or not ops.slab_takes_planes(self.rows + self.pad, self.dev[self.k].shape[1]):
+                self._backfill()
         self.stale = bool(self._stale)
         evt = torch.cuda.Event()
         evt.record(self.copy_stream)

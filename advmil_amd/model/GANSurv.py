@@ -100,12 +100,19 @@ class Generator(nn.Module):
         if not ops.ghead_ok(feats, probe):
             return None
         rng = _rng_of(self, feats)
+        # the fused kernels take ONE row map for all their draws: every active site's map must be the same object (looked up BEFORE any site
+        # is drawn, so that a mismatch can still fall back to the layer-by-layer path, which draws the sites itself)
+        tags = ((["abmil_rho"] if p1 > 0.0 else []) + (["gen_mlp0.2"] if p2 > 0.0 else []) + (["noise"] if mode == 3 else []))
+        ok, rr = _one_row_map(rng, B, tags)
+        if not ok:
+            return None
+        probe.rr = rr
         if p1 > 0.0:
-            probe.sid1, probe.seed, probe.rr = rng.site("abmil_rho", (B, rho[0].out_features), p1), rng.seed, rng.row_map(B, "abmil_rho")
+            probe.sid1, probe.seed = rng.site("abmil_rho", (B, rho[0].out_features), p1), rng.seed
         if p2 > 0.0:
-            probe.sid2, probe.seed, probe.rr = rng.site("gen_mlp0.2", (B, d2), p2), rng.seed, rng.row_map(B, "gen_mlp0.2")
+            probe.sid2, probe.seed = rng.site("gen_mlp0.2", (B, d2), p2), rng.seed
         if mode == 3:
-            probe.sid_noise, probe.seed, probe.rr = rng.site("noise", (B * d2,), None), rng.seed, rng.row_map(B, "noise")
+            probe.sid_noise, probe.seed = rng.site("noise", (B * d2,), None), rng.seed
         return probe
 
     def finish(self, feats, zero_noise=False, noise=None, pred_out=None):
@@ -120,6 +127,20 @@ class Generator(nn.Module):
 
     def forward(self, x, x_ext, zero_noise=False, noise=None):
         return self.finish(self.features(x, x_ext), zero_noise, noise)
+
+
+def _one_row_map(rng, n_rows, tags):
+    """(True, the row map shared by the call sites `tags` for a tensor of n_rows rows) -- or (False, None) when two of them resolve to
+    different maps (ops.SITE_LAYOUTS): a fused kernel that draws several sites from one map would then differ from the layer-by-layer
+    and the single-process draws without any error."""
+    rr, first = None, True
+    for t in tags:
+        m = rng.row_map(n_rows, t)
+        if first:
+            rr, first = m, False
+        elif m is not rr:                    # (identity, not torch.equal: no device sync inside a step that may be under graph capture)
+            return False, None
+    return True, rr
 
 
 class _PairNet(nn.Module):
@@ -260,14 +281,16 @@ class PrjDiscriminator(_PairNet):
         probe = ops.TailSpec(*[[(m.weight, m.bias, act, p, 0) for (m, act, p, _) in layers] for layers in chains], prj_w, prj_b, prj_src, None, None)
         if not ops.dtail_ok(B, probe):       # (decided BEFORE any call site is drawn: the layer-by-layer path draws its own)
             return None
-        spec_l, seed, rr = [], None, None
+        ok, rr = _one_row_map(rng, B, [ptag for layers in chains for (_, _, p, ptag) in layers if p > 0.0])
+        if not ok:                           # (sites whose maps differ: the layer-by-layer path, one map per site)
+            return None
+        spec_l, seed = [], None
         for layers in chains:
             out = []
             for (m, act, p, ptag) in layers:
                 sid = 0
                 if p > 0.0:
                     sid, seed = rng.site(ptag, (B, m.out_features), p), rng.seed
-                    rr = rng.row_map(B, ptag)
                 out.append((m.weight, m.bias, act, p, sid))
             spec_l.append(out)
         return ops.TailSpec(spec_l[0], spec_l[1], prj_w, prj_b, prj_src, seed, rr)

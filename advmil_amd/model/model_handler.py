@@ -481,8 +481,7 @@ class MyHandler(object):
             return X                             # x_storage = 'bf16': the slab is its own (single) operand plane, nothing to derive
         spl = getattr(x0, "_advmil_stager_planes", None) if ok else None
         stale = bool(getattr(x0, "_advmil_fp32_stale", False))
-        if (spl is not None and spl.hi.shape[0] == X.shape[0] and X.shape[0] >= 4096 and ops.USE_PLANES and ops.get_gemm_mode() == "bf16x3"
-                and (ops.SLAB_PLANES_ANY or ops.gemm_plan_planes(X.shape[0], 128, c))):
+        if spl is not None and spl.hi.shape[0] == X.shape[0] and ops.slab_takes_planes(X.shape[0], c):
             X._advmil_planes = spl               # assembled by the staging slab from the cached bags' planes (copy stream)
             if stale:
                 # cached bags were staged as planes only (ingest.SlabStager.add_device): nothing may read this slab's fp32 rows

@@ -423,6 +423,13 @@ SMALL_LINEAR = os.environ.get("ADVMIL_SMALL_LINEAR", "1") != "0"
 SMALL_LINEAR_ROWS = int(os.environ.get("ADVMIL_SMALL_LINEAR_ROWS", "8"))
 
 
+def slab_takes_planes(rows, C):
+    """Will a step slab of `rows` x C fp32 rows be read through its operand planes (so that staging may skip its fp32 rows)? The ONE
+    rule of ingest.SlabStager.ready() -- which back-fills the fp32 rows when it says no -- and MyHandler._slab_build_static, which
+    attaches the planes when it says yes."""
+    return bool(rows >= 4096 and USE_PLANES and get_gemm_mode() == "bf16x3" and (SLAB_PLANES_ANY or gemm_plan_planes(rows, 128, C)))
+
+
 def planes_of(x):
     """Planes of an activation / slab tensor, or None. A bf16 slab is its own (single) plane."""
     if is_bf16_slab(x):
@@ -909,6 +916,9 @@ def _arena_grad(p):
     one accumulate launch per parameter per bag."""
     g = getattr(p, "_arena_grad", None) if p is not None else None
     if g is not None and FUSED_WGRAD and p.requires_grad:
+        o = getattr(p, "_arena_owner", None)
+        if o is not None and o._grad_clean and not torch.cuda.is_current_stream_capturing():
+            o._grad_clean = False            # a kernel is about to add into the arena: it is no longer known to be all zero (optim.FlatAdam)
         return g
     return None
 

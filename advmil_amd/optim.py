@@ -73,6 +73,7 @@ class FlatAdam(torch.optim.Optimizer):
                 p.data = self.flat_param[o:o + k].view(p.shape)
                 p.grad = self.flat_grad[o:o + k].view(p.shape)
                 p._arena_grad = p.grad                     # backward kernels accumulate here directly (ops._arena_grad)
+                p._arena_owner = self                      # ... and tell this optimizer that its arena is being written (grad_is_clean)
                 self._views.append((p, o, k))
             for g in self.param_groups:
                 for p in g["params"]:
@@ -90,11 +91,35 @@ class FlatAdam(torch.optim.Optimizer):
         for p, o, k in self._views:
             p._advmil_planes = (self, p._version, ops.Planes(self.planes.hi[o:o + k].view(p.shape), self.planes.lo[o:o + k].view(p.shape)))
 
+    # ---- "is the gradient arena known to be all zero?" A step(clear_grad=True) zeroes the arena behind its read, so the zero_grad()
+    # that follows has nothing to fill. The knowledge is HOST state about DEVICE memory, so every writer must be seen:
+    #   * kernels that accumulate into arena slots get them from ops._arena_grad, which calls mark_grad_dirty();
+    #   * torch-side writes (autograd's AccumulateGrad, p.grad.add_(), ...) move flat_grad's version counter (views share it);
+    #   * nothing is recorded while a stream is being CAPTURED (no kernel runs then): a captured step's zero_grad() launches no fill
+    #     when the capturer said the graph starts from a clean arena (`capture_assumes_clean`, set by graphed.GraphedStep, whose
+    #     replay() makes that true), and the flag is set again by replay() -- never by the captured calls themselves.
+    _grad_clean = False
+    _clean_version = -1
+    capture_assumes_clean = False
+
+    def mark_grad_dirty(self):
+        self._grad_clean = False
+
+    def mark_grad_clean(self):
+        self._grad_clean, self._clean_version = True, self.flat_grad._version
+
+    def grad_is_clean(self):
+        return bool(self._grad_clean and self.flat_grad._version == self._clean_version)
+
     def zero_grad(self, set_to_none: bool = False):
-        if getattr(self, "_grad_clean", False):
+        if torch.cuda.is_current_stream_capturing():
+            if not self.capture_assumes_clean:
+                self.flat_grad.zero_()
+        elif self.grad_is_clean():
             self._grad_clean = False         # the last step cleared the arena behind its read (step(clear_grad=True)): nothing to fill
         else:
             self.flat_grad.zero_()
+            self._grad_clean = False
         for p, o, k in self._views:          # re-attach if someone replaced .grad
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
                 p.grad = self.flat_grad[o:o + k].view(p.shape)
@@ -112,7 +137,11 @@ class FlatAdam(torch.optim.Optimizer):
         ops.adam_step(self.flat_param, self.flat_grad, self.flat_m, self.flat_v, self.flat_wd if self._has_wd else None,
                       self.step_t, g0["lr"], b1, b2, g0["eps"], grad_scale, self.l1_coef, planes=self.planes, tick=tick,
                       abs_partial=abs_partial, clear_grad=clear_grad)
-        self._grad_clean = bool(clear_grad)
+        if not torch.cuda.is_current_stream_capturing():
+            if clear_grad:
+                self.mark_grad_clean()
+            else:
+                self._grad_clean = False
 
     def state_dict(self):
         n = float(self.step_t.item())

@@ -403,10 +403,12 @@ class Watchdog:
         self.th = threading.Thread(target=self._run, daemon=True)
         self.th.start()
 
-    def beat(self, what):
+    def beat(self, what, setup=None):
+        """setup = True / False switches the leash: every Case construction (pool fill, warm-up steps with collectives, graph capture)
+        and every rank-0-only section that the other ranks sit out in a barrier is SETUP; the timed legs are not."""
         self.last, self.what = time.time(), what
-        if what == "graphs captured":
-            self.setup = False
+        if setup is not None:
+            self.setup = bool(setup)
 
     def stop(self):
         self.on = False
@@ -424,9 +426,9 @@ class Watchdog:
 WATCHDOG = None
 
 
-def beat(what):
+def beat(what, setup=None):
     if WATCHDOG is not None:
-        WATCHDOG.beat(what)
+        WATCHDOG.beat(what, setup)
 
 
 def self_launch(args):
@@ -800,7 +802,7 @@ def main():
                 "note": "event-stamped waits of the 4-segment replay, max over ranks"}
 
     case = Case(torch, dev, args.mode, args.patches, args.bags, args.pool, args.gemm_mode, 1234 + rank, args.eager, world)
-    beat("graphs captured")
+    beat("graphs captured", setup=False)
     if world > 1 and os.environ.get("ADVMIL_BENCH_TEST_STALL") == str(rank):      # self-test of the watchdog: this rank stops making progress
         time.sleep(1e6)
     ok = torch.tensor([1.0 if (case.graphs or args.eager) else 0.0], device=dev)
@@ -828,11 +830,13 @@ def main():
     if world > 1 and not args.no_strong:
         if GLOBAL_STEP % world == 0:
             per = GLOBAL_STEP // world
+            beat("strong leg: building the case", setup=True)      # a second pool fill + warm-up with collectives + capture: setup again
             cs = Case(torch, dev, args.mode, args.patches, per, max(per, min(args.pool, 8 * per)), args.gemm_mode, 99 + rank, args.eager, world)
             oks = torch.tensor([1.0 if (cs.graphs or args.eager) else 0.0], device=dev)
             dist.all_reduce(oks, op=dist.ReduceOp.MIN)
             if float(oks.item()) == 0.0:
                 cs.graphs = []
+            beat("strong leg: graphs captured", setup=False)
             dts, _ = cs.timed(args.steps, args.warmup, barrier)
             strong_ranks = [round(1e3 * v / args.steps, 4) for v in per_rank(dts)]
             ts = torch.tensor([dts], dtype=torch.float64, device=dev)
@@ -855,6 +859,9 @@ def main():
     # replicas must hold bit-identical weights after the timed steps (same reduced gradients, same Adam)
     in_sync = True
     if world > 1:
+        # everything from here to the final barrier is untimed bookkeeping: the instrumented eager pass on every rank, then rank 0's own
+        # roofline / cpu_baseline / extras legs (minutes) while the other ranks wait in the barrier -> the long leash again
+        beat("timed legs done: roofline + extras", setup=True)
         cs = torch.stack([h.optimizerG.flat_param.double().sum(), h.optimizerD.flat_param.double().sum()])
         hi, lo = cs.clone(), cs.clone()
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
@@ -881,6 +888,7 @@ def main():
         torch.cuda.synchronize()
         h.overlap_gfwd = ov
         h.history.clear()
+        beat("instrumented eager pass done")
     if rank == 0 and not args.no_roofline:
         prof, ops.KERNEL_PROFILE = ops.KERNEL_PROFILE, None
         agg = {}
@@ -968,6 +976,7 @@ def main():
         del A, B, out
 
     roof = gemm_roof
+    beat("gemm roofline done")
     if rank == 0 and not args.no_roofline and args.mode == "patch":
         try:
             roof = attention_roofline(torch, ops, dev, args.patches // 16, args.bags, in_step=ist_all)
@@ -978,6 +987,7 @@ def main():
     # weighted row sum + merge over the hidden rows h[sum N, 384]; algorithmic bytes = h read once + scores read twice + attention
     # weights written once; at the step slab and at one bag (bp_every_batch = 1).
     pool_roof = None
+    beat("attention roofline done")
     if rank == 0 and not args.no_roofline and args.mode == "abmil":
         try:
             pool_roof = pool_roofline(torch, ops, dev, args.patches, args.bags)
@@ -1113,6 +1123,7 @@ def main():
             torch.cuda.synchronize()
 
     cpu = None
+    beat("extras done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only; at N > 1 the other ranks would idle in the barrier
         cpu = cpu_baseline(args, torch)
 
@@ -1143,7 +1154,9 @@ def main():
         }
         print(json.dumps(out), flush=True)
     if world > 1:
-        beat("result printed")
+        beat("result printed", setup=True)
+        if rank != 0 and WATCHDOG is not None:
+            WATCHDOG.stop()                # rank 0's untimed legs can outlast any leash: the launcher's ADVMIL_BENCH_TIMEOUT covers the wait
         dist.barrier()
         if WATCHDOG is not None:
             WATCHDOG.stop()

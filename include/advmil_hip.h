@@ -61,7 +61,9 @@ typedef struct {
   const float* maskref;
   int ldmask;
   float mask_scale;
-  int accumulate;
+  int accumulate;    /* C += v. With splits > 1 (and advmil_merge_partials): while the launch stream is in DEFERRAL (advmil_defer_sums below -- opt-in
+                      * per stream, never on by default) the `C += partials` fold is queued until the flush, so C must not be read or written by
+                      * another launch before advmil_flush_sums / advmil_defer_sums(stream, 0); outside deferral the fold is issued at once. */
   float alpha;
   /* bf16x3 operand planes (all optional, ignored in exact mode). An fp32 matrix x can be accompanied by two bf16 matrices
    * hi = bf16(x), lo = bf16(x - hi) of the SAME shape and leading dimension (advmil_split_planes; the Adam kernel emits them

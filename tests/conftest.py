@@ -10,9 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
-    # The suite's default arithmetic is the exact fp32 mode (tests that cover bf16x3 select it themselves, and put it back): an
-    # inherited ADVMIL_GEMM_MODE=bf16x3 would run the 2e-6 "same result on two paths" comparisons at 2^-17 per product.
-    os.environ.pop("ADVMIL_GEMM_MODE", None)
+    config.addinivalue_line("markers", "xbf16_contract: x_storage='bf16' case asserted at the 1e-4 contract (tests/test_parity_gpu.py)")
+    config.addinivalue_line("markers", "xbf16_same_inputs: x_storage='bf16' case against the oracle on the same rounded bags (TOL)")
+    # The SUITE's default arithmetic is the exact fp32 mode (tests that cover bf16x3 select it themselves, and put it back): the
+    # library's own default is bf16x3 (advmil_amd/_lib.py), which would run the 2e-6 "same result on two paths" comparisons at
+    # 2^-17 per product. Child processes of the suite (two-rank workers, fuzzers) inherit the setting.
+    os.environ["ADVMIL_GEMM_MODE"] = "exact"
 
 
 @pytest.fixture(scope="session")

@@ -19,6 +19,12 @@ LENS_COLLIDE = (32, 32, 32, 32, 32, 32, 32, 32)
 LENS_PAD = (2064, 2208, 2576, 2128, 2320, 2096, 2704, 2240)
 
 
+# `bp16`: the shipped step batch (cfg_nlst.yaml:71: bp_every_batch = 16) -- 2 steps x 16 ragged bags, for the W = 4 / W = 8 cases (4 / 2
+# bags per rank and step: the split SURVEY section 8e prescribes for the 8-GPU node)
+LENS_BP16 = (256, 128, 64, 192, 320, 96, 160, 224, 48, 272, 112, 208, 80, 304, 144, 176,
+             240, 32, 288, 128, 64, 336, 96, 192, 160, 16, 224, 256, 112, 80, 208, 144)
+
+
 def build_loader(kind, idxs, lens=LENS):
     from types import SimpleNamespace
     from advmil_amd import synth
@@ -40,14 +46,16 @@ def run(kind, world, rank, dp=None, device="cuda:0"):
     from advmil_amd.config import default_cfg
     from advmil_amd.model import MyHandler
     from tests import helpers as H
-    lens = LENS
-    if kind.endswith("-collide"):
+    lens, bp = LENS, 4
+    if kind.endswith("-bp16"):
+        kind, lens, bp = kind[:-len("-bp16")], LENS_BP16, 16
+    elif kind.endswith("-collide"):
         kind, lens = kind[:-len("-collide")], LENS_COLLIDE
     elif kind.endswith("-pad"):
         kind, lens = kind[:-len("-pad")], LENS_PAD
     elif kind.endswith("-env"):                      # tools/probe/dp_fuzz.py: eight bag lengths from the environment
         kind, lens = kind[:-len("-env")], tuple(int(v) for v in os.environ["DP_LENS"].split(","))
-    cfg = default_cfg(bcb_mode=kind, bp_every_batch=4)         # the GLOBAL step batch: every rank steps after 4 / world of its bags
+    cfg = default_cfg(bcb_mode=kind, bp_every_batch=bp)        # the GLOBAL step batch: every rank steps after bp / world of its bags
     if kind == "graph":
         cfg.update(bcb_dims="1024-128-128", gen_dims="128-1")
     h = MyHandler(cfg, device=device, parallel=dp)
@@ -56,7 +64,7 @@ def run(kind, world, rank, dp=None, device="cuda:0"):
         net.load_state_dict(sd, strict=True)
     h.rng.reset(4321)
     from advmil_amd.parallel import BagParallel
-    idxs = (dp or BagParallel()).shard_epoch(list(range(len(lens))), 4)     # bag i of a global step batch -> rank i mod W
+    idxs = (dp or BagParallel()).shard_epoch(list(range(len(lens))), bp)    # bag i of a global step batch -> rank i mod W
     cl = h._train_each_epoch(build_loader(kind, idxs, lens), "train", "wlabel")
     logs = h.pop_logs()
     return {"cl": cl, "logs": logs, "G": {k: v.detach().cpu() for k, v in h.netG.state_dict().items()},

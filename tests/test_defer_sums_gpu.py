@@ -86,3 +86,29 @@ def test_split_k_weight_gradient_goes_through_the_queue():
         assert float((o1.double() - ref).abs().max()) < 2e-2
     finally:
         ops.set_gemm_mode(prev)
+
+
+def test_a_reader_inside_the_deferral_flushes_first():
+    """The C-ABI contract of `accumulate` under deferral (advmil_hip.h): an accumulating split-K fold into ANY buffer (here not an arena
+    slot) is postponed until the flush, so a caller that wants to read the destination before the deferral ends calls
+    advmil_flush_sums -- after which it holds exactly what the undeferred call gives, and the queue is empty."""
+    prev = ops.get_gemm_mode()
+    ops.set_gemm_mode("bf16x3")
+    try:
+        M, N, K = 128, 64, 16384
+        a = torch.randn(K, M, device=DEV)
+        b = torch.randn(K, N, device=DEV)
+        base = torch.randn(M, N, device=DEV)
+        o1, o2 = base.clone(), base.clone()
+        ops.gemm(a, b, False, False, M, N, K, out=o1, ldc=N, accumulate=True)
+        L, s = _lib.lib(), ops._stream()
+        with ops.deferred_sums():
+            ops.gemm(a, b, False, False, M, N, K, out=o2, ldc=N, accumulate=True)
+            assert L.advmil_pending_sums(s) == 1 and torch.equal(o2, base)
+            _lib.check(L.advmil_flush_sums(s), "flush_sums")
+            assert L.advmil_pending_sums(s) == 0
+            doubled = o2 * 2.0                                   # a reader on the same stream, behind the flush
+            assert torch.equal(o2, o1) and torch.equal(doubled, o1 * 2.0)
+        assert torch.equal(o2, o1)
+    finally:
+        ops.set_gemm_mode(prev)

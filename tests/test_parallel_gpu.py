@@ -1,4 +1,4 @@
-"""GPU: the PRODUCT handler under bag-parallel (two ranks sharing the one GPU over gloo) against the single-process run over the same
+"""GPU: the PRODUCT handler under bag-parallel (2 / 4 / 8 ranks sharing the one GPU over gloo) against the single-process run over the same
 global step batches, with the SHIPPED DROPOUT RATES ON. World-size invariance (reference semantics
 model_handler.py:333-339, 412, 472-478): same dropout masks / generator noise per bag (ops.DeviceRng.rows, parallel.rng_row_maps),
 global denominators, summed gradients, all-reduced logs, all-gathered epoch collector."""
@@ -14,17 +14,27 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.timeout(600)
-@pytest.mark.parametrize("kind", ["abmil", "patch", "cluster", "graph", "abmil-collide", "patch-collide", "abmil-pad", "patch-pad", "cluster-pad"])
-def test_two_rank_step_equals_single_rank_with_dropout_on(kind, tmp_path):
+_CASES = [(k, 2) for k in ("abmil", "patch", "cluster", "graph", "abmil-collide", "patch-collide", "abmil-pad", "patch-pad", "cluster-pad")]
+# the shipped step batch of 16 bags split over 4 and 8 ranks (4 / 2 bags per rank): the row maps of every fused kernel above W = 2
+_CASES += [("abmil-bp16", 4), ("abmil-bp16", 8), ("patch-bp16", 4), ("patch-bp16", 8), ("cluster-bp16", 8)]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("kind,world", _CASES, ids=[f"{k}-w{w}" for k, w in _CASES])
+def test_multi_rank_step_equals_single_rank_with_dropout_on(kind, world, tmp_path):
     from tests import dp_worker
     want = dp_worker.run(kind, 1, 0)
     out = str(tmp_path / "r0.pt")
     port = str(29700 + os.getpid() % 1500)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, "-m", "tests.dp_worker", str(r), "2", port, out, kind], cwd=ROOT, env=env) for r in range(2)]
-    for p in procs:
-        assert p.wait(timeout=500) == 0
+    procs = [subprocess.Popen([sys.executable, "-m", "tests.dp_worker", str(r), str(world), port, out, kind], cwd=ROOT, env=env) for r in range(world)]
+    try:
+        for p in procs:
+            assert p.wait(timeout=800) == 0
+    finally:
+        for p in procs:                       # a failed rank must not leave its peers waiting in a collective
+            if p.poll() is None:
+                p.kill()
     got = torch.load(out, weights_only=False)
     # epoch collector in global bag order
     for k in ("y", "y_hat", "f_fake"):

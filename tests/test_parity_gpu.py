@@ -22,6 +22,7 @@ CONTRACT_TOL = 1e-4
 # the x_storage = 'bf16' fixture (below) runs the same checks at the CONTRACT tolerance: every bound is scaled by RELAX[0] and the
 # largest deviation it sees is recorded in SEEN
 RELAX = [1.0]
+AUX = [1.0]          # ... and the bounds of quantities outside the contract (relative attention-weight error, norms of weight deltas / gradients)
 SEEN = [0.0]
 
 
@@ -91,12 +92,12 @@ def test_G1_eval_forward_vs_reference(golden, kind, N):
     if N <= 1024:
         close(A, golden[key + "_A"], 1e-6)
         ref = torch.as_tensor(golden[key + "_A"]).double()
-        assert float(((A.cpu().double() - ref).abs() / ref).max()) < 1e-3 * RELAX[0]      # relative, weights are ~1/N
+        assert float(((A.cpu().double() - ref).abs() / ref).max()) < 1e-3 * AUX[0]      # relative, weights are ~1/N
     else:
         close(A[::32], golden[key + "_A_strided"], 1e-6)
     st = golden[key + "_Astat"]
     assert abs(float(A.double().sum()) - st[0]) < 1e-5 and int(A.argmax()) == int(st[2])
-    assert abs(float(A.max()) - st[1]) < 1e-6 * RELAX[0]
+    assert abs(float(A.max()) - st[1]) < 1e-6 * AUX[0]
 
 
 @pytest.mark.parametrize("kind", ["abmil", "patch"])
@@ -163,13 +164,13 @@ def test_G4_two_optimizer_steps_vs_reference(golden, kind):
         keys = [str(k) for k in golden[f"G4_{kind}_keys{tag}"]]
         dn = np.array([float((sd[k].double() - P0[k].double()).norm()) for k in keys])
         ref_dn = golden[f"G4_{kind}_d{tag}_stats"][:, 1]
-        assert np.all(np.abs(dn - ref_dn) <= (5e-3 * ref_dn + 5e-5) * RELAX[0]), float(np.abs(dn - ref_dn).max())   # Adam's m/sqrt(v) amplifies ulp noise where g ~ 0
+        assert np.all(np.abs(dn - ref_dn) <= (5e-3 * ref_dn + 5e-5) * AUX[0]), float(np.abs(dn - ref_dn).max())   # Adam's m/sqrt(v) amplifies ulp noise where g ~ 0
     # second-step generator gradients still sit in the arena. The reference's .grad includes the L1 term
     # (coef*sign(W), loss/utils.py:13); here that sub-gradient is applied inside the fused Adam kernel, so add it back.
     gk = [str(k) for k in golden[f"G4_{kind}_gradG2_keys"]]
     named = dict(h.netG.named_parameters())
     gn = np.array([float((named[k].grad.double() + 1e-5 * torch.sign(named[k].detach().double())).norm()) for k in gk])
-    assert np.allclose(gn, golden[f"G4_{kind}_gradG2_norm"], rtol=5e-3 * RELAX[0], atol=5e-6 * RELAX[0]), np.abs(gn - golden[f"G4_{kind}_gradG2_norm"]).max()
+    assert np.allclose(gn, golden[f"G4_{kind}_gradG2_norm"], rtol=5e-3 * AUX[0], atol=5e-6 * AUX[0]), np.abs(gn - golden[f"G4_{kind}_gradG2_norm"]).max()
 
 
 @pytest.mark.parametrize("kind", ["abmil", "patch", "cluster"])
@@ -321,6 +322,44 @@ def test_graphed_step_equals_eager_step():
             assert float((a - b).abs().max()) < 1e-6, mode
 
 
+@pytest.mark.parametrize("writer", ["torch", "kernel"])
+def test_replay_after_a_foreign_write_to_the_gradient_arena(writer):
+    """The captured step holds no gradient-arena fills (its Adam launches clear the arena behind their read), so replay() must notice
+    ANY write that happened since the last replay: a torch-side write to some p.grad (autograd's AccumulateGrad, here an in-place add:
+    the arena's version counter moves) and a kernel that was handed an arena slot by ops._arena_grad (here a product backward that
+    nobody followed with an optimizer step). Replay, foreign write, replay == replay, replay."""
+    from advmil_amd import ops
+    from advmil_amd.graphed import GraphedStep
+    res = {}
+    for dirty in (False, True):
+        h, _, _ = make_handler("abmil", bp_every_batch=2)
+        zero_dropout(h.netG); zero_dropout(h.netD)
+        xs = [[H.bag(i, 512, DEV), torch.zeros(1, 1, device=DEV)] for i in range(2)]
+        ys_host = [H.label(i) for i in range(2)]
+        ys = [y.to(DEV) for y in ys_host]
+        h.noise_hook = lambda ph, j: [H.noise_tensor(f"fw{ph}", j, 192, DEV)]
+        g = GraphedStep(h, xs, ys, ys_host, warmup=1)
+        g.replay()
+        if dirty:
+            assert h.optimizerG.grad_is_clean() and h.optimizerD.grad_is_clean()
+            if writer == "torch":
+                h.netG.backbone.attention_net[0].weight.grad.add_(3.0)
+                next(iter(h.netD.parameters())).grad.add_(-2.0)
+            else:
+                fc = h.netG.backbone.attention_net[0]
+                with ops.deferred_sums():
+                    out = ops.linear_act(xs[0][0][0], fc.weight, fc.bias, "relu")
+                    out.sum().backward()                       # the FC's backward kernels add dW / db straight into G's arena
+                next(iter(h.netD.parameters())).grad.add_(-2.0)
+            assert not h.optimizerG.grad_is_clean() and not h.optimizerD.grad_is_clean()
+        g.replay()
+        torch.cuda.synchronize()
+        assert h.optimizerG.grad_is_clean() and h.optimizerD.grad_is_clean()
+        res[dirty] = (h.optimizerG.flat_param.clone(), h.optimizerD.flat_param.clone())
+    for a, b in zip(res[False], res[True]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("p_on", [False, True])
 def test_patchgcn_vs_oracle(p_on):
     """PatchGCN (GENConv softmax gather, HIP) against the oracle's restatement on a synthetic 8-NN grid graph --
@@ -437,10 +476,13 @@ def test_G1_patch_32768_eval_forward_vs_reference(golden2):
     close(H_, golden2["G1_patch_32768_H"])
     close(A, golden2["G1_patch_32768_A"], 1e-6)
     ref = torch.as_tensor(golden2["G1_patch_32768_A"]).double()
-    assert float(((A.cpu().double() - ref).abs() / ref).max()) < 2e-3 * RELAX[0]          # relative: the weights are ~1/2048
+    assert float(((A.cpu().double() - ref).abs() / ref).max()) < 2e-3 * AUX[0]          # relative: the weights are ~1/2048
     # the transformer layer's output itself: LayerNorm outputs of magnitude ~4, so 5e-5 absolute is ~1e-5 relative (bf16x3 mode
     # measures 2.6e-5 here; y, H and A above are the contract's quantities and stay inside TOL)
-    close(enc[::64], golden2["G1_patch_32768_enc_strided"], 5e-5 if RELAX[0] == 1.0 else 1e-4)      # (x_storage = 'bf16': 4.2e-3 measured, held to 5e-3)
+    if RELAX[0] == 1.0:
+        close(enc[::64], golden2["G1_patch_32768_enc_strided"], 5e-5)
+    else:            # x_storage = 'bf16': 4.2e-3 measured on values of magnitude 4, held to 5e-3 whatever bound the contract quantities above ran at
+        close(enc[::64], golden2["G1_patch_32768_enc_strided"], 5e-3 / RELAX[0])
     st = golden2["G1_patch_32768_Astat"]
     assert abs(float(A.double().sum()) - st[0]) < 1e-5 and int(A.argmax()) == int(st[2])
 
@@ -475,11 +517,11 @@ def test_G4L_full_size_optimizer_steps_vs_reference(golden2, name):
         keys = [str(k) for k in golden2[f"{name}_keys{tag}"]]
         dn = np.array([float((sd[k].double() - P0[k].double()).norm()) for k in keys])
         ref_dn = golden2[f"{name}_d{tag}_stats"][:, 1]
-        assert np.all(np.abs(dn - ref_dn) <= (5e-3 * ref_dn + 5e-5) * RELAX[0]), float(np.abs(dn - ref_dn).max())
+        assert np.all(np.abs(dn - ref_dn) <= (5e-3 * ref_dn + 5e-5) * AUX[0]), float(np.abs(dn - ref_dn).max())
     gk = [str(k) for k in golden2[name + "_gradG_keys"]]
     named = dict(h.netG.named_parameters())
     gn = np.array([float((named[k].grad.double() + 1e-5 * torch.sign(named[k].detach().double())).norm()) for k in gk])
-    assert np.allclose(gn, golden2[name + "_gradG_last_norm"], rtol=5e-3 * RELAX[0], atol=5e-6 * RELAX[0]), np.abs(gn - golden2[name + "_gradG_last_norm"]).max()
+    assert np.allclose(gn, golden2[name + "_gradG_last_norm"], rtol=5e-3 * AUX[0], atol=5e-6 * AUX[0]), np.abs(gn - golden2[name + "_gradG_last_norm"]).max()
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -528,17 +570,27 @@ def test_bf16x3_train_mode_dropout_parity_vs_oracle(bf16x3, kind):
 
 # ---------------------------------------------------------------------------------------------------------------------
 # x_storage = 'bf16' (bags held as ONE bf16 plane; weights / activations / gradients stay hi + lo). Rounding the INPUT to bf16 is
-# not an arithmetic error of the kernels: against the oracle on the same rounded bags (the dropout-parity test below) the mode is
-# as exact as fp32 storage (~1e-6). Against the reference's goldens, which were made from the unrounded bags, it is NOT inside the
-# 1e-4 contract of BASELINE.json's north_star everywhere -- measured on the box (printed per test, pytest -rP): the full optimizer
-# steps at the headline sizes (G4L: 8192 / 32768 patches) and ABMIL at 8192 patches 8e-6 ... 6e-5, but 512-patch bags 2e-4 ... 6e-4
-# (a pooled feature averages the rounding over N patches) and the ESAT layer's output at 32768 patches 4e-3 on values of magnitude
-# 4. So the mode is an EXTRA of the bench line (sizes.*_xbf16, with its own parity block), never the headline; the asserts here
-# hold it to 1e-3 (5e-3 for the magnitude-4 transformer output): 50 x the bound of the fp32-storage modes.
+# not an arithmetic error of the kernels: against the oracle on the same rounded bags (the dropout-parity test below, held to the
+# fp32-storage TOL = 2e-5) the mode is as exact as fp32 storage (~4e-7 measured). Against the reference's goldens, which were made
+# from the unrounded bags, the deviation depends on the bag size (a pooled feature averages the rounding over N patches). Measured on
+# the box (printed per test, pytest -rP; profiles/r06_xbf16_seen.txt):
+#   * AT THE BASELINE SIZES the contract's quantities (attention weights, sampled times, G / D losses, predictions) are INSIDE the
+#     1e-4 contract of BASELINE.json's north_star and are ASSERTED there (marker `xbf16_contract`): G1 ABMIL / DeepAttMISL at 8192
+#     patches 5.0e-5 / 6.1e-5, sampled times (G2) 2.3e-5 / 5.7e-5, the full optimizer steps through the reference handler (G4L) at
+#     8192 / 8192 / 32768 patches 1.5e-5 / 2.8e-5 / 9.1e-6, ESAT's y / H / A at 32768 patches;
+#   * OUTSIDE it, and held to the relaxed 1e-3 only: 512-patch bags 2e-4 ... 6e-4, ESAT at 8192 patches 1.5e-4 (512 tokens), the
+#     two-step G4 at 512 patches 4.6e-4, and the ESAT layer's own output at 32768 patches 4.2e-3 on values of magnitude 4 (not a
+#     contract quantity; 5e-3).
+# So the mode is an EXTRA of the bench line (sizes.*_xbf16, with its own parity block), never the headline.
 # ---------------------------------------------------------------------------------------------------------------------
-XBF16_RELAX = 50.0
+XBF16_RELAX = 50.0                           # the relaxed bound (x TOL = 1e-3)
+XBF16_CONTRACT = CONTRACT_TOL / TOL          # the contract itself (x TOL = 1e-4)
+contract = pytest.mark.xbf16_contract        # this case is asserted at the contract
+exact_inputs = pytest.mark.xbf16_same_inputs  # this case compares against the oracle on the SAME rounded bags: fp32-storage TOL
+
+
 @pytest.fixture
-def bf16x(monkeypatch):
+def bf16x(monkeypatch, request):
     from advmil_amd import ops
     prev = ops.get_gemm_mode()
     ops.set_gemm_mode("bf16x3")
@@ -554,20 +606,24 @@ def bf16x(monkeypatch):
         x = bag0(seed, n, device)
         return x.to(torch.bfloat16) if str(device) != "cpu" else x
     monkeypatch.setattr(H, "bag", bag)
-    RELAX[0], SEEN[0] = XBF16_RELAX, 0.0
+    relax = (1.0 if request.node.get_closest_marker("xbf16_same_inputs") else
+             XBF16_CONTRACT if request.node.get_closest_marker("xbf16_contract") else XBF16_RELAX)
+    RELAX[0], SEEN[0] = relax, 0.0
+    AUX[0] = 1.0 if relax == 1.0 else XBF16_RELAX
     yield
-    print(f"[x_storage=bf16] largest deviation from the reference seen by this test: {SEEN[0]:.3e} (contract {CONTRACT_TOL:g}, asserted "
-          f"{XBF16_RELAX * TOL:g})")
-    RELAX[0] = 1.0
+    print(f"[x_storage=bf16] {request.node.name}: largest deviation from the reference seen: {SEEN[0]:.3e} (contract {CONTRACT_TOL:g}, "
+          f"asserted {relax * TOL:g})")
+    RELAX[0] = AUX[0] = 1.0
     ops.set_gemm_mode(prev)
 
 
-@pytest.mark.parametrize("kind", ["abmil", "patch", "cluster"])
-@pytest.mark.parametrize("N", [512, 8192])
+@pytest.mark.parametrize("N,kind", [(512, "abmil"), (512, "patch"), (512, "cluster"), pytest.param(8192, "abmil", marks=contract),
+                                    (8192, "patch"), pytest.param(8192, "cluster", marks=contract)])
 def test_bf16x_G1_eval_forward_vs_reference(golden, bf16x, kind, N):
     test_G1_eval_forward_vs_reference(golden, kind, N)
 
 
+@contract
 @pytest.mark.parametrize("kind", ["abmil", "patch"])
 def test_bf16x_G2_sampling_vs_reference(golden, bf16x, kind):
     test_G2_test_model_sampling_vs_reference(golden, kind)
@@ -578,15 +634,20 @@ def test_bf16x_G4_two_optimizer_steps_vs_reference(golden, bf16x, kind):
     test_G4_two_optimizer_steps_vs_reference(golden, kind)
 
 
+@contract
 def test_bf16x_G1_patch_32768_vs_reference(golden2, bf16x):
+    """configs[3]'s size: y, H and the attention weights at the contract; the transformer layer's own output (magnitude 4, not a
+    contract quantity) at 5e-3."""
     test_G1_patch_32768_eval_forward_vs_reference(golden2)
 
 
+@contract
 @pytest.mark.parametrize("name", ["G4L_abmil_8192", "G4L_patch_8192", "G4L_patch_32768"])
 def test_bf16x_G4L_full_size_optimizer_steps_vs_reference(golden2, bf16x, name):
     test_G4L_full_size_optimizer_steps_vs_reference(golden2, name)
 
 
+@exact_inputs
 @pytest.mark.parametrize("kind", ["abmil", "patch", "cluster"])
 def test_bf16x_train_mode_dropout_parity_vs_oracle(bf16x, kind):
     test_train_mode_dropout_parity_vs_oracle(kind)
