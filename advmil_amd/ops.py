@@ -404,6 +404,9 @@ USE_PLANES = os.environ.get("ADVMIL_PLANES", "1") != "0"
 # memo-replayed (dropped) h were neutral while the training-pass gate contraction took the 256x192 tile with the old epilogue; with
 # the persistent 256x256 tile and the plain streaming epilogue they pay (+0.4-0.8 %, two same-box A/B runs) -> on.
 DH_PLANES = os.environ.get("ADVMIL_DH_PLANES", "0") != "0"
+# round 6: dh WITH the first layer's activation backward in its epilogue (rank-1 term + bit mask + bias column sums) on the plane-fed NT
+# kernel (B = the planes of Wab^T: one small transposing copy), instead of the generic kernel's 256x192 tile
+DH_NT_FUSED = os.environ.get("ADVMIL_DH_NT_FUSED", "1") != "0"
 # the first layer's activation / dropout backward in the epilogue of the pool's dh contraction (rank-1 term + mask + bias column sums)
 ACT_BWD_IN_DH = os.environ.get("ADVMIL_ACT_BWD_IN_DH", "1") != "0"
 # dG of the gate backward as planes ONLY (no fp32 copy): its two consumers take the A operand pre-split (-30 us each, no extra bytes)
@@ -428,6 +431,24 @@ def slab_takes_planes(rows, C):
     rule of ingest.SlabStager.ready() -- which back-fills the fp32 rows when it says no -- and MyHandler._slab_build_static, which
     attaches the planes when it says yes."""
     return bool(rows >= 4096 and USE_PLANES and get_gemm_mode() == "bf16x3" and (SLAB_PLANES_ANY or gemm_plan_planes(rows, 128, C)))
+
+
+def planes_transposed(pl):
+    """Planes of x^T from the planes of a 2-D x: ONE transposing copy when hi and lo live in one allocation (the optimizer's plane arena,
+    Planes.alloc), else two."""
+    R, C = pl.hi.shape
+    out = Planes.alloc((C, R), pl.hi.device)
+    d = (pl.lo.data_ptr() - pl.hi.data_ptr()) // 2
+    do = (out.lo.data_ptr() - out.hi.data_ptr()) // 2
+    if (pl.hi.untyped_storage().data_ptr() == pl.lo.untyped_storage().data_ptr() and d > 0 and pl.hi.stride() == pl.lo.stride()
+            and pl.hi.stride(1) == 1):
+        src = pl.hi.as_strided((2, C, R), (d, 1, pl.hi.stride(0)), pl.hi.storage_offset())
+        dst = out.hi.as_strided((2, C, R), (do, R, 1), out.hi.storage_offset())
+        dst.copy_(src)
+    else:
+        out.hi.copy_(pl.hi.t())
+        out.lo.copy_(pl.lo.t())
+    return out
 
 
 def planes_of(x):
@@ -486,7 +507,12 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
             if a_planes is not None and a_planes.fp32_stale:
                 planes_only_a = True          # (A's fp32 rows were never written: pointer and pitch only)
     b_single = False
-    if is_bf16_slab(B):
+    planes_only_b = B is None                 # B exists as (two) planes only (Wab^T of the pooling backward's dh): plane-fed kernels only
+    if planes_only_b:
+        if b_planes is None or b_planes.single or get_gemm_mode() != "bf16x3" or not (82 <= tile <= 86 or 91 <= tile <= 93):
+            raise ValueError("gemm(B=None) needs two-plane b_planes, bf16x3 mode and a plane-fed tile")
+        B = b_planes.hi                       # (pointer and pitch only: never read as fp32)
+    elif is_bf16_slab(B):
         b_planes = b_planes or Planes(B, None)
         b_single = True
     else:
@@ -1301,6 +1327,7 @@ class GatedAttnPoolFn(torch.autograd.Function):
         A, pooled = softmax_pool(s, h, N, D, seg)
         ctx.save_for_backward(h, Wab, ab, A, wcv)
         ctx.hpl = hpl                          # h's operand planes: B operand of dWab = dG^T h (with dG as planes: the plane-fed TN kernel)
+        ctx.wabpl = wabpl                      # Wab's planes: transposed, the B operand of dh = dG Wab on the plane-fed NT kernel
         ctx.cfg = (p, seed, sa, sb, N, D, wc.shape, seg, rr)
         # fused weight-gradient accumulation needs every parameter's arena slot, with the a|b pairs adjacent
         gs = [_arena_grad(t) for t in (Wa, ba, Wb, bb, wc, bc)]
@@ -1325,7 +1352,11 @@ class GatedAttnPoolFn(torch.autograd.Function):
         # bf16x3: dh = dG Wab runs as an NT contraction of dG's planes (emitted by gate_bwd) with the planes of Wab^T (a 2D x D
         # transpose + split: two tiny launches) through the plane-fed kernel, when the shape qualifies
         gpl = None
-        dh_nt = bool(need_h and USE_PLANES and DH_PLANES and get_gemm_mode() == "bf16x3" and gemm_plan_planes(N, D, 2 * D))
+        # (round 6: with the first layer's activation backward in its epilogue -- ctx.act_fuse -- the launch no longer stays on the generic
+        # kernel: the plane-fed kernel's full epilogue carries the rank-1 + bit-mask + column-sum form too)
+        dh_tile = gemm_plan_planes(N, D, 2 * D) if (need_h and USE_PLANES and get_gemm_mode() == "bf16x3") else 0
+        dh_nt = bool(dh_tile and (DH_PLANES or (DH_NT_FUSED and ctx.act_fuse is not None and ctx.act_fuse[2] is not None
+                                                and getattr(ctx, "wabpl", None) is not None)))
         if dh_nt:
             gpl = Planes.alloc((N, 2 * D), h.device)
         # bf16x3, slab-sized: dG is consumed by exactly two contractions (dh = dG Wab, dWab = dG^T h) that would split it into hi + lo
@@ -1341,8 +1372,17 @@ class GatedAttnPoolFn(torch.autograd.Function):
         else:
             dG, dwc, dbc, dbias = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb, rng_row=rr, planes=gpl, planes_only=only)
         dh = None
-        fuse = ctx.act_fuse if (need_h and only and not dh_nt and ctx.act_fuse is not None) else None
-        if fuse is not None:
+        fuse = ctx.act_fuse if (need_h and only and ctx.act_fuse is not None) else None
+        wtpl = None
+        if fuse is not None and dh_nt:
+            # the bit-mask form only (a mask read back from h would be a second prefetched operand: the generic kernel's loop)
+            nrow = int(_lib.lib().advmil_gemm_f32_colsum_rows(dh_tile, N, D)) if fuse[2] is not None else 0
+            if nrow > 0:
+                tile = dh_tile
+                wtpl = planes_transposed(ctx.wabpl) if getattr(ctx, "wabpl", None) is not None else split_planes(Wab.t().contiguous())
+            else:
+                fuse = None
+        elif fuse is not None:
             tile = gemm_plan(N, D, 2 * D, True, False)[0]
             nrow = int(_lib.lib().advmil_gemm_f32_colsum_rows(tile, N, D)) if pre_a_tile_ok(tile, True, False) else 0
             if nrow <= 0:
@@ -1355,9 +1395,14 @@ class GatedAttnPoolFn(torch.autograd.Function):
             dpl = Planes.alloc((N, D), h.device)
             cws = _ws(nrow * D * 4, h.device) if gb1 is not None else None
             # the mask: the layer's bit mask when its forward left one (1/32 of the bytes, parked in LDS by the epilogue), else h itself
-            gemm(None, Wab, True, False, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg, a_planes=gpl,
-                 maskref=h if mbits is None else None, maskbits=mbits, mask_scale=1.0 / (1.0 - p1) if p1 > 0.0 else 1.0, c_planes=dpl,
-                 c_planes_only=True, colsum=cws, tile=tile)
+            if wtpl is not None:             # NT over planes: A = dG [N, 2D], B = Wab^T [D, 2D], both k-contiguous
+                gemm(None, None, True, True, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg, a_planes=gpl,
+                     b_planes=wtpl, maskbits=mbits, mask_scale=1.0 / (1.0 - p1) if p1 > 0.0 else 1.0, c_planes=dpl, c_planes_only=True,
+                     colsum=cws, tile=tile)
+            else:
+                gemm(None, Wab, True, False, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg, a_planes=gpl,
+                     maskref=h if mbits is None else None, maskbits=mbits, mask_scale=1.0 / (1.0 - p1) if p1 > 0.0 else 1.0, c_planes=dpl,
+                     c_planes_only=True, colsum=cws, tile=tile)
             if gb1 is not None:
                 _lib.check(_lib.lib().advmil_merge_partials(_p(cws), nrow, D, D, _p(gb1), 1, _stream()), "merge_partials")
             dh = torch.empty(N, D, dtype=torch.float32, device=h.device)      # token: never written, never read
