@@ -208,10 +208,11 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
   if (!A || !B || !epi || (!C && !epi->gate_wc && !epi->c_hi) || M <= 0 || N <= 0 || K <= 0) return ADVMIL_EINVAL;
   // C == NULL with c_hi / c_lo set: the operand planes of the result ONLY (a result that is consumed as a bf16x3 operand and nowhere else:
   // the ESAT in-projection feeding the attention kernels); one pass, nothing to accumulate into
-  if (!C && !epi->gate_wc && (epi->accumulate || splits != 1 || epi->c2)) return ADVMIL_EINVAL;
+  // (... and of LAYER 1 of a two-layer launch, tiles 85 / 86: checked with the tile below)
+  if (!C && !epi->gate_wc && (epi->accumulate || splits != 1 || (epi->c2 && tile != 85 && tile != 86))) return ADVMIL_EINVAL;
   if ((lda & 3) || (ldb & 3)) return ADVMIL_EINVAL;
   if (lda < (a_kc ? K : M) || ldb < (b_kc ? K : N)) return ADVMIL_EINVAL;          // a row pitch shorter than the row it strides
-  if (C && ldc < (epi->c2 ? (int64_t)epi->n_split : N)) return ADVMIL_EINVAL;      // (two-layer form: C holds the first n_split columns)
+  if (ldc < (epi->c2 ? (int64_t)epi->n_split : N) && (C || epi->c_hi)) return ADVMIL_EINVAL;      // (two-layer form: C holds the first n_split columns)
   if (a_kc ? (K & 3) : (M & 3)) return ADVMIL_EINVAL;
   if (b_kc ? (K & 3) : (N & 3)) return ADVMIL_EINVAL;
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return ADVMIL_EINVAL;
@@ -276,7 +277,11 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
     const int tnp = tile == 85 ? 4 : tile == 86 ? 2 : tile % 10, bm = 256, bkt = 32;
     const bool plain = tile == 85 || tile == 86;
     if (tile == 84 && !epi->gate_wc) return ADVMIL_EINVAL;        // 256x256: the fused gate score only
-    if (plain && (epi->gate_wc || epi->rowv || epi->maskref || epi->accumulate || (epi->seed && epi->drop_p > 0.0f))) return ADVMIL_EINVAL;
+    const bool twin = epi->t_hi != nullptr;             // the layer's train-mode twin: the only dropout a plain launch may draw
+    if (plain && (epi->gate_wc || epi->rowv || epi->maskref || epi->accumulate || (epi->seed && epi->drop_p > 0.0f && !twin))) return ADVMIL_EINVAL;
+    if (twin && (!plain || !epi->t_lo || !epi->seed || !(epi->drop_p > 0.0f) || epi->drop_p >= 1.0f || (((uintptr_t)epi->t_hi | (uintptr_t)epi->t_lo) & 7) ||
+                 (epi->t_bits && epi->ldtbits < (epi->c2 ? epi->n_split : N) / 32)))
+      return ADVMIL_EINVAL;
     if (epi->c2) {      // two layers in one launch: the plain forms only, split on a 32-column boundary inside N
       if (!plain || epi->n_split <= 0 || epi->n_split >= N || (epi->n_split & 31) || (epi->ldc2 & 3) || ((uintptr_t)epi->c2 & 15) ||
           epi->act_split != epi->n_split)

@@ -294,11 +294,33 @@ __global__ __launch_bounds__(256) void pool_partial8_kernel(const float* __restr
 // a segment share out its rows to write A_n = exp(s_n - M) / L. Same contract as softmax_stats + pool_partial8 + colsum_merge.
 // MEAN: a second partial row per workgroup, the UNWEIGHTED sum of its rows (the per-bag mean of h from the same pass over h: the
 // projection discriminator's region-level inner product, GANSurv.py:96-98, needs mean_r(fc_ins) beside the pooled fc_ins)
-template <bool MEAN>
+// PL: h arrives as its bf16x3 operand planes (h = the hi plane's address, hlo = the lo plane's; x = hi + lo, exact in fp32): the pooled
+// tensor of a slab whose producer wrote planes only (round 6: the generator's first layer leaves no fp32 copy -- 201 MB less written per
+// launch and the rows just read by the gate contraction are still in the Infinity Cache). Same 4 bytes per element, same loads per row.
+__device__ __forceinline__ void planes8(const bf16raw* __restrict__ hi, const bf16raw* __restrict__ lo, int64_t off, float4& v0, float4& v1) {
+  const uint4 a = *reinterpret_cast<const uint4*>(hi + off);
+  const uint4 b = *reinterpret_cast<const uint4*>(lo + off);
+  v0.x = __uint_as_float(a.x << 16) + __uint_as_float(b.x << 16);
+  v0.y = __uint_as_float(a.x & 0xffff0000u) + __uint_as_float(b.x & 0xffff0000u);
+  v0.z = __uint_as_float(a.y << 16) + __uint_as_float(b.y << 16);
+  v0.w = __uint_as_float(a.y & 0xffff0000u) + __uint_as_float(b.y & 0xffff0000u);
+  v1.x = __uint_as_float(a.z << 16) + __uint_as_float(b.z << 16);
+  v1.y = __uint_as_float(a.z & 0xffff0000u) + __uint_as_float(b.z & 0xffff0000u);
+  v1.z = __uint_as_float(a.w << 16) + __uint_as_float(b.w << 16);
+  v1.w = __uint_as_float(a.w & 0xffff0000u) + __uint_as_float(b.w & 0xffff0000u);
+}
+__device__ __forceinline__ float4 planes4(const bf16raw* __restrict__ hi, const bf16raw* __restrict__ lo, int64_t off) {
+  const uint2 a = *reinterpret_cast<const uint2*>(hi + off);
+  const uint2 b = *reinterpret_cast<const uint2*>(lo + off);
+  return make_float4(__uint_as_float(a.x << 16) + __uint_as_float(b.x << 16), __uint_as_float(a.x & 0xffff0000u) + __uint_as_float(b.x & 0xffff0000u),
+                     __uint_as_float(a.y << 16) + __uint_as_float(b.y << 16), __uint_as_float(a.y & 0xffff0000u) + __uint_as_float(b.y & 0xffff0000u));
+}
+
+template <bool MEAN, bool PL = false>
 __global__ __launch_bounds__(256) void pool_partial8_online_kernel(const float* __restrict__ s, const float* __restrict__ h, int64_t ldh,
                                                                    int64_t N, int64_t D, const int64_t* __restrict__ seg_ptr,
                                                                    float* __restrict__ partial, float* __restrict__ pstats, int rpb,
-                                                                   float* __restrict__ mpartial) {
+                                                                   float* __restrict__ mpartial, const bf16raw* __restrict__ hlo = nullptr) {
   __shared__ __attribute__((aligned(16))) float red[2048];      // rpp * D <= 256 / (D/8) * D = 2048 floats
   __shared__ float wts[512];                                    // rows_per_block <= 512
   __shared__ float wred[8];
@@ -350,8 +372,13 @@ __global__ __launch_bounds__(256) void pool_partial8_online_kernel(const float* 
       const int64_t n = r0 + r;
       const int64_t nn = n < end ? n : beg;                // predicated: keeps the unrolled loads independent of the bound (weight 0)
       const float wgt = wts[r];
-      const float4 v0 = *reinterpret_cast<const float4*>(h + nn * ldh + c8 * 8);
-      const float4 v1 = *reinterpret_cast<const float4*>(h + nn * ldh + c8 * 8 + 4);
+      float4 v0, v1;
+      if constexpr (PL) {
+        planes8(reinterpret_cast<const bf16raw*>(h), hlo, nn * ldh + c8 * 8, v0, v1);
+      } else {
+        v0 = *reinterpret_cast<const float4*>(h + nn * ldh + c8 * 8);
+        v1 = *reinterpret_cast<const float4*>(h + nn * ldh + c8 * 8 + 4);
+      }
       acc[0] += wgt * v0.x; acc[1] += wgt * v0.y; acc[2] += wgt * v0.z; acc[3] += wgt * v0.w;
       acc[4] += wgt * v1.x; acc[5] += wgt * v1.y; acc[6] += wgt * v1.z; acc[7] += wgt * v1.w;
       if (MEAN) {
@@ -480,12 +507,21 @@ extern "C" size_t advmil_softmax_pool_workspace_bytes(int64_t max_len, int64_t D
 }
 
 static int softmax_pool_fwd_impl(const float* s, const float* h, int64_t ldh, int64_t N, int64_t D, int nseg, const int64_t* seg_ptr,
-                                 int64_t max_len, float* A, float* pooled, float* mean, void* ws, size_t ws_bytes, hipStream_t stream);
+                                 int64_t max_len, float* A, float* pooled, float* mean, void* ws, size_t ws_bytes, hipStream_t stream,
+                                 const bf16raw* hlo = nullptr);
 
 extern "C" int advmil_softmax_pool_fwd(const float* s, const float* h, int64_t ldh, int64_t N, int64_t D, int nseg,
                                        const int64_t* seg_ptr, int64_t max_len, float* A, float* pooled, void* ws,
                                        size_t ws_bytes, advmil_stream_t stream_) {
   return softmax_pool_fwd_impl(s, h, ldh, N, D, nseg, seg_ptr, max_len, A, pooled, nullptr, ws, ws_bytes, (hipStream_t)stream_);
+}
+
+extern "C" int advmil_softmax_pool_fwd_planes(const float* s, const void* h_hi, const void* h_lo, int64_t ldh, int64_t N, int64_t D, int nseg,
+                                              const int64_t* seg_ptr, int64_t max_len, float* A, float* pooled, void* ws,
+                                              size_t ws_bytes, advmil_stream_t stream_) {
+  if (!h_hi || !h_lo) return ADVMIL_EINVAL;
+  return softmax_pool_fwd_impl(s, (const float*)h_hi, ldh, N, D, nseg, seg_ptr, max_len, A, pooled, nullptr, ws, ws_bytes, (hipStream_t)stream_,
+                               (const bf16raw*)h_lo);
 }
 
 // the unweighted partial rows sit behind the plain call's workspace, on a 16-byte boundary (they are stored as float4)
@@ -506,9 +542,12 @@ extern "C" int advmil_softmax_pool_mean_fwd(const float* s, const float* h, int6
 }
 
 static int softmax_pool_fwd_impl(const float* s, const float* h, int64_t ldh, int64_t N, int64_t D, int nseg, const int64_t* seg_ptr,
-                                 int64_t max_len, float* A, float* pooled, float* mean, void* ws, size_t ws_bytes, hipStream_t stream) {
+                                 int64_t max_len, float* A, float* pooled, float* mean, void* ws, size_t ws_bytes, hipStream_t stream,
+                                 const bf16raw* hlo) {
   if (!s || !h || !A || !pooled || !ws || N <= 0 || D <= 0 || (D & 3) || D > 1024 || (ldh & 3)) return ADVMIL_EINVAL;
   if (ldh < D || ((uintptr_t)h & 15)) return ADVMIL_EINVAL;        // rows are read as 16-byte vectors
+  // planes: 8 halfwords per 16-byte load -> D and the pitch multiples of 8; the two-launch form only; no unweighted mean beside it
+  if (hlo && (((uintptr_t)hlo & 15) || (D & 7) || (ldh & 7) || D < 16 || mean)) return ADVMIL_EINVAL;
   if (!seg_ptr && nseg > 1) return ADVMIL_EINVAL;                   // several bags need their row offsets
   if (!seg_ptr) { nseg = 1; max_len = N; }
   if (nseg < 1 || max_len <= 0 || max_len > N) return ADVMIL_EINVAL;
@@ -521,23 +560,27 @@ static int softmax_pool_fwd_impl(const float* s, const float* h, int64_t ldh, in
     float* pstats = partial + (int64_t)nseg * nblk * D;
     if (mean) {
       float* mpartial = (float*)ws + pool_mean_offset_bytes(max_len, D, nseg) / sizeof(float);
-      hipLaunchKernelGGL(pool_partial8_online_kernel<true>, dim3(nblk, nseg), dim3(256), 0, stream, s, h, ldh, N, D, seg_ptr, partial, pstats,
-                         rows_per_block(max_len), mpartial);
+      hipLaunchKernelGGL((pool_partial8_online_kernel<true, false>), dim3(nblk, nseg), dim3(256), 0, stream, s, h, ldh, N, D, seg_ptr, partial, pstats,
+                         rows_per_block(max_len), mpartial, (const bf16raw*)nullptr);
       ADVMIL_LAUNCH_CHECK();
       hipLaunchKernelGGL(pool_merge_online_kernel, dim3((unsigned)((D + 15) / 16), nseg), dim3(256), 0, stream, partial, pstats, nblk, D, s,
                          N, seg_ptr, pooled, A, stats, (const float*)mpartial, mean);
       ADVMIL_LAUNCH_CHECK();
       return ADVMIL_OK;
     }
-    hipLaunchKernelGGL(pool_partial8_online_kernel<false>, dim3(nblk, nseg), dim3(256), 0, stream, s, h, ldh, N, D, seg_ptr, partial, pstats,
-                       rows_per_block(max_len), (float*)nullptr);
+    if (hlo)
+      hipLaunchKernelGGL((pool_partial8_online_kernel<false, true>), dim3(nblk, nseg), dim3(256), 0, stream, s, h, ldh, N, D, seg_ptr, partial,
+                         pstats, rows_per_block(max_len), (float*)nullptr, hlo);
+    else
+      hipLaunchKernelGGL((pool_partial8_online_kernel<false, false>), dim3(nblk, nseg), dim3(256), 0, stream, s, h, ldh, N, D, seg_ptr, partial,
+                         pstats, rows_per_block(max_len), (float*)nullptr, (const bf16raw*)nullptr);
     ADVMIL_LAUNCH_CHECK();
     hipLaunchKernelGGL(pool_merge_online_kernel, dim3((unsigned)((D + 15) / 16), nseg), dim3(256), 0, stream, partial, pstats, nblk, D, s,
                        N, seg_ptr, pooled, A, stats, (const float*)nullptr, (float*)nullptr);
     ADVMIL_LAUNCH_CHECK();
     return ADVMIL_OK;
   }
-  if (mean) return ADVMIL_EINVAL;          // (the mean rides in the two-launch form only: D % 8 == 0)
+  if (mean || hlo) return ADVMIL_EINVAL;   // (the mean / the plane-held h ride in the two-launch form only: D % 8 == 0)
   hipLaunchKernelGGL(softmax_stats_kernel, dim3(nseg), dim3(1024), 0, stream, s, N, seg_ptr, stats);
   ADVMIL_LAUNCH_CHECK();
   if ((D & 7) == 0 && D >= 16)
@@ -557,11 +600,12 @@ static int softmax_pool_fwd_impl(const float* s, const float* h, int64_t ldh, in
 // One wave per FOUR rows, their loads issued together (one row per wave left a single 16-byte load in flight per lane: 0.52 of the
 // HBM roof at the 16-bag slab).
 #define PBD_ROWS 4
+template <bool PL>
 __global__ __launch_bounds__(256) void pool_bwd_dot_kernel(const float* __restrict__ dp, const float* __restrict__ dA,
                                                            const float* __restrict__ A, const float* __restrict__ h,
                                                            int64_t ldh, int64_t N, int64_t D,
                                                            const int64_t* __restrict__ seg_ptr, float* __restrict__ t,
-                                                           float* __restrict__ partial) {
+                                                           float* __restrict__ partial, const bf16raw* __restrict__ hlo) {
   __shared__ float red[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int b = blockIdx.y;
@@ -579,8 +623,12 @@ __global__ __launch_bounds__(256) void pool_bwd_dot_kernel(const float* __restri
         const float4 a = d4[q];
         float4 v[PBD_ROWS];
 #pragma unroll
-        for (int rr = 0; rr < PBD_ROWS; ++rr)
-          v[rr] = (n0 + rr < end) ? reinterpret_cast<const float4*>(h + (n0 + rr) * ldh)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int rr = 0; rr < PBD_ROWS; ++rr) {
+          if constexpr (PL)
+            v[rr] = (n0 + rr < end) ? planes4(reinterpret_cast<const bf16raw*>(h), hlo, (n0 + rr) * ldh + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+          else
+            v[rr] = (n0 + rr < end) ? reinterpret_cast<const float4*>(h + (n0 + rr) * ldh)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int rr = 0; rr < PBD_ROWS; ++rr) acc[rr] += a.x * v[rr].x + a.y * v[rr].y + a.z * v[rr].z + a.w * v[rr].w;
       }
@@ -627,22 +675,83 @@ __global__ __launch_bounds__(256) void pool_bwd_ds_kernel(const float* __restric
   if (n < end) ds[n] = A[n] * (ds[n] - c);
 }
 
-extern "C" int advmil_softmax_pool_bwd(const float* dpooled, const float* dA, const float* A, const float* h, int64_t ldh,
-                                       int64_t N, int64_t D, int nseg, const int64_t* seg_ptr, int64_t max_len, float* ds,
-                                       void* ws, size_t ws_bytes, advmil_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int softmax_pool_bwd_impl(const float* dpooled, const float* dA, const float* A, const float* h, const bf16raw* hlo, int64_t ldh,
+                                 int64_t N, int64_t D, int nseg, const int64_t* seg_ptr, int64_t max_len, float* ds,
+                                 void* ws, size_t ws_bytes, hipStream_t stream) {
   if (!dpooled || !A || !h || !ds || !ws || N <= 0 || D <= 0) return ADVMIL_EINVAL;
   if (ldh < D || (ldh & 3) || ((uintptr_t)h & 15)) return ADVMIL_EINVAL;
+  if (hlo && (((uintptr_t)hlo & 7) || ((uintptr_t)h & 7) || (D & 3) || (((uintptr_t)dpooled) & 15))) return ADVMIL_EINVAL;
   if (!seg_ptr && nseg > 1) return ADVMIL_EINVAL;
   if (!seg_ptr) { nseg = 1; max_len = N; }
   if (nseg < 1 || max_len <= 0 || max_len > N) return ADVMIL_EINVAL;
   if (ws_bytes < advmil_softmax_pool_workspace_bytes(max_len, D, nseg)) return ADVMIL_EWORKSPACE;
   float* partial = (float*)ws + 4;
   const int nwg = (int)((max_len + 4 * PBD_ROWS - 1) / (4 * PBD_ROWS));
-  hipLaunchKernelGGL(pool_bwd_dot_kernel, dim3(nwg, nseg), dim3(256), 0, stream, dpooled, dA, A, h, ldh, N, D, seg_ptr, ds, partial);
+  if (hlo) hipLaunchKernelGGL(pool_bwd_dot_kernel<true>, dim3(nwg, nseg), dim3(256), 0, stream, dpooled, dA, A, h, ldh, N, D, seg_ptr, ds, partial, hlo);
+  else hipLaunchKernelGGL(pool_bwd_dot_kernel<false>, dim3(nwg, nseg), dim3(256), 0, stream, dpooled, dA, A, h, ldh, N, D, seg_ptr, ds, partial, hlo);
   ADVMIL_LAUNCH_CHECK();
   hipLaunchKernelGGL(pool_bwd_ds_kernel, dim3((unsigned)((max_len + 255) / 256), nseg), dim3(256), 0, stream, A, partial, nwg, N,
                      seg_ptr, ds);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}
+
+extern "C" int advmil_softmax_pool_bwd(const float* dpooled, const float* dA, const float* A, const float* h, int64_t ldh,
+                                       int64_t N, int64_t D, int nseg, const int64_t* seg_ptr, int64_t max_len, float* ds,
+                                       void* ws, size_t ws_bytes, advmil_stream_t stream_) {
+  return softmax_pool_bwd_impl(dpooled, dA, A, h, nullptr, ldh, N, D, nseg, seg_ptr, max_len, ds, ws, ws_bytes, (hipStream_t)stream_);
+}
+extern "C" int advmil_softmax_pool_bwd_planes(const float* dpooled, const float* dA, const float* A, const void* h_hi, const void* h_lo,
+                                              int64_t ldh, int64_t N, int64_t D, int nseg, const int64_t* seg_ptr, int64_t max_len,
+                                              float* ds, void* ws, size_t ws_bytes, advmil_stream_t stream_) {
+  if (!h_hi || !h_lo) return ADVMIL_EINVAL;
+  return softmax_pool_bwd_impl(dpooled, dA, A, (const float*)h_hi, (const bf16raw*)h_lo, ldh, N, D, nseg, seg_ptr, max_len, ds, ws, ws_bytes,
+                               (hipStream_t)stream_);
+}
+
+// =====================================================================================
+// Train-mode dropout of a tensor held as operand planes: out = split(dropout(in_hi + in_lo)) as planes again, plus one bit per element
+// (out > 0). The replay of the generator's memoized first layer (ops.ForwardMemo) when that layer left planes only: 8 bytes per element
+// moved instead of 12 (fp32 in, fp32 + planes out), same draw as advmil_act_dropout_bwd's replay (stream, element index m * N + n).
+// One thread = 8 consecutive columns: 16 bytes of each plane in, 16 bytes of each plane and one BYTE of the bit words out.
+// =====================================================================================
+__global__ __launch_bounds__(256) void dropout_planes_kernel(const bf16raw* __restrict__ ihi, const bf16raw* __restrict__ ilo, int64_t M, int64_t N,
+                                                             float p, const uint64_t* __restrict__ seed, uint64_t stream_id,
+                                                             const int64_t* __restrict__ rng_row, bf16raw* __restrict__ ohi,
+                                                             bf16raw* __restrict__ olo, uint8_t* __restrict__ bits) {
+  const uint64_t key = rng_key(*seed, stream_id);
+  const float inv = hw_rcp(1.f - p);
+  const int64_t n8 = N >> 3, total = M * n8;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t row = e / n8, c = (e % n8) * 8;
+    float4 v0, v1;
+    planes8(ihi, ilo, row * N + c, v0, v1);
+    const uint64_t base = (uint64_t)((rng_row ? rng_row[row] : row) * N + c);
+    float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    uint32_t b = 0u;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      x[q] *= rng_keep(key, base + q, p, inv);
+      b |= (x[q] > 0.f) ? (1u << q) : 0u;
+    }
+    uint2 h0, l0, h1, l1;
+    split4(make_float4(x[0], x[1], x[2], x[3]), h0, l0);
+    split4(make_float4(x[4], x[5], x[6], x[7]), h1, l1);
+    *reinterpret_cast<uint4*>(ohi + row * N + c) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    *reinterpret_cast<uint4*>(olo + row * N + c) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    if (bits) bits[row * (N >> 3) + (c >> 3)] = (uint8_t)b;       // little-endian bytes of the [M, N / 32] uint32 words
+  }
+}
+
+extern "C" int advmil_dropout_planes(const void* in_hi, const void* in_lo, int64_t M, int64_t N, float drop_p, const uint64_t* seed,
+                                     uint64_t stream_id, const int64_t* rng_row, void* out_hi, void* out_lo, void* bits,
+                                     advmil_stream_t stream_) {
+  if (!in_hi || !in_lo || !out_hi || !out_lo || !seed || M <= 0 || N <= 0 || (N & 31) || !(drop_p > 0.f) || drop_p >= 1.f) return ADVMIL_EINVAL;
+  if ((((uintptr_t)in_hi | (uintptr_t)in_lo | (uintptr_t)out_hi | (uintptr_t)out_lo) & 15) || ((uintptr_t)bits & 3)) return ADVMIL_EINVAL;
+  int64_t blocks = (M * (N >> 3) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(dropout_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, (const bf16raw*)in_hi, (const bf16raw*)in_lo,
+                     M, N, drop_p, seed, stream_id, rng_row, (bf16raw*)out_hi, (bf16raw*)out_lo, (uint8_t*)bits);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }

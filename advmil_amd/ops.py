@@ -344,10 +344,11 @@ class Planes:
     """bf16x3 operand image of an fp32 matrix: hi = bf16(x), lo = bf16(x - hi), same shape/strides as x
     (include/advmil_hip.h::advmil_epilogue_t.a_hi..c_lo). A contraction given the planes of an operand skips the per-workgroup
     re-split of that operand; results are bit-identical."""
-    __slots__ = ("hi", "lo", "fp32_stale")
+    __slots__ = ("hi", "lo", "fp32_stale", "twin")
 
     def __init__(self, hi, lo):
         self.hi, self.lo = hi, lo               # lo None: a SINGLE-plane operand -- the tensor is bf16 itself (x_storage = "bf16")
+        self.twin = None                        # (Planes, bits) of the layer's train-mode twin, when the producing launch drew it (gemm_two_layers)
         # True: the fp32 tensor these planes belong to was never written (a step slab whose cached bags were staged as planes only,
         # ingest.SlabStager): a contraction given them must read the planes and nothing else
         self.fp32_stale = False
@@ -414,6 +415,11 @@ DG_PLANES_ONLY = os.environ.get("ADVMIL_DG_PLANES_ONLY", "1") != "0"
 # weight gradients dY^T X of the layers applied to the slab: X's planes (already resident for the forward) feed the B operand
 DW_PLANES = os.environ.get("ADVMIL_DW_PLANES", "1") != "0"
 MEMO_PLANES = os.environ.get("ADVMIL_MEMO_PLANES", "1") != "0"
+# round 6: the generator's first layer over the step slab (the two-layer launch) leaves its [rows, hid] output as operand planes ONLY -- the
+# gate contraction reads the planes anyway, the pooling kernels and the dropout replay of the memoized output read them too (h = hi + lo,
+# 2^-17 relative, the arithmetic of every bf16x3 contraction): 201 MB less written by the launch and by the replay, and the pooling pass
+# no longer pays for the write-back of those dirty lines (tools/probe/pool_instep.py). 0 = fp32 rows beside the planes, as until round 5.
+H_PLANES_ONLY = os.environ.get("ADVMIL_H_PLANES_ONLY", "1") != "0"
 # operand planes for EVERY step slab of >= 4096 rows, not only for those that fill the chip with the plane-fed NT kernel's 256-row tiles: the
 # deep-K weight gradients (plane-fed TN kernel from K = 8192), the planes-only dpre / dG hand-overs and the dh epilogue fusion then also
 # apply to the 1-4 bag steps of a strong split
@@ -659,7 +665,7 @@ def gemm_two_layers_ok(M, N1, N2, K):
     return gemm_two_layers_tile(M, N1, N2, K) != 0
 
 
-def gemm_two_layers(x, xpl, W1, w1pl, b1, act1, W2, w2pl, b2, act2, emit_planes1=False):
+def gemm_two_layers(x, xpl, W1, w1pl, b1, act1, W2, w2pl, b2, act2, emit_planes1=False, y1_planes_only=False, twin=None):
     """(y1, y2, planes of y1 | None): y1 = act1(x W1^T + b1) [M, N1], y2 = act2(x W2^T + b2) [M, N2] from ONE launch that stages
     every row of x once (advmil_epilogue_t two-layer form). All operands as Planes; shapes checked by gemm_two_layers_ok.
     The two weight matrices' planes are stacked for the launch (two ~1 MB copies)."""
@@ -680,12 +686,24 @@ def gemm_two_layers(x, xpl, W1, w1pl, b1, act1, W2, w2pl, b2, act2, emit_planes1
     else:
         wcat = Planes(torch.cat((w1pl.hi.reshape(N1, K), w2pl.hi.reshape(N2, K)), dim=0), torch.cat((w1pl.lo.reshape(N1, K), w2pl.lo.reshape(N2, K)), dim=0))
     dev = x.device
+    # y1_planes_only: layer 1's output exists as operand planes only (y1 is an unwritten token). twin = (p, seed, stream id, row map):
+    # layer 1's TRAIN-MODE TWIN rides along (advmil_epilogue_t.t_hi): returned as cpl.twin = (Planes of dropout(y1), keep-and-positive bits)
     y1 = torch.empty(M, N1, dtype=torch.float32, device=dev)
     y2 = torch.empty(M, N2, dtype=torch.float32, device=dev)
     cpl = None
-    if emit_planes1:
+    if emit_planes1 or y1_planes_only or twin is not None:
         cpl = Planes.alloc((M, N1), dev)
     e = Epilogue()
+    tw = None
+    if twin is not None:
+        tp, tseed, tsid, trr = twin
+        tpl = Planes.alloc((M, N1), dev)
+        tbits = torch.empty(M, N1 // 32, dtype=torch.int32, device=dev)
+        e.t_hi, e.t_lo, e.t_bits, e.ldtbits = tpl.hi.data_ptr(), tpl.lo.data_ptr(), tbits.data_ptr(), N1 // 32
+        e.drop_p, e.seed, e.stream_id = float(tp), tseed.data_ptr(), int(tsid)
+        if trr is not None:
+            e.rng_row = trr.data_ptr()
+        tw = (tpl, tbits)
     e.bias = None if b1 is None else b1.data_ptr()
     e.bias2 = None if b2 is None else b2.data_ptr()
     e.act0, e.act1, e.act_split = act1, act2, N1
@@ -700,8 +718,12 @@ def gemm_two_layers(x, xpl, W1, w1pl, b1, act1, W2, w2pl, b2, act2, emit_planes1
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
     _stamp("b", f"gemm_nt_planes_kernel<4,two layers,{N1}>", (M, N1 + N2, K, 1), 2.0 * M * (N1 + N2) * K)
-    _lib.check(_lib.lib().advmil_gemm_f32_tiled(1, 1, M, N1 + N2, K, _p(x), x.stride(0), _p(W1), K, _p(y1), N1, ctypes.byref(e), 1,
-                                                gemm_two_layers_tile(M, N1, N2, K), None, 0, _stream()), f"gemm_two_layers[{M}x({N1}+{N2})x{K}]")
+    _lib.check(_lib.lib().advmil_gemm_f32_tiled(1, 1, M, N1 + N2, K, _p(x), x.stride(0), _p(W1), K, None if y1_planes_only else _p(y1), N1,
+                                                ctypes.byref(e), 1, gemm_two_layers_tile(M, N1, N2, K), None, 0, _stream()),
+               f"gemm_two_layers[{M}x({N1}+{N2})x{K}]")
+    if cpl is not None:
+        cpl.twin = tw
+        cpl.fp32_stale = bool(y1_planes_only)
     _stamp("e", f"gemm_nt_planes_kernel<4,two layers,{N1}>", (M, N1 + N2, K, 1), 2.0 * M * (N1 + N2) * K)
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
@@ -772,7 +794,9 @@ class Segments:
         return self._div[key]
 
 
-def softmax_pool(s, h, N, D, seg=None):
+def softmax_pool(s, h, N, D, seg=None, hpl=None):
+    """hpl: h held as its operand planes (two-plane Planes, row pitch of h): the pooling reads hi + lo instead of fp32 rows (h itself may
+    be an unwritten token then)."""
     L = _lib.lib()
     nseg = 1 if seg is None else seg.nseg
     mlen = N if seg is None else seg.max_len
@@ -780,8 +804,18 @@ def softmax_pool(s, h, N, D, seg=None):
     pooled = torch.empty(nseg, D, dtype=torch.float32, device=h.device)
     wsb = L.advmil_softmax_pool_workspace_bytes(mlen, D, nseg)
     ws = _ws(wsb, h.device)
-    _lib.check(L.advmil_softmax_pool_fwd(_p(s), _p(h), h.stride(0), N, D, nseg, _p(None if seg is None else seg.ptr), mlen, _p(A),
-                                         _p(pooled), _p(ws), wsb, _stream()), "softmax_pool_fwd")
+    big = STAMPS is not None and N * D >= (1 << 24)           # bench.py: the call timed where it sits in the step (`flops` slot = bytes)
+    if big:
+        _stamp("b", "softmax_pool_fwd", (N, D, nseg), 4.0 * N * D + 12.0 * N)
+    if hpl is not None:
+        _lib.check(L.advmil_softmax_pool_fwd_planes(_p(s), _p(hpl.hi), _p(hpl.lo), hpl.hi.stride(0), N, D, nseg,
+                                                    _p(None if seg is None else seg.ptr), mlen, _p(A), _p(pooled), _p(ws), wsb, _stream()),
+                   "softmax_pool_fwd_planes")
+    else:
+        _lib.check(L.advmil_softmax_pool_fwd(_p(s), _p(h), h.stride(0), N, D, nseg, _p(None if seg is None else seg.ptr), mlen, _p(A),
+                                             _p(pooled), _p(ws), wsb, _stream()), "softmax_pool_fwd")
+    if big:
+        _stamp("e", "softmax_pool_fwd", (N, D, nseg), 4.0 * N * D + 12.0 * N)
     return A, pooled
 
 
@@ -800,17 +834,38 @@ def softmax_pool_mean(s, h, N, D, seg=None):
     return A, pooled, mean
 
 
-def softmax_pool_bwd(dpooled, dA, A, h, N, D, seg=None):
+def softmax_pool_bwd(dpooled, dA, A, h, N, D, seg=None, hpl=None):
     L = _lib.lib()
     nseg = 1 if seg is None else seg.nseg
     mlen = N if seg is None else seg.max_len
     ds = torch.empty(N, dtype=torch.float32, device=h.device)
     wsb = L.advmil_softmax_pool_workspace_bytes(mlen, D, nseg)
     ws = _ws(wsb, h.device)
-    _lib.check(L.advmil_softmax_pool_bwd(_p(dpooled), _p(dA), _p(A), _p(h), h.stride(0), N, D, nseg,
-                                         _p(None if seg is None else seg.ptr), mlen, _p(ds), _p(ws), wsb, _stream()),
-               "softmax_pool_bwd")
+    if hpl is not None:
+        _lib.check(L.advmil_softmax_pool_bwd_planes(_p(dpooled), _p(dA), _p(A), _p(hpl.hi), _p(hpl.lo), hpl.hi.stride(0), N, D, nseg,
+                                                    _p(None if seg is None else seg.ptr), mlen, _p(ds), _p(ws), wsb, _stream()),
+                   "softmax_pool_bwd_planes")
+    else:
+        _lib.check(L.advmil_softmax_pool_bwd(_p(dpooled), _p(dA), _p(A), _p(h), h.stride(0), N, D, nseg,
+                                             _p(None if seg is None else seg.ptr), mlen, _p(ds), _p(ws), wsb, _stream()),
+                   "softmax_pool_bwd")
     return ds
+
+
+def dropout_planes(pl, M, N, p, seed, sid, rng_row=None):
+    """(Planes of dropout(x), keep-and-positive bits [M, N / 32]) from the Planes of x [M, N]: the train-mode forward of a layer whose
+    eval-mode output is held as planes only (include/advmil_hip.h::advmil_dropout_planes). The result is planes-only too."""
+    out = Planes.alloc((M, N), pl.hi.device)
+    out.fp32_stale = True
+    bits = torch.empty(M, N // 32, dtype=torch.int32, device=pl.hi.device)
+    _lib.check(_lib.lib().advmil_dropout_planes(_p(pl.hi), _p(pl.lo), M, N, float(p), _p(seed), sid, _p(rng_row), _p(out.hi), _p(out.lo),
+                                                _p(bits), _stream()), "dropout_planes")
+    return out, bits
+
+
+def planes_f32(pl):
+    """fp32 image hi + lo of a planes-only tensor (the escape hatch of the rare consumers that read rows: two elementwise launches)."""
+    return pl.hi.float().add_(pl.lo)
 
 
 def gate_bwd(ab, ds, wc, N, D, p=0.0, seed=None, stream_a=0, stream_b=0, dwc=None, dbc=None, dbias=None, rng_row=None, planes=None,
@@ -1012,6 +1067,8 @@ class LinearActFn(torch.autograd.Function):
         N = W2.shape[0]
         cpl = None
         ctx.small = False
+        # a memoized / prefilled output that exists as operand planes only (H_PLANES_ONLY): y0 is an unwritten token carrying them
+        y0pl = getattr(y0, "_advmil_planes", None) if (y0 is not None and getattr(y0, "_advmil_planes_only", False)) else None
         if (SMALL_LINEAR and y0 is None and M <= min(32, SMALL_LINEAR_ROWS) and K % 4 == 0 and N <= 1024 and xpl is None and not emit and x.dtype == torch.float32
                 and (b is None or b.dtype == torch.float32)):
             # a [B, d] head / tail layer: one fp32-FMA launch (csrc/optim.hip small_linear_*), its backward one or two
@@ -1033,6 +1090,11 @@ class LinearActFn(torch.autograd.Function):
             else:
                 y = gemm(x, W2, True, True, M, N, K, bias=b, act0=act, drop_p=p, seed=seed, stream_id=sid, rng_row=rr,
                          a_planes=xpl, b_planes=wpl, c_planes=cpl, splits=1 if cpl is not None else None)
+        elif p > 0.0 and y0pl is not None:
+            # ... memoized as planes: the draw maps planes to planes (+ the keep-and-positive bits), 8 bytes per element instead of 12
+            cpl, mbits = dropout_planes(y0pl, M, N, p, seed, sid, rr)
+            y = torch.empty(M, N, dtype=torch.float32, device=x.device)       # token: never written, never read
+            LinearActFn.last_maskbits = mbits if act == ACT_RELU else None
         elif p > 0.0:       # memoized act(x W^T + b) of the eval forward: only this forward's dropout draw is new
             if emit and MEMO_PLANES and get_gemm_mode() == "bf16x3":
                 cpl = Planes.alloc((M, N), x.device)
@@ -1044,7 +1106,9 @@ class LinearActFn(torch.autograd.Function):
             LinearActFn.last_maskbits = mbits
         else:
             y = y0
+            cpl = y0pl
         LinearActFn.last_planes = cpl
+        ctx.ypl = cpl if (cpl is not None and cpl.fp32_stale) else None      # y is a token: a backward that needs its values rebuilds them
         ctx.save_for_backward(x, W2, y)
         ctx.cfg = (act, p, seed, sid, M, N, K, W.shape, b is not None, rr)
         ctx.gW, ctx.gb = _arena_grad(W), _arena_grad(b)
@@ -1123,6 +1187,8 @@ class LinearActFn(torch.autograd.Function):
             only = (DG_PLANES_ONLY and need_w and not need_x and xpl0 is not None and M >= 4096 and N % 8 == 0
                     and pre_a_tile_ok(gemm_plan(N, K, M, False, False)[0], False, False, True))
             dpl = Planes.alloc((M, N), dy.device) if only else None
+            if getattr(ctx, "ypl", None) is not None:
+                y = planes_f32(ctx.ypl)       # (the consumer did not take the activation backward into its own epilogue: rare path)
             dpre, db = act_dropout_bwd(dy, y, act, M, N, p, seed, sid, want_bias=need_b, db_out=ctx.gb if need_b else None, rng_row=rr,
                                        planes=dpl, planes_only=only)
             if only:
@@ -1196,11 +1262,15 @@ def prefill_two_layers(X, layer1, layer2):
     if xpl is None or p1 is None or p2 is None:
         return False
     emit = bool(emit1) and bool(gemm_plan_planes(M, 2 * W1m.shape[0], W1m.shape[0]))
+    # layer 1 = the generator's ReLU layer in front of the gated-attention pool: every consumer of its output reads operand planes
+    only = bool(emit and H_PLANES_ONLY and a1 == "relu" and W1m.shape[0] % 32 == 0)
     with torch.no_grad():
         y1, y2, cpl = gemm_two_layers(X, xpl, W1m.detach(), Planes(p1.hi.reshape(W1m.shape), p1.lo.reshape(W1m.shape)),
                                       None if b1 is None else b1.detach(), _ACT[a1],
                                       W2m.detach(), Planes(p2.hi.reshape(W2m.shape), p2.lo.reshape(W2m.shape)),
-                                      None if b2 is None else b2.detach(), _ACT[a2], emit)
+                                      None if b2 is None else b2.detach(), _ACT[a2], emit, y1_planes_only=only)
+    if only:
+        y1._advmil_planes, y1._advmil_planes_only = cpl, True
     PREFILL[(X.data_ptr(), tuple(X.shape), W1.data_ptr(), W1._version, _ACT[a1])] = (y1, cpl)
     PREFILL[(X.data_ptr(), tuple(X.shape), W2.data_ptr(), W2._version, _ACT[a2])] = (y2, None)
     return True
@@ -1253,14 +1323,14 @@ def linear_act(x, W, b, act="none", p=0.0, rng=None, tag="", emit_planes=False):
         emit = "only" if (big and act == "none" and p <= 0.0 and y0 is None and W.shape[0] % 8 == 0 and ATTN_QKV_PLANES) else False
     y = LinearActFn.apply(x2, W, b, _ACT[act], float(p), seed, sid, y0, rr, xpl, wpl, emit)
     cpl, LinearActFn.last_planes = LinearActFn.last_planes, None
-    if pre_planes is not None:
+    if pre_planes is not None and cpl is None:
         cpl = pre_planes                      # the two-layer launch already emitted the planes of this output
     if memo is not None and memo.mode == "record" and p <= 0.0 and not torch.is_grad_enabled():
         memo.store[key] = y
     out = y if len(lead) == 1 else y.reshape(*lead, y.shape[-1])
     if cpl is not None:
         out._advmil_planes = cpl
-        if emit == "only":
+        if emit == "only" or cpl.fp32_stale:
             out._advmil_planes_only = True    # the fp32 values of `out` were never written
     if LinearActFn.last_wants_dy_planes:
         out._advmil_wants_dy_planes = True         # the LayerNorm backward behind this layer may hand dy over as operand planes only
@@ -1305,12 +1375,14 @@ class GatedAttnPoolFn(torch.autograd.Function):
         N, D = h.shape
         ctx.act_fuse = act_fuse
         wcv = wc.detach().reshape(-1)
+        stale = hpl is not None and hpl.fp32_stale            # h is a token: every read below goes through its planes
+        ppl = hpl if stale else None
         if FUSED_GATE_SCORE and p <= 0.0 and N >= 4096 and nograd:
             # no-grad pass (the generator's eval forward of the discriminator update, test_model): nothing needs the [N, 2D] gate
             # activations, so the contraction reduces the score in its epilogue from interleaved branch rows and never stores them
             Wi, bi, wipl = gate_interleave(Wa.detach(), ba.detach(), Wb.detach(), bb.detach(), D, planes=hpl is not None)   # one tiny launch
             s = gate_partial_sum(gemm(h, Wi, True, True, N, 2 * D, D, bias=bi, gate_wc=wcv, a_planes=hpl, b_planes=wipl), bc.detach())
-            A, pooled = softmax_pool(s, h, N, D, seg)
+            A, pooled = softmax_pool(s, h, N, D, seg, ppl)
             ctx.mark_non_differentiable(s)
             return pooled, A, s
         Wab, _ = _stack2(Wa, Wb, D, D)                       # [2D, D]: a view when the two live side by side in the arena
@@ -1321,10 +1393,12 @@ class GatedAttnPoolFn(torch.autograd.Function):
             if pa_ is not None and pb_ is not None and _adjacent(pa_.hi, pb_.hi, 2) and _adjacent(pa_.lo, pb_.lo, 2):
                 wabpl = Planes(pa_.hi.as_strided((2 * D, D), (D, 1), pa_.hi.storage_offset()),
                                pa_.lo.as_strided((2 * D, D), (D, 1), pa_.lo.storage_offset()))
+            if wabpl is None and stale:
+                wabpl = split_planes(Wab.detach().contiguous())
         ab = gemm(h, Wab, True, True, N, 2 * D, D, bias=bab, act0=ACT_TANH, act1=ACT_SIGMOID, act_split=D,
                   a_planes=hpl if wabpl is not None else None, b_planes=wabpl)
         s = gate_score(ab, wcv, bc, N, D, p, seed, sa, sb, rr)
-        A, pooled = softmax_pool(s, h, N, D, seg)
+        A, pooled = softmax_pool(s, h, N, D, seg, ppl)
         ctx.save_for_backward(h, Wab, ab, A, wcv)
         ctx.hpl = hpl                          # h's operand planes: B operand of dWab = dG^T h (with dG as planes: the plane-fed TN kernel)
         ctx.wabpl = wabpl                      # Wab's planes: transposed, the B operand of dh = dG Wab on the plane-fed NT kernel
@@ -1347,7 +1421,8 @@ class GatedAttnPoolFn(torch.autograd.Function):
         dpooled = (torch.zeros(nseg, D, dtype=torch.float32, device=h.device) if dpooled is None
                    else dpooled.contiguous().reshape(nseg, D))
         dA_ = None if dA is None else dA.contiguous()
-        ds = softmax_pool_bwd(dpooled, dA_, A, h, N, D, seg)
+        stale = ctx.hpl is not None and ctx.hpl.fp32_stale    # h is a token (planes only)
+        ds = softmax_pool_bwd(dpooled, dA_, A, h, N, D, seg, ctx.hpl if stale else None)
         need_h = ctx.needs_input_grad[0]
         # bf16x3: dh = dG Wab runs as an NT contraction of dG's planes (emitted by gate_bwd) with the planes of Wab^T (a 2D x D
         # transpose + split: two tiny launches) through the plane-fed kernel, when the shape qualifies
@@ -1373,6 +1448,8 @@ class GatedAttnPoolFn(torch.autograd.Function):
             dG, dwc, dbc, dbias = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb, rng_row=rr, planes=gpl, planes_only=only)
         dh = None
         fuse = ctx.act_fuse if (need_h and only and ctx.act_fuse is not None) else None
+        if fuse is not None and stale and fuse[2] is None:
+            fuse = None                          # (no bit mask and no rows of h to read the mask back from: the layer runs its own backward)
         wtpl = None
         if fuse is not None and dh_nt:
             # the bit-mask form only (a mask read back from h would be a second prefetched operand: the generic kernel's loop)
@@ -1420,10 +1497,10 @@ class GatedAttnPoolFn(torch.autograd.Function):
         nones = (None,) * 9
         apl = gpl if only else None
         if ctx.arena is not None:
-            bpl = ctx.hpl if (apl is not None and gemm_plan_tn_planes(2 * D, D, N)[0]) else None
+            bpl = ctx.hpl if (stale or (apl is not None and gemm_plan_tn_planes(2 * D, D, N)[0])) else None
             gemm(dG, h, False, False, 2 * D, D, N, out=gWab, ldc=D, accumulate=True, a_planes=apl, b_planes=bpl)       # dG^T h
             return (dh, None, None, None, None, None, None) + nones
-        bpl = ctx.hpl if (apl is not None and gemm_plan_tn_planes(2 * D, D, N)[0]) else None
+        bpl = ctx.hpl if (stale or (apl is not None and gemm_plan_tn_planes(2 * D, D, N)[0])) else None
         dWab = gemm(dG, h, False, False, 2 * D, D, N, a_planes=apl, b_planes=bpl)
         return (dh, dWab[:D], dbias[:D], dWab[D:], dbias[D:], dwc.reshape(wcshape), dbc) + nones
 
@@ -1441,6 +1518,10 @@ def gated_attn_pool(h, Wa, ba, Wb, bb, wc, bc, p=0.0, rng=None, tag="", seg=None
     nograd = not torch.is_grad_enabled() or not any(t.requires_grad for t in (h, Wa, ba, Wb, bb, wc, bc))
     hpl = planes_of(h) if (h.shape[0] >= 4096 and h.is_contiguous() and get_gemm_mode() == "bf16x3"
                            and gemm_plan_planes(h.shape[0], 2 * h.shape[1], h.shape[1])) else None
+    if getattr(h, "_advmil_planes_only", False):
+        hpl = planes_of(h)                    # h is an unwritten token: its planes are all there is
+        if hpl is None or not hpl.fp32_stale:
+            raise RuntimeError("advmil_amd: a planes-only activation reached the gated-attention pool without its planes")
     pooled, A, s = GatedAttnPoolFn.apply(h, Wa, ba, Wb, bb, wc, bc, float(p), seed, sa, sb, seg, nograd, rr, hpl,
                                          getattr(h, "_advmil_act_fusable", None))
     return (pooled[0] if seg is None else pooled), A, s

@@ -112,6 +112,16 @@ typedef struct {
    * epilogue parks a wave's words in LDS before its first store: no per-element mask load inside the store loop. */
   const uint32_t* maskbits;
   int64_t ldbits;
+  /* TRAIN-MODE TWIN of an eval-mode ReLU layer (plain plane-fed forms, tiles 85 / 86, layer 1 of a two-layer launch included): beside the
+   * eval output (C / c_hi / c_lo, any of them) the launch writes the operand planes t_hi / t_lo (pitch ldc) of dropout(v) drawn at
+   * (seed, stream_id, drop_p, rng_row) with element index m * (n_split or N) + n -- exactly what advmil_act_dropout_bwd's replay of the
+   * memoized output would draw -- and t_bits[m * ldtbits + n / 32] bit n % 32 = (dropout(v) > 0), the mask the layer's backward takes as
+   * `maskbits`. The reference runs the generator twice per optimizer step over the same bags with the same weights (eval under no_grad for
+   * the discriminator update, model_handler.py:398-400; train for its own update, :420-425): this launch serves both. t_bits may be NULL. */
+  void* t_hi;
+  void* t_lo;
+  uint32_t* t_bits;
+  int64_t ldtbits;
 } advmil_epilogue_t;
 
 size_t advmil_gemm_f32_workspace_bytes(int64_t M, int64_t N, int splits);
@@ -241,6 +251,21 @@ int advmil_softmax_pool_mean_fwd(const float* s, const float* h, int64_t ldh, in
 int advmil_softmax_pool_bwd(const float* dpooled, const float* dA, const float* A, const float* h, int64_t ldh,
                             int64_t N, int64_t D, int nseg, const int64_t* seg_ptr, int64_t max_len, float* ds, void* ws,
                             size_t ws_bytes, advmil_stream_t stream);
+/* The same two calls with h held as its bf16x3 operand planes (h = h_hi + h_lo, exact in fp32; pitch ldh in elements, D % 8 == 0, planes
+ * 16-byte aligned): the pooled tensor of a slab whose producing contraction wrote planes only (advmil_epilogue_t.c_hi with C == NULL) --
+ * round 6: the generator's first layer keeps no fp32 copy of its [rows, 384] output. */
+int advmil_softmax_pool_fwd_planes(const float* s, const void* h_hi, const void* h_lo, int64_t ldh, int64_t N, int64_t D, int nseg,
+                                   const int64_t* seg_ptr, int64_t max_len, float* A, float* pooled, void* ws, size_t ws_bytes,
+                                   advmil_stream_t stream);
+int advmil_softmax_pool_bwd_planes(const float* dpooled, const float* dA, const float* A, const void* h_hi, const void* h_lo, int64_t ldh,
+                                   int64_t N, int64_t D, int nseg, const int64_t* seg_ptr, int64_t max_len, float* ds, void* ws,
+                                   size_t ws_bytes, advmil_stream_t stream);
+/* Train-mode dropout of a tensor held as operand planes [M, N] (N % 32 == 0): out planes = split(dropout(in_hi + in_lo)), drawn at
+ * (seed, stream_id, element index rng_row[m] * N + n) exactly as advmil_act_dropout_bwd's replay draws it, and bits[m * N / 32 + n / 32]
+ * bit n % 32 = (out > 0) (NULL: no bits). The train-mode forward of a ReLU layer whose eval-mode output is memoized as planes
+ * (model/backbone.py:60-66 run twice per optimizer step, model_handler.py:398-400 / 420-425). */
+int advmil_dropout_planes(const void* in_hi, const void* in_lo, int64_t M, int64_t N, float drop_p, const uint64_t* seed, uint64_t stream_id,
+                          const int64_t* rng_row, void* out_hi, void* out_lo, void* bits, advmil_stream_t stream);
 /* dh[n, :] = A[n] * dpooled[rowseg[n], :] -- the backward of a pooling with constant weights (the per-bag mean of the region features in
  * the projection discriminator's region-level inner product, GANSurv.py:96-98). rowseg: int32 bag index per row, NULL = one bag. */
 int advmil_seg_scale_rows(const float* dpooled, const float* A, const int32_t* rowseg, int64_t N, int64_t D, float* dh,

@@ -438,8 +438,11 @@ def test_two_layer_launch_is_bitwise_neutral(kind):
     from advmil_amd.model import MyHandler
 
     def run(two):
-        old = ops.TWO_LAYERS
+        old, old_h = ops.TWO_LAYERS, ops.H_PLANES_ONLY
         ops.TWO_LAYERS = two
+        # (the launch itself is what this test pins: with the round-6 planes-only output of layer 1 the two paths differ by design -- the
+        # pooling then reads hi + lo instead of fp32 rows; tests/test_h_planes_gpu.py covers that mode)
+        ops.H_PLANES_ONLY = False
         try:
             nb, n = 8, 16384                                  # 131072 rows: the size class where the slab keeps resident planes
             calls = []
@@ -462,7 +465,7 @@ def test_two_layer_launch_is_bitwise_neutral(kind):
             assert len(calls) == (2 if two else 0), calls      # one fused launch per D update -- or none
             return h.pop_logs(), {k: v.clone() for k, v in h.netG.state_dict().items()}, {k: v.clone() for k, v in h.netD.state_dict().items()}
         finally:
-            ops.TWO_LAYERS = old
+            ops.TWO_LAYERS, ops.H_PLANES_ONLY = old, old_h
             ops.gemm_two_layers = real
             ops.set_gemm_mode("exact")
 
