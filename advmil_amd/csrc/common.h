@@ -49,6 +49,23 @@ __device__ __forceinline__ float rng_keep(uint64_t key, uint64_t idx, float p, f
   return rng_uniform(key, idx) >= p ? inv_keep : 0.0f;
 }
 
+// Four consecutive elements idx .. idx + 3 with idx % 4 == 0 (a lane's float4): the index's high word -- and with it the term folded in
+// between the two rounds -- is the same for all four (the low word cannot wrap inside an aligned group), so it is formed once instead of
+// four times: one quarter-rate multiply in nine saved per element. Bit-identical to four rng_keep calls.
+__device__ __forceinline__ void rng_keep4(uint64_t key, uint64_t idx, float p, float inv_keep, float (&f)[4]) {
+  const uint32_t lo = (uint32_t)idx + (uint32_t)key;
+  const uint32_t mid = (uint32_t)(key >> 32) ^ ((uint32_t)(idx >> 32) * 0x85ebca77u);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    uint32_t x = lo + (uint32_t)q;
+    x ^= x >> 16; x *= 0x21f0aaadu;
+    x ^= mid;
+    x ^= x >> 15; x *= 0x735a2d97u;
+    x ^= x >> 15;
+    f[q] = ((float)(x >> 8) * 5.9604644775390625e-8f) >= p ? inv_keep : 0.0f;
+  }
+}
+
 // ---- hardware transcendentals with the result made safe to consume (every kernel of this library takes exp / log / rcp / rsq /
 // sqrt through these wrappers; each is ~1 ulp, i.e. ~1e-7 relative, far inside the path's tolerances).
 // v_exp_f32 / v_rcp_f32 run on the quarter-rate transcendental pipe (four 16-lane passes). In the fused gate-score epilogue of the

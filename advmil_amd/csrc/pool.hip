@@ -111,6 +111,54 @@ __global__ __launch_bounds__(256) void gate_score_kernel(const float* __restrict
   // one wave per row, grid-stride over rows; 16-byte loads (D % 4 == 0 on this path), wc kept in registers across rows
   const int64_t D4 = D >> 2;
   const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  if ((D & 3) == 0 && D4 == 96) {
+    // D = 384 (the shipped width): a row is 96 float4 per branch = 1.5 per lane -> TWO rows per wave and iteration are exactly 3 float4 per
+    // lane and branch, no idle lanes (one row per iteration left every second pass half empty: a quarter of the issue slots of a launch
+    // that is bound by its hash arithmetic), two rows' loads in flight. Lane l, pass t: float4 index l + 64 t of the row pair.
+    float4 w[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) w[t] = reinterpret_cast<const float4*>(wc)[(lane + 64 * t) % 96];
+    const float bias = bc[0];
+    for (int64_t n0 = 2 * wave0; n0 < N; n0 += 2 * nwaves) {
+      float accA = 0.f, accB = 0.f;
+      float4 av[3], bv[3];
+      int64_t rowi[3];
+      int qi[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int g = lane + 64 * t;
+        const int64_t n = n0 + (g >= 96 ? 1 : 0);
+        qi[t] = g >= 96 ? g - 96 : g;
+        rowi[t] = n < N ? n : n0;                     // (an odd last row: the second half re-reads the first, weight 0)
+        const float4* ra = reinterpret_cast<const float4*>(ab + rowi[t] * 2 * D);
+        av[t] = ra[qi[t]];
+        bv[t] = ra[D4 + qi[t]];
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        float4 a = av[t], b = bv[t];
+        if (drop) {
+          const uint64_t base = (uint64_t)((rng_row ? rng_row[rowi[t]] : rowi[t]) * D + qi[t] * 4);
+          float fa[4], fb[4];
+          rng_keep4(ka, base, p, inv, fa);
+          rng_keep4(kb, base, p, inv, fb);
+          a.x *= fa[0]; a.y *= fa[1]; a.z *= fa[2]; a.w *= fa[3];
+          b.x *= fb[0]; b.y *= fb[1]; b.z *= fb[2]; b.w *= fb[3];
+        }
+        const float v = a.x * b.x * w[t].x + a.y * b.y * w[t].y + a.z * b.z * w[t].z + a.w * b.w * w[t].w;
+        const bool second = lane + 64 * t >= 96;
+        accA += second ? 0.f : v;
+        accB += second ? v : 0.f;
+      }
+      accA = wave_sum(accA);
+      accB = wave_sum(accB);
+      if (lane == 0) {
+        s[n0] = accA + bias;
+        if (n0 + 1 < N) s[n0 + 1] = accB + bias;
+      }
+    }
+    return;
+  }
   if ((D & 3) == 0 && D4 <= 128) {
     float4 w[2];
 #pragma unroll
@@ -130,10 +178,11 @@ __global__ __launch_bounds__(256) void gate_score_kernel(const float* __restrict
           float4 a = ra[q], b = rb[q];
           if (drop) {
             const uint64_t base = (uint64_t)((rng_row ? rng_row[n] : n) * D + q * 4);
-            a.x *= rng_keep(ka, base, p, inv);     b.x *= rng_keep(kb, base, p, inv);
-            a.y *= rng_keep(ka, base + 1, p, inv); b.y *= rng_keep(kb, base + 1, p, inv);
-            a.z *= rng_keep(ka, base + 2, p, inv); b.z *= rng_keep(kb, base + 2, p, inv);
-            a.w *= rng_keep(ka, base + 3, p, inv); b.w *= rng_keep(kb, base + 3, p, inv);
+            float fa[4], fb[4];
+            rng_keep4(ka, base, p, inv, fa);
+            rng_keep4(kb, base, p, inv, fb);
+            a.x *= fa[0]; a.y *= fa[1]; a.z *= fa[2]; a.w *= fa[3];
+            b.x *= fb[0]; b.y *= fb[1]; b.z *= fb[2]; b.w *= fb[3];
           }
           acc += a.x * b.x * w[t].x + a.y * b.y * w[t].y + a.z * b.z * w[t].z + a.w * b.w * w[t].w;
         }
@@ -308,12 +357,6 @@ __device__ __forceinline__ void planes8(const bf16raw* __restrict__ hi, const bf
   v1.y = __uint_as_float(a.z & 0xffff0000u) + __uint_as_float(b.z & 0xffff0000u);
   v1.z = __uint_as_float(a.w << 16) + __uint_as_float(b.w << 16);
   v1.w = __uint_as_float(a.w & 0xffff0000u) + __uint_as_float(b.w & 0xffff0000u);
-}
-__device__ __forceinline__ float4 planes4(const bf16raw* __restrict__ hi, const bf16raw* __restrict__ lo, int64_t off) {
-  const uint2 a = *reinterpret_cast<const uint2*>(hi + off);
-  const uint2 b = *reinterpret_cast<const uint2*>(lo + off);
-  return make_float4(__uint_as_float(a.x << 16) + __uint_as_float(b.x << 16), __uint_as_float(a.x & 0xffff0000u) + __uint_as_float(b.x & 0xffff0000u),
-                     __uint_as_float(a.y << 16) + __uint_as_float(b.y << 16), __uint_as_float(a.y & 0xffff0000u) + __uint_as_float(b.y & 0xffff0000u));
 }
 
 template <bool MEAN, bool PL = false>
@@ -616,19 +659,30 @@ __global__ __launch_bounds__(256) void pool_bwd_dot_kernel(const float* __restri
   float acc[PBD_ROWS];
 #pragma unroll
   for (int rr = 0; rr < PBD_ROWS; ++rr) acc[rr] = 0.f;
-  if (n0 < end) {
+  if (PL && n0 < end) {
+    // h as planes: 16 bytes of each plane = 8 columns per load. The wave's 4 rows x D / 8 chunks are dealt out lane by lane (D = 384:
+    // 192 chunks = 3 per lane, no idle lanes; 8-byte loads of 4 columns measured 53 us against the fp32 kernel's 42 at the 16-bag slab)
+    const int nch = (int)(D >> 3), items = PBD_ROWS * nch;
+    for (int g = lane; g < items; g += 64) {
+      const int rr = g / nch, ch = g - rr * nch;
+      if (n0 + rr < end) {
+        float4 v0, v1;
+        planes8(reinterpret_cast<const bf16raw*>(h), hlo, (n0 + rr) * ldh + ch * 8, v0, v1);
+        const float4 a0 = *reinterpret_cast<const float4*>(dpb + ch * 8), a1 = *reinterpret_cast<const float4*>(dpb + ch * 8 + 4);
+        const float d = a0.x * v0.x + a0.y * v0.y + a0.z * v0.z + a0.w * v0.w + a1.x * v1.x + a1.y * v1.y + a1.z * v1.z + a1.w * v1.w;
+#pragma unroll
+        for (int k = 0; k < PBD_ROWS; ++k) acc[k] += (k == rr) ? d : 0.f;
+      }
+    }
+  } else if (n0 < end) {
     if ((D & 3) == 0 && (ldh & 3) == 0) {            // 16-byte loads (D = 384 -> 96 float4 per row, 1.5 per lane)
       const float4* d4 = reinterpret_cast<const float4*>(dpb);
       for (int64_t q = lane; q < (D >> 2); q += 64) {
         const float4 a = d4[q];
         float4 v[PBD_ROWS];
 #pragma unroll
-        for (int rr = 0; rr < PBD_ROWS; ++rr) {
-          if constexpr (PL)
-            v[rr] = (n0 + rr < end) ? planes4(reinterpret_cast<const bf16raw*>(h), hlo, (n0 + rr) * ldh + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-          else
-            v[rr] = (n0 + rr < end) ? reinterpret_cast<const float4*>(h + (n0 + rr) * ldh)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int rr = 0; rr < PBD_ROWS; ++rr)
+          v[rr] = (n0 + rr < end) ? reinterpret_cast<const float4*>(h + (n0 + rr) * ldh)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int rr = 0; rr < PBD_ROWS; ++rr) acc[rr] += a.x * v[rr].x + a.y * v[rr].y + a.z * v[rr].z + a.w * v[rr].w;
       }
@@ -680,7 +734,7 @@ static int softmax_pool_bwd_impl(const float* dpooled, const float* dA, const fl
                                  void* ws, size_t ws_bytes, hipStream_t stream) {
   if (!dpooled || !A || !h || !ds || !ws || N <= 0 || D <= 0) return ADVMIL_EINVAL;
   if (ldh < D || (ldh & 3) || ((uintptr_t)h & 15)) return ADVMIL_EINVAL;
-  if (hlo && (((uintptr_t)hlo & 7) || ((uintptr_t)h & 7) || (D & 3) || (((uintptr_t)dpooled) & 15))) return ADVMIL_EINVAL;
+  if (hlo && (((uintptr_t)hlo & 15) || (D & 7) || (ldh & 7) || (((uintptr_t)dpooled) & 15))) return ADVMIL_EINVAL;
   if (!seg_ptr && nseg > 1) return ADVMIL_EINVAL;
   if (!seg_ptr) { nseg = 1; max_len = N; }
   if (nseg < 1 || max_len <= 0 || max_len > N) return ADVMIL_EINVAL;
@@ -729,9 +783,12 @@ __global__ __launch_bounds__(256) void dropout_planes_kernel(const bf16raw* __re
     const uint64_t base = (uint64_t)((rng_row ? rng_row[row] : row) * N + c);
     float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
     uint32_t b = 0u;
+    float f0[4], f1[4];
+    rng_keep4(key, base, p, inv, f0);
+    rng_keep4(key, base + 4, p, inv, f1);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      x[q] *= rng_keep(key, base + q, p, inv);
+      x[q] *= q < 4 ? f0[q & 3] : f1[q & 3];
       b |= (x[q] > 0.f) ? (1u << q) : 0u;
     }
     uint2 h0, l0, h1, l1;
@@ -868,14 +925,15 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
       const float4 b4 = *reinterpret_cast<const float4*>(ab + n * 2 * D + D + m.c4 * 4);
       const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
       float ga[4], gb[4], gw[4];
+      float fa4[4] = {1.f, 1.f, 1.f, 1.f}, fb4[4] = {1.f, 1.f, 1.f, 1.f};
+      if (drop) {
+        const uint64_t idx = (uint64_t)((rng_row ? rng_row[n] : n) * D + m.c4 * 4);
+        rng_keep4(ka, idx, p, inv, fa4);
+        rng_keep4(kb, idx, p, inv, fb4);
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float fa = 1.f, fb = 1.f;
-        if (drop) {
-          const uint64_t idx = (uint64_t)((rng_row ? rng_row[n] : n) * D + m.c4 * 4 + q);
-          fa = rng_keep(ka, idx, p, inv);
-          fb = rng_keep(kb, idx, p, inv);
-        }
+        const float fa = fa4[q], fb = fb4[q];
         const float ad = av[q] * fa, bd = bv[q] * fb;      // post-dropout branch values
         gw[q] = d * ad * bd;                               // d wc[j]
         ga[q] = d * wv[q] * bd * fa * (1.f - av[q] * av[q]);   // d pre_a  (tanh')
