@@ -1086,6 +1086,7 @@ class LinearActFn(torch.autograd.Function):
                 # epilogue writes the planes INSTEAD of the fp32 values; y is an unwritten token that carries shape and autograd identity
                 gemm(x, W2, True, True, M, N, K, bias=b, act0=act, drop_p=p, seed=seed, stream_id=sid, rng_row=rr,
                      a_planes=xpl, b_planes=wpl, c_planes=cpl, c_planes_only=True)
+                cpl.fp32_stale = True
                 y = torch.empty(M, N, dtype=torch.float32, device=x.device)
             else:
                 y = gemm(x, W2, True, True, M, N, K, bias=b, act0=act, drop_p=p, seed=seed, stream_id=sid, rng_row=rr,
@@ -1222,21 +1223,32 @@ class ForwardMemo:
 
     def __init__(self):
         self.mode, self.token, self.rows_ptr, self.store = None, None, None, {}
+        # round 6 -- the chain continues behind the first layer for as long as nothing random happens: `derived` holds the tensors the
+        # record pass produced from the slab by deterministic ops alone (address -> the tensor itself: the memo keeps them ALIVE, so the
+        # allocator cannot hand the address to anything else before the replay has taken them back); a layer applied to one of them is
+        # carried like a layer applied to the slab (ESAT: FC -> LayerNorm/ReLU/mean16 -> in-projection, all of it before the first
+        # dropout of the transformer layer). `ln`: {(y address, gamma address + versions, dup): (emb, mean, rstd)} of ops.ln_relu_mean16.
+        self.derived, self.ln = {}, {}
 
     def begin(self, mode, token, rows):
-        """`rows`: the step slab. Only layers applied DIRECTLY to it are carried: an intermediate tensor's address says nothing
-        about its contents (the allocator reuses addresses), the slab is the one input both forwards provably share."""
+        """`rows`: the step slab. Only layers applied to it -- or to a tensor the record pass DERIVED from it without any random draw
+        (`derived`) -- are carried: any other intermediate tensor's address says nothing about its contents (the allocator reuses
+        addresses)."""
         if token != self.token:
-            self.store.clear()
+            self.store.clear(); self.derived.clear(); self.ln.clear()
         self.mode, self.token, self.rows_ptr = mode, token, rows.data_ptr()
+
+    def knows(self, x):
+        return self.mode is not None and (x.data_ptr() == self.rows_ptr or (MEMO_CHAIN and x.data_ptr() in self.derived))
 
     def end(self, clear=False):
         self.mode = None
         if clear:
-            self.store.clear()
+            self.store.clear(); self.derived.clear(); self.ln.clear()
 
 
 MEMO = ForwardMemo()
+MEMO_CHAIN = os.environ.get("ADVMIL_MEMO_CHAIN", "1") != "0"
 # only slab-sized layers are worth carrying (ADVMIL_MEMO_MIN_ROWS=1000000000 turns the memo off, for A/B timing)
 MEMO_MIN_ROWS = int(os.environ.get("ADVMIL_MEMO_MIN_ROWS", "4096"))
 
@@ -1287,8 +1299,9 @@ def linear_act(x, W, b, act="none", p=0.0, rng=None, tag="", emit_planes=False):
         rng = rng or default_rng(x.device)
         N = W.shape[0]
         sid, seed, rr = rng.site(tag, (x2.shape[0], N), p), rng.seed, rng.row_map(x2.shape[0], tag)
-    memo = MEMO if (MEMO.mode is not None and x2.data_ptr() == MEMO.rows_ptr and x2.shape[0] >= MEMO_MIN_ROWS
-                    and not x2.requires_grad) else None
+    # (the slab itself never needs a gradient; a derived tensor does in the replay -- the layer's backward only needs its INPUT, not how
+    # the output was obtained)
+    memo = MEMO if (MEMO.knows(x2) and x2.shape[0] >= MEMO_MIN_ROWS and (not x2.requires_grad or x2.data_ptr() != MEMO.rows_ptr)) else None
     # W._version: load_state_dict / any in-place torch write to the weight invalidates the entry (the fused Adam kernel writes
     # through raw pointers, which the memo's token -- the optimizer's update count -- covers)
     key = (x2.data_ptr(), tuple(x2.shape), W.data_ptr(), W._version, act) if memo is not None else None
@@ -1327,6 +1340,7 @@ def linear_act(x, W, b, act="none", p=0.0, rng=None, tag="", emit_planes=False):
         cpl = pre_planes                      # the two-layer launch already emitted the planes of this output
     if memo is not None and memo.mode == "record" and p <= 0.0 and not torch.is_grad_enabled():
         memo.store[key] = y
+        memo.derived[y.data_ptr()] = y
     out = y if len(lead) == 1 else y.reshape(*lead, y.shape[-1])
     if cpl is not None:
         out._advmil_planes = cpl
@@ -1532,13 +1546,18 @@ class LNReLUMean16Fn(torch.autograd.Function):
     (model/backbone_utils.py:161-167)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, eps, ycol=None, dy_planes=False, dup=1):
+    def forward(ctx, y, gamma, beta, eps, ycol=None, dy_planes=False, dup=1, memo=None):
         _chk(y, "y")
         y = y.contiguous()
         N, d = y.shape
         ctx.dup = dup
-        epl = Planes.alloc((N // 16, d), y.device) if (dup == 1 and _wants_row_planes(N // 16, d)) else None
-        emb, mean, rstd = ln_relu_mean16_fwd(y, gamma, beta, N, d, eps, planes=epl, dup=dup)
+        if memo is not None:                  # the record pass's result on the same y and parameters (ForwardMemo.ln): nothing to launch
+            emb, mean, rstd = memo
+            epl = None
+        else:
+            epl = Planes.alloc((N // 16, d), y.device) if (dup == 1 and _wants_row_planes(N // 16, d)) else None
+            emb, mean, rstd = ln_relu_mean16_fwd(y, gamma, beta, N, d, eps, planes=epl, dup=dup)
+        LNReLUMean16Fn.last_stats = (mean, rstd)
         LNReLUMean16Fn.last_planes = epl
         ctx.save_for_backward(y, gamma.detach(), beta.detach(), mean, rstd)
         gg, gb = _arena_grad(gamma), _arena_grad(beta)
@@ -1562,7 +1581,7 @@ class LNReLUMean16Fn(torch.autograd.Function):
             dy, dg, db = ln_relu_mean16_bwd(demb.contiguous(), y, gamma, beta, mean, rstd, N, d, ycol_out=ctx.ycol, planes=pl, dup=ctx.dup)
         if pl is not None:
             DY_PLANES[dy.data_ptr()] = (pl, (N, d))
-        return dy, dg, db, None, None, None, None
+        return dy, dg, db, None, None, None, None, None
 
 
 # operand planes of a gradient that was written as planes only: {address of the (unwritten) fp32 token: (Planes, shape)}. The consumer
@@ -1582,8 +1601,18 @@ def ln_relu_mean16(y, gamma, beta, eps=1e-5, ycol_grad=None, dup=1):
     (`_advmil_wants_dy_planes`, set by linear_act: slab-sized layer, no input gradient, no bias of its own, planes of X resident), dy is
     produced as operand planes only."""
     want = bool(LN_DY_PLANES and ycol_grad is not None and getattr(y, "_advmil_wants_dy_planes", False) and y.is_contiguous())
-    emb = LNReLUMean16Fn.apply(y, gamma, beta, eps, ycol_grad, want, int(dup))
+    # forward memo (ForwardMemo.derived / .ln): y came out of the record pass's chain -> LayerNorm/ReLU/mean16 of it is the same in the replay
+    mk = hit = None
+    if MEMO_CHAIN and MEMO.mode is not None and y.is_contiguous() and MEMO.knows(y) and not _wants_row_planes(y.shape[0] // 16, y.shape[1]):
+        mk = (y.data_ptr(), tuple(y.shape), gamma.data_ptr(), gamma._version, beta.data_ptr(), beta._version, float(eps), int(dup))
+        if MEMO.mode == "replay":
+            hit = MEMO.ln.pop(mk, None)
+    emb = LNReLUMean16Fn.apply(y, gamma, beta, eps, ycol_grad, want, int(dup), hit)
     epl, LNReLUMean16Fn.last_planes = getattr(LNReLUMean16Fn, "last_planes", None), None
+    stats, LNReLUMean16Fn.last_stats = getattr(LNReLUMean16Fn, "last_stats", None), None
+    if mk is not None and MEMO.mode == "record" and not torch.is_grad_enabled() and stats is not None:
+        MEMO.ln[mk] = (emb, stats[0], stats[1])
+        MEMO.derived[emb.data_ptr()] = emb
     if epl is not None:
         emb._advmil_planes = epl
     return emb

@@ -104,3 +104,49 @@ def test_step_with_planes_only_h_matches_the_fp32_row_step(drop):
         a, b = ga[k].double(), gb[k].double()
         scale = float(b.abs().max()) + 1e-12
         assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-8, (k, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize("kind", ["patch", "abmil"])
+def test_chained_forward_memo_is_bitwise_neutral(kind):
+    """ForwardMemo.derived (round 6): behind the generator's first layer the record pass's LayerNorm / ReLU / mean16 and the ESAT
+    in-projection are carried into the train-mode forward too (everything in front of the transformer layer's first dropout;
+    model/backbone_utils.py:158-168, 113-127). Skipping a deterministic recomputation must not move a bit: two optimizer steps with
+    the chain == two steps without, dropout ON."""
+    from advmil_amd.config import default_cfg
+    from advmil_amd.model import MyHandler
+    from tests.test_parity_gpu import load_synth
+
+    def run(chain):
+        old = ops.MEMO_CHAIN
+        ops.MEMO_CHAIN = chain
+        try:
+            nb, n = 4, 8192
+            calls = []
+            real = ops.ln_relu_mean16_fwd
+            ops.ln_relu_mean16_fwd = lambda *a, **k: (calls.append(a[3]), real(*a, **k))[1]
+            h = MyHandler(default_cfg(bcb_mode=kind, bp_every_batch=nb, gemm_mode="bf16x3"), device=DEV)
+            load_synth(h.netG, f"G-{kind}:"); load_synth(h.netD, "D-prj:")
+            h.optimizerG.refresh_planes(); h.optimizerD.refresh_planes()
+            h.rng.reset(99)
+            xs = [[H.bag(i, n, DEV), torch.zeros(1, 1, device=DEV)] for i in range(nb)]
+            ys_host = [H.label(i) for i in range(nb)]
+            ys = [y.to(DEV) for y in ys_host]
+            for i in range(2):
+                plan = h._plan(xs, ys, "wlabel", None, ys_host)
+                h._update_disc(i, xs, ys, "wlabel", None, ys_host=ys_host, plan=plan)
+                h._update_gen(i, xs, ys, "wlabel", None, ys_host=ys_host, plan=plan)
+                h.rng.advance(1)
+            torch.cuda.synchronize()
+            return (h.pop_logs(), h.optimizerG.flat_param.clone(), h.optimizerD.flat_param.clone(), len(calls))
+        finally:
+            ops.MEMO_CHAIN = old
+            ops.ln_relu_mean16_fwd = real
+            ops.set_gemm_mode("exact")
+
+    a, b = run(True), run(False)
+    for la, lb in zip(a[0], b[0]):
+        for k in lb:
+            assert float(la[k]) == float(lb[k]), k
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    if kind == "patch":
+        assert a[3] == b[3] - 2, (a[3], b[3])           # one LayerNorm/ReLU/mean16 launch less per optimizer step
