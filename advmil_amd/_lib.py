@@ -27,8 +27,7 @@ class Epilogue(ctypes.Structure):
                 ("maskref", c_void_p), ("ldmask", c_int), ("mask_scale", c_float), ("accumulate", c_int),
                 ("alpha", c_float), ("a_hi", c_void_p), ("a_lo", c_void_p), ("b_hi", c_void_p), ("b_lo", c_void_p),
                 ("c_hi", c_void_p), ("c_lo", c_void_p), ("gate_wc", c_void_p), ("gate_out", c_void_p), ("gate_np", c_int),
-                ("rng_row", c_void_p), ("c2", c_void_p), ("ldc2", c_int64), ("n_split", c_int64), ("bias2", c_void_p), ("colsum", c_void_p), ("maskbits", c_void_p), ("ldbits", c_int64),
-                ("t_hi", c_void_p), ("t_lo", c_void_p), ("t_bits", c_void_p), ("ldtbits", c_int64)]
+                ("rng_row", c_void_p), ("c2", c_void_p), ("ldc2", c_int64), ("n_split", c_int64), ("bias2", c_void_p), ("colsum", c_void_p), ("maskbits", c_void_p), ("ldbits", c_int64)]
 
 
 class DenseLayer(ctypes.Structure):

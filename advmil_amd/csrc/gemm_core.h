@@ -291,10 +291,7 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
   const int64_t N = g.N, ldo = g.ldc;
   float* const out = g.C;
   const bool drop = !PLAIN && e.seed && e.drop_p > 0.0f;
-  // PLAIN launches may carry the layer's TRAIN-MODE TWIN (advmil_epilogue_t.t_hi): the planes of dropout(v) and its keep-and-positive
-  // bits beside the eval-mode output -- the only dropout a plain launch draws
-  const bool twin = PLAIN && e.t_hi != nullptr && e.seed && e.drop_p > 0.0f;
-  const bool mapped = (drop || twin) && e.rng_row;
+  const bool mapped = drop && e.rng_row;
   const int kind = PLAIN ? 0 : (e.rowv ? 1 : (e.maskref ? 2 : (e.accumulate ? 3 : 0)));     // which per-element operand is fetched one sub-tile ahead
   // rank-1 term AND mask in one launch (dh = dG Wab + A dpooled, masked by the first layer's stored output: that layer's activation /
   // dropout backward rides in this epilogue instead of a row pass of its own): a second prefetched per-element operand
@@ -508,30 +505,6 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
           *reinterpret_cast<uint2*>(reinterpret_cast<bf16raw*>(e.c_lo) + off) = l.u;
         }
       }
-      if (twin) {        // the same values under this step's training dropout: planes + one keep-and-positive bit per element
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int rloc = a * 32 + q * 8 + rq;
-          const int64_t srow = mapped ? (int64_t)srow_i[rloc] : rbase + rloc;
-          const int64_t off = (rbase + rloc) * ldo + col;
-          union { __bf16 b[4]; uint2 u; } h, l;
-          uint32_t nib = 0u;
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const float x = res[q][t] * rng_keep(key, (uint64_t)(srow * nsp + col + t), e.drop_p, inv_keep);
-            nib |= (x > 0.0f) ? (1u << t) : 0u;
-            h.b[t] = (__bf16)x;
-            l.b[t] = (__bf16)(x - (float)h.b[t]);
-          }
-          *reinterpret_cast<uint2*>(reinterpret_cast<bf16raw*>(e.t_hi) + off) = h.u;
-          *reinterpret_cast<uint2*>(reinterpret_cast<bf16raw*>(e.t_lo) + off) = l.u;
-          if (e.t_bits) {
-            nib <<= c4;                                                     // c4 = 4 * (lane & 7): the lane's nibble of the 32-column word
-            nib |= __shfl_xor(nib, 1, 64); nib |= __shfl_xor(nib, 2, 64); nib |= __shfl_xor(nib, 4, 64);
-            if (c4 == 0) e.t_bits[(rbase + rloc) * e.ldtbits + (col >> 5)] = nib;
-          }
-        }
-      }
     }
   }
 #undef ADVMIL_EPI_PREFETCH
@@ -591,7 +564,7 @@ __device__ __forceinline__ int gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[TM
                         (!e.c2 || ((((uintptr_t)e.c2) & 15) == 0 && (e.ldc2 & 3) == 0 && (e.n_split & 31) == 0));
     if (stream) {
       if constexpr (EPI == 2) {
-        if (nmode == 0 && (!(e.seed && e.drop_p > 0.0f) || e.t_hi)) {
+        if (nmode == 0 && !(e.seed && e.drop_p > 0.0f)) {
           gemm_epilogue_stream<TM, TN, WR, WC, true>(g, acc, patch, lane, wr, wc, m0, n0, key, inv_keep);
           return TM * TN * 4;
         }

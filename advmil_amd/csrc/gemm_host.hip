@@ -277,11 +277,7 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
     const int tnp = tile == 85 ? 4 : tile == 86 ? 2 : tile % 10, bm = 256, bkt = 32;
     const bool plain = tile == 85 || tile == 86;
     if (tile == 84 && !epi->gate_wc) return ADVMIL_EINVAL;        // 256x256: the fused gate score only
-    const bool twin = epi->t_hi != nullptr;             // the layer's train-mode twin: the only dropout a plain launch may draw
-    if (plain && (epi->gate_wc || epi->rowv || epi->maskref || epi->accumulate || (epi->seed && epi->drop_p > 0.0f && !twin))) return ADVMIL_EINVAL;
-    if (twin && (!plain || !epi->t_lo || !epi->seed || !(epi->drop_p > 0.0f) || epi->drop_p >= 1.0f || (((uintptr_t)epi->t_hi | (uintptr_t)epi->t_lo) & 7) ||
-                 (epi->t_bits && epi->ldtbits < (epi->c2 ? epi->n_split : N) / 32)))
-      return ADVMIL_EINVAL;
+    if (plain && (epi->gate_wc || epi->rowv || epi->maskref || epi->accumulate || (epi->seed && epi->drop_p > 0.0f))) return ADVMIL_EINVAL;
     if (epi->c2) {      // two layers in one launch: the plain forms only, split on a 32-column boundary inside N
       if (!plain || epi->n_split <= 0 || epi->n_split >= N || (epi->n_split & 31) || (epi->ldc2 & 3) || ((uintptr_t)epi->c2 & 15) ||
           epi->act_split != epi->n_split)

@@ -6,8 +6,7 @@ with torch.cuda.graph (hipGraph underneath) and replayed. The ctypes launches go
 the hand-written kernels are captured exactly like torch's own. Dropout/noise stay fresh across replays because
 the kernels read the step seed from device memory and the graph itself bumps it.
 
-Single process: ONE graph (optionally with the generator's training forward as a parallel branch: MyHandler.overlap_gfwd, measured
-slower, off by default).
+Single process: ONE graph.
 
 Under bag-parallel (world > 1) the collectives stay OUTSIDE the graphs by default (four segments: D backward | G backbone forward |
 D Adam + G loss/backward | G Adam), so capture never depends on RCCL's graph support; D's all-reduce is started asynchronously before
@@ -33,7 +32,15 @@ CLEAR_IN_ADAM = os.environ.get("ADVMIL_CLEAR_IN_ADAM", "1") != "0"
 
 class GraphedStep:
     def __init__(self, handler, xs, ys, ys_host, mode="wlabel", label_visible_mask=None, warmup=2, force_segments=False,
-                 capture_collectives=None):
+                 capture_collectives=None, plan=None, keep_warmup=False, pool=None, site_base=None):
+        """plan: a step plan the caller built (the epoch loop's shape-keyed graphs hand over a plan whose device arrays are STATIC and
+        rewritten per batch: model_handler.StaticStepPlan). keep_warmup: the warm-up steps are real training steps of the caller --
+        their logs stay in handler.history and the last one's predictions / scores are kept in `warm_out`."""
+        self.keep_warmup, self.warm_out = bool(keep_warmup), None
+        self.pool = pool                     # a graph memory pool shared with other step graphs of the handler (they never run concurrently)
+        # every pass over the step (warm-up, capture) numbers its dropout / noise call sites from here: the epoch loop's eager steps do
+        # the same, so a replayed step draws exactly what the eager step it stands for would have drawn (same seed, same sites)
+        self.site_base = site_base
         self.force_segments = force_segments
         self.h = handler
         self.wait_events = []                # (start, stop) event pairs around the two exchange waits of the last segmented replay
@@ -45,10 +52,8 @@ class GraphedStep:
         want = bool(capture_collectives and dp.enabled and (dp.world > 1 or getattr(dp, "force", False)) and not force_segments
                     and torch.distributed.get_backend(dp.group) == "nccl")
         self._want_captured = self._agree(want)
-        if handler.dp.world > 1 or force_segments:
-            handler.overlap_gfwd = False     # the segments are separate graphs: a fork event cannot cross from one capture into another
         self.xs, self.ys = xs, ys
-        self.plan = handler._plan(xs, ys, mode, label_visible_mask, ys_host)   # python ints: baked into the graph
+        self.plan = plan if plan is not None else handler._plan(xs, ys, mode, label_visible_mask, ys_host)   # python ints: baked into the graph
         self.lrs = self._lrs()
         self.segments = []
         self.logs = None
@@ -111,11 +116,17 @@ class GraphedStep:
         side.wait_stream(cur)
         with torch.cuda.stream(side):                       # warm-up off the default stream, as capture requires
             for _ in range(warmup):
+                if self.site_base is not None:
+                    h.rng.counter = self.site_base
                 self._eager()
+            if self.keep_warmup and warmup:
+                self.warm_out = (torch.cat(self.preds, dim=0).detach().clone(), torch.cat(self.fakes, dim=0).detach().clone())
         cur.wait_stream(side)
         torch.cuda.synchronize()
+        if self.keep_warmup:
+            saved = list(h.history)          # (the caller's steps: their logs stay)
         del h.history[:]                     # the warm-up steps' own logs are dry runs
-        pool = torch.cuda.graph_pool_handle()
+        pool = self.pool if self.pool is not None else torch.cuda.graph_pool_handle()
         for opt in (h.optimizerD, h.optimizerG):             # a captured zero_grad() launches no fill: replay() hands the graph clean arenas
             opt.capture_assumes_clean = CLEAR_IN_ADAM
         try:
@@ -129,6 +140,8 @@ class GraphedStep:
 
     def _capture_graphs(self, pool):
         h = self.h
+        if self.site_base is not None:
+            h.rng.counter = self.site_base
         if self._want_captured:
             # the exchanges inside the graph: capture on every rank, then agree that it worked everywhere -- else all fall back together
             ok = True

@@ -80,10 +80,8 @@ class SlabStager:
         self.dtype = dtype
         self.store = dtype if store is None else store
         self.dev32 = [None, None]         # bf16 store fed by fp32 host bags: the H2D landing area of one batch (rounded into `dev`)
-        # ADVMIL_COPY_PRIORITY: stream priority of the copy stream (torch: lower number = higher priority; unset = default). Its launches run
-        # under the step's kernels: with a lower priority they take CU slots only where the compute stream leaves them
-        _pr = os.environ.get("ADVMIL_COPY_PRIORITY")
-        self.copy_stream = torch.cuda.Stream(device=self.device) if _pr is None else torch.cuda.Stream(device=self.device, priority=int(_pr))
+        # (a lower stream priority for the copy stream was measured in round 5: nothing -- profiles/r05_probe_staging.txt)
+        self.copy_stream = torch.cuda.Stream(device=self.device)
         self.host = [None, None]
         self.dev = [None, None]
         self.free_evt = [None, None]      # recorded on the compute stream when the step reading pair k is enqueued
@@ -242,10 +240,7 @@ class SlabStager:
         # flagged (`stale`, -> `_advmil_fp32_stale` on the step slab, ops.gemm then takes planes only); a batch that ends up without
         # complete planes or below the handler's plane threshold gets its rows after all (`_backfill`, from `ready`).
         only = bool(derive and pl is not None and PLANES_ONLY_STAGE)
-        if os.environ.get("ADVMIL_STAGE_ABLATE") == "skip":      # (timing experiment: no staging launch at all -- the slab holds garbage)
-            rc = 0
-        else:
-          rc = _lib.lib().advmil_stage_bag(
+        rc = _lib.lib().advmil_stage_bag(
             (x2.data_ptr() if only else dst.data_ptr() + a * C * esz), x2.data_ptr(), n * C * esz,
             None if pl is None else pl.hi.data_ptr() + a * C * 2, None if (pl is None or derive) else planes.hi.data_ptr(),
             None if pl is None else pl.lo.data_ptr() + a * C * 2, None if (pl is None or derive) else planes.lo.data_ptr(),

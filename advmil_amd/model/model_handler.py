@@ -57,6 +57,116 @@ class LazyLog:
         return {k: (float(v) if not isinstance(v, int) else v) for k, v in out.items()}
 
 
+class StaticStepPlan:
+    """A step plan (`MyHandler._plan`) whose device arrays live in ONE static allocation, so that the HIP graph captured over it can be
+    replayed for ANY later step batch of the same KEY -- bags per step, rows of the (padded) slab, number of real pairs / visible labels,
+    slab buffer -- after `rebind` has rewritten the arrays for that batch: bag lengths (segment offsets, per-row bag ids of the slab, of
+    its 16-row regions and of the stacked fake | real regions), labels, real / visible masks, the stacked layout's dropout row map. One
+    pinned buffer, one asynchronous copy per step. The reference's loop has no such state: it re-issues ~480 launches per bag
+    (model_handler.py:311-345); here a ragged resident epoch replays one graph per step like the fixed-shape bench does.
+
+    What may differ between the capture batch and a replayed one: only what lives in the arrays. What may NOT: everything in `key`.
+    Grids of the segmented kernels are sized for the longest bag the key admits (`bag_cap`): workgroups past a bag's end exit at once."""
+
+    @staticmethod
+    def bag_cap(lens, pad, total):
+        """Longest bag the launch grids of a key are sized for: the next power of two above the batch's longest bag (part of the key: a
+        batch with a longer bag takes another graph). Sizing them for the whole slab instead cost 0.16 ms per 16-bag step in empty
+        workgroups of the pooling backward (profiles/r06_step_profile_loop.txt)."""
+        m = max(list(lens) + [int(pad), 1])
+        return int(min(total, max(1024, 1 << (m - 1).bit_length())))
+
+    def __init__(self, handler, plan, lens, pad, cap):
+        import numpy as np
+        self.n, self.dev, self.cap = len(lens), handler.device, int(cap)
+        n, T = self.n, sum(lens) + int(pad)
+        self.T, self.has_pad = T, bool(pad)
+        ns = n + (1 if pad else 0)
+        assert T % 16 == 0 and all(v % 16 == 0 for v in lens)
+        self.has_t2 = plan.t2 is not None
+        self.has_map = plan.rng_rows is not None and "region2" in plan.rng_rows
+        # ---- layout (bytes, every array 16-byte aligned)
+        self.lay, off = {}, 0
+        def put(name, count, dt):
+            nonlocal off
+            self.lay[name] = (off, count, dt)
+            off += (count * np.dtype(dt).itemsize + 15) // 16 * 16
+        put("y", 2 * n, np.float32); put("y_t", n, np.float32); put("y_e", n, np.float32)
+        if self.has_t2:
+            put("t2", 2 * n, np.float32)
+        put("masks", 2 * n, np.float32)
+        put("seg_ptr", ns + 1, np.int64); put("seg16_ptr", ns + 1, np.int64); put("x2_ptr", 2 * ns + 1, np.int64)
+        if self.has_map:
+            put("region2", 2 * (T // 16), np.int64)
+        put("seg_row", T, np.int32); put("seg16_row", T // 16, np.int32); put("x2_row", 2 * (T // 16), np.int32)
+        self.nbytes = off
+        self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=self.dev)
+        tdt = {np.float32: torch.float32, np.int64: torch.int64, np.int32: torch.int32}
+        def view(name):
+            o, c, dt = self.lay[name]
+            return self.buf[o:o + c * np.dtype(dt).itemsize].view(tdt[dt])
+        # ---- the plan's arrays become views of the static buffer (addresses baked by the capture)
+        plan.y = view("y").view(n, 2)
+        plan.y_t, plan.y_e = view("y_t").view(n, 1), view("y_e").view(n, 1)
+        if self.has_t2:
+            plan.t2 = view("t2").view(2 * n, 1)
+        m = view("masks")
+        plan.real_mask = m[:n]
+        if plan.vis_mask is not None:
+            plan.vis_mask = m[n:]
+        seg, seg16 = plan.seg, plan.seg16
+        x2 = seg16.twice()
+        for sg, pn, rn, cap_ in ((seg, "seg_ptr", "seg_row", self.cap), (seg16, "seg16_ptr", "seg16_row", self.cap // 16),
+                                 (x2, "x2_ptr", "x2_row", self.cap // 16)):
+            sg.ptr, sg.rowseg = view(pn), view(rn)
+            sg.max_len = cap_                # grids for the longest bag the key admits (bag_cap)
+            sg.lens = sg.offsets = None      # (host-side copies would go stale: nothing on the ABMIL path reads them after construction)
+            sg._div = {k: v for k, v in sg._div.items() if k != "long"}
+        if self.has_map:
+            plan.rng_rows["region2"] = view("region2")
+        # (plan.vis / plan.is_real stay the capture batch's lists: the step only asks any(vis), which the key's counts fix)
+        self.plan = plan
+
+    def rebind(self, lens, pad, ys_host, is_real, vis, stream=None):
+        """Rewrite the arrays for a batch of the same key: ONE pinned buffer, ONE asynchronous copy (on `stream`, default the current one)."""
+        import numpy as np
+        n, T = self.n, self.T
+        assert len(lens) == n and sum(lens) + int(pad) == T and bool(pad) == self.has_pad and max(list(lens) + [int(pad)]) <= self.cap
+        host = torch.empty(self.nbytes, dtype=torch.uint8, pin_memory=True)      # (the caching host allocator keeps it until the copy ran)
+        hv = host.numpy()
+        def arr(name):
+            o, c, dt = self.lay[name]
+            return hv[o:o + c * np.dtype(dt).itemsize].view(dt)
+        y = torch.cat([h.reshape(1, 2).float() for h in ys_host], dim=0).numpy()
+        arr("y")[:] = y.reshape(-1)
+        arr("y_t")[:] = y[:, 0]
+        arr("y_e")[:] = y[:, 1]
+        if self.has_t2:
+            t2 = arr("t2")
+            t2[:n] = 0.0                     # (rows [0, n): written by the generator's head inside the step)
+            t2[n:] = y[:, 0]
+        mk = arr("masks")
+        mk[:n] = [1.0 if q else 0.0 for q in is_real]
+        mk[n:] = [1.0 if v else 0.0 for v in vis]
+        ls = list(lens) + ([int(pad)] if pad else [])
+        l16 = [v // 16 for v in ls]
+        for pn, rn, ll in (("seg_ptr", "seg_row", ls), ("seg16_ptr", "seg16_row", l16), ("x2_ptr", "x2_row", l16 + l16)):
+            a = np.asarray(ll, dtype=np.int64)
+            p = arr(pn)
+            p[0] = 0
+            np.cumsum(a, out=p[1:])
+            arr(rn)[:] = np.repeat(np.arange(len(ll), dtype=np.int32), a)
+        if self.has_map:                     # MyHandler._rng_row_maps, W = 1 with a pad
+            L, p16 = sum(lens) // 16, (int(pad) + 15) // 16
+            ar, ap = np.arange(L, dtype=np.int64), np.arange(p16, dtype=np.int64)
+            arr("region2")[:] = np.concatenate([ar, 2 * L + ap, L + ar, 2 * L + p16 + 1 + ap])
+        if stream is None:
+            self.buf.copy_(host, non_blocking=True)
+        else:
+            with torch.cuda.stream(stream):
+                self.buf.copy_(host, non_blocking=True)
+
+
 class MyHandler(object):
     def __init__(self, cfg, device=None, parallel=None):
         _check_configs(cfg)
@@ -71,19 +181,21 @@ class MyHandler(object):
         seed_everything(cfg["seed"])
         self.rng = ops.default_rng(self.device)
         self.dp = parallel or BagParallel()
-        # ADVMIL_OVERLAP_GFWD=1: the generator's training forward depends on the generator alone, so from the point where the
-        # discriminator update has its predictions it can run on a second stream (a parallel branch of the step graph), beside the
-        # discriminator's forward / backward / Adam. Python issue order -- hence every dropout site id -- is unchanged and the
-        # results are identical. Measured on the 16 x 8192 step: 3.85 ms against 3.79 ms serial -- the slab kernels of both
-        # branches each want every CU's LDS, so they time-slice and the short launches gain nothing. Off by default.
-        self.overlap_gfwd = os.environ.get("ADVMIL_OVERLAP_GFWD", "0") == "1"
+        # (The generator's training forward as a parallel stream / graph branch beside the discriminator's backward was built in round 3 and
+        # measured slower at every step size -- the slab kernels of both branches each want every CU's LDS --; retired in round 6,
+        # docs/DESIGN_HISTORY.md.)
         # rows of a staged step slab are padded with zero rows to a multiple of this (0 = off): see ingest.SlabStager.pad_rows
         self.slab_pad = int(os.environ.get("ADVMIL_SLAB_PAD", cfg.get("slab_pad", 256)))
+        # shape-keyed step graphs of the epoch loop (StaticStepPlan): cfg['step_graphs'] / ADVMIL_STEP_GRAPHS (1), the row granularity of
+        # their keys, and how many keys are kept
+        self.step_graphs = str(os.environ.get("ADVMIL_STEP_GRAPHS", cfg.get("step_graphs", 1))) != "0"
+        self.step_graph_rows = int(os.environ.get("ADVMIL_STEP_GRAPH_ROWS", cfg.get("step_graph_rows", 2048)))
+        self.step_graphs_max = int(os.environ.get("ADVMIL_STEP_GRAPHS_MAX", cfg.get("step_graphs_max", 24)))
+        self._step_graph_cache, self._step_graph_seen, self._step_graph_pool = {}, {}, None
+        self.step_graph_stats = {"replayed": 0, "captured": 0, "eager": 0}
         # 'fp32' (default) | 'bf16': how bags are held in HBM (staging slab, device-resident cache). 'bf16' = ONE bf16 plane per bag
         # (half the bytes; the contractions over the slab form each product with two MFMAs instead of three); see DESIGN.md
         self.x_storage = os.environ.get("ADVMIL_X_STORAGE", cfg.get("x_storage", "fp32"))
-        self._side_stream = None
-        self._fork_evt = self._join_evt = None
         self.cfg = cfg
         self.bcb = cfg["bcb_mode"]
         self.task = cfg["task"]
@@ -221,6 +333,12 @@ class MyHandler(object):
         fresh = []                               # (cache key, index into x_col) of the bags of this step that came over PCIe
         staged_pos = []                          # indices into x_col of the bags of this step that sit in the staging slab
         i_batch = 0
+        # Every optimizer step numbers its dropout / noise call sites from the same base and advances the device seed by one behind it --
+        # what a captured step does by itself (graphed.GraphedStep) -- so that an eager step and a replayed one draw the same masks. The
+        # base is fixed with the handler's first epoch (a replay leaves the host-side counter where it was: it must not drift with it)
+        if getattr(self, "_site_base", None) is None:
+            self._site_base = self.rng.counter
+        site_base = self._site_base
         for data_idx, data_x, data_y in train_loader:
             i_batch += 1
             yh_col.append(data_y if not data_y.is_cuda else None)
@@ -270,9 +388,13 @@ class MyHandler(object):
                     y_col = [y.to(self.device, non_blocking=True) for y in y_col]
                     y_step = torch.cat(y_col, dim=0)
                 pad = 0
+                bpl = None
                 if staged:                               # growth may have re-based the views: take the final ones
                     if len(staged_pos) == len(x_col):
-                        pad = stager.pad_rows(self.slab_pad)     # whole 256-row tiles for the slab kernels' fast forms
+                        # whole 256-row tiles for the slab kernels' fast forms; with step graphs on, whole `step_graph_rows` (2048): the
+                        # padded row count is part of a graph's key, so coarser steps mean fewer captures (at most 1.6 % more rows at 16 x 8192)
+                        sg_on = self.step_graphs and self.dp.world == 1 and self.bcb == "abmil" and self.slab_pad > 0
+                        pad = stager.pad_rows(self.step_graph_rows if sg_on else self.slab_pad)
                     # (a batch that mixes staged and device bags is concatenated, i.e. read as fp32 rows)
                     for j, v in zip(staged_pos, stager.ready(need_rows=len(staged_pos) != len(x_col))):
                         x_col[j][0] = v
@@ -286,21 +408,82 @@ class MyHandler(object):
                 if self.noise_hook is not None:
                     nz_d = [self.noise_hook("d", int(ix.reshape(-1)[0])) for ix in i_col]
                     nz_g = [self.noise_hook("g", int(ix.reshape(-1)[0])) for ix in i_col]
-                plan = self._plan(x_col, y_col, mode, mask, ys_host, y_step, pad)   # ONE plan per step batch, shared by the D and G updates
-                # bag-parallel: D's gradient exchange is started asynchronously and completed inside the first generator update, after
-                # the generator's backbone forward (which does not depend on D) has been enqueued -> the two overlap
-                overlap = self.dp.world > 1 and num_update_gen > 0
-                preds, fakes = self._update_disc(i_batch, x_col, y_col, mode, mask, ys_host=ys_host, noise=nz_d, plan=plan, defer_apply=overlap)
-                for _ in range(num_update_gen):
-                    self._update_gen(i_batch, x_col, y_col, mode, mask, ys_host=ys_host, noise=nz_g, plan=plan)
+                # ---- shape-keyed step graphs (round 6): a resident ragged step batch whose KEY has been seen before is REPLAYED -- the
+                # static plan's arrays are rewritten for this batch (one small copy), then one graph launch instead of ~53 eager ones
+                replayed = False
+                gkey = None
+                self.rng.counter = site_base
+                if (staged and len(staged_pos) == len(x_col) and self.step_graphs and self.dp.world == 1 and self.bcb == "abmil"
+                        and self.noise_hook is None and num_update_gen == 1 and ys_host is not None and bpl is not None
+                        and not torch.cuda.is_current_stream_capturing()):
+                    n_ = len(x_col)
+                    vis_ = self._vis(mode, n_, mask)
+                    real_ = [bool(float(yh[0, 1]) == 1.0) and vis_[i] for i, yh in enumerate(ys_host)]
+                    lens_ = [self._rows(x[0]) for x in x_col]
+                    x0_ = x_col[0][0]
+                    cap_ = StaticStepPlan.bag_cap(lens_, pad, sum(lens_) + pad)
+                    gkey = (self.bcb, n_, sum(lens_) + pad, cap_, int(x0_.shape[-1]), x0_.dtype, x0_.data_ptr(), bool(pad), sum(real_), n_, sum(vis_),
+                            all(vis_), mode, bool(stager.stale), ops.get_gemm_mode(), self.optimizerG.param_groups[0]["lr"],
+                            self.optimizerD.param_groups[0]["lr"])
+                    ent = self._step_graph_cache.get(gkey)
+                    if ent is not None:
+                        sp, g = ent
+                        sp.rebind(lens_, pad, ys_host, real_, vis_)
+                        g.replay()
+                        self.step_graph_stats["replayed"] += 1
+                        preds_t, fakes_t = torch.cat(g.preds, dim=0).detach(), torch.cat(g.fakes, dim=0).detach()
+                        # this step's logged statistics: the graph rewrites its own tensors with every replay -> one snapshot launch
+                        tens = [t for lg in g.logs for t in lg.tensors]
+                        flat = torch.cat([t.detach().reshape(-1).float() for t in tens])
+                        o = 0
+                        for lg in g.logs:
+                            snap = []
+                            for t in lg.tensors:
+                                snap.append(flat[o:o + t.numel()].view(t.shape)); o += t.numel()
+                            self.log(LazyLog(snap, (lambda *v, f=lg.fn, ib=i_batch: {**f(*v), "i_batch": ib})))
+                        replayed = True
+                    else:
+                        seen = self._step_graph_seen.get(gkey, 0) + 1
+                        self._step_graph_seen[gkey] = seen
+                        if seen >= 2 and len(self._step_graph_cache) < self.step_graphs_max:
+                            # second sight of this key: THIS batch's step is the capture's warm-up step (a real step), then the capture
+                            from ..graphed import GraphedStep
+                            plan = self._plan(x_col, y_col, mode, mask, ys_host, y_step, pad)
+                            sp = StaticStepPlan(self, plan, lens_, pad, cap_)
+                            sp.rebind(lens_, pad, ys_host, real_, vis_)
+                            if self._step_graph_pool is None:
+                                self._step_graph_pool = torch.cuda.graph_pool_handle()
+                            g = GraphedStep(self, x_col, y_col, ys_host, mode, mask, warmup=1, plan=plan, keep_warmup=True,
+                                            pool=self._step_graph_pool, site_base=site_base)
+                            self._step_graph_cache[gkey] = (sp, g)
+                            self.step_graph_stats["captured"] += 1
+                            for q in (-2, -1):   # (the warm-up step's two records were logged under the capture's batch number 0)
+                                lg_ = self.history[q]
+                                if isinstance(lg_, LazyLog):
+                                    self.history[q] = LazyLog(lg_.tensors, (lambda *v, f=lg_.fn, ib=i_batch: {**f(*v), "i_batch": ib}))
+                            preds_t, fakes_t = g.warm_out
+                            replayed = True
+                if not replayed:
+                    plan = self._plan(x_col, y_col, mode, mask, ys_host, y_step, pad)   # ONE plan per step batch, shared by the D and G updates
+                    if gkey is not None:     # (a batch a step graph could stand for: the same launch grids as its capture -- StaticStepPlan)
+                        plan.seg.max_len, plan.seg16.max_len, plan.seg16.twice().max_len = cap_, cap_ // 16, cap_ // 16
+                    # bag-parallel: D's gradient exchange is started asynchronously and completed inside the first generator update, after
+                    # the generator's backbone forward (which does not depend on D) has been enqueued -> the two overlap
+                    overlap = self.dp.world > 1 and num_update_gen > 0
+                    preds, fakes = self._update_disc(i_batch, x_col, y_col, mode, mask, ys_host=ys_host, noise=nz_d, plan=plan, defer_apply=overlap)
+                    for _ in range(num_update_gen):
+                        self._update_gen(i_batch, x_col, y_col, mode, mask, ys_host=ys_host, noise=nz_g, plan=plan)
+                    preds_t, fakes_t = torch.cat(preds, dim=0).detach(), torch.cat(fakes, dim=0)
+                    self.rng.advance(1)
+                    self.step_graph_stats["eager"] += 1
                 for key, j, fp in fresh:                 # first sight of these bags: keep them (and their operand planes) in HBM
                     cache.put(key, x_col[j][0], fp)
                 fresh, staged_pos = [], []
                 if staged:
                     stager.release()
                     staged = False
-                ys_all.append(y_step); yhat_all.append(torch.cat(preds, dim=0).detach())
-                ffake_all.append(torch.cat(fakes, dim=0))
+                ys_all.append(y_step); yhat_all.append(preds_t)
+                ffake_all.append(fakes_t)
                 i_col, x_col, y_col, yh_col = [], [], [], []
         cltor = {"y": None, "y_hat": None, "f_fake": None}
         if ys_all:                                      # one D2H per epoch instead of one per step
@@ -601,9 +784,6 @@ class MyHandler(object):
                                         pred_out=None if plan.t2 is None else plan.t2[:len(xs)])               # [B,1]
         finally:
             ops.MEMO.end()
-        if self.overlap_gfwd and self.dp.world == 1:      # everything _gen_forward reads exists from here on
-            self._fork_evt = torch.cuda.Event()
-            self._fork_evt.record()
         f_real = f2 = None
         # the region embedding is shared by the real and the fake pairs; with real pairs in the step it leaves its kernel stacked twice
         emb = self.netD.embed_rows(X, 2) if plan.n_real > 0 else self.netD.embed_rows(X)
@@ -698,37 +878,21 @@ class MyHandler(object):
             self.rng.rows = None
 
     def _gen_forward_body(self, xs, plan, noise=None):
-        fork, self._fork_evt = self._fork_evt, None
-        main = torch.cuda.current_stream()
-        side = main
-        if fork is not None:
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(device=self.device)
-            side = self._side_stream
-            side.wait_event(fork)
-        with torch.cuda.stream(side):
-            self.optimizerG.zero_grad()
-            X = self._slab(xs, plan)
-            # row-sized pre-dropout layer outputs of the eval forward in _disc_backward are reused -- only when this call belongs
-            # to the SAME step plan (token) and the generator has not been updated since (n_updates); an unpaired call recomputes
-            ops.MEMO.begin("replay", ("G", id(self.netG), getattr(self.optimizerG, "n_updates", 0), plan.token), X)
-            try:
-                feats = self._gen_features(X, plan, xs)
-            finally:
-                ops.MEMO.end(clear=True)
-            pred = self.netG.finish(feats, noise=self._stack_noise(noise))               # pred [B,1], graph kept
-            if side is not main:
-                pred.record_stream(main)
-                self._join_evt = torch.cuda.Event()
-                self._join_evt.record(side)
+        self.optimizerG.zero_grad()
+        X = self._slab(xs, plan)
+        # row-sized pre-dropout layer outputs of the eval forward in _disc_backward are reused -- only when this call belongs
+        # to the SAME step plan (token) and the generator has not been updated since (n_updates); an unpaired call recomputes
+        ops.MEMO.begin("replay", ("G", id(self.netG), getattr(self.optimizerG, "n_updates", 0), plan.token), X)
+        try:
+            feats = self._gen_features(X, plan, xs)
+        finally:
+            ops.MEMO.end(clear=True)
+        pred = self.netG.finish(feats, noise=self._stack_noise(noise))               # pred [B,1], graph kept
         self._g_fwd = (X, pred)
 
     def _gen_finish(self, i_batch, xs, ys, plan):
         """D's score of the predictions (updated D, frozen), the G loss and its ONE backward."""
         X, pred = self.__dict__.pop("_g_fwd")
-        join, self._join_evt = self._join_evt, None
-        if join is not None:
-            torch.cuda.current_stream().wait_event(join)
         with torch.no_grad():                                                  # nothing of D(x) depends on G
             eb, im = self.netD.bag_features_multi(self.netD.embed_rows(X), plan.seg16)
             eb, im = self._bags(eb, plan), self._bags(im, plan)
@@ -760,11 +924,6 @@ class MyHandler(object):
                 torch.autograd.backward(total, grad_tensors=self._one())
         finally:
             ops.DY_PLANES.clear()
-        if join is not None:
-            # the generator's forward ran on the side stream, so autograd ran its backward nodes there too; the weight gradients
-            # are added into the arena by raw kernels (no AccumulateGrad node -> the engine syncs nothing back): the optimizer step
-            # on this stream must wait for them
-            torch.cuda.current_stream().wait_stream(self._side_stream)
         self._st_g = (st, i_batch)
 
     def _reduce_g(self):

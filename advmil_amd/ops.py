@@ -344,11 +344,10 @@ class Planes:
     """bf16x3 operand image of an fp32 matrix: hi = bf16(x), lo = bf16(x - hi), same shape/strides as x
     (include/advmil_hip.h::advmil_epilogue_t.a_hi..c_lo). A contraction given the planes of an operand skips the per-workgroup
     re-split of that operand; results are bit-identical."""
-    __slots__ = ("hi", "lo", "fp32_stale", "twin")
+    __slots__ = ("hi", "lo", "fp32_stale")
 
     def __init__(self, hi, lo):
         self.hi, self.lo = hi, lo               # lo None: a SINGLE-plane operand -- the tensor is bf16 itself (x_storage = "bf16")
-        self.twin = None                        # (Planes, bits) of the layer's train-mode twin, when the producing launch drew it (gemm_two_layers)
         # True: the fp32 tensor these planes belong to was never written (a step slab whose cached bags were staged as planes only,
         # ingest.SlabStager): a contraction given them must read the planes and nothing else
         self.fp32_stale = False
@@ -404,7 +403,6 @@ USE_PLANES = os.environ.get("ADVMIL_PLANES", "1") != "0"
 # costs 2 % (the extra 403 MB of plane writes outweigh the staging they save) -> off unless asked for. Planes of the
 # memo-replayed (dropped) h were neutral while the training-pass gate contraction took the 256x192 tile with the old epilogue; with
 # the persistent 256x256 tile and the plain streaming epilogue they pay (+0.4-0.8 %, two same-box A/B runs) -> on.
-DH_PLANES = os.environ.get("ADVMIL_DH_PLANES", "0") != "0"
 # round 6: dh WITH the first layer's activation backward in its epilogue (rank-1 term + bit mask + bias column sums) on the plane-fed NT
 # kernel (B = the planes of Wab^T: one small transposing copy), instead of the generic kernel's 256x192 tile
 DH_NT_FUSED = os.environ.get("ADVMIL_DH_NT_FUSED", "1") != "0"
@@ -455,6 +453,15 @@ def planes_transposed(pl):
         out.hi.copy_(pl.hi.t())
         out.lo.copy_(pl.lo.t())
     return out
+
+
+def _token(M, N, device):
+    """An fp32 [M, N] tensor that carries shape and autograd identity of a result whose VALUES exist as operand planes only: never
+    written, never to be read (NaN-filled under ADVMIL_POISON_TOKENS, see PlaneHandover)."""
+    t = torch.empty(M, N, dtype=torch.float32, device=device)
+    if POISON_TOKENS:
+        t.fill_(float("nan"))
+    return t
 
 
 def planes_of(x):
@@ -665,7 +672,7 @@ def gemm_two_layers_ok(M, N1, N2, K):
     return gemm_two_layers_tile(M, N1, N2, K) != 0
 
 
-def gemm_two_layers(x, xpl, W1, w1pl, b1, act1, W2, w2pl, b2, act2, emit_planes1=False, y1_planes_only=False, twin=None):
+def gemm_two_layers(x, xpl, W1, w1pl, b1, act1, W2, w2pl, b2, act2, emit_planes1=False, y1_planes_only=False):
     """(y1, y2, planes of y1 | None): y1 = act1(x W1^T + b1) [M, N1], y2 = act2(x W2^T + b2) [M, N2] from ONE launch that stages
     every row of x once (advmil_epilogue_t two-layer form). All operands as Planes; shapes checked by gemm_two_layers_ok.
     The two weight matrices' planes are stacked for the launch (two ~1 MB copies)."""
@@ -686,24 +693,13 @@ def gemm_two_layers(x, xpl, W1, w1pl, b1, act1, W2, w2pl, b2, act2, emit_planes1
     else:
         wcat = Planes(torch.cat((w1pl.hi.reshape(N1, K), w2pl.hi.reshape(N2, K)), dim=0), torch.cat((w1pl.lo.reshape(N1, K), w2pl.lo.reshape(N2, K)), dim=0))
     dev = x.device
-    # y1_planes_only: layer 1's output exists as operand planes only (y1 is an unwritten token). twin = (p, seed, stream id, row map):
-    # layer 1's TRAIN-MODE TWIN rides along (advmil_epilogue_t.t_hi): returned as cpl.twin = (Planes of dropout(y1), keep-and-positive bits)
-    y1 = torch.empty(M, N1, dtype=torch.float32, device=dev)
+    # y1_planes_only: layer 1's output exists as operand planes only (y1 is an unwritten token)
+    y1 = _token(M, N1, dev) if y1_planes_only else torch.empty(M, N1, dtype=torch.float32, device=dev)
     y2 = torch.empty(M, N2, dtype=torch.float32, device=dev)
     cpl = None
-    if emit_planes1 or y1_planes_only or twin is not None:
+    if emit_planes1 or y1_planes_only:
         cpl = Planes.alloc((M, N1), dev)
     e = Epilogue()
-    tw = None
-    if twin is not None:
-        tp, tseed, tsid, trr = twin
-        tpl = Planes.alloc((M, N1), dev)
-        tbits = torch.empty(M, N1 // 32, dtype=torch.int32, device=dev)
-        e.t_hi, e.t_lo, e.t_bits, e.ldtbits = tpl.hi.data_ptr(), tpl.lo.data_ptr(), tbits.data_ptr(), N1 // 32
-        e.drop_p, e.seed, e.stream_id = float(tp), tseed.data_ptr(), int(tsid)
-        if trr is not None:
-            e.rng_row = trr.data_ptr()
-        tw = (tpl, tbits)
     e.bias = None if b1 is None else b1.data_ptr()
     e.bias2 = None if b2 is None else b2.data_ptr()
     e.act0, e.act1, e.act_split = act1, act2, N1
@@ -722,7 +718,6 @@ def gemm_two_layers(x, xpl, W1, w1pl, b1, act1, W2, w2pl, b2, act2, emit_planes1
                                                 ctypes.byref(e), 1, gemm_two_layers_tile(M, N1, N2, K), None, 0, _stream()),
                f"gemm_two_layers[{M}x({N1}+{N2})x{K}]")
     if cpl is not None:
-        cpl.twin = tw
         cpl.fp32_stale = bool(y1_planes_only)
     _stamp("e", f"gemm_nt_planes_kernel<4,two layers,{N1}>", (M, N1 + N2, K, 1), 2.0 * M * (N1 + N2) * K)
     if prof is not None:
@@ -917,14 +912,8 @@ def colsum(x, M, N, out=None):
     return out
 
 
-# activations that a plane-fed contraction reads next leave their producer WITH operand planes (region embedding -> ESAT in-projection,
-# the two post-norm LayerNorm outputs -> FFN / gate branches, the attention output through one split pass -> out-projection)
-ROW_PLANES = os.environ.get("ADVMIL_ROW_PLANES", "0") != "0"      # measured: ESAT 32k 9.33-9.36 ms off, 9.41-9.44 ms on (one 256-row tile per CU: the plane-fed kernel has nothing to overlap) -> opt-in
-
-
-def _wants_row_planes(rows, d):
-    """Would an NT contraction over [rows, d] activations take the plane-fed kernel (any of the widths 384 / 768 / 1152 the layer uses)?"""
-    return bool(ROW_PLANES and USE_PLANES and get_gemm_mode() == "bf16x3" and rows >= 4096 and d % 128 == 0 and gemm_plan_planes(rows, d, d))
+# (Region-level ESAT activations leaving their producers WITH operand planes -- ADVMIL_ROW_PLANES, rounds 4-5 -- measured net slower twice:
+# emitting the planes costs what the plane-fed kernel saves on 32768-row layers. Retired in round 6; profiles/r05_ab_log.txt.)
 
 
 def ln_relu_mean16_fwd(y, gamma, beta, N, d, eps=1e-5, planes=None, dup=1):
@@ -1087,14 +1076,14 @@ class LinearActFn(torch.autograd.Function):
                 gemm(x, W2, True, True, M, N, K, bias=b, act0=act, drop_p=p, seed=seed, stream_id=sid, rng_row=rr,
                      a_planes=xpl, b_planes=wpl, c_planes=cpl, c_planes_only=True)
                 cpl.fp32_stale = True
-                y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+                y = _token(M, N, x.device)
             else:
                 y = gemm(x, W2, True, True, M, N, K, bias=b, act0=act, drop_p=p, seed=seed, stream_id=sid, rng_row=rr,
                          a_planes=xpl, b_planes=wpl, c_planes=cpl, splits=1 if cpl is not None else None)
         elif p > 0.0 and y0pl is not None:
             # ... memoized as planes: the draw maps planes to planes (+ the keep-and-positive bits), 8 bytes per element instead of 12
             cpl, mbits = dropout_planes(y0pl, M, N, p, seed, sid, rr)
-            y = torch.empty(M, N, dtype=torch.float32, device=x.device)       # token: never written, never read
+            y = _token(M, N, x.device)
             LinearActFn.last_maskbits = mbits if act == ACT_RELU else None
         elif p > 0.0:       # memoized act(x W^T + b) of the eval forward: only this forward's dropout draw is new
             if emit and MEMO_PLANES and get_gemm_mode() == "bf16x3":
@@ -1156,7 +1145,7 @@ class LinearActFn(torch.autograd.Function):
             return (dx, None if (dW is None or acc_w) else dW.reshape(wshape), None if (db is None or acc_b) else db,
                     None, None, None, None, None, None, None, None, None)
         if act == ACT_NONE and p <= 0.0:
-            ent = DY_PLANES.pop(dy.data_ptr(), None) if ctx.wants_dy_planes else None
+            ent = DY_PLANES.pop(dy) if ctx.wants_dy_planes else None
             if ent is not None and ent[1] == (M, N) and need_w:
                 # dy arrived as operand planes only (written by the LayerNorm backward): dW = dy^T X with both operands pre-split
                 dpl, xpl0 = ent[0], ctx.xpl
@@ -1165,15 +1154,15 @@ class LinearActFn(torch.autograd.Function):
                     return None, None, None, None, None, None, None, None, None, None, None, None
                 dW = gemm(None, x, False, False, N, K, M, a_planes=dpl, b_planes=xpl0).reshape(wshape)
                 return None, dW, None, None, None, None, None, None, None, None, None, None
-            if ctx.wants_dy_planes and any(v[1] == (M, N) for v in DY_PLANES.values()):
+            if ctx.wants_dy_planes and DY_PLANES.pending((M, N)):
                 raise RuntimeError("advmil_amd: a gradient written as operand planes only did not reach the layer that asked for it "
                                    "(autograd re-wrapped the token tensor?)")
             dpre = dy
             if need_b:
                 db = colsum(dy, M, N, out=ctx.gb)
         else:
-            ent = DY_PLANES.pop(dy.data_ptr(), None) if ctx.act_fusable else None
-            if ent is not None and ent[1] == (M, N) and len(ent) > 2 and ent[2] == "dpre":
+            ent = DY_PLANES.pop(dy) if ctx.act_fusable else None
+            if ent is not None and ent[1] == (M, N) and ent[2] == "dpre":
                 # the consumer of y already applied this layer's activation / dropout backward in its dh contraction's epilogue: `dy` is a
                 # token, dpre arrives as operand planes, the bias gradient is merged: only the weight gradient is left
                 dpl, xpl0 = ent[0], ctx.xpl
@@ -1444,15 +1433,13 @@ class GatedAttnPoolFn(torch.autograd.Function):
         # (round 6: with the first layer's activation backward in its epilogue -- ctx.act_fuse -- the launch no longer stays on the generic
         # kernel: the plane-fed kernel's full epilogue carries the rank-1 + bit-mask + column-sum form too)
         dh_tile = gemm_plan_planes(N, D, 2 * D) if (need_h and USE_PLANES and get_gemm_mode() == "bf16x3") else 0
-        dh_nt = bool(dh_tile and (DH_PLANES or (DH_NT_FUSED and ctx.act_fuse is not None and ctx.act_fuse[2] is not None
-                                                and getattr(ctx, "wabpl", None) is not None)))
-        if dh_nt:
-            gpl = Planes.alloc((N, 2 * D), h.device)
+        dh_nt = bool(dh_tile and DH_NT_FUSED and ctx.act_fuse is not None and ctx.act_fuse[2] is not None
+                     and getattr(ctx, "wabpl", None) is not None and int(_lib.lib().advmil_gemm_f32_colsum_rows(dh_tile, N, D)) > 0)
         # bf16x3, slab-sized: dG is consumed by exactly two contractions (dh = dG Wab, dWab = dG^T h) that would split it into hi + lo
         # anyway -> the gate backward writes the planes INSTEAD of the fp32 values (same bytes) and both take their A operand pre-split
         only = (DG_PLANES_ONLY and USE_PLANES and get_gemm_mode() == "bf16x3" and N >= 4096 and (2 * D) % 8 == 0
                 and pre_a_tile_ok(gemm_plan(2 * D, D, N, False, False)[0], False, False)
-                and (not need_h or dh_nt or pre_a_tile_ok(gemm_plan(N, D, 2 * D, True, False)[0], True, False)))
+                and (not need_h or pre_a_tile_ok(gemm_plan(N, D, 2 * D, True, False)[0], True, False)))
         if only and gpl is None:
             gpl = Planes.alloc((N, 2 * D), h.device)
         if ctx.arena is not None:
@@ -1467,12 +1454,9 @@ class GatedAttnPoolFn(torch.autograd.Function):
         wtpl = None
         if fuse is not None and dh_nt:
             # the bit-mask form only (a mask read back from h would be a second prefetched operand: the generic kernel's loop)
-            nrow = int(_lib.lib().advmil_gemm_f32_colsum_rows(dh_tile, N, D)) if fuse[2] is not None else 0
-            if nrow > 0:
-                tile = dh_tile
-                wtpl = planes_transposed(ctx.wabpl) if getattr(ctx, "wabpl", None) is not None else split_planes(Wab.t().contiguous())
-            else:
-                fuse = None
+            nrow = int(_lib.lib().advmil_gemm_f32_colsum_rows(dh_tile, N, D))
+            tile = dh_tile
+            wtpl = planes_transposed(ctx.wabpl)
         elif fuse is not None:
             tile = gemm_plan(N, D, 2 * D, True, False)[0]
             nrow = int(_lib.lib().advmil_gemm_f32_colsum_rows(tile, N, D)) if pre_a_tile_ok(tile, True, False) else 0
@@ -1497,14 +1481,10 @@ class GatedAttnPoolFn(torch.autograd.Function):
             if gb1 is not None:
                 _lib.check(_lib.lib().advmil_merge_partials(_p(cws), nrow, D, D, _p(gb1), 1, _stream()), "merge_partials")
             dh = torch.empty(N, D, dtype=torch.float32, device=h.device)      # token: never written, never read
-            DY_PLANES[dh.data_ptr()] = (dpl, (N, D), "dpre")
+            DY_PLANES.put(dh, dpl, (N, D), "dpre")
         elif need_h:
             # dG [N,2D] . Wab [2D,D]  +  A[n] * dpooled[bag(n), d]   (pooling's direct path, rank-1 per bag)
-            if dh_nt:
-                WabT = Wab.t().contiguous()                                       # [D, 2D]: k (= 2D) contiguous
-                dh = gemm(None if only else dG, WabT, True, True, N, D, 2 * D, rowv=A, colv=dpooled,
-                          rowseg=None if seg is None else seg.rowseg, a_planes=gpl, b_planes=split_planes(WabT))
-            elif only:
+            if only:
                 dh = gemm(None, Wab, True, False, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg, a_planes=gpl)
             else:
                 dh = gemm(dG, Wab, True, False, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg)
@@ -1555,7 +1535,7 @@ class LNReLUMean16Fn(torch.autograd.Function):
             emb, mean, rstd = memo
             epl = None
         else:
-            epl = Planes.alloc((N // 16, d), y.device) if (dup == 1 and _wants_row_planes(N // 16, d)) else None
+            epl = None
             emb, mean, rstd = ln_relu_mean16_fwd(y, gamma, beta, N, d, eps, planes=epl, dup=dup)
         LNReLUMean16Fn.last_stats = (mean, rstd)
         LNReLUMean16Fn.last_planes = epl
@@ -1580,13 +1560,56 @@ class LNReLUMean16Fn(torch.autograd.Function):
         else:
             dy, dg, db = ln_relu_mean16_bwd(demb.contiguous(), y, gamma, beta, mean, rstd, N, d, ycol_out=ctx.ycol, planes=pl, dup=ctx.dup)
         if pl is not None:
-            DY_PLANES[dy.data_ptr()] = (pl, (N, d))
+            DY_PLANES.put(dy, pl, (N, d))
         return dy, dg, db, None, None, None, None, None
 
 
-# operand planes of a gradient that was written as planes only: {address of the (unwritten) fp32 token: (Planes, shape)}. The consumer
-# (LinearActFn.backward of the FC that produced the normalised tensor) pops its entry; a token nobody claims is a bug and raises there.
-DY_PLANES = {}
+# operand planes of a gradient that was written as planes only. The consumer (LinearActFn.backward of the FC that produced the normalised
+# tensor) pops its entry; a token nobody claims is a bug and raises there.
+class PlaneHandover:
+    """Gradients that exist as operand planes only, on their way from the backward that produced them to the ONE backward that consumes
+    them (autograd re-wraps gradient tensors, so attributes do not survive the trip; the fp32 `token` it carries is never written).
+    Per THREAD (autograd runs a handler's backward on the calling thread: model_handler sets set_multithreading_enabled(False)), keyed
+    by (device, address of the token) and holding the token itself -- while an entry lives the allocator cannot hand that address to
+    another tensor, so a stale entry can never meet a reused address. A token nobody claims raises in the consumer (`pending`) and the
+    handlers clear the table behind every backward. ADVMIL_POISON_TOKENS=1 (the GPU test suite sets it) fills every token with NaN, so
+    that anything that READS one -- a hook, retain_grad, a second consumer -- shows up instead of computing on garbage."""
+
+    def __init__(self):
+        import threading
+        self._tl = threading.local()
+
+    def _d(self):
+        d = getattr(self._tl, "d", None)
+        if d is None:
+            d = self._tl.d = {}
+        return d
+
+    def put(self, token, planes, shape, kind=None):
+        if POISON_TOKENS:
+            token.fill_(float("nan"))
+        self._d()[(token.device.index, token.data_ptr())] = (planes, tuple(shape), kind, token)
+
+    def pop(self, grad):
+        """(planes, shape, kind) handed over under the tensor `grad` arrived as, or None."""
+        ent = self._d().pop((grad.device.index, grad.data_ptr()), None)
+        return None if ent is None else ent[:3]
+
+    def pending(self, shape):
+        return any(v[1] == tuple(shape) for v in self._d().values())
+
+    def __len__(self):
+        return len(self._d())
+
+    def __bool__(self):
+        return bool(self._d())
+
+    def clear(self):
+        self._d().clear()
+
+
+POISON_TOKENS = os.environ.get("ADVMIL_POISON_TOKENS", "0") == "1"
+DY_PLANES = PlaneHandover()
 LN_DY_PLANES = os.environ.get("ADVMIL_LN_DY_PLANES", "1") != "0"
 
 
@@ -1603,7 +1626,7 @@ def ln_relu_mean16(y, gamma, beta, eps=1e-5, ycol_grad=None, dup=1):
     want = bool(LN_DY_PLANES and ycol_grad is not None and getattr(y, "_advmil_wants_dy_planes", False) and y.is_contiguous())
     # forward memo (ForwardMemo.derived / .ln): y came out of the record pass's chain -> LayerNorm/ReLU/mean16 of it is the same in the replay
     mk = hit = None
-    if MEMO_CHAIN and MEMO.mode is not None and y.is_contiguous() and MEMO.knows(y) and not _wants_row_planes(y.shape[0] // 16, y.shape[1]):
+    if MEMO_CHAIN and MEMO.mode is not None and y.is_contiguous() and MEMO.knows(y):
         mk = (y.data_ptr(), tuple(y.shape), gamma.data_ptr(), gamma._version, beta.data_ptr(), beta._version, float(eps), int(dup))
         if MEMO.mode == "replay":
             hit = MEMO.ln.pop(mk, None)
@@ -1731,11 +1754,7 @@ def mha(qkv, nhead, p=0.0, rng=None, seg=None, rowoff=None):
     planes = getattr(qkv, "_advmil_planes", None) if qkv.is_contiguous() else None
     if getattr(qkv, "_advmil_planes_only", False) and planes is None:
         raise RuntimeError("advmil_amd: qkv was produced as operand planes only and lost them on the way to ops.mha")
-    out = MhaFn.apply(qkv, nhead, float(p), seed, sid, seg, rowoff, planes)
-    if _wants_row_planes(out.shape[0], out.shape[1]):
-        # (the forward kernel sits at its 128-register bound: its epilogue takes no plane stores; one split pass over [L, d] instead)
-        out._advmil_planes = split_planes(out.detach())
-    return out
+    return MhaFn.apply(qkv, nhead, float(p), seed, sid, seg, rowoff, planes)
 
 
 class AddDropoutLayerNormFn(torch.autograd.Function):
@@ -1753,7 +1772,7 @@ class AddDropoutLayerNormFn(torch.autograd.Function):
         mean = torch.empty(R, dtype=torch.float32, device=dev)
         rstd = torch.empty(R, dtype=torch.float32, device=dev)
         g_, b_ = gamma.detach(), beta.detach()
-        ypl = Planes.alloc((R, d), dev) if _wants_row_planes(R, d) else None
+        ypl = None
         AddDropoutLayerNormFn.last_planes = ypl
         _lib.check(_lib.lib().advmil_add_dropout_ln_fwd(_p(x), _p(o), _p(g_), _p(b_), eps, R, d, p, _p(seed if p > 0.0 else None), sid,
                                                         _p(rr if p > 0.0 else None), _p(z), _p(y), _p(mean), _p(rstd),

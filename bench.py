@@ -264,7 +264,6 @@ def in_step_launch_us(torch, ops, case, replays=8):
     from advmil_amd.graphed import GraphedStep
     h = case.h
     st = ops.Stamps(case.dev)
-    ov, h.overlap_gfwd = h.overlap_gfwd, False          # one stream: a bracketed launch must not share the chip with another branch
     idx = list(range(case.bags))
     ops.STAMPS = st
     try:
@@ -280,7 +279,6 @@ def in_step_launch_us(torch, ops, case, replays=8):
             for name, shape, flops, us in st.durations_us(start=len(st.tags) - per):
                 a = acc.setdefault((name, shape), {"flops": flops, "us": []})
                 a["us"].append(us)
-    h.overlap_gfwd = ov
     h.history.clear()
     del g
     return {k: {"flops": v["flops"], "us": sum(v["us"]) / len(v["us"]), "n": len(v["us"]) // replays} for k, v in acc.items()}
@@ -597,9 +595,25 @@ def product_loop(args, torch, dev, case):
                                        "D2D copy + its plane split, later visits are hits (this synthetic epoch walks its %d distinct patients "
                                        "%.1f times, see `cache`)" % (distinct, (nbag - 2 * args.bags) / distinct))
     out["epoch1_fill_cache"]["cache"] = st1
-    out["eager_resident_ragged"] = ent(d2, "same loop, second epoch: every bag served from the HBM cache (no PCIe); step slab + operand planes "
-                                           "assembled by D2D copies on the copy stream under the previous step; eager launches")
-    out["eager_resident_ragged"]["cache"] = None if cache is None else cache.stats()
+    out["epoch2_resident_capturing"] = ent(d2, "same loop, second epoch: every bag served from the HBM cache (no PCIe); the epoch's step-batch keys "
+                                               "are new (cached bags are staged as operand planes only): first sight eager, second sight = capture of "
+                                               "the key's step graph (its cost is in this epoch), later batches replayed")
+    sg0 = dict(hh.step_graph_stats)
+    d3 = epoch("train")                                                          # epoch 3: steady state of a long run
+    sg1 = dict(hh.step_graph_stats)
+    out["resident_ragged"] = ent(d3, "same loop, third epoch (steady state): every bag from the HBM cache, step slab + operand planes assembled by D2D "
+                                     "copies on the copy stream under the previous step; every step batch whose key (bags, padded slab rows, real "
+                                     "pairs, slab buffer) has a captured graph is REPLAYED with its plan arrays rewritten (MyHandler step graphs), "
+                                     "others run eagerly")
+    out["resident_ragged"]["cache"] = None if cache is None else cache.stats()
+    out["resident_ragged"]["steps_replayed_captured_eager"] = [sg1[k] - sg0[k] for k in ("replayed", "captured", "eager")]
+    out["resident_ragged"]["step_graphs_held"] = len(hh._step_graph_cache)
+    # the same steady-state epoch with every step issued eagerly (what rounds 3-5 reported as the resident epoch)
+    hh.step_graphs_max, keep = 0, (hh._step_graph_cache, hh.step_graphs_max)
+    hh._step_graph_cache = {}
+    d4 = epoch("train")
+    hh._step_graph_cache, hh.step_graphs_max = keep
+    out["eager_resident_ragged"] = ent(d4, "same epoch with every step issued eagerly (no step graph taken): ~53 launches per step from Python")
 
     # ---- the same loop with the bags held as ONE bf16 plane (cfg x_storage = 'bf16'): a loader that stores bf16 features hands over
     # half the bytes (PCIe, staging slab, device cache); fp32 host bags would cross PCIe as they are and be rounded on the copy stream
@@ -891,11 +905,9 @@ def main():
         if rank == 0:
             ops.KERNEL_PROFILE = []
         case.cursor = 0
-        ov, h.overlap_gfwd = h.overlap_gfwd, False        # one stream: a bracketed launch must not share the chip with another branch
         for _ in range(nprof):
             case.eager_step()
         torch.cuda.synchronize()
-        h.overlap_gfwd = ov
         h.history.clear()
         beat("instrumented eager pass done")
     if rank == 0 and not args.no_roofline:

@@ -112,16 +112,6 @@ typedef struct {
    * epilogue parks a wave's words in LDS before its first store: no per-element mask load inside the store loop. */
   const uint32_t* maskbits;
   int64_t ldbits;
-  /* TRAIN-MODE TWIN of an eval-mode ReLU layer (plain plane-fed forms, tiles 85 / 86, layer 1 of a two-layer launch included): beside the
-   * eval output (C / c_hi / c_lo, any of them) the launch writes the operand planes t_hi / t_lo (pitch ldc) of dropout(v) drawn at
-   * (seed, stream_id, drop_p, rng_row) with element index m * (n_split or N) + n -- exactly what advmil_act_dropout_bwd's replay of the
-   * memoized output would draw -- and t_bits[m * ldtbits + n / 32] bit n % 32 = (dropout(v) > 0), the mask the layer's backward takes as
-   * `maskbits`. The reference runs the generator twice per optimizer step over the same bags with the same weights (eval under no_grad for
-   * the discriminator update, model_handler.py:398-400; train for its own update, :420-425): this launch serves both. t_bits may be NULL. */
-  void* t_hi;
-  void* t_lo;
-  uint32_t* t_bits;
-  int64_t ldtbits;
 } advmil_epilogue_t;
 
 size_t advmil_gemm_f32_workspace_bytes(int64_t M, int64_t N, int splits);

@@ -16,6 +16,9 @@ def pytest_configure(config):
     # library's own default is bf16x3 (advmil_amd/_lib.py), which would run the 2e-6 "same result on two paths" comparisons at
     # 2^-17 per product. Child processes of the suite (two-rank workers, fuzzers) inherit the setting.
     os.environ["ADVMIL_GEMM_MODE"] = "exact"
+    # unwritten fp32 tokens of gradients / activations that exist as operand planes only are filled with NaN under the suite: anything
+    # that reads one (instead of its planes) poisons a checked result (advmil_amd/ops.py::PlaneHandover)
+    os.environ["ADVMIL_POISON_TOKENS"] = "1"
 
 
 @pytest.fixture(scope="session")

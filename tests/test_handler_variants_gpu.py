@@ -392,43 +392,6 @@ def test_forward_memo_is_bitwise_neutral(kind):
             assert torch.equal(sa[k], sb[k]), k
 
 
-@pytest.mark.parametrize("graph", [False, True])
-def test_parallel_generator_forward_branch_is_bitwise_neutral(graph):
-    """MyHandler.overlap_gfwd (ADVMIL_OVERLAP_GFWD=1) runs the generator's training forward on a second stream / as a parallel
-    graph branch beside the discriminator's backward. Same Python issue order, same dropout sites: with dropout ON, two optimizer
-    steps must equal the serial schedule bit for bit, eagerly and under HIP-graph replay."""
-    from advmil_amd.graphed import GraphedStep
-    from advmil_amd.model import MyHandler
-
-    def run(overlap):
-        nb, n = 4, 4096                                      # slab-sized rows: the memo and the plane paths are active
-        h = MyHandler(default_cfg(bcb_mode="abmil", bp_every_batch=nb), device=DEV)
-        h.overlap_gfwd = overlap
-        load_synth(h.netG, "G-abmil:"); load_synth(h.netD, "D-prj:")
-        h.rng.reset(4321)
-        X = torch.randn(nb * n, 1024, device=DEV, generator=torch.Generator(device=DEV).manual_seed(9))
-        xs = [[X[i * n:(i + 1) * n].unsqueeze(0), torch.zeros(1, 1)] for i in range(nb)]
-        ys = [H.label(i).to(DEV) for i in range(nb)]
-        ys_host = [H.label(i) for i in range(nb)]
-        if graph:
-            g = GraphedStep(h, xs, ys, ys_host, warmup=1)
-            for _ in range(2):
-                g.replay()
-        else:
-            for i in range(2):
-                plan = h._plan(xs, ys, "wlabel", None, ys_host)
-                h._update_disc(i, xs, ys, "wlabel", None, ys_host=ys_host, plan=plan)
-                h._update_gen(i, xs, ys, "wlabel", None, ys_host=ys_host, plan=plan)
-                h.rng.advance(1)
-        torch.cuda.synchronize()
-        return {k: v.clone() for k, v in h.netG.state_dict().items()}, {k: v.clone() for k, v in h.netD.state_dict().items()}
-
-    a, b = run(False), run(True)
-    for sa, sb in zip(a, b):
-        for k in sa:
-            assert torch.equal(sa[k], sb[k]), k
-
-
 @pytest.mark.parametrize("kind", ["abmil", "patch"])
 def test_two_layer_launch_is_bitwise_neutral(kind):
     """The D update runs the generator's and the discriminator's first layer over the step slab as ONE plane-fed launch

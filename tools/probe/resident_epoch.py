@@ -42,7 +42,7 @@ loader = _DL(_DS(loader))
 hh._train_each_epoch(loader, "train")
 torch.cuda.synchronize()
 out = []
-for rep in range(3):
+for rep in range(5):
     t0 = time.perf_counter()
     hh._train_each_epoch(loader, "train")
     ti = time.perf_counter() - t0
