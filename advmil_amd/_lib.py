@@ -27,7 +27,8 @@ class Epilogue(ctypes.Structure):
                 ("maskref", c_void_p), ("ldmask", c_int), ("mask_scale", c_float), ("accumulate", c_int),
                 ("alpha", c_float), ("a_hi", c_void_p), ("a_lo", c_void_p), ("b_hi", c_void_p), ("b_lo", c_void_p),
                 ("c_hi", c_void_p), ("c_lo", c_void_p), ("gate_wc", c_void_p), ("gate_out", c_void_p), ("gate_np", c_int),
-                ("rng_row", c_void_p), ("c2", c_void_p), ("ldc2", c_int64), ("n_split", c_int64), ("bias2", c_void_p), ("colsum", c_void_p), ("maskbits", c_void_p), ("ldbits", c_int64)]
+                ("rng_row", c_void_p), ("c2", c_void_p), ("ldc2", c_int64), ("n_split", c_int64), ("bias2", c_void_p), ("colsum", c_void_p), ("maskbits", c_void_p), ("ldbits", c_int64),
+                ("gate_bits_a", c_void_p), ("gate_bits_b", c_void_p), ("ldgbits", c_int64), ("c_rows_pair32", c_int)]
 
 
 class DenseLayer(ctypes.Structure):
@@ -72,7 +73,7 @@ SIGNATURES = {
                                 c_int64, ctypes.POINTER(Epilogue), c_int, c_void_p, c_size_t, c_void_p]),
     "advmil_split_planes": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "advmil_stage_bag": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "advmil_gate_interleave": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "advmil_gate_interleave": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "advmil_gate_partial_sum": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
     "advmil_gemm_f32_gate_blocks": (c_int, [c_int, c_int64]),
     "advmil_gemm_f32_colsum_rows": (c_int64, [c_int, c_int64, c_int64]),
@@ -111,10 +112,10 @@ SIGNATURES = {
     "advmil_softmax_pool_bwd_planes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p,
                                                c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "advmil_dropout_planes": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p,
-                                      c_void_p]),
+                                      c_float, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
     "advmil_gate_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "advmil_gate_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_uint64, c_uint64, c_int64, c_int64,
-                                c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
                                 c_void_p]),
     "advmil_colsum_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "advmil_act_dropout_bwd": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_uint64, c_int64, c_int64, c_void_p,

@@ -284,7 +284,7 @@ struct OperandStage {
 // per-element operand -- 30 registers less, which is what lets the 256x256 persistent tile carry this epilogue.
 template <int TM, int TN, int WR, int WC, bool PLAIN = false>
 __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (&acc)[TM][TN], float* patch, int lane, int wr, int wc,
-                                                     int64_t m0, int64_t n0, uint64_t key, float inv_keep) {
+                                                     int64_t m0, int64_t n0, uint64_t key, float inv_keep, int nt_i = 0) {
   const advmil_epilogue_t& e = g.epi;
   const int i = lane & 31, hi = lane >> 5;
   const int c4 = (lane & 7) * 4, rq = lane >> 3;
@@ -298,6 +298,13 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
   const bool rmask = !PLAIN && kind == 1 && e.maskref != nullptr;
   const bool csum = !PLAIN && e.colsum != nullptr;      // per-wave column sums of the final values (the bias gradient of that layer)
   const bool bmask = !PLAIN && e.maskbits != nullptr;   // the mask as bits: the wave's words are parked in LDS, no load in the store loop
+  // PLAIN launches only -- the TRAINING pass of the gated attention scorer (round 6): B's rows are the two branches in blocks of 32
+  // ([a_0..31 | b_0..31 | a_32..63 | ...]: advmil_gate_interleave, pair32), so sub-tile 2u of a wave holds tanh branch columns j and
+  // sub-tile 2u + 1 the sigmoid branch columns of the SAME j in the same lanes. The activations are stored as always (the backward
+  // needs them); in passing, each row's  sum_j (a_j keep_a)(b_j keep_b) wc_j  over the wave's columns goes to gate_out -- the score
+  // pass over the stored [rows, 2D] activations (403 MB at the 16-bag slab) never runs. The keep bits come from gate_bits_a / _b
+  // (advmil_dropout_planes draws them beside the first layer's own mask): parked in LDS, no hash in the epilogue.
+  const bool gpair = PLAIN && e.gate_wc != nullptr && e.gate_bits_a != nullptr;
   const float* const xbase = kind == 1 ? e.colv : (kind == 2 ? e.maskref : out);
   const int64_t xld = kind == 1 ? N : (kind == 2 ? (int64_t)e.ldmask : ldo);
   const int64_t rbase = m0 + wr * 32 * TM, cbase = n0 + wc * 32 * TN;
@@ -307,6 +314,22 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
   int* const srow_i = reinterpret_cast<int*>(sbias + 32 * TN);
   float* const srow_f = sbias + 32 * TN + 32 * TM;
   uint32_t* const smask = reinterpret_cast<uint32_t*>(sbias + 32 * TN + 64 * TM);      // [32 TM rows][TN words]
+  if (gpair) {
+    // words of the wave's 32 TM rows x (TN / 2) pair blocks x 2 branches -> smask[(row * (TN / 2) + u) * 2 + branch]; wc of its 16 TN
+    // branch columns -> srow_f (a plain launch has no row data there)
+    constexpr int NW = 32 * TM * TN;
+    uint32_t mv[(NW + 63) / 64];
+#pragma unroll
+    for (int u = 0; u < (NW + 63) / 64; ++u) {
+      const int idx = u * 64 + lane;
+      const int br = idx & 1, pu = (idx >> 1) % (TN / 2), row = (idx >> 1) / (TN / 2);
+      const uint32_t* src = br ? e.gate_bits_b : e.gate_bits_a;
+      mv[u] = idx < NW ? src[(rbase + row) * e.ldgbits + (cbase >> 6) + pu] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < (NW + 63) / 64; ++u)
+      if (u * 64 + lane < NW) smask[u * 64 + lane] = mv[u];
+  }
   if (bmask) {
     uint32_t mv[(32 * TM * TN + 63) / 64];
 #pragma unroll
@@ -333,7 +356,7 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
       const int r = u * 64 + lane;
       const bool ok = r < 32 * TM;
       iv[u] = !ok ? 0 : (kind == 1 ? (e.rowseg ? e.rowseg[rbase + r] : 0) : (mapped ? (int)e.rng_row[rbase + r] : 0));
-      fv[u] = (ok && kind == 1) ? e.rowv[rbase + r] : 0.f;
+      fv[u] = (ok && kind == 1) ? e.rowv[rbase + r] : ((gpair && r < 16 * TN) ? e.gate_wc[(cbase >> 1) + r] : 0.f);    // (gpair: wc of the wave's branch columns)
     }
 #pragma unroll
     for (int u = 0; u < (32 * TN + 63) / 64; ++u)
@@ -345,6 +368,11 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
   }
   float4 ext[4], ext2[4];
   float cs[TN][4];
+  float gpa[4][4], gps[TM][4];       // gpair: the pending tanh branch values of a sub-tile; the rows' partial scores
+#pragma unroll
+  for (int a_ = 0; a_ < TM; ++a_)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gps[a_][q] = 0.f;
 #pragma unroll
   for (int q = 0; q < 4; ++q) { ext[q] = make_float4(0.f, 0.f, 0.f, 0.f); ext2[q] = make_float4(1.f, 1.f, 1.f, 1.f); }
 #pragma unroll
@@ -379,7 +407,7 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
       }
       const float4 b4 = *reinterpret_cast<const float4*>(sbias + b * 32 + c4);
       WAVE_LDS_SYNC();   // the reads have landed: the next sub-tile may overwrite the patch
-      const int act = cbase + b * 32 < e.act_split ? e.act0 : e.act1;
+      const int act = gpair ? ((b & 1) ? ACT_SIGMOID : ACT_TANH) : (cbase + b * 32 < e.act_split ? e.act0 : e.act1);
       const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
       if (!drop && kind == 0 && !bmask) {
         // plain bias + activation (the forward layers): the launch-uniform tests are taken once per sub-tile, not once per element
@@ -474,6 +502,24 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
 #pragma unroll
           for (int t = 0; t < 4; ++t) cs[b][t] += res[q][t];
       }
+      if (gpair) {
+        // even sub-tile: keep the (dropped) tanh values; odd sub-tile: multiply in the (dropped) sigmoid values and wc, add to the row sums
+        const int pu = b >> 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int rloc = a * 32 + q * 8 + rq;
+          const uint32_t mw = smask[(rloc * (TN / 2) + pu) * 2 + (b & 1)] >> c4;
+          if ((b & 1) == 0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) gpa[q][t] = ((mw >> t) & 1u) ? res[q][t] * inv_keep : 0.0f;
+          } else {
+            const float4 w4 = *reinterpret_cast<const float4*>(srow_f + pu * 32 + c4);
+            const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) gps[a][q] += ((mw >> t) & 1u) ? gpa[q][t] * (res[q][t] * inv_keep) * wv[t] : 0.0f;
+          }
+        }
+      }
       // next sub-tile's per-element operand: behind this sub-tile's math (the registers are free again), ahead of its stores
       if (b + 1 < TN) ADVMIL_EPI_PREFETCH(a, b + 1);
       else if (a + 1 < TM) ADVMIL_EPI_PREFETCH(a + 1, 0);
@@ -508,6 +554,16 @@ __device__ __forceinline__ void gemm_epilogue_stream(const GemmArgs& g, f32x16 (
     }
   }
 #undef ADVMIL_EPI_PREFETCH
+  if (gpair) {
+#pragma unroll
+    for (int a_ = 0; a_ < TM; ++a_)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float t = gps[a_][q];
+        t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64);     // the 8 lanes that share a row
+        if ((lane & 7) == 0) e.gate_out[(rbase + a_ * 32 + q * 8 + rq) * e.gate_np + nt_i * WC + wc] = t;
+      }
+  }
   if (csum) {
     // the wave's 32 TM rows: the 8 row-lanes (lane >> 3) hold pieces of every column; one partial row per (m tile, wave row)
     const int64_t prow = (m0 / (32 * TM * WR)) * WR + wr;
@@ -538,6 +594,8 @@ __device__ __forceinline__ int gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[TM
   if (direct && e.seed && e.drop_p > 0.0f) {
     key = rng_key(*e.seed, e.stream_id);
     inv_keep = hw_rcp(1.0f - e.drop_p);
+  } else if (direct && e.gate_bits_a && e.drop_p > 0.0f) {
+    inv_keep = hw_rcp(1.0f - e.drop_p);      // (gate pair form: the keep bits are given, only the scale is formed here)
   }
   float* const out = direct ? g.C : g.ws + (int64_t)z * g.M * g.N;
   const int64_t ldo = direct ? g.ldc : g.N;
@@ -554,7 +612,8 @@ __device__ __forceinline__ int gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[TM
   // col 2j+1 = b_j (sigmoid). Instead of storing C, each row's  sum_j tanh(.)_j * sigmoid(.)_j * wc_j  over this workgroup's
   // columns is reduced in registers / across the 8 lanes of a row and written to gate_out[row * gate_np + column-block]: the
   // no-grad generator pass then never writes (and gate_score never re-reads) the [rows, 2D] activations.
-  const bool gate_mode = direct && e.gate_wc != nullptr;
+  const bool gate_store = direct && e.gate_wc != nullptr && e.gate_bits_a != nullptr;      // training form: store AND score (streaming epilogue)
+  const bool gate_mode = direct && e.gate_wc != nullptr && !gate_store;
   if constexpr (TM * TN >= 4 && EPI != 1) {   // the slab-sized tiles (the 64x64 ... 64x192 tiles serve launch-bound shapes: generic path only)
     const int nmode = (e.rowv && e.maskref && !e.accumulate) ? 1 : (e.rowv ? 1 : 0) + (e.maskref ? 1 : 0) + (e.accumulate ? 1 : 0);
     const bool stream = direct && !gate_mode && vec_ok && (g.N % (32 * TN * WC)) == 0 && (g.M % (32 * TM * WR)) == 0 && (e.act_split & 31) == 0 &&
@@ -565,7 +624,7 @@ __device__ __forceinline__ int gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[TM
     if (stream) {
       if constexpr (EPI == 2) {
         if (nmode == 0 && !(e.seed && e.drop_p > 0.0f)) {
-          gemm_epilogue_stream<TM, TN, WR, WC, true>(g, acc, patch, lane, wr, wc, m0, n0, key, inv_keep);
+          gemm_epilogue_stream<TM, TN, WR, WC, true>(g, acc, patch, lane, wr, wc, m0, n0, key, inv_keep, nt_i);
           return TM * TN * 4;
         }
       } else {

@@ -268,7 +268,8 @@ int advmil_launch_splitk_reduce(const GemmArgs& g, hipStream_t stream) {
   const bool plain = e.accumulate && e.alpha == 1.0f && !e.bias && !e.rowv && !e.maskref && e.act0 == 0 && e.act1 == 0 &&
                      !(e.seed && e.drop_p > 0.0f) && !e.c_hi && !e.gate_wc && g.ldc == g.N && (g.N & 3) == 0 &&
                      (((uintptr_t)g.C) & 15) == 0 && g.splits <= 64;
-  if (plain) return advmil_sumq(stream, g.ws, g.splits, g.M * g.N, g.M * g.N, g.C, 1);
+  if (plain) return advmil_sumq(stream, g.ws, g.splits, g.M * g.N, g.M * g.N, g.C, 1, nullptr, 0, nullptr, 0, e.c_rows_pair32 ? g.N : 0);
+  if (e.c_rows_pair32) return ADVMIL_EINVAL;      // (rows in pair-block order: only the merge un-permutes them)
   const int64_t total = g.M * (g.N / 4);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;

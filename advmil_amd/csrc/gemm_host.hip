@@ -167,6 +167,7 @@ static int plan_exact(int64_t M, int64_t N, int64_t K, int* tile, int* splits) {
 static int tile_wc(int tile) { return (tile == 34 || tile == 24) ? 4 : 2; }
 extern "C" int advmil_gemm_f32_gate_blocks(int tile, int64_t N) {
   if (tile >= 82 && tile <= 84) return (int)(N / (64 * (tile % 10))) * 2;      // plane-fed NT kernel: 2 waves along N
+  if (tile == 85 || tile == 86) return (int)(N / (64 * (tile == 85 ? 4 : 2))) * 2;   // (its plain forms: the training gate score)
   if (g_gemm_mode != 1) {
     if (tile / 10 == 4) tile = 20 + tile % 10;
     else if (tile % 10 == 4) tile = (tile / 10 == 3) ? 23 : 22;
@@ -248,6 +249,7 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
     if (planes_usable(epi->b_hi, epi->b_lo, ldb, b_kc ? K : N)) pre |= 2;
   }
   if ((epi->c_hi != nullptr) != (epi->c_lo != nullptr)) return ADVMIL_EINVAL;
+  if (epi->c_rows_pair32 && (splits < 2 || !epi->accumulate || (M & 63) || ldc != N)) return ADVMIL_EINVAL;
   if (epi->maskbits) {    // the bit mask is read by the streaming epilogue only
     int tm_, tn_, wr_, wc_;
     if (g_gemm_mode != 1 || splits != 1 || !tile_geom(tile, tm_, tn_, wr_, wc_) || tm_ * tn_ < 4 || epi->gate_wc || epi->maskref || epi->accumulate ||
@@ -265,8 +267,12 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
       return ADVMIL_EINVAL;
     if ((M % (32 * tm_ * wr_)) || (N % (32 * tn_ * wc_)) || (((uintptr_t)epi->colsum) & 15) || (epi->act_split & 31)) return ADVMIL_EINVAL;
   }
+  const bool gate_store = epi->gate_wc && epi->gate_bits_a;      // training form (tiles 85 / 86): C is written, dropout through given keep bits
+  if (gate_store && (!epi->gate_bits_b || !C || (tile != 85 && tile != 86) || epi->seed || !(epi->drop_p > 0.0f) || epi->drop_p >= 1.0f ||
+                     (N & 127) || epi->ldgbits < N / 64 || epi->c2 || epi->c_hi || (((uintptr_t)epi->gate_wc) & 15)))
+    return ADVMIL_EINVAL;
   if (epi->gate_wc) {       // fused gate score: no split-K, no dropout, whole float4 column groups, one partial per 32*TN*... block
-    if (splits != 1 || !epi->gate_out || (N & 3) || epi->drop_p > 0.0f) return ADVMIL_EINVAL;
+    if (splits != 1 || !epi->gate_out || (N & 3) || (epi->drop_p > 0.0f && !gate_store)) return ADVMIL_EINVAL;
     if (epi->gate_np != advmil_gemm_f32_gate_blocks(tile, N)) return ADVMIL_EINVAL;
   }
   // NT form with both operands as planes: the LDS-DMA kernel (tile codes 82 / 83 = 256 x 128 / 192, 8 waves). The plan
@@ -277,14 +283,14 @@ extern "C" int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, i
     const int tnp = tile == 85 ? 4 : tile == 86 ? 2 : tile % 10, bm = 256, bkt = 32;
     const bool plain = tile == 85 || tile == 86;
     if (tile == 84 && !epi->gate_wc) return ADVMIL_EINVAL;        // 256x256: the fused gate score only
-    if (plain && (epi->gate_wc || epi->rowv || epi->maskref || epi->accumulate || (epi->seed && epi->drop_p > 0.0f))) return ADVMIL_EINVAL;
+    if (plain && ((epi->gate_wc && !gate_store) || epi->rowv || epi->maskref || epi->accumulate || (epi->seed && epi->drop_p > 0.0f))) return ADVMIL_EINVAL;
     if (epi->c2) {      // two layers in one launch: the plain forms only, split on a 32-column boundary inside N
       if (!plain || epi->n_split <= 0 || epi->n_split >= N || (epi->n_split & 31) || (epi->ldc2 & 3) || ((uintptr_t)epi->c2 & 15) ||
           epi->act_split != epi->n_split)
         return ADVMIL_EINVAL;
     }
     if (g_gemm_mode != 1 || !a_kc || !b_kc || pre != 3 || splits != 1 || (M % bm) || (K % bkt) || (N % (64 * tnp))) return ADVMIL_EINVAL;
-    if (epi->gate_wc && (!epi->gate_out || epi->drop_p > 0.0f || epi->gate_np != advmil_gemm_f32_gate_blocks(tile, N))) return ADVMIL_EINVAL;
+    if (epi->gate_wc && (!epi->gate_out || (epi->drop_p > 0.0f && !gate_store) || epi->gate_np != advmil_gemm_f32_gate_blocks(tile, N))) return ADVMIL_EINVAL;
     if (K < 64) return ADVMIL_EINVAL;                   // the three-slot ring prefetches two chunks ahead, across tiles
     if ((uint64_t)M * (uint64_t)lda * 2 >= (1ull << 32) || (uint64_t)N * (uint64_t)ldb * 2 >= (1ull << 32)) return ADVMIL_EINVAL;   // 32-bit plane offsets
     g.mtiles = (int)(M / bm);

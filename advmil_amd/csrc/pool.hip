@@ -772,9 +772,14 @@ extern "C" int advmil_softmax_pool_bwd_planes(const float* dpooled, const float*
 __global__ __launch_bounds__(256) void dropout_planes_kernel(const bf16raw* __restrict__ ihi, const bf16raw* __restrict__ ilo, int64_t M, int64_t N,
                                                              float p, const uint64_t* __restrict__ seed, uint64_t stream_id,
                                                              const int64_t* __restrict__ rng_row, bf16raw* __restrict__ ohi,
-                                                             bf16raw* __restrict__ olo, uint8_t* __restrict__ bits) {
+                                                             bf16raw* __restrict__ olo, uint8_t* __restrict__ bits, float pg,
+                                                             uint64_t stream_ga, uint64_t stream_gb, uint8_t* __restrict__ gbits_a,
+                                                             uint8_t* __restrict__ gbits_b) {
   const uint64_t key = rng_key(*seed, stream_id);
   const float inv = hw_rcp(1.f - p);
+  // (optional) the keep bits of the gated attention scorer's two branch dropouts over the SAME [M, N] index space, drawn here -- a launch
+  // bound by its memory traffic -- so that the gate contraction's epilogue, where the matrix pipe would idle, only tests bits
+  const uint64_t kga = gbits_a ? rng_key(*seed, stream_ga) : 0, kgb = gbits_a ? rng_key(*seed, stream_gb) : 0;
   const int64_t n8 = N >> 3, total = M * n8;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int64_t row = e / n8, c = (e % n8) * 8;
@@ -797,18 +802,36 @@ __global__ __launch_bounds__(256) void dropout_planes_kernel(const bf16raw* __re
     *reinterpret_cast<uint4*>(ohi + row * N + c) = make_uint4(h0.x, h0.y, h1.x, h1.y);
     *reinterpret_cast<uint4*>(olo + row * N + c) = make_uint4(l0.x, l0.y, l1.x, l1.y);
     if (bits) bits[row * (N >> 3) + (c >> 3)] = (uint8_t)b;       // little-endian bytes of the [M, N / 32] uint32 words
+    if (gbits_a) {
+      float fa0[4], fa1[4], fb0[4], fb1[4];
+      rng_keep4(kga, base, pg, 1.f, fa0); rng_keep4(kga, base + 4, pg, 1.f, fa1);
+      rng_keep4(kgb, base, pg, 1.f, fb0); rng_keep4(kgb, base + 4, pg, 1.f, fb1);
+      uint32_t wa = 0u, wb = 0u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        wa |= (fa0[q] != 0.f ? (1u << q) : 0u) | (fa1[q] != 0.f ? (16u << q) : 0u);
+        wb |= (fb0[q] != 0.f ? (1u << q) : 0u) | (fb1[q] != 0.f ? (16u << q) : 0u);
+      }
+      gbits_a[row * (N >> 3) + (c >> 3)] = (uint8_t)wa;
+      gbits_b[row * (N >> 3) + (c >> 3)] = (uint8_t)wb;
+    }
   }
 }
 
 extern "C" int advmil_dropout_planes(const void* in_hi, const void* in_lo, int64_t M, int64_t N, float drop_p, const uint64_t* seed,
-                                     uint64_t stream_id, const int64_t* rng_row, void* out_hi, void* out_lo, void* bits,
+                                     uint64_t stream_id, const int64_t* rng_row, void* out_hi, void* out_lo, void* bits, float gate_p,
+                                     uint64_t gate_stream_a, uint64_t gate_stream_b, void* gate_bits_a, void* gate_bits_b,
                                      advmil_stream_t stream_) {
   if (!in_hi || !in_lo || !out_hi || !out_lo || !seed || M <= 0 || N <= 0 || (N & 31) || !(drop_p > 0.f) || drop_p >= 1.f) return ADVMIL_EINVAL;
+  if ((gate_bits_a != nullptr) != (gate_bits_b != nullptr) || (gate_bits_a && (!(gate_p > 0.f) || gate_p >= 1.f)) ||
+      (((uintptr_t)gate_bits_a | (uintptr_t)gate_bits_b) & 3))
+    return ADVMIL_EINVAL;
   if ((((uintptr_t)in_hi | (uintptr_t)in_lo | (uintptr_t)out_hi | (uintptr_t)out_lo) & 15) || ((uintptr_t)bits & 3)) return ADVMIL_EINVAL;
   int64_t blocks = (M * (N >> 3) + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(dropout_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, (const bf16raw*)in_hi, (const bf16raw*)in_lo,
-                     M, N, drop_p, seed, stream_id, rng_row, (bf16raw*)out_hi, (bf16raw*)out_lo, (uint8_t*)bits);
+                     M, N, drop_p, seed, stream_id, rng_row, (bf16raw*)out_hi, (bf16raw*)out_lo, (uint8_t*)bits, gate_p, gate_stream_a,
+                     gate_stream_b, (uint8_t*)gate_bits_a, (uint8_t*)gate_bits_b);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }
@@ -845,13 +868,16 @@ extern "C" int advmil_seg_scale_rows(const float* dpooled, const float* A, const
 __global__ __launch_bounds__(256) void gate_interleave_kernel(const float* __restrict__ Wa, const float* __restrict__ Wb,
                                                               const float* __restrict__ ba, const float* __restrict__ bb, int D,
                                                               float* __restrict__ Wi, bf16raw* __restrict__ hi, bf16raw* __restrict__ lo,
-                                                              float* __restrict__ bi) {
+                                                              float* __restrict__ bi, int pair32) {
   const int q4 = D >> 2;                                    // float4 per row
   const int64_t total = (int64_t)2 * D * q4;
+  // output row r <- branch `br`, unit j: element-interleaved (r = 2 j + br: the no-grad fused gate score) or, pair32, in blocks of 32
+  // (r = 64 (j / 32) + 32 br + j % 32: the training form, whose stored activations the backward reads back block-wise)
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int r = (int)(e / q4), c = (int)(e % q4) * 4;     // output row r = 2 j + branch
-    const float* src = (r & 1) ? Wb : Wa;
-    const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)(r >> 1) * D + c);
+    const int r = (int)(e / q4), c = (int)(e % q4) * 4;
+    const int br = pair32 ? ((r >> 5) & 1) : (r & 1), j = pair32 ? (((r >> 6) << 5) | (r & 31)) : (r >> 1);
+    const float* src = br ? Wb : Wa;
+    const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)j * D + c);
     *reinterpret_cast<float4*>(Wi + (int64_t)r * D + c) = v;
     if (hi) {
       uint2 hh, ll;
@@ -861,7 +887,10 @@ __global__ __launch_bounds__(256) void gate_interleave_kernel(const float* __res
     }
   }
   if (blockIdx.x == 0)
-    for (int r = threadIdx.x; r < 2 * D; r += 256) bi[r] = (r & 1) ? bb[r >> 1] : ba[r >> 1];
+    for (int r = threadIdx.x; r < 2 * D; r += 256) {
+      const int br = pair32 ? ((r >> 5) & 1) : (r & 1), j = pair32 ? (((r >> 6) << 5) | (r & 31)) : (r >> 1);
+      bi[r] = br ? bb[j] : ba[j];
+    }
 }
 __global__ __launch_bounds__(256) void gate_partial_sum_kernel(const float* __restrict__ partial, int np, const float* __restrict__ bc,
                                                                int64_t N, float* __restrict__ s) {
@@ -873,13 +902,14 @@ __global__ __launch_bounds__(256) void gate_partial_sum_kernel(const float* __re
   }
 }
 extern "C" int advmil_gate_interleave(const float* Wa, const float* Wb, const float* ba, const float* bb, int D, float* Wi, void* Wi_hi,
-                                      void* Wi_lo, float* bi, advmil_stream_t stream_) {
+                                      void* Wi_lo, float* bi, int pair32, advmil_stream_t stream_) {
   if (!Wa || !Wb || !ba || !bb || !Wi || !bi || D <= 0 || (D & 3) || ((Wi_hi != nullptr) != (Wi_lo != nullptr))) return ADVMIL_EINVAL;
+  if (pair32 && (D & 31)) return ADVMIL_EINVAL;
   if (((uintptr_t)Wa & 15) || ((uintptr_t)Wb & 15) || ((uintptr_t)Wi & 15) || ((uintptr_t)Wi_hi & 7) || ((uintptr_t)Wi_lo & 7)) return ADVMIL_EINVAL;
   int64_t blocks = ((int64_t)2 * D * (D >> 2) + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(gate_interleave_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, Wa, Wb, ba, bb, D, Wi,
-                     (bf16raw*)Wi_hi, (bf16raw*)Wi_lo, bi);
+                     (bf16raw*)Wi_hi, (bf16raw*)Wi_lo, bi, pair32);
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }
@@ -900,9 +930,13 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
                                                        uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D,
                                                        float* __restrict__ dG, float* __restrict__ partial, int rpb,
                                                        const int64_t* __restrict__ rng_row, bf16raw* __restrict__ g_hi,
-                                                       bf16raw* __restrict__ g_lo) {
+                                                       bf16raw* __restrict__ g_lo, int pair32) {
   __shared__ __attribute__((aligned(16))) float red[1024];
   const RowColMap m = make_map(D);
+  // where unit j = 4 c4 .. of the two branches sits in a row of ab / dG: [a | b] halves, or (pair32, the fused training gate score's
+  // layout) blocks of 32: a_j at 64 (j / 32) + j % 32, b_j 32 further
+  const int64_t oa = pair32 ? (int64_t)(((m.c4 * 4) >> 5) << 6) + ((m.c4 * 4) & 31) : (int64_t)m.c4 * 4;
+  const int64_t ob = pair32 ? oa + 32 : D + (int64_t)m.c4 * 4;
   const bool drop = seed && p > 0.f;
   uint64_t ka = 0, kb = 0;
   float inv = 1.f;
@@ -921,8 +955,8 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
       if (n >= N) break;
       const float d = ds[n];
       if (m.c4 == 0) s_ds += d;
-      const float4 a4 = *reinterpret_cast<const float4*>(ab + n * 2 * D + m.c4 * 4);
-      const float4 b4 = *reinterpret_cast<const float4*>(ab + n * 2 * D + D + m.c4 * 4);
+      const float4 a4 = *reinterpret_cast<const float4*>(ab + n * 2 * D + oa);
+      const float4 b4 = *reinterpret_cast<const float4*>(ab + n * 2 * D + ob);
       const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
       float ga[4], gb[4], gw[4];
       float fa4[4] = {1.f, 1.f, 1.f, 1.f}, fb4[4] = {1.f, 1.f, 1.f, 1.f};
@@ -940,17 +974,17 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
         gb[q] = d * wv[q] * ad * fb * bv[q] * (1.f - bv[q]);   // d pre_b  (sigmoid')
       }
       if (dG) {    // (NULL: the caller keeps dG as planes only -- its two consumers are bf16x3 contractions that would split it anyway)
-        *reinterpret_cast<float4*>(dG + n * 2 * D + m.c4 * 4) = make_float4(ga[0], ga[1], ga[2], ga[3]);
-        *reinterpret_cast<float4*>(dG + n * 2 * D + D + m.c4 * 4) = make_float4(gb[0], gb[1], gb[2], gb[3]);
+        *reinterpret_cast<float4*>(dG + n * 2 * D + oa) = make_float4(ga[0], ga[1], ga[2], ga[3]);
+        *reinterpret_cast<float4*>(dG + n * 2 * D + ob) = make_float4(gb[0], gb[1], gb[2], gb[3]);
       }
       if (g_hi) {   // bf16x3 operand planes of dG for the contractions that read it (dh = dG Wab, dWab = dG^T h)
         uint2 hh, ll;
         split4(make_float4(ga[0], ga[1], ga[2], ga[3]), hh, ll);
-        *reinterpret_cast<uint2*>(g_hi + n * 2 * D + m.c4 * 4) = hh;
-        *reinterpret_cast<uint2*>(g_lo + n * 2 * D + m.c4 * 4) = ll;
+        *reinterpret_cast<uint2*>(g_hi + n * 2 * D + oa) = hh;
+        *reinterpret_cast<uint2*>(g_lo + n * 2 * D + oa) = ll;
         split4(make_float4(gb[0], gb[1], gb[2], gb[3]), hh, ll);
-        *reinterpret_cast<uint2*>(g_hi + n * 2 * D + D + m.c4 * 4) = hh;
-        *reinterpret_cast<uint2*>(g_lo + n * 2 * D + D + m.c4 * 4) = ll;
+        *reinterpret_cast<uint2*>(g_hi + n * 2 * D + ob) = hh;
+        *reinterpret_cast<uint2*>(g_lo + n * 2 * D + ob) = ll;
       }
       s_wc.x += gw[0]; s_wc.y += gw[1]; s_wc.z += gw[2]; s_wc.w += gw[3];
       s_a.x += ga[0]; s_a.y += ga[1]; s_a.z += ga[2]; s_a.w += ga[3];
@@ -982,11 +1016,11 @@ extern "C" size_t advmil_gate_bwd_workspace_bytes(int64_t N, int64_t D) {
 
 extern "C" int advmil_gate_bwd(const float* ab, const float* ds, const float* wc, float drop_p, const uint64_t* seed,
                                uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D, float* dG, float* dwc,
-                               float* dbc, float* dbias, int accumulate, const int64_t* rng_row, void* dG_hi, void* dG_lo, void* ws,
-                               size_t ws_bytes, advmil_stream_t stream_) {
+                               float* dbc, float* dbias, int accumulate, const int64_t* rng_row, void* dG_hi, void* dG_lo, int pair32,
+                               void* ws, size_t ws_bytes, advmil_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!ab || !ds || !wc || (!dG && !dG_hi) || !dwc || !dbc || !dbias || !ws || N <= 0 || D <= 0 || (D & 3) || D > 1024 ||
-      ((dG_hi != nullptr) != (dG_lo != nullptr)))
+      ((dG_hi != nullptr) != (dG_lo != nullptr)) || (pair32 && (D & 31)))
     return ADVMIL_EINVAL;
   if (ws_bytes < advmil_gate_bwd_workspace_bytes(N, D)) return ADVMIL_EWORKSPACE;
   const int rpb = rows_per_block(N);
@@ -994,7 +1028,7 @@ extern "C" int advmil_gate_bwd(const float* ab, const float* ds, const float* wc
   float* partial = (float*)ws;
   const int64_t stride = 3 * D + 4;
   hipLaunchKernelGGL(gate_bwd_kernel, dim3(nblk), dim3(256), 0, stream, ab, ds, wc, drop_p, seed, stream_a, stream_b, N, D,
-                     dG, partial, rpb, rng_row, (bf16raw*)dG_hi, (bf16raw*)dG_lo);
+                     dG, partial, rpb, rng_row, (bf16raw*)dG_hi, (bf16raw*)dG_lo, pair32);
   ADVMIL_LAUNCH_CHECK();
   // dwc | dbias(a) | dbias(b) | dbc are adjacent in the partial rows: one merge launch over the 3D+1 columns, three destinations
   { const int rc = advmil_sumq(stream, partial, nblk, stride, 3 * D + 1, dwc, accumulate, dbias, D, dbc, 3 * D); if (rc) return rc; }

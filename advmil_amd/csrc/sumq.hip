@@ -45,6 +45,11 @@ __global__ __launch_bounds__(256) void multi_sum_kernel(MultiSumArgs a) {
       s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
     }
     float4* dst = reinterpret_cast<float4*>(d.out + c);
+    if (d.p32n) {      // pair-block rows -> [branch][unit] rows (p32n % 4 == 0: the thread's 4 columns stay in one row)
+      const int64_t r = c / d.p32n, cc = c - r * d.p32n, half = (d.ncols / d.p32n) >> 1;
+      const int64_t rr = ((r >> 5) & 1) * half + ((r >> 6) << 5) + (r & 31);
+      dst = reinterpret_cast<float4*>(d.out + rr * d.p32n + cc);
+    }
     if (d.accumulate) { const float4 o = *dst; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
     *dst = s;
     return;
@@ -124,6 +129,7 @@ int advmil_sumq_push(hipStream_t stream, SumDesc d) {
   if (!d.partial || !d.out || d.nblk <= 0 || d.ncols <= 0) return ADVMIL_EINVAL;
   d.wide = d.nblk <= 64 && !d.out1 && !d.out2 && (d.ncols & 3) == 0 && (d.stride & 3) == 0 &&
            ((((uintptr_t)d.partial) | ((uintptr_t)d.out)) & 15) == 0;
+  if (d.p32n && (!d.wide || (d.p32n & 3) || d.ncols % (64 * d.p32n))) return ADVMIL_EINVAL;      // (the un-permuting merge: wide form only)
   std::lock_guard<std::mutex> lk(g_mu);
   Queue* q = d.accumulate ? find(stream, false) : nullptr;      // only merges INTO an accumulator are order-free until the flush
   if (!q) return launch(stream, &d, 1);

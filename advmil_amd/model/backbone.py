@@ -56,7 +56,11 @@ class ABMIL(nn.Module):
         rng = _rng_of(self, X)
         fc, p = self.attention_net[0], (self.attention_net[2].p if self.training else 0.0)
         # the epilogue also emits h's operand planes: the gate contraction below reads them through the plane-fed kernel
-        h = ops.linear_act(X, fc.weight, fc.bias, "relu", p, rng, "abmil_fc", emit_planes=True)   # [N_total, hid]
+        gate = self.attention_net[3]
+        pg = float(getattr(gate, "drop_p", 0.0)) if gate.training else 0.0
+        # (gate_sites: the pool below draws the scorer's two dropout sites next -- their keep bits ride in this layer's dropout launch)
+        h = ops.linear_act(X, fc.weight, fc.bias, "relu", p, rng, "abmil_fc", emit_planes=True,
+                           gate_sites=(pg, "gate_att_a", "gate_att_b") if (pg > 0.0 and _rng_of(gate, X) is rng) else None)   # [N_total, hid]
         pooled, A, _ = self.attention_net[3].pool(h, seg)
         self.last_attention = A.detach()
         return pooled.unsqueeze(0) if seg is None else pooled

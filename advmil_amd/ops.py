@@ -418,6 +418,9 @@ MEMO_PLANES = os.environ.get("ADVMIL_MEMO_PLANES", "1") != "0"
 # 2^-17 relative, the arithmetic of every bf16x3 contraction): 201 MB less written by the launch and by the replay, and the pooling pass
 # no longer pays for the write-back of those dirty lines (tools/probe/pool_instep.py). 0 = fp32 rows beside the planes, as until round 5.
 H_PLANES_ONLY = os.environ.get("ADVMIL_H_PLANES_ONLY", "1") != "0"
+# round 6: the TRAINING pass's gate score in the gate contraction's epilogue (branches in pair blocks of 32 columns, keep bits drawn by the
+# dropout pass over the memoized first layer): gate_score_kernel's pass over the stored [rows, 2D] activations does not run
+FUSED_GATE_TRAIN = os.environ.get("ADVMIL_FUSED_GATE_TRAIN", "1") != "0"
 # operand planes for EVERY step slab of >= 4096 rows, not only for those that fill the chip with the plane-fed NT kernel's 256-row tiles: the
 # deep-K weight gradients (plane-fed TN kernel from K = 8192), the planes-only dpre / dG hand-overs and the dh epilogue fusion then also
 # apply to the 1-4 bag steps of a strong split
@@ -502,7 +505,7 @@ def pre_a_tile_ok(tile, a_kc, b_kc, b_planes=False):
 def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=None, act_split=None, drop_p=0.0,
          seed=None, stream_id=0, rowv=None, colv=None, rowseg=None, maskref=None, mask_scale=1.0, accumulate=False,
          alpha=1.0, splits=None, tile=0, a_planes=None, b_planes=None, c_planes=None, c_planes_only=False, gate_wc=None, rng_row=None,
-         colsum=None, maskbits=None):
+         colsum=None, maskbits=None, gate_bits=None, c_rows_pair32=False):
     """C[M,N] = epilogue(alpha * op(A) op(B)); see include/advmil_hip.h::advmil_gemm_f32. a_planes / b_planes: optional
     Planes of A / B; c_planes: Planes to receive the split of the final C (pitch ldc)."""
     planes_only_a = A is None
@@ -539,7 +542,9 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
         ptile = gemm_plan_planes(M, N, K, a_kc, b_kc)          # both operands pre-split: the plane-fed LDS-DMA kernel, if the shape fits
         if ptile:
             tile, splits = ptile, 1
-            if gate_wc is not None and N % 256 == 0 and (M // 256) * (N // 256) >= 384:
+            if gate_wc is not None and gate_bits is not None:
+                tile = 85 if (N % 256 == 0 and (M // 256) * (N // 256) >= 256) else 86      # training form: a plain tile, C written too
+            elif gate_wc is not None and N % 256 == 0 and (M // 256) * (N // 256) >= 384:
                 tile = 84                                      # the fused gate score's own 256x256 form
             elif (gate_wc is None and N % 256 == 0 and (M // 256) * (N // 256) >= 384 and rowv is None and maskref is None
                   and not accumulate and (drop_p <= 0.0 or seed is None)):
@@ -556,7 +561,13 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
         tile, _ = gemm_plan(M, N, K, a_kc, b_kc) if tile == 0 else (tile, 1)
         npart = _lib.lib().advmil_gemm_f32_gate_blocks(tile, N)
         gate_out = torch.empty(M, npart, dtype=torch.float32, device=A.device)
-        splits, out, ldc = 1, None, N
+        splits, ldc = 1, N
+        if gate_bits is None:
+            out = None
+        else:             # training form (advmil_epilogue_t.gate_bits_a): the activations are stored as well, in pair-block column order
+            if not (85 <= tile <= 86):
+                raise ValueError("gemm(gate_bits=...) needs the plane-fed plain tiles (operands as planes, slab-sized M)")
+            out = torch.empty(M, N, dtype=torch.float32, device=A.device)
     elif c_planes_only:                       # the result is consumed as a bf16x3 operand only: its planes are written, no fp32 C at all
         if c_planes is None or out is not None or accumulate:
             raise ValueError("gemm(c_planes_only=True) needs c_planes, no `out`, no accumulate")
@@ -604,6 +615,10 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
         e.c_hi, e.c_lo = c_planes.hi.data_ptr(), c_planes.lo.data_ptr()
     if gate_wc is not None:
         e.gate_wc, e.gate_out, e.gate_np = gate_wc.data_ptr(), gate_out.data_ptr(), npart
+        if gate_bits is not None:
+            e.gate_bits_a, e.gate_bits_b, e.ldgbits = gate_bits[0].data_ptr(), gate_bits[1].data_ptr(), gate_bits[0].stride(0)
+    if c_rows_pair32:
+        e.c_rows_pair32 = 1
     if colsum is not None:
         e.colsum = colsum.data_ptr()
     if maskbits is not None:
@@ -645,6 +660,8 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         prof.append((name, (M, N, K, splits), 2.0 * M * N * K, e0, e1))
+    if gate_wc is not None and gate_bits is not None:
+        return out, gate_out
     return gate_out if gate_wc is not None else out
 
 
@@ -847,15 +864,21 @@ def softmax_pool_bwd(dpooled, dA, A, h, N, D, seg=None, hpl=None):
     return ds
 
 
-def dropout_planes(pl, M, N, p, seed, sid, rng_row=None):
+def dropout_planes(pl, M, N, p, seed, sid, rng_row=None, gate=None):
     """(Planes of dropout(x), keep-and-positive bits [M, N / 32]) from the Planes of x [M, N]: the train-mode forward of a layer whose
-    eval-mode output is held as planes only (include/advmil_hip.h::advmil_dropout_planes). The result is planes-only too."""
+    eval-mode output is held as planes only (include/advmil_hip.h::advmil_dropout_planes). The result is planes-only too.
+    gate = (p_gate, stream a, stream b): also the keep bits of the gated attention scorer's two branch dropouts -> (out, bits, (bits_a, bits_b))."""
     out = Planes.alloc((M, N), pl.hi.device)
     out.fp32_stale = True
     bits = torch.empty(M, N // 32, dtype=torch.int32, device=pl.hi.device)
+    gb = None
+    if gate is not None:
+        gb = (torch.empty(M, N // 32, dtype=torch.int32, device=pl.hi.device), torch.empty(M, N // 32, dtype=torch.int32, device=pl.hi.device))
     _lib.check(_lib.lib().advmil_dropout_planes(_p(pl.hi), _p(pl.lo), M, N, float(p), _p(seed), sid, _p(rng_row), _p(out.hi), _p(out.lo),
-                                                _p(bits), _stream()), "dropout_planes")
-    return out, bits
+                                                _p(bits), 0.0 if gate is None else float(gate[0]), 0 if gate is None else int(gate[1]),
+                                                0 if gate is None else int(gate[2]), _p(None if gb is None else gb[0]),
+                                                _p(None if gb is None else gb[1]), _stream()), "dropout_planes")
+    return (out, bits, gb) if gate is not None else (out, bits)
 
 
 def planes_f32(pl):
@@ -864,7 +887,7 @@ def planes_f32(pl):
 
 
 def gate_bwd(ab, ds, wc, N, D, p=0.0, seed=None, stream_a=0, stream_b=0, dwc=None, dbc=None, dbias=None, rng_row=None, planes=None,
-             planes_only=False):
+             planes_only=False, pair32=False):
     """dwc/dbc/dbias given -> gradients are ADDED into them (views of the gradient arena). planes_only: dG is written as its
     bf16x3 operand planes alone (returned dG is None)."""
     L = _lib.lib()
@@ -880,8 +903,8 @@ def gate_bwd(ab, ds, wc, N, D, p=0.0, seed=None, stream_a=0, stream_b=0, dwc=Non
     sd = seed if p > 0.0 else None
     _lib.check(L.advmil_gate_bwd(_p(ab), _p(ds), _p(wc), p, _p(sd), stream_a, stream_b, N, D, _p(dG), _p(dwc), _p(dbc),
                                  _p(dbias), 1 if acc else 0, _p(rng_row if sd is not None else None),
-                                 _p(None if planes is None else planes.hi), _p(None if planes is None else planes.lo), _p(ws), wsb,
-                                 _stream()), "gate_bwd")
+                                 _p(None if planes is None else planes.hi), _p(None if planes is None else planes.lo), 1 if pair32 else 0,
+                                 _p(ws), wsb, _stream()), "gate_bwd")
     return dG, dwc, dbc, dbias
 
 
@@ -1044,6 +1067,8 @@ class LinearActFn(torch.autograd.Function):
     last_wants_dy_planes = False
     last_act_fusable = None
     last_maskbits = None
+    gate_request = None      # (p_gate, tag_a, tag_b, rng) set by linear_act: the consumer is a gated attention pool in train mode
+    last_gate = None         # (stream a, stream b, bits_a, bits_b, p_gate, row map): drawn with this layer's own dropout (dropout_planes)
 
     @staticmethod
     def forward(ctx, x, W, b, act, p, seed, sid, y0=None, rr=None, xpl=None, wpl=None, emit=False):
@@ -1082,7 +1107,18 @@ class LinearActFn(torch.autograd.Function):
                          a_planes=xpl, b_planes=wpl, c_planes=cpl, splits=1 if cpl is not None else None)
         elif p > 0.0 and y0pl is not None:
             # ... memoized as planes: the draw maps planes to planes (+ the keep-and-positive bits), 8 bytes per element instead of 12
-            cpl, mbits = dropout_planes(y0pl, M, N, p, seed, sid, rr)
+            greq, LinearActFn.gate_request = LinearActFn.gate_request, None
+            gate = None
+            if greq is not None and N % 32 == 0:
+                pg, tag_a, tag_b, grng = greq
+                if grng.row_map(M, tag_a) is rr and grng.row_map(M, tag_b) is rr:      # one row map for the three draws of the launch
+                    # (the scorer's two sites are the next two draws anyway: the numbering is what gated_attn_pool would have produced)
+                    gate = (pg, grng.site(tag_a, (M, N), pg), grng.site(tag_b, (M, N), pg))
+            if gate is not None:
+                cpl, mbits, gb = dropout_planes(y0pl, M, N, p, seed, sid, rr, gate=gate)
+                LinearActFn.last_gate = (gate[1], gate[2], gb[0], gb[1], gate[0], rr)
+            else:
+                cpl, mbits = dropout_planes(y0pl, M, N, p, seed, sid, rr)
             y = _token(M, N, x.device)
             LinearActFn.last_maskbits = mbits if act == ACT_RELU else None
         elif p > 0.0:       # memoized act(x W^T + b) of the eval forward: only this forward's dropout draw is new
@@ -1277,7 +1313,7 @@ def prefill_two_layers(X, layer1, layer2):
     return True
 
 
-def linear_act(x, W, b, act="none", p=0.0, rng=None, tag="", emit_planes=False):
+def linear_act(x, W, b, act="none", p=0.0, rng=None, tag="", emit_planes=False, gate_sites=None):
     """x[..., K] -> [..., N] through the HIP GEMM (any leading dims are flattened). In bf16x3 mode the operands' bf16 planes are
     used when they exist (slab registered by the handler / producer-emitted activation planes / arena weight planes), and
     `emit_planes` makes the epilogue also write the planes of y (attribute `_advmil_planes`) for the contraction that reads it."""
@@ -1323,7 +1359,13 @@ def linear_act(x, W, b, act="none", p=0.0, rng=None, tag="", emit_planes=False):
     emit = bool(emit_planes) and big and bool(gemm_plan_planes(x2.shape[0], 2 * W.shape[0], W.shape[0]))
     if emit_planes == "only":                 # planes INSTEAD of fp32 values (the caller guarantees a planes-only consumer): any slab-sized layer
         emit = "only" if (big and act == "none" and p <= 0.0 and y0 is None and W.shape[0] % 8 == 0 and ATTN_QKV_PLANES) else False
+    # gate_sites = (p_gate, tag_a, tag_b): the output feeds a gated attention pool that will draw these two dropout sites next; when this
+    # call turns out to be the planes-to-planes dropout replay, their keep bits are drawn in the same launch (FUSED_GATE_TRAIN)
+    LinearActFn.gate_request = ((float(gate_sites[0]), gate_sites[1], gate_sites[2], rng) if (gate_sites is not None and FUSED_GATE_TRAIN
+                                and p > 0.0 and gate_sites[0] > 0.0 and torch.is_grad_enabled()) else None)
+    LinearActFn.last_gate = None
     y = LinearActFn.apply(x2, W, b, _ACT[act], float(p), seed, sid, y0, rr, xpl, wpl, emit)
+    LinearActFn.gate_request = None
     cpl, LinearActFn.last_planes = LinearActFn.last_planes, None
     if pre_planes is not None and cpl is None:
         cpl = pre_planes                      # the two-layer launch already emitted the planes of this output
@@ -1343,6 +1385,9 @@ def linear_act(x, W, b, act="none", p=0.0, rng=None, tag="", emit_planes=False):
         out._advmil_act_fusable = LinearActFn.last_act_fusable + (LinearActFn.last_maskbits,)
     LinearActFn.last_act_fusable = None
     LinearActFn.last_maskbits = None
+    if LinearActFn.last_gate is not None:
+        out._advmil_gate = LinearActFn.last_gate
+        LinearActFn.last_gate = None
     return out
 
 
@@ -1372,11 +1417,12 @@ class GatedAttnPoolFn(torch.autograd.Function):
     model/backbone.py:81-85) and GAPool (model/backbone_utils.py:47-56): the pooled tensor is the scored tensor in every use."""
 
     @staticmethod
-    def forward(ctx, h, Wa, ba, Wb, bb, wc, bc, p, seed, sa, sb, seg, nograd=False, rr=None, hpl=None, act_fuse=None):
+    def forward(ctx, h, Wa, ba, Wb, bb, wc, bc, p, seed, sa, sb, seg, nograd=False, rr=None, hpl=None, act_fuse=None, gate=None):
         _chk(h, "h")
         h = h.contiguous()
         N, D = h.shape
         ctx.act_fuse = act_fuse
+        ctx.pair32 = False
         wcv = wc.detach().reshape(-1)
         stale = hpl is not None and hpl.fp32_stale            # h is a token: every read below goes through its planes
         ppl = hpl if stale else None
@@ -1387,6 +1433,26 @@ class GatedAttnPoolFn(torch.autograd.Function):
             s = gate_partial_sum(gemm(h, Wi, True, True, N, 2 * D, D, bias=bi, gate_wc=wcv, a_planes=hpl, b_planes=wipl), bc.detach())
             A, pooled = softmax_pool(s, h, N, D, seg, ppl)
             ctx.mark_non_differentiable(s)
+            return pooled, A, s
+        # fused-weight-gradient slots first: the training form below needs them (its dWab rows come out in pair-block order and only the
+        # accumulating merge un-permutes them)
+        gs = [_arena_grad(t) for t in (Wa, ba, Wb, bb, wc, bc)]
+        arena_ok = all(g is not None for g in gs) and _adjacent(gs[0], gs[2]) and _adjacent(gs[1], gs[3])
+        if (gate is not None and FUSED_GATE_TRAIN and p > 0.0 and hpl is not None and arena_ok and N % 256 == 0 and D % 64 == 0
+                and get_gemm_mode() == "bf16x3" and gemm_plan_planes(N, 2 * D, D) and gemm_plan_tn_planes(2 * D, D, N)[1] > 1
+                and gemm_plan_planes(N, D, 2 * D)):
+            # TRAINING pass with the score in the contraction's epilogue: branches in pair blocks of 32 columns, keep bits from `gate`
+            Wp, bp, wppl = gate_interleave(Wa.detach(), ba.detach(), Wb.detach(), bb.detach(), D, planes=True, pair32=True)
+            ab, part = gemm(h, Wp, True, True, N, 2 * D, D, bias=bp, gate_wc=wcv, drop_p=p, a_planes=hpl, b_planes=wppl, gate_bits=gate)
+            s = gate_partial_sum(part, bc.detach())
+            A, pooled = softmax_pool(s, h, N, D, seg, ppl)
+            ctx.save_for_backward(h, Wp, ab, A, wcv)
+            ctx.hpl, ctx.wabpl, ctx.pair32 = hpl, wppl, True
+            ctx.cfg = (p, seed, sa, sb, N, D, wc.shape, seg, rr)
+            ctx.arena = (gs[0].as_strided((2 * D, D), (D, 1), gs[0].storage_offset()),
+                         gs[1].as_strided((2 * D,), (1,), gs[1].storage_offset()), gs[4].view(-1), gs[5])
+            ctx.mark_non_differentiable(s)
+            ctx.set_materialize_grads(False)
             return pooled, A, s
         Wab, _ = _stack2(Wa, Wb, D, D)                       # [2D, D]: a view when the two live side by side in the arena
         bab, _ = _stack2(ba, bb, D, 0)
@@ -1407,9 +1473,8 @@ class GatedAttnPoolFn(torch.autograd.Function):
         ctx.wabpl = wabpl                      # Wab's planes: transposed, the B operand of dh = dG Wab on the plane-fed NT kernel
         ctx.cfg = (p, seed, sa, sb, N, D, wc.shape, seg, rr)
         # fused weight-gradient accumulation needs every parameter's arena slot, with the a|b pairs adjacent
-        gs = [_arena_grad(t) for t in (Wa, ba, Wb, bb, wc, bc)]
         ctx.arena = None
-        if all(g is not None for g in gs) and _adjacent(gs[0], gs[2]) and _adjacent(gs[1], gs[3]):
+        if arena_ok:
             ctx.arena = (gs[0].as_strided((2 * D, D), (D, 1), gs[0].storage_offset()),
                          gs[1].as_strided((2 * D,), (1,), gs[1].storage_offset()), gs[4].view(-1), gs[5])
         ctx.mark_non_differentiable(s)
@@ -1418,8 +1483,9 @@ class GatedAttnPoolFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dpooled, dA, _ds_unused):
-        h, Wab, ab, A, wcv = ctx.saved_tensors
+        h, Wab, ab, A, wcv = ctx.saved_tensors               # (pair32: Wab is the pair-block stack of the two branches, and so are ab / dG)
         p, seed, sa, sb, N, D, wcshape, seg, rr = ctx.cfg
+        pair32 = bool(getattr(ctx, "pair32", False))
         nseg = 1 if seg is None else seg.nseg
         dpooled = (torch.zeros(nseg, D, dtype=torch.float32, device=h.device) if dpooled is None
                    else dpooled.contiguous().reshape(nseg, D))
@@ -1444,7 +1510,8 @@ class GatedAttnPoolFn(torch.autograd.Function):
             gpl = Planes.alloc((N, 2 * D), h.device)
         if ctx.arena is not None:
             gWab, gbab, gwc, gbc = ctx.arena
-            dG, _, _, _ = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb, dwc=gwc, dbc=gbc, dbias=gbab, rng_row=rr, planes=gpl, planes_only=only)
+            dG, _, _, _ = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb, dwc=gwc, dbc=gbc, dbias=gbab, rng_row=rr, planes=gpl, planes_only=only,
+                                   pair32=pair32)
         else:
             dG, dwc, dbc, dbias = gate_bwd(ab, ds, wcv, N, D, p, seed, sa, sb, rng_row=rr, planes=gpl, planes_only=only)
         dh = None
@@ -1488,11 +1555,13 @@ class GatedAttnPoolFn(torch.autograd.Function):
                 dh = gemm(None, Wab, True, False, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg, a_planes=gpl)
             else:
                 dh = gemm(dG, Wab, True, False, N, D, 2 * D, rowv=A, colv=dpooled, rowseg=None if seg is None else seg.rowseg)
-        nones = (None,) * 9
+        nones = (None,) * 10
         apl = gpl if only else None
         if ctx.arena is not None:
             bpl = ctx.hpl if (stale or (apl is not None and gemm_plan_tn_planes(2 * D, D, N)[0])) else None
-            gemm(dG, h, False, False, 2 * D, D, N, out=gWab, ldc=D, accumulate=True, a_planes=apl, b_planes=bpl)       # dG^T h
+            if pair32 and (apl is None or bpl is None):
+                raise RuntimeError("advmil_amd: the pair-block gate backward needs dG and h as operand planes")
+            gemm(dG, h, False, False, 2 * D, D, N, out=gWab, ldc=D, accumulate=True, a_planes=apl, b_planes=bpl, c_rows_pair32=pair32)   # dG^T h
             return (dh, None, None, None, None, None, None) + nones
         bpl = ctx.hpl if (stale or (apl is not None and gemm_plan_tn_planes(2 * D, D, N)[0])) else None
         dWab = gemm(dG, h, False, False, 2 * D, D, N, a_planes=apl, b_planes=bpl)
@@ -1503,11 +1572,18 @@ def gated_attn_pool(h, Wa, ba, Wb, bb, wc, bc, p=0.0, rng=None, tag="", seg=None
     """Returns (pooled [nseg, D] -- [D] when seg is None --, A[N], raw scores[N])."""
     sa = sb = 0
     seed = rr = None
+    gate = None
     if p > 0.0:
         rng = rng or default_rng(h.device)
-        sa = rng.site(tag + "att_a", tuple(h.shape), p)
-        sb = rng.site(tag + "att_b", tuple(h.shape), p)
-        seed, rr = rng.seed, rng.row_map(h.shape[0], tag + "att_a")
+        pre = getattr(h, "_advmil_gate", None)
+        if pre is not None and pre[4] == float(p):
+            # the two sites (and their keep bits) were drawn with the producing layer's own dropout: ops.linear_act(gate_sites=...)
+            sa, sb, gate = pre[0], pre[1], (pre[2], pre[3])
+            seed, rr = rng.seed, pre[5]
+        else:
+            sa = rng.site(tag + "att_a", tuple(h.shape), p)
+            sb = rng.site(tag + "att_b", tuple(h.shape), p)
+            seed, rr = rng.seed, rng.row_map(h.shape[0], tag + "att_a")
     # grad mode is always off INSIDE Function.forward, so "nothing here will be differentiated" is decided out here
     nograd = not torch.is_grad_enabled() or not any(t.requires_grad for t in (h, Wa, ba, Wb, bb, wc, bc))
     hpl = planes_of(h) if (h.shape[0] >= 4096 and h.is_contiguous() and get_gemm_mode() == "bf16x3"
@@ -1517,7 +1593,7 @@ def gated_attn_pool(h, Wa, ba, Wb, bb, wc, bc, p=0.0, rng=None, tag="", seg=None
         if hpl is None or not hpl.fp32_stale:
             raise RuntimeError("advmil_amd: a planes-only activation reached the gated-attention pool without its planes")
     pooled, A, s = GatedAttnPoolFn.apply(h, Wa, ba, Wb, bb, wc, bc, float(p), seed, sa, sb, seg, nograd, rr, hpl,
-                                         getattr(h, "_advmil_act_fusable", None))
+                                         getattr(h, "_advmil_act_fusable", None), gate)
     return (pooled[0] if seg is None else pooled), A, s
 
 
@@ -2139,7 +2215,7 @@ def skinny_linear(x, W, b, act="none"):
     return SkinnyLinearFn.apply(x, W, b, _ACT[act])
 
 
-def gate_interleave(Wa, ba, Wb, bb, D, planes=False):
+def gate_interleave(Wa, ba, Wb, bb, D, planes=False, pair32=False):
     """Rows a0, b0, a1, b1, ... of the two attention branches as one [2D, D] matrix (+ its bf16x3 planes) and the interleaved bias:
     the operand layout of the fused gate score (advmil_gate_interleave)."""
     Wa, Wb, ba, bb = (t.contiguous() for t in (Wa, Wb, ba, bb))
@@ -2148,7 +2224,7 @@ def gate_interleave(Wa, ba, Wb, bb, D, planes=False):
     bi = torch.empty(2 * D, dtype=torch.float32, device=dev)
     pl = Planes.alloc((2 * D, D), dev) if planes else None
     _lib.check(_lib.lib().advmil_gate_interleave(_p(Wa), _p(Wb), _p(ba), _p(bb), D, _p(Wi), _p(None if pl is None else pl.hi),
-                                                 _p(None if pl is None else pl.lo), _p(bi), _stream()), "gate_interleave")
+                                                 _p(None if pl is None else pl.lo), _p(bi), 1 if pair32 else 0, _stream()), "gate_interleave")
     return Wi, bi, pl
 
 

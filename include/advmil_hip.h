@@ -112,6 +112,18 @@ typedef struct {
    * epilogue parks a wave's words in LDS before its first store: no per-element mask load inside the store loop. */
   const uint32_t* maskbits;
   int64_t ldbits;
+  /* TRAINING form of the fused gate score (tiles 85 / 86, plain launches): gate_wc / gate_out / gate_np as above, but B's rows are the two
+   * branches in BLOCKS of 32 (advmil_gate_interleave with pair32 = 1: [a_0..31 | b_0..31 | a_32..63 | ...]) and C IS written -- tanh on the
+   * a blocks, sigmoid on the b blocks, in that blocked column order (advmil_gate_bwd with pair32 = 1 reads it back) --, while the row's
+   * sum_j (a_j ka_j)(b_j kb_j) gate_wc[j] over each column block is reduced on the way into gate_out. ka / kb = drop_p-dropout keep
+   * factors given as bits: gate_bits_a / gate_bits_b [M, ldgbits] uint32, bit j % 32 of word (m, j / 32) (advmil_dropout_planes draws them).
+   * Attn_Net_Gated in train mode (model/backbone_utils.py:24-29) without a pass over its stored activations. */
+  const uint32_t* gate_bits_a;
+  const uint32_t* gate_bits_b;
+  int64_t ldgbits;
+  /* The M rows of this launch's result are in that pair-block order (dWab = dG^T h with dG from advmil_gate_bwd(pair32 = 1)) while C holds
+   * [branch][unit] rows: accumulating split-K launches only (splits > 1, accumulate, no other epilogue term) -- the merge un-permutes. */
+  int c_rows_pair32;
 } advmil_epilogue_t;
 
 size_t advmil_gemm_f32_workspace_bytes(int64_t M, int64_t N, int splits);
@@ -127,7 +139,7 @@ int advmil_split_planes(const float* src, int64_t n, void* hi, void* lo, advmil_
  * (reference model/backbone_utils.py Attn_Net_Gated: attention_a / attention_b), its planes (Wi_hi / Wi_lo, both or neither) and the
  * interleaved bias bi[2D]; and s[n] = sum_j partial[n][j] + bc[0] over the np per-column-block partials the epilogue wrote (bc may be NULL). */
 int advmil_gate_interleave(const float* Wa, const float* Wb, const float* ba, const float* bb, int D, float* Wi, void* Wi_hi, void* Wi_lo,
-                           float* bi, advmil_stream_t stream);
+                           float* bi, int pair32, advmil_stream_t stream);
 int advmil_gate_partial_sum(const float* partial, int np, const float* bc, int64_t N, float* s, advmil_stream_t stream);
 /* column blocks a launch with this tile writes per row in gate-score mode (see advmil_epilogue_t.gate_wc) */
 int advmil_gemm_f32_gate_blocks(int tile, int64_t N);
@@ -219,6 +231,8 @@ int advmil_add_dropout_ln_bwd(const float* dy, const float* z, const float* gamm
  *   dA may be NULL. (dh gets A[n]*dpooled[d] through the rank-1 term of the gemm epilogue.)
  * gate_bwd: from ds -> dG[N,2D] = grads wrt the two pre-activations, plus dwc[D], dbc[1], dbias[2D]
  *   (column sums of dG).
+ * pair32 (gate_bwd): ab and dG hold the branches in blocks of 32 columns ([a_0..31 | b_0..31 | a_32..63 | ...], the layout the fused training
+ *   gate score stores: advmil_epilogue_t.gate_bits_a) instead of [a | b] halves; the parameter gradients keep their own order.
  * dG_hi / dG_lo (gate_bwd), out_hi / out_lo (act_dropout_bwd): optional (both or neither) bf16 [rows, cols] buffers that also receive
  *   the bf16x3 operand planes of the result, for the plane-fed contraction that reads it next.
  * `accumulate` (here and in the other backward entry points): non-zero ADDS the parameter gradients into the
@@ -253,9 +267,13 @@ int advmil_softmax_pool_bwd_planes(const float* dpooled, const float* dA, const 
 /* Train-mode dropout of a tensor held as operand planes [M, N] (N % 32 == 0): out planes = split(dropout(in_hi + in_lo)), drawn at
  * (seed, stream_id, element index rng_row[m] * N + n) exactly as advmil_act_dropout_bwd's replay draws it, and bits[m * N / 32 + n / 32]
  * bit n % 32 = (out > 0) (NULL: no bits). The train-mode forward of a ReLU layer whose eval-mode output is memoized as planes
- * (model/backbone.py:60-66 run twice per optimizer step, model_handler.py:398-400 / 420-425). */
+ * (model/backbone.py:60-66 run twice per optimizer step, model_handler.py:398-400 / 420-425).
+ * gate_bits_a / gate_bits_b (optional, both or neither; uint32 [M, N / 32]): the KEEP bits of two more dropouts of rate gate_p over the same
+ * [M, N] index space, streams gate_stream_a / _b -- the gated attention scorer's branch dropouts (model/backbone_utils.py:24-29), drawn here
+ * for the fused training gate score (advmil_epilogue_t.gate_bits_a). */
 int advmil_dropout_planes(const void* in_hi, const void* in_lo, int64_t M, int64_t N, float drop_p, const uint64_t* seed, uint64_t stream_id,
-                          const int64_t* rng_row, void* out_hi, void* out_lo, void* bits, advmil_stream_t stream);
+                          const int64_t* rng_row, void* out_hi, void* out_lo, void* bits, float gate_p, uint64_t gate_stream_a,
+                          uint64_t gate_stream_b, void* gate_bits_a, void* gate_bits_b, advmil_stream_t stream);
 /* dh[n, :] = A[n] * dpooled[rowseg[n], :] -- the backward of a pooling with constant weights (the per-bag mean of the region features in
  * the projection discriminator's region-level inner product, GANSurv.py:96-98). rowseg: int32 bag index per row, NULL = one bag. */
 int advmil_seg_scale_rows(const float* dpooled, const float* A, const int32_t* rowseg, int64_t N, int64_t D, float* dh,
@@ -263,7 +281,7 @@ int advmil_seg_scale_rows(const float* dpooled, const float* A, const int32_t* r
 size_t advmil_gate_bwd_workspace_bytes(int64_t N, int64_t D);
 int advmil_gate_bwd(const float* ab, const float* ds, const float* wc, float drop_p, const uint64_t* seed,
                     uint64_t stream_a, uint64_t stream_b, int64_t N, int64_t D, float* dG, float* dwc, float* dbc,
-                    float* dbias, int accumulate, const int64_t* rng_row, void* dG_hi, void* dG_lo, void* ws, size_t ws_bytes,
+                    float* dbias, int accumulate, const int64_t* rng_row, void* dG_hi, void* dG_lo, int pair32, void* ws, size_t ws_bytes,
                     advmil_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

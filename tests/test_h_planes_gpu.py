@@ -150,3 +150,53 @@ def test_chained_forward_memo_is_bitwise_neutral(kind):
     assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     if kind == "patch":
         assert a[3] == b[3] - 2, (a[3], b[3])           # one LayerNorm/ReLU/mean16 launch less per optimizer step
+
+
+def _gate_step(fused, nb=8, n=8192):
+    old = ops.FUSED_GATE_TRAIN
+    ops.FUSED_GATE_TRAIN = fused
+    prev = ops.get_gemm_mode()
+    try:
+        h, _, _ = make_handler("abmil", bp_every_batch=nb, gemm_mode="bf16x3")
+        xs = [[H.bag(i, n, DEV), torch.zeros(1, 1, device=DEV)] for i in range(nb)]
+        ys_host = [H.label(i) for i in range(nb)]
+        ys = [y.to(DEV) for y in ys_host]
+        h.rng.reset(5)
+        plan = h._plan(xs, ys, "wlabel", None, ys_host)
+        seen = []
+        real = ops.gate_score
+
+        def spy(*a, **k):
+            seen.append(a[3:5])
+            return real(*a, **k)
+        ops.gate_score = spy
+        try:
+            preds, _ = h._disc_backward(0, xs, ys, plan)
+            h.optimizerD.step()
+            h._gen_backward(0, xs, ys, plan)
+        finally:
+            ops.gate_score = real
+        torch.cuda.synchronize()
+        return (torch.cat([q.detach().reshape(-1) for q in preds]).clone(), {k: p.grad.clone() for k, p in h.netG.named_parameters()}, seen,
+                h.netG.backbone.last_attention.clone())
+    finally:
+        ops.FUSED_GATE_TRAIN = old
+        ops.set_gemm_mode(prev)
+
+
+def test_training_gate_score_in_the_contraction_epilogue_equals_the_score_pass():
+    """Round 6 (ops.FUSED_GATE_TRAIN): the training pass of Attn_Net_Gated (model/backbone_utils.py:24-29, dropout 0.25 on both branches)
+    stores its activations in pair blocks of 32 columns and reduces the score in the contraction's epilogue from keep bits drawn by the
+    first layer's dropout launch; the backward reads the blocked layout and the weight gradient's merge un-permutes its rows. Same
+    draws, same products: attention weights and every generator gradient agree with the score-pass form to fp32 round-off."""
+    pa, ga, sa, Aa = _gate_step(True)
+    pb, gb, sb, Ab = _gate_step(False)
+    slab = 8 * 8192
+    assert not any(t[0] == slab for t in sa), sa                 # no pass over the stored [rows, 2D] activations ...
+    assert any(t[0] == slab for t in sb), sb                     # ... which the unfused form makes
+    assert float((pa - pb).abs().max()) < 1e-6
+    assert float((Aa - Ab).abs().max()) < 2e-7 and float(Aa.sum()) > 0
+    for k in ga:
+        a, b = ga[k].double(), gb[k].double()
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-8, (k, float((a - b).abs().max()), scale)
