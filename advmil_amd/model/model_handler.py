@@ -394,7 +394,11 @@ class MyHandler(object):
                         # whole 256-row tiles for the slab kernels' fast forms; with step graphs on, whole `step_graph_rows` (2048): the
                         # padded row count is part of a graph's key, so coarser steps mean fewer captures (at most 1.6 % more rows at 16 x 8192)
                         sg_on = self.step_graphs and self.dp.world == 1 and self.bcb == "abmil" and self.slab_pad > 0
-                        pad = stager.pad_rows(self.step_graph_rows if sg_on else self.slab_pad)
+                        gran = self.slab_pad
+                        if sg_on:            # <= 1.6 % more rows: 256 below 32768 rows, 2048 (step_graph_rows) from 131072 rows on
+                            while gran * 2 <= self.step_graph_rows and gran * 2 * 64 <= stager.rows:
+                                gran *= 2
+                        pad = stager.pad_rows(gran)
                     # (a batch that mixes staged and device bags is concatenated, i.e. read as fp32 rows)
                     for j, v in zip(staged_pos, stager.ready(need_rows=len(staged_pos) != len(x_col))):
                         x_col[j][0] = v
@@ -411,17 +415,20 @@ class MyHandler(object):
                 # ---- shape-keyed step graphs (round 6): a resident ragged step batch whose KEY has been seen before is REPLAYED -- the
                 # static plan's arrays are rewritten for this batch (one small copy), then one graph launch instead of ~53 eager ones
                 replayed = False
-                gkey = None
+                gkey = cap_ = None
                 self.rng.counter = site_base
+                if staged and len(staged_pos) == len(x_col) and self.step_graphs and self.dp.world == 1 and self.bcb == "abmil":
+                    # launch grids of the segmented kernels for the longest bag a step-graph key admits: for EVERY staged batch of this
+                    # loop, graph-eligible or not, so that eager and replayed steps (and fp32 / bf16 bag storage) share one geometry
+                    lens_ = [self._rows(x[0]) for x in x_col]
+                    cap_ = StaticStepPlan.bag_cap(lens_, pad, sum(lens_) + pad)
                 if (staged and len(staged_pos) == len(x_col) and self.step_graphs and self.dp.world == 1 and self.bcb == "abmil"
                         and self.noise_hook is None and num_update_gen == 1 and ys_host is not None and bpl is not None
                         and not torch.cuda.is_current_stream_capturing()):
                     n_ = len(x_col)
                     vis_ = self._vis(mode, n_, mask)
                     real_ = [bool(float(yh[0, 1]) == 1.0) and vis_[i] for i, yh in enumerate(ys_host)]
-                    lens_ = [self._rows(x[0]) for x in x_col]
                     x0_ = x_col[0][0]
-                    cap_ = StaticStepPlan.bag_cap(lens_, pad, sum(lens_) + pad)
                     gkey = (self.bcb, n_, sum(lens_) + pad, cap_, int(x0_.shape[-1]), x0_.dtype, x0_.data_ptr(), bool(pad), sum(real_), n_, sum(vis_),
                             all(vis_), mode, bool(stager.stale), ops.get_gemm_mode(), self.optimizerG.param_groups[0]["lr"],
                             self.optimizerD.param_groups[0]["lr"])
@@ -465,7 +472,7 @@ class MyHandler(object):
                             replayed = True
                 if not replayed:
                     plan = self._plan(x_col, y_col, mode, mask, ys_host, y_step, pad)   # ONE plan per step batch, shared by the D and G updates
-                    if gkey is not None:     # (a batch a step graph could stand for: the same launch grids as its capture -- StaticStepPlan)
+                    if cap_ is not None:     # (the same launch grids as a step graph's capture: StaticStepPlan)
                         plan.seg.max_len, plan.seg16.max_len, plan.seg16.twice().max_len = cap_, cap_ // 16, cap_ // 16
                     # bag-parallel: D's gradient exchange is started asynchronously and completed inside the first generator update, after
                     # the generator's backbone forward (which does not depend on D) has been enqueued -> the two overlap

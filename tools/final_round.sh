@@ -6,9 +6,9 @@ cd "${GRAFT_REPO_ROOT:-.}"
 parts="${@:-evidence steps prof}"
 for p in $parts; do
   case $p in
-    evidence) bash tools/evidence_round.sh gpurun_out/evidence_r05 ;;
-    steps) bash tools/step_profiles.sh gpurun_out/steps_r05 ;;
-    prof) ROUND=r05 bash tools/profile_round.sh bench; ROUND=r05 bash tools/profile_round.sh pool; ROUND=r05 bash tools/profile_round.sh gemm ;;
-    fuzz) bash tools/fuzz_round.sh gpurun_out/fuzz_r05 100 ;;
+    evidence) bash tools/evidence_round.sh gpurun_out/evidence_r06 ;;
+    steps) bash tools/step_profiles.sh gpurun_out/steps_r06 ;;
+    prof) ROUND=r06 bash tools/profile_round.sh bench; ROUND=r06 bash tools/profile_round.sh pool; ROUND=r06 bash tools/profile_round.sh gemm ;;
+    fuzz) bash tools/fuzz_round.sh gpurun_out/fuzz_r06 100 ;;
   esac
 done

@@ -2,7 +2,7 @@
 # The randomised parity tools on NEW seeds (every case a fuzzer COUNTS instead of failing is appended to gpurun_out/fuzz_counted_cases.jsonl with
 # its seeds). usage (GPU box): tools/fuzz_round.sh [outdir] [seed offset]; copy what is to be judged into profiles/.
 cd "${GRAFT_REPO_ROOT:-.}"
-O=${1:-gpurun_out/fuzz_r05}
+O=${1:-gpurun_out/fuzz_r06}
 S=${2:-0}
 mkdir -p $O
 rm -f gpurun_out/fuzz_counted_cases.jsonl

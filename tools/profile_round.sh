@@ -1,10 +1,10 @@
 #!/bin/bash
-# rocprofv3 evidence for the numbers bench.py prints (run on the GPU box through gpurun; outputs under gpurun_out/prof_<round>/ (ROUND=r05 by default)).
+# rocprofv3 evidence for the numbers bench.py prints (run on the GPU box through gpurun; outputs under gpurun_out/prof_<round>/ (ROUND=r06 by default)).
 # Kernel-trace + stats runs and PMC runs are SEPARATE invocations (the pool refuses --pmc combined with API traces).
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-O=gpurun_out/prof_${ROUND:-r05}
+O=gpurun_out/prof_${ROUND:-r06}
 mkdir -p $O
 what="${1:-all}"
 if [ "$what" = all ] || [ "$what" = bench ]; then

@@ -4,7 +4,7 @@
 # at W = 16 / 8), ESAT 32k, PatchGCN 4096. usage (GPU box): tools/step_profiles.sh [outdir]
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-O=${1:-gpurun_out/steps_r05}
+O=${1:-gpurun_out/steps_r06}
 mkdir -p $O
 run() {  # tag, bench args...
   tag=$1; shift

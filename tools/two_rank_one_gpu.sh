@@ -7,6 +7,11 @@ set -e
 export ADVMIL_DIST_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 \
     bench.py --gpus 2 --steps 4 --warmup 1 --patches 2048 --pool 8 --bags 4
+# ... and with 4 and 8 ranks (the 16-bag step split 4 / 2 bags per rank in the strong leg): the row maps of every fused kernel above W = 2
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29615 \
+    bench.py --gpus 4 --steps 3 --warmup 1 --patches 1024 --pool 8 --bags 4 --no-cpu-baseline
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29617 \
+    bench.py --gpus 8 --steps 3 --warmup 1 --patches 1024 --pool 4 --bags 2 --no-cpu-baseline
 # the stall watchdog: rank 1 stops before the first collective of the timed legs -> every rank must leave with a non-zero code within seconds
 set +e
 t0=$(date +%s)
