@@ -59,7 +59,9 @@ class ABMIL(nn.Module):
         gate = self.attention_net[3]
         pg = float(getattr(gate, "drop_p", 0.0)) if gate.training else 0.0
         # (gate_sites: the pool below draws the scorer's two dropout sites next -- their keep bits ride in this layer's dropout launch)
-        h = ops.linear_act(X, fc.weight, fc.bias, "relu", p, rng, "abmil_fc", emit_planes=True,
+        # (no-grad passes -- evaluation, the eval forward of a D update that did not take the two-layer launch: planes INSTEAD of fp32 rows)
+        only = (not torch.is_grad_enabled()) and p <= 0.0 and ops.H_PLANES_ONLY and fc.weight.shape[0] % 32 == 0
+        h = ops.linear_act(X, fc.weight, fc.bias, "relu", p, rng, "abmil_fc", emit_planes="only" if only else True,
                            gate_sites=(pg, "gate_att_a", "gate_att_b") if (pg > 0.0 and _rng_of(gate, X) is rng) else None)   # [N_total, hid]
         pooled, A, _ = self.attention_net[3].pool(h, seg)
         self.last_attention = A.detach()

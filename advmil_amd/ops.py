@@ -1358,7 +1358,9 @@ def linear_act(x, W, b, act="none", p=0.0, rng=None, tag="", emit_planes=False, 
     # emit y's planes only when the contraction that reads y (the gate branches: N' = 2N columns over K' = N) will take them
     emit = bool(emit_planes) and big and bool(gemm_plan_planes(x2.shape[0], 2 * W.shape[0], W.shape[0]))
     if emit_planes == "only":                 # planes INSTEAD of fp32 values (the caller guarantees a planes-only consumer): any slab-sized layer
-        emit = "only" if (big and act == "none" and p <= 0.0 and y0 is None and W.shape[0] % 8 == 0 and ATTN_QKV_PLANES) else False
+        # (an activated layer only where nothing will differentiate through it: its backward would need the values)
+        emit = "only" if (big and (act == "none" or not torch.is_grad_enabled()) and p <= 0.0 and y0 is None and W.shape[0] % 8 == 0
+                          and ATTN_QKV_PLANES and (act == "none" or emit)) else (emit if act != "none" else False)
     # gate_sites = (p_gate, tag_a, tag_b): the output feeds a gated attention pool that will draw these two dropout sites next; when this
     # call turns out to be the planes-to-planes dropout replay, their keep bits are drawn in the same launch (FUSED_GATE_TRAIN)
     LinearActFn.gate_request = ((float(gate_sites[0]), gate_sites[1], gate_sites[2], rng) if (gate_sites is not None and FUSED_GATE_TRAIN

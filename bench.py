@@ -964,7 +964,7 @@ def main():
         achieved = flops / us / 1e6
         traffic, traffic_src = None, None
         try:      # PMC passes are separate runs (profiles/README.md); only a measurement of THIS kernel + shape + mode counts
-            pmc_name = next(n for n in ("r05_pmc_gemm.json", "r04_pmc_gemm.json", "r03_pmc_gemm.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+            pmc_name = next(n for n in ("r06_pmc_gemm.json", "r05_pmc_gemm.json", "r04_pmc_gemm.json", "r03_pmc_gemm.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
             ent = pmc.get("planes_kernel_launches" if planes_kernel else "launches", {}).get(f"{M}x{N}x{K}")
             same = ent and (ent.get("kernel", "").startswith(kname.split(",")[0].rstrip(">")) if planes_kernel else ent.get("kernel") == kname)
