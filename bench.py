@@ -281,7 +281,7 @@ def in_step_launch_us(torch, ops, case, replays=8):
                 a["us"].append(us)
     h.history.clear()
     del g
-    return {k: {"flops": v["flops"], "us": sum(v["us"]) / len(v["us"]), "n": len(v["us"]) // replays} for k, v in acc.items()}
+    return {k: {"flops": v["flops"], "us": sum(v["us"]) / len(v["us"]), "n": len(v["us"]) // replays, "series": v["us"]} for k, v in acc.items()}
 
 
 def event_time_us(torch, fn, iters, warm=3):
@@ -361,8 +361,17 @@ def pool_roofline(torch, ops, dev, patches, bags, iters=40, in_step=None):
         hits = [v for k, v in in_step.items() if k[0] == "softmax_pool_fwd" and k[1][0] == nrows and k[1][1] == Dh]
         if hits:
             us_i = sum(v["us"] * v["n"] for v in hits) / sum(v["n"] for v in hits)
+            per = None
+            if len(hits) == 1 and hits[0]["n"] == 2:      # program order inside a step: the generator's eval pass (D update), then its training pass
+                ser = hits[0]["series"]
+                ev_, tr_ = ser[0::2], ser[1::2]
+                per = {"eval_pass_us": round(sum(ev_) / len(ev_), 2), "train_pass_us": round(sum(tr_) / len(tr_), 2)}
+                per["eval_pass_frac"] = round(byt / per["eval_pass_us"] / 1e3 / 8000.0, 4)
+                per["train_pass_frac"] = round(byt / per["train_pass_us"] / 1e3 / 8000.0, 4)
+                per["note"] = ("the training pass's call runs right behind the gate contraction that STORES 403 MB of activations: it pays the write-back of "
+                               "those dirty Infinity-Cache lines (tools/probe/pool_instep.py; DESIGN.md 4.3c); the eval pass's call has no such neighbour")
             ist = {"avg_call_us": round(us_i, 2), "calls_per_step": sum(v["n"] for v in hits), "achieved": round(byt / us_i / 1e3, 1),
-                   "frac": round(byt / us_i / 1e3 / 8000.0, 4),
+                   "frac": round(byt / us_i / 1e3 / 8000.0, 4), "per_call": per,
                    "method": "device wall-clock stamps around the step's own advmil_softmax_pool_fwd calls inside a captured step (both launches + "
                              "the two inter-kernel gaps): the call between its real neighbours, at the clock the step runs at"}
     return {"bound": "hbm", "in_step": ist, "kernel": "pool_partial8_online + pool_merge_online (advmil_softmax_pool_fwd, 2 launches: online-softmax partials, merge + A)",

@@ -63,17 +63,20 @@ if fe:
     rows, D = 131072, 384
     st16, st1 = stats_avg("pool16"), stats_avg("pool1")
     out = {"command": "rocprofv3 --pmc FETCH_SIZE -- python3 tools/pool_bench.py 8192 16 12 ; separate --pmc WRITE_SIZE pass; "
-                      "durations: rocprofv3 --kernel-trace --stats -- python3 tools/pool_bench.py 8192 16 40 (and 8192 1 200)",
+                      "durations: rocprofv3 --kernel-trace --stats -- python3 tools/pool_bench.py 8192 16 40 (and 8192 1 200); h as operand planes "
+                      "(pool_bench.py's default since round 6: the <.., true> instantiations)",
            "units": "FETCH_SIZE / WRITE_SIZE are KB; FETCH_SIZE x2 (gfx950: wide coalesced reads tallied at half their bytes)",
            "rows": rows, "D": D, "kernels": {}}
-    for k in ("pool_partial8_online_kernel", "pool_merge_online_kernel", "pool_partial8_kernel", "pool_bwd_dot_kernel", "softmax_stats_kernel",
-              "pool_bwd_ds_kernel", "colsum_merge_kernel"):
-        if k not in fe:
+    wanted = ("pool_partial8_online_kernel", "pool_merge_online_kernel", "pool_partial8_kernel", "pool_bwd_dot_kernel", "softmax_stats_kernel",
+              "pool_bwd_ds_kernel", "colsum_merge_kernel")
+    for k in sorted(fe):                      # (templated kernels appear with their arguments: <MEAN, PL> -- PL = h read as operand planes)
+        base = k.split("<")[0]
+        if base not in wanted:
             continue
         fetched = 2.0 * fe[k][1] * 1024
         written = wr.get(k, (0, 0.0))[1] * 1024
         alg = {"pool_partial8_kernel": 4.0 * rows * D + 4.0 * rows, "pool_partial8_online_kernel": 4.0 * rows * D + 4.0 * rows,
-               "pool_bwd_dot_kernel": 4.0 * rows * D + 8.0 * rows}.get(k)
+               "pool_bwd_dot_kernel": 4.0 * rows * D + 8.0 * rows}.get(base)
         ent = {"fetch_bytes_per_launch": fetched, "write_bytes_per_launch": written, "hbm_bytes_per_launch": fetched + written,
                "algorithmic_bytes_per_launch": alg}
         if k in st16:
