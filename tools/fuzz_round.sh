@@ -2,6 +2,9 @@
 # The randomised parity tools on NEW seeds (every case a fuzzer COUNTS instead of failing is appended to gpurun_out/fuzz_counted_cases.jsonl with
 # its seeds). usage (GPU box): tools/fuzz_round.sh [outdir] [seed offset]; copy what is to be judged into profiles/.
 cd "${GRAFT_REPO_ROOT:-.}"
+# the probes' bounds are written for the exact arithmetic as the starting mode (those that cover bf16x3 select it themselves); the library's own
+# default is bf16x3 since round 6, so say so here, as tests/test_fuzz_gpu.py does
+export ADVMIL_GEMM_MODE=exact
 O=${1:-gpurun_out/fuzz_r06}
 S=${2:-0}
 mkdir -p $O
