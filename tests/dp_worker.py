@@ -25,13 +25,19 @@ LENS_BP16 = (256, 128, 64, 192, 320, 96, 160, 224, 48, 272, 112, 208, 80, 304, 1
              240, 32, 288, 128, 64, 336, 96, 192, 160, 16, 224, 256, 112, 80, 208, 144)
 
 
+# `big`: slab-sized bags (2 steps x 4 bags of ~8192 patches): with two ranks each rank's step slab is 16 384 rows -- the size class where the
+# two-layer launch, the planes-only first layer, the dropout of planes with the scorer's keep bits and the fused training gate score all run
+# (round 6), each with this rank's dropout row map
+LENS_BIG = (8192, 8176, 8208, 8192, 8160, 8224, 8192, 8192)
+
+
 def build_loader(kind, idxs, lens=LENS):
     from types import SimpleNamespace
     from advmil_amd import synth
     from tests import helpers as H
     loader = []
     for i in idxs:
-        x = H.bag(300 + i, max(512, max(lens)))[:, :lens[i]].contiguous()
+        x = H.bag(300 + i, max(512, max(lens)))[:, :lens[i]].contiguous() if max(lens) <= 4096 else H.bag(300 + i, lens[i])
         if kind == "graph":                  # PatchGCN: device-resident graph objects (x [N, C], edge_index [2, 8N]), as the bench feeds them
             x = x.to("cuda:0")
             ext = SimpleNamespace(x=x[0], edge_index=H.T(synth.grid_knn_graph(lens[i], 8), "cuda:0"))
@@ -49,6 +55,8 @@ def run(kind, world, rank, dp=None, device="cuda:0"):
     lens, bp = LENS, 4
     if kind.endswith("-bp16"):
         kind, lens, bp = kind[:-len("-bp16")], LENS_BP16, 16
+    elif kind.endswith("-big"):
+        kind, lens = kind[:-len("-big")], LENS_BIG
     elif kind.endswith("-collide"):
         kind, lens = kind[:-len("-collide")], LENS_COLLIDE
     elif kind.endswith("-pad"):
@@ -56,6 +64,8 @@ def run(kind, world, rank, dp=None, device="cuda:0"):
     elif kind.endswith("-env"):                      # tools/probe/dp_fuzz.py: eight bag lengths from the environment
         kind, lens = kind[:-len("-env")], tuple(int(v) for v in os.environ["DP_LENS"].split(","))
     cfg = default_cfg(bcb_mode=kind, bp_every_batch=bp)        # the GLOBAL step batch: every rank steps after bp / world of its bags
+    if lens is LENS_BIG:
+        cfg["gemm_mode"] = "bf16x3"          # the product's default arithmetic: the operand-plane paths only exist in it
     if kind == "graph":
         cfg.update(bcb_dims="1024-128-128", gen_dims="128-1")
     h = MyHandler(cfg, device=device, parallel=dp)
@@ -65,9 +75,15 @@ def run(kind, world, rank, dp=None, device="cuda:0"):
     h.rng.reset(4321)
     from advmil_amd.parallel import BagParallel
     idxs = (dp or BagParallel()).shard_epoch(list(range(len(lens))), bp)    # bag i of a global step batch -> rank i mod W
-    cl = h._train_each_epoch(build_loader(kind, idxs, lens), "train", "wlabel")
+    from advmil_amd import ops
+    score_rows, real_score = [], ops.gate_score
+    ops.gate_score = lambda *a, **k: (score_rows.append(int(a[3])), real_score(*a, **k))[1]      # (which slabs still take the score PASS)
+    try:
+        cl = h._train_each_epoch(build_loader(kind, idxs, lens), "train", "wlabel")
+    finally:
+        ops.gate_score = real_score
     logs = h.pop_logs()
-    return {"cl": cl, "logs": logs, "G": {k: v.detach().cpu() for k, v in h.netG.state_dict().items()},
+    return {"cl": cl, "logs": logs, "gate_score_rows": score_rows, "G": {k: v.detach().cpu() for k, v in h.netG.state_dict().items()},
             "D": {k: v.detach().cpu() for k, v in h.netD.state_dict().items()}}
 
 

@@ -17,6 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _CASES = [(k, 2) for k in ("abmil", "patch", "cluster", "graph", "abmil-collide", "patch-collide", "abmil-pad", "patch-pad", "cluster-pad")]
 # the shipped step batch of 16 bags split over 4 and 8 ranks (4 / 2 bags per rank): the row maps of every fused kernel above W = 2
 _CASES += [("abmil-bp16", 4), ("abmil-bp16", 8), ("patch-bp16", 4), ("patch-bp16", 8), ("cluster-bp16", 8)]
+# slab-sized bags: the round-6 plane paths (planes-only first layer, keep bits drawn with the dropout replay, fused training gate score) under a
+# rank's dropout row map -- what a rank of the 8-GPU strong split runs
+_CASES += [("abmil-big", 2)]
 
 
 @pytest.mark.timeout(900)
@@ -36,6 +39,11 @@ def test_multi_rank_step_equals_single_rank_with_dropout_on(kind, world, tmp_pat
             if p.poll() is None:
                 p.kill()
     got = torch.load(out, weights_only=False)
+    if kind.endswith("-big"):
+        # the rank really took the round-6 plane paths: no pass of gate_score_kernel over its 16 384-row slab (the score came out of the gate
+        # contraction's epilogue, from keep bits drawn under this rank's row map), and neither did the single process over its 32 768 rows
+        assert not [n for n in got["gate_score_rows"] if n >= 16384], got["gate_score_rows"]
+        assert not [n for n in want["gate_score_rows"] if n >= 16384], want["gate_score_rows"]
     # epoch collector in global bag order
     for k in ("y", "y_hat", "f_fake"):
         a, b = got["cl"][k].double().reshape(-1), want["cl"][k].double().reshape(-1)
