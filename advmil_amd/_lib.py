@@ -91,6 +91,9 @@ SIGNATURES = {
     "advmil_mha_bwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "advmil_mha_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64,
                                c_float, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "advmil_mha_bwd1_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int64]),
+    "advmil_mha_bwd1": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64,
+                                c_float, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "advmil_add_dropout_ln_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int64, c_float, c_void_p,
                                           c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "advmil_add_dropout_ln_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64]),

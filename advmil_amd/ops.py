@@ -1801,13 +1801,26 @@ class MhaFn(torch.autograd.Function):
         nseg = 1 if seg is None else seg.nseg
         mlen = Lt if seg is None else seg.max_len
         ptr = None if seg is None else seg.ptr
-        wsb = L.advmil_mha_bwd_workspace_bytes(Lt, nhead, hd)
+        one = mha_bwd_single_pass(mlen, hd)
+        wsb = L.advmil_mha_bwd1_workspace_bytes(Lt, nhead, hd, mlen) if one else L.advmil_mha_bwd_workspace_bytes(Lt, nhead, hd)
         ws = _ws(wsb, qhi.device)
         _stamp("b", "mha_bwd", (Lt, nhead, hd, nseg), 0.0)
-        _lib.check(L.advmil_mha_bwd(_p(qhi), _p(qlo), _p(out), _p(dO), _p(lse), Lt, nhead, hd, nseg, _p(ptr), mlen, p,
-                                    _p(seed if p > 0.0 else None), sid, _p(rowoff), _p(dqkv), _p(ws), wsb, _stream()), "mha_bwd")
+        _lib.check((L.advmil_mha_bwd1 if one else L.advmil_mha_bwd)(
+            _p(qhi), _p(qlo), _p(out), _p(dO), _p(lse), Lt, nhead, hd, nseg, _p(ptr), mlen, p, _p(seed if p > 0.0 else None), sid,
+            _p(rowoff), _p(dqkv), _p(ws), wsb, _stream()), "mha_bwd1" if one else "mha_bwd")
         _stamp("e", "mha_bwd", (Lt, nhead, hd, nseg), 0.0)
         return dqkv, None, None, None, None, None, None, None
+
+
+# Backward form of the attention core: "one" = advmil_mha_bwd1 (single pass over the scores, dQ through per-key-block partial
+# slabs), "two" = advmil_mha_bwd (dQ and dK / dV launches, each recomputing the scores). ADVMIL_ATTN_BWD pins one of them.
+ATTN_BWD = os.environ.get("ADVMIL_ATTN_BWD", "auto")
+
+
+def mha_bwd_single_pass(max_len, head_dim):
+    if ATTN_BWD in ("one", "two"):
+        return ATTN_BWD == "one"
+    return True
 
 
 _MHA_P_WARNED = set()

@@ -204,6 +204,16 @@ size_t advmil_mha_bwd_workspace_bytes(int64_t Ltot, int nhead, int head_dim);
 int advmil_mha_bwd(const void* qkv_hi, const void* qkv_lo, const float* out, const float* dout, const float* lse, int64_t Ltot,
                    int nhead, int head_dim, int nseg, const int64_t* ptr, int64_t max_len, float drop_p, const uint64_t* seed,
                    uint64_t stream_id, const int64_t* rng_rowoff, float* dqkv, void* ws, size_t ws_bytes, advmil_stream_t stream);
+/* The same backward in ONE pass over the scores (csrc/attn_bwd1.hip; round 6): keys stationary, dK / dV as above, and dQ from the
+ * same score tiles -- dS goes through LDS once, each 256-key block leaves an unscaled partial slab [Ltot, nhead*head_dim] in the
+ * workspace, and a reduce launch sums the blocks of a bag in block order into the q columns of dqkv. Five contractions instead of the
+ * seven of advmil_mha_bwd (which recomputes S and dP for dQ), same arguments, same dropout stream, deterministic (no atomics); results
+ * differ from advmil_mha_bwd's only in the summation order of dQ. ws >= advmil_mha_bwd1_workspace_bytes (D, the planes of dO and
+ * ceil(max_len / 256) partial slabs). */
+size_t advmil_mha_bwd1_workspace_bytes(int64_t Ltot, int nhead, int head_dim, int64_t max_len);
+int advmil_mha_bwd1(const void* qkv_hi, const void* qkv_lo, const float* out, const float* dout, const float* lse, int64_t Ltot,
+                    int nhead, int head_dim, int nseg, const int64_t* ptr, int64_t max_len, float drop_p, const uint64_t* seed,
+                    uint64_t stream_id, const int64_t* rng_rowoff, float* dqkv, void* ws, size_t ws_bytes, advmil_stream_t stream);
 /* Post-norm residual of the same layer (norm_first = False):  y = LayerNorm(x + dropout(o)) over rows of width d <= 512.
  * fwd also writes z = x + dropout(o), mean[R], rstd[R] for the backward; dropout element index = row*d + col on `stream_id`.
  * bwd: dx = LayerNorm'(dy); dob (may be NULL) = dx * keep; dgamma / dbeta = column sums (accumulate != 0 adds into them).

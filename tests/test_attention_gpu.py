@@ -32,6 +32,16 @@ def mode(request, ops):
     ops.set_gemm_mode(prev)
 
 
+@pytest.fixture(params=["two", "one"])
+def bwd_form(request, ops):
+    """Both backward forms of the attention core: advmil_mha_bwd (two launches, scores recomputed for dQ) and advmil_mha_bwd1
+    (single pass, dQ through per-key-block partial slabs)."""
+    prev = ops.ATTN_BWD
+    ops.ATTN_BWD = request.param
+    yield request.param
+    ops.ATTN_BWD = prev
+
+
 def rnd(tag, *shape, scale=1.0):
     n = int(np.prod(shape))
     return H.T(synth.normal(synth.stream_key(23, tag), n).reshape(shape) * np.float32(scale))
@@ -68,8 +78,8 @@ def host_masks(seed, sid, lens, p, rowoff=None):
 
 
 @pytest.mark.parametrize("lens,p", [([32], 0.0), ([70], 0.0), ([210], 0.25), ([512], 0.25), ([128, 64, 200], 0.25),
-                                    ([1, 5, 129], 0.0), ([2048], 0.25)])
-def test_mha_fused_fwd_bwd_vs_float64(ops, mode, lens, p):
+                                    ([1, 5, 129], 0.0), ([2048], 0.25), ([700, 257, 33, 1025], 0.25)])
+def test_mha_fused_fwd_bwd_vs_float64(ops, mode, bwd_form, lens, p):
     Lt = sum(lens)
     qkv = rnd(f"q{lens}", Lt, 3 * D, scale=0.7); go = rnd(f"g{lens}", Lt, D)
     seg = ops.Segments(lens, DEV) if len(lens) > 1 else None
@@ -94,7 +104,7 @@ def test_mha_fused_fwd_bwd_vs_float64(ops, mode, lens, p):
 
 
 @pytest.mark.parametrize("hd", [16, 32, 64])
-def test_mha_other_head_dims(ops, hd):
+def test_mha_other_head_dims(ops, bwd_form, hd):
     """nn.TransformerEncoderLayer(d_model = bcb_dims[1], nhead = 8) for the other backbone widths the reference's load_backbone
     accepts (model/backbone.py:30-33): d_model 128 / 256 / 512 -> head_dim 16 / 32 / 64, ragged bags, dropout on."""
     lens, p, d = [130, 64, 300], 0.25, NH * hd
@@ -114,6 +124,31 @@ def test_mha_other_head_dims(ops, hd):
     assert relerr(o, orf) < 1e-5, relerr(o, orf)
     for c in range(3):
         assert relerr(a.grad[:, c * d:(c + 1) * d], r.grad[:, c * d:(c + 1) * d]) < 5e-5, c
+
+
+@pytest.mark.parametrize("lens,p", [([300], 0.0), ([700, 257, 33, 1025, 1], 0.25), ([2048, 2048], 0.25)])
+def test_single_pass_backward_equals_the_two_launch_backward(ops, lens, p):
+    """advmil_mha_bwd1 against advmil_mha_bwd on the same saved forward: dK / dV come out of the same arithmetic in a different
+    order of 32-query steps, dQ is summed per 256-key block first -- fp32 round-off apart (1e-5 of each block's scale), every element."""
+    Lt = sum(lens)
+    qkv = rnd(f"sp{lens}", Lt, 3 * D, scale=0.7).to(DEV); go = rnd(f"spg{lens}", Lt, D).to(DEV)
+    seg = ops.Segments(lens, DEV)
+    grads = {}
+    prev = ops.ATTN_BWD
+    try:
+        for form in ("two", "one"):
+            ops.ATTN_BWD = form
+            rng = ops.DeviceRng(DEV, seed=79)
+            a = qkv.clone().requires_grad_(True)
+            o = ops.mha(a, NH, p, rng, seg=seg)
+            (o * go).sum().backward()
+            grads[form] = a.grad.clone()
+    finally:
+        ops.ATTN_BWD = prev
+    assert torch.isfinite(grads["one"]).all()
+    for c in range(3):
+        g1, g2 = grads["one"][:, c * D:(c + 1) * D], grads["two"][:, c * D:(c + 1) * D]
+        assert float((g1 - g2).abs().max() / g2.abs().max()) < 1e-5, c
 
 
 def test_attention_dropout_statistics():
