@@ -15,8 +15,8 @@
 //   part[key block][Ltot, H*HD];   dQ = scale * sum over the bag's key blocks, in block order  (attn_dq_reduce_kernel).
 // No atomics: results are deterministic. Matrix instructions per (wave, 64 queries): 108 (two-launch form: 60 + 84).
 //
-// LDS (144.8 KB, one workgroup per CU): ring of 2 x 16 KB [Q hi | Q lo | dO hi | dO lo] x 32 rows by LDS-DMA, K image 64 KB,
-// dS image 32 KB, 16 KB of accumulator exchange (every dQ task parks its accumulator: nothing of a tile stays in registers across
+// LDS (152.8 KB, one workgroup per CU): ring of 2 x 16 KB [Q hi | Q lo | dO hi | dO lo] x 32 rows by LDS-DMA, K image 64 KB,
+// dS image 32 KB, 24 KB of accumulator exchange (every dQ task parks its accumulator: nothing of a tile stays in registers across
 // the next trip's scores), side data (lse, D, dropout row key) of two trips.
 // Barriers per trip: A (the previous trip's dQ readers are done with the dS image; their accumulators are parked) and
 // B (dS image complete, next tile and its side data visible, this trip's ring slot free).
@@ -35,7 +35,7 @@
 #define B1_DSPL (AT_QB * 64)              // dS image plane: 256 key rows x 64 B (32 queries)
 #define B1_DS_OFF (B1_KIMG_OFF + 2 * B1_KPL)
 #define B1_SCR_OFF (B1_DS_OFF + 2 * B1_DSPL)
-#define B1_SCR_B (4 * 4096)            // one parked 32x32 fp32 accumulator per dQ task
+#define B1_SCR_B (4 * 6144)            // parked dQ accumulators: per key part [head-dim block 0: 4 KB | block 1: <= 4 KB]
 #define B1_AUX_OFF (B1_SCR_OFF + B1_SCR_B)
 #define B1_TOTAL (B1_AUX_OFF + 2 * 3 * B1_QT * 4)
 #define B1_PPW 2                          // ring DMA pieces per wave and trip
@@ -63,8 +63,14 @@ struct Tr64 {
 template <int HD, bool DROP>
 __global__ __launch_bounds__(512, 2) void attn_bwd_one_kernel(AttnArgs a) {
   constexpr int KS = HD / 16, DT = (HD + 31) / 32, UN = HD / 8;
-  constexpr int KSPLIT = 4 / DT;                       // key parts of a dQ tile: 4 tasks per trip = DT head-dim blocks x KSPLIT
+  // dQ tasks of a trip: 4 (one per wave of the quartet) = (DT / NDT) head-dim block groups x KSPLIT key parts. head_dim 48 gives a
+  // wave BOTH head-dim blocks of a key quarter (the dS fragments are read once for the two: 12 transposed reads per 6 matrix
+  // instructions instead of 16 -- the stage is bound by LDS bandwidth) and parks 4 + 2 KB (block 1 holds 16 head dims); head_dim 64
+  // would need 32 KB of exchange space for that and keeps one block per wave.
+  constexpr int NDT = HD == 48 ? 2 : 1;
+  constexpr int KSPLIT = 4 * NDT / DT;
   constexpr int KSTEPS = (AT_QB / 16) / KSPLIT;        // 16-key k-steps per part
+  constexpr int PARTB = NDT == 2 ? 6144 : 4096 * DT;   // exchange bytes per key part: [block 0 | block 1]
   __shared__ __attribute__((aligned(16))) unsigned char smem[B1_TOTAL];
   float* const sAux = reinterpret_cast<float*>(smem + B1_AUX_OFF);       // per parity: lse[32] | D[32] | rowkey[32]
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, half = lane >> 5;
@@ -108,12 +114,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_one_kernel(AttnArgs a) {
   // zero) straight into the trip's [lse 32 | D 32 | rowkey 32] block; the dropout row keys are hashed by lanes 0-3 of every wave.
   // (Scalar loads would count on lgkmcnt, which every LDS read of the loop waits on; vector loads would make the compiler put a
   // vmcnt(0) on the partial-tile stores.)
-  const float* const aux_src = ((lane & 32) ? a.dsum : a.lse) + row0 * H + h;
   auto aux_issue = [&](int tile) {
     if (wave == 0) {
-      int64_t qq = (int64_t)tile * B1_QT + (lane & 31);
+      int l2 = threadIdx.x & 63;                        // (the per-lane source pointer is formed at the issue: carried, it spilled)
+      asm volatile("" : "+v"(l2));
+      int64_t qq = (int64_t)tile * B1_QT + (l2 & 31);
       if (qq > Lg - 1) qq = Lg - 1;
-      lds_dma4(aux_src + qq * H, lds_addr(sAux + (tile & 1) * 3 * B1_QT));
+      const float* const src = ((l2 & 32) ? a.dsum : a.lse) + (row0 + qq) * H + h;
+      lds_dma4(src, lds_addr(sAux + (tile & 1) * 3 * B1_QT));
     }
   };
   auto aux_keys = [&](int tile) {
@@ -156,22 +164,27 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_one_kernel(AttnArgs a) {
   TrAddr tra;
   tra.init(lane);
   const unsigned smem_l = lds_addr(smem);
-  unsigned trk_a, trk_b;                              // K image, this wave's head-dim block (its dQ task)
+  unsigned trk_a[NDT], trk_b[NDT];                    // K image: this wave's dQ task (head-dim block(s), first row of its key part)
   {
-    const int tdt_ = (wave & 3) % DT, tkp_ = (wave & 3) / DT;         // the key part's first row is folded into the bases:
-    const unsigned kp0 = (unsigned)(tkp_ * ((AT_QB / 16) / (4 / DT)) * 16);   // every read of the dQ stage is base + immediate
-    trk_a = smem_l + B1_KIMG_OFF + kp0 * 128 + (tdt_ ? tra.a[DT - 1] : tra.a[0]);
-    trk_b = smem_l + B1_KIMG_OFF + kp0 * 128 + (tdt_ ? tra.b[DT - 1] : tra.b[0]);
-    asm volatile("" : "+v"(trk_a), "+v"(trk_b));
+    const int tx_ = wave & 3;
+    const int tkp_ = NDT == 2 ? tx_ : tx_ / DT;       // the key part's first row is folded into the bases:
+    const unsigned kp0 = (unsigned)(tkp_ * KSTEPS * 16);              // every read of the dQ stage is base + immediate
+#pragma unroll
+    for (int n = 0; n < NDT; ++n) {
+      const bool hi_blk = NDT == 2 ? n == 1 : (tx_ % DT) != 0;
+      trk_a[n] = smem_l + B1_KIMG_OFF + kp0 * 128 + (hi_blk ? tra.a[DT - 1] : tra.a[0]);
+      trk_b[n] = smem_l + B1_KIMG_OFF + kp0 * 128 + (hi_blk ? tra.b[DT - 1] : tra.b[0]);
+      asm volatile("" : "+v"(trk_a[n]), "+v"(trk_b[n]));
+    }
   }
-  auto ktr = [&](int off) {                           // K^T fragment (head dims of the task's block x 16 keys at byte offset off)
+  auto ktr = [&](int n, int off) {                    // K^T fragment (head dims of block n of the task x 16 keys at byte offset off)
     union { bf16x4_t q[2]; bf16x8 v; } r;
-    r.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(size_t)(trk_a + (unsigned)off));
-    r.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(size_t)(trk_b + (unsigned)off));
+    r.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(size_t)(trk_a[n] + (unsigned)off));
+    r.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4_t*)(size_t)(trk_b[n] + (unsigned)off));
     return r.v;
   };
   Tr64 trd;                                           // dS image, from this wave's key part on
-  trd.init(smem_l + B1_DS_OFF + (unsigned)(((wave & 3) / DT) * ((AT_QB / 16) / (4 / DT)) * 16 * 64), lane);
+  trd.init(smem_l + B1_DS_OFF + (unsigned)((NDT == 2 ? (wave & 3) : (wave & 3) / DT) * KSTEPS * 16 * 64), lane);
 
   const int64_t key = (int64_t)kt * AT_QB + wave * 32 + j;
   const bool kok = key < Lg;
@@ -187,10 +200,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_one_kernel(AttnArgs a) {
   const uint32_t kgold = (uint32_t)(key >> 2) * AT_GOLD;        // this lane's key group
   const int kbyte = (int)(key & 3) * 8;
   // dS image: this lane's row (its key) and the swizzle of that row
-  unsigned char* const ds_row = smem + B1_DS_OFF + (32 * wave + j) * 64 + 8 * half;
-  const int ds_sw = (j >> 2) & 3;                     // ((32 wave + j) >> 2) & 3
   // dQ task of this wave in the trips of its quartet
-  const int tx = wave & 3, tdt = tx % DT, tkp = tx / DT;
+  const int tx = wave & 3, tdt = NDT == 2 ? 0 : tx % DT, tkp = NDT == 2 ? tx : tx / DT;
 
   f32x16 dk[DT], dv[DT];
 #pragma unroll
@@ -203,14 +214,17 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_one_kernel(AttnArgs a) {
   // path: 92 us of 1 108 on 16 x 2048 tokens).
   const int cdt = wave >> 2, ci = wave & 3;
   const bool cown = cdt < DT && 32 * cdt + 8 * ci < HD;          // this wave's quarter exists (wave-uniform)
-  auto combine_store = [&](int tp) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto combine_load = [&](float4 (&x)[KSPLIT]) {
+    int l2 = threadIdx.x & 63;                          // (lane offset derived here: nothing of it lives across the trip)
+    asm volatile("" : "+v"(l2));
+    const unsigned char* const cscr = smem + B1_SCR_OFF + cdt * 4096 + ci * 1024 + l2 * 16;
 #pragma unroll
-    for (int kp = 0; kp < KSPLIT; ++kp) {
-      const float4 x = *reinterpret_cast<const float4*>(smem + B1_SCR_OFF + (kp * DT + cdt) * 4096 + ci * 1024 + lane * 16);
-      if (kp == 0) acc = x;
-      else { acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w; }
-    }
+    for (int kp = 0; kp < KSPLIT; ++kp) x[kp] = *reinterpret_cast<const float4*>(cscr + kp * PARTB);
+  };
+  auto combine_store = [&](int tp, const float4 (&x)[KSPLIT]) {
+    float4 acc = x[0];
+#pragma unroll
+    for (int kp = 1; kp < KSPLIT; ++kp) { acc.x += x[kp].x; acc.y += x[kp].y; acc.z += x[kp].z; acc.w += x[kp].w; }
     const int64_t q2 = (int64_t)tp * B1_QT + j;
     if (q2 < Lg)
       *reinterpret_cast<float4*>(a.dq_part + ((int64_t)kt * a.Ltot + row0 + q2) * D + h * HD + 32 * cdt + 8 * ci + 4 * half) = acc;
@@ -220,27 +234,48 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_one_kernel(AttnArgs a) {
   // even / odd k-steps, so that consecutive matrix instructions do not wait on each other), parked for the combining wave
   auto dq_stage = [&]() {
 #ifndef B1_ABL_NO_DQ
-    f32x16 q0, q1;
+    f32x16 q0, q1;                                     // NDT == 2: head-dim blocks 0 / 1; else even / odd k-steps of the one block
 #pragma unroll
     for (int r = 0; r < 16; ++r) { q0[r] = 0.f; q1[r] = 0.f; }
+    if constexpr (NDT == 2) {
 #pragma unroll
-    for (int kk = 0; kk < KSTEPS; kk += 2) {
-      const bf16x8 th0 = ktr(kk * 2048), tl0 = ktr(B1_KPL + kk * 2048);
-      const bf16x8 sh0 = trd.read(kk * 1024), sl0 = trd.read(B1_DSPL + kk * 1024);
-      const bf16x8 th1 = ktr((kk + 1) * 2048), tl1 = ktr(B1_KPL + (kk + 1) * 2048);
-      const bf16x8 sh1 = trd.read((kk + 1) * 1024), sl1 = trd.read(B1_DSPL + (kk + 1) * 1024);
-      q0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl0, sh0, q0, 0, 0, 0);
-      q1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl1, sh1, q1, 0, 0, 0);
-      q0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th0, sl0, q0, 0, 0, 0);
-      q1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th1, sl1, q1, 0, 0, 0);
-      q0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th0, sh0, q0, 0, 0, 0);
-      q1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th1, sh1, q1, 0, 0, 0);
+      for (int kk = 0; kk < KSTEPS; ++kk) {
+        const bf16x8 sh = trd.read(kk * 1024), sl = trd.read(B1_DSPL + kk * 1024);
+        const bf16x8 th0 = ktr(0, kk * 2048), tl0 = ktr(0, B1_KPL + kk * 2048);
+        const bf16x8 th1 = ktr(1, kk * 2048), tl1 = ktr(1, B1_KPL + kk * 2048);
+        q0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl0, sh, q0, 0, 0, 0);
+        q1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl1, sh, q1, 0, 0, 0);
+        q0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th0, sl, q0, 0, 0, 0);
+        q1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th1, sl, q1, 0, 0, 0);
+        q0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th0, sh, q0, 0, 0, 0);
+        q1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th1, sh, q1, 0, 0, 0);
+      }
+      unsigned char* sc = smem + B1_SCR_OFF + tkp * PARTB + lane * 16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(sc + i * 1024) = make_float4(q0[4 * i], q0[4 * i + 1], q0[4 * i + 2], q0[4 * i + 3]);
+#pragma unroll
+      for (int i = 0; i < (HD - 32) / 8; ++i)
+        *reinterpret_cast<float4*>(sc + 4096 + i * 1024) = make_float4(q1[4 * i], q1[4 * i + 1], q1[4 * i + 2], q1[4 * i + 3]);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < KSTEPS; kk += 2) {
+        const bf16x8 th0 = ktr(0, kk * 2048), tl0 = ktr(0, B1_KPL + kk * 2048);
+        const bf16x8 sh0 = trd.read(kk * 1024), sl0 = trd.read(B1_DSPL + kk * 1024);
+        const bf16x8 th1 = ktr(0, (kk + 1) * 2048), tl1 = ktr(0, B1_KPL + (kk + 1) * 2048);
+        const bf16x8 sh1 = trd.read((kk + 1) * 1024), sl1 = trd.read(B1_DSPL + (kk + 1) * 1024);
+        q0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl0, sh0, q0, 0, 0, 0);
+        q1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl1, sh1, q1, 0, 0, 0);
+        q0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th0, sl0, q0, 0, 0, 0);
+        q1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th1, sl1, q1, 0, 0, 0);
+        q0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th0, sh0, q0, 0, 0, 0);
+        q1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th1, sh1, q1, 0, 0, 0);
+      }
+      unsigned char* sc = smem + B1_SCR_OFF + tkp * PARTB + tdt * 4096 + lane * 16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<float4*>(sc + i * 1024) =
+            make_float4(q0[4 * i] + q1[4 * i], q0[4 * i + 1] + q1[4 * i + 1], q0[4 * i + 2] + q1[4 * i + 2], q0[4 * i + 3] + q1[4 * i + 3]);
     }
-    unsigned char* sc = smem + B1_SCR_OFF + (tkp * DT + tdt) * 4096 + lane * 16;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<float4*>(sc + i * 1024) =
-          make_float4(q0[4 * i] + q1[4 * i], q0[4 * i + 1] + q1[4 * i + 1], q0[4 * i + 2] + q1[4 * i + 2], q0[4 * i + 3] + q1[4 * i + 3]);
 #endif
   };
 
@@ -343,20 +378,25 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_one_kernel(AttnArgs a) {
       for (int e = 0; e < 8; ++e) w[e] = s[8 * s2 + e];
       split8(w, fh[s2].v, fl[s2].v);
     }
-    bf16x8 qh0[DT], ql0[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) { qh0[dt] = frag_tr_pre(trb, 0, 0, dt); ql0[dt] = frag_tr_pre(trb, B1_PL, 0, dt); }
+    bf16x8 qh0[DT], ql0[DT];                     // (block 0 only: with both blocks in flight across the barrier the HD >= 48 kernels spill)
+    qh0[0] = frag_tr_pre(trb, 0, 0, 0); ql0[0] = frag_tr_pre(trb, B1_PL, 0, 0);
     // ---- barrier A: trip t - 1's dQ readers have left the dS image, their accumulators are parked
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifndef B1_ABL_NO_A
     at_barrier();
 #endif
     int stores = 0;
+    float4 cx[KSPLIT];
+    const bool comb = t > 0 && cown;
 #ifndef B1_ABL_NO_STORE
-    if (t > 0 && cown) { combine_store(t - 1); stores = 1; }
+    if (comb) combine_load(cx);                  // (requested first: the image writes run under their latency)
 #endif
     // ---- dS^T image (fragment slots 0-3 / 4-7 are queries 16 s2 + 4 half + {0..3} / + 8: two 8-byte writes per plane) and
     //      dK^T[d, key] += Q^T[d, q] . dS[q, key]
+    int l3 = threadIdx.x & 63;                   // dS image: this lane's row (its key) and the swizzle of that row, derived at the use
+    asm volatile("" : "+v"(l3));
+    unsigned char* const ds_row = smem + B1_DS_OFF + (32 * wave + (l3 & 31)) * 64 + 8 * (l3 >> 5);
+    const int ds_sw = (l3 >> 2) & 3;             // ((32 wave + j) >> 2) & 3
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       unsigned char* p0 = ds_row + (((2 * s2) ^ ds_sw) << 4);
@@ -366,8 +406,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_one_kernel(AttnArgs a) {
       *reinterpret_cast<uint2*>(p0 + B1_DSPL) = make_uint2(fl[s2].u.x, fl[s2].u.y);
       *reinterpret_cast<uint2*>(p1 + B1_DSPL) = make_uint2(fl[s2].u.z, fl[s2].u.w);
     }
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef B1_ABL_NO_STORE
+    if (comb) { combine_store(t - 1, cx); stores = 1; }
+#endif
+    __builtin_amdgcn_sched_barrier(0);
     {
       bf16x8 qh1[DT], ql1[DT];
+#pragma unroll
+      for (int dt = 1; dt < DT; ++dt) { qh0[dt] = frag_tr_pre(trb, 0, 0, dt); ql0[dt] = frag_tr_pre(trb, B1_PL, 0, dt); }
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) { qh1[dt] = frag_tr_pre(trb, 0, 16, dt); ql1[dt] = frag_tr_pre(trb, B1_PL, 16, dt); }
 #pragma unroll
@@ -394,7 +441,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_one_kernel(AttnArgs a) {
   if ((wave >> 2) == ((T - 1) & 1)) dq_stage();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   at_barrier();
-  if (cown) combine_store(T - 1);
+  if (cown) {
+    float4 cx[KSPLIT];
+    combine_load(cx);
+    combine_store(T - 1, cx);
+  }
 
   int tid2 = threadIdx.x;                        // (lane coordinates derived again for the epilogue: see the forward)
   asm volatile("" : "+v"(tid2));

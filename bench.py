@@ -329,7 +329,11 @@ def attention_roofline(torch, ops, dev, L, bags, p=0.25, iters=20, in_step=None)
             method = ("device wall-clock stamps (one-thread kernels = graph nodes) around the step's own ops.mha forward (eval + training pass, mean) and "
                       "backward INSIDE a captured step, 8 replays: timed between their real neighbours, at the clock the step runs at")
     ach = (ff + fb) / (us_f + us_b) / 1e6
-    return {"bound": "mfma", "kernel": "split_planes + attn_fwd_kernel<48,drop> + attn_bwd_prep + attn_bwd_dq_kernel + attn_bwd_dkv_kernel (csrc/attn.hip)",
+    one = ops.mha_bwd_single_pass(L, 48)
+    return {"bound": "mfma", "kernel": "split_planes + attn_fwd_kernel<48,drop> (csrc/attn.hip) + attn_bwd_prep + " +
+                                       ("attn_bwd_one_kernel + attn_dq_reduce_kernel (csrc/attn_bwd1.hip: single-pass backward)" if one
+                                        else "attn_bwd_dq_kernel + attn_bwd_dkv_kernel (csrc/attn.hip: two-launch backward)"),
+            "backward_form": "one" if one else "two",
             "back_to_back": b2b,
             "tokens_per_bag": L, "bags": bags, "heads": nh, "head_dim": 48, "attn_dropout": p,
             "achieved": round(ach, 2), "peak": round(PEAK_BF16X3_TFLOPS, 1), "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16X3_TFLOPS, 4),
