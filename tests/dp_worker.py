@@ -68,7 +68,9 @@ def run(kind, world, rank, dp=None, device="cuda:0"):
         cfg["gemm_mode"] = "bf16x3"          # the product's default arithmetic: the operand-plane paths only exist in it
     if kind == "graph":
         cfg.update(bcb_dims="1024-128-128", gen_dims="128-1")
-    h = MyHandler(cfg, device=device, parallel=dp)
+    from advmil_amd import ops as _ops
+    mode0 = _ops.get_gemm_mode()             # (a handler sets the library's arithmetic mode from its cfg: restored below, so that the single-process
+    h = MyHandler(cfg, device=device, parallel=dp)       # run inside the pytest process does not leave bf16x3 behind for the files after this one)
     for net, prefix in ((h.netG, f"G-{kind}:"), (h.netD, "D-prj:")):
         sd = {k: H.T(synth.param(H.PARAM_SEED, prefix + k, tuple(v.shape))) for k, v in net.state_dict().items()}
         net.load_state_dict(sd, strict=True)
@@ -82,6 +84,7 @@ def run(kind, world, rank, dp=None, device="cuda:0"):
         cl = h._train_each_epoch(build_loader(kind, idxs, lens), "train", "wlabel")
     finally:
         ops.gate_score = real_score
+        ops.set_gemm_mode(mode0)
     logs = h.pop_logs()
     return {"cl": cl, "logs": logs, "gate_score_rows": score_rows, "G": {k: v.detach().cpu() for k, v in h.netG.state_dict().items()},
             "D": {k: v.detach().cpu() for k, v in h.netD.state_dict().items()}}

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised check of the fused attention core (ops.mha -> advmil_mha_fwd / advmil_mha_bwd) against float64: random numbers of ragged
-bags (1 .. 700 tokens each, incl. 1-token bags and lengths around the 32 / 64 / 256-row tile boundaries), head_dim 16 / 32 / 48 / 64,
+bags (1 .. 700 tokens each, some up to 1 400, incl. 1-token bags and lengths around the 32 / 64 / 256-row tile boundaries), head_dim 16 / 32 / 48 / 64,
 dropout 0 / 0.1 / 0.25 / 0.5 with the masks regenerated on the host from the kernels' counter hash, forward and all three gradient
 blocks. usage: attn_fuzz.py [cases] [seed]"""
 import os
@@ -24,7 +24,7 @@ for case in range(ncase):
     hd = rnd.choice((16, 32, 48, 48, 64))
     d = NH * hd
     nb = rnd.randint(1, 6)
-    lens = [rnd.choice(edge) if rnd.random() < 0.4 else rnd.randint(1, 700) for _ in range(nb)]
+    lens = [rnd.choice(edge) if rnd.random() < 0.4 else rnd.randint(1, 1400 if rnd.random() < 0.15 else 700) for _ in range(nb)]      # (up to six 256-key blocks: the single-pass backward's partial slabs)
     p = rnd.choice((0.0, 0.1, 0.25, 0.5))
     Lt = sum(lens)
     # (operand scale <= 1: the error of a split-bf16 score is ~2^-17 |q||k|, and the softmax turns an absolute score error into a
