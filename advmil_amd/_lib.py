@@ -88,6 +88,8 @@ SIGNATURES = {
                                       c_int64, ctypes.POINTER(Epilogue), c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "advmil_mha_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64, c_float, c_void_p, c_uint64,
                                c_void_p, c_void_p, c_void_p, c_void_p]),
+    "advmil_mha_fwd_lse": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64, c_float, c_void_p, c_uint64,
+                                   c_void_p, c_void_p, c_void_p, c_void_p]),
     "advmil_mha_bwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "advmil_mha_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64,
                                c_float, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

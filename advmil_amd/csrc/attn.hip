@@ -61,7 +61,11 @@
 // the LDS / MFMA latencies without any scheduling effort: this kernel keeps its live state under 128 VGPRs -- one 32-key
 // half-tile at a time: S (16) -> P split (16) -> O (32), Q fragments (24) -- so that TWO workgroups (4 waves per SIMD) share a CU,
 // each with a double-buffered 64 KB ring; their barriers are independent, so one workgroup's softmax runs under the other's MFMAs.
-template <int HD, bool DROP>
+// LSEIN: the log-sum-exp of every (query, head) is GIVEN (a.lse is read, not written): the train-mode forward of an optimizer step
+// whose eval-mode forward ran over the same q | k | v (the handler's forward memo: the generator's weights do not change between
+// the discriminator's and the generator's update, model_handler.py:398-425). The probabilities are then exp2(s c - lse) directly,
+// as in the backward: no running maximum, no rescaling, no row sum (18 of ~56 vector instructions per 32-key half-tile and lane).
+template <int HD, bool DROP, bool LSEIN = false>
 __global__ __launch_bounds__(512, HD == 64 ? 2 : 4) void attn_fwd_kernel(AttnArgs a) {
   constexpr int KS = HD / 16, DT = (HD + 31) / 32, UN = HD / 8;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * AT_SLOT_B];
@@ -112,6 +116,7 @@ __global__ __launch_bounds__(512, HD == 64 ? 2 : 4) void attn_fwd_kernel(AttnArg
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  if (LSEIN) m_run = qok ? a.lse[(row0 + q) * H + h] : 0.f;       // (the given log-sum-exp, log2 domain, rides in m_run)
 #ifdef AT_STAMP
   int st_i = 0;
 #endif
@@ -142,29 +147,39 @@ __global__ __launch_bounds__(512, HD == 64 ? 2 : 4) void attn_fwd_kernel(AttnArg
           if (32 * u + ACC_ROW(r, half) >= lim) s[r] = -INFINITY;
       }
       // ---- statistics, probabilities, dropout, split
-      float mx = m_run;
+      if constexpr (LSEIN) {
+        const float nl = -m_run;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      if (__any(mx != m_run)) {                  // rescale only when some query of this wave saw a new maximum (rare after the first tiles)
-        const float alpha = hw_exp2((m_run - mx) * c);
-        m_run = mx;
-        l_run *= alpha;
+        for (int r = 0; r < 16; r += 4) {
+          float e0 = fmaf(s[r], c, nl), e1 = fmaf(s[r + 1], c, nl), e2 = fmaf(s[r + 2], c, nl), e3 = fmaf(s[r + 3], c, nl);
+          hw_exp2x4(e0, e1, e2, e3);
+          s[r] = e0; s[r + 1] = e1; s[r + 2] = e2; s[r + 3] = e3;
+        }
+      } else {
+        float mx = m_run;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (__any(mx != m_run)) {                // rescale only when some query of this wave saw a new maximum (rare after the first tiles)
+          const float alpha = hw_exp2((m_run - mx) * c);
+          m_run = mx;
+          l_run *= alpha;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+          for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
+        const float nmc = -mx * c;
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) {
+          float e0 = fmaf(s[r], c, nmc), e1 = fmaf(s[r + 1], c, nmc), e2 = fmaf(s[r + 2], c, nmc), e3 = fmaf(s[r + 3], c, nmc);
+          hw_exp2x4(e0, e1, e2, e3);
+          psum += (e0 + e1) + (e2 + e3);
+          s[r] = e0; s[r + 1] = e1; s[r + 2] = e2; s[r + 3] = e3;
+        }
+        l_run += psum;
       }
-      const float nmc = -mx * c;
-      float psum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; r += 4) {
-        float e0 = fmaf(s[r], c, nmc), e1 = fmaf(s[r + 1], c, nmc), e2 = fmaf(s[r + 2], c, nmc), e3 = fmaf(s[r + 3], c, nmc);
-        hw_exp2x4(e0, e1, e2, e3);
-        psum += (e0 + e1) + (e2 + e3);
-        s[r] = e0; s[r + 1] = e1; s[r + 2] = e2; s[r + 3] = e3;
-      }
-      l_run += psum;
       if (DROP) {                                // register 4 rg + e <-> key kb + 32 u + 8 rg + 4 half + e: one hash per register group
         const uint32_t hb = hbase + (uint32_t)(t * (AT_KT / 4) + 8 * u) * AT_GOLD;
 #pragma unroll
@@ -209,7 +224,7 @@ __global__ __launch_bounds__(512, HD == 64 ? 2 : 4) void attn_fwd_kernel(AttnArg
   const int j2 = tid2 & 31, half2 = (tid2 >> 5) & 1;
   const int64_t q2 = (int64_t)qt * AT_QB + (tid2 >> 6) * 32 + j2;
   if (q2 < Lg) {
-    const float inv = (DROP ? a.inv_keep : 1.f) * hw_rcp(l_tot);
+    const float inv = LSEIN ? (DROP ? a.inv_keep : 1.f) : (DROP ? a.inv_keep : 1.f) * hw_rcp(l_tot);
     float* const orow = a.out + (row0 + q2) * D + h * HD;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -220,7 +235,7 @@ __global__ __launch_bounds__(512, HD == 64 ? 2 : 4) void attn_fwd_kernel(AttnArg
           *reinterpret_cast<float4*>(orow + d) =
               make_float4(o[dt][4 * rg] * inv, o[dt][4 * rg + 1] * inv, o[dt][4 * rg + 2] * inv, o[dt][4 * rg + 3] * inv);
       }
-    if (half2 == 0) a.lse[(row0 + q2) * H + h] = m_run * c + hw_log2(l_tot);
+    if (!LSEIN && half2 == 0) a.lse[(row0 + q2) * H + h] = m_run * c + hw_log2(l_tot);
   }
 }
 
@@ -631,6 +646,27 @@ extern "C" int advmil_mha_fwd(const void* qkv_hi, const void* qkv_lo, int64_t Lt
   a.out = out; a.lse = lse;
   const dim3 grid((unsigned)(a.ntile * nseg * nhead));
   AT_DISPATCH(attn_fwd_kernel, grid, (hipStream_t)stream_, a, head_dim);
+  ADVMIL_LAUNCH_CHECK();
+  return ADVMIL_OK;
+}
+
+// the same forward with the log-sum-exp GIVEN (dropout on: the train-mode pass behind an eval-mode pass over the same q | k | v)
+extern "C" int advmil_mha_fwd_lse(const void* qkv_hi, const void* qkv_lo, int64_t Ltot, int nhead, int head_dim, int nseg,
+                                  const int64_t* ptr, int64_t max_len, float drop_p, const uint64_t* seed, uint64_t stream_id,
+                                  const int64_t* rng_rowoff, float* out, const float* lse, advmil_stream_t stream_) {
+  AttnArgs a;
+  const int rc = attn_args(a, qkv_hi, qkv_lo, Ltot, nhead, head_dim, nseg, ptr, max_len, drop_p, seed, stream_id, rng_rowoff);
+  if (rc) return rc;
+  if (!out || !lse || ((uintptr_t)out & 15) || !a.seed) return ADVMIL_EINVAL;       // (built for the dropout pass only)
+  a.out = out; a.lse = const_cast<float*>(lse);
+  const dim3 grid((unsigned)(a.ntile * nseg * nhead));
+  hipStream_t stream = (hipStream_t)stream_;
+  switch (head_dim) {
+    case 16: hipLaunchKernelGGL((attn_fwd_kernel<16, true, true>), grid, dim3(512), 0, stream, a); break;
+    case 32: hipLaunchKernelGGL((attn_fwd_kernel<32, true, true>), grid, dim3(512), 0, stream, a); break;
+    case 48: hipLaunchKernelGGL((attn_fwd_kernel<48, true, true>), grid, dim3(512), 0, stream, a); break;
+    default: hipLaunchKernelGGL((attn_fwd_kernel<64, true, true>), grid, dim3(512), 0, stream, a); break;
+  }
   ADVMIL_LAUNCH_CHECK();
   return ADVMIL_OK;
 }

@@ -1842,8 +1842,10 @@ class MhaFn(torch.autograd.Function):
     pipe; no [H, L, L] tensor exists), three for the backward (advmil_mha_bwd). Ragged bags and any bag length are handled inside
     the kernels."""
 
+    last_lse = None          # the log-sum-exp of the forward just run (side channel to ops.mha: the forward memo keeps the eval pass's)
+
     @staticmethod
-    def forward(ctx, qkv, nhead, p, seed, sid, seg, rowoff, planes=None):
+    def forward(ctx, qkv, nhead, p, seed, sid, seg, rowoff, planes=None, lse_in=None):
         _chk(qkv, "qkv")
         qkv = qkv.contiguous()
         Lt, d3 = qkv.shape
@@ -1858,9 +1860,16 @@ class MhaFn(torch.autograd.Function):
         if planes is None:
             planes = split_planes(qkv)
         out = torch.empty(Lt, d, dtype=torch.float32, device=dev)
-        lse = torch.empty(Lt, nhead, dtype=torch.float32, device=dev)
-        _lib.check(_lib.lib().advmil_mha_fwd(_p(planes.hi), _p(planes.lo), Lt, nhead, hd, nseg, _p(ptr), mlen, p, _p(seed if p > 0.0 else None),
-                                             sid, _p(rowoff), _p(out), _p(lse), _stream()), "mha_fwd")
+        if lse_in is not None and p > 0.0 and tuple(lse_in.shape) == (Lt, nhead):
+            # the softmax statistics of the eval-mode pass over the same q | k | v (forward memo): only the dropout draw is new
+            lse = lse_in
+            _lib.check(_lib.lib().advmil_mha_fwd_lse(_p(planes.hi), _p(planes.lo), Lt, nhead, hd, nseg, _p(ptr), mlen, p, _p(seed), sid,
+                                                     _p(rowoff), _p(out), _p(lse), _stream()), "mha_fwd_lse")
+        else:
+            lse = torch.empty(Lt, nhead, dtype=torch.float32, device=dev)
+            _lib.check(_lib.lib().advmil_mha_fwd(_p(planes.hi), _p(planes.lo), Lt, nhead, hd, nseg, _p(ptr), mlen, p,
+                                                 _p(seed if p > 0.0 else None), sid, _p(rowoff), _p(out), _p(lse), _stream()), "mha_fwd")
+        MhaFn.last_lse = lse
         _stamp("e", "mha_fwd", shape_, 0.0)
         ctx.save_for_backward(planes.hi, planes.lo, out, lse)
         ctx.cfg = (nhead, hd, p, seed, sid, seg, rowoff)
@@ -1885,7 +1894,7 @@ class MhaFn(torch.autograd.Function):
             _p(qhi), _p(qlo), _p(out), _p(dO), _p(lse), Lt, nhead, hd, nseg, _p(ptr), mlen, p, _p(seed if p > 0.0 else None), sid,
             _p(rowoff), _p(dqkv), _p(ws), wsb, _stream()), "mha_bwd1" if one else "mha_bwd")
         _stamp("e", "mha_bwd", (Lt, nhead, hd, nseg), 0.0)
-        return dqkv, None, None, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None, None
 
 
 # Backward form of the attention core: "one" = advmil_mha_bwd1 (single pass over the scores, dQ through per-key-block partial
@@ -1921,7 +1930,20 @@ def mha(qkv, nhead, p=0.0, rng=None, seg=None, rowoff=None):
     planes = getattr(qkv, "_advmil_planes", None) if qkv.is_contiguous() else None
     if getattr(qkv, "_advmil_planes_only", False) and planes is None:
         raise RuntimeError("advmil_amd: qkv was produced as operand planes only and lost them on the way to ops.mha")
-    return MhaFn.apply(qkv, nhead, float(p), seed, sid, seg, rowoff, planes)
+    # Forward memo (MEMO_CHAIN): q | k | v of the train-mode pass ARE the eval-mode pass's (the in-projection's memoized output), so the
+    # softmax statistics are too: the eval pass leaves its log-sum-exp, the train pass hands it to the kernel (advmil_mha_fwd_lse)
+    memo = MEMO if (MHA_LSE_MEMO and MEMO_CHAIN and MEMO.mode is not None and planes is not None and qkv.data_ptr() in MEMO.derived) else None
+    key = (("mha_lse", qkv.data_ptr(), tuple(qkv.shape), nhead, 1 if seg is None else seg.nseg, qkv.shape[0] if seg is None else seg.max_len)
+           if memo is not None else None)
+    lse_in = memo.store.pop(key, None) if (memo is not None and memo.mode == "replay" and p > 0.0) else None
+    out = MhaFn.apply(qkv, nhead, float(p), seed, sid, seg, rowoff, planes, lse_in)
+    lse, MhaFn.last_lse = MhaFn.last_lse, None
+    if memo is not None and memo.mode == "record" and not torch.is_grad_enabled() and lse is not None:
+        memo.store[key] = lse
+    return out
+
+
+MHA_LSE_MEMO = os.environ.get("ADVMIL_MHA_LSE_MEMO", "1") != "0"
 
 
 class AddDropoutLayerNormFn(torch.autograd.Function):

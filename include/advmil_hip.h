@@ -200,6 +200,13 @@ int advmil_gemm_f32_tiled(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, c
 int advmil_mha_fwd(const void* qkv_hi, const void* qkv_lo, int64_t Ltot, int nhead, int head_dim, int nseg, const int64_t* ptr,
                    int64_t max_len, float drop_p, const uint64_t* seed, uint64_t stream_id, const int64_t* rng_rowoff, float* out,
                    float* lse, advmil_stream_t stream);
+/* The same forward with the log-sum-exp GIVEN (`lse` is read): the train-mode pass of an optimizer step behind the eval-mode pass over
+ * the same q | k | v (the reference runs the generator twice per step with unchanged weights, model_handler.py:398-425; the softmax
+ * statistics of the two passes are identical, only the dropout draw is new). Probabilities are exp2(s c - lse) directly: no running
+ * maximum, no rescaling, no row sum. Dropout must be on (seed != NULL, drop_p > 0); same mask stream as advmil_mha_fwd. */
+int advmil_mha_fwd_lse(const void* qkv_hi, const void* qkv_lo, int64_t Ltot, int nhead, int head_dim, int nseg, const int64_t* ptr,
+                       int64_t max_len, float drop_p, const uint64_t* seed, uint64_t stream_id, const int64_t* rng_rowoff, float* out,
+                       const float* lse, advmil_stream_t stream);
 size_t advmil_mha_bwd_workspace_bytes(int64_t Ltot, int nhead, int head_dim);
 int advmil_mha_bwd(const void* qkv_hi, const void* qkv_lo, const float* out, const float* dout, const float* lse, int64_t Ltot,
                    int nhead, int head_dim, int nseg, const int64_t* ptr, int64_t max_len, float drop_p, const uint64_t* seed,

@@ -332,3 +332,36 @@ def test_residual_gradients_meet_in_the_next_layers_dx_contraction(ops, mode, le
     finally:
         ops.RESIDUAL_HANDOVER = True
         ops.RESIDUAL_GRADS.clear()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hd,lens", [(48, [700, 257, 33, 1025, 1]), (32, [130, 64, 300]), (64, [2048]), (16, [5, 129])])
+def test_forward_with_the_log_sum_exp_given_equals_the_plain_forward(ops, hd, lens):
+    """advmil_mha_fwd_lse: the train-mode forward that takes the softmax statistics from the eval-mode pass over the same q | k | v
+    (the handler's forward memo) -- probabilities exp2(s c - lse) instead of the running maximum / rescale / row sum. Same dropout
+    stream: output within round-off of the plain train-mode forward -- the given statistic is one fp32 number per (query, head), its
+    rounding moves every probability of the row by ~|lse| 2^-24 -- asserted at 1e-5 of the scale (the float64 tests' own forward bound),
+    and the backward it feeds likewise."""
+    d = NH * hd
+    Lt = sum(lens)
+    qkv = rnd(f"lse{hd}{lens}", Lt, 3 * d, scale=0.7).to(DEV); go = rnd(f"lseg{hd}{lens}", Lt, d).to(DEV)
+    seg = ops.Segments(lens, DEV)
+    planes = ops.split_planes(qkv)
+    with torch.no_grad():
+        ops.MhaFn.apply(qkv, NH, 0.0, None, 0, seg, None, planes)                     # eval-mode pass: leaves the log-sum-exp
+    lse = ops.MhaFn.last_lse
+    res = []
+    for given in (None, lse):
+        rng = ops.DeviceRng(DEV, seed=81)
+        sid = rng.site("mha_attn", (Lt, NH), 0.25)
+        a = qkv.clone().requires_grad_(True)
+        o = ops.MhaFn.apply(a, NH, 0.25, rng.seed, sid, seg, None, planes, given)
+        assert (ops.MhaFn.last_lse is lse) == (given is not None)
+        (o * go).sum().backward()
+        res.append((o.detach().clone(), a.grad.clone()))
+    (o0, g0), (o1, g1) = res
+    assert torch.isfinite(o1).all() and torch.isfinite(g1).all()
+    assert float((o0 - o1).abs().max()) <= 1e-5 * float(o0.abs().max())
+    for c in range(3):
+        a_, b_ = g0[:, c * d:(c + 1) * d], g1[:, c * d:(c + 1) * d]
+        assert float((a_ - b_).abs().max()) <= 1e-5 * float(a_.abs().max())
