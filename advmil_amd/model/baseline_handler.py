@@ -135,11 +135,8 @@ class BaselineHandler(object):
         preds = self.net.finish(self.net.features_multi(X, seg, exts)[:len(xs)])
         y = ys if torch.is_tensor(ys) else torch.cat(ys, dim=0)
         net_loss = self.supervised_loss(preds, y[:, 0:1], y[:, 1:2])
-        try:
-            with ops.deferred_sums():        # the backward's merge launches of parameter-gradient partials as one (ops.deferred_sums)
-                net_loss.backward()
-        finally:
-            ops.backward_done()              # (no gradient hand-over outlives the backward: ops.ResidualGrads / PlaneHandover)
+        with ops.deferred_sums():            # the backward's merge launches of parameter-gradient partials as one (ops.deferred_sums)
+            net_loss.backward()
         total = net_loss.detach()
         if self.coef_l1 > 1e-8:
             total = total + self.coef_l1 * ops.abs_sum(self.optimizer.flat_param)[0]

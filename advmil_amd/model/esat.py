@@ -32,22 +32,19 @@ class HipTransformerEncoderLayer(nn.Module):
         tr = self.training
         sa = self.self_attn
         # [L_total, 3d]; consumed by the attention kernels alone, which read operand planes: the in-projection writes planes ONLY (bf16x3 mode)
-        # (x2 is read twice -- here and as the first residual's skip input; the two gradients meet in this layer's dx contraction, which
-        # accumulates onto the one the residual hands over: ops.ResidualGrads. Likewise the first norm's output below.)
-        qkv = ops.linear_act(x2, sa.in_proj_weight, sa.in_proj_bias, "none", emit_planes="only", take_residual_grad=True)
+        qkv = ops.linear_act(x2, sa.in_proj_weight, sa.in_proj_bias, "none", emit_planes="only")
         # attention core: one fused launch for all (ragged) bags of the slab; `rng_rowoff` (set by the handler under
         # bag-parallel) addresses the dropout row ids of the single-process run
         o = ops.mha(qkv, self.nhead, sa.dropout if tr else 0.0, rng, seg=seg, rowoff=getattr(seg, "rng_rowoff", None))
         o = ops.linear_act(o, sa.out_proj.weight, sa.out_proj.bias, "none")
         x2 = ops.add_dropout_layer_norm(x2, o, self.norm1.weight, self.norm1.bias, self.norm1.eps,
-                                        self.dropout1.p if tr else 0.0, rng, "esat_drop1", hand_residual_grad=True)
+                                        self.dropout1.p if tr else 0.0, rng, "esat_drop1")
         # (every [L, d] activation of the layer reaches its contraction with operand planes: the region embedding and the two LayerNorm
         # outputs leave their kernels with them, the FFN's hidden rows get them from this epilogue, the attention output from one split pass)
-        f = ops.linear_act(x2, self.linear1.weight, self.linear1.bias, "relu", self.dropout.p if tr else 0.0, rng, "esat_ffn", emit_planes=True,
-                           take_residual_grad=True)
+        f = ops.linear_act(x2, self.linear1.weight, self.linear1.bias, "relu", self.dropout.p if tr else 0.0, rng, "esat_ffn", emit_planes=True)
         f = ops.linear_act(f, self.linear2.weight, self.linear2.bias, "none")
         return ops.add_dropout_layer_norm(x2, f, self.norm2.weight, self.norm2.bias, self.norm2.eps,
-                                          self.dropout2.p if tr else 0.0, rng, "esat_drop2", hand_residual_grad=True)
+                                          self.dropout2.p if tr else 0.0, rng, "esat_drop2")
 
     def forward(self, x):
         if x.dim() != 3 or x.shape[0] != 1:

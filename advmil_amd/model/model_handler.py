@@ -822,7 +822,7 @@ class MyHandler(object):
             with torch.autograd.set_multithreading_enabled(False), ops.deferred_sums():       # backward on THIS thread (see _gen_finish)
                 torch.autograd.backward(loss, grad_tensors=self._one())  # (the root gradient is a cached 1: no fill launch per step)
         finally:
-            ops.backward_done()             # (a backward that raised may have left a plane hand-over behind: never let it meet a reused address)
+            ops.DY_PLANES.clear()            # (a backward that raised may have left a plane hand-over behind: never let it meet a reused address)
         self._st_d = (st, plan, i_batch)     # this rank's partial sums over the global denominators; reduced + logged in _disc_apply
         if plan.t2 is not None and pred.data_ptr() == plan.t2.data_ptr() and not torch.cuda.is_current_stream_capturing():
             pred = pred.clone()              # the plan's buffer is rewritten by its next step; the collector keeps these
@@ -930,7 +930,7 @@ class MyHandler(object):
             with torch.autograd.set_multithreading_enabled(False), ops.deferred_sums():
                 torch.autograd.backward(total, grad_tensors=self._one())
         finally:
-            ops.backward_done() 
+            ops.DY_PLANES.clear()
         self._st_g = (st, i_batch)
 
     def _reduce_g(self):

@@ -1068,7 +1068,6 @@ class LinearActFn(torch.autograd.Function):
     last_act_fusable = None
     last_maskbits = None
     gate_request = None      # (p_gate, tag_a, tag_b, rng) set by linear_act: the consumer is a gated attention pool in train mode
-    take_residual = False    # set by linear_act: x is also the skip input of a post-norm residual that hands its gradient over (ResidualGrads)
     last_gate = None         # (stream a, stream b, bits_a, bits_b, p_gate, row map): drawn with this layer's own dropout (dropout_planes)
 
     @staticmethod
@@ -1076,8 +1075,6 @@ class LinearActFn(torch.autograd.Function):
         if not is_bf16_slab(x):               # (a bf16 slab is read through its plane only: linear_act made sure of that)
             _chk(x, "x")
         _chk(W, "weight")
-        take, LinearActFn.take_residual = LinearActFn.take_residual, False
-        ctx.resid_key = ResidualGrads.key(x) if (take and x.is_contiguous() and ctx.needs_input_grad[0]) else None
         x = x.contiguous()
         W2 = W.detach().reshape(W.shape[0], -1)
         M, K = x.shape
@@ -1181,10 +1178,6 @@ class LinearActFn(torch.autograd.Function):
             _lib.check(L.advmil_small_linear_bwd(_p(dy), _p(y), _p(x), K, _p(W2), M, N, K, act, float(p) if use else 0.0,
                                                  _p(seed if use else None), sid, _p(rr if use else None), _p(dW), 1 if acc_w else 0, _p(db),
                                                  1 if acc_b else 0, _p(dx), K, _p(ws), wsb, _stream()), f"small_linear_bwd[{M}x{N}x{K}]")
-            if need_x and ctx.resid_key is not None:
-                rg = RESIDUAL_GRADS.pop(ctx.resid_key)
-                if rg is not None:
-                    dx = dx.add_(rg)
             return (dx, None if (dW is None or acc_w) else dW.reshape(wshape), None if (db is None or acc_b) else db,
                     None, None, None, None, None, None, None, None, None)
         if act == ACT_NONE and p <= 0.0:
@@ -1239,16 +1232,7 @@ class LinearActFn(torch.autograd.Function):
                 gemm(dpre, x, False, False, N, K, M, out=ctx.gW.view(N, K), ldc=K, accumulate=True, b_planes=xpl)
             else:
                 dW = gemm(dpre, x, False, False, N, K, M, b_planes=xpl).reshape(wshape)
-        dx = None
-        if need_x:                                           # dpre W
-            rg = RESIDUAL_GRADS.pop(ctx.resid_key) if ctx.resid_key is not None else None
-            if rg is not None:                               # ... added onto the skip gradient the residual behind this layer handed over
-                # (splits = 1: a split-K fold into `rg` would be DEFERRED inside ops.deferred_sums() -- the handlers' backward -- and the
-                # next launch reads dx)
-                gemm(dpre, W2, True, False, M, K, N, out=rg, ldc=K, accumulate=True, splits=1)
-                dx = rg
-            else:
-                dx = gemm(dpre, W2, True, False, M, K, N)
+        dx = gemm(dpre, W2, True, False, M, K, N) if need_x else None                   # dpre W
         return dx, dW, (None if ctx.gb is not None else db), None, None, None, None, None, None, None, None, None
 
 
@@ -1329,12 +1313,10 @@ def prefill_two_layers(X, layer1, layer2):
     return True
 
 
-def linear_act(x, W, b, act="none", p=0.0, rng=None, tag="", emit_planes=False, gate_sites=None, take_residual_grad=False):
+def linear_act(x, W, b, act="none", p=0.0, rng=None, tag="", emit_planes=False, gate_sites=None):
     """x[..., K] -> [..., N] through the HIP GEMM (any leading dims are flattened). In bf16x3 mode the operands' bf16 planes are
     used when they exist (slab registered by the handler / producer-emitted activation planes / arena weight planes), and
-    `emit_planes` makes the epilogue also write the planes of y (attribute `_advmil_planes`) for the contraction that reads it.
-    `take_residual_grad`: x is ALSO the skip input of an ops.add_dropout_layer_norm(..., hand_residual_grad=True) call further on:
-    this layer's backward adds its input gradient onto the one that residual hands over (ops.ResidualGrads)."""
+    `emit_planes` makes the epilogue also write the planes of y (attribute `_advmil_planes`) for the contraction that reads it."""
     lead = x.shape[:-1]
     x2 = x if x.dim() == 2 else x.reshape(-1, x.shape[-1])        # (a 2-D input keeps its object: operand planes are attributes)
     sid, seed, rr = 0, None, None
@@ -1384,9 +1366,7 @@ def linear_act(x, W, b, act="none", p=0.0, rng=None, tag="", emit_planes=False, 
     LinearActFn.gate_request = ((float(gate_sites[0]), gate_sites[1], gate_sites[2], rng) if (gate_sites is not None and FUSED_GATE_TRAIN
                                 and p > 0.0 and gate_sites[0] > 0.0 and torch.is_grad_enabled()) else None)
     LinearActFn.last_gate = None
-    LinearActFn.take_residual = bool(take_residual_grad and RESIDUAL_HANDOVER and torch.is_grad_enabled() and x2.requires_grad)
     y = LinearActFn.apply(x2, W, b, _ACT[act], float(p), seed, sid, y0, rr, xpl, wpl, emit)
-    LinearActFn.take_residual = False
     LinearActFn.gate_request = None
     cpl, LinearActFn.last_planes = LinearActFn.last_planes, None
     if pre_planes is not None and cpl is None:
@@ -1706,62 +1686,6 @@ class PlaneHandover:
         self._d().clear()
 
 
-class ResidualGrads:
-    """The gradient of a post-norm residual's skip input, on its way from AddDropoutLayerNormFn.backward to the backward of the
-    layer that read the SAME tensor (the ESAT layer: x feeds the in-projection and `LayerNorm(x + dropout(attn))`, the first norm's
-    output feeds linear1 and the second norm): that layer's dx contraction ACCUMULATES into it (C += dpre W) and returns the sum, the
-    residual returns no gradient for x -- autograd's own `add` launch over [L, d] is gone. Only between two calls that opted in
-    (ops.linear_act(..., take_residual_grad=True) / ops.add_dropout_layer_norm(..., hand_residual_grad=True)) on the same tensor;
-    keyed by (device, address, shape) of x, which both Functions keep alive until their backward (ONE table for the process, behind a
-    lock: autograd runs a plain .backward() on its device thread and a handler's on the calling thread -- the check behind the
-    backward must see either). The residual's backward always runs first (the other layer's gradient arrives through it). An entry
-    nobody claims is a lost gradient: the handlers check `pending()` behind every backward and raise."""
-
-    def __init__(self):
-        import threading
-        self._lock = threading.Lock()
-        self._tab = {}
-
-    @staticmethod
-    def key(x):
-        return (x.device.index, x.data_ptr(), tuple(x.shape))
-
-    def put(self, key, g):
-        with self._lock:
-            if key in self._tab:
-                raise RuntimeError("advmil_amd: two residual gradients handed over for the same tensor")
-            self._tab[key] = g
-
-    def pop(self, key):
-        with self._lock:
-            return self._tab.pop(key, None)
-
-    def pending(self):
-        with self._lock:
-            return len(self._tab)
-
-    def clear(self):
-        with self._lock:
-            self._tab.clear()
-
-
-RESIDUAL_GRADS = ResidualGrads()
-
-
-def backward_done():
-    """Behind every backward of a handler (in a `finally`): no hand-over may outlive it. A plane hand-over left by a backward that
-    raised is dropped (it must never meet a reused address); a residual gradient nobody claimed is a LOST gradient and raises
-    (unless an exception is already on its way)."""
-    import sys
-    DY_PLANES.clear()
-    n = RESIDUAL_GRADS.pending()
-    RESIDUAL_GRADS.clear()
-    if n and sys.exc_info()[0] is None:
-        raise RuntimeError(f"advmil_amd: {n} residual gradient(s) handed over by add_dropout_layer_norm were not taken by the layer that "
-                           "read the same input (linear_act(..., take_residual_grad=True) missing, or its input needed no gradient)")
-
-
-RESIDUAL_HANDOVER = os.environ.get("ADVMIL_RESIDUAL_HANDOVER", "1") != "0"
 POISON_TOKENS = os.environ.get("ADVMIL_POISON_TOKENS", "0") == "1"
 DY_PLANES = PlaneHandover()
 LN_DY_PLANES = os.environ.get("ADVMIL_LN_DY_PLANES", "1") != "0"
@@ -1951,9 +1875,8 @@ class AddDropoutLayerNormFn(torch.autograd.Function):
     nn.TransformerEncoderLayer with norm_first=False) as one launch each way; dropout index = row*d + col on stream `sid`."""
 
     @staticmethod
-    def forward(ctx, x, o, gamma, beta, eps, p, seed, sid, rr=None, hand=False):
+    def forward(ctx, x, o, gamma, beta, eps, p, seed, sid, rr=None):
         _chk(x, "x"); _chk(o, "o")
-        ctx.hand_key = ResidualGrads.key(x) if (hand and x.is_contiguous() and ctx.needs_input_grad[0]) else None
         x, o = x.contiguous(), o.contiguous()
         R, d = x.shape
         dev = x.device
@@ -1993,20 +1916,15 @@ class AddDropoutLayerNormFn(torch.autograd.Function):
                                                wsb, _stream()), "add_dropout_ln_bwd")
         if do is None:
             do = dx
-        if ctx.hand_key is not None:          # x's other consumer adds its own gradient onto dx (ResidualGrads): none returned here
-            RESIDUAL_GRADS.put(ctx.hand_key, dx if do is not dx else dx.clone())
-            dx = None
-        return (dx, do, None, None, None, None, None, None, None, None) if acc else (dx, do, dg, db, None, None, None, None, None, None)
+        return (dx, do, None, None, None, None, None, None, None) if acc else (dx, do, dg, db, None, None, None, None, None)
 
 
-def add_dropout_layer_norm(x, o, gamma, beta, eps=1e-5, p=0.0, rng=None, tag="", hand_residual_grad=False):
-    """`hand_residual_grad`: x was ALSO the input of an ops.linear_act(..., take_residual_grad=True) call: the gradient of the skip path
-    is handed to that layer's backward instead of being returned (ops.ResidualGrads)."""
+def add_dropout_layer_norm(x, o, gamma, beta, eps=1e-5, p=0.0, rng=None, tag=""):
     sid, seed, rr = 0, None, None
     if p > 0.0:
         rng = rng or default_rng(x.device)
         sid, seed, rr = rng.site(tag, tuple(o.shape), p), rng.seed, rng.row_map(o.shape[0], tag)
-    y = AddDropoutLayerNormFn.apply(x, o, gamma, beta, float(eps), float(p), seed, sid, rr, bool(hand_residual_grad and RESIDUAL_HANDOVER))
+    y = AddDropoutLayerNormFn.apply(x, o, gamma, beta, float(eps), float(p), seed, sid, rr)
     ypl, AddDropoutLayerNormFn.last_planes = getattr(AddDropoutLayerNormFn, "last_planes", None), None
     if ypl is not None:
         y._advmil_planes = ypl

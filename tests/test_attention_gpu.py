@@ -286,55 +286,6 @@ def test_in_projection_writes_qkv_as_operand_planes_only(ops, training):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lens,training", [([2048, 1536, 512, 1040], True), ([24], True), ([300, 77], False)])
-def test_residual_gradients_meet_in_the_next_layers_dx_contraction(ops, mode, lens, training):
-    """Each post-norm residual of the ESAT layer reads a tensor that a contraction reads too (x: in-projection + first residual; the
-    first norm's output: linear1 + second residual). The residual's backward hands its skip gradient to that layer, whose dx
-    contraction accumulates onto it (ops.ResidualGrads) -- autograd's two [L, d] `add` launches are gone. Same summands, same order
-    of the one addition per element: output and every gradient EQUAL with the hand-over on and off (slab-sized, small-linear-sized
-    and eval-mode cases), nothing pending afterwards; an unclaimed hand-over raises behind the backward."""
-    from advmil_amd.model.esat import HipTransformerEncoderLayer
-    torch.manual_seed(6)
-    layer = HipTransformerEncoderLayer(384, 8, 384, 0.25).cuda()
-    layer.train(training)
-    g = torch.Generator(device="cuda").manual_seed(10)
-    x = torch.randn(sum(lens), 384, device="cuda", generator=g)
-    go = torch.randn(sum(lens), 384, device="cuda", generator=g)
-    seg = ops.Segments(lens, x.device) if len(lens) > 1 else None
-    outs = []
-    try:
-        for on in (False, True):
-            ops.RESIDUAL_HANDOVER = on
-            layer.rng = ops.DeviceRng(x.device, seed=78)
-            for p_ in layer.parameters():
-                p_.grad = None
-            xi = x.clone().requires_grad_(True)
-            y = layer.forward_rows(xi, seg)
-            (y * go).sum().backward()
-            assert ops.RESIDUAL_GRADS.pending() == 0
-            ops.backward_done()
-            outs.append((y.detach().clone(), xi.grad.clone(), [p_.grad.clone() for p_ in layer.parameters()]))
-        (y0, gx0, gp0), (y1, gx1, gp1) = outs
-        assert torch.isfinite(gx1).all() and torch.equal(y0, y1)
-        assert float((gx0 - gx1).abs().max()) <= 1e-6 * float(gx0.abs().max())
-        for a, b in zip(gp0, gp1):
-            assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max() + 1e-30)
-        # a residual that hands its gradient over to nobody: caught behind the backward
-        ops.RESIDUAL_HANDOVER = True
-        xi = x.clone().requires_grad_(True)
-        o = torch.randn_like(x).requires_grad_(True)
-        y = ops.add_dropout_layer_norm(xi, o, layer.norm1.weight, layer.norm1.bias, 1e-5, 0.0, None, "t", hand_residual_grad=True)
-        (y * go).sum().backward()
-        assert ops.RESIDUAL_GRADS.pending() == 1 and xi.grad is None
-        with pytest.raises(RuntimeError):
-            ops.backward_done()
-        assert ops.RESIDUAL_GRADS.pending() == 0
-    finally:
-        ops.RESIDUAL_HANDOVER = True
-        ops.RESIDUAL_GRADS.clear()
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("hd,lens", [(48, [700, 257, 33, 1025, 1]), (32, [130, 64, 300]), (64, [2048]), (16, [5, 129])])
 def test_forward_with_the_log_sum_exp_given_equals_the_plain_forward(ops, hd, lens):
     """advmil_mha_fwd_lse: the train-mode forward that takes the softmax statistics from the eval-mode pass over the same q | k | v

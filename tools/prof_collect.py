@@ -107,6 +107,20 @@ if va:
             ent["avg_us"] = st[k][1]
             ent["mfma_pipe_busy_frac_at_2.4GHz"] = ent["mfma_busy_cycles"] / (st[k][1] * 1e-6 * 2.4e9 * 1024)
         out["kernels"][k] = ent
+    # the two-launch backward (ADVMIL_ATTN_BWD=two), same tool: its dQ / dK,dV kernels beside the single-pass kernel above
+    va2, mf2, mb2 = counter("attn2048_two_sq", "SQ_INSTS_VALU"), counter("attn2048_two_sq", "SQ_INSTS_MFMA"), counter("attn2048_two_sq", "SQ_VALU_MFMA_BUSY_CYCLES")
+    if va2:
+        st2 = stats_avg("attn2048_two")
+        out["two_launch_backward"] = {}
+        for k in va2:
+            if not (k.startswith("attn_bwd_dq") or k.startswith("attn_bwd_dkv")):
+                continue
+            ent = {"valu_insts": va2[k][1], "mfma_insts": mf2.get(k, (0, 0))[1], "mfma_busy_cycles": mb2.get(k, (0, 0))[1]}
+            if ent["mfma_insts"]:
+                ent["valu_per_mfma"] = ent["valu_insts"] / ent["mfma_insts"]
+            if k in st2:
+                ent["avg_us"] = st2[k][1]
+            out["two_launch_backward"][k] = ent
     json.dump(out, open(os.path.join(DST, f"{TAG}_pmc_attn.json"), "w"), indent=1)
 
 # ---- slab contractions: HBM traffic per launch + instruction mix, generic (on-the-fly split) and plane-fed kernels

@@ -41,6 +41,11 @@ fi
 if [ "$what" = all ] || [ "$what" = attn ]; then
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/attn2048 -- python3 tools/attn_bench.py 2048 16 0.25 10 > $O/attn2048.log 2>&1
   timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/attn2048_sq -- python3 tools/attn_bench.py 2048 16 0.25 4 > $O/attn2048_sq.log 2>&1
+  # the two-launch backward beside the single-pass one (the default since round 6): same tool, ADVMIL_ATTN_BWD=two in the profiler's own environment
+  export ADVMIL_ATTN_BWD=two
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/attn2048_two -- python3 tools/attn_bench.py 2048 16 0.25 10 > $O/attn2048_two.log 2>&1
+  timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/attn2048_two_sq -- python3 tools/attn_bench.py 2048 16 0.25 4 > $O/attn2048_two_sq.log 2>&1
+  unset ADVMIL_ATTN_BWD
 fi
 # compact listing of what was produced (the CSVs themselves are merged back under gpurun_out/)
 find $O -name "*kernel_stats.csv" -o -name "*counter_collection.csv" | sort
