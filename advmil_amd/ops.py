@@ -628,6 +628,11 @@ def gemm(A, B, a_kc, b_kc, M, N, K, out=None, ldc=None, bias=None, act0=0, act1=
         ptile, splits = gemm_plan(M, N, K, a_kc, b_kc)
         if tile == 0:
             tile = ptile
+    if accumulate and splits > 1 and _DEFER_KEEP is not None and out is not None and not _is_arena(out):
+        # Inside ops.deferred_sums() the `C += partials` fold of a split-K launch is QUEUED until the context's exit (advmil_defer_sums):
+        # right for the optimizer's gradient arena, which nothing reads before the step, wrong for any other destination -- the next
+        # launch would read C without the partials. Such a call takes the fold-free plan.
+        splits = 1
     if b_only and not (91 <= tile <= 93) and tile not in (22, 12, 11) and not (tile in (34, 24) and not a_kc and not b_kc):
         tile = 22                             # a bf16 / planes-only B operand has no fp32 image: land on a kernel that stages B from its plane(s)
     if planes_only_a and a_planes.single and not (82 <= tile <= 86) and tile not in (22, 12, 11):
@@ -1014,6 +1019,14 @@ def _arena_grad(p):
             o._grad_clean = False            # a kernel is about to add into the arena: it is no longer known to be all zero (optim.FlatAdam)
         return g
     return None
+
+
+# storages of the optimizers' flat gradient arenas (optim.FlatAdam registers them): the only destinations a DEFERRED accumulate may have
+ARENA_STORAGES = set()
+
+
+def _is_arena(t):
+    return t.untyped_storage().data_ptr() in ARENA_STORAGES
 
 
 def _adjacent(a, b, itemsize=4):

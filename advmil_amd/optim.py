@@ -54,6 +54,7 @@ class FlatAdam(torch.optim.Optimizer):
             total += (p.numel() + 7) // 8 * 8
         self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        ops.ARENA_STORAGES.add(self.flat_grad.untyped_storage().data_ptr())     # (a deferred split-K fold may only land here: ops.gemm)
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_wd = torch.zeros(total, dtype=torch.float32, device=dev)
