@@ -21,8 +21,9 @@
 // Barriers per trip: A (the previous trip's dQ readers are done with the dS image; their accumulators are parked) and
 // B (dS image complete, next tile and its side data visible, this trip's ring slot free).
 // The memory counter: vmcnt counts loads AND stores in issue order. The only vector-memory operations of the loop are the ring's
-// DMA pieces (2 per wave and trip, issued behind barrier B) and the partial-tile stores (behind barrier A, by two waves per trip);
-// a wave waits for its pieces of the next tile with vmcnt(stores it issued since); the side data (lse, D) ride the DMA as one more
+// DMA pieces (2 per wave and trip, issued behind barrier B) and the partial-tile stores (behind barrier A: every wave combines and
+// stores one quarter of the previous trip's tile, at most one 16-byte store per lane); a wave waits for its pieces of the next tile
+// with vmcnt(stores it issued since); the side data (lse, D) ride the DMA as one more
 // piece, so that no load result lives in a register and no compiler-inserted vmcnt(0) sits on the stores' latency.
 #include "attn_core.h"
 

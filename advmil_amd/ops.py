@@ -1776,7 +1776,8 @@ class MhaFn(torch.autograd.Function):
     model/backbone_utils.py:113-127): packed qkv[L_total, 3d] of a slab of bags (`seg`; None = one bag) -> O[L_total, d]; attention
     never crosses a bag. The kernels read qkv as its two bf16x3 operand planes (`planes`: emitted by the in-projection's epilogue,
     else one advmil_split_planes pass here). ONE fused launch (advmil_mha_fwd: QK^T, online softmax, dropout, PV on the matrix
-    pipe; no [H, L, L] tensor exists), three for the backward (advmil_mha_bwd). Ragged bags and any bag length are handled inside
+    pipe; no [H, L, L] tensor exists), three for the backward (advmil_mha_bwd1: prep, ONE pass over the scores for dQ / dK / dV, the
+    reduce of dQ's per-key-block partial slabs; ADVMIL_ATTN_BWD=two: advmil_mha_bwd, prep + dQ + dK/dV). Ragged bags and any bag length are handled inside
     the kernels."""
 
     last_lse = None          # the log-sum-exp of the forward just run (side channel to ops.mha: the forward memo keeps the eval pass's)
