@@ -96,6 +96,19 @@ def test_attention_group_checks_head_dim_and_segments(L):
     need = lib.advmil_mha_bwd_workspace_bytes(512, 8, 48)
     assert need >= 512 * 8 * 4 + 2 * 512 * 384 * 2
     assert lib.advmil_mha_bwd(p(0), p(1), p(2), p(3), p(4), 512, 8, 48, 1, None, 512, 0.0, None, 0, None, p(5), p(6), need - 16, None) == EWORKSPACE
+    # the single-pass backward: its workspace also holds ceil(max_len / 256) partial slabs of dQ; same argument checks
+    need1 = lib.advmil_mha_bwd1_workspace_bytes(512, 8, 48, 512)
+    assert need1 >= need + 2 * 512 * 384 * 4
+    assert lib.advmil_mha_bwd1_workspace_bytes(512, 8, 48, 100) == need + 1 * 512 * 384 * 4        # one 256-key block per bag
+    bwd1 = lambda hd=48, nseg=1, mlen=512, ws=need1, out=p(2): lib.advmil_mha_bwd1(   # noqa: E731
+        p(0), p(1), out, p(3), p(4), 512, 8, hd, nseg, None, mlen, 0.0, None, 0, None, p(5), p(6), ws, None)
+    assert bwd1(ws=need1 - 16) == EWORKSPACE
+    assert bwd1(ws=need) == EWORKSPACE                                         # the two-launch form's workspace does not hold the slabs
+    assert bwd1(hd=40) == EINVAL and bwd1(nseg=4, mlen=128) == EINVAL and bwd1(out=None) == EINVAL
+    # the forward with the log-sum-exp given is the dropout pass only
+    lse_fwd = lambda pd=0.25, seed=p(4), lse=p(3): lib.advmil_mha_fwd_lse(   # noqa: E731
+        p(0), p(1), 512, 8, 48, 1, None, 512, pd, seed, 0, None, p(2), lse, None)
+    assert lse_fwd(pd=0.0) == EINVAL and lse_fwd(seed=None) == EINVAL and lse_fwd(lse=None) == EINVAL
 
 
 def test_optimizer_graph_and_evaluator_groups(L):
